@@ -1,0 +1,119 @@
+/*
+ * magent_runtime_api.h -- C-ABI of the MI355X-native grid-world step engine (libmagent.so).
+ *
+ * This is the drop-in boundary.  Every symbol in PART 1 replaces, with the same name, argument order,
+ * argument meaning and return value (always 0), the function the reference exports from
+ * /root/reference/src/runtime_api.h:20-56 and that python/magent/gridworld.py binds through ctypes
+ * (python/magent/c_lib.py:11-21 loads "<pkg>/../../build/libmagent.so").  Plain pointers and ints only:
+ * no torch / HIP types appear in any signature.
+ *
+ * Ownership (same as the reference): the caller owns every data buffer and sizes it from
+ * env_get_info("num") x the *_space infos; the engine owns the opaque EnvHandle until env_delete_game.
+ * PART 1 buffers are HOST memory; each call is synchronous (outputs valid on return).
+ * PART 2 is additive: the same operations on DEVICE pointers, asynchronous on the environment's HIP stream.
+ *
+ * Errors: like the reference (LOG(FATAL) -> std::terminate under ctypes, utility.h:77-80) an invalid
+ * argument or an unsupported feature prints "magent-amd FATAL: ..." to stderr and aborts; nothing returns
+ * non-zero expecting the caller to look.
+ */
+#ifndef MAGENT_AMD_RUNTIME_API_H
+#define MAGENT_AMD_RUNTIME_API_H
+
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *EnvHandle;  /* reference: Environment*  (Environment.h:36) */
+typedef int GroupHandle;  /* reference: Environment.h:12; -1 = walls / "no group" (GridWorld.cc:184) */
+
+/* ---------------------------------------------------------------------------------------------------
+ * PART 1 -- the reference C-ABI (host buffers, synchronous)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* runtime_api.h:21  name must be "GridWorld" ("DiscreteSnake" is a different game: FATAL unsupported). */
+int env_new_game(EnvHandle *game, const char *name);
+/* runtime_api.h:22 */
+int env_delete_game(EnvHandle game);
+/* runtime_api.h:23 -> GridWorld::set_config (GridWorld.cc:120-149).  keys: map_width,map_height (int*),
+ * food_mode,turn_mode,minimap_mode,goal_mode (bool*), embedding_size (int*), render_dir (char*), seed (int*).
+ * Additive key: device_id (int*) selects the HIP device (before env_reset). */
+int env_config_game(EnvHandle game, const char *name, void *p_value);
+
+/* runtime_api.h:26 -> GridWorld::reset (GridWorld.cc:72-118) */
+int env_reset(EnvHandle game);
+/* runtime_api.h:27 -> GridWorld::get_observation (GridWorld.cc:292-401)
+ * buffer[0] = view   float[n][view_h][view_w][n_channel], buffer[1] = feature float[n][feature_size] */
+int env_get_observation(EnvHandle game, GroupHandle group, float **buffer);
+/* runtime_api.h:28 -> GridWorld::set_action (GridWorld.cc:403-454); actions int32[n] */
+int env_set_action(EnvHandle game, GroupHandle group, const int *actions);
+/* runtime_api.h:29 -> GridWorld::step (GridWorld.cc:456-631) */
+int env_step(EnvHandle game, int *done);
+/* runtime_api.h:30 -> GridWorld::get_reward (GridWorld.cc:694-704); buffer float[n] */
+int env_get_reward(EnvHandle game, GroupHandle group, float *buffer);
+
+/* runtime_api.h:33 -> GridWorld::get_info (GridWorld.cc:709-894).  names: num,id,pos,alive,global_minimap,
+ * walls_info,render_window_info,attack_event,action_space,view_space,feature_space,view2attack,attack_base,
+ * groups_info,both_attack (mean_info: deprecated in the reference, FATAL here). */
+int env_get_info(EnvHandle game, GroupHandle group, const char *name, void *buffer);
+
+/* runtime_api.h:36-37 -> RenderGenerator (text video dump; host-side, off the hot path) */
+int env_render(EnvHandle game);
+int env_render_next_file(EnvHandle game);
+
+/* runtime_api.h:43 -> AgentType::AgentType (AgentType.cc:30-123) */
+int gridworld_register_agent_type(EnvHandle game, const char *name, int n, const char **keys, float *values);
+/* runtime_api.h:44 -> GridWorld::new_group (GridWorld.cc:160-169) */
+int gridworld_new_group(EnvHandle game, const char *agent_type_name, GroupHandle *group);
+/* runtime_api.h:45-46 -> GridWorld::add_agents (GridWorld.cc:180-290); method = random|custom|fill */
+int gridworld_add_agents(EnvHandle game, GroupHandle group, int n, const char *method,
+                         const int *pos_x, const int *pos_y, const int *dir);
+
+/* runtime_api.h:49 -> GridWorld::clear_dead (GridWorld.cc:633-665) */
+int gridworld_clear_dead(EnvHandle game);
+/* runtime_api.h:50 -> GridWorld::set_goal (deprecated in the reference; accepted and ignored unless
+ * goal_mode, which is FATAL unsupported) */
+int gridworld_set_goal(EnvHandle game, GroupHandle group, const char *method, const int *linear_buffer);
+
+/* runtime_api.h:53-56 -> RewardEngine.cc:28-69 */
+int gridworld_define_agent_symbol(EnvHandle game, int no, int group, int index);
+int gridworld_define_event_node(EnvHandle game, int no, int op, int *inputs, int n_inputs);
+int gridworld_add_reward_rule(EnvHandle game, int on, int *receiver, float *value, int n_receiver,
+                              bool is_terminal, bool auto_value);
+
+/* runtime_api.h:61-62: the second game of the reference; exported so that the symbol table matches,
+ * FATAL "unsupported" when called. */
+int discrete_snake_clear_dead(EnvHandle game);
+int discrete_snake_add_object(EnvHandle game, int obj_id, int n, const char *method, const int *linear_buffer);
+
+/* ---------------------------------------------------------------------------------------------------
+ * PART 2 -- additive MI355X extensions (device-resident buffers; SURVEY.md 8b "extensions allowed")
+ * All pointers below are DEVICE pointers on the environment's device.  Calls enqueue work on the
+ * environment's HIP stream and return without waiting; env_sync() waits for the stream.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* same layout as env_get_observation, written straight into caller-owned device memory */
+int env_get_observation_device(EnvHandle game, GroupHandle group, float **device_buffer);
+/* actions int32[n] in device memory */
+int env_set_action_device(EnvHandle game, GroupHandle group, const int *device_actions);
+/* rewards float[n] in device memory */
+int env_get_reward_device(EnvHandle game, GroupHandle group, float *device_buffer);
+/* name = id (int32[n]) | pos (int32[n][2]) | alive (uint8[n]) | hp (float[n]) into device memory */
+int env_get_info_device(EnvHandle game, GroupHandle group, const char *name, void *device_buffer);
+/* wait until everything enqueued on the environment's stream has finished */
+int env_sync(EnvHandle game);
+/* the environment's hipStream_t, as an opaque pointer (for event timing / interop by the caller) */
+int env_get_stream(EnvHandle game, void **stream);
+
+/* Kernel timing with HIP events recorded on the environment's stream.
+ * env_profile_enable(game, 1) starts recording one event pair per launch of each named kernel;
+ * env_profile_read returns, for kernel `name` ("render", "paint", "minimap", "attack", "move", ...),
+ * the number of recorded launches and their total duration in milliseconds, and resets the counters. */
+int env_profile_enable(EnvHandle game, int on);
+int env_profile_read(EnvHandle game, const char *name, int *n_launches, float *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGENT_AMD_RUNTIME_API_H */

@@ -1,0 +1,463 @@
+"""Host-side mirror of the reference's ``magent.GridWorld`` operator interface.
+
+Same class / method names, argument meaning and return shapes as reference python/magent/gridworld.py:14-482
+(GridWorld) and :571-800 (Config / Event / AgentSymbol / CircleRange / SectorRange), written from scratch on top
+of the C-ABI declared in include/magent_runtime_api.h.  On top of the reference surface it adds the
+device-resident calls (``*_device``) of the MI355X engine.
+
+The ``lib`` argument exists for the tests: the same wrapper can drive the CPU checkers under oracle/.
+The product path never does that -- by default the HIP library is loaded, and loading fails if it is absent.
+"""
+import ctypes
+import importlib
+import os
+
+import numpy as np
+
+from . import c_lib
+
+_F32P = ctypes.POINTER(ctypes.c_float)
+_I32P = ctypes.POINTER(ctypes.c_int32)
+
+
+def _i32(a):
+    return a.ctypes.data_as(_I32P)
+
+
+def _f32(a):
+    return a.ctypes.data_as(_F32P)
+
+
+def _gid(handle):
+    """group handles are ctypes.c_int32 objects in the reference (gridworld.py:94-96); accept ints too"""
+    return handle.value if hasattr(handle, "value") else int(handle)
+
+
+# key -> python type that decides how env_config_game's void* is filled (reference gridworld.py:46-63)
+_CONFIG_KINDS = {
+    "map_width": int, "map_height": int, "embedding_size": int, "device_id": int,
+    "food_mode": bool, "turn_mode": bool, "minimap_mode": bool, "revive_mode": bool, "goal_mode": bool,
+    "render_dir": str,
+}
+
+
+class GridWorld(object):
+    OBS_INDEX_VIEW = 0
+    OBS_INDEX_HP = 1
+
+    def __init__(self, config, lib=None, **kwargs):
+        """config: name of a built-in game ("battle", "gather", "pursuit", kwargs -> its get_config) or a Config"""
+        self._lib = c_lib.load(lib) if (lib is None or isinstance(lib, str)) else lib
+        L = self._lib
+        if isinstance(config, str):
+            config = _builtin_config(config, **kwargs)
+
+        self.game = ctypes.c_void_p()
+        L.env_new_game(ctypes.byref(self.game), b"GridWorld")
+
+        self._device_id = int(config.config_dict.get(
+            "device_id", os.environ.get("MAGENT_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+        for key, val in config.config_dict.items():
+            kind = _CONFIG_KINDS[key]
+            if key == "device_id" and not getattr(L, "has_device_api", False):
+                continue  # additive key: only the MI355X engine knows it
+            if kind is int:
+                L.env_config_game(self.game, key.encode(), ctypes.cast(ctypes.byref(ctypes.c_int(val)), ctypes.c_void_p))
+            elif kind is bool:
+                L.env_config_game(self.game, key.encode(), ctypes.cast(ctypes.byref(ctypes.c_bool(val)), ctypes.c_void_p))
+            else:
+                L.env_config_game(self.game, key.encode(), ctypes.cast(ctypes.c_char_p(val.encode()), ctypes.c_void_p))
+
+        # agent types: parallel key/value arrays; a range object expands to (radius, angle) (gridworld.py:66-86)
+        for name, attr in config.agent_type_dict.items():
+            flat = {}
+            for k, v in attr.items():
+                if k in ("view_range", "attack_range"):
+                    stem = k.split("_")[0]
+                    flat[stem + "_radius"], flat[stem + "_angle"] = v.radius, v.angle
+                else:
+                    flat[k] = v
+            keys = (ctypes.c_char_p * len(flat))(*[k.encode() for k in flat])
+            vals = (ctypes.c_float * len(flat))(*[float(v) for v in flat.values()])
+            L.gridworld_register_agent_type(self.game, name.encode(), len(flat), keys, vals)
+
+        self._send_reward_rules(config)
+
+        self.group_handles = []
+        for type_name in config.groups:
+            h = ctypes.c_int32()
+            L.gridworld_new_group(self.game, type_name.encode(), ctypes.byref(h))
+            self.group_handles.append(h)
+
+        self._obs_cache = ({}, {})
+        self.view_space, self.feature_space, self.action_space = {}, {}, {}
+        tmp = np.empty(3, dtype=np.int32)
+        for h in self.group_handles:
+            L.env_get_info(self.game, h.value, b"view_space", tmp.ctypes.data)
+            self.view_space[h.value] = (int(tmp[0]), int(tmp[1]), int(tmp[2]))
+            L.env_get_info(self.game, h.value, b"feature_space", tmp.ctypes.data)
+            self.feature_space[h.value] = (int(tmp[0]),)
+            L.env_get_info(self.game, h.value, b"action_space", tmp.ctypes.data)
+            self.action_space[h.value] = (int(tmp[0]),)
+
+    # ------------------------------------------------------------------ setup
+    def reset(self):
+        self._lib.env_reset(self.game)
+
+    def add_walls(self, method, **kwargs):
+        """method 'random' (n=...) | 'custom' (pos=[(x,y),...]) | 'fill' (pos=(x,y), size=(w,h))"""
+        kwargs["dir"] = 0
+        self.add_agents(-1, method, **kwargs)
+
+    def new_group(self, name):
+        h = ctypes.c_int32()
+        self._lib.gridworld_new_group(self.game, name.encode(), ctypes.byref(h))
+        return h
+
+    def add_agents(self, handle, method, **kwargs):
+        """method 'random' (n=...) | 'custom' (pos=[(x,y[,dir]),...]) | 'fill' (pos=(x,y), size=(w,h)[, dir])"""
+        L, g = self._lib, _gid(handle)
+        if method == "random":
+            L.gridworld_add_agents(self.game, g, int(kwargs["n"]), b"random", None, None, None)
+        elif method == "custom":
+            pos = np.asarray(kwargs["pos"], dtype=np.int32)
+            if pos.size == 0:
+                return
+            xs = np.ascontiguousarray(pos[:, 0])
+            ys = np.ascontiguousarray(pos[:, 1])
+            ds = np.ascontiguousarray(pos[:, 2]) if pos.shape[1] >= 3 else np.zeros(len(pos), dtype=np.int32)
+            L.gridworld_add_agents(self.game, g, len(pos), b"custom", _i32(xs), _i32(ys), _i32(ds))
+        elif method == "fill":
+            (x, y), (w, h) = kwargs["pos"][:2], kwargs["size"][:2]
+            packed = np.array([x, y, w, h, kwargs.get("dir", 0)], dtype=np.int32)
+            L.gridworld_add_agents(self.game, g, 0, b"fill", _i32(packed), None, None)
+        else:
+            raise ValueError("unknown placement method %r" % (method,))
+
+    # ------------------------------------------------------------------ run (host buffers: reference ABI)
+    def _buf(self, which, g, shape):
+        cache = self._obs_cache[which]
+        buf = cache.get(g)
+        if buf is None or buf.shape != shape:
+            buf = cache[g] = np.empty(shape, dtype=np.float32)
+        return buf
+
+    def get_observation(self, handle):
+        """-> (view float32[n,H,W,C], feature float32[n,F]); buffers are reused between calls like the reference"""
+        g = _gid(handle)
+        n = self.get_num(g)
+        view = self._buf(0, g, (n,) + self.view_space[g])
+        feat = self._buf(1, g, (n,) + self.feature_space[g])
+        bufs = (_F32P * 2)(_f32(view), _f32(feat))
+        self._lib.env_get_observation(self.game, g, bufs)
+        return view, feat
+
+    def set_action(self, handle, actions):
+        assert isinstance(actions, np.ndarray) and actions.dtype == np.int32
+        actions = np.ascontiguousarray(actions)
+        self._lib.env_set_action(self.game, _gid(handle), _i32(actions))
+
+    def step(self):
+        done = ctypes.c_int32(0)
+        self._lib.env_step(self.game, ctypes.byref(done))
+        return bool(done.value)
+
+    def get_reward(self, handle):
+        g = _gid(handle)
+        out = np.empty(self.get_num(g), dtype=np.float32)
+        self._lib.env_get_reward(self.game, g, _f32(out))
+        return out
+
+    def clear_dead(self):
+        self._lib.gridworld_clear_dead(self.game)
+
+    # ------------------------------------------------------------------ info
+    def get_handles(self):
+        return self.group_handles
+
+    def _info(self, g, name, buf):
+        self._lib.env_get_info(self.game, g, name, buf.ctypes.data)
+        return buf
+
+    def get_num(self, handle):
+        return int(self._info(_gid(handle), b"num", np.zeros(1, dtype=np.int32))[0])
+
+    def get_action_space(self, handle):
+        return self.action_space[_gid(handle)]
+
+    def get_view_space(self, handle):
+        return self.view_space[_gid(handle)]
+
+    def get_feature_space(self, handle):
+        return self.feature_space[_gid(handle)]
+
+    def get_agent_id(self, handle):
+        g = _gid(handle)
+        return self._info(g, b"id", np.empty(self.get_num(g), dtype=np.int32))
+
+    def get_alive(self, handle):
+        g = _gid(handle)
+        return self._info(g, b"alive", np.empty(self.get_num(g), dtype=np.bool_))
+
+    def get_pos(self, handle):
+        g = _gid(handle)
+        return self._info(g, b"pos", np.empty((self.get_num(g), 2), dtype=np.int32))
+
+    def get_view2attack(self, handle):
+        """-> (attack_base, int32[H,W]): view cell -> attack action index or -1 (GridWorld.cc:853-872)"""
+        g = _gid(handle)
+        table = self._info(g, b"view2attack", np.empty(self.view_space[g][:2], dtype=np.int32))
+        base = self._info(g, b"attack_base", np.zeros(1, dtype=np.int32))
+        return int(base[0]), table
+
+    def get_global_minimap(self, height, width):
+        buf = np.empty((height, width, len(self.group_handles)), dtype=np.float32)
+        buf[0, 0, 0], buf[0, 0, 1] = height, width  # in-params travel in the out-buffer (GridWorld.cc:741-742)
+        return self._info(-1, b"global_minimap", buf)
+
+    def get_mean_info(self, handle):
+        raise NotImplementedError("mean_info is deprecated in the reference and not provided by this engine")
+
+    def set_seed(self, seed):
+        self._lib.env_config_game(self.game, b"seed", ctypes.cast(ctypes.byref(ctypes.c_int(seed)), ctypes.c_void_p))
+
+    # ------------------------------------------------------------------ render (host-side text dump)
+    def set_render_dir(self, name):
+        if not os.path.exists(name):
+            os.mkdir(name)
+        self._lib.env_config_game(self.game, b"render_dir", ctypes.cast(ctypes.c_char_p(name.encode()), ctypes.c_void_p))
+
+    def render(self):
+        self._lib.env_render(self.game)
+
+    def _get_groups_info(self):
+        return self._info(-1, b"groups_info", np.empty((len(self.group_handles), 5), dtype=np.int32))
+
+    def _get_walls_info(self):
+        buf = self._info(-1, b"walls_info", np.empty((100 * 100, 2), dtype=np.int32))
+        return buf[1:1 + buf[0, 0]]
+
+    def _get_render_info(self, x_range, y_range):
+        n = sum(self.get_num(h) for h in self.group_handles)
+        buf = np.empty((n + 1, 4), dtype=np.int32)
+        buf[0] = x_range[0], y_range[0], x_range[1], y_range[1]
+        self._info(-1, b"render_window_info", buf)
+        n_agent, n_event = int(buf[0, 0]), int(buf[0, 1])
+        agents = {int(r[0]): [int(r[1]), int(r[2]), int(r[3])] for r in buf[1:1 + n_agent]}
+        events = self._info(-1, b"attack_event", np.empty((n_event, 3), dtype=np.int32))
+        return agents, events
+
+    def set_goal(self, handle, method, *args, **kwargs):
+        if method != "random":
+            raise NotImplementedError
+        self._lib.gridworld_set_goal(self.game, _gid(handle), b"random", None)
+
+    def __del__(self):
+        game, self.game = getattr(self, "game", None), None
+        if game:
+            self._lib.env_delete_game(game)
+
+    # ------------------------------------------------------------------ MI355X extensions (device buffers)
+    def _require_device_api(self):
+        if not getattr(self._lib, "has_device_api", False):
+            raise RuntimeError("this library does not export the device-resident API")
+
+    def get_observation_device(self, handle, view=None, feature=None):
+        """Render observations straight into torch CUDA(HIP) tensors; asynchronous on the env stream."""
+        import torch
+        self._require_device_api()
+        g = _gid(handle)
+        n = self.get_num(g)
+        dev = torch.device("cuda", self.device_id)
+        if view is None:
+            view = torch.empty((n,) + self.view_space[g], dtype=torch.float32, device=dev)
+        if feature is None:
+            feature = torch.empty((n,) + self.feature_space[g], dtype=torch.float32, device=dev)
+        assert view.is_contiguous() and feature.is_contiguous()
+        assert view.numel() >= n * int(np.prod(self.view_space[g])) and feature.numel() >= n * self.feature_space[g][0]
+        ptrs = (ctypes.c_void_p * 2)(view.data_ptr(), feature.data_ptr())
+        self._lib.env_get_observation_device(self.game, g, ptrs)
+        return view, feature
+
+    def set_action_device(self, handle, actions):
+        """actions: int32 torch tensor on the env's device (must be complete on the env stream's timeline)"""
+        self._require_device_api()
+        assert actions.dtype.is_floating_point is False and actions.element_size() == 4 and actions.is_contiguous()
+        self._lib.env_set_action_device(self.game, _gid(handle), actions.data_ptr())
+
+    def get_reward_device(self, handle, out=None):
+        import torch
+        self._require_device_api()
+        g = _gid(handle)
+        if out is None:
+            out = torch.empty(self.get_num(g), dtype=torch.float32, device=torch.device("cuda", self.device_id))
+        self._lib.env_get_reward_device(self.game, g, out.data_ptr())
+        return out
+
+    def get_info_device(self, handle, name, out):
+        self._require_device_api()
+        self._lib.env_get_info_device(self.game, _gid(handle), name.encode(), out.data_ptr())
+        return out
+
+    def sync(self):
+        self._require_device_api()
+        self._lib.env_sync(self.game)
+
+    @property
+    def device_id(self):
+        return self._device_id
+
+    def profile_enable(self, on=True):
+        self._require_device_api()
+        self._lib.env_profile_enable(self.game, int(bool(on)))
+
+    def profile_read(self, name):
+        """-> (n_launches, total_ms) measured with HIP events on the env stream since the last read"""
+        self._require_device_api()
+        n, ms = ctypes.c_int32(0), ctypes.c_float(0)
+        self._lib.env_profile_read(self.game, name.encode(), ctypes.byref(n), ctypes.byref(ms))
+        return n.value, ms.value
+
+    # ------------------------------------------------------------------ reward-rule serialisation
+    def _send_reward_rules(self, config):
+        """Flatten the event expressions into numbered symbols / nodes (protocol of gridworld.py:493-565).
+
+        Numbering order is part of the protocol: receivers first, then the symbols met in a pre-order walk of the
+        rule's expression; nodes in pre-order.  The reference passes 6 of the 7 arguments of
+        gridworld_add_reward_rule (auto_value missing, gridworld.py:564-565); only OP_ALIGN reads it, so False here.
+        """
+        L, game = self._lib, self.game
+        sym_no, node_no = {}, {}
+
+        def walk_symbols(node):
+            for item in node.inputs:
+                if isinstance(item, EventNode):
+                    walk_symbols(item)
+                elif isinstance(item, AgentSymbol):
+                    sym_no.setdefault(item, len(sym_no))
+
+        def walk_nodes(node):
+            node_no.setdefault(node, len(node_no))
+            for item in node.inputs:
+                if isinstance(item, EventNode):
+                    walk_nodes(item)
+
+        for on, receivers, _values, _terminal in config.reward_rules:
+            for s in receivers:
+                sym_no.setdefault(s, len(sym_no))
+            walk_symbols(on)
+        for on, _r, _v, _t in config.reward_rules:
+            walk_nodes(on)
+
+        for s, no in sym_no.items():
+            L.gridworld_define_agent_symbol(game, no, s.group, s.index)
+        for node, no in node_no.items():
+            args = np.array([node_no[i] if isinstance(i, EventNode) else sym_no[i] if isinstance(i, AgentSymbol) else i
+                             for i in node.inputs], dtype=np.int32)
+            L.gridworld_define_event_node(game, no, node.op, _i32(args), len(args))
+        for on, receivers, values, terminal in config.reward_rules:
+            recv = np.array([sym_no[s] for s in receivers], dtype=np.int32)
+            if len(values) == 1 and values[0] == "auto":
+                vals = np.zeros(len(recv), dtype=np.float32)
+            else:
+                vals = np.array(values, dtype=np.float32)
+            L.gridworld_add_reward_rule(game, node_no[on], _i32(recv), _f32(vals), len(recv), bool(terminal), False)
+
+
+# ---------------------------------------------------------------------- reward description DSL
+class EventNode(object):
+    """AST node of an event expression; op codes are the engine's EventOp enum (grid_def.h:18-24)"""
+    OP_AND, OP_OR, OP_NOT = 0, 1, 2
+    OP_KILL, OP_AT, OP_IN, OP_COLLIDE, OP_ATTACK, OP_DIE, OP_IN_A_LINE, OP_ALIGN = 3, 4, 5, 6, 7, 8, 9, 10
+    _BINARY = {"kill": OP_KILL, "attack": OP_ATTACK, "collide": OP_COLLIDE}
+    _UNARY = {"die": OP_DIE, "in_a_line": OP_IN_A_LINE, "align": OP_ALIGN}
+
+    def __init__(self, op=None, inputs=(), predicate=None):
+        self.op, self.inputs, self.predicate = op, list(inputs), predicate
+
+    def __call__(self, subject, predicate, *args):
+        if predicate in self._BINARY:
+            return EventNode(self._BINARY[predicate], [subject, args[0]], predicate)
+        if predicate in self._UNARY:
+            return EventNode(self._UNARY[predicate], [subject], predicate)
+        if predicate == "at":
+            return EventNode(self.OP_AT, [subject, args[0][0], args[0][1]], predicate)
+        if predicate == "in":
+            (xa, ya), (xb, yb) = args[0]
+            return EventNode(self.OP_IN, [subject, min(xa, xb), min(ya, yb), max(xa, xb), max(ya, yb)], predicate)
+        raise Exception("invalid predicate of event " + predicate)
+
+    def __and__(self, other):
+        return EventNode(self.OP_AND, [self, other])
+
+    def __or__(self, other):
+        return EventNode(self.OP_OR, [self, other])
+
+    def __invert__(self):
+        return EventNode(self.OP_NOT, [self])
+
+
+Event = EventNode()
+
+
+class AgentSymbol(object):
+    """a group member in an event: index 'any' (-1), 'all' (-2) or a fixed int"""
+    def __init__(self, group, index):
+        self.group = -1 if group is None else group
+        self.index = {"any": -1, "all": -2}.get(index, index)
+        assert isinstance(self.index, int), "index must be 'any', 'all' or an int"
+
+    def __str__(self):
+        return "agent(%d,%d)" % (self.group, self.index)
+
+
+class Config(object):
+    """game description: global settings, agent types, groups, reward rules"""
+    def __init__(self):
+        self.config_dict, self.agent_type_dict, self.groups, self.reward_rules = {}, {}, [], []
+
+    def set(self, args):
+        self.config_dict.update(args)
+
+    def register_agent_type(self, name, attr):
+        if name in self.agent_type_dict:
+            raise Exception("type name %s already exists" % name)
+        self.agent_type_dict[name] = attr
+        return name
+
+    def add_group(self, agent_type):
+        self.groups.append(agent_type)
+        return len(self.groups) - 1
+
+    def add_reward_rule(self, on, receiver, value, terminal=False):
+        if not isinstance(receiver, (tuple, list)):
+            receiver, value = [receiver], [value]
+        if len(receiver) != len(value):
+            raise Exception("the length of receiver and value should be equal")
+        self.reward_rules.append([on, list(receiver), list(value), terminal])
+
+
+class CircleRange(object):
+    def __init__(self, radius):
+        self.radius, self.angle = radius, 360
+
+    def __str__(self):
+        return "circle(%g)" % self.radius
+
+
+class SectorRange(object):
+    def __init__(self, radius, angle):
+        if angle >= 180:
+            raise Exception("the angle of a sector should be smaller than 180 degree")
+        self.radius, self.angle = radius, angle
+
+    def __str__(self):
+        return "sector(%g, %g)" % (self.radius, self.angle)
+
+
+def _builtin_config(name, **kwargs):
+    try:
+        mod = importlib.import_module("magent_amd.builtin.config." + name)
+    except ImportError:
+        raise BaseException('unknown built-in game "' + name + '"')
+    return mod.get_config(**kwargs)

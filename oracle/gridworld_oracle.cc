@@ -1,0 +1,565 @@
+// gridworld_oracle.cc -- TEST INFRASTRUCTURE ONLY.
+//
+// A single-threaded CPU restatement of the reference grid-world hot path (GridWorld::step / get_observation and
+// the small calls around them), used ONLY as the checker by tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg.  The product (magent_amd/csrc) never includes, links or calls anything in this file.
+//
+// Parity status: PINNED.  This restatement is checked (tests/test_oracle_vs_reference.py) against the reference
+// engine itself, compiled from /root/reference/src into oracle/_ref/libmagent_ref.so and run with
+// OMP_NUM_THREADS=1, on seeded trajectories; and against the golden vectors under tests/golden/ that were generated
+// from that build (tests/golden/make_golden.py).  The reference's own tests hold no vectors.
+//
+// It exports the same C-ABI names as the product so one Python wrapper drives all of them (RTLD_LOCAL).
+// State is kept as per-group struct-of-arrays + a packed occupancy grid; the *order* of every loop that the
+// reference executes sequentially is kept literally, because the results depend on it.
+//
+// Scope: what SURVEY.md section 8 puts on the path -- no food_mode / turn_mode / goal_mode / can_absorb, reward
+// rules of the shape Event(a, attack|kill|collide, b) with 'any' symbols.  Anything else aborts with a message.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+[[noreturn]] void fatal(const char *fmt, const char *arg = "") {
+    std::fprintf(stderr, "magent-oracle FATAL: ");
+    std::fprintf(stderr, fmt, arg);
+    std::fprintf(stderr, "\n");
+    std::abort();
+}
+
+// std::default_random_engine of libstdc++ == minstd_rand0 (GridWorld.h:105): x <- 16807 x mod (2^31 - 1)
+struct MinStd {
+    uint64_t x = 1;
+    void seed(unsigned long s) { x = s % 2147483647ul; if (x == 0) x = 1; }
+    uint64_t operator()() { x = (x * 16807ull) % 2147483647ull; return x; }
+};
+
+// Range.h:149-190 (CircleRange).  Mask over a width x width rectangle + (dx,dy) per in-range index.
+struct Range {
+    int width = 0, height = 0, count = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    std::vector<uint8_t> in;
+    std::vector<int> dx, dy;
+    void circle(float radius, float inner_radius, int parity) {
+        const double eps = 1e-8;
+        width = 2 * int(radius + eps) + parity;
+        int center = (int)radius;
+        if (width % 2 != parity) width++;
+        height = width;
+        in.assign(width * width, 0);
+        dx.clear(); dy.clear(); count = 0;
+        double delta = (parity == 0 ? 0.5 : 0);
+        for (int i = 0; i < width; i++)
+            for (int j = 0; j < width; j++) {
+                double ax = std::fabs(j - center + delta), ay = std::fabs(i - center + delta);
+                double dis = std::sqrt(ax * ax + ay * ay);
+                if (dis < radius + eps && dis > inner_radius - eps) {
+                    in[i * width + j] = 1;
+                    dx.push_back(j - center); dy.push_back(i - center); count++;
+                }
+            }
+        x1 = y1 = -center;
+        x2 = y2 = width - center - 1;
+    }
+};
+
+// AgentType.cc:30-123
+struct AgentType {
+    std::string name;
+    int width = 1, length = 1;
+    float speed = 1.0f, hp = 1.0f, view_radius = 1, view_angle = 360, attack_radius = 0, attack_angle = 0;
+    float damage = 0, step_recover = 0, kill_supply = 0, food_supply = 0, eat_ability = 0, trace = 0;
+    float step_reward = 0, kill_reward = 0, dead_penalty = 0, attack_penalty = 0;
+    float hear_radius = 0, speak_radius = 0; int speak_ability = 0;
+    bool attack_in_group = false, can_absorb = false;
+    int view_x_offset = 0, view_y_offset = 0, att_x_offset = 0, att_y_offset = 0;
+    Range view, attack, move;
+    int move_base = 0, turn_base = 0, attack_base = 0, n_action = 0;
+};
+
+enum { OP_KILL = 3, OP_COLLIDE = 6, OP_ATTACK = 7, OP_NULL = 11 };  // grid_def.h:18-24
+
+struct Group {
+    AgentType *type = nullptr;
+    // one entry per agent, in the reference's vector<Agent*> order
+    std::vector<int> x, y, id, last_action, last_op;
+    std::vector<float> hp, next_reward, last_reward;
+    std::vector<uint8_t> dead;
+    std::vector<int64_t> op_obj;  // packed (group<<32 | index) or -1
+    int dead_ct = 0;
+    float reward = 0;             // Group::next_reward
+    int size() const { return (int)x.size(); }
+    void clear() {
+        x.clear(); y.clear(); id.clear(); last_action.clear(); last_op.clear(); hp.clear(); next_reward.clear();
+        last_reward.clear(); dead.clear(); op_obj.clear(); dead_ct = 0;
+    }
+};
+
+struct Symbol { int group = 0, index = 0; };
+struct Node { int op = OP_NULL; std::vector<int> raw; };
+struct Rule { int on = 0; std::vector<int> recv; std::vector<float> val; bool terminal = false, trigger = false; };
+struct Pending { int g, i, act; };
+
+const int EMPTY = -1, WALL = -2;
+
+struct World {
+    int w = 0, h = 0, embedding = 0;
+    bool minimap = false, large_map = false;
+    int n_sep = 1;
+    MinStd rng;
+    std::map<std::string, AgentType> types;
+    std::vector<Group> groups;
+    std::vector<int> occ_g, occ_i;  // per cell: group (EMPTY / WALL / >=0) and index within the group
+    std::vector<Symbol> symbols; std::vector<Node> nodes; std::vector<Rule> rules;
+    std::vector<Pending> attack_buf, move_bound;
+    std::vector<std::vector<Pending>> move_sep;
+    int id_counter = 0;
+
+    int cell(int x, int y) const { return y * w + x; }
+    int g2c(int g) const { return 1 + g * (minimap ? 3 : 2); }  // GridWorld.cc:915-924 (no food_mode)
+    int feature_size(int g) const { return embedding + groups[g].type->n_action + 1 + (minimap ? 2 : 0); }
+
+    // Map.cc:454-470
+    bool blank_area(int x, int y, int bw, int bh, int self_g = -9, int self_i = -9) const {
+        if (x < 0 || y < 0 || x + bw >= w || y + bh >= h) return false;
+        for (int i = 0; i < bw; i++)
+            for (int j = 0; j < bh; j++) {
+                int c = cell(x + i, y + j);
+                if (occ_g[c] == WALL) return false;
+                if (occ_g[c] >= 0 && !(occ_g[c] == self_g && occ_i[c] == self_i)) return false;
+            }
+        return true;
+    }
+    void fill(int x, int y, int bw, int bh, int g, int i) {
+        for (int a = 0; a < bw; a++) for (int b = 0; b < bh; b++) { int c = cell(x + a, y + b); occ_g[c] = g; occ_i[c] = i; }
+    }
+    // Map.cc:108-115
+    int add_wall(int x, int y) {
+        int c = cell(x, y);
+        if (occ_g[c] >= 0) return 1;
+        occ_g[c] = WALL;
+        return 0;
+    }
+    // Map.cc:49-63
+    void random_blank(int bw, int bh, int &ox, int &oy) {
+        int tries = 0;
+        while (true) {
+            int x = (int)rng() % (w - bw);
+            int y = (int)rng() % (h - bh);
+            if (blank_area(x, y, bw, bh)) { ox = x; oy = y; return; }
+            if (tries++ > w * h) fatal("cannot find a blank position in a filled map");
+        }
+    }
+    void remove_agent(int g, int i) {
+        Group &G = groups[g];
+        fill(G.x[i], G.y[i], G.type->width, G.type->length, EMPTY, 0);
+    }
+};
+
+World *W(void *h) { return (World *)h; }
+
+}  // namespace
+
+extern "C" {
+
+int env_new_game(void **game, const char *name) {
+    if (std::strcmp(name, "GridWorld") != 0) fatal("unsupported game %s", name);
+    *game = new World();
+    return 0;
+}
+int env_delete_game(void *game) { delete W(game); return 0; }
+
+// GridWorld.cc:120-149
+int env_config_game(void *game, const char *key, void *p) {
+    World &e = *W(game);
+    std::string k(key);
+    if (k == "map_width") e.w = *(int *)p;
+    else if (k == "map_height") e.h = *(int *)p;
+    else if (k == "minimap_mode") e.minimap = *(bool *)p;
+    else if (k == "embedding_size") e.embedding = *(int *)p;
+    else if (k == "seed") e.rng.seed((unsigned long)*(int *)p);
+    else if (k == "food_mode" || k == "turn_mode" || k == "goal_mode") { if (*(bool *)p) fatal("%s is outside the hot-path scope", key); }
+    else if (k == "render_dir") {}
+    else fatal("invalid argument in set_config: %s", key);
+    return 0;
+}
+
+// AgentType.cc:30-123
+int gridworld_register_agent_type(void *game, const char *name, int n, const char **keys, float *values) {
+    World &e = *W(game);
+    if (e.types.count(name)) fatal("duplicated agent type %s", name);
+    AgentType t; t.name = name;
+    for (int i = 0; i < n; i++) {
+        std::string k(keys[i]); float v = values[i];
+        if (k == "width") t.width = (int)(v + 0.5); else if (k == "length") t.length = (int)(v + 0.5);
+        else if (k == "speed") t.speed = v; else if (k == "hp") t.hp = v;
+        else if (k == "view_radius") t.view_radius = v; else if (k == "view_angle") t.view_angle = v;
+        else if (k == "attack_radius") t.attack_radius = v; else if (k == "attack_angle") t.attack_angle = v;
+        else if (k == "hear_radius") t.hear_radius = v; else if (k == "speak_radius") t.speak_radius = v;
+        else if (k == "speak_ability") t.speak_ability = (int)(v + 0.5);
+        else if (k == "damage") t.damage = v; else if (k == "trace") t.trace = v; else if (k == "eat_ability") t.eat_ability = v;
+        else if (k == "step_recover") t.step_recover = v; else if (k == "kill_supply") t.kill_supply = v;
+        else if (k == "food_supply") t.food_supply = v;
+        else if (k == "attack_in_group") t.attack_in_group = bool(int(v + 0.5)); else if (k == "can_absorb") t.can_absorb = bool(int(v + 0.5));
+        else if (k == "step_reward") t.step_reward = v; else if (k == "kill_reward") t.kill_reward = v;
+        else if (k == "dead_penalty") t.dead_penalty = v; else if (k == "attack_penalty") t.attack_penalty = v;
+        else if (k == "view_x_offset" || k == "view_y_offset" || k == "att_x_offset" || k == "att_y_offset" ||
+                 k == "turn_x_offset" || k == "turn_y_offset") {}  // overwritten below, as in the reference
+        else fatal("invalid agent config %s", keys[i]);
+    }
+    if (t.can_absorb) fatal("can_absorb is outside the hot-path scope");
+    int parity = t.width % 2;
+    if (t.view_angle < 180 || t.attack_angle < 180) fatal("sector ranges are outside the hot-path scope");
+    if (std::fabs(t.view_angle - 360) > 1e-5 || std::fabs(t.attack_angle - 360) > 1e-5) fatal("only angle = 360 is supported");
+    t.view.circle(t.view_radius, 0, parity);
+    t.attack.circle(t.attack_radius, t.width / 2.0f, parity);
+    t.move.circle(t.speed, 0, 1);
+    t.view_x_offset = t.att_x_offset = t.width / 2;
+    t.view_y_offset = t.att_y_offset = t.length / 2;
+    t.move_base = 0; t.turn_base = t.move.count; t.attack_base = t.turn_base;
+    t.n_action = t.attack_base + t.attack.count;
+    e.types[name] = t;
+    return 0;
+}
+
+int gridworld_new_group(void *game, const char *type_name, int *group) {
+    World &e = *W(game);
+    auto it = e.types.find(type_name);
+    if (it == e.types.end()) fatal("invalid name of agent type in new_group: %s", type_name);
+    *group = (int)e.groups.size();
+    Group g; g.type = &it->second;
+    e.groups.push_back(g);
+    return 0;
+}
+
+// GridWorld.cc:72-118 + Map.cc:23-47
+int env_reset(void *game) {
+    World &e = *W(game);
+    e.id_counter = 0;
+    e.large_map = e.w * e.h > 99 * 99;
+    e.n_sep = e.large_map ? (e.w * e.h > 1000 * 1000 ? 16 : 8) : 1;
+    e.move_sep.assign(e.n_sep, {});
+    e.move_bound.clear(); e.attack_buf.clear();
+    e.occ_g.assign((size_t)e.w * e.h, EMPTY); e.occ_i.assign((size_t)e.w * e.h, 0);
+    for (int i = 0; i < e.w; i++) { e.add_wall(i, 0); e.add_wall(i, e.h - 1); }
+    for (int i = 0; i < e.h; i++) { e.add_wall(0, i); e.add_wall(e.w - 1, i); }
+    for (auto &g : e.groups) g.clear();
+    for (auto &r : e.rules) {  // accepted rule shapes only (see header)
+        const Node &on = e.nodes[r.on];
+        if (!(on.op == OP_ATTACK || on.op == OP_KILL || on.op == OP_COLLIDE)) fatal("reward rule event outside the hot-path scope");
+        if (e.symbols[on.raw[0]].index != -1 || e.symbols[on.raw[1]].index != -1) fatal("only 'any' symbols are supported");
+        for (int s : r.recv) if (s != on.raw[0] && s != on.raw[1]) fatal("receiver must take part in the event");
+    }
+    return 0;
+}
+
+// GridWorld.cc:171-290
+static void place(World &e, int g, int x, int y) {
+    Group &G = e.groups[g]; AgentType &t = *G.type;
+    if (!e.blank_area(x, y, t.width, t.length)) return;  // silently ignored (LOG(WARNING) compiled out)
+    int i = G.size();
+    G.x.push_back(x); G.y.push_back(y); G.id.push_back(e.id_counter++);
+    G.hp.push_back(t.hp); G.last_action.push_back(t.n_action); G.last_op.push_back(OP_NULL); G.op_obj.push_back(-1);
+    G.last_reward.push_back(0.0f); G.next_reward.push_back(t.step_reward); G.dead.push_back(0);
+    e.fill(x, y, t.width, t.length, g, i);
+}
+
+int gridworld_add_agents(void *game, int group, int n, const char *method, const int *px, const int *py, const int *) {
+    World &e = *W(game);
+    std::string m(method);
+    if (group == -1) {
+        if (m == "random") { for (int i = 0; i < n; i++) { int x, y; e.random_blank(1, 1, x, y); e.add_wall(x, y); } }
+        else if (m == "custom") { for (int i = 0; i < n; i++) e.add_wall(px[i], py[i]); }
+        else if (m == "fill") { for (int x = px[0]; x < px[0] + px[2]; x++) for (int y = px[1]; y < px[1] + px[3]; y++) e.add_wall(x, y); }
+        else fatal("unsupported method in add_agents: %s", method);
+        return 0;
+    }
+    if (group < 0 || group >= (int)e.groups.size()) fatal("invalid group handle in add_agents");
+    AgentType &t = *e.groups[group].type;
+    if (m == "random") { for (int i = 0; i < n; i++) { int x, y; e.random_blank(t.width, t.length, x, y); place(e, group, x, y); } }
+    else if (m == "custom") { for (int i = 0; i < n; i++) place(e, group, px[i], py[i]); }
+    else if (m == "fill") {
+        for (int x = px[0]; x < px[0] + px[2]; x += t.width) for (int y = px[1]; y < px[1] + px[3]; y += t.length) place(e, group, x, y);
+    } else fatal("unsupported method in add_agents: %s", method);
+    return 0;
+}
+
+// GridWorld.cc:292-401 + Map.cc:129-207 (dir == NORTH always: no turn_mode)
+int env_get_observation(void *game, int group, float **bufs) {
+    World &e = *W(game);
+    Group &G = e.groups[group]; AgentType &t = *G.type;
+    const int n = G.size(), VH = t.view.height, VW = t.view.width, NG = (int)e.groups.size();
+    const int C = e.g2c(NG), F = e.feature_size(group);
+    float *view = bufs[0], *feat = bufs[1];
+    std::memset(view, 0, sizeof(float) * (size_t)n * VH * VW * C);
+    std::memset(feat, 0, sizeof(float) * (size_t)n * F);
+    if (n == 0) return 0;  // the reference dereferences agents[0] here when minimap_mode (UB); nothing to write
+
+    std::vector<int> trans(C);  // GridWorld.cc:897-913
+    { int base = e.g2c(0); for (int i = 0; i < base; i++) trans[i] = i;
+      for (int i = 0; i < NG; i++) { trans[e.g2c((group + i) % NG)] = base; base += e.minimap ? 3 : 2; } }
+
+    const int scale_h = (e.h + VH - 1) / VH, scale_w = (e.w + VW - 1) / VW;
+    std::vector<float> mini;
+    if (e.minimap) {  // GridWorld.cc:331-360
+        mini.assign((size_t)VH * VW * NG, 0.0f);
+        for (int g = 0; g < NG; g++) {
+            Group &O = e.groups[g];
+            size_t total = 0;
+            for (int j = 0; j < O.size(); j++) { mini[((O.y[j] / scale_h) * VW + O.x[j] / scale_w) * NG + g]++; total++; }
+            for (int c = 0; c < VH * VW; c++) mini[c * NG + g] /= total;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        float *out = view + (size_t)i * VH * VW * C;
+        const int eye_x = G.x[i] + t.view_x_offset, eye_y = G.y[i] + t.view_y_offset;
+        const int x1 = eye_x + t.view.x1, y1 = eye_y + t.view.y1, x2 = eye_x + t.view.x2, y2 = eye_y + t.view.y2;
+        const int sx = std::max(x1, 0), ex = std::min(x2, e.w - 1), sy = std::max(y1, 0), ey = std::min(y2, e.h - 1);
+        for (int x = sx; x <= ex; x++)
+            for (int y = sy; y <= ey; y++) {
+                const int vx = x - x1, vy = y - y1, c = e.cell(x, y), og = e.occ_g[c];
+                if (og == EMPTY || !t.view.in[vy * VW + vx]) continue;
+                const int ch = trans[og == WALL ? 0 : e.g2c(og)];
+                out[(vy * VW + vx) * C + ch] = 1;
+                if (og >= 0) out[(vy * VW + vx) * C + ch + 1] = e.groups[og].hp[e.occ_i[c]] / e.groups[og].type->hp;
+            }
+        if (e.minimap) {  // GridWorld.cc:371-384: unmasked copy + self marker on EVERY group's minimap channel
+            const int self_x = G.x[i] / scale_w, self_y = G.y[i] / scale_h;
+            for (int j = 0; j < NG; j++) {
+                const int mc = trans[e.g2c(j)] + 2;
+                for (int k = 0; k < VH * VW; k++) out[k * C + mc] = mini[k * NG + j];
+                out[(self_y * VW + self_x) * C + mc] += 1;
+            }
+        }
+        float *f = feat + (size_t)i * F;  // GridWorld.cc:386-396, GridWorld.h:157-166
+        for (int b = 0, v = G.id[i]; b < e.embedding; b++, v >>= 1) f[b] = (float)(v & 1);
+        f[e.embedding + G.last_action[i]] = 1;
+        f[e.embedding + t.n_action] = G.last_reward[i];
+        if (e.minimap) {
+            f[e.embedding + t.n_action + 1] = (float)G.x[i] / e.w;
+            f[e.embedding + t.n_action + 2] = (float)G.y[i] / e.h;
+        }
+    }
+    return 0;
+}
+
+// GridWorld.cc:403-454
+int env_set_action(void *game, int group, const int *actions) {
+    World &e = *W(game);
+    Group &G = e.groups[group]; AgentType &t = *G.type;
+    const int bandwidth = (e.w + e.n_sep - 1) / e.n_sep;
+    for (int i = 0; i < G.size(); i++) {
+        int act = actions[i];
+        G.last_action[i] = act;
+        if (act < t.attack_base) {  // move (turn_base == attack_base without turn_mode)
+            if (e.large_map) {
+                int x_ = G.x[i] % bandwidth;
+                if (x_ < 4 || x_ > bandwidth - 4) e.move_bound.push_back({group, i, act - t.move_base});
+                else e.move_sep[G.x[i] / bandwidth].push_back({group, i, act - t.move_base});
+            } else e.move_bound.push_back({group, i, act - t.move_base});
+        } else e.attack_buf.push_back({group, i, act - t.attack_base});
+    }
+    return 0;
+}
+
+// GridWorld.cc:456-631
+int env_step(void *game, int *done) {
+    World &e = *W(game);
+    // shuffle (GridWorld.cc:464-468)
+    for (int i = 0; i < (int)e.attack_buf.size(); i++) {
+        int j = (int)e.rng() % (i + 1);
+        std::swap(e.attack_buf[i], e.attack_buf[j]);
+    }
+    // attack (GridWorld.cc:475-506, Map.cc:209-310, GridWorld.h:203-209)
+    for (const Pending &p : e.attack_buf) {
+        Group &A = e.groups[p.g]; AgentType &at = *A.type;
+        if (A.dead[p.i]) continue;
+        const int ox = A.x[p.i] + at.att_x_offset + at.attack.dx[p.act], oy = A.y[p.i] + at.att_y_offset + at.attack.dy[p.act];
+        int tg = EMPTY, ti = 0;
+        if (ox >= 0 && ox < e.w && oy >= 0 && oy < e.h) { tg = e.occ_g[e.cell(ox, oy)]; ti = e.occ_i[e.cell(ox, oy)]; }
+        if (tg < 0 || (!at.attack_in_group && tg == p.g)) { A.next_reward[p.i] += at.attack_penalty; continue; }
+        Group &T = e.groups[tg]; AgentType &tt = *T.type;
+        float reward = 0.0f;
+        T.hp[ti] -= at.damage;
+        if (T.hp[ti] < 0.0) { T.dead[ti] = 1; T.next_reward[ti] = tt.dead_penalty; }
+        if (T.dead[ti]) {
+            A.last_op[p.i] = OP_KILL; A.op_obj[p.i] = ((int64_t)tg << 32) | (uint32_t)ti;
+            e.remove_agent(tg, ti);
+            T.dead_ct++;
+            A.hp[p.i] = std::min(at.hp, A.hp[p.i] + tt.kill_supply);
+            reward = tt.kill_reward;
+        } else {
+            A.last_op[p.i] = OP_ATTACK; A.op_obj[p.i] = ((int64_t)tg << 32) | (uint32_t)ti;
+        }
+        A.next_reward[p.i] += reward + at.attack_penalty;
+    }
+    e.attack_buf.clear();
+    // starve / recover (GridWorld.cc:519-542, GridWorld.h:194-209)
+    for (int g = 0; g < (int)e.groups.size(); g++) {
+        Group &G = e.groups[g]; AgentType &t = *G.type;
+        for (int i = 0; i < G.size(); i++) {
+            if (G.dead[i]) continue;
+            if (t.step_recover > 0) G.hp[i] = std::min(t.hp, G.hp[i] + t.step_recover);
+            else {
+                G.hp[i] -= -t.step_recover;
+                if (G.hp[i] < 0.0) { G.dead[i] = 1; G.next_reward[i] = t.dead_penalty; }
+            }
+            if (G.dead[i]) { e.remove_agent(g, i); G.dead_ct++; }
+        }
+    }
+    // move: stripes in index order, then the boundary list (GridWorld.cc:574-613, Map.cc:313-358)
+    auto run = [&](std::vector<Pending> &buf) {
+        for (const Pending &p : buf) {
+            Group &G = e.groups[p.g]; AgentType &t = *G.type;
+            if (G.dead[p.i]) continue;
+            const int nx = G.x[p.i] + t.move.dx[p.act], ny = G.y[p.i] + t.move.dy[p.act];
+            if (e.blank_area(nx, ny, t.width, t.length, p.g, p.i)) {
+                e.fill(G.x[p.i], G.y[p.i], t.width, t.length, EMPTY, 0);
+                e.fill(nx, ny, t.width, t.length, p.g, p.i);
+                G.x[p.i] = nx; G.y[p.i] = ny;
+            } else if (!(nx < 0 || ny < 0 || nx + t.width >= e.w || ny + t.length >= e.h)) {  // Map.cc:486-501
+                for (int a = 0; a < t.width; a++) {
+                    bool found = false;
+                    for (int b = 0; b < t.length; b++) {
+                        int c = e.cell(nx + a, ny + b);
+                        if (e.occ_g[c] >= 0 && !(e.occ_g[c] == p.g && e.occ_i[c] == p.i)) {
+                            G.last_op[p.i] = OP_COLLIDE; G.op_obj[p.i] = ((int64_t)e.occ_g[c] << 32) | (uint32_t)e.occ_i[c];
+                            found = true; break;
+                        }
+                    }
+                    if (found) break;
+                }
+            }
+        }
+        buf.clear();
+    };
+    for (auto &b : e.move_sep) run(b);
+    run(e.move_bound);
+    // reward rules (GridWorld.cc:681-692, RewardEngine.cc:216-443) for Event(a, op, b), a/b = 'any'
+    for (Rule &r : e.rules) {
+        r.trigger = false;
+        const Node &on = e.nodes[r.on];
+        const Symbol &sa = e.symbols[on.raw[0]], &sb = e.symbols[on.raw[1]];
+        Group &A = e.groups[sa.group];
+        for (int i = 0; i < A.size(); i++) {
+            if (A.op_obj[i] < 0) continue;
+            int tg = (int)(A.op_obj[i] >> 32), ti = (int)(uint32_t)A.op_obj[i];
+            if (tg != sb.group || A.last_op[i] != on.op) continue;
+            r.trigger = true;
+            for (size_t k = 0; k < r.recv.size(); k++) {
+                if (r.recv[k] == on.raw[0]) A.next_reward[i] += r.val[k];
+                else e.groups[tg].next_reward[ti] += r.val[k];
+            }
+        }
+    }
+    // done (GridWorld.cc:619-630)
+    int live = 0;
+    for (auto &g : e.groups) if (g.size() - g.dead_ct > 0) live++;
+    *done = live < (int)e.groups.size();
+    for (auto &r : e.rules) if (r.trigger && r.terminal) *done = 1;
+    return 0;
+}
+
+// GridWorld.cc:694-704
+int env_get_reward(void *game, int group, float *buf) {
+    Group &G = W(game)->groups[group];
+    for (int i = 0; i < G.size(); i++) buf[i] = G.next_reward[i] + G.reward;
+    return 0;
+}
+
+// GridWorld.cc:633-665 + GridWorld.h:168-174
+int gridworld_clear_dead(void *game) {
+    World &e = *W(game);
+    for (int g = 0; g < (int)e.groups.size(); g++) {
+        Group &G = e.groups[g]; AgentType &t = *G.type;
+        G.reward = 0;
+        int pt = 0;
+        for (int j = 0; j < G.size(); j++) {
+            if (G.dead[j]) continue;
+            G.x[pt] = G.x[j]; G.y[pt] = G.y[j]; G.id[pt] = G.id[j]; G.hp[pt] = G.hp[j]; G.last_action[pt] = G.last_action[j];
+            G.last_reward[pt] = G.next_reward[j]; G.next_reward[pt] = t.step_reward; G.last_op[pt] = OP_NULL; G.op_obj[pt] = -1;
+            G.dead[pt] = 0;
+            e.fill(G.x[pt], G.y[pt], t.width, t.length, g, pt);
+            pt++;
+        }
+        G.x.resize(pt); G.y.resize(pt); G.id.resize(pt); G.hp.resize(pt); G.last_action.resize(pt); G.last_reward.resize(pt);
+        G.next_reward.resize(pt); G.last_op.resize(pt); G.op_obj.resize(pt); G.dead.resize(pt);
+        G.dead_ct = 0;
+    }
+    return 0;
+}
+
+// GridWorld.cc:709-894
+int env_get_info(void *game, int group, const char *name, void *buf) {
+    World &e = *W(game);
+    int *ib = (int *)buf; float *fb = (float *)buf; bool *bb = (bool *)buf;
+    std::string k(name);
+    if (k == "num") ib[0] = e.groups[group].size();
+    else if (k == "id") { Group &G = e.groups[group]; for (int i = 0; i < G.size(); i++) ib[i] = G.id[i]; }
+    else if (k == "pos") { Group &G = e.groups[group]; for (int i = 0; i < G.size(); i++) { ib[2 * i] = G.x[i]; ib[2 * i + 1] = G.y[i]; } }
+    else if (k == "alive") { Group &G = e.groups[group]; for (int i = 0; i < G.size(); i++) bb[i] = !G.dead[i]; }
+    else if (k == "action_space") ib[0] = e.groups[group].type->n_action;
+    else if (k == "view_space") { ib[0] = e.groups[group].type->view.height; ib[1] = e.groups[group].type->view.width; ib[2] = e.g2c((int)e.groups.size()); }
+    else if (k == "feature_space") ib[0] = e.feature_size(group);
+    else if (k == "attack_base") ib[0] = e.groups[group].type->attack_base;
+    else if (k == "view2attack") {
+        AgentType &t = *e.groups[group].type;
+        std::fill(ib, ib + t.view.height * t.view.width, -1);
+        for (int i = 0; i < t.attack.count; i++) ib[(t.attack.dy[i] - t.view.y1) * t.view.width + (t.attack.dx[i] - t.view.x1)] = i;
+    } else if (k == "global_minimap") {
+        int vh = (int)std::lround(fb[0]), vw = (int)std::lround(fb[1]), NG = (int)e.groups.size();
+        std::memset(fb, 0, sizeof(float) * vh * vw * NG);
+        int sh = (e.h + vh - 1) / vh, sw = (e.w + vw - 1) / vw;
+        for (int i = 0; i < NG; i++) {
+            int ch = (i - group + NG) % NG; Group &O = e.groups[i];
+            for (int j = 0; j < O.size(); j++) fb[((O.y[j] / sh) * vw + O.x[j] / sw) * NG + ch]++;
+            for (int c = 0; c < vh * vw; c++) fb[c * NG + ch] /= O.size();
+        }
+    } else if (k == "walls_info") {
+        int ct = 0;
+        for (int c = 0; c < e.w * e.h; c++) if (e.occ_g[c] == WALL) { ct++; ib[2 * ct] = c % e.w; ib[2 * ct + 1] = c / e.w; }
+        ib[0] = ct;
+    } else if (k == "groups_info") {
+        const int colors[][3] = {{192, 64, 64}, {64, 64, 192}, {64, 192, 64}, {64, 64, 64}};
+        for (int i = 0; i < (int)e.groups.size(); i++) {
+            ib[5 * i] = e.groups[i].type->width; ib[5 * i + 1] = e.groups[i].type->length;
+            for (int c = 0; c < 3; c++) ib[5 * i + 2 + c] = colors[i][c];
+        }
+    } else fatal("unsupported info name in get_info: %s", name);
+    return 0;
+}
+
+// RewardEngine.cc:28-69
+int gridworld_define_agent_symbol(void *game, int no, int group, int index) {
+    World &e = *W(game);
+    if (no >= (int)e.symbols.size()) e.symbols.resize(no + 1);
+    e.symbols[no].group = group; e.symbols[no].index = index;
+    return 0;
+}
+int gridworld_define_event_node(void *game, int no, int op, int *inputs, int n) {
+    World &e = *W(game);
+    if (no >= (int)e.nodes.size()) e.nodes.resize(no + 1);
+    e.nodes[no].op = op;
+    for (int i = 0; i < n; i++) e.nodes[no].raw.push_back(inputs[i]);
+    return 0;
+}
+int gridworld_add_reward_rule(void *game, int on, int *recv, float *val, int n, bool terminal, bool) {
+    Rule r; r.on = on; r.terminal = terminal;
+    for (int i = 0; i < n; i++) { r.recv.push_back(recv[i]); r.val.push_back(val[i]); }
+    W(game)->rules.push_back(r);
+    return 0;
+}
+
+int gridworld_set_goal(void *, int, const char *, const int *) { fatal("set_goal is deprecated in the reference; outside the hot-path scope"); }
+int env_render(void *) { return 0; }
+int env_render_next_file(void *) { return 0; }
+int discrete_snake_clear_dead(void *) { fatal("DiscreteSnake is a different game; outside the hot-path scope"); }
+int discrete_snake_add_object(void *, int, int, const char *, const int *) { fatal("DiscreteSnake is a different game; outside the hot-path scope"); }
+
+}  // extern "C"
