@@ -1,0 +1,93 @@
+// engine.h -- data model shared by the HIP kernels (kernels.hip) and the host engine (engine.hip).
+//
+// MI355X-first layout (not the reference's AoS heap objects, GridWorld.h:131-253 / Map.h:23-29):
+//   * every group is a set of struct-of-arrays device buffers indexed by the agent's position in the group
+//     (the reference's vector<Agent*> order), so all per-agent kernels load/store fully coalesced;
+//   * the map is one int32 per cell (`occ`): EMPTY, WALL or a packed agent reference (group, index);
+//   * `viewcell` is a painted copy of the map for the observation renderer: {group code, hp / type.hp} per cell,
+//     8 bytes, so the renderer does ONE coalesced load per cell and no dependent gather;
+//   * order-dependent phases (attack, move) do not keep lists: each agent carries its pending action and an order
+//     key, and the sequential result is recovered by fixed-point / pointer-jumping kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace magent_amd {
+
+constexpr int MAXG = 8;                 // groups per environment
+constexpr int REF_SHIFT = 27;           // packed agent reference = (group << 27) | index
+constexpr int REF_MASK = (1 << REF_SHIFT) - 1;
+constexpr int OCC_EMPTY = -1;
+constexpr int OCC_WALL = -2;
+
+// pending action of an agent for the coming step: (kind << 16) | payload
+constexpr int PEND_NONE = 0;
+constexpr int PEND_MOVE = 1 << 16;
+constexpr int PEND_ATTACK = 2 << 16;
+constexpr int PEND_ARG = 0xFFFF;
+
+// EventOp values the engine stores in last_op (reference grid_def.h:18-24)
+constexpr int OP_KILL = 3, OP_COLLIDE = 6, OP_ATTACK = 7, OP_NULL = 11;
+
+constexpr int RANK_INF = 0x7FFFFFFF;    // "never dies in the attack phase"
+constexpr unsigned MV_FAIL = 0xFFFFFFFFu, MV_OK = 0xFFFFFFFEu;  // move status; anything else = "depends on ref"
+constexpr unsigned long long CLAIM_NONE = ~0ull;
+
+__host__ __device__ inline int ref_pack(int g, int i) { return (g << REF_SHIFT) | i; }
+__host__ __device__ inline int ref_group(int r) { return r >> REF_SHIFT; }
+__host__ __device__ inline int ref_index(int r) { return r & REF_MASK; }
+
+// per-type constants (reference AgentType.h:14-46), by group
+struct TypeDev {
+    float hp, damage, step_recover, kill_supply, kill_reward, dead_penalty, attack_penalty, step_reward;
+    int attack_in_group;
+    int n_move, n_attack;        // action layout: [0, n_move) moves, [n_move, n_move + n_attack) attacks
+    int move_off, attack_off;    // offsets into WorldView::delta (int2 {dx,dy} per action payload)
+    int view_w, view_h;          // observation window
+    int view_x1, view_y1;        // window origin relative to the agent position (includes view_x/y_offset)
+    int mask_off;                // offset into WorldView::mask (view_h * view_w bytes, 1 = inside the view range)
+};
+
+// device arrays of one group; n = current number of agents (dead ones included until clear_dead)
+struct GroupDev {
+    int n;
+    int *x, *y, *id, *last_action, *op_obj, *pend;
+    float *hp, *next_reward, *last_reward;
+    unsigned char *dead, *last_op;
+    unsigned *key;               // attack: sequence number -> rank after the shuffle; move: order key
+    int *drank_a, *drank_b;      // attack fixed point: rank at which the agent dies (ping-pong)
+    unsigned *mv;                // move resolution status / dependency
+    int *hits;                   // reward rules: number of rule hits received as the object of an event
+};
+
+struct WorldView {
+    int w, h, G;
+    int *occ;
+    int2 *viewcell;
+    unsigned long long *claim;
+    const int2 *delta;
+    const unsigned char *mask;
+    int *counters;               // [0] changed flag, [1] attack count, [2..2+MAXG) dead_ct, [16..) rule triggers
+    TypeDev type[MAXG];
+    GroupDev grp[MAXG];
+    int any_kill_supply;
+    int large_map, bandwidth;    // reference large_map_mode striping (GridWorld.cc:75-85, 407-425)
+};
+
+constexpr int CTR_CHANGED = 0, CTR_ATTACK = 1, CTR_DEAD = 2, CTR_TRIGGER = 16, CTR_TOTAL = 64;
+
+// observation render parameters for one get_observation(group) call
+struct RenderArgs {
+    int g;                       // observing group
+    int n;                       // agents to render
+    int VH, VW, C, S;            // window, channels, S = VH*VW*C floats per agent
+    int F, E, NA;                // feature size, embedding size, n_action
+    int minimap;                 // minimap_mode
+    int scale_w, scale_h;
+    int chan_desc[32];           // per output channel: (kind << 8) | (code & 0xff); kind 0 = has, 1 = hp, 2 = minimap
+    int totals[MAXG];            // group sizes (minimap divisor)
+    const int *mini_counts;      // int[G][VH*VW] histogram
+    float *view, *feat;
+};
+
+}  // namespace magent_amd

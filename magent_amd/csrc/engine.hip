@@ -1,0 +1,860 @@
+// engine.hip -- host side of the MI355X grid-world engine: configuration, agent types, placement, per-call
+// orchestration of the kernels in kernels.hip on one HIP stream per environment.
+//
+// Mirrors the behaviour of the reference's GridWorld class (src/gridworld/GridWorld.{h,cc}) for the hot-path scope
+// of SURVEY.md section 8.  The product never falls back to a CPU engine: every state-changing operation after
+// placement runs on the GPU.  The only host-side algorithmic pieces are the cold-path placement (add_agents, which
+// the reference defines as sequential rejection sampling on the engine RNG) and, in this round, the attack
+// shuffle's permutation (a function of the RNG state and the attack count only).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "engine_host.h"
+
+namespace magent_amd {
+
+[[noreturn]] void fatal(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    std::fprintf(stderr, "magent-amd FATAL: ");
+    std::vfprintf(stderr, fmt, ap);
+    std::fprintf(stderr, "\n");
+    va_end(ap);
+    std::abort();
+}
+
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) fatal("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ ranges / types
+// CircleRange of the reference (Range.h:149-190): double arithmetic and eps constants reproduced exactly
+void HostRange::circle(float radius, float inner_radius, int parity) {
+    const double eps = 1e-8;
+    width = 2 * int(radius + eps) + parity;
+    const int center = (int)radius;
+    if (width % 2 != parity) width++;
+    height = width;
+    in.assign((size_t)width * width, 0);
+    dx.clear(); dy.clear(); count = 0;
+    const double delta = (parity == 0 ? 0.5 : 0);
+    for (int i = 0; i < width; i++)
+        for (int j = 0; j < width; j++) {
+            double ax = std::fabs(j - center + delta), ay = std::fabs(i - center + delta);
+            double dis = std::sqrt(ax * ax + ay * ay);
+            if (dis < radius + eps && dis > inner_radius - eps) {
+                in[(size_t)i * width + j] = 1;
+                dx.push_back(j - center); dy.push_back(i - center); count++;
+            }
+        }
+    x1 = y1 = -center;
+    x2 = y2 = width - center - 1;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+struct Env::ProfScope {
+    Env &e; Env::ProfSlot *slot = nullptr; hipEvent_t a{}, b{};
+    ProfScope(Env &env, const char *name) : e(env) {
+        if (!e.prof_on) return;
+        slot = &e.prof[name];
+        a = e.prof_event(); b = e.prof_event();
+        HIP_OK(hipEventRecord(a, e.stream));
+    }
+    ~ProfScope() {
+        if (!slot) return;
+        HIP_OK(hipEventRecord(b, e.stream));
+        slot->pending.emplace_back(a, b);
+    }
+};
+
+hipEvent_t Env::prof_event() {
+    if (!prof_pool.empty()) { hipEvent_t ev = prof_pool.back(); prof_pool.pop_back(); return ev; }
+    hipEvent_t ev;
+    HIP_OK(hipEventCreate(&ev));
+    return ev;
+}
+
+void Env::profile_read(const char *name, int *n, float *ms) {
+    use_device();
+    HIP_OK(hipStreamSynchronize(stream));
+    ProfSlot &s = prof[name];
+    *n = (int)s.pending.size();
+    *ms = 0;
+    for (auto &p : s.pending) {
+        float t = 0;
+        HIP_OK(hipEventElapsedTime(&t, p.first, p.second));
+        *ms += t;
+        prof_pool.push_back(p.first); prof_pool.push_back(p.second);
+    }
+    s.pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------------ lifecycle
+Env::Env() {
+    const char *d = std::getenv("MAGENT_DEVICE");
+    if (!d) d = std::getenv("LOCAL_RANK");
+    device_id = d ? std::atoi(d) : 0;
+    rng.seed(0);  // GridWorld.cc:29
+}
+
+template <class T>
+static void dfree(T *&p) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+Env::~Env() {
+    if (!device_ready) return;
+    use_device();
+    (void)hipStreamSynchronize(stream);
+    for (auto &g : groups) free_group(g);
+    dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_counters); dfree(d_gtab); dfree(d_ttab);
+    dfree(d_delta); dfree(d_mask); dfree(d_mini); dfree(d_sums); dfree(d_rank); dfree(d_actions);
+    dfree(d_stage_view); dfree(d_stage_feat); dfree(d_stage_small);
+    if (h_counters) (void)hipHostFree(h_counters);
+    if (h_rank) (void)hipHostFree(h_rank);
+    for (auto &kv : prof) for (auto &p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto ev : prof_pool) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(stream);
+}
+
+void Env::use_device() { HIP_OK(hipSetDevice(device_id)); }
+
+void Env::init_device() {
+    if (device_ready) return;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        fatal("no HIP device available (%s). This engine has no CPU fallback.", hipGetErrorString(e));
+    if (device_id >= count) fatal("device_id %d out of range (%d devices)", device_id, count);
+    use_device();
+    HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_OK(hipMalloc(&d_counters, sizeof(int) * CTR_TOTAL));
+    HIP_OK(hipMemset(d_counters, 0, sizeof(int) * CTR_TOTAL));
+    HIP_OK(hipMalloc(&d_gtab, sizeof(GroupDev) * MAXG));
+    HIP_OK(hipMalloc(&d_ttab, sizeof(TypeDev) * MAXG));
+    HIP_OK(hipHostMalloc((void **)&h_counters, sizeof(int) * CTR_TOTAL, hipHostMallocDefault));
+    device_ready = true;
+}
+
+// ------------------------------------------------------------------------------------------------ configuration
+// GridWorld::set_config (GridWorld.cc:120-149)
+void Env::set_config(const char *key, void *p) {
+    std::string k(key);
+    if (k == "map_width") width = *(int *)p;
+    else if (k == "map_height") height = *(int *)p;
+    else if (k == "minimap_mode") minimap_mode = *(bool *)p;
+    else if (k == "embedding_size") embedding_size = *(int *)p;
+    else if (k == "seed") rng.seed((unsigned long)*(int *)p);
+    else if (k == "device_id") { if (device_ready && *(int *)p != device_id) fatal("device_id must be set before env_reset"); device_id = *(int *)p; }
+    else if (k == "render_dir") render_dir = (const char *)p;
+    else if (k == "food_mode" || k == "turn_mode" || k == "goal_mode") {
+        if (*(bool *)p) fatal("%s is outside the hot-path scope of this engine (SURVEY.md 8a)", key);
+    } else fatal("invalid argument in GridWorld::set_config : %s", key);
+}
+
+// AgentType::AgentType (AgentType.cc:30-123)
+void Env::register_agent_type(const char *name, int n, const char **keys, float *values) {
+    if (types.count(name)) fatal("duplicated name of agent type in GridWorld::register_agent_type : %s", name);
+    HostType t;
+    t.name = name;
+    for (int i = 0; i < n; i++) {
+        std::string k(keys[i]);
+        float v = values[i];
+        if (k == "width") t.width = (int)(v + 0.5);
+        else if (k == "length") t.length = (int)(v + 0.5);
+        else if (k == "speed") t.speed = v;
+        else if (k == "hp") t.hp = v;
+        else if (k == "view_radius") t.view_radius = v;
+        else if (k == "view_angle") t.view_angle = v;
+        else if (k == "attack_radius") t.attack_radius = v;
+        else if (k == "attack_angle") t.attack_angle = v;
+        else if (k == "damage") t.damage = v;
+        else if (k == "step_recover") t.step_recover = v;
+        else if (k == "kill_supply") t.kill_supply = v;
+        else if (k == "attack_in_group") t.attack_in_group = bool(int(v + 0.5));
+        else if (k == "can_absorb") t.can_absorb = bool(int(v + 0.5));
+        else if (k == "step_reward") t.step_reward = v;
+        else if (k == "kill_reward") t.kill_reward = v;
+        else if (k == "dead_penalty") t.dead_penalty = v;
+        else if (k == "attack_penalty") t.attack_penalty = v;
+        else if (k == "hear_radius" || k == "speak_radius" || k == "speak_ability" || k == "trace" || k == "eat_ability" ||
+                 k == "food_supply" || k == "view_x_offset" || k == "view_y_offset" || k == "att_x_offset" ||
+                 k == "att_y_offset" || k == "turn_x_offset" || k == "turn_y_offset") {
+            // accepted like the reference; never read on this path (offsets are recomputed, AgentType.cc:106-108)
+        } else fatal("invalid agent config in AgentType::AgentType : %s", keys[i]);
+    }
+    if (t.width != 1 || t.length != 1) fatal("agent type %s: multi-cell bodies (%dx%d) are not on the GPU path yet (SURVEY.md 8f rank 4)", name, t.width, t.length);
+    if (t.can_absorb) fatal("agent type %s: can_absorb is outside the hot-path scope", name);
+    if (t.view_angle < 180 || t.attack_angle < 180) fatal("agent type %s: sector ranges are outside the hot-path scope", name);
+    if (std::fabs(t.view_angle - 360) > 1e-5 || std::fabs(t.attack_angle - 360) > 1e-5)
+        fatal("only supports ranges with angle = 360, when angle > 180.");
+    const int parity = t.width % 2;
+    t.view.circle(t.view_radius, 0, parity);
+    t.attack.circle(t.attack_radius, t.width / 2.0f, parity);
+    t.move.circle(t.speed, 0, 1);
+    t.view_x_offset = t.att_x_offset = t.width / 2;
+    t.view_y_offset = t.att_y_offset = t.length / 2;
+    t.attack_base = t.move.count;  // no turn_mode: move | attack
+    t.n_action = t.attack_base + t.attack.count;
+    if (t.n_action > PEND_ARG) fatal("action space too large");
+    types[name] = t;
+}
+
+void Env::new_group(const char *type_name, int *handle) {
+    auto it = types.find(type_name);
+    if (it == types.end()) fatal("invalid name of agent type in new_group : %s", type_name);
+    if ((int)groups.size() >= MAXG) fatal("at most %d groups are supported", MAXG);
+    *handle = (int)groups.size();
+    HostGroup g;
+    g.type = &it->second;
+    groups.push_back(g);
+}
+
+int Env::n_channel() const { return 1 + (int)groups.size() * (minimap_mode ? 3 : 2); }  // GridWorld.cc:915-924
+int Env::feature_size(int g) const { return embedding_size + groups[g].type->n_action + 1 + (minimap_mode ? 2 : 0); }
+
+// RewardEngine.cc:28-69
+void Env::define_agent_symbol(int no, int group, int index) {
+    if (no >= (int)symbols.size()) symbols.resize(no + 1);
+    symbols[no] = {group, index};
+}
+void Env::define_event_node(int no, int op, int *inputs, int n) {
+    if (no >= (int)nodes.size()) nodes.resize(no + 1);
+    nodes[no].op = op;
+    for (int i = 0; i < n; i++) nodes[no].raw.push_back(inputs[i]);
+}
+void Env::add_reward_rule(int on, int *recv, float *val, int n, bool terminal) {
+    HostRule r;
+    r.on = on; r.terminal = terminal;
+    for (int i = 0; i < n; i++) { r.recv.push_back(recv[i]); r.val.push_back(val[i]); }
+    rules.push_back(r);
+}
+
+// translate the accepted rule shapes into kernel arguments; anything else is refused loudly
+void Env::compile_rules() {
+    rule_args.clear();
+    if ((int)rules.size() > CTR_TOTAL - CTR_TRIGGER) fatal("too many reward rules");
+    for (size_t k = 0; k < rules.size(); k++) {
+        const HostRule &r = rules[k];
+        if (r.on < 0 || r.on >= (int)nodes.size()) fatal("reward rule %zu refers to an undefined event", k);
+        const HostNode &on = nodes[r.on];
+        if (!(on.op == OP_ATTACK || on.op == OP_KILL || on.op == OP_COLLIDE) || on.raw.size() != 2)
+            fatal("reward rule %zu: only Event(a, attack|kill|collide, b) is on the GPU path (SURVEY.md 8a row a8)", k);
+        const HostSymbol &sa = symbols[on.raw[0]], &sb = symbols[on.raw[1]];
+        if (sa.index != -1 || sb.index != -1) fatal("reward rule %zu: only 'any' agent symbols are on the GPU path", k);
+        if (sa.group < 0 || sa.group >= (int)groups.size() || sb.group < 0 || sb.group >= (int)groups.size())
+            fatal("reward rule %zu: invalid group in agent symbol", k);
+        RuleArgs a{};
+        a.ga = sa.group; a.gb = sb.group; a.op = on.op; a.rule_no = (int)k;
+        for (size_t i = 0; i < r.recv.size(); i++) {
+            if (r.recv[i] == on.raw[0]) { if (a.n_subj == 4) fatal("too many receivers"); a.v_subj[a.n_subj++] = r.val[i]; }
+            else if (r.recv[i] == on.raw[1]) { if (a.n_obj == 4) fatal("too many receivers"); a.v_obj[a.n_obj++] = r.val[i]; }
+            else fatal("reward rule %zu: a receiver must be the subject or the object of the event", k);
+        }
+        if (a.n_subj && a.n_obj && a.ga == a.gb)
+            fatal("reward rule %zu: subject and object receivers in the same group interleave float adds; not on the GPU path", k);
+        rule_args.push_back(a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ device buffers
+template <class T>
+static void grow(T *&p, size_t &cap, size_t need, hipStream_t stream, bool keep = false, size_t keep_n = 0) {
+    if (need <= cap) return;
+    size_t ncap = std::max(need, cap * 2);
+    T *q = nullptr;
+    HIP_OK(hipMalloc(&q, sizeof(T) * ncap));
+    if (p) {
+        HIP_OK(hipStreamSynchronize(stream));
+        if (keep && keep_n) HIP_OK(hipMemcpy(q, p, sizeof(T) * keep_n, hipMemcpyDeviceToDevice));
+        HIP_OK(hipFree(p));
+    }
+    p = q; cap = ncap;
+}
+
+void Env::free_group(HostGroup &g) {
+    GroupDev &c = g.cur, &a = g.alt;
+    dfree(c.x); dfree(c.y); dfree(c.id); dfree(c.last_action); dfree(c.op_obj); dfree(c.pend); dfree(c.hp);
+    dfree(c.next_reward); dfree(c.last_reward); dfree(c.dead); dfree(c.last_op); dfree(c.key); dfree(c.drank_a);
+    dfree(c.drank_b); dfree(c.mv); dfree(c.hits);
+    dfree(a.x); dfree(a.y); dfree(a.id); dfree(a.last_action); dfree(a.hp); dfree(a.next_reward); dfree(a.last_reward);
+    g.cap = 0; g.n = 0;
+}
+
+template <class T>
+static void regrow(T *&p, size_t old_n, size_t ncap) {
+    T *q = nullptr;
+    HIP_OK(hipMalloc(&q, sizeof(T) * ncap));
+    if (p && old_n) HIP_OK(hipMemcpy(q, p, sizeof(T) * old_n, hipMemcpyDeviceToDevice));
+    if (p) HIP_OK(hipFree(p));
+    p = q;
+}
+
+void Env::ensure_capacity(HostGroup &g, int need) {
+    if (need <= g.cap) return;
+    HIP_OK(hipStreamSynchronize(stream));
+    size_t ncap = std::max<size_t>(std::max<size_t>(need, (size_t)g.cap * 2), 1024);
+    size_t n = g.n;
+    GroupDev &c = g.cur, &a = g.alt;
+    regrow(c.x, n, ncap); regrow(c.y, n, ncap); regrow(c.id, n, ncap); regrow(c.last_action, n, ncap);
+    regrow(c.op_obj, n, ncap); regrow(c.pend, n, ncap); regrow(c.hp, n, ncap); regrow(c.next_reward, n, ncap);
+    regrow(c.last_reward, n, ncap); regrow(c.dead, n, ncap); regrow(c.last_op, n, ncap); regrow(c.key, n, ncap);
+    regrow(c.drank_a, n, ncap); regrow(c.drank_b, n, ncap); regrow(c.mv, n, ncap); regrow(c.hits, n, ncap);
+    HIP_OK(hipMemset(c.hits, 0, sizeof(int) * ncap));
+    regrow(a.x, 0, ncap); regrow(a.y, 0, ncap); regrow(a.id, 0, ncap); regrow(a.last_action, 0, ncap);
+    regrow(a.hp, 0, ncap); regrow(a.next_reward, 0, ncap); regrow(a.last_reward, 0, ncap);
+    g.cap = (int)ncap;
+    tables_valid = false;
+}
+
+WorldView Env::view() const {
+    WorldView W{};
+    W.w = width; W.h = height; W.G = (int)groups.size();
+    W.occ = d_occ; W.viewcell = d_viewcell; W.claim = d_claim; W.delta = d_delta; W.mask = d_mask; W.counters = d_counters;
+    W.any_kill_supply = any_kill_supply;
+    W.large_map = large_map_mode; W.bandwidth = bandwidth;
+    for (int g = 0; g < W.G; g++) {
+        W.type[g] = groups[g].tdev;
+        W.grp[g] = groups[g].cur;
+        W.grp[g].n = groups[g].n;
+    }
+    return W;
+}
+
+void Env::ensure_tables() {
+    if (tables_valid) return;
+    launch_set_tables(stream, view(), d_gtab, d_ttab);
+    tables_valid = true;
+}
+
+int *Env::read_counters() {
+    HIP_OK(hipMemcpyAsync(h_counters, d_counters, sizeof(int) * CTR_TOTAL, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    return h_counters;
+}
+
+bool Env::read_changed() {
+    HIP_OK(hipMemcpyAsync(h_counters, d_counters, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    return h_counters[CTR_CHANGED] != 0;
+}
+
+void Env::clear_changed() { HIP_OK(hipMemsetAsync(d_counters + CTR_CHANGED, 0, sizeof(int), stream)); }
+
+// ------------------------------------------------------------------------------------------------ reset / placement
+// GridWorld::reset (GridWorld.cc:72-118) + Map::reset (Map.cc:23-47).  Does not reseed the RNG.
+void Env::reset() {
+    if (width <= 2 || height <= 2) fatal("map_width / map_height must be configured before reset");
+    if ((long long)width * height > (1ll << 30)) fatal("map too large");
+    init_device();
+    use_device();
+    HIP_OK(hipStreamSynchronize(stream));
+    id_counter = 0;
+    large_map_mode = width * height > 99 * 99;
+    const int n_sep = large_map_mode ? (width * height > 1000 * 1000 ? 16 : 8) : 1;
+    bandwidth = (width + n_sep - 1) / n_sep;
+    const size_t ncell = (size_t)width * height;
+    if (ncell != map_cells) {
+        dfree(d_occ); dfree(d_viewcell); dfree(d_claim);
+        HIP_OK(hipMalloc(&d_occ, sizeof(int) * ncell));
+        HIP_OK(hipMalloc(&d_viewcell, sizeof(int2) * ncell));
+        HIP_OK(hipMalloc(&d_claim, sizeof(unsigned long long) * ncell));
+        map_cells = ncell;
+    }
+    h_occ.assign(ncell, OCC_EMPTY);
+    for (int i = 0; i < width; i++) { h_occ[i] = OCC_WALL; h_occ[(size_t)(height - 1) * width + i] = OCC_WALL; }
+    for (int i = 0; i < height; i++) { h_occ[(size_t)i * width] = OCC_WALL; h_occ[(size_t)i * width + width - 1] = OCC_WALL; }
+    h_occ_valid = true;
+    upload_occ();
+
+    // per-type constant tables (action deltas, view masks) for the groups of this game
+    std::vector<int2> delta;
+    std::vector<unsigned char> mask;
+    any_kill_supply = 0;
+    int total_attack = 0;
+    for (auto &g : groups) {
+        HostType &t = *g.type;
+        TypeDev d{};
+        d.hp = t.hp; d.damage = t.damage; d.step_recover = t.step_recover; d.kill_supply = t.kill_supply;
+        d.kill_reward = t.kill_reward; d.dead_penalty = t.dead_penalty; d.attack_penalty = t.attack_penalty;
+        d.step_reward = t.step_reward; d.attack_in_group = t.attack_in_group;
+        d.n_move = t.move.count; d.n_attack = t.attack.count;
+        d.move_off = (int)delta.size();
+        for (int k = 0; k < t.move.count; k++) delta.push_back(make_int2(t.move.dx[k], t.move.dy[k]));
+        d.attack_off = (int)delta.size();
+        for (int k = 0; k < t.attack.count; k++) delta.push_back(make_int2(t.attack.dx[k] + t.att_x_offset, t.attack.dy[k] + t.att_y_offset));
+        d.view_w = t.view.width; d.view_h = t.view.height;
+        d.view_x1 = t.view.x1 + t.view_x_offset; d.view_y1 = t.view.y1 + t.view_y_offset;
+        d.mask_off = (int)mask.size();
+        mask.insert(mask.end(), t.view.in.begin(), t.view.in.end());
+        g.tdev = d;
+        if (t.kill_supply != 0) any_kill_supply = 1;
+        total_attack += t.attack.count;
+        g.n = 0; g.group_reward = 0; g.acted = false; g.h_dead = 0;
+    }
+    if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
+    if (n_channel() > 32) fatal("too many observation channels");
+    dfree(d_delta); dfree(d_mask);
+    HIP_OK(hipMalloc(&d_delta, sizeof(int2) * std::max<size_t>(delta.size(), 1)));
+    HIP_OK(hipMalloc(&d_mask, std::max<size_t>(mask.size(), 1)));
+    if (!delta.empty()) HIP_OK(hipMemcpy(d_delta, delta.data(), sizeof(int2) * delta.size(), hipMemcpyHostToDevice));
+    if (!mask.empty()) HIP_OK(hipMemcpy(d_mask, mask.data(), mask.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(d_counters, 0, sizeof(int) * CTR_TOTAL));
+    move_seq_base = 0;
+    if (!rules_compiled) { compile_rules(); rules_compiled = true; }  // once, like init_reward_description
+    tables_valid = false;
+    paint_valid = false;
+}
+
+void Env::download_occ() {
+    if (h_occ_valid) return;
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(h_occ.data(), d_occ, sizeof(int) * h_occ.size(), hipMemcpyDeviceToHost));
+    h_occ_valid = true;
+}
+
+void Env::upload_occ() {
+    HIP_OK(hipMemcpy(d_occ, h_occ.data(), sizeof(int) * h_occ.size(), hipMemcpyHostToDevice));
+    paint_valid = false;
+}
+
+// Map::is_blank_area for a 1x1 body (Map.cc:454-470)
+bool Env::host_blank(int x, int y) const {
+    if (x < 0 || y < 0 || x + 1 >= width || y + 1 >= height) return false;
+    return h_occ[(size_t)y * width + x] == OCC_EMPTY;
+}
+
+// Map::get_random_blank (Map.cc:49-63): two RNG draws per try
+void Env::host_random_blank(int &ox, int &oy) {
+    int tries = 0;
+    while (true) {
+        int x = (int)rng() % (width - 1);
+        int y = (int)rng() % (height - 1);
+        if (host_blank(x, y)) { ox = x; oy = y; return; }
+        if (tries++ > width * height) fatal("cannot find a blank position in a filled map");
+    }
+}
+
+// GridWorld::add_agents (GridWorld.cc:180-290).  Cold path: placement is defined sequentially by the reference.
+void Env::add_agents(int group, int n, const char *method, const int *px, const int *py, const int *pdir) {
+    (void)pdir;
+    if (!device_ready) fatal("add_agents called before reset");
+    use_device();
+    download_occ();
+    std::string m(method);
+    auto add_wall = [&](int x, int y) {  // Map::add_wall (Map.cc:108-115)
+        if (x < 0 || x >= width || y < 0 || y >= height) fatal("wall position (%d, %d) out of the map", x, y);
+        int &c = h_occ[(size_t)y * width + x];
+        if (c >= 0) return;              // occupied by an agent: ignored
+        c = OCC_WALL;
+    };
+    if (group == -1) {
+        if (m == "random") { for (int i = 0; i < n; i++) { int x, y; host_random_blank(x, y); add_wall(x, y); } }
+        else if (m == "custom") { for (int i = 0; i < n; i++) add_wall(px[i], py[i]); }
+        else if (m == "fill") { for (int x = px[0]; x < px[0] + px[2]; x++) for (int y = px[1]; y < px[1] + px[3]; y++) add_wall(x, y); }
+        else fatal("unsupported method in GridWorld::add_agents : %s", method);
+        upload_occ();
+        return;
+    }
+    if (group < 0 || group >= (int)groups.size()) fatal("invalid group handle in GridWorld::add_agents : %d", group);
+    HostGroup &G = groups[group];
+    std::vector<int> sx, sy, sid;
+    auto place = [&](int x, int y) {     // add_or_error: occupied positions are silently skipped, the id is reused
+        if (!host_blank(x, y)) return;
+        h_occ[(size_t)y * width + x] = ref_pack(group, G.n + (int)sx.size());
+        sx.push_back(x); sy.push_back(y); sid.push_back(id_counter++);
+    };
+    if (m == "random") { for (int i = 0; i < n; i++) { int x, y; host_random_blank(x, y); place(x, y); } }
+    else if (m == "custom") { for (int i = 0; i < n; i++) place(px[i], py[i]); }
+    else if (m == "fill") { for (int x = px[0]; x < px[0] + px[2]; x++) for (int y = px[1]; y < px[1] + px[3]; y++) place(x, y); }
+    else fatal("unsupported method in GridWorld::add_agents : %s", method);
+
+    const int k = (int)sx.size();
+    if (G.n + k > REF_MASK) fatal("too many agents in one group");
+    if (k > 0) {
+        ensure_capacity(G, G.n + k);
+        HIP_OK(hipStreamSynchronize(stream));
+        const HostType &t = *G.type;
+        GroupDev &c = G.cur;
+        const size_t o = G.n;
+        auto up = [&](auto *dst, const auto &vec) {
+            HIP_OK(hipMemcpy(dst + o, vec.data(), sizeof(vec[0]) * vec.size(), hipMemcpyHostToDevice));
+        };
+        up(c.x, sx); up(c.y, sy); up(c.id, sid);
+        up(c.hp, std::vector<float>(k, t.hp));
+        up(c.last_action, std::vector<int>(k, t.n_action));          // GridWorld.h:140 "dangerous here !"
+        up(c.next_reward, std::vector<float>(k, t.step_reward));     // Agent ctor -> init_reward (GridWorld.h:168-174)
+        up(c.last_reward, std::vector<float>(k, 0.0f));
+        up(c.op_obj, std::vector<int>(k, -1));
+        up(c.pend, std::vector<int>(k, PEND_NONE));
+        up(c.dead, std::vector<unsigned char>(k, 0));
+        up(c.last_op, std::vector<unsigned char>(k, (unsigned char)OP_NULL));
+        G.n += k;
+        tables_valid = false;
+    }
+    upload_occ();
+}
+
+// ------------------------------------------------------------------------------------------------ observation
+void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *feat) {
+    const HostGroup &G = groups[g];
+    const HostType &t = *G.type;
+    const int NG = (int)groups.size();
+    R = RenderArgs{};
+    R.g = g; R.n = G.n;
+    R.VH = t.view.height; R.VW = t.view.width; R.C = n_channel(); R.S = R.VH * R.VW * R.C;
+    R.F = feature_size(g); R.E = embedding_size; R.NA = t.n_action;
+    R.minimap = minimap_mode;
+    R.scale_h = (height + R.VH - 1) / R.VH;   // GridWorld.cc:328-329
+    R.scale_w = (width + R.VW - 1) / R.VW;
+    // channel layout symmetric to every group (GridWorld.cc:897-913): block k belongs to group (g + k) % NG
+    const int stride = minimap_mode ? 3 : 2;
+    R.chan_desc[0] = (0 << 8) | (OCC_WALL & 0xff);
+    for (int k = 0; k < NG; k++) {
+        int j = (g + k) % NG, base = 1 + k * stride;
+        R.chan_desc[base] = (0 << 8) | j;
+        R.chan_desc[base + 1] = (1 << 8) | j;
+        if (minimap_mode) R.chan_desc[base + 2] = (2 << 8) | j;
+    }
+    for (int j = 0; j < NG; j++) R.totals[j] = groups[j].n;
+    R.mini_counts = d_mini;
+    R.view = view; R.feat = feat;
+
+    int AG = 16;
+    WorldView W = view_for_plan();
+    while (AG > 4 && render_lds_bytes(W, R, AG) > 48 * 1024) AG -= 4;
+    if (render_lds_bytes(W, R, AG) > 150 * 1024) fatal("view window too large for the LDS-tiled renderer");
+    P.AG = AG;
+    int tiles = (R.n + AG - 1) / AG;
+    P.xcd_chunk = tiles >= 64 ? tiles / 8 : 0;
+    P.div_vhw = make_fastdiv(R.VH * R.VW); P.div_vw = make_fastdiv(R.VW); P.div_s = make_fastdiv(R.S);
+    P.div_c = make_fastdiv(R.C); P.div_f = make_fastdiv(R.F);
+}
+
+WorldView Env::view_for_plan() const { WorldView W{}; W.G = (int)groups.size(); return W; }
+
+// GridWorld::get_observation (GridWorld.cc:292-401) into DEVICE buffers, asynchronous on the env stream
+void Env::observe_device(int g, float *view, float *feat) {
+    if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_observation : %d", g);
+    use_device();
+    HostGroup &G = groups[g];
+    if (G.n == 0) return;   // the reference dereferences agents[0] here (UB); nothing to write for n = 0
+    ensure_tables();
+    WorldView W = this->view();
+    if (!paint_valid) {
+        ProfScope p(*this, "paint");
+        launch_paint(stream, W, d_gtab, d_ttab);
+        paint_valid = true;
+    }
+    RenderArgs R; RenderPlan P;
+    plan_render(g, R, P, view, feat);
+    if (minimap_mode) {
+        size_t need = (size_t)W.G * R.VH * R.VW;
+        grow(d_mini, mini_cap, need, stream);
+        R.mini_counts = d_mini;
+        ProfScope p(*this, "minimap");
+        launch_minimap(stream, W, R, d_mini);
+    }
+    const bool aligned = (((uintptr_t)view) & 15) == 0;
+    {
+        ProfScope p(*this, "render");
+        launch_render(stream, W, R, P, aligned, aligned && nt_stores);
+    }
+}
+
+// host-buffer variant (the reference ABI): render into a staging buffer, then copy out
+void Env::observe_host(int g, float *view, float *feat) {
+    if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_observation : %d", g);
+    use_device();
+    HostGroup &G = groups[g];
+    if (G.n == 0) return;
+    const HostType &t = *G.type;
+    size_t nv = (size_t)G.n * t.view.height * t.view.width * n_channel(), nf = (size_t)G.n * feature_size(g);
+    grow(d_stage_view, stage_view_cap, nv, stream);
+    grow(d_stage_feat, stage_feat_cap, nf, stream);
+    observe_device(g, d_stage_view, d_stage_feat);
+    HIP_OK(hipMemcpyAsync(view, d_stage_view, sizeof(float) * nv, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(feat, d_stage_feat, sizeof(float) * nf, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ set_action
+void Env::set_action_device(int g, const int *d_act) {
+    if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in set_action : %d", g);
+    use_device();
+    HostGroup &G = groups[g];
+    if (G.acted) fatal("set_action called twice for group %d before step: the reference would execute both action lists; unsupported", g);
+    G.acted = true;
+    if (G.n == 0) return;
+    ensure_tables();
+    int nb = (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
+    grow(d_sums, sums_cap, (size_t)nb, stream);
+    ProfScope p(*this, "set_action");
+    launch_set_action(stream, view(), g, d_act, move_seq_base, d_sums);
+    move_seq_base += G.n;
+}
+
+void Env::set_action_host(int g, const int *actions) {
+    if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in set_action : %d", g);
+    use_device();
+    HostGroup &G = groups[g];
+    if (G.n > 0) {
+        grow(d_actions, actions_cap, (size_t)G.n, stream);
+        HIP_OK(hipMemcpyAsync(d_actions, actions, sizeof(int) * G.n, hipMemcpyHostToDevice, stream));
+    }
+    set_action_device(g, d_actions);
+    HIP_OK(hipStreamSynchronize(stream));   // d_actions is reused by the next call
+}
+
+// ------------------------------------------------------------------------------------------------ step
+// GridWorld::step (GridWorld.cc:456-631)
+void Env::step(int *done) {
+    if (!device_ready) fatal("step called before reset");
+    use_device();
+    ensure_tables();
+    WorldView W = view();
+    int total_n = 0;
+    for (auto &g : groups) total_n += g.n;
+
+    // ---- attack: the shuffle consumes exactly A draws (GridWorld.cc:464-468); rank[seq] = shuffled position
+    const int A = read_counters()[CTR_ATTACK];
+    if (A > 0) {
+        ProfScope p(*this, "attack");
+        if ((size_t)A > rank_cap) {
+            if (h_rank) HIP_OK(hipHostFree(h_rank));
+            size_t ncap = std::max<size_t>((size_t)A, rank_cap * 2);
+            HIP_OK(hipHostMalloc((void **)&h_rank, sizeof(int) * ncap, hipHostMallocDefault));
+            dfree(d_rank);
+            HIP_OK(hipMalloc(&d_rank, sizeof(int) * ncap));
+            rank_cap = ncap;
+        }
+        shuffle_perm.resize(A);
+        for (int i = 0; i < A; i++) shuffle_perm[i] = i;
+        for (int i = 0; i < A; i++) {
+            int j = (int)rng() % (i + 1);
+            std::swap(shuffle_perm[i], shuffle_perm[j]);
+        }
+        for (int pos = 0; pos < A; pos++) h_rank[shuffle_perm[pos]] = pos;
+        HIP_OK(hipMemcpyAsync(d_rank, h_rank, sizeof(int) * A, hipMemcpyHostToDevice, stream));
+        launch_attack_rank(stream, W, d_rank);
+        int use_b = 0, iters = 0;
+        while (true) {
+            clear_changed();
+            launch_attack_iter(stream, W, d_gtab, d_ttab, use_b);
+            use_b ^= 1;
+            iters++;
+            if (!read_changed()) break;
+            if (iters > 100000) fatal("attack resolution did not converge");
+        }
+        launch_attack_apply(stream, W, d_gtab, d_ttab, use_b);
+        last_attack_iters = iters;
+    }
+    // ---- starve / recover
+    if (total_n > 0) {
+        ProfScope p(*this, "starve");
+        launch_starve(stream, W);
+    }
+    // ---- move
+    if (total_n > 0) {
+        ProfScope p(*this, "move");
+        clear_changed();
+        launch_move_prep(stream, W, d_gtab);
+        int iters = 0;
+        while (read_changed()) {
+            clear_changed();
+            launch_move_jump(stream, W, d_gtab);
+            if (++iters > 100000) fatal("move resolution did not converge");
+        }
+        launch_move_apply(stream, W, d_gtab);
+        last_move_iters = iters;
+    }
+    // ---- reward rules + end of step
+    if (total_n > 0) {
+        ProfScope p(*this, "rules");
+        for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
+        launch_finish(stream, W);
+    }
+    const int *c = read_counters();
+    int live = 0;
+    for (size_t g = 0; g < groups.size(); g++) {
+        groups[g].h_dead = c[CTR_DEAD + g];
+        groups[g].acted = false;
+        if (groups[g].n - groups[g].h_dead > 0) live++;
+    }
+    *done = live < (int)groups.size();   // GridWorld.cc:619-624
+    for (size_t k = 0; k < rules.size(); k++) if (c[CTR_TRIGGER + k] && rules[k].terminal) *done = 1;
+    // attack count and rule triggers are per step; dead_ct lives until clear_dead
+    HIP_OK(hipMemsetAsync(d_counters + CTR_ATTACK, 0, sizeof(int), stream));
+    HIP_OK(hipMemsetAsync(d_counters + CTR_TRIGGER, 0, sizeof(int) * (CTR_TOTAL - CTR_TRIGGER), stream));
+    move_seq_base = 0;
+    h_occ_valid = false;
+    paint_valid = false;
+}
+
+// ------------------------------------------------------------------------------------------------ reward / clear_dead
+void Env::get_reward_device(int g, float *out) {
+    if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_reward : %d", g);
+    use_device();
+    GroupDev G = groups[g].cur; G.n = groups[g].n;
+    launch_get_reward(stream, G, groups[g].group_reward, out);
+}
+
+void Env::get_reward_host(int g, float *out) {
+    int n = groups[g].n;
+    if (n == 0) return;
+    grow(d_stage_small, stage_small_cap, (size_t)n * 8, stream);
+    get_reward_device(g, (float *)d_stage_small);
+    HIP_OK(hipMemcpyAsync(out, d_stage_small, sizeof(float) * n, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+}
+
+// GridWorld::clear_dead (GridWorld.cc:633-665)
+void Env::clear_dead() {
+    if (!device_ready) fatal("clear_dead called before reset");
+    use_device();
+    ProfScope p(*this, "clear_dead");
+    WorldView W = view();
+    bool any = false;
+    for (size_t g = 0; g < groups.size(); g++) {
+        HostGroup &G = groups[g];
+        G.group_reward = 0;
+        if (G.h_dead > 0) {
+            int nb = (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
+            grow(d_sums, sums_cap, (size_t)nb, stream);
+            GroupDev D = G.cur;   // survivors: double-buffered arrays go to alt, the rest is reset in place
+            D.x = G.alt.x; D.y = G.alt.y; D.id = G.alt.id; D.hp = G.alt.hp; D.last_action = G.alt.last_action;
+            D.last_reward = G.alt.last_reward; D.next_reward = G.alt.next_reward;
+            const int new_n = G.n - G.h_dead;
+            launch_compact(stream, W, (int)g, D, new_n, d_sums);
+            std::swap(G.cur.x, G.alt.x); std::swap(G.cur.y, G.alt.y); std::swap(G.cur.id, G.alt.id);
+            std::swap(G.cur.hp, G.alt.hp); std::swap(G.cur.last_action, G.alt.last_action);
+            std::swap(G.cur.last_reward, G.alt.last_reward); std::swap(G.cur.next_reward, G.alt.next_reward);
+            G.n = new_n;
+            G.h_dead = 0;
+            any = true;
+        } else {
+            launch_init_reward(stream, W, (int)g);
+        }
+    }
+    HIP_OK(hipMemsetAsync(d_counters + CTR_DEAD, 0, sizeof(int) * MAXG, stream));
+    if (any) { tables_valid = false; h_occ_valid = false; }
+}
+
+// ------------------------------------------------------------------------------------------------ info
+void Env::info_device(int g, const char *name, void *out) {
+    if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_info : %d", g);
+    use_device();
+    GroupDev G = groups[g].cur; G.n = groups[g].n;
+    if (G.n == 0) return;
+    std::string k(name);
+    if (k == "id") HIP_OK(hipMemcpyAsync(out, G.id, sizeof(int) * G.n, hipMemcpyDeviceToDevice, stream));
+    else if (k == "hp") HIP_OK(hipMemcpyAsync(out, G.hp, sizeof(float) * G.n, hipMemcpyDeviceToDevice, stream));
+    else if (k == "pos") launch_get_pos(stream, G, (int *)out);
+    else if (k == "alive") launch_get_alive(stream, G, (unsigned char *)out);
+    else fatal("unsupported info name in get_info_device : %s", name);
+}
+
+// GridWorld::get_info (GridWorld.cc:709-894)
+void Env::info_host(int g, const char *name, void *buf) {
+    std::string k(name);
+    int *ib = (int *)buf; float *fb = (float *)buf;
+    auto need_group = [&]() { if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_info(%s) : %d", name, g); };
+    if (k == "num") { need_group(); ib[0] = groups[g].n; return; }
+    if (k == "action_space") { need_group(); ib[0] = groups[g].type->n_action; return; }
+    if (k == "view_space") { need_group(); ib[0] = groups[g].type->view.height; ib[1] = groups[g].type->view.width; ib[2] = n_channel(); return; }
+    if (k == "feature_space") { need_group(); ib[0] = feature_size(g); return; }
+    if (k == "attack_base") { need_group(); ib[0] = groups[g].type->attack_base; return; }
+    if (k == "view2attack") {  // GridWorld.cc:853-870
+        need_group();
+        const HostType &t = *groups[g].type;
+        std::fill(ib, ib + t.view.height * t.view.width, -1);
+        for (int i = 0; i < t.attack.count; i++) ib[(t.attack.dy[i] - t.view.y1) * t.view.width + (t.attack.dx[i] - t.view.x1)] = i;
+        return;
+    }
+    if (k == "groups_info") {
+        const int colors[][3] = {{192, 64, 64}, {64, 64, 192}, {64, 192, 64}, {64, 64, 64}};
+        for (size_t i = 0; i < groups.size(); i++) {
+            ib[5 * i] = groups[i].type->width; ib[5 * i + 1] = groups[i].type->length;
+            for (int c = 0; c < 3; c++) ib[5 * i + 2 + c] = colors[i % 4][c];
+        }
+        return;
+    }
+    if (k == "both_attack") { ib[0] = 0; return; }
+    if (k == "mean_info") fatal("mean_info is deprecated in the reference and not provided by this engine");
+    if (!device_ready) fatal("get_info(%s) called before reset", name);
+    use_device();
+    if (k == "id" || k == "pos" || k == "alive") {
+        need_group();
+        int n = groups[g].n;
+        if (n == 0) return;
+        size_t bytes = k == "pos" ? sizeof(int) * 2 * n : k == "alive" ? (size_t)n : sizeof(int) * n;
+        grow(d_stage_small, stage_small_cap, (size_t)n * 8, stream);
+        info_device(g, name, d_stage_small);
+        HIP_OK(hipMemcpyAsync(buf, d_stage_small, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        return;
+    }
+    if (k == "walls_info") {
+        download_occ();
+        int ct = 0;
+        for (size_t c = 0; c < h_occ.size(); c++) if (h_occ[c] == OCC_WALL) { ct++; ib[2 * ct] = (int)(c % width); ib[2 * ct + 1] = (int)(c / width); }
+        ib[0] = ct;
+        return;
+    }
+    if (k == "global_minimap") {  // GridWorld.cc:738-764 (cold path: positions are fetched to the host)
+        int vh = (int)std::lround(fb[0]), vw = (int)std::lround(fb[1]), NG = (int)groups.size();
+        std::memset(fb, 0, sizeof(float) * vh * vw * NG);
+        int sh = (height + vh - 1) / vh, sw = (width + vw - 1) / vw;
+        HIP_OK(hipStreamSynchronize(stream));
+        for (int i = 0; i < NG; i++) {
+            int ch = (i - g + NG) % NG, n = groups[i].n;
+            std::vector<int> xs(n), ys(n);
+            if (n) {
+                HIP_OK(hipMemcpy(xs.data(), groups[i].cur.x, sizeof(int) * n, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(ys.data(), groups[i].cur.y, sizeof(int) * n, hipMemcpyDeviceToHost));
+            }
+            for (int j = 0; j < n; j++) fb[((ys[j] / sh) * vw + xs[j] / sw) * NG + ch]++;
+            for (int c = 0; c < vh * vw; c++) fb[c * NG + ch] /= (size_t)n;
+        }
+        return;
+    }
+    if (k == "render_window_info") {  // GridWorld.cc:797-834; attack events are not recorded by this engine
+        int x1 = ib[0], y1 = ib[1], x2 = ib[2], y2 = ib[3], ct = 1;
+        HIP_OK(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < groups.size(); i++) {
+            int n = groups[i].n;
+            std::vector<int> xs(n), ys(n), ids(n);
+            if (n) {
+                HIP_OK(hipMemcpy(xs.data(), groups[i].cur.x, sizeof(int) * n, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(ys.data(), groups[i].cur.y, sizeof(int) * n, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(ids.data(), groups[i].cur.id, sizeof(int) * n, hipMemcpyDeviceToHost));
+            }
+            for (int j = 0; j < n; j++) {
+                if (xs[j] < x1 || xs[j] > x2 || ys[j] < y1 || ys[j] > y2) continue;
+                ib[4 * ct] = ids[j]; ib[4 * ct + 1] = xs[j]; ib[4 * ct + 2] = ys[j]; ib[4 * ct + 3] = (int)i;
+                ct++;
+            }
+        }
+        ib[0] = ct - 1; ib[1] = 0;
+        return;
+    }
+    if (k == "attack_event") return;
+    fatal("unsupported info name in GridWorld::get_info : %s", name);
+}
+
+void Env::sync() {
+    if (!device_ready) return;
+    use_device();
+    HIP_OK(hipStreamSynchronize(stream));
+}
+
+}  // namespace magent_amd

@@ -1,0 +1,152 @@
+// engine_host.h -- host-side classes of the engine (definitions in engine.hip, C-ABI in runtime_api.hip).
+#pragma once
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "engine.h"
+#include "launch.h"
+
+namespace magent_amd {
+
+[[noreturn]] void fatal(const char *fmt, ...);
+
+// std::default_random_engine of libstdc++ is minstd_rand0 (reference GridWorld.h:105): x <- 16807 x mod (2^31 - 1).
+// seed(s): state = s mod m, 0 -> 1 (so seed(0) == seed(1)); outputs are in [1, 2^31 - 2].
+struct MinStd {
+    unsigned long long x = 1;
+    void seed(unsigned long s) { x = s % 2147483647ul; if (x == 0) x = 1; }
+    unsigned long long operator()() { x = (x * 16807ull) % 2147483647ull; return x; }
+};
+
+struct HostRange {
+    int width = 0, height = 0, count = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    std::vector<unsigned char> in;
+    std::vector<int> dx, dy;
+    void circle(float radius, float inner_radius, int parity);
+};
+
+struct HostType {
+    std::string name;
+    int width = 1, length = 1;
+    float speed = 1.0f, hp = 1.0f, view_radius = 1, view_angle = 360, attack_radius = 0, attack_angle = 0;
+    float damage = 0, step_recover = 0, kill_supply = 0;
+    float step_reward = 0, kill_reward = 0, dead_penalty = 0, attack_penalty = 0;
+    bool attack_in_group = false, can_absorb = false;
+    int view_x_offset = 0, view_y_offset = 0, att_x_offset = 0, att_y_offset = 0;
+    HostRange view, attack, move;
+    int attack_base = 0, n_action = 0;
+};
+
+struct HostGroup {
+    HostType *type = nullptr;
+    int n = 0, cap = 0;
+    GroupDev cur{}, alt{};       // alt holds the second copy of the arrays that clear_dead compacts
+    TypeDev tdev{};
+    float group_reward = 0;
+    bool acted = false;          // set_action seen since the last step
+    int h_dead = 0;              // dead_ct as of the last step (GridWorld.h Group::dead_ct)
+};
+
+struct HostSymbol { int group = 0, index = 0; };
+struct HostNode { int op = OP_NULL; std::vector<int> raw; };
+struct HostRule { int on = 0; std::vector<int> recv; std::vector<float> val; bool terminal = false; };
+
+class Env {
+public:
+    Env();
+    ~Env();
+
+    // reference interface (GridWorld.h:38-128)
+    void set_config(const char *key, void *p);
+    void register_agent_type(const char *name, int n, const char **keys, float *values);
+    void new_group(const char *type_name, int *handle);
+    void define_agent_symbol(int no, int group, int index);
+    void define_event_node(int no, int op, int *inputs, int n);
+    void add_reward_rule(int on, int *recv, float *val, int n, bool terminal);
+    void reset();
+    void add_agents(int group, int n, const char *method, const int *px, const int *py, const int *pdir);
+    void observe_host(int g, float *view, float *feat);
+    void set_action_host(int g, const int *actions);
+    void step(int *done);
+    void get_reward_host(int g, float *out);
+    void clear_dead();
+    void info_host(int g, const char *name, void *buf);
+
+    // device-resident extensions
+    void observe_device(int g, float *view, float *feat);
+    void set_action_device(int g, const int *d_act);
+    void get_reward_device(int g, float *out);
+    void info_device(int g, const char *name, void *out);
+    void sync();
+    void profile_read(const char *name, int *n, float *ms);
+
+    hipStream_t stream{};
+    bool prof_on = false;
+    bool nt_stores = true;
+    int last_attack_iters = 0, last_move_iters = 0;
+
+private:
+    struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+    struct ProfScope;
+    std::map<std::string, ProfSlot> prof;
+    std::vector<hipEvent_t> prof_pool;
+    hipEvent_t prof_event();
+
+    void use_device();
+    void init_device();
+    void free_group(HostGroup &g);
+    void ensure_capacity(HostGroup &g, int need);
+    void ensure_tables();
+    WorldView view() const;
+    WorldView view_for_plan() const;
+    int *read_counters();
+    bool read_changed();
+    void clear_changed();
+    void compile_rules();
+    void download_occ();
+    void upload_occ();
+    bool host_blank(int x, int y) const;
+    void host_random_blank(int &ox, int &oy);
+    void plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *feat);
+    int n_channel() const;
+    int feature_size(int g) const;
+
+    // configuration
+    int width = 0, height = 0, embedding_size = 0, device_id = 0;
+    bool minimap_mode = false, large_map_mode = false;
+    int bandwidth = 1;
+    std::string render_dir;
+    MinStd rng;
+    std::map<std::string, HostType> types;
+    std::vector<HostGroup> groups;
+    std::vector<HostSymbol> symbols;
+    std::vector<HostNode> nodes;
+    std::vector<HostRule> rules;
+    std::vector<RuleArgs> rule_args;
+    bool rules_compiled = false;
+    int id_counter = 0, any_kill_supply = 0, move_seq_base = 0;
+
+    // device state
+    bool device_ready = false, tables_valid = false, paint_valid = false;
+    size_t map_cells = 0;
+    int *d_occ = nullptr;
+    int2 *d_viewcell = nullptr;
+    unsigned long long *d_claim = nullptr;
+    int *d_counters = nullptr, *h_counters = nullptr;
+    GroupDev *d_gtab = nullptr;
+    TypeDev *d_ttab = nullptr;
+    int2 *d_delta = nullptr;
+    unsigned char *d_mask = nullptr;
+    int *d_mini = nullptr; size_t mini_cap = 0;
+    int *d_sums = nullptr; size_t sums_cap = 0;
+    int *d_rank = nullptr, *h_rank = nullptr; size_t rank_cap = 0;
+    int *d_actions = nullptr; size_t actions_cap = 0;
+    float *d_stage_view = nullptr, *d_stage_feat = nullptr; size_t stage_view_cap = 0, stage_feat_cap = 0;
+    unsigned char *d_stage_small = nullptr; size_t stage_small_cap = 0;
+    std::vector<int> h_occ; bool h_occ_valid = false;
+    std::vector<int> shuffle_perm;
+};
+
+}  // namespace magent_amd

@@ -1,0 +1,61 @@
+// launch.h -- host-visible launch wrappers of kernels.hip and the small plan structs they take.
+#pragma once
+#include "engine.h"
+
+namespace magent_amd {
+
+// n / d for a divisor fixed at launch time: q = (t + ((n - t) >> 1)) >> shift with t = umulhi(n, mul)
+// (round-up method; exact for every 32-bit n).  d == 1 is flagged.
+struct FastDiv {
+    unsigned mul, shift, one;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f{0, 0, 0};
+    if (d <= 1) { f.one = 1; return f; }
+    unsigned s = 0;
+    while ((1ull << s) < d) s++;                         // s = ceil(log2 d), 1..32
+    unsigned long long m = ((1ull << 32) * ((1ull << s) - d)) / d + 1;
+    f.mul = (unsigned)m;
+    f.shift = s - 1;
+    return f;
+}
+
+// how the render kernel tiles one get_observation call
+struct RenderPlan {
+    int AG;          // agents per workgroup (multiple of 4 so every tile starts 16-byte aligned)
+    int xcd_chunk;   // tiles / 8 when the XCD-aware tile mapping is on, else 0
+    FastDiv div_vhw, div_vw, div_s, div_c, div_f;
+};
+
+// one reward rule Event(a, op, b), a/b = 'any'
+struct RuleArgs {
+    int ga, gb, op, rule_no;
+    int n_subj, n_obj;            // receivers that are the subject / the object of the event
+    float v_subj[4], v_obj[4];
+};
+
+void launch_set_tables(hipStream_t s, const WorldView &W, GroupDev *gtab, TypeDev *ttab);
+void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab);
+void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts);
+size_t render_lds_bytes(const WorldView &W, const RenderArgs &R, int AG);
+void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt);
+void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
+void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank);
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b);
+void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b);
+void launch_starve(hipStream_t s, const WorldView &W);
+void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);
+void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab);
+void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
+void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A);
+void launch_finish(hipStream_t s, const WorldView &W);
+void launch_get_reward(hipStream_t s, const GroupDev &G, float group_reward, float *out);
+void launch_get_pos(hipStream_t s, const GroupDev &G, int *out);
+void launch_get_alive(hipStream_t s, const GroupDev &G, unsigned char *out);
+void launch_init_reward(hipStream_t s, const WorldView &W, int g);
+void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D, int new_n, int *sums);
+
+constexpr int SCAN_TILE_HOST = 256 * 8;  // must equal SCAN_TILE in kernels.hip
+constexpr int ATTACK_KMAX_HOST = 32;     // must equal ATT_KMAX in kernels.hip
+
+}  // namespace magent_amd

@@ -1,0 +1,64 @@
+// runtime_api.hip -- the C-ABI of libmagent.so (include/magent_runtime_api.h): thin trampolines onto Env.
+// Replaces reference src/runtime_api.cc:15-163 symbol for symbol; PART 2 adds the device-resident calls.
+#include <cstring>
+
+#include "../../include/magent_runtime_api.h"
+#include "engine_host.h"
+
+using magent_amd::Env;
+using magent_amd::fatal;
+
+static inline Env *E(EnvHandle h) {
+    if (!h) fatal("null environment handle");
+    return (Env *)h;
+}
+
+extern "C" {
+
+int env_new_game(EnvHandle *game, const char *name) {
+    if (std::strcmp(name, "GridWorld") != 0)   // reference throws std::invalid_argument (runtime_api.cc:23)
+        fatal("invalid name of game '%s': this engine provides GridWorld only (DiscreteSnake is a different game)", name);
+    *game = new Env();
+    return 0;
+}
+int env_delete_game(EnvHandle game) { delete E(game); return 0; }
+int env_config_game(EnvHandle game, const char *name, void *p_value) { E(game)->set_config(name, p_value); return 0; }
+int env_reset(EnvHandle game) { E(game)->reset(); return 0; }
+int env_get_observation(EnvHandle game, GroupHandle group, float **buffer) { E(game)->observe_host(group, buffer[0], buffer[1]); return 0; }
+int env_set_action(EnvHandle game, GroupHandle group, const int *actions) { E(game)->set_action_host(group, actions); return 0; }
+int env_step(EnvHandle game, int *done) { E(game)->step(done); return 0; }
+int env_get_reward(EnvHandle game, GroupHandle group, float *buffer) { E(game)->get_reward_host(group, buffer); return 0; }
+int env_get_info(EnvHandle game, GroupHandle group, const char *name, void *buffer) { E(game)->info_host(group, name, buffer); return 0; }
+int env_render(EnvHandle) { return 0; }            // text video dump: host-side, off the hot path
+int env_render_next_file(EnvHandle) { return 0; }
+
+int gridworld_register_agent_type(EnvHandle game, const char *name, int n, const char **keys, float *values) {
+    E(game)->register_agent_type(name, n, keys, values); return 0;
+}
+int gridworld_new_group(EnvHandle game, const char *agent_type_name, GroupHandle *group) { E(game)->new_group(agent_type_name, group); return 0; }
+int gridworld_add_agents(EnvHandle game, GroupHandle group, int n, const char *method, const int *pos_x, const int *pos_y, const int *dir) {
+    E(game)->add_agents(group, n, method, pos_x, pos_y, dir); return 0;
+}
+int gridworld_clear_dead(EnvHandle game) { E(game)->clear_dead(); return 0; }
+int gridworld_set_goal(EnvHandle, GroupHandle, const char *, const int *) { return 0; }  // deprecated in the reference; goals are never observed without goal_mode
+int gridworld_define_agent_symbol(EnvHandle game, int no, int group, int index) { E(game)->define_agent_symbol(no, group, index); return 0; }
+int gridworld_define_event_node(EnvHandle game, int no, int op, int *inputs, int n_inputs) { E(game)->define_event_node(no, op, inputs, n_inputs); return 0; }
+int gridworld_add_reward_rule(EnvHandle game, int on, int *receiver, float *value, int n_receiver, bool is_terminal, bool /*auto_value*/) {
+    E(game)->add_reward_rule(on, receiver, value, n_receiver, is_terminal); return 0;
+}
+int discrete_snake_clear_dead(EnvHandle) { fatal("DiscreteSnake is a different game; not provided by this engine"); }
+int discrete_snake_add_object(EnvHandle, int, int, const char *, const int *) { fatal("DiscreteSnake is a different game; not provided by this engine"); }
+
+// ---- PART 2: device-resident extensions
+int env_get_observation_device(EnvHandle game, GroupHandle group, float **device_buffer) {
+    E(game)->observe_device(group, device_buffer[0], device_buffer[1]); return 0;
+}
+int env_set_action_device(EnvHandle game, GroupHandle group, const int *device_actions) { E(game)->set_action_device(group, device_actions); return 0; }
+int env_get_reward_device(EnvHandle game, GroupHandle group, float *device_buffer) { E(game)->get_reward_device(group, device_buffer); return 0; }
+int env_get_info_device(EnvHandle game, GroupHandle group, const char *name, void *device_buffer) { E(game)->info_device(group, name, device_buffer); return 0; }
+int env_sync(EnvHandle game) { E(game)->sync(); return 0; }
+int env_get_stream(EnvHandle game, void **stream) { *stream = (void *)E(game)->stream; return 0; }
+int env_profile_enable(EnvHandle game, int on) { E(game)->prof_on = on != 0; return 0; }
+int env_profile_read(EnvHandle game, const char *name, int *n_launches, float *total_ms) { E(game)->profile_read(name, n_launches, total_ms); return 0; }
+
+}  // extern "C"

@@ -1,0 +1,38 @@
+"""GPU parity tests: the HIP engine (through the C-ABI) against the CPU oracle, bit for bit.
+
+Every observable output of every step is compared: view and feature tensors, ids, rewards, alive masks, positions,
+group sizes, the done flag.  Floats are compared as raw 32-bit patterns (tolerance: none -- the path is integer /
+index work plus float adds, subtracts and divisions replayed in the reference's order).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+SCENARIOS = H.scenarios()
+with open(os.path.join(H.GOLDEN_DIR, "digests.json")) as f:
+    DIGESTS = json.load(f)
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return H.ensure_oracle()
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_hip_matches_oracle_and_golden(name, oracle):
+    got = H.run(SCENARIOS[name], H.HIP_LIB)
+    want = H.run(SCENARIOS[name], oracle)
+    H.assert_same(want, got, name)
+    assert H.digest(got) == DIGESTS[name]["sha256"]     # the committed vectors from the compiled reference
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) did not travel")
+@pytest.mark.parametrize("name", ["battle_brawl", "battle_largemap", "gather"])
+def test_hip_matches_compiled_reference(name):
+    H.assert_same(H.run(SCENARIOS[name], H.REF_LIB), H.run(SCENARIOS[name], H.HIP_LIB), name)
