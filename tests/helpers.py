@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 import magent_amd
-from magent_amd import gridworld as gw
+from magent_amd import gridworld as gw  # noqa: F401
+from magent_amd.builtin.config import _games
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -35,7 +36,7 @@ def have_ref():
 # ---------------------------------------------------------------------------------------------- scenarios
 def config_for(game, map_size, **over):
     """built-in game, optionally with agent-type overrides {type_name: {attr: value}} for edge-case scenarios"""
-    cfg = magent_amd.builtin.config._games.make(game, map_size)
+    cfg = _games.make(game, map_size)
     for tname, attrs in over.items():
         cfg.agent_type_dict[tname].update(attrs)
     return cfg
@@ -67,7 +68,6 @@ def run(sc, lib, record=None):
 
     Order of calls per step follows examples/train_battle.py:61-109: get_observation + set_action per group,
     step, get_reward / get_alive / get_pos / get_num per group, clear_dead."""
-    import magent_amd.builtin.config._games  # noqa: F401
     env, handles = sc.build(lib)
     rs = np.random.RandomState(sc.action_seed)
     acting = sc.acting if sc.acting is not None else list(range(len(handles)))

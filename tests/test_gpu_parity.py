@@ -36,3 +36,24 @@ def test_hip_matches_oracle_and_golden(name, oracle):
 @pytest.mark.parametrize("name", ["battle_brawl", "battle_largemap", "gather"])
 def test_hip_matches_compiled_reference(name):
     H.assert_same(H.run(SCENARIOS[name], H.REF_LIB), H.run(SCENARIOS[name], H.HIP_LIB), name)
+
+
+def test_full_size_battle_two_steps(oracle):
+    """BASELINE.json's headline size (battle 1000x1000, 2x400k agents, the workload bench.py times): two full steps,
+    every output compared with the oracle bit for bit (3.9 GB of observations per step)."""
+    import hashlib
+    sc = H.Scenario("battle_c3", "battle", 1000, place=[(0, "random", {"n": 400000}), (1, "random", {"n": 400000})], steps=2)
+    state = {}
+
+    def keep(step, rec):  # hash step by step so that only one step of one engine is held in memory
+        state.setdefault("steps", []).append({k: hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() for k, v in rec.items()})
+        rec.clear()
+
+    H.run(sc, H.HIP_LIB, record=keep)
+    got, state = state["steps"], {}
+    H.run(sc, oracle, record=keep)
+    want = state["steps"]
+    assert len(got) == len(want) == 2
+    for s in range(2):
+        for k in sorted(want[s]):
+            assert got[s][k] == want[s][k], "step %d %s differs" % (s, k)
