@@ -144,7 +144,8 @@ def main():
     G = len(handles)
     vs, fs = env.get_view_space(handles[0]), env.get_feature_space(handles[0])
     n_action = env.get_action_space(handles[0])[0]
-    bytes_per_agent = 4 * (vs[0] * vs[1] * vs[2] + fs[0])
+    view_bytes_per_agent = 4 * vs[0] * vs[1] * vs[2]   # what k_render writes (the dominant kernel)
+    feat_bytes_per_agent = 4 * fs[0]                   # what k_features writes
 
     # caller-owned device buffers (the reference's ownership convention), sized once for the initial population
     views = [torch.empty((n0[g],) + vs, dtype=torch.float32, device=dev) for g in range(G)]
@@ -181,7 +182,7 @@ def main():
     env.sync()
     if not args.no_profile:
         env.profile_enable(True)
-        for name in ("render", "paint", "minimap", "attack", "move", "set_action", "starve", "rules", "clear_dead"):
+        for name in ("render", "features", "paint", "minimap", "attack", "move", "set_action", "starve", "rules", "clear_dead"):
             env.profile_read(name)
     rendered_agents = 0
     torch.cuda.synchronize()
@@ -212,9 +213,11 @@ def main():
     roofline, breakdown = None, {}
     if not args.no_profile:
         n_launch, ms = env.profile_read("render")
+        n_feat, ms_feat = env.profile_read("features")
         if n_launch and ms > 0:
-            per_launch_bytes = rendered_agents * bytes_per_agent / n_launch
-            achieved = (rendered_agents * bytes_per_agent) / (ms * 1e-3) / 1e9
+            # algorithmic bytes of the dominant kernel: every element of the view tensor written exactly once
+            # (4*VH*VW*C per agent; the 4*F feature bytes belong to k_features, timed separately)
+            achieved = rendered_agents * view_bytes_per_agent / (ms * 1e-3) / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "render_pmc.json")
             if os.path.exists(pmc):
@@ -225,13 +228,16 @@ def main():
             roofline = {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
-                        "algorithmic_bytes_per_launch": int(per_launch_bytes)}
+                        "algorithmic_bytes_per_launch": int(rendered_agents * view_bytes_per_agent / n_launch),
+                        "obs_total_GBs": round(rendered_agents * (view_bytes_per_agent + feat_bytes_per_agent)
+                                               / ((ms + ms_feat) * 1e-3) / 1e9, 1)}
         for name in ("paint", "minimap", "attack", "move", "set_action", "starve", "rules", "clear_dead"):
             k, t_ms = env.profile_read(name)
             if k:
                 breakdown[name + "_ms_per_step"] = round(t_ms / args.steps, 4)
         if roofline:
             breakdown["render_ms_per_step"] = round(ms / args.steps, 4)
+            breakdown["features_ms_per_step"] = round(ms_feat / args.steps, 4)
         env.profile_enable(False)
 
     if rank == 0:

@@ -86,7 +86,7 @@ struct RenderArgs {
     int scale_w, scale_h;
     int chan_desc[32];           // per output channel: (kind << 8) | (code & 0xff); kind 0 = has, 1 = hp, 2 = minimap
     int totals[MAXG];            // group sizes (minimap divisor)
-    const int *mini_counts;      // int[G][VH*VW] histogram
+    const float *mini;           // float[G][VH*VW]: count / total per group (k_minimap_norm)
     float *view, *feat;
 };
 

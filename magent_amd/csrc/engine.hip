@@ -104,6 +104,11 @@ Env::Env() {
     if (!d) d = std::getenv("LOCAL_RANK");
     device_id = d ? std::atoi(d) : 0;
     rng.seed(0);  // GridWorld.cc:29
+    // tuning knobs for experiments (defaults are the measured best)
+    if (const char *v = std::getenv("MAGENT_RENDER_SPAN")) render_steps_per_span = std::atoi(v);
+    if (const char *v = std::getenv("MAGENT_RENDER_UNROLL")) render_unroll = std::atoi(v);
+    if (const char *v = std::getenv("MAGENT_HOST_SHUFFLE")) host_shuffle = std::atoi(v) != 0;
+    if (const char *v = std::getenv("MAGENT_RENDER_NT")) nt_stores = std::atoi(v) != 0;
 }
 
 template <class T>
@@ -117,7 +122,7 @@ Env::~Env() {
     (void)hipStreamSynchronize(stream);
     for (auto &g : groups) free_group(g);
     dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_counters); dfree(d_gtab); dfree(d_ttab);
-    dfree(d_delta); dfree(d_mask); dfree(d_mini); dfree(d_sums); dfree(d_rank); dfree(d_actions);
+    dfree(d_delta); dfree(d_mask); dfree(d_mini); dfree(d_minif); dfree(d_sums); dfree(d_rank); dfree(d_shuf); dfree(d_actions);
     dfree(d_stage_view); dfree(d_stage_feat); dfree(d_stage_small);
     if (h_counters) (void)hipHostFree(h_counters);
     if (h_rank) (void)hipHostFree(h_rank);
@@ -526,18 +531,20 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
         if (minimap_mode) R.chan_desc[base + 2] = (2 << 8) | j;
     }
     for (int j = 0; j < NG; j++) R.totals[j] = groups[j].n;
-    R.mini_counts = d_mini;
+    R.mini = d_minif;
     R.view = view; R.feat = feat;
 
-    int AG = 16;
-    WorldView W = view_for_plan();
-    while (AG > 4 && render_lds_bytes(W, R, AG) > 48 * 1024) AG -= 4;
-    if (render_lds_bytes(W, R, AG) > 150 * 1024) fatal("view window too large for the LDS-tiled renderer");
-    P.AG = AG;
-    int tiles = (R.n + AG - 1) / AG;
-    P.xcd_chunk = tiles >= 64 ? tiles / 8 : 0;
-    P.div_vhw = make_fastdiv(R.VH * R.VW); P.div_vw = make_fastdiv(R.VW); P.div_s = make_fastdiv(R.S);
-    P.div_c = make_fastdiv(R.C); P.div_f = make_fastdiv(R.F);
+    // flat decomposition of the n * VH * VW window cells into 64-cell wave steps, `steps_per_span` per workgroup
+    if ((long long)R.n * R.VH * R.VW >= (1ll << 31)) fatal("observation too large for 32-bit cell indexing");
+    const long long steps = ((long long)R.n * R.VH * R.VW + 63) / 64;
+    int per = render_steps_per_span > 0 ? render_steps_per_span : 32;
+    P.steps_per_span = per;
+    P.spans = (int)((steps + per - 1) / per);
+    P.xcd_chunk = P.spans >= 64 ? P.spans / 8 : 0;
+    P.strip_floats = 64 * R.C;
+    P.unroll = render_unroll;
+    P.div_vhw = make_fastdiv(R.VH * R.VW); P.div_vw = make_fastdiv(R.VW); P.div_f = make_fastdiv(R.F);
+    P.div_scale_w = make_fastdiv(R.scale_w); P.div_scale_h = make_fastdiv(R.scale_h);
 }
 
 WorldView Env::view_for_plan() const { WorldView W{}; W.G = (int)groups.size(); return W; }
@@ -560,14 +567,19 @@ void Env::observe_device(int g, float *view, float *feat) {
     if (minimap_mode) {
         size_t need = (size_t)W.G * R.VH * R.VW;
         grow(d_mini, mini_cap, need, stream);
-        R.mini_counts = d_mini;
+        grow(d_minif, minif_cap, need, stream);
+        R.mini = d_minif;
         ProfScope p(*this, "minimap");
-        launch_minimap(stream, W, R, d_mini);
+        launch_minimap(stream, W, R, d_mini, d_minif);
     }
     const bool aligned = (((uintptr_t)view) & 15) == 0;
     {
         ProfScope p(*this, "render");
         launch_render(stream, W, R, P, aligned, aligned && nt_stores);
+    }
+    {
+        ProfScope p(*this, "features");
+        launch_features(stream, W, R, P, (((uintptr_t)feat) & 15) == 0);
     }
 }
 
@@ -629,22 +641,30 @@ void Env::step(int *done) {
     const int A = read_counters()[CTR_ATTACK];
     if (A > 0) {
         ProfScope p(*this, "attack");
-        if ((size_t)A > rank_cap) {
-            if (h_rank) HIP_OK(hipHostFree(h_rank));
-            size_t ncap = std::max<size_t>((size_t)A, rank_cap * 2);
-            HIP_OK(hipHostMalloc((void **)&h_rank, sizeof(int) * ncap, hipHostMallocDefault));
-            dfree(d_rank);
-            HIP_OK(hipMalloc(&d_rank, sizeof(int) * ncap));
-            rank_cap = ncap;
+        if (host_shuffle) {   // the reference's literal loop on the host (kept for A/B checks: MAGENT_HOST_SHUFFLE=1)
+            if ((size_t)A > hrank_cap) {
+                if (h_rank) HIP_OK(hipHostFree(h_rank));
+                hrank_cap = std::max<size_t>((size_t)A, hrank_cap * 2);
+                HIP_OK(hipHostMalloc((void **)&h_rank, sizeof(int) * hrank_cap, hipHostMallocDefault));
+            }
+            grow(d_rank, rank_cap, (size_t)A, stream);
+            shuffle_perm.resize(A);
+            for (int i = 0; i < A; i++) shuffle_perm[i] = i;
+            for (int i = 0; i < A; i++) {
+                int j = (int)rng() % (i + 1);
+                std::swap(shuffle_perm[i], shuffle_perm[j]);
+            }
+            for (int pos = 0; pos < A; pos++) h_rank[shuffle_perm[pos]] = pos;
+            HIP_OK(hipMemcpyAsync(d_rank, h_rank, sizeof(int) * A, hipMemcpyHostToDevice, stream));
+        } else {              // exact parallel replay on the device; the host only advances the engine state by A draws
+            grow(d_rank, rank_cap, (size_t)A, stream);
+            grow(d_shuf, shuf_cap, (size_t)A * 5, stream);
+            int nb = (A + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
+            grow(d_sums, sums_cap, (size_t)nb, stream);
+            int *sj = d_shuf, *scount = d_shuf + A, *soff = d_shuf + 2 * (size_t)A, *scur = d_shuf + 3 * (size_t)A, *slist = d_shuf + 4 * (size_t)A;
+            launch_shuffle(stream, A, (unsigned)rng.x, sj, scount, soff, scur, slist, d_sums, d_rank);
+            rng.skip((unsigned)A);
         }
-        shuffle_perm.resize(A);
-        for (int i = 0; i < A; i++) shuffle_perm[i] = i;
-        for (int i = 0; i < A; i++) {
-            int j = (int)rng() % (i + 1);
-            std::swap(shuffle_perm[i], shuffle_perm[j]);
-        }
-        for (int pos = 0; pos < A; pos++) h_rank[shuffle_perm[pos]] = pos;
-        HIP_OK(hipMemcpyAsync(d_rank, h_rank, sizeof(int) * A, hipMemcpyHostToDevice, stream));
         launch_attack_rank(stream, W, d_rank);
         int use_b = 0, iters = 0;
         while (true) {

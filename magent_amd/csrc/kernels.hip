@@ -14,6 +14,7 @@
 //   k_compact_* / k_init_reward      GridWorld::clear_dead GridWorld.cc:633-665, Agent::init_reward GridWorld.h:168-174
 #include "engine.h"
 #include "launch.h"
+#include <algorithm>
 
 namespace magent_amd {
 
@@ -80,132 +81,171 @@ __global__ void __launch_bounds__(256) k_minimap(WorldView W, RenderArgs R, int 
         if (s_hist[k]) atomicAdd(&counts[j * VHW + k], s_hist[k]);
 }
 
-// ------------------------------------------------------------------------------------------------ observation render
-// One workgroup renders AG consecutive agents of the observing group.
-//   phase 0: agent positions + the G minimaps (count / total, float) into LDS
-//   phase 1: each agent's VH x VW window of `viewcell` into LDS (masked by the view range and the map bounds)
-//   phase 2: the AG * S output floats as a contiguous float4 stream, every element written exactly once
-//            (zeros included: the reference's memset GridWorld.cc:310 is fused into the stores)
-//   phase 3: the AG * F feature floats
-// The output is the algorithmic traffic (4 * (S + F) bytes per agent); map reads come from L2 / LDS.
-// blockIdx -> agent tile mapping is XCD-aware: the 8 XCDs each walk a contiguous eighth of the agent range, so
-// spatially ordered groups keep each XCD's map window resident in its own L2.
-template <bool VEC4, bool NT>
-__global__ void __launch_bounds__(256) k_render(WorldView W, RenderArgs R, RenderPlan P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int VHW = R.VH * R.VW, AG = P.AG, G = W.G;
-    int2 *s_cell = (int2 *)smem;                     // [AG][VHW]
-    float *s_mini = (float *)(s_cell + AG * VHW);    // [G][VHW]
-    int *s_ax = (int *)(s_mini + G * VHW);           // [AG]
-    int *s_ay = s_ax + AG;                           // [AG]
-    int *s_self = s_ay + AG;                         // [AG]  minimap cell of the agent itself
-    int *s_desc = s_self + AG;                       // [C]
+// ------------------------------------------------------------------------------------------------ minimap normalise
+// mini[j][cell] = float(count) / float(total_j) exactly as the reference (GridWorld.cc:350,356): float ++ saturates
+// at 2^24; an empty group divides 0 by 0 and the x86 default NaN the reference then holds is 0xFFC00000.
+__global__ void __launch_bounds__(256) k_minimap_norm(RenderArgs R, int G, const int *counts, float *mini) {
+    const int VHW = R.VH * R.VW;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= G * VHW) return;
+    int tot = R.totals[k / VHW];
+    mini[k] = tot == 0 ? __int_as_float(0xFFC00000) : __fdiv_rn((float)min(counts[k], 1 << 24), (float)(unsigned)tot);
+}
 
-    // XCD-aware tile index: hardware places block b on XCD b % 8 (speed only, never correctness)
-    int tile = blockIdx.x;
-    if (P.xcd_chunk > 0 && tile < P.xcd_chunk * 8) tile = (tile & 7) * P.xcd_chunk + (tile >> 3);
-    const int a0 = tile * AG;
-    const int nA = min(AG, R.n - a0);
-    if (nA <= 0) return;
+// ------------------------------------------------------------------------------------------------ observation render
+// The view tensor of a group is one contiguous array of n * VH * VW cells x C floats.  The kernel walks it as a flat
+// sequence of window cells, 64 cells (one per lane) per wave step:
+//   load   : the lane's cell of `viewcell` (ONE 8-byte load, masked by the view range and the map bounds) and the
+//            G minimap floats of its window position; agent x / y are wave-broadcast loads (a wave spans <= 2 agents)
+//   expand : a wave-uniform loop over the C channels (descriptor = scalar load) turns the cell into its C floats --
+//            no lane diverges on the channel kind -- written to a wave-private LDS strip of 64 * C floats
+//   store  : the strip is read back as float4 and streamed out: 256 * C bytes per step, contiguous, starting on a
+//            128-byte line (256 * C is a multiple of 128), 1 KiB per global_store_dwordx4 wave instruction.
+// No workgroup barrier, 1.75 KiB of LDS per wave: occupancy is bounded by the 32 waves / CU limit, not by LDS.
+// Every output element is written exactly once, zeros included (the reference's memset, GridWorld.cc:310, is fused
+// into the stores): the output is the algorithmic traffic, 4 * VH * VW * C bytes per agent.
+// Workgroups own contiguous spans of the cell sequence, and the span index is XCD-aware (blockIdx b runs on XCD
+// b % 8): each XCD walks one contiguous eighth of the agents, so spatially ordered groups keep its part of the map
+// in its own L2.
+constexpr int RENDER_WAVES = 4;
+
+template <bool VEC4, bool NT, int U>
+__global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, RenderArgs R, RenderPlan P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int VHW = R.VH * R.VW, C = R.C, G = W.G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *strip = (float *)smem + (size_t)wave * P.strip_floats;      // [64][C], wave-private
+
+    int span = blockIdx.x;
+    if (P.xcd_chunk > 0 && span < P.xcd_chunk * 8) span = (span & 7) * P.xcd_chunk + (span >> 3);
     const GroupDev Gd = W.grp[R.g];
     const TypeDev T = W.type[R.g];
-    const int tid = threadIdx.x;
-
-    // ---- phase 0
-    if (tid < AG) {
-        int x = 0, y = 0;
-        if (tid < nA) { x = Gd.x[a0 + tid]; y = Gd.y[a0 + tid]; }
-        s_ax[tid] = x; s_ay[tid] = y;
-        s_self[tid] = R.minimap ? (y / R.scale_h) * R.VW + (x / R.scale_w) : -1;
-    }
-    if (tid < R.C) s_desc[tid] = R.chan_desc[tid];
-    if (R.minimap) {
-        for (int k = tid; k < G * VHW; k += 256) {
-            int j = fdiv_u32(k, P.div_vhw);
-            int cnt = R.mini_counts[k], tot = R.totals[j];
-            // float(count) / float(total) as the reference (GridWorld.cc:350,356); float ++ saturates at 2^24;
-            // an empty group divides 0 by 0: the x86 default NaN the reference produces is 0xFFC00000
-            float v = tot == 0 ? __int_as_float(0xFFC00000) : __fdiv_rn((float)min(cnt, 1 << 24), (float)(unsigned)tot);
-            s_mini[k] = v;
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 1: windows -> LDS
     const unsigned char *mask = W.mask + T.mask_off;
-    for (int k = tid; k < nA * VHW; k += 256) {
-        int a = fdiv_u32(k, P.div_vhw);
-        int cell = k - a * VHW;
-        int vy = fdiv_u32(cell, P.div_vw);
-        int vx = cell - vy * R.VW;
-        int mx = s_ax[a] + T.view_x1 + vx, my = s_ay[a] + T.view_y1 + vy;
-        int2 rec = make_int2(OCC_EMPTY, 0);
-        if (mask[cell] && mx >= 0 && mx < W.w && my >= 0 && my < W.h) rec = W.viewcell[my * W.w + mx];
-        s_cell[k] = rec;
-    }
-    __syncthreads();
+    const unsigned total_cells = (unsigned)R.n * (unsigned)VHW;
+    const size_t total_floats = (size_t)total_cells * C;
+    const int q_per_step = 16 * C;                                     // float4 per 64-cell step
 
-    // ---- phase 2: stream the view tensor
-    const int total = nA * R.S;
-    float *out = R.view + (size_t)a0 * R.S;
-    auto value_at = [&](int a, int cell, int c) -> float {
-        int desc = s_desc[c];
-        int kind = desc >> 8, code = desc & 0xff;
-        if (kind == 2) {                               // minimap channel of group `code`: unmasked copy + self marker
-            float m = s_mini[code * VHW + cell];
-            if (cell == s_self[a] && m == m) m += 1.0f;  // NaN stays the same NaN (x86 propagates the operand)
-            return m;
-        }
-        int2 rec = s_cell[a * VHW + cell];
-        bool hit = (rec.x & 0xff) == code;
-        return hit ? (kind == 0 ? 1.0f : __int_as_float(rec.y)) : 0.0f;
-    };
-    if (VEC4) {
-        const int nq = total >> 2;
-        for (int q = tid; q < nq; q += 256) {
-            unsigned e = (unsigned)q << 2;
-            int a = fdiv_u32(e, P.div_s);
-            int rem = e - a * R.S;
-            int cell = fdiv_u32(rem, P.div_c);
-            int c = rem - cell * R.C;
-            float v[4];
+    // U consecutive steps per wave iteration: all their loads are issued before the first expansion, so a wave
+    // keeps U independent (x/y -> viewcell) load chains in flight
+    for (int it = wave * U; it < P.steps_per_span; it += RENDER_WAVES * U) {
+        const unsigned step0 = (unsigned)span * P.steps_per_span + it;
+        if (step0 * 64u >= total_cells) break;
+        int cellv[U], xv[U], yv[U];
+        bool valid[U];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                v[k] = value_at(a, cell, c);
-                if (++c == R.C) { c = 0; if (++cell == VHW) { cell = 0; ++a; } }
+        for (int u = 0; u < U; u++) {
+            const unsigned k = (step0 + u) * 64u + lane;
+            valid[u] = k < total_cells;
+            const int a = valid[u] ? (int)fdiv_u32(k, P.div_vhw) : 0;
+            cellv[u] = valid[u] ? (int)(k - a * VHW) : 0;
+            xv[u] = Gd.x[a]; yv[u] = Gd.y[a];
+        }
+        int2 recv[U];
+        float miniv[U][MAXG];   // minimap value of this window position for channel block b (group (g + b) % G)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int vy = fdiv_u32(cellv[u], P.div_vw);
+            const int vx = cellv[u] - vy * R.VW;
+            const int mx = xv[u] + T.view_x1 + vx, my = yv[u] + T.view_y1 + vy;
+            const bool in = valid[u] && mask[cellv[u]] && mx >= 0 && mx < W.w && my >= 0 && my < W.h;
+            recv[u] = in ? W.viewcell[my * W.w + mx] : make_int2(OCC_EMPTY, 0);
+            if (R.minimap) {
+                int j = R.g;
+#pragma unroll
+                for (int b = 0; b < MAXG; b++)
+                    if (b < G) { miniv[u][b] = R.mini[j * VHW + cellv[u]]; j = (j + 1 == G) ? 0 : j + 1; }
             }
-            v4f f4 = {v[0], v[1], v[2], v[3]};
-            if (NT) __builtin_nontemporal_store(f4, (v4f *)out + q);
-            else ((v4f *)out)[q] = f4;
         }
-        for (int e = (nq << 2) + tid; e < total; e += 256) {   // < 4 trailing floats of the last tile
-            int a = fdiv_u32(e, P.div_s);
-            int rem = e - a * R.S;
-            int cell = fdiv_u32(rem, P.div_c);
-            out[e] = value_at(a, cell, rem - cell * R.C);
-        }
-    } else {
-        for (int e = tid; e < total; e += 256) {
-            int a = fdiv_u32(e, P.div_s);
-            int rem = e - a * R.S;
-            int cell = fdiv_u32(rem, P.div_c);
-            out[e] = value_at(a, cell, rem - cell * R.C);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned k0 = (step0 + u) * 64u;
+            if (k0 >= total_cells) break;
+            const int cell = cellv[u];
+            const int code = recv[u].x & 0xff;
+            const float hp = __int_as_float(recv[u].y);
+            bool self = false;
+            if (R.minimap) self = cell == (int)(fdiv_u32(yv[u], P.div_scale_h) * R.VW + fdiv_u32(xv[u], P.div_scale_w));
+            // ---- expand: channel layout [wall | (has, hp[, minimap]) of group (g + b) % G for b = 0..G-1]
+            // (GridWorld.cc:897-913); the loop is over wave-uniform values only -- no lane diverges, nothing is loaded
+            float *dst = strip + lane * C;
+            dst[0] = code == (OCC_WALL & 0xff) ? 1.0f : 0.0f;
+            {
+                int j = R.g;
+                const int stride = R.minimap ? 3 : 2;
+#pragma unroll
+                for (int b = 0; b < MAXG; b++)
+                    if (b < G) {
+                        const bool m = code == j;
+                        float *d = dst + 1 + b * stride;
+                        d[0] = m ? 1.0f : 0.0f;
+                        d[1] = m ? hp : 0.0f;
+                        if (R.minimap) {
+                            float v = miniv[u][b];
+                            if (self && v == v) v += 1.0f;   // NaN stays the same NaN (x86 propagates the operand)
+                            d[2] = v;                        // unmasked copy + self marker (GridWorld.cc:374-383)
+                        }
+                        j = (j + 1 == G) ? 0 : j + 1;
+                    }
+            }
+            // wave-private LDS hand-over between lanes: LDS ops of one wave execute in order; the fences keep the
+            // compiler from moving accesses across the hand-over
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- store
+            const size_t f0 = (size_t)k0 * C;                          // first float of this step
+            const size_t remain = total_floats - f0;
+            if (VEC4) {
+                const int nq = remain >= (size_t)(64 * C) ? q_per_step : (int)(remain >> 2);
+                v4f *out4 = (v4f *)(R.view + f0);
+                const v4f *src4 = (const v4f *)strip;
+                for (int q = lane; q < nq; q += 64) {
+                    v4f f4 = src4[q];
+                    if (NT) __builtin_nontemporal_store(f4, out4 + q);
+                    else out4[q] = f4;
+                }
+                if (remain < (size_t)(64 * C))                         // < 4 trailing floats of the whole tensor
+                    for (int e = (nq << 2) + lane; e < (int)remain; e += 64) R.view[f0 + e] = strip[e];
+            } else {
+                const int ne = remain >= (size_t)(64 * C) ? 64 * C : (int)remain;
+                for (int e = lane; e < ne; e += 64) R.view[f0 + e] = strip[e];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the strip is reused by the next step
+            __builtin_amdgcn_wave_barrier();
         }
     }
+}
 
-    // ---- phase 3: features [id bits x E | one-hot last_action x NA | last_reward | x / w | y / h]
-    float *fo = R.feat + (size_t)a0 * R.F;
-    for (int k = tid; k < nA * R.F; k += 256) {
-        int a = fdiv_u32(k, P.div_f);
-        int f = k - a * R.F;
-        int i = a0 + a;
-        float v = 0.0f;
-        if (f < R.E) v = (f < 31) ? (float)((Gd.id[i] >> f) & 1) : 0.0f;
-        else if (f < R.E + R.NA) v = (Gd.last_action[i] == f - R.E) ? 1.0f : 0.0f;
-        else if (f == R.E + R.NA) v = Gd.last_reward[i];        // a fresh agent's last_action == NA lands here and
-        else if (f == R.E + R.NA + 1) v = __fdiv_rn((float)s_ax[a], (float)W.w);  // is overwritten (GridWorld.cc:390-392)
-        else if (f == R.E + R.NA + 2) v = __fdiv_rn((float)s_ay[a], (float)W.h);
-        fo[k] = v;
+// feature rows [id bits x E | one-hot last_action x NA | last_reward | x / w | y / h] (GridWorld.cc:386-396)
+__device__ __forceinline__ float feature_value(const WorldView &W, const RenderArgs &R, const GroupDev &Gd, int i, int f) {
+    if (f < R.E) return (f < 31) ? (float)((Gd.id[i] >> f) & 1) : 0.0f;
+    if (f < R.E + R.NA) return (Gd.last_action[i] == f - R.E) ? 1.0f : 0.0f;
+    if (f == R.E + R.NA) return Gd.last_reward[i];                       // a fresh agent's last_action == NA lands here
+    if (f == R.E + R.NA + 1) return __fdiv_rn((float)Gd.x[i], (float)W.w);  // and is overwritten (GridWorld.cc:390-392)
+    return __fdiv_rn((float)Gd.y[i], (float)W.h);
+}
+
+template <bool VEC4>
+__global__ void __launch_bounds__(256) k_features(WorldView W, RenderArgs R, RenderPlan P) {
+    const GroupDev Gd = W.grp[R.g];
+    const unsigned total = (unsigned)R.n * (unsigned)R.F;
+    const unsigned nq = VEC4 ? total >> 2 : 0;
+    for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        unsigned k = q << 2;
+        int i = fdiv_u32(k, P.div_f);
+        int f = k - i * R.F;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v[e] = feature_value(W, R, Gd, i, f);
+            if (++f == R.F) { f = 0; ++i; }
+        }
+        v4f f4 = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(f4, (v4f *)R.feat + q);
+    }
+    for (unsigned k = (nq << 2) + blockIdx.x * blockDim.x + threadIdx.x; k < total; k += gridDim.x * blockDim.x) {
+        const int i = fdiv_u32(k, P.div_f);
+        R.feat[k] = feature_value(W, R, Gd, i, k - i * R.F);
     }
 }
 
@@ -309,6 +349,93 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_c(WorldView W, int 
     const GroupDev G = W.grp[g];
     const int n_move = W.type[g].n_move;
     block_rank([&](int i) { return actions[i] >= n_move; }, [&](int i, int r) { G.key[i] = (unsigned)r; }, G.n, sums[blockIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------ generic int scan
+// exclusive prefix sum of an int array, ISCAN_TILE items per block, 8 consecutive items per thread
+constexpr int ISCAN_ITEMS = 8, ISCAN_TILE = 256 * ISCAN_ITEMS;
+
+__global__ void __launch_bounds__(256) k_iscan_a(const int *in, int n, int *sums) {
+    __shared__ int s_w[4];
+    int base = blockIdx.x * ISCAN_TILE + threadIdx.x * ISCAN_ITEMS, t = 0;
+#pragma unroll
+    for (int k = 0; k < ISCAN_ITEMS; k++) if (base + k < n) t += in[base + k];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ void __launch_bounds__(256) k_iscan_c(const int *in, int n, const int *sums, int *out) {
+    __shared__ int s_w[4];
+    int base = blockIdx.x * ISCAN_TILE + threadIdx.x * ISCAN_ITEMS;
+    int v[ISCAN_ITEMS], t = 0;
+#pragma unroll
+    for (int k = 0; k < ISCAN_ITEMS; k++) { v[k] = base + k < n ? in[base + k] : 0; t += v[k]; }
+    int x = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d); if (lane_id() >= d) x += y; }
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int run = sums[blockIdx.x] + x - t;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += s_w[w];
+#pragma unroll
+    for (int k = 0; k < ISCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+}
+
+// ------------------------------------------------------------------------------------------------ attack shuffle
+// The reference shuffles the attack list with `for i: j = (int)rng() % (i + 1); swap(buf[i], buf[j])`
+// (GridWorld.cc:464-468), rng = minstd_rand0.  Exact parallel replay:
+//   draw   j_i from the i-th engine output, by LCG skip-ahead: r_i = 16807^(i+1) * x0 mod (2^31 - 1)
+//   bucket for every position v the sorted list of steps k with j_k == v (counting sort + tiny insertion sorts)
+//   chase  element i sits at j_i after step i; it is moved again by the first later step k whose j_k equals its
+//          position, and then sits at k.  Following that chain (expected length O(log A)) gives its final position.
+__device__ __forceinline__ unsigned mulmod31(unsigned a, unsigned b) {
+    unsigned long long p = (unsigned long long)a * b;
+    unsigned long long r = (p & 0x7FFFFFFFull) + (p >> 31);
+    r = (r & 0x7FFFFFFFull) + (r >> 31);
+    return (unsigned)(r >= 0x7FFFFFFFull ? r - 0x7FFFFFFFull : r);
+}
+
+__global__ void __launch_bounds__(256) k_shuffle_draw(int A, unsigned x0, int *j, int *count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A) return;
+    unsigned e = (unsigned)i + 1u, base = 16807u, acc = x0;
+    while (e) { if (e & 1u) acc = mulmod31(acc, base); base = mulmod31(base, base); e >>= 1; }
+    int ji = (int)(acc % (unsigned)(i + 1));   // (int)rng() % (i + 1): outputs are in [1, 2^31 - 2]
+    j[i] = ji;
+    atomicAdd(&count[ji], 1);
+}
+
+__global__ void __launch_bounds__(256) k_shuffle_fill(int A, const int *j, const int *offset, int *cursor, int *list) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A) return;
+    int v = j[k];
+    list[offset[v] + atomicAdd(&cursor[v], 1)] = k;
+}
+
+__global__ void __launch_bounds__(256) k_shuffle_sort(int A, const int *offset, const int *count, int *list) {
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= A) return;
+    int n = count[v];
+    if (n < 2) return;
+    int *b = list + offset[v];
+    for (int a = 1; a < n; a++) { int x = b[a], c = a - 1; while (c >= 0 && b[c] > x) { b[c + 1] = b[c]; c--; } b[c + 1] = x; }
+}
+
+__global__ void __launch_bounds__(256) k_shuffle_chase(int A, const int *j, const int *offset, const int *count, const int *list, int *rank) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A) return;
+    int p = j[i], t = i;
+    while (true) {
+        const int *b = list + offset[p];
+        int n = count[p], nxt = -1;
+        for (int c = 0; c < n; c++) { int k = b[c]; if (k > t) { nxt = k; break; } }   // buckets are short and sorted
+        if (nxt < 0) break;
+        p = nxt; t = nxt;
+    }
+    rank[i] = p;
 }
 
 // ------------------------------------------------------------------------------------------------ attack phase
@@ -684,7 +811,7 @@ void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const
     hipLaunchKernelGGL(k_paint, dim3(blocks), dim3(256), 0, s, W, gtab, ttab);
 }
 
-void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts) {
+void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts, float *mini) {
     int VHW = R.VH * R.VW;
     (void)hipMemsetAsync(counts, 0, sizeof(int) * W.G * VHW, s);
     int mx = 1;
@@ -692,20 +819,25 @@ void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int 
     int bx = (mx + 255) / 256;
     if (bx > 512) bx = 512;
     hipLaunchKernelGGL(k_minimap, dim3(bx, W.G), dim3(256), VHW * sizeof(int), s, W, R, counts);
-}
-
-size_t render_lds_bytes(const WorldView &W, const RenderArgs &R, int AG) {
-    int VHW = R.VH * R.VW;
-    return (size_t)AG * VHW * 8 + (size_t)W.G * VHW * 4 + (size_t)AG * 12 + (size_t)R.C * 4;
+    hipLaunchKernelGGL(k_minimap_norm, dim3((W.G * VHW + 255) / 256), dim3(256), 0, s, R, W.G, counts, mini);
 }
 
 void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt) {
     if (R.n <= 0) return;
-    int tiles = (R.n + P.AG - 1) / P.AG;
-    size_t lds = render_lds_bytes(W, R, P.AG);
-    if (vec4 && nt) hipLaunchKernelGGL((k_render<true, true>), dim3(tiles), dim3(256), lds, s, W, R, P);
-    else if (vec4) hipLaunchKernelGGL((k_render<true, false>), dim3(tiles), dim3(256), lds, s, W, R, P);
-    else hipLaunchKernelGGL((k_render<false, false>), dim3(tiles), dim3(256), lds, s, W, R, P);
+    size_t lds = (size_t)RENDER_WAVES * P.strip_floats * sizeof(float);
+    dim3 grid(P.spans), block(64 * RENDER_WAVES);
+    if (!vec4) hipLaunchKernelGGL((k_render<false, false, 1>), grid, block, lds, s, W, R, P);
+    else if (P.unroll == 2) { if (nt) hipLaunchKernelGGL((k_render<true, true, 2>), grid, block, lds, s, W, R, P); else hipLaunchKernelGGL((k_render<true, false, 2>), grid, block, lds, s, W, R, P); }
+    else if (P.unroll == 4) { if (nt) hipLaunchKernelGGL((k_render<true, true, 4>), grid, block, lds, s, W, R, P); else hipLaunchKernelGGL((k_render<true, false, 4>), grid, block, lds, s, W, R, P); }
+    else { if (nt) hipLaunchKernelGGL((k_render<true, true, 1>), grid, block, lds, s, W, R, P); else hipLaunchKernelGGL((k_render<true, false, 1>), grid, block, lds, s, W, R, P); }
+}
+
+void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4) {
+    if (R.n <= 0) return;
+    unsigned total = (unsigned)R.n * (unsigned)R.F;
+    int fb = (int)std::min<unsigned>((total / 4 + 255) / 256 + 1, 2048);
+    if (vec4) hipLaunchKernelGGL((k_features<true>), dim3(fb), dim3(256), 0, s, W, R, P);
+    else hipLaunchKernelGGL((k_features<false>), dim3(fb), dim3(256), 0, s, W, R, P);
 }
 
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums) {
@@ -715,6 +847,20 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
     hipLaunchKernelGGL(k_set_action_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, call_base, sums);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, W.counters + CTR_ATTACK);
     hipLaunchKernelGGL(k_set_action_c, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, sums);
+}
+
+void launch_shuffle(hipStream_t s, int A, unsigned x0, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank) {
+    (void)hipMemsetAsync(count, 0, sizeof(int) * A, s);
+    (void)hipMemsetAsync(cursor, 0, sizeof(int) * A, s);
+    dim3 g((A + 255) / 256), b(256);
+    int nb = (A + ISCAN_TILE - 1) / ISCAN_TILE;
+    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, A, x0, j, count);
+    hipLaunchKernelGGL(k_iscan_a, dim3(nb), b, 0, s, count, A, sums);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, (int *)nullptr);
+    hipLaunchKernelGGL(k_iscan_c, dim3(nb), b, 0, s, count, A, sums, offset);
+    hipLaunchKernelGGL(k_shuffle_fill, g, b, 0, s, A, j, offset, cursor, list);
+    hipLaunchKernelGGL(k_shuffle_sort, g, b, 0, s, A, offset, count, list);
+    hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, A, j, offset, count, list, rank);
 }
 
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank) {

@@ -22,9 +22,12 @@ inline FastDiv make_fastdiv(unsigned d) {
 
 // how the render kernel tiles one get_observation call
 struct RenderPlan {
-    int AG;          // agents per workgroup (multiple of 4 so every tile starts 16-byte aligned)
-    int xcd_chunk;   // tiles / 8 when the XCD-aware tile mapping is on, else 0
-    FastDiv div_vhw, div_vw, div_s, div_c, div_f;
+    int spans;           // workgroups; each owns `steps_per_span` consecutive 64-cell steps of the flat cell sequence
+    int steps_per_span;
+    int xcd_chunk;       // spans / 8 when the XCD-aware span mapping is on, else 0
+    int strip_floats;    // 64 * C: wave-private LDS strip
+    int unroll;          // 64-cell steps whose loads a wave keeps in flight together (1, 2, 4 or 8)
+    FastDiv div_vhw, div_vw, div_f, div_scale_w, div_scale_h;
 };
 
 // one reward rule Event(a, op, b), a/b = 'any'
@@ -36,9 +39,10 @@ struct RuleArgs {
 
 void launch_set_tables(hipStream_t s, const WorldView &W, GroupDev *gtab, TypeDev *ttab);
 void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab);
-void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts);
-size_t render_lds_bytes(const WorldView &W, const RenderArgs &R, int AG);
+void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts, float *mini);
 void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt);
+void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4);
+void launch_shuffle(hipStream_t s, int A, unsigned x0, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank);
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank);
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b);
