@@ -1,0 +1,161 @@
+"""CPU tests of the product's host logic and of the C-ABI surface -- no compute call, no GPU.
+
+The HIP library is cross-compiled by __graft_entry__.build(); loading it and calling the pre-reset entry points
+(configuration, agent types, groups, the *_space / view2attack infos) touches no device."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+ROOT = H.ROOT
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    if not os.path.exists(H.HIP_LIB):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+    return H.HIP_LIB
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "magent_runtime_api.h")).read()
+    return sorted(set(re.findall(r"^int\s+(\w+)\s*\(", text, flags=re.M)))
+
+
+def test_header_declares_the_reference_abi():
+    names = declared_symbols()
+    for must in ("env_new_game", "env_delete_game", "env_config_game", "env_reset", "env_get_observation", "env_set_action",
+                 "env_step", "env_get_reward", "env_get_info", "env_render", "env_render_next_file",
+                 "gridworld_register_agent_type", "gridworld_new_group", "gridworld_add_agents", "gridworld_clear_dead",
+                 "gridworld_set_goal", "gridworld_define_agent_symbol", "gridworld_define_event_node",
+                 "gridworld_add_reward_rule", "discrete_snake_clear_dead", "discrete_snake_add_object"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    lib = ctypes.CDLL(hip_lib, mode=os.RTLD_LOCAL)
+    for name in declared_symbols():
+        assert hasattr(lib, name), "libmagent.so does not export %s" % name
+
+
+def test_oracle_exports_the_reference_abi():
+    lib = ctypes.CDLL(H.ensure_oracle(), mode=os.RTLD_LOCAL)
+    from magent_amd import c_lib
+    for name, _ in c_lib.REFERENCE_ABI:
+        assert hasattr(lib, name)
+
+
+def test_product_does_not_link_the_oracle(hip_lib):
+    out = subprocess.run(["ldd", hip_lib], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "magent_ref" not in out
+    assert "libamdhip64" in out
+
+
+@pytest.mark.parametrize("game,size", [("battle", 40), ("gather", 60)])
+def test_pre_reset_infos_match_oracle(hip_lib, game, size):
+    """spaces, action layout and the view2attack table are host-side tables (Range.h / AgentType.cc restated):
+    the product must agree with the oracle without ever touching a device"""
+    import magent_amd
+    a = magent_amd.GridWorld(game, lib=hip_lib, map_size=size)
+    b = magent_amd.GridWorld(game, lib=H.ensure_oracle(), map_size=size)
+    for ha, hb in zip(a.get_handles(), b.get_handles()):
+        assert a.get_view_space(ha) == b.get_view_space(hb)
+        assert a.get_feature_space(ha) == b.get_feature_space(hb)
+        assert a.get_action_space(ha) == b.get_action_space(hb)
+        (ba, ta), (bb, tb) = a.get_view2attack(ha), b.get_view2attack(hb)
+        assert ba == bb and np.array_equal(ta, tb)
+
+
+def test_battle_spaces_known_answers(hip_lib):
+    import magent_amd
+    env = magent_amd.GridWorld("battle", lib=hip_lib, map_size=100)
+    h = env.get_handles()[0]
+    assert env.get_view_space(h) == (13, 13, 7) and env.get_feature_space(h) == (34,) and env.get_action_space(h) == (21,)
+
+
+def test_unsupported_features_fail_loudly(hip_lib):
+    """no silent approximation: an out-of-scope feature aborts the process with a message"""
+    code = ("import magent_amd, sys\n"
+            "from magent_amd.builtin.config import _games\n"
+            "cfg = _games.make('pursuit', 40)\n"
+            "magent_amd.GridWorld(cfg, lib=%r)\n" % hip_lib)
+    env = dict(os.environ, MAGENT_AMD_NO_TORCH="1", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert p.returncode != 0 and "magent-amd FATAL" in p.stderr and "multi-cell" in p.stderr
+
+
+def test_no_cpu_fallback_without_gpu(hip_lib):
+    """on a box without a HIP device env_reset must abort, not fall back to anything"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    code = ("import magent_amd\n"
+            "env = magent_amd.GridWorld('battle', lib=%r, map_size=30)\n"
+            "env.reset()\n" % hip_lib)
+    env = dict(os.environ, MAGENT_AMD_NO_TORCH="1", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert p.returncode != 0 and "no HIP device" in p.stderr
+
+
+def test_reward_rule_serialisation_order():
+    """symbols are numbered receivers-first then in expression order, nodes in pre-order (gridworld.py:493-565)"""
+    from magent_amd import gridworld as gw
+    calls = []
+
+    class Spy(object):
+        has_device_api = False
+
+        def __getattr__(self, name):
+            def f(*args):
+                calls.append((name, args))
+                if name == "env_get_info":
+                    pass
+                return 0
+            return f
+
+    cfg = gw.Config()
+    cfg.set({"map_width": 10, "map_height": 10})
+    t = cfg.register_agent_type("t", {"width": 1, "length": 1, "hp": 1, "speed": 1, "view_range": gw.CircleRange(1),
+                                      "attack_range": gw.CircleRange(1)})
+    g0, g1 = cfg.add_group(t), cfg.add_group(t)
+    a, b = gw.AgentSymbol(g0, "any"), gw.AgentSymbol(g1, "any")
+    cfg.add_reward_rule(gw.Event(a, "attack", b), receiver=[a, b], value=[1, -1])
+    cfg.add_reward_rule(gw.Event(b, "kill", a), receiver=b, value=2)
+    env = gw.GridWorld.__new__(gw.GridWorld)
+    env._lib, env.game = Spy(), None
+    env._send_reward_rules(cfg)
+    syms = [(c[1][1], c[1][2], c[1][3]) for c in calls if c[0] == "gridworld_define_agent_symbol"]
+    assert syms == [(0, g0, -1), (1, g1, -1)]
+    nodes = [(c[1][1], c[1][2]) for c in calls if c[0] == "gridworld_define_event_node"]
+    assert nodes == [(0, gw.EventNode.OP_ATTACK), (1, gw.EventNode.OP_KILL)]
+    rules = [c[1][1] for c in calls if c[0] == "gridworld_add_reward_rule"]
+    assert rules == [0, 1]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/python/magent"), reason="reference python package not present")
+def test_reference_wrapper_binds_to_the_new_library(hip_lib, tmp_path):
+    """the UNMODIFIED reference wrapper finds every symbol it calls in the new library.
+    (Only pre-reset calls here: this container has no GPU.)"""
+    (tmp_path / "build").mkdir()
+    os.symlink(hip_lib, tmp_path / "build" / "libmagent.so")
+    import shutil
+    shutil.copytree("/root/reference/python", tmp_path / "python")   # scratch copy: c_lib.py resolves ../../build physically
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import magent\n"
+            "env = magent.GridWorld('battle', map_size=50)\n"
+            "h = env.get_handles()[0]\n"
+            "t = lambda v: tuple(int(i) for i in v)\n"
+            "print(t(env.get_view_space(h)), t(env.get_feature_space(h)), t(env.get_action_space(h)), env.get_view2attack(h)[0])\n"
+            % str(tmp_path / "python"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.strip() == "(13, 13, 7) (34,) (21,) 13"
