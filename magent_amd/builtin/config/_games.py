@@ -4,6 +4,7 @@ Values are those of the reference's game files -- they are data the parity tests
   battle : python/magent/builtin/config/battle.py:6-33
   pursuit: python/magent/builtin/config/pursuit.py:4-33
   gather : examples/train_gather.py:14-43
+  forest : python/magent/builtin/config/forest.py:6-33 (no reward rule; deer carry kill_supply)
 """
 from ... import gridworld as gw
 
@@ -23,6 +24,15 @@ _GAMES = {
                "prey": dict(width=1, length=1, hp=1, speed=1.5, view_range=4, attack_range=0)},
         groups=["predator", "prey"],
         rules=[(0, "attack", 1, "so", [1, -1])],
+    ),
+    "forest": dict(
+        settings={"embedding_size": 10},
+        types={"deer": dict(width=1, length=1, hp=5, speed=1, view_range=1, attack_range=0, damage=0, step_recover=0.2,
+                            food_supply=0, kill_supply=8),
+               "tiger": dict(width=1, length=1, hp=10, speed=1, view_range=4, attack_range=1, damage=3, step_recover=-0.5,
+                             food_supply=0, kill_supply=0, step_reward=1, attack_penalty=-0.1)},
+        groups=["deer", "tiger"],
+        rules=[],
     ),
     "gather": dict(
         settings={"minimap_mode": True},

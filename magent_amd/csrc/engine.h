@@ -43,6 +43,7 @@ struct TypeDev {
     int attack_in_group;
     int n_move, n_attack;        // action layout: [0, n_move) moves, [n_move, n_move + n_attack) attacks
     int move_off, attack_off;    // offsets into WorldView::delta (int2 {dx,dy} per action payload)
+    int attack_bit;              // first bit of this group's attack offsets in the per-cell hit word
     int view_w, view_h;          // observation window
     int view_x1, view_y1;        // window origin relative to the agent position (includes view_x/y_offset)
     int mask_off;                // offset into WorldView::mask (view_h * view_w bytes, 1 = inside the view range)

@@ -258,6 +258,9 @@ void Env::compile_rules() {
         if (sa.index != -1 || sb.index != -1) fatal("reward rule %zu: only 'any' agent symbols are on the GPU path", k);
         if (sa.group < 0 || sa.group >= (int)groups.size() || sb.group < 0 || sb.group >= (int)groups.size())
             fatal("reward rule %zu: invalid group in agent symbol", k);
+        // one symbol as subject AND object: the reference binds the object over the subject's entity
+        // (RewardEngine.cc:17-24, 405-408) and then tests the target against itself -- the rule can never fire
+        if (on.raw[0] == on.raw[1]) continue;
         RuleArgs a{};
         a.ga = sa.group; a.gb = sb.group; a.op = on.op; a.rule_no = (int)k;
         for (size_t i = 0; i < r.recv.size(); i++) {
@@ -395,6 +398,7 @@ void Env::reset() {
         d.n_move = t.move.count; d.n_attack = t.attack.count;
         d.move_off = (int)delta.size();
         for (int k = 0; k < t.move.count; k++) delta.push_back(make_int2(t.move.dx[k], t.move.dy[k]));
+        d.attack_bit = total_attack;
         d.attack_off = (int)delta.size();
         for (int k = 0; k < t.attack.count; k++) delta.push_back(make_int2(t.attack.dx[k] + t.att_x_offset, t.attack.dy[k] + t.att_y_offset));
         d.view_w = t.view.width; d.view_h = t.view.height;
@@ -405,6 +409,14 @@ void Env::reset() {
         if (t.kill_supply != 0) any_kill_supply = 1;
         total_attack += t.attack.count;
         g.n = 0; g.group_reward = 0; g.acted = false; g.h_dead = 0;
+    }
+    // most hits one target can receive: attack offsets of every group allowed to attack it
+    attack_kmax = 1;
+    for (size_t t = 0; t < groups.size(); t++) {
+        int k = 0;
+        for (size_t a = 0; a < groups.size(); a++)
+            if (a != t || groups[a].type->attack_in_group) k += groups[a].type->attack.count;
+        attack_kmax = std::max(attack_kmax, k);
     }
     if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
     if (n_channel() > 32) fatal("too many observation channels");
@@ -669,13 +681,13 @@ void Env::step(int *done) {
         int use_b = 0, iters = 0;
         while (true) {
             clear_changed();
-            launch_attack_iter(stream, W, d_gtab, d_ttab, use_b);
+            launch_attack_iter(stream, W, d_gtab, d_ttab, use_b, attack_kmax);
             use_b ^= 1;
             iters++;
             if (!read_changed()) break;
             if (iters > 100000) fatal("attack resolution did not converge");
         }
-        launch_attack_apply(stream, W, d_gtab, d_ttab, use_b);
+        launch_attack_apply(stream, W, d_gtab, d_ttab, use_b, attack_kmax);
         last_attack_iters = iters;
     }
     // ---- starve / recover

@@ -134,7 +134,7 @@ private:
     std::vector<HostRule> rules;
     std::vector<RuleArgs> rule_args;
     bool rules_compiled = false;
-    int id_counter = 0, any_kill_supply = 0, move_seq_base = 0;
+    int id_counter = 0, any_kill_supply = 0, move_seq_base = 0, attack_kmax = 1;
 
     // device state
     bool device_ready = false, tables_valid = false, paint_valid = false;

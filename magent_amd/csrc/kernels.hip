@@ -440,13 +440,28 @@ __global__ void __launch_bounds__(256) k_shuffle_chase(int A, const int *j, cons
 
 // ------------------------------------------------------------------------------------------------ attack phase
 // rank[seq] = position of attack-list entry `seq` after the reference's shuffle (GridWorld.cc:464-468)
-__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank) {
-    const GroupDev G = W.grp[blockIdx.y];
+__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits) {
+    const int g = blockIdx.y;
+    const GroupDev G = W.grp[g];
+    const TypeDev T = W.type[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
-    bool att = (G.pend[i] & ~PEND_ARG) == PEND_ATTACK;
+    const int pend = G.pend[i];
+    const bool att = (pend & ~PEND_ARG) == PEND_ATTACK;
+    const bool dead = G.dead[i];
     if (att) G.key[i] = (unsigned)rank[G.key[i]];
-    G.drank_a[i] = G.dead[i] ? -1 : RANK_INF;   // agents dead before the phase never act and are not on the map
+    G.drank_a[i] = dead ? -1 : RANK_INF;   // agents dead before the phase never act and are not on the map
+    // push one bit per (attacker group, attack offset) onto the target's cell: targets then enumerate only the
+    // hits they actually receive (one word per target instead of a scan of every attack offset around it)
+    if (att && !dead) {
+        const int k = pend & PEND_ARG;
+        int2 d = W.delta[T.attack_off + k];
+        int tx = G.x[i] + d.x, ty = G.y[i] + d.y;
+        if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
+            int o = W.occ[ty * W.w + tx];
+            if (o >= 0 && (T.attack_in_group || ref_group(o) != g)) atomicOr(&hitbits[ty * W.w + tx], 1u << (T.attack_bit + k));
+        }
+    }
 }
 
 // Exact parallel form of the sequential attack loop.  For a target t the incoming hits are found by PULLING:
@@ -454,17 +469,15 @@ __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *ran
 // pos(t) - d; it hits iff its pending action is "attack with offset d".  Hits are sorted by rank (LDS) and replayed
 // in order: a hit counts iff its attacker is still alive at that rank (death_rank[attacker] > rank).  death_rank
 // is iterated to its fixed point; after k rounds every event of dependency depth <= k is final.
-constexpr int ATT_THREADS = 128, ATT_KMAX = 32;
-
-struct HitList {
-    int n;
-};
+constexpr int ATT_THREADS = 128;
 
 template <bool APPLY>
 __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab,
-                                                             int use_b /* read drank_b, write drank_a */) {
-    __shared__ unsigned s_rank[ATT_KMAX][ATT_THREADS];
-    __shared__ int s_ref[ATT_KMAX][ATT_THREADS];
+                                                             int use_b /* read drank_b, write drank_a */,
+                                                             const unsigned *hitbits, int kmax) {
+    extern __shared__ unsigned s_hit[];               // [kmax][ATT_THREADS] ranks, then [kmax][ATT_THREADS] refs
+    unsigned *s_rank = s_hit;
+    int *s_ref = (int *)(s_hit + kmax * ATT_THREADS);
     const int g = blockIdx.y, tid = threadIdx.x;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
@@ -476,31 +489,37 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     if (dr_me_cur == -1) { if (!APPLY) dr_self_next[i] = -1; return; }   // dead before the phase
 
     const int x = G.x[i], y = G.y[i];
-    // ---- gather incoming hits
+    // ---- gather incoming hits: bit (attack_bit[ga] + k) of my cell's word is set iff the agent standing at
+    // pos - delta(ga, k) attacks me with offset k
     int nh = 0;
-    for (int ga = 0; ga < W.G; ga++) {
-        const TypeDev TA = W.type[ga];
-        if (TA.n_attack == 0 || (!TA.attack_in_group && ga == g)) continue;
-        const GroupDev A = W.grp[ga];
-        for (int k = 0; k < TA.n_attack; k++) {
-            int2 d = W.delta[TA.attack_off + k];
-            int ax = x - d.x, ay = y - d.y;
-            if (ax < 0 || ax >= W.w || ay < 0 || ay >= W.h) continue;
-            int o = W.occ[ay * W.w + ax];
-            if (o < 0 || ref_group(o) != ga) continue;
-            int ai = ref_index(o);
-            if (A.pend[ai] != (PEND_ATTACK | k)) continue;
-            if (nh < ATT_KMAX) { s_rank[nh][tid] = A.key[ai]; s_ref[nh][tid] = o; }
-            nh++;
+    unsigned bits = hitbits[y * W.w + x];
+    if (bits) {
+        for (int ga = 0; ga < W.G; ga++) {
+            const TypeDev TA = W.type[ga];
+            if (TA.n_attack == 0) continue;
+            unsigned mine = (bits >> TA.attack_bit) & (TA.n_attack >= 32 ? 0xFFFFFFFFu : ((1u << TA.n_attack) - 1u));
+            const GroupDev A = W.grp[ga];
+            while (mine) {
+                int k = __ffs(mine) - 1;
+                mine &= mine - 1;
+                int2 d = W.delta[TA.attack_off + k];
+                int o = W.occ[(y - d.y) * W.w + (x - d.x)];
+                int ai = ref_index(o);
+                s_rank[nh * ATT_THREADS + tid] = A.key[ai]; s_ref[nh * ATT_THREADS + tid] = o;
+                nh++;
+            }
         }
     }
-    if (nh > ATT_KMAX) nh = ATT_KMAX;   // cannot happen: the host checks sum(n_attack) <= ATT_KMAX at reset
     // ---- insertion sort by rank (ranks are unique)
     for (int a = 1; a < nh; a++) {
-        unsigned r = s_rank[a][tid]; int f = s_ref[a][tid];
+        unsigned r = s_rank[a * ATT_THREADS + tid]; int f = s_ref[a * ATT_THREADS + tid];
         int b = a - 1;
-        while (b >= 0 && s_rank[b][tid] > r) { s_rank[b + 1][tid] = s_rank[b][tid]; s_ref[b + 1][tid] = s_ref[b][tid]; b--; }
-        s_rank[b + 1][tid] = r; s_ref[b + 1][tid] = f;
+        while (b >= 0 && s_rank[b * ATT_THREADS + tid] > r) {
+            s_rank[(b + 1) * ATT_THREADS + tid] = s_rank[b * ATT_THREADS + tid];
+            s_ref[(b + 1) * ATT_THREADS + tid] = s_ref[b * ATT_THREADS + tid];
+            b--;
+        }
+        s_rank[(b + 1) * ATT_THREADS + tid] = r; s_ref[(b + 1) * ATT_THREADS + tid] = f;
     }
     // ---- own attack (needed for kill_supply replay and, in APPLY, for the attacker-side results)
     const int pend = G.pend[i];
@@ -526,9 +545,9 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     int dr = RANK_INF;
     bool supplied = !supply;
     for (int k = 0; k < nh; k++) {
-        unsigned r = s_rank[k][tid];
+        unsigned r = s_rank[k * ATT_THREADS + tid];
         if (!supplied && my_rank < r) { hp = fminf(T.hp, hp + ttab[ref_group(tgt)].kill_supply); supplied = true; }
-        int a = s_ref[k][tid];
+        int a = s_ref[k * ATT_THREADS + tid];
         const GroupDev A = gtab[ref_group(a)];
         int adr = (use_b ? A.drank_b : A.drank_a)[ref_index(a)];
         if ((unsigned)adr > r) {                       // attacker alive when its turn comes (RANK_INF > any rank)
@@ -560,10 +579,20 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     if (dr != RANK_INF) {
         G.dead[i] = 1;
         nr = T.dead_penalty;                           // overwrites what was accumulated (GridWorld.h:207)
-        W.occ[y * W.w + x] = OCC_EMPTY;
-        atomicAdd(&W.counters[CTR_DEAD + g], 1);
+        atomicAdd(&W.counters[CTR_DEAD + g], 1);       // the map cell is cleared by k_attack_bury: other lanes of THIS
+                                                       // launch still find their attackers through the map
     }
     G.next_reward[i] = nr;
+}
+
+// removes the agents that died in this attack phase from the map (Map::remove_agent, Map.cc:272), after every
+// reader of the phase-start map is done
+__global__ void __launch_bounds__(256) k_attack_bury(WorldView W, int use_b) {
+    const GroupDev G = W.grp[blockIdx.y];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.n) return;
+    int dr = (use_b ? G.drank_b : G.drank_a)[i];
+    if (dr != -1 && dr != RANK_INF) W.occ[G.y[i] * W.w + G.x[i]] = OCC_EMPTY;
 }
 
 // ------------------------------------------------------------------------------------------------ starve / recover
@@ -863,14 +892,19 @@ void launch_shuffle(hipStream_t s, int A, unsigned x0, int *j, int *count, int *
     hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, A, j, offset, count, list, rank);
 }
 
+// hit bits live in the (then unused) claim array of the move phase
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank) {
-    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank);
+    (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);
+    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim);
 }
-void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b) {
-    hipLaunchKernelGGL((k_attack_eval<false>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), 0, s, W, gtab, ttab, use_b);
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax) {
+    size_t lds = (size_t)kmax * ATT_THREADS * 8;
+    hipLaunchKernelGGL((k_attack_eval<false>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, use_b, (const unsigned *)W.claim, kmax);
 }
-void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b) {
-    hipLaunchKernelGGL((k_attack_eval<true>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), 0, s, W, gtab, ttab, use_b);
+void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax) {
+    size_t lds = (size_t)kmax * ATT_THREADS * 8;
+    hipLaunchKernelGGL((k_attack_eval<true>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, use_b, (const unsigned *)W.claim, kmax);
+    hipLaunchKernelGGL(k_attack_bury, grid_all(W, 256), dim3(256), 0, s, W, use_b);
 }
 void launch_starve(hipStream_t s, const WorldView &W) { hipLaunchKernelGGL(k_starve, grid_all(W, 256), dim3(256), 0, s, W); }
 

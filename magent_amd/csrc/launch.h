@@ -45,8 +45,8 @@ void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, con
 void launch_shuffle(hipStream_t s, int A, unsigned x0, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank);
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank);
-void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b);
-void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b);
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax);
+void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax);
 void launch_starve(hipStream_t s, const WorldView &W);
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab);
@@ -60,6 +60,6 @@ void launch_init_reward(hipStream_t s, const WorldView &W, int g);
 void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D, int new_n, int *sums);
 
 constexpr int SCAN_TILE_HOST = 256 * 8;  // must equal SCAN_TILE in kernels.hip
-constexpr int ATTACK_KMAX_HOST = 32;     // must equal ATT_KMAX in kernels.hip
+constexpr int ATTACK_KMAX_HOST = 32;     // attack offsets of all groups share one 32-bit word per cell
 
 }  // namespace magent_amd

@@ -447,6 +447,10 @@ int env_step(void *game, int *done) {
         const Node &on = e.nodes[r.on];
         const Symbol &sa = e.symbols[on.raw[0]], &sb = e.symbols[on.raw[1]];
         Group &A = e.groups[sa.group];
+        // One symbol used as subject AND object: binding the object overwrites the subject's entity
+        // (AgentSymbol::bind_with_check, RewardEngine.cc:17-24 via :405-408), so the event is tested on the target
+        // against itself and can never hold (nobody attacks, kills or collides with itself).
+        if (on.raw[0] == on.raw[1]) continue;
         for (int i = 0; i < A.size(); i++) {
             if (A.op_obj[i] < 0) continue;
             int tg = (int)(A.op_obj[i] >> 32), ti = (int)(uint32_t)A.op_obj[i];

@@ -42,25 +42,90 @@ def config_for(game, map_size, **over):
     return cfg
 
 
+def custom_tri(map_w, map_h):
+    """three groups of three different types, every supported rule shape (subject / object receivers, kill, collide),
+    in-group attack, kill_supply, a non-square map"""
+    cfg = gw.Config()
+    cfg.set({"map_width": map_w, "map_height": map_h, "minimap_mode": True, "embedding_size": 4})
+    a = cfg.register_agent_type("a", dict(width=1, length=1, hp=6, speed=2, view_range=gw.CircleRange(5), attack_range=gw.CircleRange(1.5),
+                                          damage=2, step_recover=0.1, step_reward=-0.01, kill_reward=3, dead_penalty=-0.5, attack_penalty=-0.05))
+    b = cfg.register_agent_type("b", dict(width=1, length=1, hp=4, speed=3, view_range=gw.CircleRange(4), attack_range=gw.CircleRange(2),
+                                          damage=3, step_recover=0, attack_in_group=1, kill_supply=2.5, kill_reward=1, dead_penalty=-1))
+    c = cfg.register_agent_type("c", dict(width=1, length=1, hp=9, speed=1, view_range=gw.CircleRange(2), attack_range=gw.CircleRange(1),
+                                          damage=1.5, step_recover=-0.3, kill_supply=4, attack_penalty=-0.2, step_reward=0.25))
+    ga, gb, gc = cfg.add_group(a), cfg.add_group(b), cfg.add_group(c)
+    sa, sb, sc_ = gw.AgentSymbol(ga, "any"), gw.AgentSymbol(gb, "any"), gw.AgentSymbol(gc, "any")
+    cfg.add_reward_rule(gw.Event(sa, "attack", sb), receiver=[sa, sb], value=[0.3, -0.7])
+    cfg.add_reward_rule(gw.Event(sb, "kill", sc_), receiver=sb, value=2.25)
+    cfg.add_reward_rule(gw.Event(sc_, "collide", sa), receiver=[sa], value=[-0.125])
+    cfg.add_reward_rule(gw.Event(sb, "attack", sb), receiver=sb, value=0.0625)      # same symbol twice: never fires
+    sb2 = gw.AgentSymbol(gb, "any")
+    cfg.add_reward_rule(gw.Event(sb, "attack", sb2), receiver=sb, value=0.03125)    # in-group attack, subject paid
+    cfg.add_reward_rule(gw.Event(sb2, "attack", sb), receiver=sb, value=-0.015625)  # in-group attack, object pays
+    cfg.add_reward_rule(gw.Event(sc_, "attack", sa), receiver=[sa, sa, sc_], value=[-0.2, 0.05, 0.4])
+    return cfg
+
+
+def custom_chase(map_size):
+    """no minimap, no embedding (the pursuit layout with a 1x1 predator): rule rewards land on the object of the event"""
+    cfg = gw.Config()
+    cfg.set({"map_width": map_size, "map_height": map_size})
+    pred = cfg.register_agent_type("predator", dict(width=1, length=1, hp=1, speed=1, view_range=gw.CircleRange(5),
+                                                    attack_range=gw.CircleRange(2), attack_penalty=-0.2))
+    prey = cfg.register_agent_type("prey", dict(width=1, length=1, hp=1, speed=1.5, view_range=gw.CircleRange(4),
+                                                attack_range=gw.CircleRange(0)))
+    gp, gq = cfg.add_group(pred), cfg.add_group(prey)
+    a, b = gw.AgentSymbol(gp, "any"), gw.AgentSymbol(gq, "any")
+    cfg.add_reward_rule(gw.Event(a, "attack", b), receiver=[a, b], value=[1, -1])
+    return cfg
+
+
+CUSTOM = {"tri": custom_tri, "chase": custom_chase}
+
+
 class Scenario(object):
-    """a reproducible episode: game + placement recipe + random action stream"""
+    """a reproducible episode: game + placement recipe + random action stream
+
+    game     : built-in game name, or ("custom-name", args...) for one of the CUSTOM configs
+    events   : {step: [("add", group, method, kw) | ("walls", method, kw) | ("reset", placements)]} applied before
+               that step's observations -- mid-episode placement and a second episode on the same engine (the RNG
+               stream continues across reset, GridWorld.cc:72-118)"""
 
     def __init__(self, name, game, map_size, seed=12345, place=(), steps=10, action_seed=0, walls=0,
-                 acting=None, over=None, clear_every=1, obs_every=1):
+                 acting=None, over=None, clear_every=1, obs_every=1, events=None):
         self.name, self.game, self.map_size, self.seed = name, game, map_size, seed
         self.place, self.steps, self.action_seed, self.walls = list(place), steps, action_seed, walls
         self.acting, self.over, self.clear_every, self.obs_every = acting, over or {}, clear_every, obs_every
+        self.events = events or {}
+
+    def config(self):
+        if isinstance(self.game, tuple):
+            return CUSTOM[self.game[0]](*self.game[1:])
+        return config_for(self.game, self.map_size, **self.over)
+
+    def populate(self, env, place, walls):
+        if walls:
+            env.add_walls(method="random", n=walls)
+        handles = env.get_handles()
+        for g, method, kw in place:
+            env.add_agents(handles[g], method, **kw)
 
     def build(self, lib):
-        env = magent_amd.GridWorld(config_for(self.game, self.map_size, **self.over), lib=lib)
+        env = magent_amd.GridWorld(self.config(), lib=lib)
         env.set_seed(self.seed)
         env.reset()
-        if self.walls:
-            env.add_walls(method="random", n=self.walls)
-        handles = env.get_handles()
-        for g, method, kw in self.place:
-            env.add_agents(handles[g], method, **kw)
-        return env, handles
+        self.populate(env, self.place, self.walls)
+        return env, env.get_handles()
+
+    def apply_events(self, env, step):
+        for ev in self.events.get(step, ()):
+            if ev[0] == "add":
+                env.add_agents(env.get_handles()[ev[1]], ev[2], **ev[3])
+            elif ev[0] == "walls":
+                env.add_walls(method=ev[1], **ev[2])
+            elif ev[0] == "reset":
+                env.reset()
+                self.populate(env, ev[1], 0)
 
 
 def run(sc, lib, record=None):
@@ -74,6 +139,7 @@ def run(sc, lib, record=None):
     out = []
     for step in range(sc.steps):
         rec = {}
+        sc.apply_events(env, step)
         for g, h in enumerate(handles):
             n = env.get_num(h)
             if step % sc.obs_every == 0 and n > 0:
@@ -88,12 +154,14 @@ def run(sc, lib, record=None):
             rec["alive%d" % g] = env.get_alive(h).astype(np.uint8)
             rec["pos%d" % g] = env.get_pos(h)
             rec["num%d" % g] = np.array([env.get_num(h)], dtype=np.int32)
+        if step % 7 == 3:
+            rec["global_minimap"] = env.get_global_minimap(5, 6).copy()
         if (step + 1) % sc.clear_every == 0:
             env.clear_dead()
         out.append(rec)
         if record is not None:
             record(step, rec)
-        if all(env.get_num(h) == 0 for h in handles):
+        if all(env.get_num(h) == 0 for h in handles) and not any(k > step for k in sc.events):
             break
     return out
 
@@ -150,6 +218,18 @@ def scenarios():
         Scenario("gather_largemap", "gather", 130, place=[rnd(0, 1500), rnd(1, 6000)], acting=[1], steps=8, action_seed=12),
         Scenario("battle_lowhp", "battle", 40, place=[rnd(0, 500), rnd(1, 500)], steps=15, action_seed=13,
                  over={"small": {"hp": 3, "step_recover": -0.4}}),
+        Scenario("battle_brawl_dense_big", "battle", 300, place=[rnd(0, 40000), rnd(1, 40000)], steps=6, action_seed=21,
+                 obs_every=3, over={"small": {"hp": 4, "damage": 3, "step_recover": 0}}),
+        Scenario("forest", "forest", 50, place=[rnd(0, 500), rnd(1, 250)], walls=60, steps=25, action_seed=15),
+        Scenario("tri_rect", ("tri", 70, 45), 0, place=[rnd(0, 500), rnd(1, 400), rnd(2, 450)], walls=80, steps=25, action_seed=16),
+        Scenario("tri_rect_large", ("tri", 150, 101), 0, place=[rnd(0, 3000), rnd(1, 3000), rnd(2, 2500)], steps=10, action_seed=17),
+        Scenario("chase", ("chase", 40), 0, place=[rnd(0, 150), rnd(1, 300)], walls=40, steps=20, action_seed=18),
+        Scenario("battle_events", "battle", 45, place=[rnd(0, 300), rnd(1, 300)], steps=24, action_seed=19,
+                 over={"small": {"hp": 4, "damage": 3}},
+                 events={5: [("add", 0, "random", {"n": 80}), ("walls", "random", {"n": 30})],
+                         9: [("add", 1, "custom", {"pos": [(1, 1), (2, 2), (2, 2), (43, 43), (0, 0)]}),
+                             ("walls", "fill", {"pos": (20, 20), "size": (3, 2)})],
+                         14: [("reset", [(0, "random", {"n": 200}), (1, "fill", {"pos": (5, 5), "size": (10, 12)})])]}),
         Scenario("battle_one_side", "battle", 12, place=[rnd(0, 60), rnd(1, 3)], steps=40, action_seed=14,
                  over={"small": {"damage": 12}}),
     ]
