@@ -1,0 +1,145 @@
+"""GPU tests at BASELINE.json's full size through size-independent properties of the domain, plus equivalence of the
+host-buffer ABI and the device-resident ABI.  (Bit-exact comparison with the oracle at full size is
+tests/test_gpu_parity.py::test_full_size_battle_two_steps.)"""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _make(game, size, n, seed=12345, over=None):
+    import magent_amd
+    env = magent_amd.GridWorld(H.config_for(game, size, **(over or {})), lib=H.HIP_LIB)
+    env.set_seed(seed)
+    env.reset()
+    for h in env.get_handles():
+        env.add_agents(h, "random", n=n)
+    return env
+
+
+def test_full_size_invariants():
+    """battle 1000x1000, 2x400k agents, 6 steps on the device-resident path"""
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    env = _make("battle", 1000, 400000, over={"small": {"hp": 4, "damage": 3}})   # low hp: many deaths per step
+    handles = env.get_handles()
+    W = 1000
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    total_dead = 0
+    for step in range(6):
+        cells_all, n_alive_all = [], 0
+        for g, h in enumerate(handles):
+            n = env.get_num(h)
+            view, feat = env.get_observation_device(h)
+            view2, feat2 = env.get_observation_device(h)
+            pos = env.get_info_device(h, "pos", torch.empty((n, 2), dtype=torch.int32, device=dev))
+            hp = env.get_info_device(h, "hp", torch.empty(n, dtype=torch.float32, device=dev))
+            env.sync()
+            # idempotence: rendering twice gives the same bits
+            assert torch.equal(view.view(torch.int32), view2.view(torch.int32)) and torch.equal(feat, feat2)
+            # every agent sees itself in the centre: own "has" = 1, own hp channel = hp / type.hp (all alive here)
+            assert bool((view[:, 6, 6, 1] == 1).all())
+            assert torch.equal(view[:, 6, 6, 2], hp / 4.0)
+            # wall channel: 1 exactly where the window leaves the inner map (x or y == 0 or W-1), inside the view range
+            xs, ys = pos[:, 0].long(), pos[:, 1].long()
+            left = view[:, 6, :, 0]                                   # centre row, 13 columns
+            col = torch.arange(13, device=dev)[None, :] - 6 + xs[:, None]
+            assert torch.equal(left, ((col == 0) | (col == W - 1)).float())
+            # minimap channels: own-group map sums to 1 (+1 self marker), float tolerance 1e-4
+            s_own = view[:, :, :, 3].sum(dim=(1, 2))
+            assert torch.allclose(s_own, torch.full_like(s_own, 2.0), atol=1e-3)
+            # features: x / w and y / h in the last two slots
+            # (expected values by numpy on the host: torch's device division is not IEEE-rounded, the engine's is)
+            fx = pos[:, 0].cpu().numpy().astype(np.float32) / np.float32(W)
+            fy = pos[:, 1].cpu().numpy().astype(np.float32) / np.float32(W)
+            assert np.array_equal(feat[:, 32].cpu().numpy(), fx) and np.array_equal(feat[:, 33].cpu().numpy(), fy)
+            cells_all.append(ys * W + xs)
+            n_alive_all += n
+            env.set_action_device(h, torch.randint(21, (n,), dtype=torch.int32, device=dev, generator=gen))
+            torch.cuda.synchronize()
+        # no two agents share a cell
+        cells = torch.cat(cells_all)
+        assert torch.unique(cells).numel() == cells.numel() == n_alive_all
+        env.step()
+        expect = []
+        for h in handles:
+            n = env.get_num(h)
+            alive = env.get_info_device(h, "alive", torch.empty(n, dtype=torch.uint8, device=dev))
+            hp = env.get_info_device(h, "hp", torch.empty(n, dtype=torch.float32, device=dev))
+            rew = env.get_reward_device(h)
+            env.sync()
+            assert bool(torch.isfinite(rew).all())
+            assert torch.equal(alive.bool(), hp >= 0)                 # dead iff hp < 0 (GridWorld.h:205)
+            # dead_penalty overwrites what was accumulated (GridWorld.h:207); a victim whose own attack landed before it
+            # died still collects the 'attack' rule bonus afterwards (RewardEngine loops over dead agents too)
+            rd = rew[~alive.bool()]
+            lo, hi = np.float32(-0.1), np.float32(-0.1) + np.float32(0.2)
+            assert bool(((rd == float(lo)) | (rd == float(hi))).all())
+            dead = int((~alive.bool()).sum())
+            total_dead += dead
+            expect.append(n - dead)
+        env.clear_dead()
+        assert [env.get_num(h) for h in handles] == expect            # conservation
+        env.clear_dead()                                              # a second clear_dead removes nobody
+        assert [env.get_num(h) for h in handles] == expect
+    assert total_dead > 10000
+
+
+def test_host_and_device_abi_agree():
+    """the reference ABI (numpy buffers) and the device-resident ABI return the same bits"""
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    env = _make("gather", 120, 3000)
+    handles = env.get_handles()
+    rs = np.random.RandomState(3)
+    for step in range(5):
+        for h in handles:
+            n = env.get_num(h)
+            v_host, f_host = env.get_observation(h)
+            v_dev, f_dev = env.get_observation_device(h)
+            env.sync()
+            assert v_dev.cpu().numpy().tobytes() == v_host.tobytes() and f_dev.cpu().numpy().tobytes() == f_host.tobytes()
+        acts = rs.randint(33, size=env.get_num(handles[1])).astype(np.int32)
+        env.set_action_device(handles[1], torch.from_numpy(acts).to(dev))
+        torch.cuda.synchronize()
+        env.step()
+        for h in handles:
+            r_dev = env.get_reward_device(h)
+            env.sync()
+            assert r_dev.cpu().numpy().tobytes() == env.get_reward(h).tobytes()
+            n = env.get_num(h)
+            p_dev = env.get_info_device(h, "pos", torch.empty((n, 2), dtype=torch.int32, device=dev))
+            env.sync()
+            assert np.array_equal(p_dev.cpu().numpy(), env.get_pos(h))
+        env.clear_dead()
+
+
+def test_two_environments_in_one_process_are_independent():
+    """no global state: two engines stepped alternately give what each gives alone"""
+    a = H.run(H.scenarios()["battle_brawl"], H.HIP_LIB)
+    sc1, sc2 = H.scenarios()["battle_brawl"], H.scenarios()["gather"]
+    env1, h1 = sc1.build(H.HIP_LIB)
+    env2, h2 = sc2.build(H.HIP_LIB)
+    rs1, rs2 = np.random.RandomState(sc1.action_seed), np.random.RandomState(sc2.action_seed)
+    for step in range(10):
+        for g, h in enumerate(h1):
+            v, f = env1.get_observation(h)
+            assert v.tobytes() == a[step]["view%d" % g].tobytes()
+            env1.get_agent_id(h)
+            env1.set_action(h, rs1.randint(21, size=env1.get_num(h)).astype(np.int32))
+        env2.get_observation(h2[1])
+        env2.set_action(h2[1], rs2.randint(33, size=env2.get_num(h2[1])).astype(np.int32))
+        env2.step()
+        env1.step()
+        for g, h in enumerate(h1):
+            assert env1.get_reward(h).tobytes() == a[step]["reward%d" % g].tobytes()
+        env2.clear_dead()
+        env1.clear_dead()
