@@ -1,7 +1,11 @@
 // engine_host.h -- host-side classes of the engine (definitions in engine.hip, C-ABI in runtime_api.hip).
 #pragma once
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -57,6 +61,23 @@ struct HostGroup {
 struct HostSymbol { int group = 0, index = 0; };
 struct HostNode { int op = OP_NULL; std::vector<int> raw; };
 struct HostRule { int on = 0; std::vector<int> recv; std::vector<float> val; bool terminal = false; };
+
+// a few persistent worker threads that split one large memcpy (pinned staging -> caller's pageable buffer)
+class CopyPool {
+public:
+    explicit CopyPool(int n_threads);
+    ~CopyPool();
+    void copy(void *dst, const void *src, size_t bytes);   // returns when done
+private:
+    void worker(int id);
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    char *dst = nullptr; const char *src = nullptr; size_t bytes = 0;
+    unsigned long long generation = 0;
+    int pending = 0;
+    bool stop = false;
+};
 
 class Env {
 public:
@@ -118,6 +139,7 @@ private:
     bool host_blank(int x, int y) const;
     void host_random_blank(int &ox, int &oy);
     void plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *feat);
+    void copy_out(void *host_dst, const void *dev_src, size_t bytes);
     int n_channel() const;
     int feature_size(int g) const;
 
@@ -156,6 +178,13 @@ private:
     float *d_stage_view = nullptr, *d_stage_feat = nullptr; size_t stage_view_cap = 0, stage_feat_cap = 0;
     unsigned char *d_stage_small = nullptr; size_t stage_small_cap = 0;
     std::vector<int> h_occ; bool h_occ_valid = false;
+    // pipelined device -> pageable-host copy: pinned ring + worker threads
+    static constexpr int COPY_RING = 3;
+    static constexpr size_t COPY_CHUNK = 32u << 20;
+    char *h_ring[COPY_RING] = {nullptr, nullptr, nullptr};
+    hipEvent_t ring_ev[COPY_RING] = {};
+    hipStream_t copy_stream{};
+    CopyPool *pool = nullptr;
     std::vector<int> shuffle_perm;
 };
 

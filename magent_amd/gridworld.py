@@ -136,11 +136,13 @@ class GridWorld(object):
 
     # ------------------------------------------------------------------ run (host buffers: reference ABI)
     def _buf(self, which, g, shape):
+        """observation buffer of group g: grown when the group grows, otherwise the same memory (a leading slice) --
+        like the reference's in-place resize (gridworld.py:203-213) it keeps the pages touched and the address stable"""
         cache = self._obs_cache[which]
         buf = cache.get(g)
-        if buf is None or buf.shape != shape:
+        if buf is None or buf.shape[1:] != shape[1:] or buf.shape[0] < shape[0]:
             buf = cache[g] = np.empty(shape, dtype=np.float32)
-        return buf
+        return buf[:shape[0]]
 
     def get_observation(self, handle):
         """-> (view float32[n,H,W,C], feature float32[n,F]); buffers are reused between calls like the reference"""
