@@ -1,0 +1,148 @@
+"""The callers of the hot path: model hosting, episode buffer, the PyTorch DQN that stands where
+the reference keeps its TensorFlow one, and the reference's own examples/train_battle.py running UNMODIFIED on the
+`magent` import name.  CPU tests drive the CPU oracle as the engine (no GPU here); the gpu test drives the HIP engine."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+ROOT = H.ROOT
+
+
+def test_piecewise_decay_and_friends():
+    from magent_amd import utility as U
+    assert U.piecewise_decay(0, [0, 700, 1400], [1, 0.2, 0.05]) == 1
+    assert abs(U.piecewise_decay(350, [0, 700, 1400], [1, 0.2, 0.05]) - 0.6) < 1e-12
+    assert U.piecewise_decay(5000, [0, 700, 1400], [1, 0.2, 0.05]) == 0.05
+    assert U.linear_decay(10, 100, 0.1) == pytest.approx(0.91)
+    assert U.rec_round([1.234, [2.345, 3.456]]) == [1.23, [2.35, 3.46]] or U.rec_round([1.234, [2.345, 3.456]])[0] == 1.23
+
+
+def test_episodes_buffer_tracks_a_capped_random_subset():
+    from magent_amd.utility import EpisodesBuffer
+    np.random.seed(0)
+    buf = EpisodesBuffer(capacity=5)
+    ids = np.arange(100, 120, dtype=np.int32)
+    views, feats = np.random.rand(20, 3, 3, 2).astype(np.float32), np.random.rand(20, 4).astype(np.float32)
+    alive = np.ones(20, dtype=bool); alive[3] = False
+    for t in range(3):
+        buf.record_step(ids, (views + t, feats + t), np.arange(20), np.full(20, float(t)), alive)
+    eps = list(buf.episodes())
+    assert len(eps) == 5 and buf.is_full
+    for key, e in buf.buffer.items():
+        i = key - 100
+        assert len(e.rewards) == 3 and e.rewards == [0.0, 1.0, 2.0] and e.actions == [i, i, i]
+        assert np.array_equal(e.views[2], views[i] + 2) and e.terminal == (i == 3)
+    new_ids = np.arange(200, 210, dtype=np.int32)     # a full buffer admits nobody new
+    buf.record_step(new_ids, (views[:10], feats[:10]), np.zeros(10), np.zeros(10), np.ones(10, bool))
+    assert len(buf.buffer) == 5
+
+
+def _tiny_env(lib):
+    import magent_amd
+    env = magent_amd.GridWorld("battle", lib=lib, map_size=20)
+    env.reset()
+    h0, h1 = env.get_handles()
+    env.add_agents(h0, "random", n=20)
+    env.add_agents(h1, "random", n=20)
+    return env, (h0, h1)
+
+
+def _play_round(env, handles, models, steps, eps=1.0):
+    """the call sequence of examples/train_battle.py:61-109"""
+    for _ in range(steps):
+        obs, ids, acts = {}, {}, {}
+        for i, h in enumerate(handles):
+            obs[i] = env.get_observation(h)
+            ids[i] = env.get_agent_id(h)
+            models[i].infer_action(obs[i], ids[i], "e_greedy", eps, block=False)
+        for i, h in enumerate(handles):
+            acts[i] = models[i].fetch_action()
+            env.set_action(h, acts[i])
+        done = env.step()
+        for i, h in enumerate(handles):
+            models[i].sample_step(env.get_reward(h), env.get_alive(h), block=False)
+        env.clear_dead()
+        for m in models:
+            m.check_done()
+        if done:
+            break
+    for m in models:
+        m.train(print_every=1000, block=False)
+    return [m.fetch_train() for m in models]
+
+
+def test_dqn_learns_something_on_cpu(tmp_path):
+    import torch
+    import magent_amd
+    from magent_amd.builtin.torch_model import DeepQNetwork
+    from magent_amd.model import ProcessingModel
+    torch.manual_seed(0); np.random.seed(0)
+    env, handles = _tiny_env(H.ensure_oracle())
+    models = [ProcessingModel(env, h, "m%d" % i, 20000 + i, 100, DeepQNetwork, batch_size=32, memory_size=4096,
+                              target_update=50, train_freq=2, device="cpu") for i, h in enumerate(handles)]
+    before = [p.detach().clone() for p in models[0].model.qnet.parameters()]
+    results = _play_round(env, handles, models, steps=25)
+    for loss, value in results:
+        assert np.isfinite(loss) and np.isfinite(value) and loss > 0
+    after = list(models[0].model.qnet.parameters())
+    assert any(not torch.equal(a, b) for a, b in zip(after, before))
+    # acting: greedy is deterministic, epsilon = 1 is uniform over the action space
+    v, f = env.get_observation(handles[0])
+    a1 = models[0].model.infer_action((v, f), None, policy="greedy")
+    a2 = models[0].model.infer_action((v, f), None, policy="greedy")
+    assert a1.dtype == np.int32 and np.array_equal(a1, a2) and a1.min() >= 0 and a1.max() < 21
+    # checkpoints round-trip
+    models[0].save(str(tmp_path), 3)
+    fresh = DeepQNetwork(env, handles[0], "m0", memory_size=16, device="cpu")
+    fresh.load(str(tmp_path), 3)
+    assert np.array_equal(fresh.infer_action((v, f), None, policy="greedy"), a1)
+
+
+def test_magent_alias_exposes_the_reference_names():
+    import magent
+    from magent.builtin.tf_model import DeepQNetwork
+    from magent.builtin.rule_model import RandomActor
+    assert magent.GridWorld is magent.gridworld.GridWorld and magent.ProcessingModel is magent.model.ProcessingModel
+    assert callable(magent.utility.init_logger) and callable(magent.utility.sample_observation)
+    assert DeepQNetwork.__name__ == "DeepQNetwork" and RandomActor is not None
+    cfg = magent.gridworld.Config()
+    cfg.set({"map_width": 10, "map_height": 10})
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/examples/train_battle.py"), reason="reference examples not present")
+def test_reference_train_battle_runs_unmodified(tmp_path):
+    """examples/train_battle.py, byte for byte the reference's file, against `import magent` = this repository.
+    Engine = CPU oracle here (no GPU in this container); on a GPU box the same command runs the HIP engine."""
+    (tmp_path / "build").mkdir()
+    env = dict(os.environ, PYTHONPATH=ROOT, MAGENT_AMD_LIB=H.ensure_oracle(), OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, "/root/reference/examples/train_battle.py", "--train", "--n_round", "1", "--map_size", "20"],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "===== train =====" in p.stdout and "round time" in p.stdout
+
+
+@pytest.mark.gpu
+def test_training_round_on_gpu():
+    """same loop, HIP engine + DQN on the same GPU"""
+    import torch
+    from magent_amd.builtin.torch_model import DeepQNetwork
+    from magent_amd.model import ProcessingModel
+    assert torch.cuda.is_available()
+    env, handles = _tiny_env(H.HIP_LIB)
+    models = [ProcessingModel(env, h, "g%d" % i, 20000 + i, 100, DeepQNetwork, batch_size=32, memory_size=4096,
+                              target_update=50, train_freq=2) for i, h in enumerate(handles)]
+    assert models[0].model.device.type == "cuda"
+    for loss, value in _play_round(env, handles, models, steps=25):
+        assert np.isfinite(loss) and np.isfinite(value)
+    # device-resident observations feed the network without touching the host
+    view, feat = env.get_observation_device(handles[0])
+    env.sync()
+    acts = models[0].model.infer_action((view, feat), None, policy="greedy")
+    assert isinstance(acts, torch.Tensor) and acts.dtype == torch.int32 and acts.is_cuda
+    env.set_action_device(handles[0], acts)
+    torch.cuda.synchronize()
