@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <map>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -198,7 +200,7 @@ Env::~Env() {
     (void)hipStreamSynchronize(stream);
     for (auto &g : groups) free_group(g);
     dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_counters); dfree(d_gtab); dfree(d_ttab);
-    dfree(d_delta); dfree(d_mask); dfree(d_mini); dfree(d_minif); dfree(d_sums); dfree(d_rank); dfree(d_shuf); dfree(d_actions);
+    dfree(d_delta); dfree(d_mask); dfree(d_mini); dfree(d_minif); dfree(d_sums); dfree(d_rank); dfree(d_shuf); dfree(d_events); dfree(d_actions);
     dfree(d_stage_view); dfree(d_stage_feat); dfree(d_stage_small);
     if (pool) {
         delete pool;
@@ -448,6 +450,7 @@ void Env::reset() {
     use_device();
     HIP_OK(hipStreamSynchronize(stream));
     id_counter = 0;
+    file_ct++; frame_ct = 0;   // RenderGenerator::next_file (GridWorld.cc:97)
     large_map_mode = width * height > 99 * 99;
     const int n_sep = large_map_mode ? (width * height > 1000 * 1000 ? 16 : 8) : 1;
     bandwidth = (width + n_sep - 1) / n_sep;
@@ -767,9 +770,18 @@ void Env::step(int *done) {
             if (!read_changed()) break;
             if (iters > 100000) fatal("attack resolution did not converge");
         }
+        if (!first_render) {   // attack events are recorded once rendering has started (GridWorld.cc:484,508)
+            grow(d_events, events_cap, (size_t)A, stream);
+            launch_attack_events(stream, W, use_b, d_events);
+            std::vector<int4> ev(A);
+            HIP_OK(hipMemcpyAsync(ev.data(), d_events, sizeof(int4) * A, hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            attack_events.clear();
+            for (const int4 &e : ev) if (e.w) attack_events.push_back({e.x, e.y, e.z});
+        }
         launch_attack_apply(stream, W, d_gtab, d_ttab, use_b, attack_kmax);
         last_attack_iters = iters;
-    }
+    } else if (!first_render) attack_events.clear();
     // ---- starve / recover
     if (total_n > 0) {
         ProfScope p(*this, "starve");
@@ -939,7 +951,8 @@ void Env::info_host(int g, const char *name, void *buf) {
         }
         return;
     }
-    if (k == "render_window_info") {  // GridWorld.cc:797-834; attack events are not recorded by this engine
+    if (k == "render_window_info") {  // GridWorld.cc:797-834
+        first_render = false;
         int x1 = ib[0], y1 = ib[1], x2 = ib[2], y2 = ib[3], ct = 1;
         HIP_OK(hipStreamSynchronize(stream));
         for (size_t i = 0; i < groups.size(); i++) {
@@ -956,11 +969,80 @@ void Env::info_host(int g, const char *name, void *buf) {
                 ct++;
             }
         }
-        ib[0] = ct - 1; ib[1] = 0;
+        ib[0] = ct - 1; ib[1] = (int)attack_events.size();
         return;
     }
-    if (k == "attack_event") return;
+    if (k == "attack_event") {
+        for (size_t i = 0; i < attack_events.size(); i++) { ib[3 * i] = attack_events[i].id; ib[3 * i + 1] = attack_events[i].x; ib[3 * i + 2] = attack_events[i].y; }
+        return;
+    }
     fatal("unsupported info name in GridWorld::get_info : %s", name);
+}
+
+// ------------------------------------------------------------------------------------------------ render (text dump)
+// RenderGenerator::gen_config (RenderGenerator.cc:57-105)
+void Env::gen_render_config() {
+    std::ofstream f(render_dir + "/config.json");
+    const int colors[][3] = {{192, 64, 64}, {64, 64, 192}, {64, 192, 64}, {64, 64, 64}};
+    auto rgba = [](int r, int g, int b, float a) { std::stringstream ss; ss << "\"rgba(" << r << "," << g << "," << b << "," << a << ")\""; return ss.str(); };
+    auto kv = [&](const char *key, auto value, bool last = false) { f << "\"" << key << "\": " << value; f << (last ? "" : ",") << std::endl; };
+    f << "{" << std::endl;
+    kv("width", width); kv("height", height); kv("static-file", "\"static.map\"");
+    kv("obstacle-style", rgba(127, 127, 127, 1)); kv("dynamic-file-directory", "\".\"");
+    kv("attack-style", rgba(63, 63, 63, 0.8f)); kv("minimap-width", 300); kv("minimap-height", 250);
+    f << "\"group\" : [" << std::endl;
+    for (size_t i = 0; i < groups.size(); i++) {
+        const HostType &t = *groups[i].type;
+        const int *c = colors[i % 4];
+        f << "{" << std::endl;
+        kv("height", t.length); kv("width", t.width); kv("style", rgba(c[0], c[1], c[2], 1)); kv("anchor", "[0, 0]");
+        kv("max-speed", (int)t.speed); kv("speed-style", rgba(c[0], c[1], c[2], 0.01f));
+        kv("vision-radius", t.view_radius); kv("vision-angle", t.view_angle); kv("vision-style", rgba(c[0], c[1], c[2], 0.2f));
+        kv("attack-radius", t.attack_radius); kv("attack-angle", t.attack_angle); kv("attack-style", rgba(c[0], c[1], c[2], 0.1f));
+        kv("broadcast-radius", 1, true);
+        f << (i + 1 == groups.size() ? "}" : "},") << std::endl;
+    }
+    f << "]" << std::endl << "}" << std::endl;
+}
+
+// GridWorld::render (GridWorld.cc:939-949) + RenderGenerator::render_a_frame (RenderGenerator.cc:108-185)
+void Env::render() {
+    if (!device_ready) fatal("render called before reset");
+    use_device();
+    if (first_render) {
+        first_render = false;
+        if (!render_dir.empty()) gen_render_config();
+    }
+    if (render_dir.empty()) return;
+    HIP_OK(hipStreamSynchronize(stream));
+    std::ofstream fout(render_dir + "/video_" + std::to_string(file_ct) + ".txt", frame_ct == 0 ? std::ios::out : std::ios::app);
+    if (frame_ct == 0) {
+        download_occ();
+        size_t n_wall = 0;
+        for (int c : h_occ) n_wall += c == OCC_WALL;
+        fout << "W " << n_wall << std::endl;
+        for (size_t c = 0; c < h_occ.size(); c++) if (h_occ[c] == OCC_WALL) fout << (c % width) << " " << (c / width) << std::endl;
+    }
+    size_t n_agents = 0;
+    for (auto &g : groups) n_agents += g.n;
+    fout << "F " << n_agents << " " << attack_events.size() << " " << 0 << std::endl;
+    for (size_t i = 0; i < groups.size(); i++) {
+        const int n = groups[i].n;
+        if (n == 0) continue;
+        std::vector<int> xs(n), ys(n), ids(n);
+        std::vector<float> hp(n);
+        HIP_OK(hipMemcpy(xs.data(), groups[i].cur.x, sizeof(int) * n, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(ys.data(), groups[i].cur.y, sizeof(int) * n, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(ids.data(), groups[i].cur.id, sizeof(int) * n, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(hp.data(), groups[i].cur.hp, sizeof(float) * n, hipMemcpyDeviceToHost));
+        const float type_hp = groups[i].type->hp;
+        for (int j = 0; j < n; j++) {
+            int pct = std::min(std::max(0, int(100 * hp[j] / type_hp)), 100);
+            fout << ids[j] << " " << pct << " " << 270 << " " << xs[j] << " " << ys[j] << " " << i << std::endl;  // dir NORTH
+        }
+    }
+    for (const AttackEvent &e : attack_events) fout << 0 << " " << e.id << " " << e.x << " " << e.y << std::endl;
+    if (frame_ct++ > frame_per_file) { frame_ct = 0; file_ct++; }
 }
 
 void Env::sync() {

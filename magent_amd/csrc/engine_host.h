@@ -99,6 +99,7 @@ public:
     void get_reward_host(int g, float *out);
     void clear_dead();
     void info_host(int g, const char *name, void *buf);
+    void render();
 
     // device-resident extensions
     void observe_device(int g, float *view, float *feat);
@@ -148,6 +149,13 @@ private:
     bool minimap_mode = false, large_map_mode = false;
     int bandwidth = 1;
     std::string render_dir;
+    // text video dump (reference RenderGenerator.{h,cc}); host-side, off the hot path
+    bool first_render = true;
+    int file_ct = 0, frame_ct = 0, frame_per_file = 10000;
+    struct AttackEvent { int id, x, y; };
+    std::vector<AttackEvent> attack_events;
+    int4 *d_events = nullptr; size_t events_cap = 0;
+    void gen_render_config();
     MinStd rng;
     std::map<std::string, HostType> types;
     std::vector<HostGroup> groups;

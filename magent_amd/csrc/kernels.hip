@@ -585,6 +585,23 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     G.next_reward[i] = nr;
 }
 
+// render support: ev[rank] = {attacker id, target x, target y, 1} for every attack that was executed (attacker alive at
+// its turn), in the order the reference appends them (GridWorld.cc:483-485: before the blank-target test, so blank and
+// out-of-board targets are recorded too); {.,.,.,0} for list entries whose attacker was already dead
+__global__ void __launch_bounds__(256) k_attack_events(WorldView W, int use_b, int4 *ev) {
+    const int g = blockIdx.y;
+    const GroupDev G = W.grp[g];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.n) return;
+    const int pend = G.pend[i];
+    if ((pend & ~PEND_ARG) != PEND_ATTACK) return;
+    const unsigned my_rank = G.key[i];
+    const int dr = (use_b ? G.drank_b : G.drank_a)[i];
+    int2 d = W.delta[W.type[g].attack_off + (pend & PEND_ARG)];
+    const bool executed = dr != -1 && (unsigned)dr > my_rank;
+    ev[my_rank] = make_int4(G.id[i], G.x[i] + d.x, G.y[i] + d.y, executed ? 1 : 0);
+}
+
 // removes the agents that died in this attack phase from the map (Map::remove_agent, Map.cc:272), after every
 // reader of the phase-start map is done
 __global__ void __launch_bounds__(256) k_attack_bury(WorldView W, int use_b) {
@@ -900,6 +917,9 @@ void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank) {
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax) {
     size_t lds = (size_t)kmax * ATT_THREADS * 8;
     hipLaunchKernelGGL((k_attack_eval<false>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, use_b, (const unsigned *)W.claim, kmax);
+}
+void launch_attack_events(hipStream_t s, const WorldView &W, int use_b, int4 *ev) {
+    hipLaunchKernelGGL(k_attack_events, grid_all(W, 256), dim3(256), 0, s, W, use_b, ev);
 }
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax) {
     size_t lds = (size_t)kmax * ATT_THREADS * 8;

@@ -47,6 +47,7 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank);
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax);
+void launch_attack_events(hipStream_t s, const WorldView &W, int use_b, int4 *ev);
 void launch_starve(hipStream_t s, const WorldView &W);
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab);

@@ -29,8 +29,8 @@ int env_set_action(EnvHandle game, GroupHandle group, const int *actions) { E(ga
 int env_step(EnvHandle game, int *done) { E(game)->step(done); return 0; }
 int env_get_reward(EnvHandle game, GroupHandle group, float *buffer) { E(game)->get_reward_host(group, buffer); return 0; }
 int env_get_info(EnvHandle game, GroupHandle group, const char *name, void *buffer) { E(game)->info_host(group, name, buffer); return 0; }
-int env_render(EnvHandle) { return 0; }            // text video dump: host-side, off the hot path
-int env_render_next_file(EnvHandle) { return 0; }
+int env_render(EnvHandle game) { E(game)->render(); return 0; }   // text video dump (RenderGenerator): host-side, off the hot path
+int env_render_next_file(EnvHandle) { return 0; }                 // the reference casts the handle to DiscreteSnake here (runtime_api.cc:85-88)
 
 int gridworld_register_agent_type(EnvHandle game, const char *name, int n, const char **keys, float *values) {
     E(game)->register_agent_type(name, n, keys, values); return 0;

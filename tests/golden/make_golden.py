@@ -66,6 +66,17 @@ def main():
     with open(os.path.join(HERE, "digests.json"), "w") as f:
         json.dump(digests, f, indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(HERE, "kat_appendix_b.npz"), **appendix_b(H.REF_LIB))
+    # text video dump of the reference's RenderGenerator for a short episode
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    files = H.render_episode(H.REF_LIB, tmp)
+    out = os.path.join(HERE, "render_battle16")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    for name, data in files.items():
+        open(os.path.join(out, name), "wb").write(data)
+    print("render files:", {k: len(v) for k, v in files.items()})
 
 
 if __name__ == "__main__":

@@ -166,6 +166,24 @@ def run(sc, lib, record=None):
     return out
 
 
+def render_episode(lib, out_dir, steps=6):
+    """a short battle with the text video dump on: returns {file name: bytes} of what env.render() wrote"""
+    sc = Scenario("render", "battle", 16, place=[(0, "random", {"n": 30}), (1, "random", {"n": 30})], steps=steps, action_seed=4,
+                  over={"small": {"hp": 3, "damage": 2}})
+    env, handles = sc.build(lib)
+    env.set_render_dir(out_dir)
+    rs = np.random.RandomState(sc.action_seed)
+    for step in range(steps):
+        for h in handles:
+            env.set_action(h, rs.randint(21, size=env.get_num(h)).astype(np.int32))
+        env.step()
+        env.render()                       # before clear_dead, like examples/train_battle.py:88-96
+        if step == 2:
+            env._get_render_info((0, 15), (0, 15))
+        env.clear_dead()
+    return {name: open(os.path.join(out_dir, name), "rb").read() for name in sorted(os.listdir(out_dir))}
+
+
 def digest(trajectory):
     """SHA-256 over every array of every step (dtype + shape + bytes), in key order"""
     h = hashlib.sha256()

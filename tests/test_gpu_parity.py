@@ -57,3 +57,14 @@ def test_full_size_battle_two_steps(oracle):
     for s in range(2):
         for k in sorted(want[s]):
             assert got[s][k] == want[s][k], "step %d %s differs" % (s, k)
+
+
+def test_render_text_dump_matches_reference(tmp_path):
+    """env.render(): config.json and video_N.txt byte-identical to what the reference's RenderGenerator wrote
+    (tests/golden/render_battle16, generated from the compiled reference), attack events included"""
+    got = H.render_episode(H.HIP_LIB, str(tmp_path))
+    gold_dir = os.path.join(H.GOLDEN_DIR, "render_battle16")
+    want = {name: open(os.path.join(gold_dir, name), "rb").read() for name in sorted(os.listdir(gold_dir))}
+    assert sorted(got) == sorted(want)
+    for name in want:
+        assert got[name] == want[name], name
