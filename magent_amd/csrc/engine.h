@@ -4,8 +4,9 @@
 //   * every group is a set of struct-of-arrays device buffers indexed by the agent's position in the group
 //     (the reference's vector<Agent*> order), so all per-agent kernels load/store fully coalesced;
 //   * the map is one int32 per cell (`occ`): EMPTY, WALL or a packed agent reference (group, index);
-//   * `viewcell` is a painted copy of the map for the observation renderer: {group code, hp / type.hp} per cell,
-//     8 bytes, so the renderer does ONE coalesced load per cell and no dependent gather;
+//   * `viewcell` is a painted copy of the map for the observation renderer: {group code, hp / type.hp} per cell
+//     (one 32-bit word when there are <= 3 groups, else 8 bytes), so the renderer does ONE load per cell and no
+//     dependent gather;
 //   * order-dependent phases (attack, move) do not keep lists: each agent carries its pending action and an order
 //     key, and the sequential result is recovered by fixed-point / pointer-jumping kernels.
 #pragma once
@@ -75,7 +76,7 @@ struct WorldView {
     int large_map, bandwidth;    // reference large_map_mode striping (GridWorld.cc:75-85, 407-425)
 };
 
-constexpr int CTR_CHANGED = 0, CTR_ATTACK = 1, CTR_DEAD = 2, CTR_TRIGGER = 16, CTR_TOTAL = 64;
+constexpr int CTR_CHANGED = 0, CTR_ATTACK = 1, CTR_DEAD = 2, CTR_PACK_OVERFLOW = 12, CTR_TRIGGER = 16, CTR_TOTAL = 64;
 
 // observation render parameters for one get_observation(group) call
 struct RenderArgs {

@@ -814,6 +814,7 @@ void Env::step(int *done) {
         groups[g].acted = false;
         if (groups[g].n - groups[g].h_dead > 0) live++;
     }
+    if (c[CTR_PACK_OVERFLOW]) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
     *done = live < (int)groups.size();   // GridWorld.cc:619-624
     for (size_t k = 0; k < rules.size(); k++) if (c[CTR_TRIGGER + k] && rules[k].terminal) *done = 1;
     // attack count and rule triggers are per step; dead_ct lives until clear_dead

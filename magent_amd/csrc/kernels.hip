@@ -47,6 +47,12 @@ __global__ void k_set_tables(WorldView W, GroupDev *gtab, TypeDev *ttab) {
 // ------------------------------------------------------------------------------------------------ paint
 // viewcell[c] = {group | EMPTY | WALL, bits(hp / type.hp)}: one pass over the map, coalesced 4 B in / 8 B out.
 // The division is the reference's `p->get_hp() / p->get_type().hp` (Map.cc:197), IEEE round-to-nearest.
+// With at most 3 groups the record packs into ONE 32-bit word: hp / type.hp lies in [0, 1] (hp is capped at type.hp
+// and agents with hp < 0 are off the map), so the two top bits of its float pattern are free for the group; EMPTY and
+// WALL are the two all-ones-ish sentinels.  Half the footprint: the 1000 x 1000 map is 4 MB and lives in an XCD's L2.
+constexpr unsigned VC_EMPTY = 0xFFFFFFFFu, VC_WALL = 0xFFFFFFFEu;
+
+template <bool PACKED>
 __global__ void __launch_bounds__(256) k_paint(WorldView W, const GroupDev *gtab, const TypeDev *ttab) {
     const int ncell = W.w * W.h;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) {
@@ -57,7 +63,13 @@ __global__ void __launch_bounds__(256) k_paint(WorldView W, const GroupDev *gtab
             rec.x = g;
             rec.y = __float_as_int(__fdiv_rn(gtab[g].hp[i], ttab[g].hp));
         }
-        W.viewcell[c] = rec;
+        if (PACKED) {
+            unsigned v = o == OCC_EMPTY ? VC_EMPTY : o == OCC_WALL ? VC_WALL : (((unsigned)rec.x << 30) | (unsigned)rec.y);
+            if (o >= 0 && ((unsigned)rec.y >> 30)) W.counters[CTR_PACK_OVERFLOW] = 1;   // ratio outside [0, 2): never expected
+            ((unsigned *)W.viewcell)[c] = v;
+        } else {
+            W.viewcell[c] = rec;
+        }
     }
 }
 
@@ -109,7 +121,7 @@ __global__ void __launch_bounds__(256) k_minimap_norm(RenderArgs R, int G, const
 // in its own L2.
 constexpr int RENDER_WAVES = 4;
 
-template <bool VEC4, bool NT, int U>
+template <bool VEC4, bool NT, int U, bool PACKED>
 __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, RenderArgs R, RenderPlan P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int VHW = R.VH * R.VW, C = R.C, G = W.G;
@@ -148,7 +160,12 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, Rende
             const int vx = cellv[u] - vy * R.VW;
             const int mx = xv[u] + T.view_x1 + vx, my = yv[u] + T.view_y1 + vy;
             const bool in = valid[u] && mask[cellv[u]] && mx >= 0 && mx < W.w && my >= 0 && my < W.h;
-            recv[u] = in ? W.viewcell[my * W.w + mx] : make_int2(OCC_EMPTY, 0);
+            if (PACKED) {
+                const unsigned v = in ? ((const unsigned *)W.viewcell)[my * W.w + mx] : VC_EMPTY;
+                recv[u] = v >= VC_WALL ? make_int2(v == VC_WALL ? OCC_WALL : OCC_EMPTY, 0) : make_int2((int)(v >> 30), (int)(v & 0x3FFFFFFFu));
+            } else {
+                recv[u] = in ? W.viewcell[my * W.w + mx] : make_int2(OCC_EMPTY, 0);
+            }
             if (R.minimap) {
                 int j = R.g;
 #pragma unroll
@@ -854,7 +871,8 @@ void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const
     int ncell = W.w * W.h;
     int blocks = (ncell + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_paint, dim3(blocks), dim3(256), 0, s, W, gtab, ttab);
+    if (W.G <= 3) hipLaunchKernelGGL(k_paint<true>, dim3(blocks), dim3(256), 0, s, W, gtab, ttab);
+    else hipLaunchKernelGGL(k_paint<false>, dim3(blocks), dim3(256), 0, s, W, gtab, ttab);
 }
 
 void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts, float *mini) {
@@ -872,10 +890,15 @@ void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const
     if (R.n <= 0) return;
     size_t lds = (size_t)RENDER_WAVES * P.strip_floats * sizeof(float);
     dim3 grid(P.spans), block(64 * RENDER_WAVES);
-    if (!vec4) hipLaunchKernelGGL((k_render<false, false, 1>), grid, block, lds, s, W, R, P);
-    else if (P.unroll == 2) { if (nt) hipLaunchKernelGGL((k_render<true, true, 2>), grid, block, lds, s, W, R, P); else hipLaunchKernelGGL((k_render<true, false, 2>), grid, block, lds, s, W, R, P); }
-    else if (P.unroll == 4) { if (nt) hipLaunchKernelGGL((k_render<true, true, 4>), grid, block, lds, s, W, R, P); else hipLaunchKernelGGL((k_render<true, false, 4>), grid, block, lds, s, W, R, P); }
-    else { if (nt) hipLaunchKernelGGL((k_render<true, true, 1>), grid, block, lds, s, W, R, P); else hipLaunchKernelGGL((k_render<true, false, 1>), grid, block, lds, s, W, R, P); }
+    const bool packed = W.G <= 3;   // must match launch_paint
+#define RENDER_LAUNCH(V, N, UU, PK) hipLaunchKernelGGL((k_render<V, N, UU, PK>), grid, block, lds, s, W, R, P)
+#define RENDER_PK(V, N, UU) do { if (packed) RENDER_LAUNCH(V, N, UU, true); else RENDER_LAUNCH(V, N, UU, false); } while (0)
+    if (!vec4) RENDER_PK(false, false, 1);
+    else if (P.unroll == 2) { if (nt) RENDER_PK(true, true, 2); else RENDER_PK(true, false, 2); }
+    else if (P.unroll == 4) { if (nt) RENDER_PK(true, true, 4); else RENDER_PK(true, false, 4); }
+    else { if (nt) RENDER_PK(true, true, 1); else RENDER_PK(true, false, 1); }
+#undef RENDER_PK
+#undef RENDER_LAUNCH
 }
 
 void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4) {

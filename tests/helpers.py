@@ -80,7 +80,21 @@ def custom_chase(map_size):
     return cfg
 
 
-CUSTOM = {"tri": custom_tri, "chase": custom_chase}
+def custom_quad(map_size):
+    """four groups (the unpacked 8-byte view-cell format; 4 x 8 = 32 attack offsets fill the per-cell hit word)"""
+    cfg = gw.Config()
+    cfg.set({"map_width": map_size, "map_height": map_size, "minimap_mode": True, "embedding_size": 3})
+    t = cfg.register_agent_type("q", dict(width=1, length=1, hp=5, speed=2, view_range=gw.CircleRange(3), attack_range=gw.CircleRange(1.5),
+                                          damage=2, step_recover=0.05, step_reward=-0.01, kill_reward=2, dead_penalty=-0.3,
+                                          attack_penalty=-0.1))
+    gs = [cfg.add_group(t) for _ in range(4)]
+    syms = [gw.AgentSymbol(g, "any") for g in gs]
+    for i in range(4):
+        cfg.add_reward_rule(gw.Event(syms[i], "attack", syms[(i + 1) % 4]), receiver=syms[i], value=0.1 * (i + 1))
+    return cfg
+
+
+CUSTOM = {"tri": custom_tri, "chase": custom_chase, "quad": custom_quad}
 
 
 class Scenario(object):
@@ -241,6 +255,7 @@ def scenarios():
         Scenario("forest", "forest", 50, place=[rnd(0, 500), rnd(1, 250)], walls=60, steps=25, action_seed=15),
         Scenario("tri_rect", ("tri", 70, 45), 0, place=[rnd(0, 500), rnd(1, 400), rnd(2, 450)], walls=80, steps=25, action_seed=16),
         Scenario("tri_rect_large", ("tri", 150, 101), 0, place=[rnd(0, 3000), rnd(1, 3000), rnd(2, 2500)], steps=10, action_seed=17),
+        Scenario("quad", ("quad", 36), 0, place=[rnd(0, 150), rnd(1, 150), rnd(2, 150), rnd(3, 150)], steps=20, action_seed=22),
         Scenario("chase", ("chase", 40), 0, place=[rnd(0, 150), rnd(1, 300)], walls=40, steps=20, action_seed=18),
         Scenario("battle_events", "battle", 45, place=[rnd(0, 300), rnd(1, 300)], steps=24, action_seed=19,
                  over={"small": {"hp": 4, "damage": 3}},
