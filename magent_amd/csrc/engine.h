@@ -42,6 +42,7 @@ __host__ __device__ inline int ref_index(int r) { return r & REF_MASK; }
 struct TypeDev {
     float hp, damage, step_recover, kill_supply, kill_reward, dead_penalty, attack_penalty, step_reward;
     int attack_in_group;
+    int bw, bl;                  // body width (x) and length (y) in cells; the agent's position is its top-left cell
     int n_move, n_attack;        // action layout: [0, n_move) moves, [n_move, n_move + n_attack) attacks
     int move_off, attack_off;    // offsets into WorldView::delta (int2 {dx,dy} per action payload)
     int attack_bit;              // first bit of this group's attack offsets in the per-cell hit word
@@ -73,6 +74,7 @@ struct WorldView {
     TypeDev type[MAXG];
     GroupDev grp[MAXG];
     int any_kill_supply;
+    int any_multicell;           // some group has a body larger than one cell: generic move resolution
     int large_map, bandwidth;    // reference large_map_mode striping (GridWorld.cc:75-85, 407-425)
 };
 

@@ -280,7 +280,7 @@ void Env::register_agent_type(const char *name, int n, const char **keys, float 
             // accepted like the reference; never read on this path (offsets are recomputed, AgentType.cc:106-108)
         } else fatal("invalid agent config in AgentType::AgentType : %s", keys[i]);
     }
-    if (t.width != 1 || t.length != 1) fatal("agent type %s: multi-cell bodies (%dx%d) are not on the GPU path yet (SURVEY.md 8f rank 4)", name, t.width, t.length);
+    if (t.width < 1 || t.length < 1 || t.width > 16 || t.length > 16) fatal("agent type %s: body %dx%d out of range", name, t.width, t.length);
     if (t.can_absorb) fatal("agent type %s: can_absorb is outside the hot-path scope", name);
     if (t.view_angle < 180 || t.attack_angle < 180) fatal("agent type %s: sector ranges are outside the hot-path scope", name);
     if (std::fabs(t.view_angle - 360) > 1e-5 || std::fabs(t.attack_angle - 360) > 1e-5)
@@ -412,6 +412,7 @@ WorldView Env::view() const {
     W.w = width; W.h = height; W.G = (int)groups.size();
     W.occ = d_occ; W.viewcell = d_viewcell; W.claim = d_claim; W.delta = d_delta; W.mask = d_mask; W.counters = d_counters;
     W.any_kill_supply = any_kill_supply;
+    W.any_multicell = any_multicell;
     W.large_map = large_map_mode; W.bandwidth = bandwidth;
     for (int g = 0; g < W.G; g++) {
         W.type[g] = groups[g].tdev;
@@ -471,7 +472,7 @@ void Env::reset() {
     // per-type constant tables (action deltas, view masks) for the groups of this game
     std::vector<int2> delta;
     std::vector<unsigned char> mask;
-    any_kill_supply = 0;
+    any_kill_supply = 0; any_multicell = 0;
     int total_attack = 0;
     for (auto &g : groups) {
         HostType &t = *g.type;
@@ -479,6 +480,8 @@ void Env::reset() {
         d.hp = t.hp; d.damage = t.damage; d.step_recover = t.step_recover; d.kill_supply = t.kill_supply;
         d.kill_reward = t.kill_reward; d.dead_penalty = t.dead_penalty; d.attack_penalty = t.attack_penalty;
         d.step_reward = t.step_reward; d.attack_in_group = t.attack_in_group;
+        d.bw = t.width; d.bl = t.length;
+        if (t.width * t.length > 1) any_multicell = 1;
         d.n_move = t.move.count; d.n_attack = t.attack.count;
         d.move_off = (int)delta.size();
         for (int k = 0; k < t.move.count; k++) delta.push_back(make_int2(t.move.dx[k], t.move.dy[k]));
@@ -500,8 +503,10 @@ void Env::reset() {
         int k = 0;
         for (size_t a = 0; a < groups.size(); a++)
             if (a != t || groups[a].type->attack_in_group) k += groups[a].type->attack.count;
+        k *= groups[t].type->width * groups[t].type->length;   // every body cell can be hit with every offset
         attack_kmax = std::max(attack_kmax, k);
     }
+    if (attack_kmax > 256) fatal("attack ranges x body size too large for the LDS hit lists (%d > 256)", attack_kmax);
     if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
     if (n_channel() > 32) fatal("too many observation channels");
     dfree(d_delta); dfree(d_mask);
@@ -528,19 +533,22 @@ void Env::upload_occ() {
     paint_valid = false;
 }
 
-// Map::is_blank_area for a 1x1 body (Map.cc:454-470)
-bool Env::host_blank(int x, int y) const {
-    if (x < 0 || y < 0 || x + 1 >= width || y + 1 >= height) return false;
-    return h_occ[(size_t)y * width + x] == OCC_EMPTY;
+// Map::is_blank_area (Map.cc:454-470)
+bool Env::host_blank(int x, int y, int bw, int bl) const {
+    if (x < 0 || y < 0 || x + bw >= width || y + bl >= height) return false;
+    for (int i = 0; i < bw; i++)
+        for (int j = 0; j < bl; j++)
+            if (h_occ[(size_t)(y + j) * width + x + i] != OCC_EMPTY) return false;
+    return true;
 }
 
 // Map::get_random_blank (Map.cc:49-63): two RNG draws per try
-void Env::host_random_blank(int &ox, int &oy) {
+void Env::host_random_blank(int bw, int bl, int &ox, int &oy) {
     int tries = 0;
     while (true) {
-        int x = (int)rng() % (width - 1);
-        int y = (int)rng() % (height - 1);
-        if (host_blank(x, y)) { ox = x; oy = y; return; }
+        int x = (int)rng() % (width - bw);
+        int y = (int)rng() % (height - bl);
+        if (host_blank(x, y, bw, bl)) { ox = x; oy = y; return; }
         if (tries++ > width * height) fatal("cannot find a blank position in a filled map");
     }
 }
@@ -559,7 +567,7 @@ void Env::add_agents(int group, int n, const char *method, const int *px, const 
         c = OCC_WALL;
     };
     if (group == -1) {
-        if (m == "random") { for (int i = 0; i < n; i++) { int x, y; host_random_blank(x, y); add_wall(x, y); } }
+        if (m == "random") { for (int i = 0; i < n; i++) { int x, y; host_random_blank(1, 1, x, y); add_wall(x, y); } }
         else if (m == "custom") { for (int i = 0; i < n; i++) add_wall(px[i], py[i]); }
         else if (m == "fill") { for (int x = px[0]; x < px[0] + px[2]; x++) for (int y = px[1]; y < px[1] + px[3]; y++) add_wall(x, y); }
         else fatal("unsupported method in GridWorld::add_agents : %s", method);
@@ -569,14 +577,16 @@ void Env::add_agents(int group, int n, const char *method, const int *px, const 
     if (group < 0 || group >= (int)groups.size()) fatal("invalid group handle in GridWorld::add_agents : %d", group);
     HostGroup &G = groups[group];
     std::vector<int> sx, sy, sid;
+    const int bw = G.type->width, bl = G.type->length;
     auto place = [&](int x, int y) {     // add_or_error: occupied positions are silently skipped, the id is reused
-        if (!host_blank(x, y)) return;
-        h_occ[(size_t)y * width + x] = ref_pack(group, G.n + (int)sx.size());
+        if (!host_blank(x, y, bw, bl)) return;
+        const int ref = ref_pack(group, G.n + (int)sx.size());
+        for (int i = 0; i < bw; i++) for (int j = 0; j < bl; j++) h_occ[(size_t)(y + j) * width + x + i] = ref;
         sx.push_back(x); sy.push_back(y); sid.push_back(id_counter++);
     };
-    if (m == "random") { for (int i = 0; i < n; i++) { int x, y; host_random_blank(x, y); place(x, y); } }
+    if (m == "random") { for (int i = 0; i < n; i++) { int x, y; host_random_blank(bw, bl, x, y); place(x, y); } }
     else if (m == "custom") { for (int i = 0; i < n; i++) place(px[i], py[i]); }
-    else if (m == "fill") { for (int x = px[0]; x < px[0] + px[2]; x++) for (int y = px[1]; y < px[1] + px[3]; y++) place(x, y); }
+    else if (m == "fill") { for (int x = px[0]; x < px[0] + px[2]; x += bw) for (int y = px[1]; y < px[1] + px[3]; y += bl) place(x, y); }
     else fatal("unsupported method in GridWorld::add_agents : %s", method);
 
     const int k = (int)sx.size();
@@ -761,12 +771,16 @@ void Env::step(int *done) {
             rng.skip((unsigned)A);
         }
         launch_attack_rank(stream, W, d_rank);
+        // Jacobi rounds run in pairs with ONE convergence check per pair (the flag of the second round): a host
+        // round-trip costs about as much as a round, and two rounds settle almost every step
         int use_b = 0, iters = 0;
         while (true) {
+            launch_attack_iter(stream, W, d_gtab, d_ttab, use_b, attack_kmax);
+            use_b ^= 1;
             clear_changed();
             launch_attack_iter(stream, W, d_gtab, d_ttab, use_b, attack_kmax);
             use_b ^= 1;
-            iters++;
+            iters += 2;
             if (!read_changed()) break;
             if (iters > 100000) fatal("attack resolution did not converge");
         }
@@ -790,15 +804,33 @@ void Env::step(int *done) {
     // ---- move
     if (total_n > 0) {
         ProfScope p(*this, "move");
-        clear_changed();
-        launch_move_prep(stream, W, d_gtab);
         int iters = 0;
-        while (read_changed()) {
+        if (!any_multicell) {
             clear_changed();
-            launch_move_jump(stream, W, d_gtab);
-            if (++iters > 100000) fatal("move resolution did not converge");
+            launch_move_prep(stream, W, d_gtab);
+            // pointer jumping: `move_jump_batch` rounds per convergence check (a resolved agent is a no-op later)
+            while (read_changed()) {
+                for (int k = 0; k < move_jump_batch; k++) {
+                    if (k == move_jump_batch - 1) clear_changed();
+                    launch_move_jump(stream, W, d_gtab);
+                }
+                iters += move_jump_batch;
+                if (iters > 1000000) fatal("move resolution did not converge");
+            }
+            launch_move_apply(stream, W, d_gtab);
+        } else {   // bodies larger than one cell: generic sweeps (kernels.hip, "move, generic bodies")
+            clear_changed();
+            launch_movg_prep(stream, W);
+            while (read_changed()) {
+                for (int k = 0; k < move_jump_batch; k++) {
+                    if (k == move_jump_batch - 1) clear_changed();
+                    launch_movg_sweep(stream, W, d_gtab);
+                }
+                iters += move_jump_batch;
+                if (iters > 1000000) fatal("move resolution did not converge");
+            }
+            launch_movg_apply(stream, W, d_gtab);
         }
-        launch_move_apply(stream, W, d_gtab);
         last_move_iters = iters;
     }
     // ---- reward rules + end of step

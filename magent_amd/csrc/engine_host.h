@@ -115,6 +115,7 @@ public:
     int render_steps_per_span = 0;  // 0 = default
     int render_unroll = 1;
     bool host_shuffle = false;
+    int move_jump_batch = 3;
     int last_attack_iters = 0, last_move_iters = 0;
 
 private:
@@ -137,8 +138,8 @@ private:
     void compile_rules();
     void download_occ();
     void upload_occ();
-    bool host_blank(int x, int y) const;
-    void host_random_blank(int &ox, int &oy);
+    bool host_blank(int x, int y, int bw, int bl) const;
+    void host_random_blank(int bw, int bl, int &ox, int &oy);
     void plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *feat);
     void copy_out(void *host_dst, const void *dev_src, size_t bytes);
     int n_channel() const;
@@ -164,7 +165,7 @@ private:
     std::vector<HostRule> rules;
     std::vector<RuleArgs> rule_args;
     bool rules_compiled = false;
-    int id_counter = 0, any_kill_supply = 0, move_seq_base = 0, attack_kmax = 1;
+    int id_counter = 0, any_kill_supply = 0, any_multicell = 0, move_seq_base = 0, attack_kmax = 1;
 
     // device state
     bool device_ready = false, tables_valid = false, paint_valid = false;

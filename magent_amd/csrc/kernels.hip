@@ -37,6 +37,12 @@ __device__ __forceinline__ int wave_rank(bool pred, int &wave_total) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
 
+// writes `v` into every map cell of a bw x bl body whose top-left cell is (x, y) (Map::fill_area / clear_area)
+__device__ __forceinline__ void body_fill(const WorldView &W, int x, int y, int bw, int bl, int v) {
+    for (int by = 0; by < bl; by++)
+        for (int bx = 0; bx < bw; bx++) W.occ[(y + by) * W.w + x + bx] = v;
+}
+
 // ------------------------------------------------------------------------------------------------ device tables
 // copies the by-value group/type tables into device memory for kernels that index them per lane
 __global__ void k_set_tables(WorldView W, GroupDev *gtab, TypeDev *ttab) {
@@ -486,7 +492,7 @@ __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *ran
 // pos(t) - d; it hits iff its pending action is "attack with offset d".  Hits are sorted by rank (LDS) and replayed
 // in order: a hit counts iff its attacker is still alive at that rank (death_rank[attacker] > rank).  death_rank
 // is iterated to its fixed point; after k rounds every event of dependency depth <= k is final.
-constexpr int ATT_THREADS = 128;
+constexpr int ATT_THREADS = 64;   // one wave per workgroup: the hit lists (kmax x 64 x 8 B of LDS) bound the occupancy
 
 template <bool APPLY>
 __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab,
@@ -509,24 +515,27 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     // ---- gather incoming hits: bit (attack_bit[ga] + k) of my cell's word is set iff the agent standing at
     // pos - delta(ga, k) attacks me with offset k
     int nh = 0;
-    unsigned bits = hitbits[y * W.w + x];
-    if (bits) {
-        for (int ga = 0; ga < W.G; ga++) {
-            const TypeDev TA = W.type[ga];
-            if (TA.n_attack == 0) continue;
-            unsigned mine = (bits >> TA.attack_bit) & (TA.n_attack >= 32 ? 0xFFFFFFFFu : ((1u << TA.n_attack) - 1u));
-            const GroupDev A = W.grp[ga];
-            while (mine) {
-                int k = __ffs(mine) - 1;
-                mine &= mine - 1;
-                int2 d = W.delta[TA.attack_off + k];
-                int o = W.occ[(y - d.y) * W.w + (x - d.x)];
-                int ai = ref_index(o);
-                s_rank[nh * ATT_THREADS + tid] = A.key[ai]; s_ref[nh * ATT_THREADS + tid] = o;
-                nh++;
+    for (int by = 0; by < T.bl; by++)
+        for (int bx = 0; bx < T.bw; bx++) {      // an attacker hits ONE cell; a multi-cell body collects from all of its cells
+            const int cx = x + bx, cy = y + by;
+            unsigned bits = hitbits[cy * W.w + cx];
+            if (!bits) continue;
+            for (int ga = 0; ga < W.G; ga++) {
+                const TypeDev TA = W.type[ga];
+                if (TA.n_attack == 0) continue;
+                unsigned mine = (bits >> TA.attack_bit) & (TA.n_attack >= 32 ? 0xFFFFFFFFu : ((1u << TA.n_attack) - 1u));
+                const GroupDev A = W.grp[ga];
+                while (mine) {
+                    int k = __ffs(mine) - 1;
+                    mine &= mine - 1;
+                    int2 d = W.delta[TA.attack_off + k];
+                    int o = W.occ[(cy - d.y) * W.w + (cx - d.x)];   // the attacker's own top-left cell
+                    int ai = ref_index(o);
+                    s_rank[nh * ATT_THREADS + tid] = A.key[ai]; s_ref[nh * ATT_THREADS + tid] = o;
+                    nh++;
+                }
             }
         }
-    }
     // ---- insertion sort by rank (ranks are unique)
     for (int a = 1; a < nh; a++) {
         unsigned r = s_rank[a * ATT_THREADS + tid]; int f = s_ref[a * ATT_THREADS + tid];
@@ -626,7 +635,7 @@ __global__ void __launch_bounds__(256) k_attack_bury(WorldView W, int use_b) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
     int dr = (use_b ? G.drank_b : G.drank_a)[i];
-    if (dr != -1 && dr != RANK_INF) W.occ[G.y[i] * W.w + G.x[i]] = OCC_EMPTY;
+    if (dr != -1 && dr != RANK_INF) body_fill(W, G.x[i], G.y[i], W.type[blockIdx.y].bw, W.type[blockIdx.y].bl, OCC_EMPTY);
 }
 
 // ------------------------------------------------------------------------------------------------ starve / recover
@@ -641,7 +650,7 @@ __global__ void __launch_bounds__(256) k_starve(WorldView W) {
         if (T.step_recover > 0) hp = fminf(T.hp, hp + T.step_recover);
         else {
             hp -= -T.step_recover;
-            if (hp < 0.0f) { died = true; G.dead[i] = 1; G.next_reward[i] = T.dead_penalty; W.occ[G.y[i] * W.w + G.x[i]] = OCC_EMPTY; }
+            if (hp < 0.0f) { died = true; G.dead[i] = 1; G.next_reward[i] = T.dead_penalty; body_fill(W, G.x[i], G.y[i], T.bw, T.bl, OCC_EMPTY); }
         }
         G.hp[i] = hp;
     }
@@ -760,6 +769,149 @@ __global__ void __launch_bounds__(256) k_move_enter(WorldView W) {
     G.x[i] = c - ny * W.w; G.y[i] = ny;
 }
 
+// ------------------------------------------------------------------------------------------------ move, generic bodies
+// Bodies larger than one cell (Map::do_move with width x height rectangles, Map.cc:313-333, 454-470).  A mover m with
+// target rectangle T(m) succeeds iff, at its turn, every cell of T(m) outside its own body is free:
+//   * the cell's phase-start occupant O has left: O moves before m (key(O) < key(m)), O's move succeeds, and O's new
+//     rectangle does not cover the cell again;
+//   * no mover m' with key(m') < key(m) whose move succeeds has entered it (the cell lies in T(m')).
+// Both conditions only look at lower keys, so the recursion is well founded and its unique solution is the
+// sequential result; it is solved by sweeps that decide every agent whose lower-key dependencies are decided.
+// Entrants are found by pulling: a mover of group g' with move k and top-left p enters cell c iff
+// c - d_k - (bx, by) == p for some body offset -- checked against the map and the pending actions.
+struct MoveProbe {
+    bool blocked;     // some cell is definitely not free at m's turn
+    bool undecided;   // a lower-key dependency is still unknown
+    int blocker;      // first occupant Map::get_collide would meet (x outer, y inner), -1 if none
+};
+
+template <bool WANT_BLOCKER>
+__device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g, int i, int tgt_cell) {
+    const GroupDev G = W.grp[g];
+    const TypeDev T = W.type[g];
+    const unsigned key = G.key[i];
+    const int x0 = G.x[i], y0 = G.y[i];
+    const int ny = tgt_cell / W.w, nx = tgt_cell - ny * W.w;
+    const int self = ref_pack(g, i);
+    MoveProbe r{false, false, -1};
+    for (int bx = 0; bx < T.bw; bx++)
+        for (int by = 0; by < T.bl; by++) {
+            const int cx = nx + bx, cy = ny + by, c = cy * W.w + cx;
+            int occupant = -1;                       // who holds the cell when m's turn comes
+            bool unknown = false;
+            const int o = W.occ[c];
+            if (o == OCC_WALL) { r.blocked = true; continue; }   // walls block but are never a collide object
+            if (o >= 0 && o != self) {
+                const GroupDev O = gtab[ref_group(o)];
+                const int oi = ref_index(o);
+                const int ot = O.drank_a[oi];
+                bool gone = false;
+                if (ot >= 0 && O.key[oi] < key) {
+                    const TypeDev TO = W.type[ref_group(o)];
+                    const int oy = ot / W.w, ox = ot - oy * W.w;
+                    const bool covers_again = cx >= ox && cx < ox + TO.bw && cy >= oy && cy < oy + TO.bl;
+                    const unsigned st = O.mv[oi];
+                    if (!covers_again) { if (st == MV_OK) gone = true; else if (st != MV_FAIL) unknown = true; }
+                }
+                if (!gone) occupant = o;             // (possibly only "maybe": flagged by `unknown`)
+            }
+            if (occupant < 0 || unknown) {
+                // entrants with lower keys
+                for (int ga = 0; ga < W.G && occupant < 0; ga++) {
+                    const TypeDev TA = W.type[ga];
+                    const GroupDev A = W.grp[ga];
+                    for (int k = 0; k < TA.n_move && occupant < 0; k++) {
+                        const int2 d = W.delta[TA.move_off + k];
+                        if ((d.x | d.y) == 0) continue;
+                        for (int ax = 0; ax < TA.bw && occupant < 0; ax++)
+                            for (int ay = 0; ay < TA.bl; ay++) {
+                                const int px = cx - d.x - ax, py = cy - d.y - ay;
+                                if (px < 0 || py < 0 || px >= W.w || py >= W.h) continue;
+                                const int e = W.occ[py * W.w + px];
+                                if (e < 0 || e == self || ref_group(e) != ga) continue;
+                                const int ei = ref_index(e);
+                                if (A.x[ei] != px || A.y[ei] != py) continue;          // not that body's top-left cell
+                                if (A.pend[ei] != (PEND_MOVE | k) || A.drank_a[ei] < 0 || A.key[ei] >= key) continue;
+                                const unsigned st = A.mv[ei];
+                                if (st == MV_OK) { occupant = e; break; }
+                                if (st != MV_FAIL) unknown = true;
+                            }
+                    }
+                }
+            }
+            if (occupant >= 0 && !unknown) {
+                r.blocked = true;
+                if (WANT_BLOCKER && r.blocker < 0) r.blocker = occupant;
+            } else if (unknown) r.undecided = true;
+            if (!WANT_BLOCKER && r.blocked) return r;
+        }
+    return r;
+}
+
+// candidates: alive movers with a non-zero delta whose target rectangle is inside the map (Map.cc:455)
+__global__ void __launch_bounds__(256) k_movg_prep(WorldView W) {
+    const int g = blockIdx.y;
+    const GroupDev G = W.grp[g];
+    const TypeDev T = W.type[g];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.n) return;
+    int t = -1;
+    const int pend = G.pend[i];
+    if (!G.dead[i] && (pend & ~PEND_ARG) == PEND_MOVE) {
+        int2 d = W.delta[T.move_off + (pend & PEND_ARG)];
+        int nx = G.x[i] + d.x, ny = G.y[i] + d.y;
+        if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + T.bw < W.w && ny + T.bl < W.h) t = ny * W.w + nx;
+    }
+    G.drank_a[i] = t;
+    G.mv[i] = t >= 0 ? 0u : MV_FAIL;      // 0 = undecided (the packed-dependency encoding of the 1x1 path is not used here)
+    if (t >= 0) W.counters[CTR_CHANGED] = 1;
+}
+
+__global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev *gtab) {
+    const int g = blockIdx.y;
+    const GroupDev G = W.grp[g];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.n) return;
+    const int t = G.drank_a[i];
+    if (t < 0 || G.mv[i] >= MV_OK) return;
+    MoveProbe r = move_probe<false>(W, gtab, g, i, t);
+    if (r.blocked) G.mv[i] = MV_FAIL;
+    else if (!r.undecided) G.mv[i] = MV_OK;
+    else W.counters[CTR_CHANGED] = 1;
+}
+
+// Map::get_collide for failed moves (Map.cc:334-353, 486-501): first agent met in the target rectangle
+__global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDev *gtab) {
+    const int g = blockIdx.y;
+    const GroupDev G = W.grp[g];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.n) return;
+    const int t = G.drank_a[i];
+    if (t < 0 || G.mv[i] != MV_FAIL) return;
+    MoveProbe r = move_probe<true>(W, gtab, g, i, t);
+    if (r.blocker >= 0) { G.last_op[i] = OP_COLLIDE; G.op_obj[i] = r.blocker; }
+}
+
+__global__ void __launch_bounds__(256) k_movg_vacate(WorldView W) {
+    const int g = blockIdx.y;
+    const GroupDev G = W.grp[g];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.n || G.drank_a[i] < 0 || G.mv[i] != MV_OK) return;
+    body_fill(W, G.x[i], G.y[i], W.type[g].bw, W.type[g].bl, OCC_EMPTY);
+}
+
+__global__ void __launch_bounds__(256) k_movg_enter(WorldView W) {
+    const int g = blockIdx.y;
+    const GroupDev G = W.grp[g];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.n) return;
+    const int c = G.drank_a[i];
+    if (c < 0 || G.mv[i] != MV_OK) return;
+    const int ny = c / W.w, nx = c - ny * W.w;
+    body_fill(W, nx, ny, W.type[g].bw, W.type[g].bl, ref_pack(g, i));
+    G.x[i] = nx; G.y[i] = ny;
+}
+
 // ------------------------------------------------------------------------------------------------ reward rules
 // Event(a, op, b) with 'any' symbols: every agent i of group(a), in index order, whose last_op == op and whose
 // op_obj is in group(b) triggers the rule once (RewardEngine.cc:373-414).  Receivers that are the subject are added
@@ -838,13 +990,14 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_compact_a(GroupDev G, int *sum
 __global__ void __launch_bounds__(SCAN_THREADS) k_compact_c(WorldView W, int g, GroupDev D, const int *sums) {
     const GroupDev G = W.grp[g];
     const float step_reward = W.type[g].step_reward;
+    const int bw = W.type[g].bw, bl = W.type[g].bl;
     block_rank([&](int i) { return !G.dead[i]; },
                [&](int i, int r) {
                    int x = G.x[i], y = G.y[i];
                    D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
                    D.last_reward[r] = G.next_reward[i];
                    D.next_reward[r] = step_reward;
-                   W.occ[y * W.w + x] = ref_pack(g, r);
+                   body_fill(W, x, y, bw, bl, ref_pack(g, r));
                },
                G.n, sums[blockIdx.x]);
 }
@@ -957,6 +1110,16 @@ void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     hipLaunchKernelGGL(k_move_prep, g, dim3(256), 0, s, W);
     hipLaunchKernelGGL(k_move_claim, g, dim3(256), 0, s, W, gtab);
     hipLaunchKernelGGL(k_move_init, g, dim3(256), 0, s, W);
+}
+void launch_movg_prep(hipStream_t s, const WorldView &W) { hipLaunchKernelGGL(k_movg_prep, grid_all(W, 256), dim3(256), 0, s, W); }
+void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
+    hipLaunchKernelGGL(k_movg_sweep, grid_all(W, 256), dim3(256), 0, s, W, gtab);
+}
+void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
+    dim3 g = grid_all(W, 256);
+    hipLaunchKernelGGL(k_movg_collide, g, dim3(256), 0, s, W, gtab);
+    hipLaunchKernelGGL(k_movg_vacate, g, dim3(256), 0, s, W);
+    hipLaunchKernelGGL(k_movg_enter, g, dim3(256), 0, s, W);
 }
 void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     hipLaunchKernelGGL(k_move_jump, grid_all(W, 256), dim3(256), 0, s, W, gtab);

@@ -50,6 +50,9 @@ void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab
 void launch_attack_events(hipStream_t s, const WorldView &W, int use_b, int4 *ev);
 void launch_starve(hipStream_t s, const WorldView &W);
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);
+void launch_movg_prep(hipStream_t s, const WorldView &W);
+void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab);
+void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A);

@@ -94,7 +94,26 @@ def custom_quad(map_size):
     return cfg
 
 
-CUSTOM = {"tri": custom_tri, "chase": custom_chase, "quad": custom_quad}
+def custom_bodies(map_w, map_h):
+    """multi-cell bodies of three shapes (3x2, 2x2, 1x1) that attack and block each other; minimap on"""
+    cfg = gw.Config()
+    cfg.set({"map_width": map_w, "map_height": map_h, "minimap_mode": True, "embedding_size": 5})
+    big = cfg.register_agent_type("big", dict(width=3, length=2, hp=8, speed=2, view_range=gw.CircleRange(5), attack_range=gw.CircleRange(2.5),
+                                              damage=2, step_recover=0.2, kill_reward=2, dead_penalty=-1, attack_penalty=-0.1))
+    mid = cfg.register_agent_type("mid", dict(width=2, length=2, hp=4, speed=1, view_range=gw.CircleRange(4), attack_range=gw.CircleRange(2),
+                                              damage=1.5, step_recover=-0.1, kill_supply=1.5, kill_reward=1, attack_in_group=1))
+    tiny = cfg.register_agent_type("tiny", dict(width=1, length=1, hp=2, speed=3, view_range=gw.CircleRange(3), attack_range=gw.CircleRange(1),
+                                                damage=1, step_reward=0.05, dead_penalty=-2))
+    g0, g1, g2 = cfg.add_group(big), cfg.add_group(mid), cfg.add_group(tiny)
+    a, b, c = gw.AgentSymbol(g0, "any"), gw.AgentSymbol(g1, "any"), gw.AgentSymbol(g2, "any")
+    cfg.add_reward_rule(gw.Event(a, "attack", b), receiver=[a, b], value=[0.5, -0.25])
+    cfg.add_reward_rule(gw.Event(b, "kill", c), receiver=b, value=1.5)
+    cfg.add_reward_rule(gw.Event(c, "collide", a), receiver=c, value=-0.0625)
+    cfg.add_reward_rule(gw.Event(b, "collide", b2 := gw.AgentSymbol(g1, "any")), receiver=b, value=-0.03125)
+    return cfg
+
+
+CUSTOM = {"tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
 
 
 class Scenario(object):
@@ -256,6 +275,12 @@ def scenarios():
         Scenario("tri_rect", ("tri", 70, 45), 0, place=[rnd(0, 500), rnd(1, 400), rnd(2, 450)], walls=80, steps=25, action_seed=16),
         Scenario("tri_rect_large", ("tri", 150, 101), 0, place=[rnd(0, 3000), rnd(1, 3000), rnd(2, 2500)], steps=10, action_seed=17),
         Scenario("quad", ("quad", 36), 0, place=[rnd(0, 150), rnd(1, 150), rnd(2, 150), rnd(3, 150)], steps=20, action_seed=22),
+        Scenario("pursuit", "pursuit", 40, walls=48, place=[rnd(0, 20), rnd(1, 40)], steps=40, action_seed=23),
+        Scenario("pursuit_dense", "pursuit", 30, walls=30, place=[rnd(0, 60), rnd(1, 120)], steps=30, action_seed=24),
+        Scenario("pursuit_large", "pursuit", 140, walls=600, place=[rnd(0, 1500), rnd(1, 3000)], steps=10, action_seed=25),
+        Scenario("bodies", ("bodies", 48, 37), 0, walls=40, place=[rnd(0, 60), rnd(1, 90), rnd(2, 150)], steps=30, action_seed=26),
+        Scenario("bodies_large", ("bodies", 130, 111), 0, walls=300, place=[rnd(0, 500), rnd(1, 900), rnd(2, 1500),
+                 (0, "fill", {"pos": (100, 80), "size": (12, 10)})], steps=10, action_seed=27),
         Scenario("chase", ("chase", 40), 0, place=[rnd(0, 150), rnd(1, 300)], walls=40, steps=20, action_seed=18),
         Scenario("battle_events", "battle", 45, place=[rnd(0, 300), rnd(1, 300)], steps=24, action_seed=19,
                  over={"small": {"hp": 4, "damage": 3}},
