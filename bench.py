@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--map-size", type=int, default=MAP_SIZE)
     ap.add_argument("--agents", type=int, default=N_PER_GROUP, help="agents per group")
+    ap.add_argument("--workload", choices=["battle", "test_1m"], default="battle",
+                    help="test_1m: the reference's own harness (scripts/test/test_1m.py): pursuit-like game, map sqrt(20 N), "
+                         "N/10 walls, N/2 prey + N/2 2x2 predators, N = 2 * --agents")
     ap.add_argument("--gather", choices=["none", "obs"], default="none",
                     help="obs: all_gather the observation tensors of every replica over RCCL each step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,45 +135,59 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from magent_amd.builtin.config import _games
-    cfg = _games.make("battle", args.map_size)
+    if args.workload == "test_1m":
+        args.map_size = int((2 * args.agents * 20) ** 0.5)
+        cfg = _games.make("pursuit", args.map_size)
+    else:
+        cfg = _games.make("battle", args.map_size)
     cfg.set({"device_id": local_rank})
     env = magent_amd.GridWorld(cfg)
     env.set_seed(12345 + rank)
     env.reset()
     handles = env.get_handles()
-    for h in handles:
-        env.add_agents(h, "random", n=args.agents)
+    if args.workload == "test_1m":
+        env.add_walls(method="random", n=2 * args.agents // 10)
+        for h in reversed(handles):
+            env.add_agents(h, "random", n=args.agents)
+    else:
+        for h in handles:
+            env.add_agents(h, "random", n=args.agents)
     n0 = [env.get_num(h) for h in handles]
     G = len(handles)
-    vs, fs = env.get_view_space(handles[0]), env.get_feature_space(handles[0])
-    n_action = env.get_action_space(handles[0])[0]
-    view_bytes_per_agent = 4 * vs[0] * vs[1] * vs[2]   # what k_render writes (the dominant kernel)
-    feat_bytes_per_agent = 4 * fs[0]                   # what k_features writes
+    vss = [env.get_view_space(h) for h in handles]
+    fss = [env.get_feature_space(h) for h in handles]
+    n_actions = [env.get_action_space(h)[0] for h in handles]
+    view_bytes = [4 * v[0] * v[1] * v[2] for v in vss]   # per agent: what k_render writes (the dominant kernel)
+    feat_bytes = [4 * f[0] for f in fss]                 # per agent: what k_features writes
 
     # caller-owned device buffers (the reference's ownership convention), sized once for the initial population
-    views = [torch.empty((n0[g],) + vs, dtype=torch.float32, device=dev) for g in range(G)]
-    feats = [torch.empty((n0[g],) + fs, dtype=torch.float32, device=dev) for g in range(G)]
+    views = [torch.empty((n0[g],) + vss[g], dtype=torch.float32, device=dev) for g in range(G)]
+    feats = [torch.empty((n0[g],) + fss[g], dtype=torch.float32, device=dev) for g in range(G)]
     rewards = [torch.empty(n0[g], dtype=torch.float32, device=dev) for g in range(G)]
     total_steps = args.steps + args.warmup
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)
-    actions = [[torch.randint(n_action, (n0[g],), dtype=torch.int32, device=dev, generator=gen) for g in range(G)]
+    actions = [[torch.randint(n_actions[g], (n0[g],), dtype=torch.int32, device=dev, generator=gen) for g in range(G)]
                for _ in range(total_steps)]
-    gathered = None
-    if args.gather == "obs" and world > 1:
-        gathered = [[torch.empty_like(views[g]) for _ in range(world)] for g in range(G)]
+    from magent_amd import replicas
+    do_gather = args.gather == "obs" and world > 1
     torch.cuda.synchronize()
+
+    rendered = {"view": 0, "feat": 0}
 
     def one_step(s):
         n_now = 0
         for g, h in enumerate(handles):
-            n_now += env.get_num(h)
+            n = env.get_num(h)
+            n_now += n
+            rendered["view"] += n * view_bytes[g]
+            rendered["feat"] += n * feat_bytes[g]
             env.get_observation_device(h, views[g], feats[g])
             env.set_action_device(h, actions[s][g])
-        if gathered is not None:
+        if do_gather:   # the north star's batched-observation gather: every replica's view tensor to every rank
             env.sync()
-            for g in range(G):
-                dist.all_gather(gathered[g], views[g])
+            for g, h in enumerate(handles):
+                replicas.gather_observations(views[g], env.get_num(h), capacity=n0[g])
         env.step()
         for g, h in enumerate(handles):
             env.get_reward_device(h, rewards[g])
@@ -184,7 +201,7 @@ def main():
         env.profile_enable(True)
         for name in ("render", "features", "paint", "minimap", "attack", "move", "set_action", "starve", "rules", "clear_dead"):
             env.profile_read(name)
-    rendered_agents = 0
+    rendered["view"] = rendered["feat"] = 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -194,7 +211,6 @@ def main():
     for s in range(args.warmup, total_steps):
         n_now = one_step(s)
         agent_steps += n_now
-        rendered_agents += n_now
     env.sync()
     torch.cuda.synchronize()
     if world > 1:
@@ -217,7 +233,7 @@ def main():
         if n_launch and ms > 0:
             # algorithmic bytes of the dominant kernel: every element of the view tensor written exactly once
             # (4*VH*VW*C per agent; the 4*F feature bytes belong to k_features, timed separately)
-            achieved = rendered_agents * view_bytes_per_agent / (ms * 1e-3) / 1e9
+            achieved = rendered["view"] / (ms * 1e-3) / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "render_pmc.json")
             if os.path.exists(pmc):
@@ -228,9 +244,8 @@ def main():
             roofline = {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
-                        "algorithmic_bytes_per_launch": int(rendered_agents * view_bytes_per_agent / n_launch),
-                        "obs_total_GBs": round(rendered_agents * (view_bytes_per_agent + feat_bytes_per_agent)
-                                               / ((ms + ms_feat) * 1e-3) / 1e9, 1)}
+                        "algorithmic_bytes_per_launch": int(rendered["view"] / n_launch),
+                        "obs_total_GBs": round((rendered["view"] + rendered["feat"]) / ((ms + ms_feat) * 1e-3) / 1e9, 1)}
         for name in ("paint", "minimap", "attack", "move", "set_action", "starve", "rules", "clear_dead"):
             k, t_ms = env.profile_read(name)
             if k:
@@ -254,8 +269,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": WORKLOAD if (args.map_size, args.agents) == (MAP_SIZE, N_PER_GROUP) else
-                       "battle %dx%d, 2x%d agents, random placement, random actions" % (args.map_size, args.map_size, args.agents),
+            "config": {"workload": WORKLOAD if (args.workload, args.map_size, args.agents) == ("battle", MAP_SIZE, N_PER_GROUP) else
+                       ("reference test_1m.py harness: pursuit-like %dx%d, %d walls, %d prey + %d 2x2 predators" % (
+                           args.map_size, args.map_size, 2 * args.agents // 10, args.agents, args.agents)
+                        if args.workload == "test_1m" else
+                        "battle %dx%d, 2x%d agents, random placement, random actions" % (args.map_size, args.map_size, args.agents)),
                        "envs": world, "parallelism": "replicas x%d" % world, "gather": args.gather,
                        "agents_at_start": n0, "agents_at_end": [env.get_num(h) for h in handles],
                        "io": "device-resident (env_*_device C-ABI)"},

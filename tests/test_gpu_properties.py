@@ -143,3 +143,36 @@ def test_two_environments_in_one_process_are_independent():
             assert env1.get_reward(h).tobytes() == a[step]["reward%d" % g].tobytes()
         env2.clear_dead()
         env1.clear_dead()
+
+
+def test_unaligned_output_pointers_take_the_scalar_store_path():
+    """a caller may hand a view / feature pointer that is not 16-byte aligned: same bits through the scalar path"""
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    env = _make("battle", 60, 777)
+    h = env.get_handles()[0]
+    n = env.get_num(h)
+    v_ref, f_ref = env.get_observation_device(h)
+    S, F = int(np.prod(env.get_view_space(h))), env.get_feature_space(h)[0]
+    big_v = torch.zeros(n * S + 8, dtype=torch.float32, device=dev)
+    big_f = torch.zeros(n * F + 8, dtype=torch.float32, device=dev)
+    for off in (1, 2, 3):
+        v = big_v[off:off + n * S].view((n,) + env.get_view_space(h))
+        f = big_f[off:off + n * F].view(n, F)
+        assert v.data_ptr() % 16 != 0
+        env.get_observation_device(h, v, f)
+        env.sync()
+        assert torch.equal(v.view(torch.int32), v_ref.view(torch.int32)) and torch.equal(f, f_ref)
+        assert float(big_v[:off].abs().sum()) == 0 and float(big_v[off + n * S:].abs().sum()) == 0   # nothing outside
+        big_v.zero_(); big_f.zero_()
+        torch.cuda.synchronize()
+
+
+def test_reference_1m_methodology_small():
+    """the reference's own throughput harness (scripts/test/test_1m.py:66-74): pursuit-like game on a
+    sqrt(20 N) map with N/10 random walls, N/2 prey, N/2 2x2 predators -- here N = 20000, compared with the oracle"""
+    N = 20000
+    size = int(np.sqrt(N * 20))
+    sc = H.Scenario("test_1m_small", "pursuit", size, walls=N // 10,
+                    place=[(1, "random", {"n": N // 2}), (0, "random", {"n": N // 2})], steps=4, action_seed=31, obs_every=2)
+    H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, H.HIP_LIB), "test_1m_small")

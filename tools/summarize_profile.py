@@ -51,7 +51,7 @@ def main():
             rec = {"kernel": k.split("(")[0], "fetch_bytes_per_launch": fetch[k] * 1024, "write_bytes_per_launch": write.get(k, 0) * 1024,
                    "hbm_bytes_per_launch": (fetch[k] + write.get(k, 0)) * 1024,
                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB*1024; WRITE_SIZE calibrated on k_paint "
-                           "(exactly w*h*8 bytes); FETCH_SIZE is uncalibrated for 8-byte gathers on gfx950 and counts "
+                           "(it writes exactly w*h*4 bytes packed / w*h*8 unpacked); FETCH_SIZE is uncalibrated for 8-byte gathers on gfx950 and counts "
                            "Infinity-Cache hits (MI355X_MICROARCH.md, HBM section) -- an upper bound on HBM reads",
                    "source": tag}
             json.dump(rec, open(os.path.join(out_dir, "render_pmc.json"), "w"), indent=1)
