@@ -114,13 +114,27 @@ class DeepQNetwork(BaseModel):
         step = max(1, min(n, self.infer_batch_size))
         for beg in range(0, n, step):
             v, f = self._tensor(view[beg:beg + step]), self._tensor(feature[beg:beg + step])
-            best = self.qnet(v, f).argmax(dim=1).to(torch.int32)
+            m = len(v)
+            # group sizes change every step (deaths); pad the batch to a bucketed size so the convolution library sees
+            # a handful of shapes instead of tuning a kernel for every n
+            bucket = self._bucket(m)
+            if bucket != m:
+                v = torch.cat([v, v.new_zeros((bucket - m,) + tuple(v.shape[1:]))])
+                f = torch.cat([f, f.new_zeros((bucket - m,) + tuple(f.shape[1:]))])
+            best = self.qnet(v, f)[:m].argmax(dim=1).to(torch.int32)
             rnd = torch.randint(self.num_actions, best.shape, dtype=torch.int32, device=self.device)
             explore = torch.rand(best.shape, device=self.device) < eps
             out[beg:beg + step] = torch.where(explore, rnd, best)
         if isinstance(view, torch.Tensor):
             return out
         return out.cpu().numpy()
+
+    @staticmethod
+    def _bucket(m):
+        if m <= 64:
+            return 64
+        p = 1 << (m - 1).bit_length()          # next power of two
+        return p if m > (p * 3) // 4 else (p * 3) // 4 if m > p // 2 else p // 2
 
     # ------------------------------------------------------------------ learning
     def _add_to_replay_buffer(self, sample_buffer):
@@ -135,8 +149,12 @@ class DeepQNetwork(BaseModel):
                 terminal[-1] = True
             else:
                 mask[-1] = 0
-            self.mem_view.put(self._tensor(np.stack(ep.views)))
-            self.mem_feature.put(self._tensor(np.stack(ep.features)))
+            if isinstance(ep.views[0], torch.Tensor):
+                self.mem_view.put(torch.stack(ep.views).to(self.device))
+                self.mem_feature.put(torch.stack(ep.features).to(self.device))
+            else:
+                self.mem_view.put(self._tensor(np.stack(ep.views)))
+                self.mem_feature.put(self._tensor(np.stack(ep.features)))
             self.mem_action.put(self._tensor(np.asarray(ep.actions), torch.int64))
             self.mem_reward.put(self._tensor(np.asarray(ep.rewards, dtype=np.float32)))
             self.mem_terminal.put(self._tensor(terminal, torch.bool))

@@ -790,7 +790,6 @@ __device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g,
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
     const unsigned key = G.key[i];
-    const int x0 = G.x[i], y0 = G.y[i];
     const int ny = tgt_cell / W.w, nx = tgt_cell - ny * W.w;
     const int self = ref_pack(g, i);
     MoveProbe r{false, false, -1};

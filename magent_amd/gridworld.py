@@ -45,10 +45,17 @@ class GridWorld(object):
     OBS_INDEX_VIEW = 0
     OBS_INDEX_HP = 1
 
-    def __init__(self, config, lib=None, **kwargs):
-        """config: name of a built-in game ("battle", "gather", "pursuit", kwargs -> its get_config) or a Config"""
+    def __init__(self, config, lib=None, device_obs=None, **kwargs):
+        """config: name of a built-in game ("battle", "gather", "pursuit", kwargs -> its get_config) or a Config
+        device_obs: get_observation() returns torch tensors living on the engine's GPU instead of numpy arrays (the
+                    same reused buffers, no PCIe); default from the environment variable MAGENT_DEVICE_OBS=1.  Lets an
+                    unmodified training script keep observations, policy and replay memory on the device."""
         self._lib = c_lib.load(lib) if (lib is None or isinstance(lib, str)) else lib
         L = self._lib
+        if device_obs is None:
+            device_obs = os.environ.get("MAGENT_DEVICE_OBS", "0") == "1"
+        self._device_obs = bool(device_obs) and getattr(L, "has_device_api", False)
+        self._dev_cache = ({}, {})
         if isinstance(config, str):
             config = _builtin_config(config, **kwargs)
 
@@ -148,13 +155,33 @@ class GridWorld(object):
         """-> (view float32[n,H,W,C], feature float32[n,F]); buffers are reused between calls like the reference"""
         g = _gid(handle)
         n = self.get_num(g)
+        if self._device_obs:
+            return self._observe_device_cached(g, n)
         view = self._buf(0, g, (n,) + self.view_space[g])
         feat = self._buf(1, g, (n,) + self.feature_space[g])
         bufs = (_F32P * 2)(_f32(view), _f32(feat))
         self._lib.env_get_observation(self.game, g, bufs)
         return view, feat
 
+    def _observe_device_cached(self, g, n):
+        import torch
+        out = []
+        for which, space in ((0, self.view_space[g]), (1, self.feature_space[g])):
+            buf = self._dev_cache[which].get(g)
+            if buf is None or buf.shape[0] < n:
+                buf = self._dev_cache[which][g] = torch.empty((n,) + space, dtype=torch.float32,
+                                                              device=torch.device("cuda", self._device_id))
+            out.append(buf[:n])
+        self.get_observation_device(g, out[0], out[1])
+        self.sync()
+        return out[0], out[1]
+
     def set_action(self, handle, actions):
+        if not isinstance(actions, np.ndarray):   # a torch int32 tensor on the engine's device
+            import torch
+            assert isinstance(actions, torch.Tensor) and actions.dtype == torch.int32 and actions.is_cuda
+            torch.cuda.current_stream(actions.device).synchronize()   # the producer of `actions` has finished
+            return self.set_action_device(handle, actions.contiguous())
         assert isinstance(actions, np.ndarray) and actions.dtype == np.int32
         actions = np.ascontiguousarray(actions)
         self._lib.env_set_action(self.game, _gid(handle), _i32(actions))

@@ -14,9 +14,13 @@ class EpisodesBufferEntry(object):
         self.views, self.features, self.actions, self.rewards, self.terminal = [], [], [], [], False
 
     def append(self, view, feature, action, reward, alive):
-        self.views.append(np.array(view, copy=True))
-        self.features.append(np.array(feature, copy=True))
-        self.actions.append(action)
+        if isinstance(view, np.ndarray):
+            self.views.append(np.array(view, copy=True))
+            self.features.append(np.array(feature, copy=True))
+        else:                                   # torch rows of a device-resident observation: stay on the device
+            self.views.append(view.clone())
+            self.features.append(feature.clone())
+        self.actions.append(int(action))
         self.rewards.append(reward)
         if not alive:
             self.terminal = True
@@ -51,8 +55,13 @@ class EpisodesBuffer(object):
             return
         tracked = np.fromiter(self.buffer.keys(), dtype=np.int64, count=len(self.buffer))
         rows = np.nonzero(np.isin(ids, tracked, assume_unique=False))[0]
-        for i in rows:
-            self.buffer[int(ids[i])].append(views[i], features[i], acts[i], rewards[i], alives[i])
+        if not isinstance(acts, np.ndarray):    # device tensor of actions: fetch only the tracked rows
+            import torch
+            acts_rows = acts[torch.as_tensor(rows, device=acts.device)].cpu().numpy() if len(rows) else np.zeros(0, np.int32)
+        else:
+            acts_rows = acts[rows]
+        for k, i in enumerate(rows):
+            self.buffer[int(ids[i])].append(views[i], features[i], acts_rows[k], rewards[i], alives[i])
 
     def reset(self):
         self.buffer = {}

@@ -146,3 +146,31 @@ def test_training_round_on_gpu():
     assert isinstance(acts, torch.Tensor) and acts.dtype == torch.int32 and acts.is_cuda
     env.set_action_device(handles[0], acts)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_device_resident_training_round_on_gpu():
+    """device_obs=True: get_observation hands out torch tensors on the engine's GPU; policy, episode buffer and replay
+    memory never touch the host -- through the very same call sequence"""
+    import torch
+    import magent_amd
+    from magent_amd.builtin.torch_model import DeepQNetwork
+    from magent_amd.model import ProcessingModel
+    env = magent_amd.GridWorld("battle", lib=H.HIP_LIB, map_size=24, device_obs=True)
+    env.reset()
+    handles = env.get_handles()
+    for h in handles:
+        env.add_agents(h, "random", n=40)
+    v, f = env.get_observation(handles[0])
+    assert isinstance(v, torch.Tensor) and v.is_cuda and tuple(v.shape) == (40, 13, 13, 7)
+    ref = magent_amd.GridWorld("battle", lib=H.HIP_LIB, map_size=24)       # host-buffer twin: same bits
+    ref.reset()
+    for h in ref.get_handles():
+        ref.add_agents(h, "random", n=40)
+    assert v.cpu().numpy().tobytes() == ref.get_observation(ref.get_handles()[0])[0].tobytes()
+    models = [ProcessingModel(env, h, "d%d" % i, 20000 + i, 50, DeepQNetwork, batch_size=32, memory_size=2048,
+                              target_update=50, train_freq=2) for i, h in enumerate(handles)]
+    for loss, value in _play_round(env, handles, models, steps=20):
+        assert np.isfinite(loss) and np.isfinite(value)
+    ep = next(iter(models[0].sample_buffer.episodes()), None)
+    assert models[0].model.mem_view.buf.is_cuda
