@@ -576,12 +576,18 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
         int a = s_ref[k * ATT_THREADS + tid];
         const GroupDev A = gtab[ref_group(a)];
         int adr = (use_b ? A.drank_b : A.drank_a)[ref_index(a)];
-        if ((unsigned)adr > r) {                       // attacker alive when its turn comes (RANK_INF > any rank)
+        // the attacker is alive when its turn comes iff it did not die at an EARLIER rank.  adr == r happens only when
+        // the attacker is this very agent hitting its own body (in-group attack of a body whose range covers its own
+        // cells) and that hit is the fatal one: the attack did run (RANK_INF >= any rank)
+        if ((unsigned)adr >= r) {
             hp -= ttab[ref_group(a)].damage;
             if (hp < 0.0f) { dr = (int)r; break; }     // death iff hp < 0 strictly (GridWorld.h:205)
         }
     }
-    if (!supplied && dr == RANK_INF) hp = fminf(T.hp, hp + ttab[ref_group(tgt)].kill_supply);
+    // the kill supply of my own attack: normally skipped once I am dead -- except when I killed MYSELF, where
+    // Map::do_attack still feeds the (dead) attacker (Map.cc:266-274)
+    const bool self_kill = tgt == ref_pack(g, i) && (unsigned)dr == my_rank;
+    if (!supplied && (dr == RANK_INF || self_kill)) hp = fminf(T.hp, hp + ttab[ref_group(tgt)].kill_supply);
 
     if (!APPLY) {
         dr_self_next[i] = dr;
@@ -590,24 +596,29 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     }
     // ---- APPLY (the iterate has converged: dr == dr_me_cur)
     float nr = G.next_reward[i];
-    if (attacker && (unsigned)dr > my_rank) {          // alive at my turn (GridWorld.cc:479-480)
+    float own = 0.0f;                                  // what my own attack adds to my reward
+    bool acted = false;
+    if (attacker && (unsigned)dr >= my_rank) {         // alive at my turn (GridWorld.cc:479-480)
+        acted = true;
         if (tgt < 0 || (unsigned)tgt_dr < my_rank) {   // blank, or the target died before my turn (Map.cc:229-231)
-            nr += T.attack_penalty;
+            own = T.attack_penalty;
         } else {
             float reward = 0.0f;
             if ((unsigned)tgt_dr == my_rank) { G.last_op[i] = OP_KILL; reward = ttab[ref_group(tgt)].kill_reward; }
             else G.last_op[i] = OP_ATTACK;
             G.op_obj[i] = tgt;
-            nr += reward + T.attack_penalty;           // add_reward(reward + attack_penalty) (GridWorld.cc:505)
+            own = reward + T.attack_penalty;           // add_reward(reward + attack_penalty) (GridWorld.cc:505)
         }
     }
     G.hp[i] = hp;
     if (dr != RANK_INF) {
         G.dead[i] = 1;
-        nr = T.dead_penalty;                           // overwrites what was accumulated (GridWorld.h:207)
         atomicAdd(&W.counters[CTR_DEAD + g], 1);       // the map cell is cleared by k_attack_bury: other lanes of THIS
                                                        // launch still find their attackers through the map
-    }
+        // dead_penalty overwrites what was accumulated (GridWorld.h:207); only a self-inflicted death is followed by
+        // the attacker's own add_reward (the overwrite happens inside do_attack, the add after it)
+        nr = self_kill ? T.dead_penalty + own : T.dead_penalty;
+    } else if (acted) nr += own;
     G.next_reward[i] = nr;
 }
 
@@ -624,7 +635,7 @@ __global__ void __launch_bounds__(256) k_attack_events(WorldView W, int use_b, i
     const unsigned my_rank = G.key[i];
     const int dr = (use_b ? G.drank_b : G.drank_a)[i];
     int2 d = W.delta[W.type[g].attack_off + (pend & PEND_ARG)];
-    const bool executed = dr != -1 && (unsigned)dr > my_rank;
+    const bool executed = dr != -1 && (unsigned)dr >= my_rank;
     ev[my_rank] = make_int4(G.id[i], G.x[i] + d.x, G.y[i] + d.y, executed ? 1 : 0);
 }
 

@@ -132,6 +132,8 @@ class Scenario(object):
         self.events = events or {}
 
     def config(self):
+        if callable(self.game):
+            return self.game()
         if isinstance(self.game, tuple):
             return CUSTOM[self.game[0]](*self.game[1:])
         return config_for(self.game, self.map_size, **self.over)
@@ -215,6 +217,76 @@ def render_episode(lib, out_dir, steps=6):
             env._get_render_info((0, 15), (0, 15))
         env.clear_dead()
     return {name: open(os.path.join(out_dir, name), "rb").read() for name in sorted(os.listdir(out_dir))}
+
+
+_ATTACK_COUNT = {0: 0, 1: 4, 1.5: 8, 2: 12, 2.5: 20}
+
+
+def fuzz_scenario(seed):
+    """a random game inside the engine's scope: 2-4 groups, random body sizes / ranges / hp / damage / recover /
+    kill_supply / in-group attack, random rules (subject and object receivers, attack | kill | collide), random map
+    shape, walls, densities, clear_dead cadence and non-acting groups -- for differential testing"""
+    rs = np.random.RandomState(seed)
+    G = int(rs.choice([2, 2, 2, 3, 3, 4]))
+    w = int(rs.randint(12, 150))
+    h = w if rs.rand() < 0.5 else int(rs.randint(12, 150))
+    minimap, emb = bool(rs.rand() < 0.6), int(rs.choice([0, 3, 10]))
+    frac = lambda lo, hi: float(rs.randint(int(lo * 16), int(hi * 16) + 1)) / 16.0
+    while True:
+        specs = []
+        for g in range(G):
+            bw, bl = (1, 1) if rs.rand() < 0.65 else (int(rs.randint(1, 4)), int(rs.randint(1, 4)))
+            specs.append(dict(width=bw, length=bl, hp=frac(1, 12), speed=float(rs.choice([0, 1, 1, 1.5, 2, 2, 3])),
+                              view_range=float(rs.choice([1, 2, 3, 4, 5, 6, 7])), attack_range=float(rs.choice([0, 1, 1, 1.5, 1.5, 2, 2.5])),
+                              damage=frac(0, 6), step_recover=float(rs.choice([0, 0, 0.1, 0.25, -0.25, -0.5])),
+                              kill_supply=float(rs.choice([0, 0, 0, 2.5, 8])), attack_in_group=int(rs.rand() < 0.3),
+                              step_reward=frac(-0.25, 0.25), kill_reward=frac(0, 5), dead_penalty=frac(-2, 0),
+                              attack_penalty=frac(-0.5, 0)))
+        # engine limits: the attack offsets of all groups share a 32-bit word; hit lists are bounded
+        if sum(_ATTACK_COUNT[t["attack_range"]] for t in specs) > 32:
+            continue
+        kmax = max(t["width"] * t["length"] * sum(_ATTACK_COUNT[a["attack_range"]] for j, a in enumerate(specs)
+                                                  if j != i or a["attack_in_group"]) for i, t in enumerate(specs))
+        if kmax <= 256 and all(max(t["width"], t["length"]) + 2 < min(w, h) for t in specs):
+            break
+    rules = []
+    for _ in range(int(rs.randint(0, 5))):
+        a, b = int(rs.randint(G)), int(rs.randint(G))
+        op = str(rs.choice(["attack", "attack", "kill", "collide"]))
+        who = str(rs.choice(["s", "o", "so", "os", "ss"]))
+        if a == b and "s" in who and "o" in who:
+            who = "s"
+        rules.append((a, op, b, who, [frac(-1, 1) for _ in who]))
+
+    def make():
+        cfg = gw.Config()
+        cfg.set({"map_width": w, "map_height": h, "minimap_mode": minimap, "embedding_size": emb})
+        names = []
+        for g, t in enumerate(specs):
+            t = dict(t)
+            t["view_range"], t["attack_range"] = gw.CircleRange(t["view_range"]), gw.CircleRange(t["attack_range"])
+            names.append(cfg.register_agent_type("t%d" % g, t))
+        hs = [cfg.add_group(n) for n in names]
+        for a, op, b, who, vals in rules:
+            sa, sb = gw.AgentSymbol(hs[a], "any"), gw.AgentSymbol(hs[b], "any")
+            cfg.add_reward_rule(gw.Event(sa, op, sb), receiver=[{"s": sa, "o": sb}[c] for c in who], value=vals)
+        return cfg
+
+    area = (w - 2) * (h - 2)
+    density = float(rs.choice([0.03, 0.1, 0.2, 0.3]))
+    if any(t["width"] * t["length"] > 1 for t in specs):
+        density = min(density, 0.12)       # rejection-sampled placement of big bodies needs room
+    place = []
+    for g, t in enumerate(specs):
+        n = max(1, int(area * density / G / (t["width"] * t["length"])))
+        if rs.rand() < 0.15:
+            place.append((g, "fill", {"pos": (int(rs.randint(1, w // 2)), int(rs.randint(1, h // 2))),
+                                      "size": (int(rs.randint(2, w // 5 + 3)), int(rs.randint(2, h // 5 + 3)))}))
+        place.append((g, "random", {"n": min(n, 4000)}))
+    acting = [g for g in range(G) if rs.rand() < 0.85] or [0]
+    return Scenario("fuzz%d" % seed, make, 0, seed=int(rs.randint(1, 1 << 20)), place=place, steps=int(rs.randint(6, 14)),
+                    action_seed=seed, walls=int(area * float(rs.choice([0, 0, 0.02, 0.08]))), acting=acting,
+                    clear_every=int(rs.choice([1, 1, 1, 2])), obs_every=int(rs.choice([1, 1, 2])))
 
 
 def digest(trajectory):

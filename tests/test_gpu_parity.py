@@ -68,3 +68,12 @@ def test_render_text_dump_matches_reference(tmp_path):
     assert sorted(got) == sorted(want)
     for name in want:
         assert got[name] == want[name], name
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_fuzz_random_games(block, oracle):
+    """differential fuzzing (tests/helpers.fuzz_scenario): random in-scope games -- group count, body sizes, ranges,
+    hp / damage / recover / kill_supply, in-group attack, random rules, map shape, walls, density, clear_dead cadence"""
+    for seed in range(block * 25, block * 25 + 25):
+        sc = H.fuzz_scenario(seed)
+        H.assert_same(H.run(sc, oracle), H.run(sc, H.HIP_LIB), sc.name)

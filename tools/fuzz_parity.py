@@ -1,0 +1,29 @@
+"""Differential fuzzing: random in-scope games, engine A vs engine B, bit for bit.
+
+  python tools/fuzz_parity.py ref oracle 0 300      # here: pins the CPU restatement against the compiled reference
+  python tools/fuzz_parity.py oracle hip 0 300      # GPU box: the HIP engine against the oracle
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["OMP_NUM_THREADS"] = "1"
+if "hip" in sys.argv[1:3]:
+    import torch  # noqa: F401
+import helpers as H  # noqa: E402
+
+LIBS = {"ref": H.REF_LIB, "oracle": H.ensure_oracle(), "hip": H.HIP_LIB}
+a, b, lo, hi = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+bad, t0 = [], time.time()
+for seed in range(lo, hi):
+    sc = H.fuzz_scenario(seed)
+    print("seed", seed, flush=True, file=sys.stderr)
+    try:
+        H.assert_same(H.run(sc, LIBS[a]), H.run(sc, LIBS[b]), sc.name)
+    except AssertionError as e:
+        bad.append(seed)
+        print("FAIL seed %d: %s" % (seed, str(e)[:300]), flush=True)
+print("%d seeds, %d failures %s, %.1fs" % (hi - lo, len(bad), bad, time.time() - t0))
+sys.exit(1 if bad else 0)
