@@ -766,7 +766,7 @@ void Env::step(int *done) {
             grow(d_shuf, shuf_cap, (size_t)A * 5, stream);
             int nb = (A + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
             grow(d_sums, sums_cap, (size_t)nb, stream);
-            int *sj = d_shuf, *scount = d_shuf + A, *soff = d_shuf + 2 * (size_t)A, *scur = d_shuf + 3 * (size_t)A, *slist = d_shuf + 4 * (size_t)A;
+            int *sj = d_shuf, *scount = d_shuf + A, *scur = d_shuf + 2 * (size_t)A, *soff = d_shuf + 3 * (size_t)A, *slist = d_shuf + 4 * (size_t)A;
             launch_shuffle(stream, A, (unsigned)rng.x, sj, scount, soff, scur, slist, d_sums, d_rank);
             rng.skip((unsigned)A);
         }
@@ -804,31 +804,27 @@ void Env::step(int *done) {
     // ---- move
     if (total_n > 0) {
         ProfScope p(*this, "move");
+        // Resolution rounds are launched in batches with ONE convergence check per batch (the flag of the batch's last
+        // round; a resolved agent is a no-op in later rounds).  No check before the first batch: a host round trip
+        // costs more than the rounds it could save.
         int iters = 0;
-        if (!any_multicell) {
-            clear_changed();
-            launch_move_prep(stream, W, d_gtab);
-            // pointer jumping: `move_jump_batch` rounds per convergence check (a resolved agent is a no-op later)
-            while (read_changed()) {
+        auto batch = [&](auto round) {
+            do {
                 for (int k = 0; k < move_jump_batch; k++) {
                     if (k == move_jump_batch - 1) clear_changed();
-                    launch_move_jump(stream, W, d_gtab);
+                    round();
                 }
                 iters += move_jump_batch;
                 if (iters > 1000000) fatal("move resolution did not converge");
-            }
+            } while (read_changed());
+        };
+        if (!any_multicell) {
+            launch_move_prep(stream, W, d_gtab);
+            batch([&] { launch_move_jump(stream, W, d_gtab); });     // pointer jumping
             launch_move_apply(stream, W, d_gtab);
         } else {   // bodies larger than one cell: generic sweeps (kernels.hip, "move, generic bodies")
-            clear_changed();
             launch_movg_prep(stream, W);
-            while (read_changed()) {
-                for (int k = 0; k < move_jump_batch; k++) {
-                    if (k == move_jump_batch - 1) clear_changed();
-                    launch_movg_sweep(stream, W, d_gtab);
-                }
-                iters += move_jump_batch;
-                if (iters > 1000000) fatal("move resolution did not converge");
-            }
+            batch([&] { launch_movg_sweep(stream, W, d_gtab); });
             launch_movg_apply(stream, W, d_gtab);
         }
         last_move_iters = iters;

@@ -411,7 +411,8 @@ __global__ void __launch_bounds__(256) k_iscan_c(const int *in, int n, const int
 // The reference shuffles the attack list with `for i: j = (int)rng() % (i + 1); swap(buf[i], buf[j])`
 // (GridWorld.cc:464-468), rng = minstd_rand0.  Exact parallel replay:
 //   draw   j_i from the i-th engine output, by LCG skip-ahead: r_i = 16807^(i+1) * x0 mod (2^31 - 1)
-//   bucket for every position v the sorted list of steps k with j_k == v (counting sort + tiny insertion sorts)
+//   bucket for every position v the list of steps k with j_k == v (counting sort: int atomics + scan; buckets hold
+//          ln(A / v) entries on average, so they are scanned rather than sorted)
 //   chase  element i sits at j_i after step i; it is moved again by the first later step k whose j_k equals its
 //          position, and then sits at k.  Following that chain (expected length O(log A)) gives its final position.
 __device__ __forceinline__ unsigned mulmod31(unsigned a, unsigned b) {
@@ -438,24 +439,15 @@ __global__ void __launch_bounds__(256) k_shuffle_fill(int A, const int *j, const
     list[offset[v] + atomicAdd(&cursor[v], 1)] = k;
 }
 
-__global__ void __launch_bounds__(256) k_shuffle_sort(int A, const int *offset, const int *count, int *list) {
-    int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= A) return;
-    int n = count[v];
-    if (n < 2) return;
-    int *b = list + offset[v];
-    for (int a = 1; a < n; a++) { int x = b[a], c = a - 1; while (c >= 0 && b[c] > x) { b[c + 1] = b[c]; c--; } b[c + 1] = x; }
-}
-
 __global__ void __launch_bounds__(256) k_shuffle_chase(int A, const int *j, const int *offset, const int *count, const int *list, int *rank) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A) return;
     int p = j[i], t = i;
     while (true) {
         const int *b = list + offset[p];
-        int n = count[p], nxt = -1;
-        for (int c = 0; c < n; c++) { int k = b[c]; if (k > t) { nxt = k; break; } }   // buckets are short and sorted
-        if (nxt < 0) break;
+        int n = count[p], nxt = 0x7FFFFFFF;
+        for (int c = 0; c < n; c++) { int k = b[c]; if (k > t && k < nxt) nxt = k; }   // buckets are short (unsorted)
+        if (nxt == 0x7FFFFFFF) break;
         p = nxt; t = nxt;
     }
     rank[i] = p;
@@ -1082,8 +1074,7 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
 }
 
 void launch_shuffle(hipStream_t s, int A, unsigned x0, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank) {
-    (void)hipMemsetAsync(count, 0, sizeof(int) * A, s);
-    (void)hipMemsetAsync(cursor, 0, sizeof(int) * A, s);
+    (void)hipMemsetAsync(count, 0, sizeof(int) * 2 * (size_t)A, s);   // count and cursor are adjacent
     dim3 g((A + 255) / 256), b(256);
     int nb = (A + ISCAN_TILE - 1) / ISCAN_TILE;
     hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, A, x0, j, count);
@@ -1091,7 +1082,6 @@ void launch_shuffle(hipStream_t s, int A, unsigned x0, int *j, int *count, int *
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, (int *)nullptr);
     hipLaunchKernelGGL(k_iscan_c, dim3(nb), b, 0, s, count, A, sums, offset);
     hipLaunchKernelGGL(k_shuffle_fill, g, b, 0, s, A, j, offset, cursor, list);
-    hipLaunchKernelGGL(k_shuffle_sort, g, b, 0, s, A, offset, count, list);
     hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, A, j, offset, count, list, rank);
 }
 
