@@ -111,6 +111,9 @@ def main():
                          "N/10 walls, N/2 prey + N/2 2x2 predators, N = 2 * --agents")
     ap.add_argument("--gather", choices=["none", "obs"], default="none",
                     help="obs: all_gather the observation tensors of every replica over RCCL each step")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to dry-run the N > 1 "
+                         "code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
@@ -128,11 +131,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()   # dry run: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the tiny timing reductions live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from magent_amd.builtin.config import _games
     if args.workload == "test_1m":
@@ -187,7 +196,8 @@ def main():
         if do_gather:   # the north star's batched-observation gather: every replica's view tensor to every rank
             env.sync()
             for g, h in enumerate(handles):
-                replicas.gather_observations(views[g], env.get_num(h), capacity=n0[g])
+                src = views[g] if args.backend == "nccl" else views[g].cpu()
+                replicas.gather_observations(src, env.get_num(h), capacity=n0[g])
         env.step()
         for g, h in enumerate(handles):
             env.get_reward_device(h, rewards[g])
@@ -218,13 +228,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        a = torch.tensor([agent_steps], dtype=torch.float64, device=dev)
-        dist.all_reduce(a, op=dist.ReduceOp.SUM)
-        agent_steps = float(a.item())
+    if world > 1:   # whole-job aggregate over the slowest replica's time
+        elapsed = replicas.max_over_replicas(elapsed, device=red_dev)
+        agent_steps = replicas.sum_over_replicas(agent_steps, device=red_dev)
 
     roofline, breakdown = None, {}
     if not args.no_profile:
