@@ -789,7 +789,7 @@ struct MoveProbe {
 };
 
 template <bool WANT_BLOCKER>
-__device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g, int i, int tgt_cell) {
+__device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g, int i, int tgt_cell, const unsigned *wanted) {
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
     const unsigned key = G.key[i];
@@ -817,8 +817,9 @@ __device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g,
                 }
                 if (!gone) occupant = o;             // (possibly only "maybe": flagged by `unknown`)
             }
-            if (occupant < 0 || unknown) {
-                // entrants with lower keys
+            // entrants with lower keys -- only where some OTHER candidate's target rectangle covers the cell at all
+            // (wanted[c] counts the candidates whose rectangle covers c; mine is one of them)
+            if ((occupant < 0 || unknown) && wanted[c] > 1) {
                 for (int ga = 0; ga < W.G && occupant < 0; ga++) {
                     const TypeDev TA = W.type[ga];
                     const GroupDev A = W.grp[ga];
@@ -851,7 +852,7 @@ __device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g,
 }
 
 // candidates: alive movers with a non-zero delta whose target rectangle is inside the map (Map.cc:455)
-__global__ void __launch_bounds__(256) k_movg_prep(WorldView W) {
+__global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted) {
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
@@ -866,31 +867,35 @@ __global__ void __launch_bounds__(256) k_movg_prep(WorldView W) {
     }
     G.drank_a[i] = t;
     G.mv[i] = t >= 0 ? 0u : MV_FAIL;      // 0 = undecided (the packed-dependency encoding of the 1x1 path is not used here)
-    if (t >= 0) W.counters[CTR_CHANGED] = 1;
+    if (t >= 0) {
+        const int ny = t / W.w, nx = t - ny * W.w;
+        for (int by = 0; by < T.bl; by++)
+            for (int bx = 0; bx < T.bw; bx++) atomicAdd(&wanted[(ny + by) * W.w + nx + bx], 1u);
+    }
 }
 
-__global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev *gtab) {
+__global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev *gtab, const unsigned *wanted) {
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
     const int t = G.drank_a[i];
     if (t < 0 || G.mv[i] >= MV_OK) return;
-    MoveProbe r = move_probe<false>(W, gtab, g, i, t);
+    MoveProbe r = move_probe<false>(W, gtab, g, i, t, wanted);
     if (r.blocked) G.mv[i] = MV_FAIL;
     else if (!r.undecided) G.mv[i] = MV_OK;
     else W.counters[CTR_CHANGED] = 1;
 }
 
 // Map::get_collide for failed moves (Map.cc:334-353, 486-501): first agent met in the target rectangle
-__global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDev *gtab) {
+__global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDev *gtab, const unsigned *wanted) {
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
     const int t = G.drank_a[i];
     if (t < 0 || G.mv[i] != MV_FAIL) return;
-    MoveProbe r = move_probe<true>(W, gtab, g, i, t);
+    MoveProbe r = move_probe<true>(W, gtab, g, i, t, wanted);
     if (r.blocker >= 0) { G.last_op[i] = OP_COLLIDE; G.op_obj[i] = r.blocker; }
 }
 
@@ -1111,13 +1116,17 @@ void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     hipLaunchKernelGGL(k_move_claim, g, dim3(256), 0, s, W, gtab);
     hipLaunchKernelGGL(k_move_init, g, dim3(256), 0, s, W);
 }
-void launch_movg_prep(hipStream_t s, const WorldView &W) { hipLaunchKernelGGL(k_movg_prep, grid_all(W, 256), dim3(256), 0, s, W); }
+// the per-cell "wanted" counters live in the claim array (unused by the generic path otherwise)
+void launch_movg_prep(hipStream_t s, const WorldView &W) {
+    (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);
+    hipLaunchKernelGGL(k_movg_prep, grid_all(W, 256), dim3(256), 0, s, W, (unsigned *)W.claim);
+}
 void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
-    hipLaunchKernelGGL(k_movg_sweep, grid_all(W, 256), dim3(256), 0, s, W, gtab);
+    hipLaunchKernelGGL(k_movg_sweep, grid_all(W, 256), dim3(256), 0, s, W, gtab, (const unsigned *)W.claim);
 }
 void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     dim3 g = grid_all(W, 256);
-    hipLaunchKernelGGL(k_movg_collide, g, dim3(256), 0, s, W, gtab);
+    hipLaunchKernelGGL(k_movg_collide, g, dim3(256), 0, s, W, gtab, (const unsigned *)W.claim);
     hipLaunchKernelGGL(k_movg_vacate, g, dim3(256), 0, s, W);
     hipLaunchKernelGGL(k_movg_enter, g, dim3(256), 0, s, W);
 }
