@@ -653,8 +653,6 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
     P.div_scale_w = make_fastdiv(R.scale_w); P.div_scale_h = make_fastdiv(R.scale_h);
 }
 
-WorldView Env::view_for_plan() const { WorldView W{}; W.G = (int)groups.size(); return W; }
-
 // GridWorld::get_observation (GridWorld.cc:292-401) into DEVICE buffers, asynchronous on the env stream
 void Env::observe_device(int g, float *view, float *feat) {
     if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_observation : %d", g);

@@ -131,7 +131,6 @@ private:
     void ensure_capacity(HostGroup &g, int need);
     void ensure_tables();
     WorldView view() const;
-    WorldView view_for_plan() const;
     int *read_counters();
     bool read_changed();
     void clear_changed();

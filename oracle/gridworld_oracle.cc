@@ -4,7 +4,7 @@
 // the small calls around them), used ONLY as the checker by tests/, __graft_entry__.smoke() and bench.py's
 // cpu_baseline leg.  The product (magent_amd/csrc) never includes, links or calls anything in this file.
 //
-// Parity status: PINNED.  This restatement is checked (tests/test_oracle_vs_reference.py) against the reference
+// Parity status: PINNED.  This restatement is checked (tests/test_oracle.py; tools/fuzz_parity.py ref oracle) against the reference
 // engine itself, compiled from /root/reference/src into oracle/_ref/libmagent_ref.so and run with
 // OMP_NUM_THREADS=1, on seeded trajectories; and against the golden vectors under tests/golden/ that were generated
 // from that build (tests/golden/make_golden.py).  The reference's own tests hold no vectors.
