@@ -36,6 +36,14 @@ def main():
     for r in rows[:24]:
         lines.append("| `%s` | %s | %.1f | %.3f | %s |" % (r["Name"].split("(")[0][:70], r["Calls"], float(r["AverageNs"]) / 1e3,
                                                         float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+    log = stats_dir.rstrip("/") + ".log"
+    if os.path.exists(log):
+        for line in open(log, errors="ignore"):
+            if line.startswith("{") and '"roofline"' in line:
+                rec = json.loads(line)
+                lines += ["", "bench.py's own HIP-event timing in this very run (must agree with the k_render row above):",
+                          "", "```", json.dumps(rec["roofline"]), "```",
+                          "", "whole job in the profiled run: %.3e %s, %.3f ms/step" % (rec["value"], rec["unit"], rec["ms_per_step"])]
     if len(sys.argv) >= 5:
         fetch, nf = pmc_avg(sys.argv[3], "FETCH_SIZE")
         write, _ = pmc_avg(sys.argv[4], "WRITE_SIZE")
