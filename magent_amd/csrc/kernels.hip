@@ -240,12 +240,25 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, Rende
 }
 
 // feature rows [id bits x E | one-hot last_action x NA | last_reward | x / w | y / h] (GridWorld.cc:386-396)
-__device__ __forceinline__ float feature_value(const WorldView &W, const RenderArgs &R, const GroupDev &Gd, int i, int f) {
-    if (f < R.E) return (f < 31) ? (float)((Gd.id[i] >> f) & 1) : 0.0f;
-    if (f < R.E + R.NA) return (Gd.last_action[i] == f - R.E) ? 1.0f : 0.0f;
-    if (f == R.E + R.NA) return Gd.last_reward[i];                       // a fresh agent's last_action == NA lands here
-    if (f == R.E + R.NA + 1) return __fdiv_rn((float)Gd.x[i], (float)W.w);  // and is overwritten (GridWorld.cc:390-392)
-    return __fdiv_rn((float)Gd.y[i], (float)W.h);
+struct AgentFeat { int id, la; float lr, fx, fy; };
+
+__device__ __forceinline__ AgentFeat load_feat(const WorldView &W, const GroupDev &Gd, int i) {
+    AgentFeat a;
+    a.id = Gd.id[i]; a.la = Gd.last_action[i]; a.lr = Gd.last_reward[i];
+    a.fx = __fdiv_rn((float)Gd.x[i], (float)W.w);
+    a.fy = __fdiv_rn((float)Gd.y[i], (float)W.h);
+    return a;
+}
+
+// value of feature slot f from registers (no loads, no divergent paths with memory behind them)
+__device__ __forceinline__ float feature_value(const RenderArgs &R, const AgentFeat &a, int f) {
+    const int rel = f - R.E;
+    float v = (f < 31 && ((a.id >> f) & 1)) ? 1.0f : 0.0f;                 // id bits, LSB first
+    v = f >= R.E ? (a.la == rel ? 1.0f : 0.0f) : v;                        // one-hot last action
+    v = rel == R.NA ? a.lr : v;                                            // a fresh agent's last_action == NA lands here
+    v = rel == R.NA + 1 ? a.fx : v;                                        // and is overwritten (GridWorld.cc:390-392)
+    v = rel == R.NA + 2 ? a.fy : v;
+    return v;
 }
 
 template <bool VEC4>
@@ -254,21 +267,26 @@ __global__ void __launch_bounds__(256) k_features(WorldView W, RenderArgs R, Ren
     const unsigned total = (unsigned)R.n * (unsigned)R.F;
     const unsigned nq = VEC4 ? total >> 2 : 0;
     for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
-        unsigned k = q << 2;
-        int i = fdiv_u32(k, P.div_f);
+        const unsigned k = q << 2;
+        const int i = fdiv_u32(k, P.div_f);
         int f = k - i * R.F;
+        // four consecutive floats touch at most two agents when F >= 4 (the feature row always holds >= 2 slots, so
+        // the general case walks on); both agents' fields are loaded up front so the loads overlap
+        AgentFeat a0 = load_feat(W, Gd, i), a1 = load_feat(W, Gd, min(i + 1, R.n - 1));
+        int cur = i;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            v[e] = feature_value(W, R, Gd, i, f);
-            if (++f == R.F) { f = 0; ++i; }
+            if (cur > i + 1) { a1 = load_feat(W, Gd, cur); }               // only when F < 3 (never in practice)
+            v[e] = feature_value(R, cur == i ? a0 : a1, f);
+            if (++f == R.F) { f = 0; ++cur; }
         }
         v4f f4 = {v[0], v[1], v[2], v[3]};
         __builtin_nontemporal_store(f4, (v4f *)R.feat + q);
     }
     for (unsigned k = (nq << 2) + blockIdx.x * blockDim.x + threadIdx.x; k < total; k += gridDim.x * blockDim.x) {
         const int i = fdiv_u32(k, P.div_f);
-        R.feat[k] = feature_value(W, R, Gd, i, k - i * R.F);
+        R.feat[k] = feature_value(R, load_feat(W, Gd, i), k - i * R.F);
     }
 }
 
@@ -1064,7 +1082,7 @@ void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const
 void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4) {
     if (R.n <= 0) return;
     unsigned total = (unsigned)R.n * (unsigned)R.F;
-    int fb = (int)std::min<unsigned>((total / 4 + 255) / 256 + 1, 2048);
+    int fb = (int)std::min<unsigned>((total / 4 + 255) / 256 + 1, 16384);   // ~1 float4 per thread: latency-bound gathers
     if (vec4) hipLaunchKernelGGL((k_features<true>), dim3(fb), dim3(256), 0, s, W, R, P);
     else hipLaunchKernelGGL((k_features<false>), dim3(fb), dim3(256), 0, s, W, R, P);
 }
