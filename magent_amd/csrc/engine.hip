@@ -518,7 +518,7 @@ void Env::reset() {
     move_seq_base = 0;
     if (!rules_compiled) { compile_rules(); rules_compiled = true; }  // once, like init_reward_description
     tables_valid = false;
-    paint_valid = false;
+    paint_valid = false; mini_valid = false;
 }
 
 void Env::download_occ() {
@@ -530,7 +530,7 @@ void Env::download_occ() {
 
 void Env::upload_occ() {
     HIP_OK(hipMemcpy(d_occ, h_occ.data(), sizeof(int) * h_occ.size(), hipMemcpyHostToDevice));
-    paint_valid = false;
+    paint_valid = false; mini_valid = false;
 }
 
 // Map::is_blank_area (Map.cc:454-470)
@@ -673,8 +673,13 @@ void Env::observe_device(int g, float *view, float *feat) {
         grow(d_mini, mini_cap, need, stream);
         grow(d_minif, minif_cap, need, stream);
         R.mini = d_minif;
-        ProfScope p(*this, "minimap");
-        launch_minimap(stream, W, R, d_mini, d_minif);
+        long long pop = 0;
+        for (auto &gr : groups) pop = pop * 1000003ll + gr.n;
+        if (!(mini_valid && mini_vh == R.VH && mini_vw == R.VW && mini_pop == pop)) {
+            ProfScope p(*this, "minimap");
+            launch_minimap(stream, W, R, d_mini, d_minif);
+            mini_valid = true; mini_vh = R.VH; mini_vw = R.VW; mini_pop = pop;
+        }
     }
     const bool aligned = (((uintptr_t)view) & 15) == 0;
     {
@@ -848,7 +853,7 @@ void Env::step(int *done) {
     HIP_OK(hipMemsetAsync(d_counters + CTR_TRIGGER, 0, sizeof(int) * (CTR_TOTAL - CTR_TRIGGER), stream));
     move_seq_base = 0;
     h_occ_valid = false;
-    paint_valid = false;
+    paint_valid = false; mini_valid = false;
 }
 
 // ------------------------------------------------------------------------------------------------ reward / clear_dead
@@ -897,7 +902,7 @@ void Env::clear_dead() {
         }
     }
     HIP_OK(hipMemsetAsync(d_counters + CTR_DEAD, 0, sizeof(int) * MAXG, stream));
-    if (any) { tables_valid = false; h_occ_valid = false; }
+    if (any) { tables_valid = false; h_occ_valid = false; mini_valid = false; }
 }
 
 // ------------------------------------------------------------------------------------------------ info

@@ -168,6 +168,8 @@ private:
 
     // device state
     bool device_ready = false, tables_valid = false, paint_valid = false;
+    // the minimap histogram depends on the view shape and on the positions only: both groups of a battle step share it
+    bool mini_valid = false; int mini_vh = 0, mini_vw = 0; long long mini_pop = -1;
     size_t map_cells = 0;
     int *d_occ = nullptr;
     int2 *d_viewcell = nullptr;
