@@ -43,12 +43,12 @@ def cpu_baseline_worker(args):
     import numpy as np
     import magent_amd
     lib = args.cpu_lib
-    env = magent_amd.GridWorld("battle", lib=lib, map_size=MAP_SIZE)
+    env = magent_amd.GridWorld("battle", lib=lib, map_size=args.map_size)
     env.set_seed(12345)
     env.reset()
     handles = env.get_handles()
     for h in handles:
-        env.add_agents(h, "random", n=N_PER_GROUP)
+        env.add_agents(h, "random", n=args.agents)
     rs = np.random.RandomState(0)
     agent_steps, elapsed = 0, 0.0
     for step in range(args.cpu_steps + 1):
@@ -69,7 +69,7 @@ def cpu_baseline_worker(args):
     print(json.dumps({"agent_steps": agent_steps, "seconds": elapsed}))
 
 
-def run_cpu_baseline():
+def run_cpu_baseline(map_size=MAP_SIZE, agents=N_PER_GROUP, steps=2):
     ref = os.path.join(ROOT, "oracle", "_ref", "libmagent_ref.so")
     port = os.path.join(ROOT, "oracle", "liboracle.so")
     if os.path.exists(ref):
@@ -81,12 +81,12 @@ def run_cpu_baseline():
     ncpu = os.cpu_count() or 1
     best = None
     threads = [1] if kind == "port" else sorted({1, max(1, ncpu // 2)})
-    steps = 2
     for th in threads:
         env = dict(os.environ, OMP_NUM_THREADS=str(th), MAGENT_AMD_NO_TORCH="1")
         try:
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--cpu-lib", lib,
-                                  "--cpu-steps", str(steps)], env=env, capture_output=True, text=True, timeout=600)
+                                  "--cpu-steps", str(steps), "--map-size", str(map_size), "--agents", str(agents)],
+                                 env=env, capture_output=True, text=True, timeout=600)
             rec = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # the baseline is a reported extra; never fail the bench for it
             sys.stderr.write("cpu_baseline(%d threads) failed: %r\n" % (th, e))
@@ -287,7 +287,9 @@ def main():
             "breakdown": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = run_cpu_baseline()
+            small = args.map_size * args.map_size <= 250000
+            rec["cpu_baseline"] = run_cpu_baseline(args.map_size, args.agents, steps=200 if small else 2) \
+                if args.workload == "battle" else None
         else:
             rec["cpu_baseline"] = None
         print(json.dumps(rec))

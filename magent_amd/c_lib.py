@@ -49,9 +49,15 @@ DEVICE_ABI = [
 ]
 
 _cache = {}
+_lock = __import__("threading").Lock()
 
 
 def load(path=None):
+    with _lock:   # environments may be constructed from several threads at once
+        return _load(path)
+
+
+def _load(path=None):
     """dlopen the engine library and declare argtypes for every entry point it exports.
 
     RTLD_LOCAL on purpose: the CPU checkers under oracle/ export the same names and must be loadable

@@ -68,12 +68,7 @@ class GridWorld(object):
             kind = _CONFIG_KINDS[key]
             if key == "device_id" and not getattr(L, "has_device_api", False):
                 continue  # additive key: only the MI355X engine knows it
-            if kind is int:
-                L.env_config_game(self.game, key.encode(), ctypes.cast(ctypes.byref(ctypes.c_int(val)), ctypes.c_void_p))
-            elif kind is bool:
-                L.env_config_game(self.game, key.encode(), ctypes.cast(ctypes.byref(ctypes.c_bool(val)), ctypes.c_void_p))
-            else:
-                L.env_config_game(self.game, key.encode(), ctypes.cast(ctypes.c_char_p(val.encode()), ctypes.c_void_p))
+            self._config(key, kind, val)
 
         # agent types: parallel key/value arrays; a range object expands to (radius, angle) (gridworld.py:66-86)
         for name, attr in config.agent_type_dict.items():
@@ -106,6 +101,18 @@ class GridWorld(object):
             self.feature_space[h.value] = (int(tmp[0]),)
             L.env_get_info(self.game, h.value, b"action_space", tmp.ctypes.data)
             self.action_space[h.value] = (int(tmp[0]),)
+
+    def _config(self, key, kind, val):
+        """env_config_game takes a void* whose pointee type depends on the key (GridWorld.cc:120-149); the ctypes
+        object is held in a local until the call returns"""
+        if kind is int:
+            box = ctypes.c_int(val)
+        elif kind is bool:
+            box = ctypes.c_bool(val)
+        else:
+            box = ctypes.create_string_buffer(val.encode())
+        self._lib.env_config_game(self.game, key.encode(), ctypes.addressof(box))
+        del box
 
     # ------------------------------------------------------------------ setup
     def reset(self):
@@ -248,13 +255,13 @@ class GridWorld(object):
         raise NotImplementedError("mean_info is deprecated in the reference and not provided by this engine")
 
     def set_seed(self, seed):
-        self._lib.env_config_game(self.game, b"seed", ctypes.cast(ctypes.byref(ctypes.c_int(seed)), ctypes.c_void_p))
+        self._config("seed", int, int(seed))
 
     # ------------------------------------------------------------------ render (host-side text dump)
     def set_render_dir(self, name):
         if not os.path.exists(name):
             os.mkdir(name)
-        self._lib.env_config_game(self.game, b"render_dir", ctypes.cast(ctypes.c_char_p(name.encode()), ctypes.c_void_p))
+        self._config("render_dir", str, name)
 
     def render(self):
         self._lib.env_render(self.game)
