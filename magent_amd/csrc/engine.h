@@ -70,7 +70,7 @@ struct WorldView {
     unsigned long long *claim;
     const int2 *delta;
     const unsigned char *mask;
-    int *counters;               // [0] changed flag, [1] attack count, [2..2+MAXG) dead_ct, [16..) rule triggers
+    int *counters;               // CTR_* below: changed flag, attack count, dead_ct per group, gates, rule triggers
     TypeDev type[MAXG];
     GroupDev grp[MAXG];
     int any_kill_supply;
@@ -79,6 +79,11 @@ struct WorldView {
 };
 
 constexpr int CTR_CHANGED = 0, CTR_ATTACK = 1, CTR_DEAD = 2, CTR_PACK_OVERFLOW = 12, CTR_TRIGGER = 16, CTR_TOTAL = 64;
+// single-sync step: fixed-point rounds are launched optimistically and gated on the device
+constexpr int CTR_NEED_HOST = 10;   // 0 = the step ran through; 1 / 2 = attack / move rounds ran out, host continues
+constexpr int CTR_PHASE_DONE = 11;  // the current fixed point has converged: further rounds of this phase return at once
+constexpr int CTR_RNG = 13;         // engine RNG state (minstd_rand0), advanced on the device by the attack shuffle
+constexpr int CTR_LAST_A = 14;      // attack-list length of the last step (host information)
 
 // observation render parameters for one get_observation(group) call
 struct RenderArgs {

@@ -186,6 +186,9 @@ Env::Env() {
     if (const char *v = std::getenv("MAGENT_RENDER_SPAN")) render_steps_per_span = std::atoi(v);
     if (const char *v = std::getenv("MAGENT_RENDER_UNROLL")) render_unroll = std::atoi(v);
     if (const char *v = std::getenv("MAGENT_HOST_SHUFFLE")) host_shuffle = std::atoi(v) != 0;
+    if (const char *v = std::getenv("MAGENT_CHECKED_STEP")) checked_step = std::atoi(v) != 0;
+    if (const char *v = std::getenv("MAGENT_OPT_ATTACK_PAIRS")) opt_attack_pairs = std::max(0, std::atoi(v));
+    if (const char *v = std::getenv("MAGENT_OPT_MOVE_BATCHES")) opt_move_batches = std::max(0, std::atoi(v));
     if (const char *v = std::getenv("MAGENT_RENDER_NT")) nt_stores = std::atoi(v) != 0;
 }
 
@@ -241,7 +244,7 @@ void Env::set_config(const char *key, void *p) {
     else if (k == "map_height") height = *(int *)p;
     else if (k == "minimap_mode") minimap_mode = *(bool *)p;
     else if (k == "embedding_size") embedding_size = *(int *)p;
-    else if (k == "seed") rng.seed((unsigned long)*(int *)p);
+    else if (k == "seed") { rng.seed((unsigned long)*(int *)p); rng_on_device = false; }
     else if (k == "device_id") { if (device_ready && *(int *)p != device_id) fatal("device_id must be set before env_reset"); device_id = *(int *)p; }
     else if (k == "render_dir") render_dir = (const char *)p;
     else if (k == "food_mode" || k == "turn_mode" || k == "goal_mode") {
@@ -515,6 +518,7 @@ void Env::reset() {
     if (!delta.empty()) HIP_OK(hipMemcpy(d_delta, delta.data(), sizeof(int2) * delta.size(), hipMemcpyHostToDevice));
     if (!mask.empty()) HIP_OK(hipMemcpy(d_mask, mask.data(), mask.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemset(d_counters, 0, sizeof(int) * CTR_TOTAL));
+    rng_on_device = false;
     move_seq_base = 0;
     if (!rules_compiled) { compile_rules(); rules_compiled = true; }  // once, like init_reward_description
     tables_valid = false;
@@ -546,6 +550,7 @@ bool Env::host_blank(int x, int y, int bw, int bl) const {
 void Env::host_random_blank(int bw, int bl, int &ox, int &oy) {
     int tries = 0;
     while (true) {
+        rng_on_device = false;   // the host draws: its copy of the engine state is the current one again
         int x = (int)rng() % (width - bw);
         int y = (int)rng() % (height - bl);
         if (host_blank(x, y, bw, bl)) { ox = x; oy = y; return; }
@@ -736,7 +741,71 @@ void Env::set_action_host(int g, const int *actions) {
 }
 
 // ------------------------------------------------------------------------------------------------ step
-// GridWorld::step (GridWorld.cc:456-631)
+// GridWorld::step (GridWorld.cc:456-631).
+//
+// Two drivers over the same kernels:
+//   * single-sync (default): every phase is enqueued without waiting for the device.  The attack list length and the
+//     engine RNG state are read on the device; the fixed-point rounds of the attack and move phases are launched
+//     optimistically (`opt_attack_pairs` pairs, `opt_move_batches` batches) and gated on the device -- a round
+//     returns at once when its phase has converged.  ONE readback at the end returns `done`, the death counts, the
+//     RNG state and whether a phase ran out of rounds; in that (rare) case everything after that phase has been
+//     skipped on the device and the host continues from exactly that state with the checked driver.
+//   * checked: the host reads the convergence flag after every pair / batch (also used while the text render is
+//     recording attack events, and with MAGENT_HOST_SHUFFLE / MAGENT_CHECKED_STEP for A/B runs).
+void Env::shuffle_buffers(int n_max) {
+    grow(d_rank, rank_cap, (size_t)n_max, stream);
+    grow(d_shuf, shuf_cap, (size_t)n_max * 5, stream);
+    int nb = (n_max + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
+    grow(d_sums, sums_cap, (size_t)nb, stream);
+}
+
+void Env::push_rng() {
+    if (rng_on_device) return;
+    launch_set_rng(stream, d_counters, (unsigned)rng.x);
+    rng_on_device = true;
+}
+
+// attack rounds, host-checked: pairs with ONE convergence check per pair (the flag of the second round)
+void Env::attack_rounds_checked(const WorldView &W) {
+    int iters = 0;
+    while (true) {
+        clear_changed();
+        launch_attack_iter(stream, W, d_gtab, d_ttab, 0, attack_kmax, 0);
+        launch_attack_iter(stream, W, d_gtab, d_ttab, 1, attack_kmax, 1);
+        iters += 2;
+        if (!read_changed()) break;
+        if (iters > 1000000) fatal("attack resolution did not converge");
+    }
+    last_attack_iters = iters;
+}
+
+// move rounds, host-checked: `move_jump_batch` rounds per convergence check (a resolved agent is a no-op later)
+void Env::move_rounds_checked(const WorldView &W) {
+    int iters = 0;
+    do {
+        clear_changed();
+        for (int k = 0; k < move_jump_batch; k++) {
+            const int last = k == move_jump_batch - 1;
+            if (any_multicell) launch_movg_sweep(stream, W, d_gtab, last); else launch_move_jump(stream, W, d_gtab, last);
+        }
+        iters += move_jump_batch;
+        if (iters > 1000000) fatal("move resolution did not converge");
+    } while (read_changed());
+    last_move_iters = iters;
+}
+
+void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 = after move rounds */) {
+    if (from == 0) {
+        launch_attack_apply(stream, W, d_gtab, d_ttab, 0, attack_kmax);
+        launch_starve(stream, W);
+        if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);
+        move_rounds_checked(W);
+    }
+    if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
+    for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
+    launch_finish(stream, W);
+}
+
 void Env::step(int *done) {
     if (!device_ready) fatal("step called before reset");
     use_device();
@@ -744,101 +813,125 @@ void Env::step(int *done) {
     WorldView W = view();
     int total_n = 0;
     for (auto &g : groups) total_n += g.n;
+    const bool fast = !checked_step && !host_shuffle && first_render;
+    const int *c = nullptr;
 
-    // ---- attack: the shuffle consumes exactly A draws (GridWorld.cc:464-468); rank[seq] = shuffled position
-    const int A = read_counters()[CTR_ATTACK];
-    if (A > 0) {
-        ProfScope p(*this, "attack");
-        if (host_shuffle) {   // the reference's literal loop on the host (kept for A/B checks: MAGENT_HOST_SHUFFLE=1)
-            if ((size_t)A > hrank_cap) {
-                if (h_rank) HIP_OK(hipHostFree(h_rank));
-                hrank_cap = std::max<size_t>((size_t)A, hrank_cap * 2);
-                HIP_OK(hipHostMalloc((void **)&h_rank, sizeof(int) * hrank_cap, hipHostMallocDefault));
+    if (total_n == 0) {
+        c = read_counters();
+    } else if (fast) {
+        // ---------------- single-sync driver
+        shuffle_buffers(total_n);
+        push_rng();
+        int *sj = d_shuf, *scount = d_shuf + total_n, *scur = d_shuf + 2 * (size_t)total_n, *soff = d_shuf + 3 * (size_t)total_n,
+            *slist = d_shuf + 4 * (size_t)total_n;
+        {
+            ProfScope p(*this, "attack");
+            launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank);
+            launch_attack_rank(stream, W, d_rank);
+            launch_phase_begin(stream, d_counters);
+            for (int pair = 0; pair < opt_attack_pairs; pair++) {
+                launch_attack_iter(stream, W, d_gtab, d_ttab, 0, attack_kmax, 0);
+                launch_attack_iter(stream, W, d_gtab, d_ttab, 1, attack_kmax, 1);   // only the pair's second round reports
+                launch_gate(stream, d_counters, pair == opt_attack_pairs - 1 ? 1 : 0, 0);
             }
-            grow(d_rank, rank_cap, (size_t)A, stream);
-            shuffle_perm.resize(A);
-            for (int i = 0; i < A; i++) shuffle_perm[i] = i;
-            for (int i = 0; i < A; i++) {
-                int j = (int)rng() % (i + 1);
-                std::swap(shuffle_perm[i], shuffle_perm[j]);
-            }
-            for (int pos = 0; pos < A; pos++) h_rank[shuffle_perm[pos]] = pos;
-            HIP_OK(hipMemcpyAsync(d_rank, h_rank, sizeof(int) * A, hipMemcpyHostToDevice, stream));
-        } else {              // exact parallel replay on the device; the host only advances the engine state by A draws
-            grow(d_rank, rank_cap, (size_t)A, stream);
-            grow(d_shuf, shuf_cap, (size_t)A * 5, stream);
-            int nb = (A + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
-            grow(d_sums, sums_cap, (size_t)nb, stream);
-            int *sj = d_shuf, *scount = d_shuf + A, *scur = d_shuf + 2 * (size_t)A, *soff = d_shuf + 3 * (size_t)A, *slist = d_shuf + 4 * (size_t)A;
-            launch_shuffle(stream, A, (unsigned)rng.x, sj, scount, soff, scur, slist, d_sums, d_rank);
-            rng.skip((unsigned)A);
+            if (opt_attack_pairs == 0) launch_gate(stream, d_counters, 1, 1);
+            launch_attack_apply(stream, W, d_gtab, d_ttab, 0, attack_kmax);
         }
-        launch_attack_rank(stream, W, d_rank);
-        // Jacobi rounds run in pairs with ONE convergence check per pair (the flag of the second round): a host
-        // round-trip costs about as much as a round, and two rounds settle almost every step
-        int use_b = 0, iters = 0;
-        while (true) {
-            launch_attack_iter(stream, W, d_gtab, d_ttab, use_b, attack_kmax);
-            use_b ^= 1;
-            clear_changed();
-            launch_attack_iter(stream, W, d_gtab, d_ttab, use_b, attack_kmax);
-            use_b ^= 1;
-            iters += 2;
-            if (!read_changed()) break;
-            if (iters > 100000) fatal("attack resolution did not converge");
+        {
+            ProfScope p(*this, "starve");
+            launch_starve(stream, W);
         }
-        if (!first_render) {   // attack events are recorded once rendering has started (GridWorld.cc:484,508)
-            grow(d_events, events_cap, (size_t)A, stream);
-            launch_attack_events(stream, W, use_b, d_events);
-            std::vector<int4> ev(A);
-            HIP_OK(hipMemcpyAsync(ev.data(), d_events, sizeof(int4) * A, hipMemcpyDeviceToHost, stream));
-            HIP_OK(hipStreamSynchronize(stream));
-            attack_events.clear();
-            for (const int4 &e : ev) if (e.w) attack_events.push_back({e.x, e.y, e.z});
-        }
-        launch_attack_apply(stream, W, d_gtab, d_ttab, use_b, attack_kmax);
-        last_attack_iters = iters;
-    } else if (!first_render) attack_events.clear();
-    // ---- starve / recover
-    if (total_n > 0) {
-        ProfScope p(*this, "starve");
-        launch_starve(stream, W);
-    }
-    // ---- move
-    if (total_n > 0) {
-        ProfScope p(*this, "move");
-        // Resolution rounds are launched in batches with ONE convergence check per batch (the flag of the batch's last
-        // round; a resolved agent is a no-op in later rounds).  No check before the first batch: a host round trip
-        // costs more than the rounds it could save.
-        int iters = 0;
-        auto batch = [&](auto round) {
-            do {
+        {
+            ProfScope p(*this, "move");
+            if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);
+            launch_phase_begin(stream, d_counters);
+            for (int b = 0; b < opt_move_batches; b++) {
                 for (int k = 0; k < move_jump_batch; k++) {
-                    if (k == move_jump_batch - 1) clear_changed();
-                    round();
+                    const int last = k == move_jump_batch - 1;
+                    if (any_multicell) launch_movg_sweep(stream, W, d_gtab, last); else launch_move_jump(stream, W, d_gtab, last);
                 }
-                iters += move_jump_batch;
-                if (iters > 1000000) fatal("move resolution did not converge");
-            } while (read_changed());
-        };
-        if (!any_multicell) {
-            launch_move_prep(stream, W, d_gtab);
-            batch([&] { launch_move_jump(stream, W, d_gtab); });     // pointer jumping
-            launch_move_apply(stream, W, d_gtab);
-        } else {   // bodies larger than one cell: generic sweeps (kernels.hip, "move, generic bodies")
-            launch_movg_prep(stream, W);
-            batch([&] { launch_movg_sweep(stream, W, d_gtab); });
-            launch_movg_apply(stream, W, d_gtab);
+                launch_gate(stream, d_counters, b == opt_move_batches - 1 ? 2 : 0, 0);
+            }
+            if (opt_move_batches == 0) launch_gate(stream, d_counters, 2, 1);
+            if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
         }
-        last_move_iters = iters;
+        {
+            ProfScope p(*this, "rules");
+            for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
+            launch_finish(stream, W);
+        }
+        c = read_counters();
+        if (c[CTR_NEED_HOST]) {   // a phase ran out of optimistic rounds: continue from that state, host-checked
+            const int phase = c[CTR_NEED_HOST];
+            fallback_steps++;
+            HIP_OK(hipMemsetAsync(d_counters + CTR_NEED_HOST, 0, 2 * sizeof(int), stream));   // NEED_HOST, PHASE_DONE
+            clear_changed();
+            if (phase == 1) { attack_rounds_checked(W); phase_tail(W, 0); }
+            else { move_rounds_checked(W); phase_tail(W, 1); }
+            c = read_counters();
+        }
+        rng.x = (unsigned)c[CTR_RNG];   // the device advanced the engine state by A draws
+    } else {
+        // ---------------- checked driver
+        HIP_OK(hipMemsetAsync(d_counters + CTR_NEED_HOST, 0, 2 * sizeof(int), stream));
+        const int A = read_counters()[CTR_ATTACK];
+        if (A > 0) {
+            ProfScope p(*this, "attack");
+            shuffle_buffers(std::max(A, total_n));
+            if (host_shuffle) {   // the reference's literal loop on the host (MAGENT_HOST_SHUFFLE=1, for A/B checks)
+                if (rng_on_device) { rng.x = (unsigned)read_counters()[CTR_RNG]; }
+                if ((size_t)A > hrank_cap) {
+                    if (h_rank) HIP_OK(hipHostFree(h_rank));
+                    hrank_cap = std::max<size_t>((size_t)A, hrank_cap * 2);
+                    HIP_OK(hipHostMalloc((void **)&h_rank, sizeof(int) * hrank_cap, hipHostMallocDefault));
+                }
+                shuffle_perm.resize(A);
+                for (int i = 0; i < A; i++) shuffle_perm[i] = i;
+                for (int i = 0; i < A; i++) {
+                    int j = (int)rng() % (i + 1);
+                    std::swap(shuffle_perm[i], shuffle_perm[j]);
+                }
+                for (int pos = 0; pos < A; pos++) h_rank[shuffle_perm[pos]] = pos;
+                HIP_OK(hipMemcpyAsync(d_rank, h_rank, sizeof(int) * A, hipMemcpyHostToDevice, stream));
+                rng_on_device = false;
+            } else {              // exact parallel replay on the device
+                push_rng();
+                int *sj = d_shuf, *scount = d_shuf + total_n, *scur = d_shuf + 2 * (size_t)total_n,
+                    *soff = d_shuf + 3 * (size_t)total_n, *slist = d_shuf + 4 * (size_t)total_n;
+                launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank);
+            }
+            launch_attack_rank(stream, W, d_rank);
+            attack_rounds_checked(W);
+            if (!first_render) {   // attack events are recorded once rendering has started (GridWorld.cc:484,508)
+                grow(d_events, events_cap, (size_t)A, stream);
+                launch_attack_events(stream, W, 0, d_events);
+                std::vector<int4> ev(A);
+                HIP_OK(hipMemcpyAsync(ev.data(), d_events, sizeof(int4) * A, hipMemcpyDeviceToHost, stream));
+                HIP_OK(hipStreamSynchronize(stream));
+                attack_events.clear();
+                for (const int4 &e : ev) if (e.w) attack_events.push_back({e.x, e.y, e.z});
+            }
+            launch_attack_apply(stream, W, d_gtab, d_ttab, 0, attack_kmax);
+        } else if (!first_render) attack_events.clear();
+        {
+            ProfScope p(*this, "starve");
+            launch_starve(stream, W);
+        }
+        {
+            ProfScope p(*this, "move");
+            if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);
+            move_rounds_checked(W);
+            if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
+        }
+        {
+            ProfScope p(*this, "rules");
+            for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
+            launch_finish(stream, W);
+        }
+        c = read_counters();
+        if (rng_on_device) rng.x = (unsigned)c[CTR_RNG];
     }
-    // ---- reward rules + end of step
-    if (total_n > 0) {
-        ProfScope p(*this, "rules");
-        for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
-        launch_finish(stream, W);
-    }
-    const int *c = read_counters();
+
     int live = 0;
     for (size_t g = 0; g < groups.size(); g++) {
         groups[g].h_dead = c[CTR_DEAD + g];

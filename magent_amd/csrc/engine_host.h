@@ -116,7 +116,9 @@ public:
     int render_unroll = 1;
     bool host_shuffle = false;
     int move_jump_batch = 3;
-    int last_attack_iters = 0, last_move_iters = 0;
+    int last_attack_iters = 0, last_move_iters = 0, fallback_steps = 0;
+    bool checked_step = false;            // host-checked convergence instead of the single-sync driver
+    int opt_attack_pairs = 2, opt_move_batches = 2;   // optimistic rounds of the single-sync driver
 
 private:
     struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
@@ -135,6 +137,12 @@ private:
     bool read_changed();
     void clear_changed();
     void compile_rules();
+    void shuffle_buffers(int n_max);
+    void push_rng();
+    void attack_rounds_checked(const WorldView &W);
+    void move_rounds_checked(const WorldView &W);
+    void phase_tail(const WorldView &W, int from);
+    bool rng_on_device = false;           // the device copy of the RNG state (CTR_RNG) is current
     void download_occ();
     void upload_occ();
     bool host_blank(int x, int y, int bw, int bl) const;

@@ -43,6 +43,32 @@ __device__ __forceinline__ void body_fill(const WorldView &W, int x, int y, int 
         for (int bx = 0; bx < bw; bx++) W.occ[(y + by) * W.w + x + bx] = v;
 }
 
+// Gates of the single-sync step (engine.hip: Env::step).  Fixed-point rounds are launched without waiting for the
+// host; a round returns at once when its phase has already converged, and everything after a phase whose rounds ran
+// out returns at once so that the host can take over from exactly that state.
+__device__ __forceinline__ bool gate_round(const WorldView &W) { return (W.counters[CTR_PHASE_DONE] | W.counters[CTR_NEED_HOST]) != 0; }
+__device__ __forceinline__ bool gate_after(const WorldView &W) { return W.counters[CTR_NEED_HOST] != 0; }
+
+__global__ void k_phase_begin(int *counters) {
+    if (threadIdx.x == 0) { counters[CTR_PHASE_DONE] = 0; counters[CTR_CHANGED] = 0; }
+}
+// after a batch of rounds: converged iff the batch's last round changed nothing; `fail_code` != 0 marks the last batch
+__global__ void k_gate(int *counters, int fail_code, int force) {
+    if (threadIdx.x != 0) return;
+    if (force) { if (!counters[CTR_NEED_HOST]) counters[CTR_NEED_HOST] = fail_code; return; }   // tests: no optimistic round
+    if (!counters[CTR_PHASE_DONE] && !counters[CTR_CHANGED]) counters[CTR_PHASE_DONE] = 1;
+    counters[CTR_CHANGED] = 0;
+    if (fail_code && !counters[CTR_PHASE_DONE] && !counters[CTR_NEED_HOST]) counters[CTR_NEED_HOST] = fail_code;
+}
+__global__ void k_set_rng(int *counters, unsigned x) { if (threadIdx.x == 0) counters[CTR_RNG] = (int)x; }
+
+// memset that respects the gate: the claim array still holds the attack phase's hit bits when the host has to continue
+// the attack rounds
+__global__ void __launch_bounds__(256) k_fill32_gated(WorldView W, unsigned *p, unsigned v, size_t n) {
+    if (gate_after(W)) return;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 // ------------------------------------------------------------------------------------------------ device tables
 // copies the by-value group/type tables into device memory for kernels that index them per lane
 __global__ void k_set_tables(WorldView W, GroupDev *gtab, TypeDev *ttab) {
@@ -440,24 +466,36 @@ __device__ __forceinline__ unsigned mulmod31(unsigned a, unsigned b) {
     return (unsigned)(r >= 0x7FFFFFFFull ? r - 0x7FFFFFFFull : r);
 }
 
-__global__ void __launch_bounds__(256) k_shuffle_draw(int A, unsigned x0, int *j, int *count) {
+__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *count) {
+    const int A = counters[CTR_ATTACK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A) return;
-    unsigned e = (unsigned)i + 1u, base = 16807u, acc = x0;
+    unsigned e = (unsigned)i + 1u, base = 16807u, acc = (unsigned)counters[CTR_RNG];
     while (e) { if (e & 1u) acc = mulmod31(acc, base); base = mulmod31(base, base); e >>= 1; }
     int ji = (int)(acc % (unsigned)(i + 1));   // (int)rng() % (i + 1): outputs are in [1, 2^31 - 2]
     j[i] = ji;
     atomicAdd(&count[ji], 1);
 }
 
-__global__ void __launch_bounds__(256) k_shuffle_fill(int A, const int *j, const int *offset, int *cursor, int *list) {
+// the engine state after the shuffle's A draws: x <- 16807^A x (the host mirror is refreshed at the end-of-step readback)
+__global__ void k_rng_skip(int *counters) {
+    if (threadIdx.x != 0) return;
+    unsigned e = (unsigned)counters[CTR_ATTACK], base = 16807u, acc = (unsigned)counters[CTR_RNG];
+    counters[CTR_LAST_A] = (int)e;
+    while (e) { if (e & 1u) acc = mulmod31(acc, base); base = mulmod31(base, base); e >>= 1; }
+    counters[CTR_RNG] = (int)acc;
+}
+
+__global__ void __launch_bounds__(256) k_shuffle_fill(const int *counters, const int *j, const int *offset, int *cursor, int *list) {
+    const int A = counters[CTR_ATTACK];
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= A) return;
     int v = j[k];
     list[offset[v] + atomicAdd(&cursor[v], 1)] = k;
 }
 
-__global__ void __launch_bounds__(256) k_shuffle_chase(int A, const int *j, const int *offset, const int *count, const int *list, int *rank) {
+__global__ void __launch_bounds__(256) k_shuffle_chase(const int *counters, const int *j, const int *offset, const int *count, const int *list, int *rank) {
+    const int A = counters[CTR_ATTACK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A) return;
     int p = j[i], t = i;
@@ -474,6 +512,7 @@ __global__ void __launch_bounds__(256) k_shuffle_chase(int A, const int *j, cons
 // ------------------------------------------------------------------------------------------------ attack phase
 // rank[seq] = position of attack-list entry `seq` after the reference's shuffle (GridWorld.cc:464-468)
 __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits) {
+    if (W.counters[CTR_ATTACK] == 0) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
@@ -507,7 +546,8 @@ constexpr int ATT_THREADS = 64;   // one wave per workgroup: the hit lists (kmax
 template <bool APPLY>
 __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab,
                                                              int use_b /* read drank_b, write drank_a */,
-                                                             const unsigned *hitbits, int kmax) {
+                                                             const unsigned *hitbits, int kmax, int set_flag) {
+    if (W.counters[CTR_ATTACK] == 0 || (APPLY ? gate_after(W) : gate_round(W))) return;
     extern __shared__ unsigned s_hit[];               // [kmax][ATT_THREADS] ranks, then [kmax][ATT_THREADS] refs
     unsigned *s_rank = s_hit;
     int *s_ref = (int *)(s_hit + kmax * ATT_THREADS);
@@ -601,7 +641,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
 
     if (!APPLY) {
         dr_self_next[i] = dr;
-        if (dr != dr_me_cur) W.counters[CTR_CHANGED] = 1;
+        if (set_flag && dr != dr_me_cur) W.counters[CTR_CHANGED] = 1;   // only the last round of a pair reports
         return;
     }
     // ---- APPLY (the iterate has converged: dr == dr_me_cur)
@@ -652,6 +692,7 @@ __global__ void __launch_bounds__(256) k_attack_events(WorldView W, int use_b, i
 // removes the agents that died in this attack phase from the map (Map::remove_agent, Map.cc:272), after every
 // reader of the phase-start map is done
 __global__ void __launch_bounds__(256) k_attack_bury(WorldView W, int use_b) {
+    if (gate_after(W) || W.counters[CTR_ATTACK] == 0) return;
     const GroupDev G = W.grp[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
@@ -661,6 +702,7 @@ __global__ void __launch_bounds__(256) k_attack_bury(WorldView W, int use_b) {
 
 // ------------------------------------------------------------------------------------------------ starve / recover
 __global__ void __launch_bounds__(256) k_starve(WorldView W) {
+    if (gate_after(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
@@ -687,6 +729,7 @@ __global__ void __launch_bounds__(256) k_starve(WorldView W) {
 //   only points to lower keys, resolved by pointer jumping.
 // tgt (= drank_a, free after the attack phase): target cell of a move candidate, -1 otherwise.
 __global__ void __launch_bounds__(256) k_move_prep(WorldView W) {
+    if (gate_after(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
@@ -706,6 +749,7 @@ __global__ void __launch_bounds__(256) k_move_prep(WorldView W) {
 }
 
 __global__ void __launch_bounds__(256) k_move_claim(WorldView W, const GroupDev *gtab) {
+    if (gate_after(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -724,6 +768,7 @@ __global__ void __launch_bounds__(256) k_move_claim(WorldView W, const GroupDev 
 }
 
 __global__ void __launch_bounds__(256) k_move_init(WorldView W) {
+    if (gate_after(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -734,10 +779,11 @@ __global__ void __launch_bounds__(256) k_move_init(WorldView W) {
     if ((unsigned)cl != (unsigned)ref_pack(g, i)) return;          // not the static winner: stays MV_FAIL
     int o = W.occ[c];
     if (o == OCC_EMPTY) G.mv[i] = MV_OK;
-    else { G.mv[i] = (unsigned)o; W.counters[CTR_CHANGED] = 1; }  // succeeds iff the occupant o succeeds
+    else G.mv[i] = (unsigned)o;                                    // succeeds iff the occupant o succeeds
 }
 
-__global__ void __launch_bounds__(256) k_move_jump(WorldView W, const GroupDev *gtab) {
+__global__ void __launch_bounds__(256) k_move_jump(WorldView W, const GroupDev *gtab, int set_flag) {
+    if (gate_round(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -746,11 +792,12 @@ __global__ void __launch_bounds__(256) k_move_jump(WorldView W, const GroupDev *
     if (m >= MV_OK) return;
     unsigned s = gtab[ref_group((int)m)].mv[ref_index((int)m)];
     G.mv[i] = s;                                                   // OK / FAIL resolve me; otherwise jump
-    if (s < MV_OK) W.counters[CTR_CHANGED] = 1;
+    if (set_flag && s < MV_OK) W.counters[CTR_CHANGED] = 1;   // only the last round of a batch reports
 }
 
 // collide bookkeeping for failed moves (Map.cc:334-353) + vacate the old cells of successful ones
 __global__ void __launch_bounds__(256) k_move_apply1(WorldView W, const GroupDev *gtab) {
+    if (gate_after(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -772,6 +819,7 @@ __global__ void __launch_bounds__(256) k_move_apply1(WorldView W, const GroupDev
 }
 
 __global__ void __launch_bounds__(256) k_move_vacate(WorldView W) {
+    if (gate_after(W)) return;
     const GroupDev G = W.grp[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n || G.drank_a[i] < 0 || G.mv[i] != MV_OK) return;
@@ -779,6 +827,7 @@ __global__ void __launch_bounds__(256) k_move_vacate(WorldView W) {
 }
 
 __global__ void __launch_bounds__(256) k_move_enter(WorldView W) {
+    if (gate_after(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -871,6 +920,7 @@ __device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g,
 
 // candidates: alive movers with a non-zero delta whose target rectangle is inside the map (Map.cc:455)
 __global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted) {
+    if (gate_after(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
@@ -892,7 +942,8 @@ __global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted
     }
 }
 
-__global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev *gtab, const unsigned *wanted) {
+__global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev *gtab, const unsigned *wanted, int set_flag) {
+    if (gate_round(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -902,11 +953,12 @@ __global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev 
     MoveProbe r = move_probe<false>(W, gtab, g, i, t, wanted);
     if (r.blocked) G.mv[i] = MV_FAIL;
     else if (!r.undecided) G.mv[i] = MV_OK;
-    else W.counters[CTR_CHANGED] = 1;
+    else if (set_flag) W.counters[CTR_CHANGED] = 1;
 }
 
 // Map::get_collide for failed moves (Map.cc:334-353, 486-501): first agent met in the target rectangle
 __global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDev *gtab, const unsigned *wanted) {
+    if (gate_after(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -918,6 +970,7 @@ __global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDe
 }
 
 __global__ void __launch_bounds__(256) k_movg_vacate(WorldView W) {
+    if (gate_after(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -926,6 +979,7 @@ __global__ void __launch_bounds__(256) k_movg_vacate(WorldView W) {
 }
 
 __global__ void __launch_bounds__(256) k_movg_enter(WorldView W) {
+    if (gate_after(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -943,6 +997,7 @@ __global__ void __launch_bounds__(256) k_movg_enter(WorldView W) {
 // by the subject's own thread; receivers that are the object are counted with an int atomic and replayed as `hits`
 // sequential float adds of the same value -- order-independent, hence exact.
 __global__ void __launch_bounds__(256) k_rule(WorldView W, RuleArgs A) {
+    if (gate_after(W)) return;
     const GroupDev G = W.grp[A.ga];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool trig = false;
@@ -962,6 +1017,7 @@ __global__ void __launch_bounds__(256) k_rule(WorldView W, RuleArgs A) {
 }
 
 __global__ void __launch_bounds__(256) k_rule_obj(WorldView W, RuleArgs A) {
+    if (gate_after(W)) return;
     const GroupDev G = W.grp[A.gb];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
@@ -975,6 +1031,7 @@ __global__ void __launch_bounds__(256) k_rule_obj(WorldView W, RuleArgs A) {
 
 // end of step: pending actions are consumed
 __global__ void __launch_bounds__(256) k_finish(WorldView W) {
+    if (gate_after(W)) return;
     const GroupDev G = W.grp[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < G.n) G.pend[i] = PEND_NONE;
@@ -1096,39 +1153,45 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
     hipLaunchKernelGGL(k_set_action_c, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, sums);
 }
 
-void launch_shuffle(hipStream_t s, int A, unsigned x0, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank) {
-    (void)hipMemsetAsync(count, 0, sizeof(int) * 2 * (size_t)A, s);   // count and cursor are adjacent
-    dim3 g((A + 255) / 256), b(256);
-    int nb = (A + ISCAN_TILE - 1) / ISCAN_TILE;
-    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, A, x0, j, count);
-    hipLaunchKernelGGL(k_iscan_a, dim3(nb), b, 0, s, count, A, sums);
+// n_max = upper bound of the attack-list length (the number of agents); the actual length is read on the device
+void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank) {
+    (void)hipMemsetAsync(count, 0, sizeof(int) * 2 * (size_t)n_max, s);   // count and cursor are adjacent
+    dim3 g((n_max + 255) / 256), b(256);
+    int nb = (n_max + ISCAN_TILE - 1) / ISCAN_TILE;
+    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, j, count);
+    hipLaunchKernelGGL(k_iscan_a, dim3(nb), b, 0, s, count, n_max, sums);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, (int *)nullptr);
-    hipLaunchKernelGGL(k_iscan_c, dim3(nb), b, 0, s, count, A, sums, offset);
-    hipLaunchKernelGGL(k_shuffle_fill, g, b, 0, s, A, j, offset, cursor, list);
-    hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, A, j, offset, count, list, rank);
+    hipLaunchKernelGGL(k_iscan_c, dim3(nb), b, 0, s, count, n_max, sums, offset);
+    hipLaunchKernelGGL(k_shuffle_fill, g, b, 0, s, counters, j, offset, cursor, list);
+    hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, j, offset, count, list, rank);
+    hipLaunchKernelGGL(k_rng_skip, dim3(1), dim3(64), 0, s, counters);
 }
+void launch_set_rng(hipStream_t s, int *counters, unsigned x) { hipLaunchKernelGGL(k_set_rng, dim3(1), dim3(64), 0, s, counters, x); }
+void launch_phase_begin(hipStream_t s, int *counters) { hipLaunchKernelGGL(k_phase_begin, dim3(1), dim3(64), 0, s, counters); }
+void launch_gate(hipStream_t s, int *counters, int fail_code, int force) { hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, counters, fail_code, force); }
 
 // hit bits live in the (then unused) claim array of the move phase
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank) {
     (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);
     hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim);
 }
-void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax) {
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax, int set_flag) {
     size_t lds = (size_t)kmax * ATT_THREADS * 8;
-    hipLaunchKernelGGL((k_attack_eval<false>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, use_b, (const unsigned *)W.claim, kmax);
+    hipLaunchKernelGGL((k_attack_eval<false>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, use_b, (const unsigned *)W.claim, kmax, set_flag);
 }
 void launch_attack_events(hipStream_t s, const WorldView &W, int use_b, int4 *ev) {
     hipLaunchKernelGGL(k_attack_events, grid_all(W, 256), dim3(256), 0, s, W, use_b, ev);
 }
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax) {
     size_t lds = (size_t)kmax * ATT_THREADS * 8;
-    hipLaunchKernelGGL((k_attack_eval<true>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, use_b, (const unsigned *)W.claim, kmax);
+    hipLaunchKernelGGL((k_attack_eval<true>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, use_b, (const unsigned *)W.claim, kmax, 0);
     hipLaunchKernelGGL(k_attack_bury, grid_all(W, 256), dim3(256), 0, s, W, use_b);
 }
 void launch_starve(hipStream_t s, const WorldView &W) { hipLaunchKernelGGL(k_starve, grid_all(W, 256), dim3(256), 0, s, W); }
 
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
-    (void)hipMemsetAsync(W.claim, 0xFF, sizeof(unsigned long long) * (size_t)W.w * W.h, s);
+    const size_t words = 2 * (size_t)W.w * W.h;
+    hipLaunchKernelGGL(k_fill32_gated, dim3((unsigned)std::min<size_t>((words + 255) / 256, 2048)), dim3(256), 0, s, W, (unsigned *)W.claim, 0xFFFFFFFFu, words);
     dim3 g = grid_all(W, 256);
     hipLaunchKernelGGL(k_move_prep, g, dim3(256), 0, s, W);
     hipLaunchKernelGGL(k_move_claim, g, dim3(256), 0, s, W, gtab);
@@ -1136,11 +1199,12 @@ void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
 }
 // the per-cell "wanted" counters live in the claim array (unused by the generic path otherwise)
 void launch_movg_prep(hipStream_t s, const WorldView &W) {
-    (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);
+    const size_t words = (size_t)W.w * W.h;
+    hipLaunchKernelGGL(k_fill32_gated, dim3((unsigned)std::min<size_t>((words + 255) / 256, 2048)), dim3(256), 0, s, W, (unsigned *)W.claim, 0u, words);
     hipLaunchKernelGGL(k_movg_prep, grid_all(W, 256), dim3(256), 0, s, W, (unsigned *)W.claim);
 }
-void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
-    hipLaunchKernelGGL(k_movg_sweep, grid_all(W, 256), dim3(256), 0, s, W, gtab, (const unsigned *)W.claim);
+void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, int set_flag) {
+    hipLaunchKernelGGL(k_movg_sweep, grid_all(W, 256), dim3(256), 0, s, W, gtab, (const unsigned *)W.claim, set_flag);
 }
 void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     dim3 g = grid_all(W, 256);
@@ -1148,8 +1212,8 @@ void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) 
     hipLaunchKernelGGL(k_movg_vacate, g, dim3(256), 0, s, W);
     hipLaunchKernelGGL(k_movg_enter, g, dim3(256), 0, s, W);
 }
-void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
-    hipLaunchKernelGGL(k_move_jump, grid_all(W, 256), dim3(256), 0, s, W, gtab);
+void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, int set_flag) {
+    hipLaunchKernelGGL(k_move_jump, grid_all(W, 256), dim3(256), 0, s, W, gtab, set_flag);
 }
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     dim3 g = grid_all(W, 256);
