@@ -187,8 +187,8 @@ Env::Env() {
     if (const char *v = std::getenv("MAGENT_RENDER_UNROLL")) render_unroll = std::atoi(v);
     if (const char *v = std::getenv("MAGENT_HOST_SHUFFLE")) host_shuffle = std::atoi(v) != 0;
     if (const char *v = std::getenv("MAGENT_CHECKED_STEP")) checked_step = std::atoi(v) != 0;
-    if (const char *v = std::getenv("MAGENT_OPT_ATTACK_PAIRS")) opt_attack_pairs = std::max(0, std::atoi(v));
-    if (const char *v = std::getenv("MAGENT_OPT_MOVE_BATCHES")) opt_move_batches = std::max(0, std::atoi(v));
+    if (const char *v = std::getenv("MAGENT_OPT_ATTACK_PAIRS")) { opt_attack_pairs = std::max(0, std::atoi(v)); opt_fixed = true; }
+    if (const char *v = std::getenv("MAGENT_OPT_MOVE_BATCHES")) { opt_move_batches = std::max(0, std::atoi(v)); opt_fixed = true; }
     if (const char *v = std::getenv("MAGENT_RENDER_NT")) nt_stores = std::atoi(v) != 0;
 }
 
@@ -828,13 +828,13 @@ void Env::step(int *done) {
             ProfScope p(*this, "attack");
             launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank);
             launch_attack_rank(stream, W, d_rank);
-            launch_phase_begin(stream, d_counters);
-            for (int pair = 0; pair < opt_attack_pairs; pair++) {
+            const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
+            for (int pair = 0; pair < pairs; pair++) {
                 launch_attack_iter(stream, W, d_gtab, d_ttab, 0, attack_kmax, 0);
                 launch_attack_iter(stream, W, d_gtab, d_ttab, 1, attack_kmax, 1);   // only the pair's second round reports
-                launch_gate(stream, d_counters, pair == opt_attack_pairs - 1 ? 1 : 0, 0);
+                launch_gate(stream, d_counters, pair == pairs - 1 ? 1 : 0, 0);
             }
-            if (opt_attack_pairs == 0) launch_gate(stream, d_counters, 1, 1);
+            if (pairs == 0) launch_gate(stream, d_counters, 1, 1);
             launch_attack_apply(stream, W, d_gtab, d_ttab, 0, attack_kmax);
         }
         {
@@ -844,15 +844,15 @@ void Env::step(int *done) {
         {
             ProfScope p(*this, "move");
             if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);
-            launch_phase_begin(stream, d_counters);
-            for (int b = 0; b < opt_move_batches; b++) {
+            const int batches = opt_fixed ? opt_move_batches : (boost_move > 0 ? 2 : 1);
+            for (int b = 0; b < batches; b++) {
                 for (int k = 0; k < move_jump_batch; k++) {
                     const int last = k == move_jump_batch - 1;
                     if (any_multicell) launch_movg_sweep(stream, W, d_gtab, last); else launch_move_jump(stream, W, d_gtab, last);
                 }
-                launch_gate(stream, d_counters, b == opt_move_batches - 1 ? 2 : 0, 0);
+                launch_gate(stream, d_counters, b == batches - 1 ? 2 : 0, 0);
             }
-            if (opt_move_batches == 0) launch_gate(stream, d_counters, 2, 1);
+            if (batches == 0) launch_gate(stream, d_counters, 2, 1);
             if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
         }
         {
@@ -864,6 +864,7 @@ void Env::step(int *done) {
         if (c[CTR_NEED_HOST]) {   // a phase ran out of optimistic rounds: continue from that state, host-checked
             const int phase = c[CTR_NEED_HOST];
             fallback_steps++;
+            if (phase == 1) boost_attack = 64; else boost_move = 64;   // deeper dependency chains around: one more batch
             HIP_OK(hipMemsetAsync(d_counters + CTR_NEED_HOST, 0, 2 * sizeof(int), stream));   // NEED_HOST, PHASE_DONE
             clear_changed();
             if (phase == 1) { attack_rounds_checked(W); phase_tail(W, 0); }
@@ -871,6 +872,8 @@ void Env::step(int *done) {
             c = read_counters();
         }
         rng.x = (unsigned)c[CTR_RNG];   // the device advanced the engine state by A draws
+        if (boost_attack > 0) boost_attack--;
+        if (boost_move > 0) boost_move--;
     } else {
         // ---------------- checked driver
         HIP_OK(hipMemsetAsync(d_counters + CTR_NEED_HOST, 0, 2 * sizeof(int), stream));
@@ -942,8 +945,7 @@ void Env::step(int *done) {
     *done = live < (int)groups.size();   // GridWorld.cc:619-624
     for (size_t k = 0; k < rules.size(); k++) if (c[CTR_TRIGGER + k] && rules[k].terminal) *done = 1;
     // attack count and rule triggers are per step; dead_ct lives until clear_dead
-    HIP_OK(hipMemsetAsync(d_counters + CTR_ATTACK, 0, sizeof(int), stream));
-    HIP_OK(hipMemsetAsync(d_counters + CTR_TRIGGER, 0, sizeof(int) * (CTR_TOTAL - CTR_TRIGGER), stream));
+    launch_step_reset(stream, d_counters);
     move_seq_base = 0;
     h_occ_valid = false;
     paint_valid = false; mini_valid = false;

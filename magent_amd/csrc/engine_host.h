@@ -118,7 +118,9 @@ public:
     int move_jump_batch = 3;
     int last_attack_iters = 0, last_move_iters = 0, fallback_steps = 0;
     bool checked_step = false;            // host-checked convergence instead of the single-sync driver
-    int opt_attack_pairs = 2, opt_move_batches = 2;   // optimistic rounds of the single-sync driver
+    // optimistic rounds of the single-sync driver: one pair / batch, two for 64 steps after a run-out (or fixed by env)
+    int opt_attack_pairs = 1, opt_move_batches = 1, boost_attack = 0, boost_move = 0;
+    bool opt_fixed = false;
 
 private:
     struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };

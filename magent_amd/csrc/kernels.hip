@@ -49,9 +49,6 @@ __device__ __forceinline__ void body_fill(const WorldView &W, int x, int y, int 
 __device__ __forceinline__ bool gate_round(const WorldView &W) { return (W.counters[CTR_PHASE_DONE] | W.counters[CTR_NEED_HOST]) != 0; }
 __device__ __forceinline__ bool gate_after(const WorldView &W) { return W.counters[CTR_NEED_HOST] != 0; }
 
-__global__ void k_phase_begin(int *counters) {
-    if (threadIdx.x == 0) { counters[CTR_PHASE_DONE] = 0; counters[CTR_CHANGED] = 0; }
-}
 // after a batch of rounds: converged iff the batch's last round changed nothing; `fail_code` != 0 marks the last batch
 __global__ void k_gate(int *counters, int fail_code, int force) {
     if (threadIdx.x != 0) return;
@@ -59,6 +56,11 @@ __global__ void k_gate(int *counters, int fail_code, int force) {
     if (!counters[CTR_PHASE_DONE] && !counters[CTR_CHANGED]) counters[CTR_PHASE_DONE] = 1;
     counters[CTR_CHANGED] = 0;
     if (fail_code && !counters[CTR_PHASE_DONE] && !counters[CTR_NEED_HOST]) counters[CTR_NEED_HOST] = fail_code;
+}
+// per-step counters back to zero after the end-of-step readback (dead_ct lives until clear_dead)
+__global__ void k_step_reset(int *counters) {
+    if (threadIdx.x == 0) counters[CTR_ATTACK] = 0;
+    for (int k = CTR_TRIGGER + threadIdx.x; k < CTR_TOTAL; k += blockDim.x) counters[k] = 0;
 }
 __global__ void k_set_rng(int *counters, unsigned x) { if (threadIdx.x == 0) counters[CTR_RNG] = (int)x; }
 
@@ -359,6 +361,30 @@ __device__ __forceinline__ void block_rank(Pred pred, Emit emit, int n, int bloc
     }
 }
 
+// One-workgroup form for small groups (n <= SOLO_MAX): a single 1024-thread workgroup walks the group in tiles and
+// carries the running rank itself -- one launch instead of three when the whole job is launch-latency bound.
+constexpr int SOLO_THREADS = 1024, SOLO_MAX = 32768;
+
+template <class Pred, class Emit>
+__device__ __forceinline__ int solo_rank(Pred pred, Emit emit, int n, int base) {
+    __shared__ int s_w[SOLO_THREADS / 64];
+    const int wave = threadIdx.x >> 6;
+    int run = base;
+    for (int t0 = 0; t0 < n; t0 += SOLO_THREADS) {
+        const int i = t0 + threadIdx.x;
+        const bool p = i < n && pred(i);
+        int wtot, r = wave_rank(p, wtot);
+        if (lane_id() == 0) s_w[wave] = wtot;
+        __syncthreads();
+        int before = 0, all = 0;
+        for (int v = 0; v < SOLO_THREADS / 64; v++) { int t = s_w[v]; all += t; if (v < wave) before += t; }
+        if (p) emit(i, run + before + r);
+        run += all;
+        __syncthreads();
+    }
+    return run;
+}
+
 // pass B: exclusive scan of block totals in place; counter[slot] is the running base and receives the new total
 __global__ void __launch_bounds__(1024) k_scan_blocks(int *sums, int nb, int *counter) {
     __shared__ int s_w[16];
@@ -418,6 +444,27 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_c(WorldView W, int 
     block_rank([&](int i) { return actions[i] >= n_move; }, [&](int i, int r) { G.key[i] = (unsigned)r; }, G.n, sums[blockIdx.x]);
 }
 
+__global__ void __launch_bounds__(SOLO_THREADS) k_set_action_solo(WorldView W, int g, const int *actions, int call_base) {
+    const GroupDev G = W.grp[g];
+    const TypeDev T = W.type[g];
+    const int base = W.counters[CTR_ATTACK];
+    for (int i = threadIdx.x; i < G.n; i += SOLO_THREADS) {
+        int act = actions[i];
+        G.last_action[i] = act;
+        if (act < T.n_move) {
+            unsigned bound = 0;
+            if (W.large_map) { int x_ = G.x[i] % W.bandwidth; bound = (x_ < 4 || x_ > W.bandwidth - 4) ? 1u : 0u; }
+            G.pend[i] = PEND_MOVE | act;
+            G.key[i] = (bound << 31) | (unsigned)(call_base + i);
+        } else {
+            G.pend[i] = PEND_ATTACK | (act - T.n_move);
+        }
+    }
+    __syncthreads();   // base was read by every thread before the total is written back
+    int total = solo_rank([&](int i) { return actions[i] >= T.n_move; }, [&](int i, int r) { G.key[i] = (unsigned)r; }, G.n, base);
+    if (threadIdx.x == 0) W.counters[CTR_ATTACK] = total;
+}
+
 // ------------------------------------------------------------------------------------------------ generic int scan
 // exclusive prefix sum of an int array, ISCAN_TILE items per block, 8 consecutive items per thread
 constexpr int ISCAN_ITEMS = 8, ISCAN_TILE = 256 * ISCAN_ITEMS;
@@ -449,6 +496,26 @@ __global__ void __launch_bounds__(256) k_iscan_c(const int *in, int n, const int
     for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += s_w[w];
 #pragma unroll
     for (int k = 0; k < ISCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+}
+
+__global__ void __launch_bounds__(SOLO_THREADS) k_iscan_solo(const int *in, int n, int *out) {
+    __shared__ int s_w[SOLO_THREADS / 64];
+    const int wave = threadIdx.x >> 6;
+    int run = 0;
+    for (int t0 = 0; t0 < n; t0 += SOLO_THREADS) {
+        const int i = t0 + threadIdx.x;
+        const int v = i < n ? in[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d); if (lane_id() >= d) x += y; }
+        if (lane_id() == 63) s_w[wave] = x;
+        __syncthreads();
+        int before = 0, all = 0;
+        for (int w = 0; w < SOLO_THREADS / 64; w++) { int t = s_w[w]; all += t; if (w < wave) before += t; }
+        if (i < n) out[i] = run + before + x - v;
+        run += all;
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ attack shuffle
@@ -512,6 +579,7 @@ __global__ void __launch_bounds__(256) k_shuffle_chase(const int *counters, cons
 // ------------------------------------------------------------------------------------------------ attack phase
 // rank[seq] = position of attack-list entry `seq` after the reference's shuffle (GridWorld.cc:464-468)
 __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits) {
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) { W.counters[CTR_PHASE_DONE] = 0; W.counters[CTR_CHANGED] = 0; }   // attack rounds start
     if (W.counters[CTR_ATTACK] == 0) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
@@ -703,6 +771,7 @@ __global__ void __launch_bounds__(256) k_attack_bury(WorldView W, int use_b) {
 // ------------------------------------------------------------------------------------------------ starve / recover
 __global__ void __launch_bounds__(256) k_starve(WorldView W) {
     if (gate_after(W)) return;
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) { W.counters[CTR_PHASE_DONE] = 0; W.counters[CTR_CHANGED] = 0; }   // move rounds start
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
@@ -1084,6 +1153,21 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_compact_c(WorldView W, int g, 
                G.n, sums[blockIdx.x]);
 }
 
+__global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int g, GroupDev D) {
+    const GroupDev G = W.grp[g];
+    const float step_reward = W.type[g].step_reward;
+    const int bw = W.type[g].bw, bl = W.type[g].bl;
+    solo_rank([&](int i) { return !G.dead[i]; },
+              [&](int i, int r) {
+                  int x = G.x[i], y = G.y[i];
+                  D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
+                  D.last_reward[r] = G.next_reward[i];
+                  D.next_reward[r] = step_reward;
+                  body_fill(W, x, y, bw, bl, ref_pack(g, r));
+              },
+              G.n, 0);
+}
+
 // the non-double-buffered per-agent state of the survivors
 __global__ void __launch_bounds__(256) k_compact_reset(GroupDev D, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1147,6 +1231,7 @@ void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, con
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums) {
     int n = W.grp[g].n;
     if (n <= 0) return;
+    if (n <= SOLO_MAX) { hipLaunchKernelGGL(k_set_action_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, actions, call_base); return; }
     int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_set_action_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, call_base, sums);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, W.counters + CTR_ATTACK);
@@ -1159,15 +1244,19 @@ void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count,
     dim3 g((n_max + 255) / 256), b(256);
     int nb = (n_max + ISCAN_TILE - 1) / ISCAN_TILE;
     hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, j, count);
-    hipLaunchKernelGGL(k_iscan_a, dim3(nb), b, 0, s, count, n_max, sums);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, (int *)nullptr);
-    hipLaunchKernelGGL(k_iscan_c, dim3(nb), b, 0, s, count, n_max, sums, offset);
+    if (n_max <= SOLO_MAX) {
+        hipLaunchKernelGGL(k_iscan_solo, dim3(1), dim3(SOLO_THREADS), 0, s, count, n_max, offset);
+    } else {
+        hipLaunchKernelGGL(k_iscan_a, dim3(nb), b, 0, s, count, n_max, sums);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, (int *)nullptr);
+        hipLaunchKernelGGL(k_iscan_c, dim3(nb), b, 0, s, count, n_max, sums, offset);
+    }
     hipLaunchKernelGGL(k_shuffle_fill, g, b, 0, s, counters, j, offset, cursor, list);
     hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, j, offset, count, list, rank);
     hipLaunchKernelGGL(k_rng_skip, dim3(1), dim3(64), 0, s, counters);
 }
+void launch_step_reset(hipStream_t s, int *counters) { hipLaunchKernelGGL(k_step_reset, dim3(1), dim3(64), 0, s, counters); }
 void launch_set_rng(hipStream_t s, int *counters, unsigned x) { hipLaunchKernelGGL(k_set_rng, dim3(1), dim3(64), 0, s, counters, x); }
-void launch_phase_begin(hipStream_t s, int *counters) { hipLaunchKernelGGL(k_phase_begin, dim3(1), dim3(64), 0, s, counters); }
 void launch_gate(hipStream_t s, int *counters, int fail_code, int force) { hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, counters, fail_code, force); }
 
 // hit bits live in the (then unused) claim array of the move phase
@@ -1246,10 +1335,14 @@ void launch_init_reward(hipStream_t s, const WorldView &W, int g) {
 void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D, int new_n, int *sums) {
     int n = W.grp[g].n;
     if (n <= 0) return;
-    int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_compact_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W.grp[g], sums);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, (int *)nullptr);
-    hipLaunchKernelGGL(k_compact_c, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, D, sums);
+    if (n <= SOLO_MAX) {
+        hipLaunchKernelGGL(k_compact_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, D);
+    } else {
+        int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+        hipLaunchKernelGGL(k_compact_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W.grp[g], sums);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, (int *)nullptr);
+        hipLaunchKernelGGL(k_compact_c, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, D, sums);
+    }
     if (new_n > 0) hipLaunchKernelGGL(k_compact_reset, dim3((new_n + 255) / 256), dim3(256), 0, s, D, new_n);
 }
 

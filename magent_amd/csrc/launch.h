@@ -44,7 +44,7 @@ void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const
 void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4);
 void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank);
 void launch_set_rng(hipStream_t s, int *counters, unsigned x);
-void launch_phase_begin(hipStream_t s, int *counters);
+void launch_step_reset(hipStream_t s, int *counters);
 void launch_gate(hipStream_t s, int *counters, int fail_code, int force);
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank);
