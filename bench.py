@@ -106,9 +106,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--map-size", type=int, default=MAP_SIZE)
     ap.add_argument("--agents", type=int, default=N_PER_GROUP, help="agents per group")
-    ap.add_argument("--workload", choices=["battle", "test_1m"], default="battle",
+    ap.add_argument("--workload", choices=["battle", "test_1m", "gather"], default="battle",
                     help="test_1m: the reference's own harness (scripts/test/test_1m.py): pursuit-like game, map sqrt(20 N), "
-                         "N/10 walls, N/2 prey + N/2 2x2 predators, N = 2 * --agents")
+                         "N/10 walls, N/2 prey + N/2 2x2 predators, N = 2 * --agents; "
+                         "gather: BASELINE config 4 (examples/train_gather.py: --agents agents + agents/5 food, only agents act)")
     ap.add_argument("--gather", choices=["none", "obs"], default="none",
                     help="obs: all_gather the observation tensors of every replica over RCCL each step")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -147,6 +148,8 @@ def main():
     if args.workload == "test_1m":
         args.map_size = int((2 * args.agents * 20) ** 0.5)
         cfg = _games.make("pursuit", args.map_size)
+    elif args.workload == "gather":
+        cfg = _games.make("gather", args.map_size)
     else:
         cfg = _games.make("battle", args.map_size)
     cfg.set({"device_id": local_rank})
@@ -154,10 +157,15 @@ def main():
     env.set_seed(12345 + rank)
     env.reset()
     handles = env.get_handles()
+    acting = list(range(len(handles)))
     if args.workload == "test_1m":
         env.add_walls(method="random", n=2 * args.agents // 10)
         for h in reversed(handles):
             env.add_agents(h, "random", n=args.agents)
+    elif args.workload == "gather":   # group 0 = food (never observed, never acts), group 1 = agents
+        env.add_agents(handles[0], "random", n=args.agents // 5)
+        env.add_agents(handles[1], "random", n=args.agents)
+        acting = [1]
     else:
         for h in handles:
             env.add_agents(h, "random", n=args.agents)
@@ -187,6 +195,8 @@ def main():
     def one_step(s):
         n_now = 0
         for g, h in enumerate(handles):
+            if g not in acting:
+                continue
             n = env.get_num(h)
             n_now += n
             rendered["view"] += n * view_bytes[g]
@@ -200,7 +210,8 @@ def main():
                 replicas.gather_observations(src, env.get_num(h), capacity=n0[g])
         env.step()
         for g, h in enumerate(handles):
-            env.get_reward_device(h, rewards[g])
+            if g in acting:
+                env.get_reward_device(h, rewards[g])
         env.clear_dead()
         return n_now
 
@@ -279,6 +290,8 @@ def main():
                        ("reference test_1m.py harness: pursuit-like %dx%d, %d walls, %d prey + %d 2x2 predators" % (
                            args.map_size, args.map_size, 2 * args.agents // 10, args.agents, args.agents)
                         if args.workload == "test_1m" else
+                        "gather %dx%d (train_gather.py), %d agents + %d food, only the agents act" % (
+                            args.map_size, args.map_size, args.agents, args.agents // 5) if args.workload == "gather" else
                         "battle %dx%d, 2x%d agents, random placement, random actions" % (args.map_size, args.map_size, args.agents)),
                        "envs": world, "parallelism": "replicas x%d" % world, "gather": args.gather,
                        "agents_at_start": n0, "agents_at_end": [env.get_num(h) for h in handles],

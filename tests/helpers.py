@@ -360,6 +360,10 @@ def scenarios():
                          9: [("add", 1, "custom", {"pos": [(1, 1), (2, 2), (2, 2), (43, 43), (0, 0)]}),
                              ("walls", "fill", {"pos": (20, 20), "size": (3, 2)})],
                          14: [("reset", [(0, "random", {"n": 200}), (1, "fill", {"pos": (5, 5), "size": (10, 12)})])]}),
+        Scenario("battle_grow", "battle", 70, place=[rnd(0, 50), rnd(1, 50)], steps=12, action_seed=28,
+                 over={"small": {"hp": 4, "damage": 3}},
+                 events={3: [("add", 0, "random", {"n": 1800})], 6: [("add", 1, "random", {"n": 1500})],
+                         9: [("add", 0, "fill", {"pos": (2, 2), "size": (6, 60)})]}),
         Scenario("battle_one_side", "battle", 12, place=[rnd(0, 60), rnd(1, 3)], steps=40, action_seed=14,
                  over={"small": {"damage": 12}}),
     ]
