@@ -1,8 +1,9 @@
 // kernels.hip -- hand-written HIP kernels of the grid-world step engine for gfx950 (CDNA4, wave64).
 //
 // No dense contraction on this path: MFMA is unused on purpose.  The rules that matter are coalesced SoA access,
-// LDS staging of the map windows, wide streaming stores, wave ballots for in-wave ranking and 64-bit global
-// atomics (umin) for move arbitration.  Compiled with -ffp-contract=off; float ops keep the reference's order.
+// wave-private LDS strips that turn per-cell work into 1 KiB streaming stores, wave ballots for in-wave ranking,
+// LDS / global integer atomics (histogram, hit bits, 64-bit umin move arbitration) and as few host round trips as
+// possible.  Compiled with -ffp-contract=off; float ops keep the reference's order.
 //
 // Reference semantics each kernel restates (file:line into /root/reference/src/gridworld):
 //   k_paint / k_minimap / k_render   GridWorld::get_observation GridWorld.cc:292-401, Map::extract_view Map.cc:129-207

@@ -176,3 +176,16 @@ def test_reference_1m_methodology_small():
     sc = H.Scenario("test_1m_small", "pursuit", size, walls=N // 10,
                     place=[(1, "random", {"n": N // 2}), (0, "random", {"n": N // 2})], steps=4, action_seed=31, obs_every=2)
     H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, H.HIP_LIB), "test_1m_small")
+
+
+def test_info_queries_match_oracle():
+    """the cold get_info names of the interactive tools: walls_info, groups_info, view2attack, global_minimap"""
+    sc = H.scenarios()["battle_walls"]
+    a, ha = sc.build(H.HIP_LIB)
+    b, hb = sc.build(H.ensure_oracle())
+    wa, wb = a._get_walls_info(), b._get_walls_info()
+    assert wa.shape == wb.shape and np.array_equal(wa, wb) and len(wa) > 150
+    assert np.array_equal(a._get_groups_info(), b._get_groups_info())
+    for x, y in zip(ha, hb):
+        assert a.get_view2attack(x)[0] == b.get_view2attack(y)[0] and np.array_equal(a.get_view2attack(x)[1], b.get_view2attack(y)[1])
+    assert a.get_global_minimap(7, 9).tobytes() == b.get_global_minimap(7, 9).tobytes()
