@@ -646,7 +646,8 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
     R.view = view; R.feat = feat;
 
     // flat decomposition of the n * VH * VW window cells into 64-cell wave steps, `steps_per_span` per workgroup
-    if ((long long)R.n * R.VH * R.VW >= (1ll << 31)) fatal("observation too large for 32-bit cell indexing");
+    if ((long long)R.n * R.VH * R.VW >= (1ll << 31) || (long long)R.n * R.F >= (1ll << 32))
+        fatal("observation too large for 32-bit cell indexing");
     const long long steps = ((long long)R.n * R.VH * R.VW + 63) / 64;
     int per = render_steps_per_span > 0 ? render_steps_per_span : 32;
     P.steps_per_span = per;
@@ -695,6 +696,7 @@ void Env::observe_device(int g, float *view, float *feat) {
         ProfScope p(*this, "features");
         launch_features(stream, W, R, P, (((uintptr_t)feat) & 15) == 0);
     }
+    HIP_OK(hipGetLastError());
 }
 
 // host-buffer variant (the reference ABI): render into a staging buffer, then copy out
@@ -946,6 +948,7 @@ void Env::step(int *done) {
     for (size_t k = 0; k < rules.size(); k++) if (c[CTR_TRIGGER + k] && rules[k].terminal) *done = 1;
     // attack count and rule triggers are per step; dead_ct lives until clear_dead
     launch_step_reset(stream, d_counters);
+    HIP_OK(hipGetLastError());
     move_seq_base = 0;
     h_occ_valid = false;
     paint_valid = false; mini_valid = false;
