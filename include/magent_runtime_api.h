@@ -101,6 +101,14 @@ int env_set_action_device(EnvHandle game, GroupHandle group, const int *device_a
 int env_get_reward_device(EnvHandle game, GroupHandle group, float *device_buffer);
 /* name = id (int32[n]) | pos (int32[n][2]) | alive (uint8[n]) | hp (float[n]) into device memory */
 int env_get_info_device(EnvHandle game, GroupHandle group, const char *name, void *device_buffer);
+/* env_step for n independent environments at once: all steps are enqueued (each on its environment's stream) before
+ * the first is waited for, so their device work overlaps; done[i] as env_step */
+int env_step_many(EnvHandle *games, int n, int *done);
+/* One full cycle (per group: observe -> set_action; step; rewards; clear_dead) of n_env independent environments,
+ * driven by n_threads host threads inside the library.  Device pointer arrays are indexed [e * n_group + g]; a NULL
+ * entry skips that call for that group.  Small worlds are launch-latency bound: concurrent environments fill the GPU. */
+int env_cycle_many(EnvHandle *games, int n_env, int n_group, float **view, float **feat, const int **actions,
+                   float **rewards, int *done, int n_threads);
 /* wait until everything enqueued on the environment's stream has finished */
 int env_sync(EnvHandle game);
 /* the environment's hipStream_t, as an opaque pointer (for event timing / interop by the caller) */

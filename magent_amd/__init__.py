@@ -4,6 +4,6 @@ Only the hot path lives here: the C-ABI library (csrc/, built into lib/libmagent
 the reference's ``magent.GridWorld`` operator interface (gridworld.py).
 """
 from . import gridworld
-from .gridworld import GridWorld
+from .gridworld import EnvBatch, GridWorld, step_many
 
-__all__ = ["gridworld", "GridWorld"]
+__all__ = ["gridworld", "GridWorld", "step_many", "EnvBatch"]

@@ -809,18 +809,31 @@ void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 
 }
 
 void Env::step(int *done) {
+    step_begin();
+    step_end(done);
+}
+
+void Env::enqueue_counters() {
+    HIP_OK(hipMemcpyAsync(h_counters, d_counters, sizeof(int) * CTR_TOTAL, hipMemcpyDeviceToHost, stream));
+}
+
+// everything of the step that needs no answer from the device (single-sync driver), or the whole host-checked step
+void Env::step_begin() {
     if (!device_ready) fatal("step called before reset");
+    if (step_pending) fatal("step_begin called twice without step_end");
     use_device();
     ensure_tables();
     WorldView W = view();
     int total_n = 0;
     for (auto &g : groups) total_n += g.n;
     const bool fast = !checked_step && !host_shuffle && first_render;
-    const int *c = nullptr;
+    step_pending = true;
+    step_was_fast = false;
 
     if (total_n == 0) {
-        c = read_counters();
+        enqueue_counters();
     } else if (fast) {
+        step_was_fast = true;
         // ---------------- single-sync driver
         shuffle_buffers(total_n);
         push_rng();
@@ -862,20 +875,7 @@ void Env::step(int *done) {
             for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
             launch_finish(stream, W);
         }
-        c = read_counters();
-        if (c[CTR_NEED_HOST]) {   // a phase ran out of optimistic rounds: continue from that state, host-checked
-            const int phase = c[CTR_NEED_HOST];
-            fallback_steps++;
-            if (phase == 1) boost_attack = 64; else boost_move = 64;   // deeper dependency chains around: one more batch
-            HIP_OK(hipMemsetAsync(d_counters + CTR_NEED_HOST, 0, 2 * sizeof(int), stream));   // NEED_HOST, PHASE_DONE
-            clear_changed();
-            if (phase == 1) { attack_rounds_checked(W); phase_tail(W, 0); }
-            else { move_rounds_checked(W); phase_tail(W, 1); }
-            c = read_counters();
-        }
-        rng.x = (unsigned)c[CTR_RNG];   // the device advanced the engine state by A draws
-        if (boost_attack > 0) boost_attack--;
-        if (boost_move > 0) boost_move--;
+        enqueue_counters();
     } else {
         // ---------------- checked driver
         HIP_OK(hipMemsetAsync(d_counters + CTR_NEED_HOST, 0, 2 * sizeof(int), stream));
@@ -933,9 +933,34 @@ void Env::step(int *done) {
             for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
             launch_finish(stream, W);
         }
-        c = read_counters();
-        if (rng_on_device) rng.x = (unsigned)c[CTR_RNG];
+        enqueue_counters();
     }
+}
+
+// the one host synchronisation of the step: `done`, death counts, RNG state, and the (rare) continuation when a
+// phase ran out of optimistic rounds
+void Env::step_end(int *done) {
+    if (!step_pending) fatal("step_end without step_begin");
+    step_pending = false;
+    use_device();
+    HIP_OK(hipStreamSynchronize(stream));
+    const int *c = h_counters;
+    if (step_was_fast) {
+        if (c[CTR_NEED_HOST]) {   // continue from exactly the device state the gates froze, host-checked
+            WorldView W = view();
+            const int phase = c[CTR_NEED_HOST];
+            fallback_steps++;
+            if (phase == 1) boost_attack = 64; else boost_move = 64;   // deeper dependency chains around: one more batch
+            HIP_OK(hipMemsetAsync(d_counters + CTR_NEED_HOST, 0, 2 * sizeof(int), stream));   // NEED_HOST, PHASE_DONE
+            clear_changed();
+            if (phase == 1) { attack_rounds_checked(W); phase_tail(W, 0); }
+            else { move_rounds_checked(W); phase_tail(W, 1); }
+            c = read_counters();
+        }
+        if (boost_attack > 0) boost_attack--;
+        if (boost_move > 0) boost_move--;
+    }
+    if (rng_on_device) rng.x = (unsigned)c[CTR_RNG];   // the device advanced the engine state by A draws
 
     int live = 0;
     for (size_t g = 0; g < groups.size(); g++) {

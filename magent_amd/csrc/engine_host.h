@@ -96,6 +96,8 @@ public:
     void observe_host(int g, float *view, float *feat);
     void set_action_host(int g, const int *actions);
     void step(int *done);
+    void step_begin();            // enqueue the step without waiting (several environments can overlap)
+    void step_end(int *done);     // wait for it
     void get_reward_host(int g, float *out);
     void clear_dead();
     void info_host(int g, const char *name, void *buf);
@@ -139,6 +141,8 @@ private:
     bool read_changed();
     void clear_changed();
     void compile_rules();
+    void enqueue_counters();
+    bool step_pending = false, step_was_fast = false;
     void shuffle_buffers(int n_max);
     void push_rng();
     void attack_rounds_checked(const WorldView &W);

@@ -1,6 +1,9 @@
 // runtime_api.hip -- the C-ABI of libmagent.so (include/magent_runtime_api.h): thin trampolines onto Env.
 // Replaces reference src/runtime_api.cc:15-163 symbol for symbol; PART 2 adds the device-resident calls.
+#include <atomic>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "../../include/magent_runtime_api.h"
 #include "engine_host.h"
@@ -56,6 +59,41 @@ int env_get_observation_device(EnvHandle game, GroupHandle group, float **device
 int env_set_action_device(EnvHandle game, GroupHandle group, const int *device_actions) { E(game)->set_action_device(group, device_actions); return 0; }
 int env_get_reward_device(EnvHandle game, GroupHandle group, float *device_buffer) { E(game)->get_reward_device(group, device_buffer); return 0; }
 int env_get_info_device(EnvHandle game, GroupHandle group, const char *name, void *device_buffer) { E(game)->info_device(group, name, device_buffer); return 0; }
+// step several environments with overlapped device work: every step is enqueued on its environment's own stream
+// before the first one is waited for (small worlds are launch-latency bound; concurrent environments fill the gaps)
+int env_step_many(EnvHandle *games, int n, int *done) {
+    for (int i = 0; i < n; i++) E(games[i])->step_begin();
+    for (int i = 0; i < n; i++) E(games[i])->step_end(&done[i]);
+    return 0;
+}
+// One full environment cycle -- for each group: observe into device buffers, set device actions; step; rewards;
+// clear_dead (the loop body of examples/train_battle.py:61-109) -- for n_env independent environments, driven by
+// n_threads host threads inside the library (no Python GIL, one HIP stream per environment).  Arrays are indexed
+// [e * n_group + g]; a NULL view / actions / rewards entry skips that call for that group.
+int env_cycle_many(EnvHandle *games, int n_env, int n_group, float **view, float **feat, const int **actions,
+                   float **rewards, int *done, int n_threads) {
+    auto one = [&](int e) {
+        Env *env = E(games[e]);
+        for (int g = 0; g < n_group; g++) {
+            const int k = e * n_group + g;
+            if (view && view[k]) env->observe_device(g, view[k], feat[k]);
+            if (actions && actions[k]) env->set_action_device(g, actions[k]);
+        }
+        env->step(&done[e]);
+        for (int g = 0; g < n_group; g++) {
+            const int k = e * n_group + g;
+            if (rewards && rewards[k]) env->get_reward_device(g, rewards[k]);
+        }
+        env->clear_dead();
+    };
+    if (n_threads <= 1 || n_env <= 1) { for (int e = 0; e < n_env; e++) one(e); return 0; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    const int nt = n_threads < n_env ? n_threads : n_env;
+    for (int t = 0; t < nt; t++) pool.emplace_back([&] { for (int e; (e = next.fetch_add(1)) < n_env;) one(e); });
+    for (auto &th : pool) th.join();
+    return 0;
+}
 int env_sync(EnvHandle game) { E(game)->sync(); return 0; }
 int env_get_stream(EnvHandle game, void **stream) { *stream = (void *)E(game)->stream; return 0; }
 int env_profile_enable(EnvHandle game, int on) { E(game)->prof_on = on != 0; return 0; }

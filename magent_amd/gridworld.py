@@ -491,6 +491,47 @@ class SectorRange(object):
         return "sector(%g, %g)" % (self.radius, self.angle)
 
 
+def step_many(envs):
+    """env.step() for several independent environments with their device work overlapped (one host thread): every
+    step is enqueued on its environment's stream before the first is waited for.  Returns the list of done flags."""
+    lib = envs[0]._lib
+    n = len(envs)
+    handles = (ctypes.c_void_p * n)(*[e.game for e in envs])
+    done = (ctypes.c_int32 * n)()
+    lib.env_step_many(handles, n, done)
+    return [bool(d) for d in done]
+
+
+class EnvBatch(object):
+    """Several independent environments on one GPU, cycled together by host threads inside the library.
+
+    cycle(views, feats, actions, rewards): per environment and group, observe into the given device tensors, set the
+    device actions, step, fetch rewards, clear_dead -- one library call for the whole batch (env_cycle_many)."""
+
+    def __init__(self, envs, n_threads=8):
+        self.envs, self.n_threads = list(envs), n_threads
+        self._lib = self.envs[0]._lib
+        self.n_group = len(self.envs[0].group_handles)
+        n = len(self.envs)
+        self._handles = (ctypes.c_void_p * n)(*[e.game for e in self.envs])
+        self._done = (ctypes.c_int32 * n)()
+
+    def _ptrs(self, tensors):
+        n = len(self.envs) * self.n_group
+        arr = (ctypes.c_void_p * n)()
+        if tensors is not None:
+            for e, per_env in enumerate(tensors):
+                for g, t in enumerate(per_env):
+                    arr[e * self.n_group + g] = None if t is None else t.data_ptr()
+        return arr
+
+    def cycle(self, views=None, feats=None, actions=None, rewards=None):
+        """each argument: list (per env) of lists (per group) of CUDA tensors or None; returns the done flags"""
+        self._lib.env_cycle_many(self._handles, len(self.envs), self.n_group, self._ptrs(views), self._ptrs(feats),
+                                 self._ptrs(actions), self._ptrs(rewards), self._done, self.n_threads)
+        return [bool(d) for d in self._done]
+
+
 def _builtin_config(name, **kwargs):
     try:
         mod = importlib.import_module("magent_amd.builtin.config." + name)

@@ -189,3 +189,69 @@ def test_info_queries_match_oracle():
     for x, y in zip(ha, hb):
         assert a.get_view2attack(x)[0] == b.get_view2attack(y)[0] and np.array_equal(a.get_view2attack(x)[1], b.get_view2attack(y)[1])
     assert a.get_global_minimap(7, 9).tobytes() == b.get_global_minimap(7, 9).tobytes()
+
+
+def test_env_batch_equals_standalone_environments():
+    """magent_amd.EnvBatch (env_cycle_many: library threads, one stream per environment) and step_many give every
+    environment exactly what it computes when driven alone"""
+    torch = _torch()
+    import magent_amd
+    dev = torch.device("cuda", 0)
+    K, N, STEPS = 5, 300, 8
+
+    def make(k):
+        env = magent_amd.GridWorld(H.config_for("battle", 36, small={"hp": 4, "damage": 3}), lib=H.HIP_LIB)
+        env.set_seed(100 + k); env.reset()
+        for h in env.get_handles():
+            env.add_agents(h, "random", n=N)
+        return env
+
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    acts = [[[torch.randint(21, (N,), dtype=torch.int32, device=dev, generator=gen) for _ in range(2)] for _ in range(K)] for _ in range(STEPS)]
+    torch.cuda.synchronize()
+
+    def buffers():
+        return ([[torch.zeros((N, 13, 13, 7), device=dev) for _ in range(2)] for _ in range(K)],
+                [[torch.zeros((N, 34), device=dev) for _ in range(2)] for _ in range(K)],
+                [[torch.zeros(N, device=dev) for _ in range(2)] for _ in range(K)])
+
+    # (a) alone, one call at a time
+    solo, log_a = [make(k) for k in range(K)], []
+    va, fa, ra = buffers()
+    for s in range(STEPS):
+        for k, e in enumerate(solo):
+            for g, h in enumerate(e.get_handles()):
+                e.get_observation_device(h, va[k][g], fa[k][g]); e.set_action_device(h, acts[s][k][g])
+            e.step()
+            for g, h in enumerate(e.get_handles()):
+                e.get_reward_device(h, ra[k][g])
+            e.sync()
+            log_a.append([t.clone() for t in va[k] + fa[k] + ra[k]] + [e.get_pos(h).copy() for h in e.get_handles()])
+            e.clear_dead()
+    # (b) batched
+    envs, log_b = [make(k) for k in range(K)], []
+    batch = magent_amd.EnvBatch(envs, n_threads=3)
+    vb, fb, rb = buffers()
+    for s in range(STEPS):
+        nums = [[e.get_num(h) for h in e.get_handles()] for e in envs]
+        # positions must be read before clear_dead: cycle() includes it, so compare the post-clear state instead
+        batch.cycle(vb, fb, acts[s], rb)
+        for e in envs:
+            e.sync()
+        log_b.append([[t.clone() for t in vb[k] + fb[k] + rb[k]] for k in range(K)])
+    i = 0
+    for s in range(STEPS):
+        for k in range(K):
+            for ta, tb in zip(log_a[i][:6], log_b[s][k]):
+                assert torch.equal(ta.view(torch.int32), tb.view(torch.int32)), (s, k)
+            i += 1
+    for a, b in zip(solo, envs):
+        for ha, hb in zip(a.get_handles(), b.get_handles()):
+            assert np.array_equal(a.get_pos(ha), b.get_pos(hb)) and a.get_num(ha) == b.get_num(hb)
+    # (c) step_many
+    e1, e2 = make(0), make(1)
+    for e in (e1, e2):
+        for g, h in enumerate(e.get_handles()):
+            e.set_action_device(h, acts[0][0][g])
+    dones = magent_amd.step_many([e1, e2])
+    assert dones == [False, False]
