@@ -248,9 +248,11 @@ def main():
         n_launch, ms = env.profile_read("render")
         n_feat, ms_feat = env.profile_read("features")
         if n_launch and ms > 0:
-            # algorithmic bytes of the dominant kernel: every element of the view tensor written exactly once
-            # (4*VH*VW*C per agent; the 4*F feature bytes belong to k_features, timed separately)
-            achieved = rendered["view"] / (ms * 1e-3) / 1e9
+            # algorithmic bytes of the dominant kernel: every element of the observation written exactly once
+            # (B_obs = 4*(VH*VW*C + F) per agent; the feature rows ride in the render launch)
+            fused = n_feat == 0
+            obs_bytes = rendered["view"] + (rendered["feat"] if fused else 0)
+            achieved = obs_bytes / (ms * 1e-3) / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "render_pmc.json")
             if os.path.exists(pmc):
@@ -261,7 +263,7 @@ def main():
             roofline = {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
-                        "algorithmic_bytes_per_launch": int(rendered["view"] / n_launch),
+                        "algorithmic_bytes_per_launch": int(obs_bytes / n_launch),
                         "obs_total_GBs": round((rendered["view"] + rendered["feat"]) / ((ms + ms_feat) * 1e-3) / 1e9, 1)}
         for name in ("paint", "minimap", "attack", "move", "set_action", "starve", "rules", "clear_dead"):
             k, t_ms = env.profile_read(name)

@@ -676,7 +676,10 @@ void Env::observe_device(int g, float *view, float *feat) {
     plan_render(g, R, P, view, feat);
     if (minimap_mode) {
         size_t need = (size_t)W.G * R.VH * R.VW;
-        grow(d_mini, mini_cap, need, stream);
+        if (need > mini_cap) {   // the histogram buffer is kept zero between uses (k_minimap_norm zeroes what it reads)
+            grow(d_mini, mini_cap, need, stream);
+            HIP_OK(hipMemsetAsync(d_mini, 0, sizeof(int) * mini_cap, stream));
+        }
         grow(d_minif, minif_cap, need, stream);
         R.mini = d_minif;
         long long pop = 0;
@@ -687,14 +690,17 @@ void Env::observe_device(int g, float *view, float *feat) {
             mini_valid = true; mini_vh = R.VH; mini_vw = R.VW; mini_pop = pop;
         }
     }
-    const bool aligned = (((uintptr_t)view) & 15) == 0;
+    const bool aligned = (((uintptr_t)view) & 15) == 0, feat_aligned = (((uintptr_t)feat) & 15) == 0;
+    // the feature rows ride in the render launch (its trailing workgroups) when both pointers have the same alignment
+    const unsigned feat_q = (unsigned)R.n * (unsigned)R.F / 4;
+    P.feat_blocks = aligned == feat_aligned ? (int)std::min<unsigned>((feat_q + 255) / 256 + 1, 16384) : 0;
     {
         ProfScope p(*this, "render");
         launch_render(stream, W, R, P, aligned, aligned && nt_stores);
     }
-    {
+    if (P.feat_blocks == 0) {
         ProfScope p(*this, "features");
-        launch_features(stream, W, R, P, (((uintptr_t)feat) & 15) == 0);
+        launch_features(stream, W, R, P, feat_aligned);
     }
     HIP_OK(hipGetLastError());
 }
@@ -805,7 +811,7 @@ void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 
     }
     if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
     for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
-    launch_finish(stream, W);
+    if (any_multicell) launch_finish(stream, W);   // (the 1x1 move commit already consumed the pending actions)
 }
 
 void Env::step(int *done) {
@@ -873,7 +879,7 @@ void Env::step_begin() {
         {
             ProfScope p(*this, "rules");
             for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
-            launch_finish(stream, W);
+            if (any_multicell) launch_finish(stream, W);
         }
         enqueue_counters();
     } else {
@@ -931,7 +937,7 @@ void Env::step_begin() {
         {
             ProfScope p(*this, "rules");
             for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
-            launch_finish(stream, W);
+            if (any_multicell) launch_finish(stream, W);
         }
         enqueue_counters();
     }
@@ -1024,7 +1030,7 @@ void Env::clear_dead() {
             launch_init_reward(stream, W, (int)g);
         }
     }
-    HIP_OK(hipMemsetAsync(d_counters + CTR_DEAD, 0, sizeof(int) * MAXG, stream));
+    // (the death counters of the compacted groups were zeroed by the compaction kernels; the others were zero)
     if (any) { tables_valid = false; h_occ_valid = false; mini_valid = false; }
 }
 

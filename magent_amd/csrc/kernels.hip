@@ -131,12 +131,72 @@ __global__ void __launch_bounds__(256) k_minimap(WorldView W, RenderArgs R, int 
 // ------------------------------------------------------------------------------------------------ minimap normalise
 // mini[j][cell] = float(count) / float(total_j) exactly as the reference (GridWorld.cc:350,356): float ++ saturates
 // at 2^24; an empty group divides 0 by 0 and the x86 default NaN the reference then holds is 0xFFC00000.
-__global__ void __launch_bounds__(256) k_minimap_norm(RenderArgs R, int G, const int *counts, float *mini) {
+__global__ void __launch_bounds__(256) k_minimap_norm(RenderArgs R, int G, int *counts, float *mini) {
     const int VHW = R.VH * R.VW;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= G * VHW) return;
     int tot = R.totals[k / VHW];
     mini[k] = tot == 0 ? __int_as_float(0xFFC00000) : __fdiv_rn((float)min(counts[k], 1 << 24), (float)(unsigned)tot);
+    counts[k] = 0;   // the next histogram starts from zero (the buffer is zeroed when it is allocated)
+}
+
+// ------------------------------------------------------------------------------------------------ feature rows
+// feature rows [id bits x E | one-hot last_action x NA | last_reward | x / w | y / h] (GridWorld.cc:386-396)
+struct AgentFeat { int id, la; float lr, fx, fy; };
+
+__device__ __forceinline__ AgentFeat load_feat(const WorldView &W, const GroupDev &Gd, int i) {
+    AgentFeat a;
+    a.id = Gd.id[i]; a.la = Gd.last_action[i]; a.lr = Gd.last_reward[i];
+    a.fx = __fdiv_rn((float)Gd.x[i], (float)W.w);
+    a.fy = __fdiv_rn((float)Gd.y[i], (float)W.h);
+    return a;
+}
+
+// value of feature slot f from registers (no loads, no divergent paths with memory behind them)
+__device__ __forceinline__ float feature_value(const RenderArgs &R, const AgentFeat &a, int f) {
+    const int rel = f - R.E;
+    float v = (f < 31 && ((a.id >> f) & 1)) ? 1.0f : 0.0f;                 // id bits, LSB first
+    v = f >= R.E ? (a.la == rel ? 1.0f : 0.0f) : v;                        // one-hot last action
+    v = rel == R.NA ? a.lr : v;                                            // a fresh agent's last_action == NA lands here
+    v = rel == R.NA + 1 ? a.fx : v;                                        // and is overwritten (GridWorld.cc:390-392)
+    v = rel == R.NA + 2 ? a.fy : v;
+    return v;
+}
+
+// the feature tensor of the group, as float4 where the pointer allows; `block` of `n_blocks` workgroups of 256 threads
+template <bool VEC4>
+__device__ __forceinline__ void features_body(const WorldView &W, const RenderArgs &R, const RenderPlan &P, unsigned block, unsigned n_blocks) {
+    const GroupDev Gd = W.grp[R.g];
+    const unsigned total = (unsigned)R.n * (unsigned)R.F;
+    const unsigned nq = VEC4 ? total >> 2 : 0;
+    for (unsigned q = block * 256u + threadIdx.x; q < nq; q += n_blocks * 256u) {
+        const unsigned k = q << 2;
+        const int i = fdiv_u32(k, P.div_f);
+        int f = k - i * R.F;
+        // four consecutive floats touch at most two agents when F >= 4 (the feature row always holds >= 2 slots, so
+        // the general case walks on); both agents' fields are loaded up front so the loads overlap
+        AgentFeat a0 = load_feat(W, Gd, i), a1 = load_feat(W, Gd, min(i + 1, R.n - 1));
+        int cur = i;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (cur > i + 1) { a1 = load_feat(W, Gd, cur); }               // only when F < 3 (never in practice)
+            v[e] = feature_value(R, cur == i ? a0 : a1, f);
+            if (++f == R.F) { f = 0; ++cur; }
+        }
+        v4f f4 = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(f4, (v4f *)R.feat + q);
+    }
+    for (unsigned k = (nq << 2) + block * 256u + threadIdx.x; k < total; k += n_blocks * 256u) {
+        const int i = fdiv_u32(k, P.div_f);
+        R.feat[k] = feature_value(R, load_feat(W, Gd, i), k - i * R.F);
+    }
+}
+
+// stand-alone launch, used when the feature pointer is not 16-byte aligned while the view pointer is (or vice versa)
+template <bool VEC4>
+__global__ void __launch_bounds__(256) k_features(WorldView W, RenderArgs R, RenderPlan P) {
+    features_body<VEC4>(W, R, P, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------ observation render
@@ -163,6 +223,10 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, Rende
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *strip = (float *)smem + (size_t)wave * P.strip_floats;      // [64][C], wave-private
 
+    if ((int)blockIdx.x >= P.spans) {   // the trailing workgroups write the group's feature rows (3 % of the bytes)
+        features_body<VEC4>(W, R, P, blockIdx.x - P.spans, gridDim.x - P.spans);
+        return;
+    }
     int span = blockIdx.x;
     if (P.xcd_chunk > 0 && span < P.xcd_chunk * 8) span = (span & 7) * P.xcd_chunk + (span >> 3);
     const GroupDev Gd = W.grp[R.g];
@@ -265,57 +329,6 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, Rende
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the strip is reused by the next step
             __builtin_amdgcn_wave_barrier();
         }
-    }
-}
-
-// feature rows [id bits x E | one-hot last_action x NA | last_reward | x / w | y / h] (GridWorld.cc:386-396)
-struct AgentFeat { int id, la; float lr, fx, fy; };
-
-__device__ __forceinline__ AgentFeat load_feat(const WorldView &W, const GroupDev &Gd, int i) {
-    AgentFeat a;
-    a.id = Gd.id[i]; a.la = Gd.last_action[i]; a.lr = Gd.last_reward[i];
-    a.fx = __fdiv_rn((float)Gd.x[i], (float)W.w);
-    a.fy = __fdiv_rn((float)Gd.y[i], (float)W.h);
-    return a;
-}
-
-// value of feature slot f from registers (no loads, no divergent paths with memory behind them)
-__device__ __forceinline__ float feature_value(const RenderArgs &R, const AgentFeat &a, int f) {
-    const int rel = f - R.E;
-    float v = (f < 31 && ((a.id >> f) & 1)) ? 1.0f : 0.0f;                 // id bits, LSB first
-    v = f >= R.E ? (a.la == rel ? 1.0f : 0.0f) : v;                        // one-hot last action
-    v = rel == R.NA ? a.lr : v;                                            // a fresh agent's last_action == NA lands here
-    v = rel == R.NA + 1 ? a.fx : v;                                        // and is overwritten (GridWorld.cc:390-392)
-    v = rel == R.NA + 2 ? a.fy : v;
-    return v;
-}
-
-template <bool VEC4>
-__global__ void __launch_bounds__(256) k_features(WorldView W, RenderArgs R, RenderPlan P) {
-    const GroupDev Gd = W.grp[R.g];
-    const unsigned total = (unsigned)R.n * (unsigned)R.F;
-    const unsigned nq = VEC4 ? total >> 2 : 0;
-    for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
-        const unsigned k = q << 2;
-        const int i = fdiv_u32(k, P.div_f);
-        int f = k - i * R.F;
-        // four consecutive floats touch at most two agents when F >= 4 (the feature row always holds >= 2 slots, so
-        // the general case walks on); both agents' fields are loaded up front so the loads overlap
-        AgentFeat a0 = load_feat(W, Gd, i), a1 = load_feat(W, Gd, min(i + 1, R.n - 1));
-        int cur = i;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            if (cur > i + 1) { a1 = load_feat(W, Gd, cur); }               // only when F < 3 (never in practice)
-            v[e] = feature_value(R, cur == i ? a0 : a1, f);
-            if (++f == R.F) { f = 0; ++cur; }
-        }
-        v4f f4 = {v[0], v[1], v[2], v[3]};
-        __builtin_nontemporal_store(f4, (v4f *)R.feat + q);
-    }
-    for (unsigned k = (nq << 2) + blockIdx.x * blockDim.x + threadIdx.x; k < total; k += gridDim.x * blockDim.x) {
-        const int i = fdiv_u32(k, P.div_f);
-        R.feat[k] = feature_value(R, load_feat(W, Gd, i), k - i * R.F);
     }
 }
 
@@ -545,18 +558,15 @@ __global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *
     atomicAdd(&count[ji], 1);
 }
 
-// the engine state after the shuffle's A draws: x <- 16807^A x (the host mirror is refreshed at the end-of-step readback)
-__global__ void k_rng_skip(int *counters) {
-    if (threadIdx.x != 0) return;
-    unsigned e = (unsigned)counters[CTR_ATTACK], base = 16807u, acc = (unsigned)counters[CTR_RNG];
-    counters[CTR_LAST_A] = (int)e;
-    while (e) { if (e & 1u) acc = mulmod31(acc, base); base = mulmod31(base, base); e >>= 1; }
-    counters[CTR_RNG] = (int)acc;
-}
-
-__global__ void __launch_bounds__(256) k_shuffle_fill(const int *counters, const int *j, const int *offset, int *cursor, int *list) {
+__global__ void __launch_bounds__(256) k_shuffle_fill(int *counters, const int *j, const int *offset, int *cursor, int *list) {
     const int A = counters[CTR_ATTACK];
     int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) {   // the engine state after the shuffle's A draws: x <- 16807^A x (every draw has read the old state:
+        unsigned e = (unsigned)A, base = 16807u, acc = (unsigned)counters[CTR_RNG];   // k_shuffle_draw ran before)
+        counters[CTR_LAST_A] = A;
+        while (e) { if (e & 1u) acc = mulmod31(acc, base); base = mulmod31(base, base); e >>= 1; }
+        counters[CTR_RNG] = (int)acc;   // the host mirror is refreshed at the end-of-step readback
+    }
     if (k >= A) return;
     int v = j[k];
     list[offset[v] + atomicAdd(&cursor[v], 1)] = k;
@@ -888,25 +898,25 @@ __global__ void __launch_bounds__(256) k_move_apply1(WorldView W, const GroupDev
     G.op_obj[i] = blocker;
 }
 
-__global__ void __launch_bounds__(256) k_move_vacate(WorldView W) {
-    if (gate_after(W)) return;
-    const GroupDev G = W.grp[blockIdx.y];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n || G.drank_a[i] < 0 || G.mv[i] != MV_OK) return;
-    W.occ[G.y[i] * W.w + G.x[i]] = OCC_EMPTY;
-}
-
-__global__ void __launch_bounds__(256) k_move_enter(WorldView W) {
+// successful 1x1 moves: leave the old cell, enter the new one.  One launch: a cell that a successful mover leaves is
+// either entered by the static winner of that cell (which succeeds exactly when the leaver does, and then writes the
+// cell itself) or by nobody (no claim on it: the leaver clears it) -- no cell is written by two agents
+__global__ void __launch_bounds__(256) k_move_commit(WorldView W) {
     if (gate_after(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n) return;
-    int c = G.drank_a[i];
-    if (c < 0 || G.mv[i] != MV_OK) return;
-    W.occ[c] = ref_pack(g, i);
-    int ny = c / W.w;
-    G.x[i] = c - ny * W.w; G.y[i] = ny;
+    if (i < G.n) {
+        const int c = G.drank_a[i];
+        if (c >= 0 && G.mv[i] == MV_OK) {
+            const int old = G.y[i] * W.w + G.x[i];
+            if (W.claim[old] == CLAIM_NONE) W.occ[old] = OCC_EMPTY;
+            W.occ[c] = ref_pack(g, i);
+            const int ny = c / W.w;
+            G.x[i] = c - ny * W.w; G.y[i] = ny;
+        }
+        G.pend[i] = PEND_NONE;   // end of step: pending actions are consumed (also done by k_finish for the generic path)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ move, generic bodies
@@ -1158,20 +1168,24 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int 
     const GroupDev G = W.grp[g];
     const float step_reward = W.type[g].step_reward;
     const int bw = W.type[g].bw, bl = W.type[g].bl;
-    solo_rank([&](int i) { return !G.dead[i]; },
-              [&](int i, int r) {
-                  int x = G.x[i], y = G.y[i];
-                  D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
-                  D.last_reward[r] = G.next_reward[i];
-                  D.next_reward[r] = step_reward;
-                  body_fill(W, x, y, bw, bl, ref_pack(g, r));
-              },
-              G.n, 0);
+    const int alive = solo_rank([&](int i) { return !G.dead[i]; },
+                                [&](int i, int r) {
+                                    int x = G.x[i], y = G.y[i];
+                                    D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
+                                    D.last_reward[r] = G.next_reward[i];
+                                    D.next_reward[r] = step_reward;
+                                    body_fill(W, x, y, bw, bl, ref_pack(g, r));
+                                },
+                                G.n, 0);
+    // every read of the in-place arrays is done (solo_rank ends with a barrier): reset them for the survivors
+    for (int r = threadIdx.x; r < alive; r += SOLO_THREADS) { D.dead[r] = 0; D.last_op[r] = OP_NULL; D.op_obj[r] = -1; D.pend[r] = PEND_NONE; }
+    if (threadIdx.x == 0) W.counters[CTR_DEAD + g] = 0;
 }
 
 // the non-double-buffered per-agent state of the survivors
-__global__ void __launch_bounds__(256) k_compact_reset(GroupDev D, int n) {
+__global__ void __launch_bounds__(256) k_compact_reset(GroupDev D, int n, int *dead_counter) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *dead_counter = 0;
     if (i >= n) return;
     D.dead[i] = 0; D.last_op[i] = OP_NULL; D.op_obj[i] = -1; D.pend[i] = PEND_NONE;
 }
@@ -1197,7 +1211,6 @@ void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const
 
 void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts, float *mini) {
     int VHW = R.VH * R.VW;
-    (void)hipMemsetAsync(counts, 0, sizeof(int) * W.G * VHW, s);
     int mx = 1;
     for (int g = 0; g < W.G; g++) mx = W.grp[g].n > mx ? W.grp[g].n : mx;
     int bx = (mx + 255) / 256;
@@ -1209,7 +1222,7 @@ void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int 
 void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt) {
     if (R.n <= 0) return;
     size_t lds = (size_t)RENDER_WAVES * P.strip_floats * sizeof(float);
-    dim3 grid(P.spans), block(64 * RENDER_WAVES);
+    dim3 grid(P.spans + P.feat_blocks), block(64 * RENDER_WAVES);
     const bool packed = W.G <= 3;   // must match launch_paint
 #define RENDER_LAUNCH(V, N, UU, PK) hipLaunchKernelGGL((k_render<V, N, UU, PK>), grid, block, lds, s, W, R, P)
 #define RENDER_PK(V, N, UU) do { if (packed) RENDER_LAUNCH(V, N, UU, true); else RENDER_LAUNCH(V, N, UU, false); } while (0)
@@ -1254,7 +1267,6 @@ void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count,
     }
     hipLaunchKernelGGL(k_shuffle_fill, g, b, 0, s, counters, j, offset, cursor, list);
     hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, j, offset, count, list, rank);
-    hipLaunchKernelGGL(k_rng_skip, dim3(1), dim3(64), 0, s, counters);
 }
 void launch_step_reset(hipStream_t s, int *counters) { hipLaunchKernelGGL(k_step_reset, dim3(1), dim3(64), 0, s, counters); }
 void launch_set_rng(hipStream_t s, int *counters, unsigned x) { hipLaunchKernelGGL(k_set_rng, dim3(1), dim3(64), 0, s, counters, x); }
@@ -1308,8 +1320,7 @@ void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, i
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     dim3 g = grid_all(W, 256);
     hipLaunchKernelGGL(k_move_apply1, g, dim3(256), 0, s, W, gtab);
-    hipLaunchKernelGGL(k_move_vacate, g, dim3(256), 0, s, W);
-    hipLaunchKernelGGL(k_move_enter, g, dim3(256), 0, s, W);
+    hipLaunchKernelGGL(k_move_commit, g, dim3(256), 0, s, W);
 }
 
 void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A) {
@@ -1338,13 +1349,14 @@ void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D,
     if (n <= 0) return;
     if (n <= SOLO_MAX) {
         hipLaunchKernelGGL(k_compact_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, D);
+        return;
     } else {
         int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
         hipLaunchKernelGGL(k_compact_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W.grp[g], sums);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, (int *)nullptr);
         hipLaunchKernelGGL(k_compact_c, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, D, sums);
     }
-    if (new_n > 0) hipLaunchKernelGGL(k_compact_reset, dim3((new_n + 255) / 256), dim3(256), 0, s, D, new_n);
+    hipLaunchKernelGGL(k_compact_reset, dim3((std::max(new_n, 1) + 255) / 256), dim3(256), 0, s, D, new_n, W.counters + CTR_DEAD + g);
 }
 
 }  // namespace magent_amd

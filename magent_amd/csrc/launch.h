@@ -24,6 +24,7 @@ inline FastDiv make_fastdiv(unsigned d) {
 struct RenderPlan {
     int spans;           // workgroups; each owns `steps_per_span` consecutive 64-cell steps of the flat cell sequence
     int steps_per_span;
+    int feat_blocks;     // trailing workgroups of the render launch that write the feature rows (0 = separate launch)
     int xcd_chunk;       // spans / 8 when the XCD-aware span mapping is on, else 0
     int strip_floats;    // 64 * C: wave-private LDS strip
     int unroll;          // 64-cell steps whose loads a wave keeps in flight together (1, 2, 4 or 8)
