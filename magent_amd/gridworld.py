@@ -291,7 +291,10 @@ class GridWorld(object):
     def __del__(self):
         game, self.game = getattr(self, "game", None), None
         if game:
-            self._lib.env_delete_game(game)
+            try:
+                self._lib.env_delete_game(game)
+            except Exception:   # interpreter shutdown: ctypes / the library may already be gone
+                pass
 
     # ------------------------------------------------------------------ MI355X extensions (device buffers)
     def _require_device_api(self):
