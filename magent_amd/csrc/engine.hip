@@ -285,12 +285,16 @@ void Env::register_agent_type(const char *name, int n, const char **keys, float 
     }
     if (t.width < 1 || t.length < 1 || t.width > 16 || t.length > 16) fatal("agent type %s: body %dx%d out of range", name, t.width, t.length);
     if (t.can_absorb) fatal("agent type %s: can_absorb is outside the hot-path scope", name);
-    if (t.view_angle < 180 || t.attack_angle < 180) fatal("agent type %s: sector ranges are outside the hot-path scope", name);
-    if (std::fabs(t.view_angle - 360) > 1e-5 || std::fabs(t.attack_angle - 360) > 1e-5)
+    // A type registered without an attack range keeps the defaults attack_radius = 0, attack_angle = 0 and gets
+    // SectorRange(0, 0): height = (int)(0 + 0.5) = 0 rows, i.e. no attack action at all (Range.h:106-139,
+    // AgentType.cc:95-102; examples/train_trans.py).  Real sectors stay outside the hot-path scope.
+    const bool no_attack = t.attack_angle < 180 && (int)(t.attack_radius + 0.5) == 0;
+    if (t.view_angle < 180 || (t.attack_angle < 180 && !no_attack)) fatal("agent type %s: sector ranges are outside the hot-path scope", name);
+    if (std::fabs(t.view_angle - 360) > 1e-5 || (!no_attack && std::fabs(t.attack_angle - 360) > 1e-5))
         fatal("only supports ranges with angle = 360, when angle > 180.");
     const int parity = t.width % 2;
     t.view.circle(t.view_radius, 0, parity);
-    t.attack.circle(t.attack_radius, t.width / 2.0f, parity);
+    if (!no_attack) t.attack.circle(t.attack_radius, t.width / 2.0f, parity);
     t.move.circle(t.speed, 0, 1);
     t.view_x_offset = t.att_x_offset = t.width / 2;
     t.view_y_offset = t.att_y_offset = t.length / 2;

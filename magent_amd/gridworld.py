@@ -248,7 +248,7 @@ class GridWorld(object):
 
     def get_global_minimap(self, height, width):
         buf = np.empty((height, width, len(self.group_handles)), dtype=np.float32)
-        buf[0, 0, 0], buf[0, 0, 1] = height, width  # in-params travel in the out-buffer (GridWorld.cc:741-742)
+        buf.reshape(-1)[:2] = height, width  # in-params travel in the out-buffer's first two floats (GridWorld.cc:741-742)
         return self._info(-1, b"global_minimap", buf)
 
     def get_mean_info(self, handle):

@@ -113,7 +113,17 @@ def custom_bodies(map_w, map_h):
     return cfg
 
 
-CUSTOM = {"tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
+def custom_trans(map_size):
+    """examples/train_trans.py:17-37: ONE group, a type registered without any attack range, a 2:1 map"""
+    cfg = gw.Config()
+    cfg.set({"map_width": map_size * 2, "map_height": map_size, "minimap_mode": True, "embedding_size": 10})
+    agent = cfg.register_agent_type("agent", dict(width=1, length=1, hp=10, speed=1, view_range=gw.CircleRange(6),
+                                                  damage=2, step_recover=0.1, step_reward=-1))
+    cfg.add_group(agent)
+    return cfg
+
+
+CUSTOM = {"trans": custom_trans, "tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
 
 
 class Scenario(object):
@@ -353,6 +363,8 @@ def scenarios():
         Scenario("bodies", ("bodies", 48, 37), 0, walls=40, place=[rnd(0, 60), rnd(1, 90), rnd(2, 150)], steps=30, action_seed=26),
         Scenario("bodies_large", ("bodies", 130, 111), 0, walls=300, place=[rnd(0, 500), rnd(1, 900), rnd(2, 1500),
                  (0, "fill", {"pos": (100, 80), "size": (12, 10)})], steps=10, action_seed=27),
+        Scenario("trans", ("trans", 40), 0, walls=150, place=[rnd(0, 300), (0, "fill", {"pos": (60, 10), "size": (4, 12)})],
+                 steps=15, action_seed=29),
         Scenario("chase", ("chase", 40), 0, place=[rnd(0, 150), rnd(1, 300)], walls=40, steps=20, action_seed=18),
         Scenario("battle_events", "battle", 45, place=[rnd(0, 300), rnd(1, 300)], steps=24, action_seed=19,
                  over={"small": {"hp": 4, "damage": 3}},
