@@ -128,3 +128,13 @@ def rec_round(x, ndigits=2):
     if isinstance(x, (list, tuple, np.ndarray)):
         return [rec_round(v, ndigits) for v in x]
     return round(float(x), ndigits)
+
+
+def check_model(name):
+    """the reference downloads pre-trained TensorFlow checkpoints here (utility.py:260-305); there is no network and no
+    TensorFlow in this build: report what is missing instead"""
+    import os
+    path = os.path.join("data", name + "_model")
+    if not os.path.exists(path):
+        raise FileNotFoundError("pre-trained model %r is not shipped with this build (expected under %s)" % (name, path))
+    return True

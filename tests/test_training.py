@@ -112,6 +112,11 @@ def test_magent_alias_exposes_the_reference_names():
     assert DeepQNetwork.__name__ == "DeepQNetwork" and RandomActor is not None
     cfg = magent.gridworld.Config()
     cfg.set({"map_width": 10, "map_height": 10})
+    from magent.builtin.mx_model import DeepQNetwork as MX     # train_gather.py imports the MXNet name
+    from magent.builtin.tf_model import DeepRecurrentQNetwork   # train_trans.py imports it; constructing it is refused
+    assert MX is DeepQNetwork
+    with pytest.raises(NotImplementedError):
+        DeepRecurrentQNetwork()
 
 
 @pytest.mark.skipif(not os.path.isfile("/root/reference/examples/train_battle.py"), reason="reference examples not present")
