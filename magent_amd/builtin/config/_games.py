@@ -5,6 +5,7 @@ Values are those of the reference's game files -- they are data the parity tests
   pursuit: python/magent/builtin/config/pursuit.py:4-33
   gather : examples/train_gather.py:14-43
   forest : python/magent/builtin/config/forest.py:6-33 (no reward rule; deer carry kill_supply)
+  double_attack: python/magent/builtin/config/double_attack.py:8-42 (two tigers on one deer: Event & Event)
 """
 from ... import gridworld as gw
 
@@ -34,6 +35,15 @@ _GAMES = {
         groups=["deer", "tiger"],
         rules=[],
     ),
+    "double_attack": dict(
+        settings={"embedding_size": 10},
+        types={"deer": dict(width=1, length=1, hp=5, speed=1, view_range=1, attack_range=0, step_recover=0.2, kill_supply=8),
+               "tiger": dict(width=1, length=1, hp=10, speed=1, view_range=4, attack_range=1, damage=1, step_recover=-0.2)},
+        groups=["deer", "tiger"],
+        rules=[],
+        # (subject group a, subject group b, predicate, object group, receivers, values): Event(a, p, c) & Event(b, p, c)
+        pair_rules=[(1, 1, "attack", 0, "ab", [1, 1])],
+    ),
     "gather": dict(
         settings={"minimap_mode": True},
         types={"agent": dict(width=1, length=1, hp=3, speed=3, view_range=7, attack_range=1, damage=6, step_recover=0,
@@ -60,4 +70,9 @@ def make(game, map_size):
         s = gw.AgentSymbol(handles[subj], index="any")
         o = gw.AgentSymbol(handles[obj], index="any")
         cfg.add_reward_rule(gw.Event(s, pred, o), receiver=[{"s": s, "o": o}[c] for c in who], value=list(values))
+    for ga, gb, pred, gc, who, values in spec.get("pair_rules", ()):
+        a, b = gw.AgentSymbol(handles[ga], index="any"), gw.AgentSymbol(handles[gb], index="any")
+        c = gw.AgentSymbol(handles[gc], index="any")
+        cfg.add_reward_rule(gw.Event(a, pred, c) & gw.Event(b, pred, c), receiver=[{"a": a, "b": b, "c": c}[k] for k in who],
+                            value=list(values))
     return cfg

@@ -342,8 +342,43 @@ void Env::compile_rules() {
         const HostRule &r = rules[k];
         if (r.on < 0 || r.on >= (int)nodes.size()) fatal("reward rule %zu refers to an undefined event", k);
         const HostNode &on = nodes[r.on];
-        if (!(on.op == OP_ATTACK || on.op == OP_KILL || on.op == OP_COLLIDE) || on.raw.size() != 2)
-            fatal("reward rule %zu: only Event(a, attack|kill|collide, b) is on the GPU path (SURVEY.md 8a row a8)", k);
+        auto binary = [&](const HostNode &n) { return (n.op == OP_ATTACK || n.op == OP_KILL || n.op == OP_COLLIDE) && n.raw.size() == 2; };
+        auto any_sym = [&](int no) {
+            if (no < 0 || no >= (int)symbols.size()) fatal("reward rule %zu refers to an undefined agent symbol", k);
+            const HostSymbol &sy = symbols[no];
+            if (sy.index != -1) fatal("reward rule %zu: only 'any' agent symbols are on the GPU path", k);
+            if (sy.group < 0 || sy.group >= (int)groups.size()) fatal("reward rule %zu: invalid group in agent symbol", k);
+            return sy.group;
+        };
+        if (on.op == 0 /* and */ && on.raw.size() == 2 && on.raw[0] >= 0 && on.raw[1] >= 0 && on.raw[0] < (int)nodes.size() &&
+            on.raw[1] < (int)nodes.size() && binary(nodes[on.raw[0]]) && binary(nodes[on.raw[1]])) {
+            // Event(a, p, c) & Event(b, q, c): "two agents act on the same third" (builtin/config/double_attack.py:33-40)
+            const HostNode *e1 = &nodes[on.raw[0]], *e2 = &nodes[on.raw[1]];
+            if (e1->raw[1] != e2->raw[1] || e1->raw[0] == e2->raw[0] || e1->raw[0] == e1->raw[1] || e2->raw[0] == e2->raw[1])
+                fatal("reward rule %zu: `&` is on the GPU path for Event(a, p, c) & Event(b, q, c) with distinct symbols a, b, c", k);
+            if (e2->raw[0] < e1->raw[0]) std::swap(e1, e2);   // the search binds symbols in ascending number (RewardEngine.cc:155-189)
+            RuleArgs a{};
+            a.pair = 1; a.rule_no = (int)k;
+            a.ga = any_sym(e1->raw[0]); a.op = e1->op;
+            a.gy = any_sym(e2->raw[0]); a.op_y = e2->op;
+            a.gb = any_sym(e1->raw[1]);
+            for (size_t i = 0; i < r.recv.size(); i++) {
+                int *cnt; float *val;
+                if (r.recv[i] == e1->raw[0]) { cnt = &a.n_subj; val = a.v_subj; }
+                else if (r.recv[i] == e2->raw[0]) { cnt = &a.n_y; val = a.v_y; }
+                else if (r.recv[i] == e1->raw[1]) { cnt = &a.n_obj; val = a.v_obj; }
+                else fatal("reward rule %zu: a receiver must be a symbol of the event", k);
+                if (*cnt == 4) fatal("too many receivers");
+                val[(*cnt)++] = r.val[i];
+            }
+            if (a.n_obj && (a.gb == a.ga || a.gb == a.gy))
+                fatal("reward rule %zu: paying the shared object inside a subject's group interleaves float adds; not on the GPU path", k);
+            rule_args.push_back(a);
+            continue;
+        }
+        if (!binary(on))
+            fatal("reward rule %zu: only Event(a, attack|kill|collide, b) and Event(a, p, c) & Event(b, q, c) are on the GPU path "
+                  "(SURVEY.md 8a row a8)", k);
         const HostSymbol &sa = symbols[on.raw[0]], &sb = symbols[on.raw[1]];
         if (sa.index != -1 || sb.index != -1) fatal("reward rule %zu: only 'any' agent symbols are on the GPU path", k);
         if (sa.group < 0 || sa.group >= (int)groups.size() || sb.group < 0 || sb.group >= (int)groups.size())

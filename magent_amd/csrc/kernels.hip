@@ -1109,6 +1109,84 @@ __global__ void __launch_bounds__(256) k_rule_obj(WorldView W, RuleArgs A) {
     G.hits[i] = 0;
 }
 
+// Event(x, op, c) & Event(y, op_y, c): the reference's search (RewardEngine.cc:216-306) binds x over its group, then y
+// over its group skipping the agent bound to x, re-binds c to y's target, and pays the receivers once per ordered
+// pair (i, j) with  last_op[i] == op, last_op[j] == op_y, op_obj[i] == op_obj[j] in c's group.  Per agent t that is
+//   [v_y x #{partners i < t}] [v_x x #{partners j}] [v_y x #{partners i > t}]
+// when x and y share a group and predicate (t plays both parts; pairs come in (i, j) order), and a run of one value
+// otherwise.  The partners are found through a per-target list: head in the target's `hits`, links in `mv`.
+__device__ __forceinline__ int pair_roles(const WorldView &W, const RuleArgs &A, int g, int i) {
+    const GroupDev &G = W.grp[g];
+    int o = G.op_obj[i];
+    if (o < 0 || ref_group(o) != A.gb) return 0;
+    int op = G.last_op[i];
+    return ((g == A.ga && op == A.op) ? 1 : 0) | ((g == A.gy && op == A.op_y) ? 2 : 0);
+}
+
+__global__ void __launch_bounds__(256) k_pair_link(WorldView W, RuleArgs A) {
+    if (gate_after(W)) return;
+    const int g = blockIdx.y ? A.gy : A.ga;
+    const GroupDev G = W.grp[g];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.n || !pair_roles(W, A, g, i)) return;
+    G.mv[i] = (unsigned)atomicExch(&W.grp[A.gb].hits[ref_index(G.op_obj[i])], ref_pack(g, i) + 1);
+}
+
+__global__ void __launch_bounds__(256) k_pair_pay(WorldView W, RuleArgs A) {
+    if (gate_after(W)) return;
+    const int g = blockIdx.y ? A.gy : A.ga;
+    const GroupDev G = W.grp[g];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool trig = false;
+    if (i < G.n) {
+        const int mine = pair_roles(W, A, g, i);
+        if (mine) {
+            int y_lt = 0, y_gt = 0, n_x = 0;   // pairs in which this agent is y (partner before / after it), is x
+            for (int r = W.grp[A.gb].hits[ref_index(G.op_obj[i])]; r != 0;) {
+                const int ug = ref_group(r - 1), ui = ref_index(r - 1);
+                r = (int)W.grp[ug].mv[ui];
+                if (ug == g && ui == i) continue;
+                const int theirs = pair_roles(W, A, ug, ui);
+                if ((mine & 1) && (theirs & 2)) n_x++;
+                if ((mine & 2) && (theirs & 1)) { if (ug == g && ui > i) y_gt++; else y_lt++; }
+            }
+            if (n_x | y_lt | y_gt) {
+                trig = true;
+                float nr = G.next_reward[i];
+                for (; y_lt > 0; y_lt--) for (int k = 0; k < A.n_y; k++) nr += A.v_y[k];
+                for (; n_x > 0; n_x--) for (int k = 0; k < A.n_subj; k++) nr += A.v_subj[k];
+                for (; y_gt > 0; y_gt--) for (int k = 0; k < A.n_y; k++) nr += A.v_y[k];
+                G.next_reward[i] = nr;
+            }
+        }
+    }
+    if (__ballot(trig) && lane_id() == 0) W.counters[CTR_TRIGGER + A.rule_no] = 1;
+}
+
+// the object's share (one run of v_obj per ordered pair) and the reset of the list heads
+__global__ void __launch_bounds__(256) k_pair_obj(WorldView W, RuleArgs A) {
+    if (gate_after(W)) return;
+    const GroupDev G = W.grp[A.gb];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.n) return;
+    int r = G.hits[i];
+    if (!r) return;
+    G.hits[i] = 0;
+    if (!A.n_obj) return;
+    int nx = 0, ny = 0, nboth = 0;
+    while (r != 0) {
+        const int ug = ref_group(r - 1), ui = ref_index(r - 1);
+        const int roles = pair_roles(W, A, ug, ui);
+        nx += roles & 1; ny += (roles >> 1) & 1; nboth += roles == 3;
+        r = (int)W.grp[ug].mv[ui];
+    }
+    int pairs = nx * ny - nboth;
+    if (!pairs) return;
+    float nr = G.next_reward[i];
+    for (; pairs > 0; pairs--) for (int k = 0; k < A.n_obj; k++) nr += A.v_obj[k];
+    G.next_reward[i] = nr;
+}
+
 // end of step: pending actions are consumed
 __global__ void __launch_bounds__(256) k_finish(WorldView W) {
     if (gate_after(W)) return;
@@ -1325,6 +1403,15 @@ void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) 
 
 void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A) {
     int na = W.grp[A.ga].n, nb = W.grp[A.gb].n;
+    if (A.pair) {
+        int ny = W.grp[A.gy].n;
+        if (na <= 0 || ny <= 0 || nb <= 0) return;
+        dim3 grid((std::max(na, ny) + 255) / 256, A.ga == A.gy ? 1 : 2);
+        hipLaunchKernelGGL(k_pair_link, grid, dim3(256), 0, s, W, A);
+        hipLaunchKernelGGL(k_pair_pay, grid, dim3(256), 0, s, W, A);
+        hipLaunchKernelGGL(k_pair_obj, dim3((nb + 255) / 256), dim3(256), 0, s, W, A);
+        return;
+    }
     if (na > 0) hipLaunchKernelGGL(k_rule, dim3((na + 255) / 256), dim3(256), 0, s, W, A);
     if (A.n_obj && na > 0 && nb > 0) hipLaunchKernelGGL(k_rule_obj, dim3((nb + 255) / 256), dim3(256), 0, s, W, A);
 }

@@ -31,11 +31,15 @@ struct RenderPlan {
     FastDiv div_vhw, div_vw, div_f, div_scale_w, div_scale_h;
 };
 
-// one reward rule Event(a, op, b), a/b = 'any'
+// one reward rule, symbols 'any':  Event(a, op, b)                        -- pair == 0: ga/op = subject, gb = object
+//                                   Event(x, op, c) & Event(y, op_y, c)     -- pair == 1: ga/op = x (the symbol the reference's
+//                                       search binds first = the lower-numbered one), gy/op_y = y, gb = c
 struct RuleArgs {
     int ga, gb, op, rule_no;
-    int n_subj, n_obj;            // receivers that are the subject / the object of the event
+    int n_subj, n_obj;            // receivers that are the (first) subject / the object of the event
     float v_subj[4], v_obj[4];
+    int pair, gy, op_y, n_y;
+    float v_y[4];
 };
 
 void launch_set_tables(hipStream_t s, const WorldView &W, GroupDev *gtab, TypeDev *ttab);

@@ -13,14 +13,16 @@
 // State is kept as per-group struct-of-arrays + a packed occupancy grid; the *order* of every loop that the
 // reference executes sequentially is kept literally, because the results depend on it.
 //
-// Scope: what SURVEY.md section 8 puts on the path -- no food_mode / turn_mode / goal_mode / can_absorb, reward
-// rules of the shape Event(a, attack|kill|collide, b) with 'any' symbols.  Anything else aborts with a message.
+// Scope: what SURVEY.md section 8 puts on the path -- no food_mode / turn_mode / goal_mode / can_absorb.  Reward rules
+// are evaluated by the reference's recursive search over symbol bindings, literally (and/or/not over attack, kill,
+// collide, die, at, in; 'any', 'all' and fixed-index symbols); align / in_a_line abort with a message.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -83,7 +85,8 @@ struct AgentType {
     int move_base = 0, turn_base = 0, attack_base = 0, n_action = 0;
 };
 
-enum { OP_KILL = 3, OP_COLLIDE = 6, OP_ATTACK = 7, OP_NULL = 11 };  // grid_def.h:18-24
+enum { OP_AND = 0, OP_OR = 1, OP_NOT = 2, OP_KILL = 3, OP_AT = 4, OP_IN = 5, OP_COLLIDE = 6, OP_ATTACK = 7, OP_DIE = 8,
+       OP_IN_A_LINE = 9, OP_ALIGN = 10, OP_NULL = 11 };  // grid_def.h:18-24
 
 struct Group {
     AgentType *type = nullptr;
@@ -101,9 +104,16 @@ struct Group {
     }
 };
 
-struct Symbol { int group = 0, index = 0; };
-struct Node { int op = OP_NULL; std::vector<int> raw; };
-struct Rule { int on = 0; std::vector<int> recv; std::vector<float> val; bool terminal = false, trigger = false; };
+struct Symbol { int group = 0, index = 0; int64_t entity = -1; };   // entity: packed (group<<32 | index) of the bound agent
+struct Node {
+    int op = OP_NULL; std::vector<int> raw;
+    std::vector<int> related;                 // EventNode::related_symbols (a std::set ordered by address = by number)
+    std::vector<std::pair<int, int>> infer;   // EventNode::infer_map in key order; the first insertion of a key wins
+};
+struct Rule {
+    int on = 0; std::vector<int> recv; std::vector<float> val; bool terminal = false, trigger = false;
+    std::vector<int> input_syms, infer_obj;   // RewardRule::input_symbols / infer_obj (RewardEngine.cc:155-189); -1 = none
+};
 struct Pending { int g, i, act; };
 
 const int EMPTY = -1, WALL = -2;
@@ -254,11 +264,38 @@ int env_reset(void *game) {
     for (int i = 0; i < e.w; i++) { e.add_wall(i, 0); e.add_wall(i, e.h - 1); }
     for (int i = 0; i < e.h; i++) { e.add_wall(0, i); e.add_wall(e.w - 1, i); }
     for (auto &g : e.groups) g.clear();
-    for (auto &r : e.rules) {  // accepted rule shapes only (see header)
-        const Node &on = e.nodes[r.on];
-        if (!(on.op == OP_ATTACK || on.op == OP_KILL || on.op == OP_COLLIDE)) fatal("reward rule event outside the hot-path scope");
-        if (e.symbols[on.raw[0]].index != -1 || e.symbols[on.raw[1]].index != -1) fatal("only 'any' symbols are supported");
-        for (int s : r.recv) if (s != on.raw[0] && s != on.raw[1]) fatal("receiver must take part in the event");
+    // GridWorld::init_reward_description (RewardEngine.cc:105-214): related symbols, inference pairs, DFS order
+    std::function<void(Node &)> collect = [&](Node &n) {
+        n.related.clear(); n.infer.clear();
+        auto add_sym = [&](int s) { if (std::find(n.related.begin(), n.related.end(), s) == n.related.end()) n.related.push_back(s); };
+        auto add_inf = [&](std::pair<int, int> p) { for (auto &q : n.infer) if (q.first == p.first) return; n.infer.push_back(p); };
+        switch (n.op) {
+            case OP_AND: case OP_OR: case OP_NOT:
+                for (size_t k = 0; k < (n.op == OP_NOT ? 1u : 2u); k++) {
+                    Node &c = e.nodes[n.raw[k]];
+                    collect(c);
+                    for (int s2 : c.related) add_sym(s2);
+                    for (auto &p : c.infer) add_inf(p);
+                }
+                break;
+            case OP_KILL: case OP_COLLIDE: case OP_ATTACK: add_sym(n.raw[0]); add_sym(n.raw[1]); add_inf({n.raw[0], n.raw[1]}); break;
+            case OP_AT: case OP_IN: case OP_DIE: add_sym(n.raw[0]); break;
+            default: fatal("reward rule event outside the hot-path scope (align / in_a_line)");
+        }
+        std::sort(n.related.begin(), n.related.end());
+        std::sort(n.infer.begin(), n.infer.end());
+    };
+    for (auto &r : e.rules) {
+        Node &on = e.nodes[r.on];
+        collect(on);
+        r.input_syms.clear(); r.infer_obj.clear();
+        std::vector<int> added;
+        auto has = [&](int s2) { return std::find(added.begin(), added.end(), s2) != added.end(); };
+        for (int s2 : on.related) {           // first pass: symbols whose object can be inferred
+            if (has(s2)) continue;
+            for (auto &p : on.infer) if (p.first == s2) { r.input_syms.push_back(s2); r.infer_obj.push_back(p.second); added.push_back(s2); added.push_back(p.second); break; }
+        }
+        for (int s2 : on.related) if (!has(s2)) { r.input_syms.push_back(s2); r.infer_obj.push_back(-1); }
     }
     return 0;
 }
@@ -445,26 +482,82 @@ int env_step(void *game, int *done) {
     };
     for (auto &b : e.move_sep) run(b);
     run(e.move_bound);
-    // reward rules (GridWorld.cc:681-692, RewardEngine.cc:216-443) for Event(a, op, b), a/b = 'any'
+    // reward rules: GridWorld::calc_reward / calc_rule / calc_event_node (GridWorld.cc:681-692, RewardEngine.cc:216-443),
+    // the recursive search over symbol bindings, literally
+    std::vector<std::vector<char>> involved(e.groups.size());
+    for (size_t g = 0; g < e.groups.size(); g++) involved[g].assign(e.groups[g].size(), 0);
+    auto ref = [](int g, int i) { return ((int64_t)g << 32) | (uint32_t)i; };
+    auto bind = [&](int sym, int64_t ent) {   // AgentSymbol::bind_with_check (RewardEngine.cc:15-24)
+        Symbol &sy = e.symbols[sym];
+        int g = (int)(ent >> 32), i = (int)(uint32_t)ent;
+        if (sy.group != g) return false;
+        if (sy.index != -1 && sy.index != i) return false;
+        sy.entity = ent;
+        return true;
+    };
+    std::function<bool(const Node &)> holds = [&](const Node &n) -> bool {
+        switch (n.op) {
+            case OP_ATTACK: case OP_KILL: case OP_COLLIDE: {
+                const Symbol &s0 = e.symbols[n.raw[0]];
+                int64_t obj = e.symbols[n.raw[1]].entity;
+                if (s0.index == -2) {
+                    Group &G = e.groups[s0.group];
+                    for (int i = 0; i < G.size(); i++) if (!(G.last_op[i] == n.op && G.op_obj[i] == obj)) return false;
+                    return true;
+                }
+                Group &G = e.groups[(int)(s0.entity >> 32)]; int i = (int)(uint32_t)s0.entity;
+                return G.last_op[i] == n.op && G.op_obj[i] == obj;
+            }
+            case OP_DIE: case OP_AT: case OP_IN: {
+                const Symbol &s0 = e.symbols[n.raw[0]];
+                auto one = [&](Group &G, int i) {
+                    if (n.op == OP_DIE) return (bool)G.dead[i];
+                    if (n.op == OP_AT) return G.x[i] == n.raw[1] && G.y[i] == n.raw[2];
+                    return G.x[i] > n.raw[1] && G.x[i] < n.raw[3] && G.y[i] > n.raw[2] && G.y[i] < n.raw[4];
+                };
+                if (s0.index == -2) { Group &G = e.groups[s0.group]; for (int i = 0; i < G.size(); i++) if (!one(G, i)) return false; return true; }
+                return one(e.groups[(int)(s0.entity >> 32)], (int)(uint32_t)s0.entity);
+            }
+            case OP_AND: return holds(e.nodes[n.raw[0]]) && holds(e.nodes[n.raw[1]]);
+            case OP_OR: return holds(e.nodes[n.raw[0]]) || holds(e.nodes[n.raw[1]]);
+            case OP_NOT: return !holds(e.nodes[n.raw[0]]);
+        }
+        return false;
+    };
     for (Rule &r : e.rules) {
         r.trigger = false;
-        const Node &on = e.nodes[r.on];
-        const Symbol &sa = e.symbols[on.raw[0]], &sb = e.symbols[on.raw[1]];
-        Group &A = e.groups[sa.group];
-        // One symbol used as subject AND object: binding the object overwrites the subject's entity
-        // (AgentSymbol::bind_with_check, RewardEngine.cc:17-24 via :405-408), so the event is tested on the target
-        // against itself and can never hold (nobody attacks, kills or collides with itself).
-        if (on.raw[0] == on.raw[1]) continue;
-        for (int i = 0; i < A.size(); i++) {
-            if (A.op_obj[i] < 0) continue;
-            int tg = (int)(A.op_obj[i] >> 32), ti = (int)(uint32_t)A.op_obj[i];
-            if (tg != sb.group || A.last_op[i] != on.op) continue;
-            r.trigger = true;
-            for (size_t k = 0; k < r.recv.size(); k++) {
-                if (r.recv[k] == on.raw[0]) A.next_reward[i] += r.val[k];
-                else e.groups[tg].next_reward[ti] += r.val[k];
+        std::function<void(size_t)> search = [&](size_t now) {
+            if (now == r.input_syms.size()) {
+                if (!holds(e.nodes[r.on])) return;
+                r.trigger = true;
+                for (size_t k = 0; k < r.recv.size(); k++) {
+                    Symbol &sy = e.symbols[r.recv[k]];
+                    if (sy.index == -2) e.groups[sy.group].reward += r.val[k];
+                    else e.groups[(int)(sy.entity >> 32)].next_reward[(uint32_t)sy.entity] += r.val[k];
+                }
+                return;
             }
-        }
+            Symbol &sy = e.symbols[r.input_syms[now]];
+            const int inf = r.infer_obj[now];
+            Group &G = e.groups[sy.group];
+            if (sy.index == -1) {
+                for (int i = 0; i < G.size(); i++) {
+                    sy.entity = ref(sy.group, i);
+                    if (involved[sy.group][i]) continue;
+                    involved[sy.group][i] = 1;
+                    if (inf >= 0) { if (G.op_obj[i] >= 0 && bind(inf, G.op_obj[i])) search(now + 1); }
+                    else search(now + 1);
+                    involved[sy.group][i] = 0;
+                }
+            } else if (sy.index == -2) {
+                if (inf >= 0) { if (G.size() > 0 && G.op_obj[0] >= 0 && bind(inf, G.op_obj[0])) search(now + 1); }
+                else search(now + 1);
+            } else if (sy.index < G.size()) {
+                sy.entity = ref(sy.group, sy.index);
+                if (inf >= 0 && G.op_obj[sy.index] >= 0 && bind(inf, G.op_obj[sy.index])) search(now + 1);
+            }
+        };
+        search(0);
     }
     // done (GridWorld.cc:619-630)
     int live = 0;

@@ -123,7 +123,34 @@ def custom_trans(map_size):
     return cfg
 
 
-CUSTOM = {"trans": custom_trans, "tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
+def custom_duo(map_size):
+    """Event(a, p, c) & Event(b, p, c) in every supported arrangement: both subjects in one group with different values
+    (the per-agent float adds interleave by agent order), the second subject declared first, subjects in two groups,
+    the object paid, different predicates for the two subjects, in-group targets"""
+    cfg = gw.Config()
+    cfg.set({"map_width": map_size, "map_height": map_size, "embedding_size": 3})
+    deer = cfg.register_agent_type("deer", dict(width=1, length=1, hp=6, speed=1, view_range=gw.CircleRange(2), attack_range=gw.CircleRange(0),
+                                                step_recover=0.2, kill_supply=3, step_reward=0.0625))
+    tiger = cfg.register_agent_type("tiger", dict(width=1, length=1, hp=10, speed=1, view_range=gw.CircleRange(4), attack_range=gw.CircleRange(1.5),
+                                                  damage=1, step_recover=-0.1, step_reward=-0.03125, attack_penalty=-0.1))
+    wolf = cfg.register_agent_type("wolf", dict(width=2, length=1, hp=7, speed=2, view_range=gw.CircleRange(3), attack_range=gw.CircleRange(2),
+                                                damage=1.5, attack_in_group=1, kill_reward=1.5))
+    gd, gt, gwf = cfg.add_group(deer), cfg.add_group(tiger), cfg.add_group(wolf)
+    b0 = gw.AgentSymbol(gt, "any")      # declared before its partner: it is the outer loop of the search
+    a, b, c = gw.AgentSymbol(gt, "any"), gw.AgentSymbol(gt, "any"), gw.AgentSymbol(gd, "any")
+    w1, w2 = gw.AgentSymbol(gwf, "any"), gw.AgentSymbol(gwf, "any")
+    ev = gw.Event
+    cfg.add_reward_rule(ev(a, "attack", c) & ev(b, "attack", c), receiver=[a, b], value=[1, 0.3])
+    cfg.add_reward_rule(ev(a, "attack", c) & ev(b0, "attack", c), receiver=[a, b0], value=[0.7, -0.15])
+    cfg.add_reward_rule(ev(a, "attack", c) & ev(w1, "attack", c), receiver=[w1, a, c], value=[0.45, 0.11, -0.6])
+    cfg.add_reward_rule(ev(w1, "kill", c) & ev(a, "attack", c), receiver=[a, w1, a], value=[2.2, 0.9, -0.05])
+    cfg.add_reward_rule(ev(w1, "attack", w2) & ev(a, "attack", w2), receiver=[w1, a], value=[0.35, 0.21])
+    cfg.add_reward_rule(ev(a, "attack", c) & ev(b, "kill", c), receiver=[b, a], value=[1.3, 0.17])
+    cfg.add_reward_rule(ev(w1, "attack", c), receiver=[w1], value=[0.019])
+    return cfg
+
+
+CUSTOM = {"duo": custom_duo, "trans": custom_trans, "tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
 
 
 class Scenario(object):
@@ -234,7 +261,8 @@ _ATTACK_COUNT = {0: 0, 1: 4, 1.5: 8, 2: 12, 2.5: 20}
 
 def fuzz_scenario(seed):
     """a random game inside the engine's scope: 2-4 groups, random body sizes / ranges / hp / damage / recover /
-    kill_supply / in-group attack, random rules (subject and object receivers, attack | kill | collide), random map
+    kill_supply / in-group attack, random rules (subject and object receivers, attack | kill | collide, pairs of events
+    joined by `&`), random map
     shape, walls, densities, clear_dead cadence and non-acting groups -- for differential testing"""
     rs = np.random.RandomState(seed)
     G = int(rs.choice([2, 2, 2, 3, 3, 4]))
@@ -267,6 +295,14 @@ def fuzz_scenario(seed):
         if a == b and "s" in who and "o" in who:
             who = "s"
         rules.append((a, op, b, who, [frac(-1, 1) for _ in who]))
+    pair_rules = []
+    for _ in range(int(rs.choice([0, 0, 1, 2]))):
+        a, b, c = int(rs.randint(G)), int(rs.randint(G)), int(rs.randint(G))
+        who = str(rs.choice(["ab", "ba", "a", "b", "abc", "cab", "aab", "c"]))
+        if c in (a, b):
+            who = who.replace("c", "") or "a"          # the object is paid only from another group (engine scope)
+        pair_rules.append((a, b, str(rs.choice(["attack", "attack", "kill"])), str(rs.choice(["attack", "attack", "kill"])), c,
+                           who, [frac(-1, 1) for _ in who], bool(rs.rand() < 0.5)))
 
     def make():
         cfg = gw.Config()
@@ -280,6 +316,14 @@ def fuzz_scenario(seed):
         for a, op, b, who, vals in rules:
             sa, sb = gw.AgentSymbol(hs[a], "any"), gw.AgentSymbol(hs[b], "any")
             cfg.add_reward_rule(gw.Event(sa, op, sb), receiver=[{"s": sa, "o": sb}[c] for c in who], value=vals)
+        for a, b, opa, opb, c, who, vals, b_first in pair_rules:
+            if b_first:
+                sb, sa = gw.AgentSymbol(hs[b], "any"), gw.AgentSymbol(hs[a], "any")
+            else:
+                sa, sb = gw.AgentSymbol(hs[a], "any"), gw.AgentSymbol(hs[b], "any")
+            sc_ = gw.AgentSymbol(hs[c], "any")
+            cfg.add_reward_rule(gw.Event(sa, opa, sc_) & gw.Event(sb, opb, sc_),
+                                receiver=[{"a": sa, "b": sb, "c": sc_}[k] for k in who], value=vals)
         return cfg
 
     area = (w - 2) * (h - 2)
@@ -376,6 +420,10 @@ def scenarios():
                  over={"small": {"hp": 4, "damage": 3}},
                  events={3: [("add", 0, "random", {"n": 1800})], 6: [("add", 1, "random", {"n": 1500})],
                          9: [("add", 0, "fill", {"pos": (2, 2), "size": (6, 60)})]}),
+        Scenario("double_attack", "double_attack", 30, place=[rnd(0, 120), rnd(1, 200)], walls=20, steps=25, action_seed=31),
+        Scenario("duo", ("duo", 34), 0, place=[rnd(0, 150), rnd(1, 260), rnd(2, 60)], walls=30, steps=25, action_seed=32),
+        Scenario("duo_dense", ("duo", 26), 0, place=[rnd(0, 80), rnd(1, 300), rnd(2, 30)], steps=20, action_seed=34),
+        Scenario("duo_large", ("duo", 120), 0, place=[rnd(0, 2500), rnd(1, 3500), rnd(2, 800)], steps=8, action_seed=33),
         Scenario("battle_one_side", "battle", 12, place=[rnd(0, 60), rnd(1, 3)], steps=40, action_seed=14,
                  over={"small": {"damage": 12}}),
     ]
