@@ -32,6 +32,11 @@ constexpr int OP_KILL = 3, OP_COLLIDE = 6, OP_ATTACK = 7, OP_NULL = 11;
 
 constexpr int RANK_INF = 0x7FFFFFFF;    // "never dies in the attack phase"
 constexpr unsigned MV_FAIL = 0xFFFFFFFFu, MV_OK = 0xFFFFFFFEu;  // move status; anything else = "depends on ref"
+// generic move resolution with can_absorb types: the mover bumped into a goal that is already taken (nothing happens),
+// or is itself taken in by goal `ref` (it dies and leaves the map at its turn): 0x80000000 | ref, ref < 2^30
+constexpr unsigned MV_SILENT = 0xFFFFFFFDu, MV_TAKEN_BIT = 0x80000000u;
+__host__ __device__ inline bool mv_taken(unsigned s) { return (s >> 30) == 2u; }
+__host__ __device__ inline int mv_taken_by(unsigned s) { return (int)(s & 0x3FFFFFFFu); }
 constexpr unsigned long long CLAIM_NONE = ~0ull;
 
 __host__ __device__ inline int ref_pack(int g, int i) { return (g << REF_SHIFT) | i; }
@@ -42,6 +47,7 @@ __host__ __device__ inline int ref_index(int r) { return r & REF_MASK; }
 struct TypeDev {
     float hp, damage, step_recover, kill_supply, kill_reward, dead_penalty, attack_penalty, step_reward;
     int attack_in_group;
+    int can_absorb;              // a "goal": the first mover that bumps into it is taken in (Map.cc:341-350)
     int bw, bl;                  // body width (x) and length (y) in cells; the agent's position is its top-left cell
     int n_move, n_attack;        // action layout: [0, n_move) moves, [n_move, n_move + n_attack) attacks
     int move_off, attack_off;    // offsets into WorldView::delta (int2 {dx,dy} per action payload)
@@ -57,6 +63,7 @@ struct GroupDev {
     int *x, *y, *id, *last_action, *op_obj, *pend;
     float *hp, *next_reward, *last_reward;
     unsigned char *dead, *last_op;
+    unsigned char *absorbed;     // can_absorb types: this goal has taken a mover in (GridWorld.h:191-192)
     unsigned *key;               // attack: sequence number -> rank after the shuffle; move: order key
     int *drank_a, *drank_b;      // attack fixed point: rank at which the agent dies (ping-pong)
     unsigned *mv;                // move resolution status / dependency
@@ -74,11 +81,14 @@ struct WorldView {
     TypeDev type[MAXG];
     GroupDev grp[MAXG];
     int any_kill_supply;
-    int any_multicell;           // some group has a body larger than one cell: generic move resolution
+    int any_multicell;           // some group has a body larger than one cell (or can absorb): generic move resolution
+    int any_absorb;              // some type is can_absorb
     int large_map, bandwidth;    // reference large_map_mode striping (GridWorld.cc:75-85, 407-425)
 };
 
-constexpr int CTR_CHANGED = 0, CTR_ATTACK = 1, CTR_DEAD = 2, CTR_PACK_OVERFLOW = 12, CTR_TRIGGER = 16, CTR_TOTAL = 64;
+constexpr int CTR_CHANGED = 0, CTR_ATTACK = 1, CTR_DEAD = 2, CTR_PACK_OVERFLOW = 12, CTR_TRIGGER = 16, CTR_TRIGGER_END = 64;
+// movers taken in by goals, per group: dead, but not counted in the reference's dead_ct (Map.cc:345); cleared with CTR_DEAD
+constexpr int CTR_TAKEN = 64, CTR_UNSUPPORTED = 72, CTR_TOTAL = 80;
 // single-sync step: fixed-point rounds are launched optimistically and gated on the device
 constexpr int CTR_NEED_HOST = 10;   // 0 = the step ran through; 1 / 2 = attack / move rounds ran out, host continues
 constexpr int CTR_PHASE_DONE = 11;  // the current fixed point has converged: further rounds of this phase return at once

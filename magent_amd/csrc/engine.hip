@@ -284,7 +284,6 @@ void Env::register_agent_type(const char *name, int n, const char **keys, float 
         } else fatal("invalid agent config in AgentType::AgentType : %s", keys[i]);
     }
     if (t.width < 1 || t.length < 1 || t.width > 16 || t.length > 16) fatal("agent type %s: body %dx%d out of range", name, t.width, t.length);
-    if (t.can_absorb) fatal("agent type %s: can_absorb is outside the hot-path scope", name);
     // A type registered without an attack range keeps the defaults attack_radius = 0, attack_angle = 0 and gets
     // SectorRange(0, 0): height = (int)(0 + 0.5) = 0 rows, i.e. no attack action at all (Range.h:106-139,
     // AgentType.cc:95-102; examples/train_trans.py).  Real sectors stay outside the hot-path scope.
@@ -418,7 +417,7 @@ void Env::free_group(HostGroup &g) {
     GroupDev &c = g.cur, &a = g.alt;
     dfree(c.x); dfree(c.y); dfree(c.id); dfree(c.last_action); dfree(c.op_obj); dfree(c.pend); dfree(c.hp);
     dfree(c.next_reward); dfree(c.last_reward); dfree(c.dead); dfree(c.last_op); dfree(c.key); dfree(c.drank_a);
-    dfree(c.drank_b); dfree(c.mv); dfree(c.hits);
+    dfree(c.drank_b); dfree(c.mv); dfree(c.hits); dfree(c.absorbed); dfree(a.absorbed);
     dfree(a.x); dfree(a.y); dfree(a.id); dfree(a.last_action); dfree(a.hp); dfree(a.next_reward); dfree(a.last_reward);
     g.cap = 0; g.n = 0;
 }
@@ -443,6 +442,7 @@ void Env::ensure_capacity(HostGroup &g, int need) {
     regrow(c.last_reward, n, ncap); regrow(c.dead, n, ncap); regrow(c.last_op, n, ncap); regrow(c.key, n, ncap);
     regrow(c.drank_a, n, ncap); regrow(c.drank_b, n, ncap); regrow(c.mv, n, ncap); regrow(c.hits, n, ncap);
     HIP_OK(hipMemset(c.hits, 0, sizeof(int) * ncap));
+    regrow(c.absorbed, n, ncap); regrow(a.absorbed, 0, ncap);
     regrow(a.x, 0, ncap); regrow(a.y, 0, ncap); regrow(a.id, 0, ncap); regrow(a.last_action, 0, ncap);
     regrow(a.hp, 0, ncap); regrow(a.next_reward, 0, ncap); regrow(a.last_reward, 0, ncap);
     g.cap = (int)ncap;
@@ -455,6 +455,7 @@ WorldView Env::view() const {
     W.occ = d_occ; W.viewcell = d_viewcell; W.claim = d_claim; W.delta = d_delta; W.mask = d_mask; W.counters = d_counters;
     W.any_kill_supply = any_kill_supply;
     W.any_multicell = any_multicell;
+    W.any_absorb = any_absorb;
     W.large_map = large_map_mode; W.bandwidth = bandwidth;
     for (int g = 0; g < W.G; g++) {
         W.type[g] = groups[g].tdev;
@@ -514,7 +515,7 @@ void Env::reset() {
     // per-type constant tables (action deltas, view masks) for the groups of this game
     std::vector<int2> delta;
     std::vector<unsigned char> mask;
-    any_kill_supply = 0; any_multicell = 0;
+    any_kill_supply = 0; any_multicell = 0; any_absorb = 0;
     int total_attack = 0;
     for (auto &g : groups) {
         HostType &t = *g.type;
@@ -523,7 +524,9 @@ void Env::reset() {
         d.kill_reward = t.kill_reward; d.dead_penalty = t.dead_penalty; d.attack_penalty = t.attack_penalty;
         d.step_reward = t.step_reward; d.attack_in_group = t.attack_in_group;
         d.bw = t.width; d.bl = t.length;
+        d.can_absorb = t.can_absorb;
         if (t.width * t.length > 1) any_multicell = 1;
+        if (t.can_absorb) any_absorb = any_multicell = 1;   // goals: the generic move resolution knows how movers are taken in
         d.n_move = t.move.count; d.n_attack = t.attack.count;
         d.move_off = (int)delta.size();
         for (int k = 0; k < t.move.count; k++) delta.push_back(make_int2(t.move.dx[k], t.move.dy[k]));
@@ -537,7 +540,7 @@ void Env::reset() {
         g.tdev = d;
         if (t.kill_supply != 0) any_kill_supply = 1;
         total_attack += t.attack.count;
-        g.n = 0; g.group_reward = 0; g.acted = false; g.h_dead = 0;
+        g.n = 0; g.group_reward = 0; g.acted = false; g.h_dead = 0; g.h_taken = 0;
     }
     // most hits one target can receive: attack offsets of every group allowed to attack it
     attack_kmax = 1;
@@ -652,6 +655,7 @@ void Env::add_agents(int group, int n, const char *method, const int *px, const 
         up(c.op_obj, std::vector<int>(k, -1));
         up(c.pend, std::vector<int>(k, PEND_NONE));
         up(c.dead, std::vector<unsigned char>(k, 0));
+        up(c.absorbed, std::vector<unsigned char>(k, 0));
         up(c.last_op, std::vector<unsigned char>(k, (unsigned char)OP_NULL));
         G.n += k;
         tables_valid = false;
@@ -715,14 +719,16 @@ void Env::observe_device(int g, float *view, float *feat) {
     plan_render(g, R, P, view, feat);
     if (minimap_mode) {
         size_t need = (size_t)W.G * R.VH * R.VW;
-        if (need > mini_cap) {   // the histogram buffer is kept zero between uses (k_minimap_norm zeroes what it reads)
-            grow(d_mini, mini_cap, need, stream);
+        const size_t need_counts = need + MAXG;      // + the per-group count of agents left out (k_minimap, skip mode)
+        if (need_counts > mini_cap) {   // the histogram buffer is kept zero between uses (k_minimap_norm zeroes what it reads)
+            grow(d_mini, mini_cap, need_counts, stream);
             HIP_OK(hipMemsetAsync(d_mini, 0, sizeof(int) * mini_cap, stream));
         }
         grow(d_minif, minif_cap, need, stream);
         R.mini = d_minif;
         long long pop = 0;
         for (auto &gr : groups) pop = pop * 1000003ll + gr.n;
+        pop = pop * 2 + (G.type->can_absorb ? 1 : 0);   // the observing type decides whether absorbed agents count
         if (!(mini_valid && mini_vh == R.VH && mini_vw == R.VW && mini_pop == pop)) {
             ProfScope p(*this, "minimap");
             launch_minimap(stream, W, R, d_mini, d_minif);
@@ -1010,9 +1016,11 @@ void Env::step_end(int *done) {
     int live = 0;
     for (size_t g = 0; g < groups.size(); g++) {
         groups[g].h_dead = c[CTR_DEAD + g];
+        groups[g].h_taken = c[CTR_TAKEN + g];
         groups[g].acted = false;
         if (groups[g].n - groups[g].h_dead > 0) live++;
     }
+    if (c[CTR_UNSUPPORTED]) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
     if (c[CTR_PACK_OVERFLOW]) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
     *done = live < (int)groups.size();   // GridWorld.cc:619-624
     for (size_t k = 0; k < rules.size(); k++) if (c[CTR_TRIGGER + k] && rules[k].terminal) *done = 1;
@@ -1051,19 +1059,20 @@ void Env::clear_dead() {
     for (size_t g = 0; g < groups.size(); g++) {
         HostGroup &G = groups[g];
         G.group_reward = 0;
-        if (G.h_dead > 0) {
+        if (G.h_dead + G.h_taken > 0) {
             int nb = (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
             grow(d_sums, sums_cap, (size_t)nb, stream);
             GroupDev D = G.cur;   // survivors: double-buffered arrays go to alt, the rest is reset in place
             D.x = G.alt.x; D.y = G.alt.y; D.id = G.alt.id; D.hp = G.alt.hp; D.last_action = G.alt.last_action;
-            D.last_reward = G.alt.last_reward; D.next_reward = G.alt.next_reward;
-            const int new_n = G.n - G.h_dead;
+            D.last_reward = G.alt.last_reward; D.next_reward = G.alt.next_reward; D.absorbed = G.alt.absorbed;
+            const int new_n = G.n - G.h_dead - G.h_taken;
             launch_compact(stream, W, (int)g, D, new_n, d_sums);
             std::swap(G.cur.x, G.alt.x); std::swap(G.cur.y, G.alt.y); std::swap(G.cur.id, G.alt.id);
             std::swap(G.cur.hp, G.alt.hp); std::swap(G.cur.last_action, G.alt.last_action);
             std::swap(G.cur.last_reward, G.alt.last_reward); std::swap(G.cur.next_reward, G.alt.next_reward);
+            std::swap(G.cur.absorbed, G.alt.absorbed);
             G.n = new_n;
-            G.h_dead = 0;
+            G.h_dead = 0; G.h_taken = 0;
             any = true;
         } else {
             launch_init_reward(stream, W, (int)g);
@@ -1158,13 +1167,16 @@ void Env::info_host(int g, const char *name, void *buf) {
         for (size_t i = 0; i < groups.size(); i++) {
             int n = groups[i].n;
             std::vector<int> xs(n), ys(n), ids(n);
+            std::vector<unsigned char> taken(n, 1);
             if (n) {
                 HIP_OK(hipMemcpy(xs.data(), groups[i].cur.x, sizeof(int) * n, hipMemcpyDeviceToHost));
                 HIP_OK(hipMemcpy(ys.data(), groups[i].cur.y, sizeof(int) * n, hipMemcpyDeviceToHost));
                 HIP_OK(hipMemcpy(ids.data(), groups[i].cur.id, sizeof(int) * n, hipMemcpyDeviceToHost));
+                if (groups[i].type->can_absorb) HIP_OK(hipMemcpy(taken.data(), groups[i].cur.absorbed, n, hipMemcpyDeviceToHost));
             }
             for (int j = 0; j < n; j++) {
                 if (xs[j] < x1 || xs[j] > x2 || ys[j] < y1 || ys[j] > y2) continue;
+                if (!taken[j]) continue;   // a goal shows once it has taken a mover in (GridWorld.cc:821-822)
                 ib[4 * ct] = ids[j]; ib[4 * ct + 1] = xs[j]; ib[4 * ct + 2] = ys[j]; ib[4 * ct + 3] = (int)i;
                 ct++;
             }
@@ -1224,7 +1236,13 @@ void Env::render() {
         for (size_t c = 0; c < h_occ.size(); c++) if (h_occ[c] == OCC_WALL) fout << (c % width) << " " << (c / width) << std::endl;
     }
     size_t n_agents = 0;
-    for (auto &g : groups) n_agents += g.n;
+    std::vector<std::vector<unsigned char>> taken(groups.size());
+    for (size_t i = 0; i < groups.size(); i++) {   // goals are drawn once they have taken a mover in (RenderGenerator.cc:128-141)
+        taken[i].assign(groups[i].n, 1);
+        if (groups[i].type->can_absorb && groups[i].n)
+            HIP_OK(hipMemcpy(taken[i].data(), groups[i].cur.absorbed, groups[i].n, hipMemcpyDeviceToHost));
+        for (unsigned char t : taken[i]) n_agents += t;
+    }
     fout << "F " << n_agents << " " << attack_events.size() << " " << 0 << std::endl;
     for (size_t i = 0; i < groups.size(); i++) {
         const int n = groups[i].n;
@@ -1237,6 +1255,7 @@ void Env::render() {
         HIP_OK(hipMemcpy(hp.data(), groups[i].cur.hp, sizeof(float) * n, hipMemcpyDeviceToHost));
         const float type_hp = groups[i].type->hp;
         for (int j = 0; j < n; j++) {
+            if (!taken[i][j]) continue;
             int pct = std::min(std::max(0, int(100 * hp[j] / type_hp)), 100);
             fout << ids[j] << " " << pct << " " << 270 << " " << xs[j] << " " << ys[j] << " " << i << std::endl;  // dir NORTH
         }

@@ -56,6 +56,7 @@ struct HostGroup {
     float group_reward = 0;
     bool acted = false;          // set_action seen since the last step
     int h_dead = 0;              // dead_ct as of the last step (GridWorld.h Group::dead_ct)
+    int h_taken = 0;             // movers taken in by goals: dead, but never counted in dead_ct (Map.cc:345)
 };
 
 struct HostSymbol { int group = 0, index = 0; };
@@ -178,7 +179,7 @@ private:
     std::vector<HostRule> rules;
     std::vector<RuleArgs> rule_args;
     bool rules_compiled = false;
-    int id_counter = 0, any_kill_supply = 0, any_multicell = 0, move_seq_base = 0, attack_kmax = 1;
+    int id_counter = 0, any_kill_supply = 0, any_multicell = 0, any_absorb = 0, move_seq_base = 0, attack_kmax = 1;
 
     // device state
     bool device_ready = false, tables_valid = false, paint_valid = false;

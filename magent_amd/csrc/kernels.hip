@@ -61,7 +61,7 @@ __global__ void k_gate(int *counters, int fail_code, int force) {
 // per-step counters back to zero after the end-of-step readback (dead_ct lives until clear_dead)
 __global__ void k_step_reset(int *counters) {
     if (threadIdx.x == 0) counters[CTR_ATTACK] = 0;
-    for (int k = CTR_TRIGGER + threadIdx.x; k < CTR_TOTAL; k += blockDim.x) counters[k] = 0;
+    for (int k = CTR_TRIGGER + threadIdx.x; k < CTR_TRIGGER_END; k += blockDim.x) counters[k] = 0;
 }
 __global__ void k_set_rng(int *counters, unsigned x) { if (threadIdx.x == 0) counters[CTR_RNG] = (int)x; }
 
@@ -112,7 +112,9 @@ __global__ void __launch_bounds__(256) k_paint(WorldView W, const GroupDev *gtab
 // counts[j][cell] = number of agents of group j whose (x / scale_w, y / scale_h) is cell (GridWorld.cc:341-352;
 // dead-but-not-cleared agents are counted, as in the reference).  LDS int atomics per block, then one global
 // atomic per non-empty bin.  blockIdx.y = group.
-__global__ void __launch_bounds__(256) k_minimap(WorldView W, RenderArgs R, int *counts) {
+// `skip`: the observing type is can_absorb -- absorbed agents are left out and counted in left_out[j], which the
+// normalisation takes off the divisor (GridWorld.cc:343-347: the OBSERVING group's type decides).
+__global__ void __launch_bounds__(256) k_minimap(WorldView W, RenderArgs R, int *counts, int *left_out, int skip) {
     extern __shared__ int s_hist[];
     const int VHW = R.VH * R.VW, j = blockIdx.y;
     const GroupDev G = W.grp[j];
@@ -120,6 +122,7 @@ __global__ void __launch_bounds__(256) k_minimap(WorldView W, RenderArgs R, int 
     for (int k = threadIdx.x; k < VHW; k += blockDim.x) s_hist[k] = 0;
     __syncthreads();
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < G.n; i += gridDim.x * blockDim.x) {
+        if (skip && G.absorbed[i]) { atomicAdd(&left_out[j], 1); continue; }
         int cx = G.x[i] / R.scale_w, cy = G.y[i] / R.scale_h;
         atomicAdd(&s_hist[cy * R.VW + cx], 1);
     }
@@ -131,11 +134,11 @@ __global__ void __launch_bounds__(256) k_minimap(WorldView W, RenderArgs R, int 
 // ------------------------------------------------------------------------------------------------ minimap normalise
 // mini[j][cell] = float(count) / float(total_j) exactly as the reference (GridWorld.cc:350,356): float ++ saturates
 // at 2^24; an empty group divides 0 by 0 and the x86 default NaN the reference then holds is 0xFFC00000.
-__global__ void __launch_bounds__(256) k_minimap_norm(RenderArgs R, int G, int *counts, float *mini) {
+__global__ void __launch_bounds__(256) k_minimap_norm(RenderArgs R, int G, int *counts, float *mini, const int *left_out, int skip) {
     const int VHW = R.VH * R.VW;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= G * VHW) return;
-    int tot = R.totals[k / VHW];
+    int tot = R.totals[k / VHW] - (skip ? left_out[k / VHW] : 0);
     mini[k] = tot == 0 ? __int_as_float(0xFFC00000) : __fdiv_rn((float)min(counts[k], 1 << 24), (float)(unsigned)tot);
     counts[k] = 0;   // the next histogram starts from zero (the buffer is zeroed when it is allocated)
 }
@@ -935,7 +938,35 @@ struct MoveProbe {
     int blocker;      // first occupant Map::get_collide would meet (x outer, y inner), -1 if none
 };
 
-template <bool WANT_BLOCKER>
+// every move candidate (other than `self`) with a lower key whose target rectangle covers cell (cx, cy), found by
+// pulling: f(packed ref, move status) -> true stops the search
+template <class F>
+__device__ __forceinline__ void for_each_entrant(const WorldView &W, int cx, int cy, unsigned key, int self, F f) {
+    for (int ga = 0; ga < W.G; ga++) {
+        const TypeDev TA = W.type[ga];
+        const GroupDev A = W.grp[ga];
+        for (int k = 0; k < TA.n_move; k++) {
+            const int2 d = W.delta[TA.move_off + k];
+            if ((d.x | d.y) == 0) continue;
+            for (int ax = 0; ax < TA.bw; ax++)
+                for (int ay = 0; ay < TA.bl; ay++) {
+                    const int px = cx - d.x - ax, py = cy - d.y - ay;
+                    if (px < 0 || py < 0 || px >= W.w || py >= W.h) continue;
+                    const int e = W.occ[py * W.w + px];
+                    if (e < 0 || e == self || ref_group(e) != ga) continue;
+                    const int ei = ref_index(e);
+                    if (A.x[ei] != px || A.y[ei] != py) continue;          // not that body's top-left cell
+                    if (A.pend[ei] != (PEND_MOVE | k) || A.drank_a[ei] < 0 || A.key[ei] >= key) continue;
+                    if (f(e, A.mv[ei])) return;
+                }
+        }
+    }
+}
+
+// MODE 0: is the move blocked? (stops at the first definite obstacle)   MODE 1: all moves are decided -- who is the
+// collide object?   MODE 2 (can_absorb types present): the outcome depends on WHICH agent is met first, so the scan
+// stops at the first cell that holds an agent or whose state is still unknown
+template <int MODE>
 __device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g, int i, int tgt_cell, const unsigned *wanted) {
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
@@ -960,40 +991,30 @@ __device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g,
                     const int oy = ot / W.w, ox = ot - oy * W.w;
                     const bool covers_again = cx >= ox && cx < ox + TO.bw && cy >= oy && cy < oy + TO.bl;
                     const unsigned st = O.mv[oi];
-                    if (!covers_again) { if (st == MV_OK) gone = true; else if (st != MV_FAIL) unknown = true; }
+                    if (mv_taken(st)) gone = true;                       // taken in by a goal: off the map
+                    else if (st == 0) unknown = !covers_again || W.any_absorb;
+                    else if (st == MV_OK && !covers_again) gone = true;
                 }
                 if (!gone) occupant = o;             // (possibly only "maybe": flagged by `unknown`)
             }
             // entrants with lower keys -- only where some OTHER candidate's target rectangle covers the cell at all
             // (wanted[c] counts the candidates whose rectangle covers c; mine is one of them)
-            if ((occupant < 0 || unknown) && wanted[c] > 1) {
-                for (int ga = 0; ga < W.G && occupant < 0; ga++) {
-                    const TypeDev TA = W.type[ga];
-                    const GroupDev A = W.grp[ga];
-                    for (int k = 0; k < TA.n_move && occupant < 0; k++) {
-                        const int2 d = W.delta[TA.move_off + k];
-                        if ((d.x | d.y) == 0) continue;
-                        for (int ax = 0; ax < TA.bw && occupant < 0; ax++)
-                            for (int ay = 0; ay < TA.bl; ay++) {
-                                const int px = cx - d.x - ax, py = cy - d.y - ay;
-                                if (px < 0 || py < 0 || px >= W.w || py >= W.h) continue;
-                                const int e = W.occ[py * W.w + px];
-                                if (e < 0 || e == self || ref_group(e) != ga) continue;
-                                const int ei = ref_index(e);
-                                if (A.x[ei] != px || A.y[ei] != py) continue;          // not that body's top-left cell
-                                if (A.pend[ei] != (PEND_MOVE | k) || A.drank_a[ei] < 0 || A.key[ei] >= key) continue;
-                                const unsigned st = A.mv[ei];
-                                if (st == MV_OK) { occupant = e; break; }
-                                if (st != MV_FAIL) unknown = true;
-                            }
-                    }
-                }
+            if ((occupant < 0 || unknown) && wanted[c] > 1)
+                for_each_entrant(W, cx, cy, key, self, [&](int e, unsigned st) {
+                    if (st == MV_OK) { occupant = e; return true; }
+                    if (st == 0) unknown = true;
+                    return false;
+                });
+            if (MODE == 2) {
+                if (unknown) { r.undecided = true; return r; }
+                if (occupant >= 0) { r.blocked = true; r.blocker = occupant; return r; }
+                continue;
             }
             if (occupant >= 0 && !unknown) {
                 r.blocked = true;
-                if (WANT_BLOCKER && r.blocker < 0) r.blocker = occupant;
+                if (MODE == 1 && r.blocker < 0) r.blocker = occupant;
             } else if (unknown) r.undecided = true;
-            if (!WANT_BLOCKER && r.blocked) return r;
+            if (MODE == 0 && r.blocked) return r;
         }
     return r;
 }
@@ -1013,6 +1034,8 @@ __global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted
         int nx = G.x[i] + d.x, ny = G.y[i] + d.y;
         if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + T.bw < W.w && ny + T.bl < W.h) t = ny * W.w + nx;
     }
+    // goals that move themselves are outside the engine's scope (no shipped game gives them actions): reported, not guessed
+    if (t >= 0 && T.can_absorb) { W.counters[CTR_UNSUPPORTED] = 1; t = -1; }
     G.drank_a[i] = t;
     G.mv[i] = t >= 0 ? 0u : MV_FAIL;      // 0 = undecided (the packed-dependency encoding of the 1x1 path is not used here)
     if (t >= 0) {
@@ -1029,10 +1052,48 @@ __global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev 
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
     const int t = G.drank_a[i];
-    if (t < 0 || G.mv[i] >= MV_OK) return;
-    MoveProbe r = move_probe<false>(W, gtab, g, i, t, wanted);
-    if (r.blocked) G.mv[i] = MV_FAIL;
-    else if (!r.undecided) G.mv[i] = MV_OK;
+    if (t < 0 || G.mv[i] != 0) return;
+    if (!W.any_absorb) {
+        MoveProbe r = move_probe<0>(W, gtab, g, i, t, wanted);
+        if (r.blocked) G.mv[i] = MV_FAIL;
+        else if (!r.undecided) G.mv[i] = MV_OK;
+        else if (set_flag) W.counters[CTR_CHANGED] = 1;
+        return;
+    }
+    // Map::do_move with goals (Map.cc:334-353): the collide object is the first agent met; a goal that is still free
+    // takes the mover in, a taken one is bumped without any effect
+    MoveProbe r = move_probe<2>(W, gtab, g, i, t, wanted);
+    unsigned st = 0;
+    if (!r.undecided) {
+        if (!r.blocked) st = MV_OK;
+        else if (r.blocker < 0 || !W.type[ref_group(r.blocker)].can_absorb) st = MV_FAIL;
+        else {
+            const int bg = ref_group(r.blocker), bi = ref_index(r.blocker);
+            const GroupDev B = gtab[bg];
+            if (B.absorbed[bi]) st = MV_SILENT;
+            else {   // free at phase start: is it still free at my turn?  (goals do not move: their cells are static)
+                const TypeDev TB = W.type[bg];
+                const unsigned key = G.key[i];
+                const int self = ref_pack(g, i), goal = r.blocker;
+                bool lost = false, unknown = false;
+                for (int bx = 0; bx < TB.bw && !lost; bx++)
+                    for (int by = 0; by < TB.bl && !lost; by++) {
+                        const int cx = B.x[bi] + bx, cy = B.y[bi] + by;
+                        const int ty = t / W.w, tx = t - ty * W.w;
+                        const bool mine = cx >= tx && cx < tx + W.type[g].bw && cy >= ty && cy < ty + W.type[g].bl;
+                        if (wanted[cy * W.w + cx] <= (mine ? 1u : 0u)) continue;   // no other candidate reaches this cell
+                        for_each_entrant(W, cx, cy, key, self, [&](int, unsigned s2) {
+                            if (mv_taken(s2) && mv_taken_by(s2) == goal) { lost = true; return true; }
+                            if (s2 == 0) unknown = true;
+                            return false;
+                        });
+                    }
+                if (lost) st = MV_SILENT;
+                else if (!unknown) st = MV_TAKEN_BIT | (unsigned)goal;
+            }
+        }
+    }
+    if (st) G.mv[i] = st;
     else if (set_flag) W.counters[CTR_CHANGED] = 1;
 }
 
@@ -1044,9 +1105,21 @@ __global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDe
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
     const int t = G.drank_a[i];
-    if (t < 0 || G.mv[i] != MV_FAIL) return;
-    MoveProbe r = move_probe<true>(W, gtab, g, i, t, wanted);
-    if (r.blocker >= 0) { G.last_op[i] = OP_COLLIDE; G.op_obj[i] = r.blocker; }
+    if (t < 0) return;
+    const unsigned st = G.mv[i];
+    if (st == MV_FAIL) {
+        MoveProbe r = move_probe<1>(W, gtab, g, i, t, wanted);
+        if (r.blocker >= 0) { G.last_op[i] = OP_COLLIDE; G.op_obj[i] = r.blocker; }
+    } else if (mv_taken(st)) {   // exactly one mover per goal ends up here
+        const int goal = mv_taken_by(st);
+        const GroupDev B = gtab[ref_group(goal)];
+        const int bi = ref_index(goal);
+        B.absorbed[bi] = 1;
+        B.hp[bi] = B.hp[bi] * 2;
+        G.dead[i] = 1;
+        G.last_op[i] = OP_COLLIDE; G.op_obj[i] = goal;
+        atomicAdd(&W.counters[CTR_TAKEN + g], 1);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_movg_vacate(WorldView W) {
@@ -1054,7 +1127,7 @@ __global__ void __launch_bounds__(256) k_movg_vacate(WorldView W) {
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n || G.drank_a[i] < 0 || G.mv[i] != MV_OK) return;
+    if (i >= G.n || G.drank_a[i] < 0 || !(G.mv[i] == MV_OK || mv_taken(G.mv[i]))) return;
     body_fill(W, G.x[i], G.y[i], W.type[g].bw, W.type[g].bl, OCC_EMPTY);
 }
 
@@ -1235,6 +1308,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_compact_c(WorldView W, int g, 
                [&](int i, int r) {
                    int x = G.x[i], y = G.y[i];
                    D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
+                   D.absorbed[r] = G.absorbed[i];
                    D.last_reward[r] = G.next_reward[i];
                    D.next_reward[r] = step_reward;
                    body_fill(W, x, y, bw, bl, ref_pack(g, r));
@@ -1250,6 +1324,7 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int 
                                 [&](int i, int r) {
                                     int x = G.x[i], y = G.y[i];
                                     D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
+                   D.absorbed[r] = G.absorbed[i];
                                     D.last_reward[r] = G.next_reward[i];
                                     D.next_reward[r] = step_reward;
                                     body_fill(W, x, y, bw, bl, ref_pack(g, r));
@@ -1257,13 +1332,13 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int 
                                 G.n, 0);
     // every read of the in-place arrays is done (solo_rank ends with a barrier): reset them for the survivors
     for (int r = threadIdx.x; r < alive; r += SOLO_THREADS) { D.dead[r] = 0; D.last_op[r] = OP_NULL; D.op_obj[r] = -1; D.pend[r] = PEND_NONE; }
-    if (threadIdx.x == 0) W.counters[CTR_DEAD + g] = 0;
+    if (threadIdx.x == 0) { W.counters[CTR_DEAD + g] = 0; W.counters[CTR_TAKEN + g] = 0; }
 }
 
 // the non-double-buffered per-agent state of the survivors
 __global__ void __launch_bounds__(256) k_compact_reset(GroupDev D, int n, int *dead_counter) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *dead_counter = 0;
+    if (i == 0) { dead_counter[0] = 0; dead_counter[CTR_TAKEN - CTR_DEAD] = 0; }
     if (i >= n) return;
     D.dead[i] = 0; D.last_op[i] = OP_NULL; D.op_obj[i] = -1; D.pend[i] = PEND_NONE;
 }
@@ -1283,25 +1358,29 @@ void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const
     int ncell = W.w * W.h;
     int blocks = (ncell + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    if (W.G <= 3) hipLaunchKernelGGL(k_paint<true>, dim3(blocks), dim3(256), 0, s, W, gtab, ttab);
+    if (W.G <= 3 && !W.any_absorb) hipLaunchKernelGGL(k_paint<true>, dim3(blocks), dim3(256), 0, s, W, gtab, ttab);
     else hipLaunchKernelGGL(k_paint<false>, dim3(blocks), dim3(256), 0, s, W, gtab, ttab);
 }
 
 void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts, float *mini) {
     int VHW = R.VH * R.VW;
+    const int skip = W.type[R.g].can_absorb;
+    int *left_out = counts;      // the first MAXG ints of the buffer; the histogram follows
+    counts += MAXG;
+    if (skip) (void)hipMemsetAsync(left_out, 0, sizeof(int) * MAXG, s);
     int mx = 1;
     for (int g = 0; g < W.G; g++) mx = W.grp[g].n > mx ? W.grp[g].n : mx;
     int bx = (mx + 255) / 256;
     if (bx > 512) bx = 512;
-    hipLaunchKernelGGL(k_minimap, dim3(bx, W.G), dim3(256), VHW * sizeof(int), s, W, R, counts);
-    hipLaunchKernelGGL(k_minimap_norm, dim3((W.G * VHW + 255) / 256), dim3(256), 0, s, R, W.G, counts, mini);
+    hipLaunchKernelGGL(k_minimap, dim3(bx, W.G), dim3(256), VHW * sizeof(int), s, W, R, counts, left_out, skip);
+    hipLaunchKernelGGL(k_minimap_norm, dim3((W.G * VHW + 255) / 256), dim3(256), 0, s, R, W.G, counts, mini, left_out, skip);
 }
 
 void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt) {
     if (R.n <= 0) return;
     size_t lds = (size_t)RENDER_WAVES * P.strip_floats * sizeof(float);
     dim3 grid(P.spans + P.feat_blocks), block(64 * RENDER_WAVES);
-    const bool packed = W.G <= 3;   // must match launch_paint
+    const bool packed = W.G <= 3 && !W.any_absorb;   // must match launch_paint
 #define RENDER_LAUNCH(V, N, UU, PK) hipLaunchKernelGGL((k_render<V, N, UU, PK>), grid, block, lds, s, W, R, P)
 #define RENDER_PK(V, N, UU) do { if (packed) RENDER_LAUNCH(V, N, UU, true); else RENDER_LAUNCH(V, N, UU, false); } while (0)
     if (!vec4) RENDER_PK(false, false, 1);

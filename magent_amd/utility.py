@@ -138,3 +138,24 @@ def check_model(name):
     if not os.path.exists(path):
         raise FileNotFoundError("pre-trained model %r is not shipped with this build (expected under %s)" % (name, path))
     return True
+
+
+class FontProvider(object):
+    """8x8 pixel font for the `arrange` game's goal layouts (reference python/magent/utility.py:271-305).
+
+    The file holds one glyph per line: eight comma-separated byte literals, one byte per row, bit j = pixel j.
+    `get(ch)` returns the glyph as an 8x8 list of 0/1 rows; `ch` is a character or a code point."""
+    width = height = 8
+
+    def __init__(self, filename):
+        self.data = []
+        with open(filename) as f:
+            for line in f:
+                fields = [x.strip() for x in line.split(",") if x.strip()]
+                if not fields:
+                    continue
+                rows = [int(x, 0) for x in fields[:self.height]]
+                self.data.append([[(row >> j) & 1 for j in range(self.width)] for row in rows])
+
+    def get(self, ch):
+        return self.data[ch if isinstance(ch, int) else ord(ch)]

@@ -13,7 +13,7 @@
 // State is kept as per-group struct-of-arrays + a packed occupancy grid; the *order* of every loop that the
 // reference executes sequentially is kept literally, because the results depend on it.
 //
-// Scope: what SURVEY.md section 8 puts on the path -- no food_mode / turn_mode / goal_mode / can_absorb.  Reward rules
+// Scope: what SURVEY.md section 8 puts on the path -- no food_mode / turn_mode / goal_mode.  Reward rules
 // are evaluated by the reference's recursive search over symbol bindings, literally (and/or/not over attack, kill,
 // collide, die, at, in; 'any', 'all' and fixed-index symbols); align / in_a_line abort with a message.
 #include <algorithm>
@@ -93,14 +93,14 @@ struct Group {
     // one entry per agent, in the reference's vector<Agent*> order
     std::vector<int> x, y, id, last_action, last_op;
     std::vector<float> hp, next_reward, last_reward;
-    std::vector<uint8_t> dead;
+    std::vector<uint8_t> dead, absorbed;   // absorbed: a can_absorb agent ("goal") that has taken in a mover (GridWorld.h:191-192)
     std::vector<int64_t> op_obj;  // packed (group<<32 | index) or -1
     int dead_ct = 0;
     float reward = 0;             // Group::next_reward
     int size() const { return (int)x.size(); }
     void clear() {
         x.clear(); y.clear(); id.clear(); last_action.clear(); last_op.clear(); hp.clear(); next_reward.clear();
-        last_reward.clear(); dead.clear(); op_obj.clear(); dead_ct = 0;
+        last_reward.clear(); dead.clear(); absorbed.clear(); op_obj.clear(); dead_ct = 0;
     }
 };
 
@@ -223,7 +223,6 @@ int gridworld_register_agent_type(void *game, const char *name, int n, const cha
                  k == "turn_x_offset" || k == "turn_y_offset") {}  // overwritten below, as in the reference
         else fatal("invalid agent config %s", keys[i]);
     }
-    if (t.can_absorb) fatal("can_absorb is outside the hot-path scope");
     int parity = t.width % 2;
     // A type registered without an attack range keeps the defaults attack_radius = 0, attack_angle = 0 and gets
     // SectorRange(0, 0): height = (int)(0 + 0.5) = 0 rows, i.e. no attack action at all (Range.h:106-139,
@@ -307,7 +306,7 @@ static void place(World &e, int g, int x, int y) {
     int i = G.size();
     G.x.push_back(x); G.y.push_back(y); G.id.push_back(e.id_counter++);
     G.hp.push_back(t.hp); G.last_action.push_back(t.n_action); G.last_op.push_back(OP_NULL); G.op_obj.push_back(-1);
-    G.last_reward.push_back(0.0f); G.next_reward.push_back(t.step_reward); G.dead.push_back(0);
+    G.last_reward.push_back(0.0f); G.next_reward.push_back(t.step_reward); G.dead.push_back(0); G.absorbed.push_back(0);
     e.fill(x, y, t.width, t.length, g, i);
 }
 
@@ -353,7 +352,10 @@ int env_get_observation(void *game, int group, float **bufs) {
         for (int g = 0; g < NG; g++) {
             Group &O = e.groups[g];
             size_t total = 0;
-            for (int j = 0; j < O.size(); j++) { mini[((O.y[j] / scale_h) * VW + O.x[j] / scale_w) * NG + g]++; total++; }
+            for (int j = 0; j < O.size(); j++) {
+                if (t.can_absorb && O.absorbed[j]) continue;   // the OBSERVING group's type decides (GridWorld.cc:343-347)
+                mini[((O.y[j] / scale_h) * VW + O.x[j] / scale_w) * NG + g]++; total++;
+            }
             for (int c = 0; c < VH * VW; c++) mini[c * NG + g] /= total;
         }
     }
@@ -458,7 +460,7 @@ int env_step(void *game, int *done) {
     auto run = [&](std::vector<Pending> &buf) {
         for (const Pending &p : buf) {
             Group &G = e.groups[p.g]; AgentType &t = *G.type;
-            if (G.dead[p.i]) continue;
+            if (G.dead[p.i] || G.absorbed[p.i]) continue;
             const int nx = G.x[p.i] + t.move.dx[p.act], ny = G.y[p.i] + t.move.dy[p.act];
             if (e.blank_area(nx, ny, t.width, t.length, p.g, p.i)) {
                 e.fill(G.x[p.i], G.y[p.i], t.width, t.length, EMPTY, 0);
@@ -470,8 +472,16 @@ int env_step(void *game, int *done) {
                     for (int b = 0; b < t.length; b++) {
                         int c = e.cell(nx + a, ny + b);
                         if (e.occ_g[c] >= 0 && !(e.occ_g[c] == p.g && e.occ_i[c] == p.i)) {
-                            G.last_op[p.i] = OP_COLLIDE; G.op_obj[p.i] = ((int64_t)e.occ_g[c] << 32) | (uint32_t)e.occ_i[c];
-                            found = true; break;
+                            found = true;
+                            Group &O = e.groups[e.occ_g[c]]; const int oi = e.occ_i[c];
+                            if (O.type->can_absorb) {           // Map.cc:341-350: the first mover to bump into a goal is taken in
+                                if (O.absorbed[oi]) break;      // a goal that is already taken: nothing happens, not even a collide
+                                O.absorbed[oi] = 1; O.hp[oi] = O.hp[oi] * 2;
+                                G.dead[p.i] = 1;                // dead without counting in dead_ct (Map.cc:345-346)
+                                e.remove_agent(p.g, p.i);
+                            }
+                            G.last_op[p.i] = OP_COLLIDE; G.op_obj[p.i] = ((int64_t)e.occ_g[c] << 32) | (uint32_t)oi;
+                            break;
                         }
                     }
                     if (found) break;
@@ -585,12 +595,12 @@ int gridworld_clear_dead(void *game) {
             if (G.dead[j]) continue;
             G.x[pt] = G.x[j]; G.y[pt] = G.y[j]; G.id[pt] = G.id[j]; G.hp[pt] = G.hp[j]; G.last_action[pt] = G.last_action[j];
             G.last_reward[pt] = G.next_reward[j]; G.next_reward[pt] = t.step_reward; G.last_op[pt] = OP_NULL; G.op_obj[pt] = -1;
-            G.dead[pt] = 0;
+            G.dead[pt] = 0; G.absorbed[pt] = G.absorbed[j];
             e.fill(G.x[pt], G.y[pt], t.width, t.length, g, pt);
             pt++;
         }
         G.x.resize(pt); G.y.resize(pt); G.id.resize(pt); G.hp.resize(pt); G.last_action.resize(pt); G.last_reward.resize(pt);
-        G.next_reward.resize(pt); G.last_op.resize(pt); G.op_obj.resize(pt); G.dead.resize(pt);
+        G.next_reward.resize(pt); G.last_op.resize(pt); G.op_obj.resize(pt); G.dead.resize(pt); G.absorbed.resize(pt);
         G.dead_ct = 0;
     }
     return 0;

@@ -150,7 +150,29 @@ def custom_duo(map_size):
     return cfg
 
 
-CUSTOM = {"duo": custom_duo, "trans": custom_trans, "tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
+def custom_arrange(map_size, live):
+    """examples/train_arrange.py:181-214: goals are agents of a `can_absorb` type; the first mover that bumps into a free goal
+    is taken in (it dies, the goal's hp doubles) and is paid by the collide rule.  `live` adds a 2x2 group that attacks goals and movers and bumps into goals
+    itself; the goals are observed too (a goal-typed observer leaves taken goals out of its minimap)"""
+    cfg = gw.Config()
+    cfg.set({"map_width": map_size, "map_height": map_size, "minimap_mode": True, "embedding_size": 12})
+    goal = cfg.register_agent_type("goal", {"width": 1, "length": 1, "can_absorb": True})
+    agent = cfg.register_agent_type("agent", dict(width=1, length=1, hp=10, speed=2, view_range=gw.CircleRange(6),
+                                                  step_recover=-10.0 / 400, step_reward=0))
+    g_goal, g_agent = cfg.add_group(goal), cfg.add_group(agent)
+    g, a = gw.AgentSymbol(g_goal, "any"), gw.AgentSymbol(g_agent, "any")
+    cfg.add_reward_rule(gw.Event(a, "collide", g), receiver=a, value=10)
+    if live:
+        brute = cfg.register_agent_type("brute", dict(width=2, length=2, hp=6, speed=1, view_range=gw.CircleRange(4),
+                                                      attack_range=gw.CircleRange(2), damage=0.75, kill_reward=1, step_reward=-0.01))
+        g_brute = cfg.add_group(brute)
+        b = gw.AgentSymbol(g_brute, "any")
+        cfg.add_reward_rule(gw.Event(b, "collide", g), receiver=[b, g], value=[3, 0.5])
+        cfg.add_reward_rule(gw.Event(b, "attack", g), receiver=b, value=0.25)
+    return cfg
+
+
+CUSTOM = {"arrange": custom_arrange, "duo": custom_duo, "trans": custom_trans, "tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
 
 
 class Scenario(object):
@@ -338,6 +360,10 @@ def fuzz_scenario(seed):
                                       "size": (int(rs.randint(2, w // 5 + 3)), int(rs.randint(2, h // 5 + 3)))}))
         place.append((g, "random", {"n": min(n, 4000)}))
     acting = [g for g in range(G) if rs.rand() < 0.85] or [0]
+    if rs.rand() < 0.15:          # one group of goals (can_absorb); goals are never given actions (engine scope)
+        goal = int(rs.randint(G))
+        specs[goal]["can_absorb"] = True
+        acting = [g for g in acting if g != goal]
     return Scenario("fuzz%d" % seed, make, 0, seed=int(rs.randint(1, 1 << 20)), place=place, steps=int(rs.randint(6, 14)),
                     action_seed=seed, walls=int(area * float(rs.choice([0, 0, 0.02, 0.08]))), acting=acting,
                     clear_every=int(rs.choice([1, 1, 1, 2])), obs_every=int(rs.choice([1, 1, 2])))
@@ -424,6 +450,11 @@ def scenarios():
         Scenario("duo", ("duo", 34), 0, place=[rnd(0, 150), rnd(1, 260), rnd(2, 60)], walls=30, steps=25, action_seed=32),
         Scenario("duo_dense", ("duo", 26), 0, place=[rnd(0, 80), rnd(1, 300), rnd(2, 30)], steps=20, action_seed=34),
         Scenario("duo_large", ("duo", 120), 0, place=[rnd(0, 2500), rnd(1, 3500), rnd(2, 800)], steps=8, action_seed=33),
+        Scenario("arrange", ("arrange", 40, False), 0, place=[rnd(0, 180), rnd(1, 300)], walls=60, acting=[1], steps=30, action_seed=35),
+        Scenario("arrange_live", ("arrange", 44, True), 0, place=[rnd(0, 220), rnd(1, 350), rnd(2, 40)], walls=40, steps=30,
+                 acting=[1, 2], action_seed=36, clear_every=2),
+        Scenario("arrange_large", ("arrange", 125, True), 0, place=[rnd(0, 2500), rnd(1, 3500), rnd(2, 300)], steps=10,
+                 acting=[1, 2], action_seed=37),
         Scenario("battle_one_side", "battle", 12, place=[rnd(0, 60), rnd(1, 3)], steps=40, action_seed=14,
                  over={"small": {"damage": 12}}),
     ]

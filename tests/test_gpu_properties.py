@@ -1,10 +1,16 @@
 """GPU tests at BASELINE.json's full size through size-independent properties of the domain, plus equivalence of the
 host-buffer ABI and the device-resident ABI.  (Bit-exact comparison with the oracle at full size is
 tests/test_gpu_parity.py::test_full_size_battle_two_steps.)"""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
 import helpers as H
+
+ROOT = H.ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -255,3 +261,18 @@ def test_env_batch_equals_standalone_environments():
             e.set_action_device(h, acts[0][0][g])
     dones = magent_amd.step_many([e1, e2])
     assert dones == [False, False]
+
+
+def test_moving_goals_are_refused_loudly():
+    """a can_absorb agent that is given a move action is outside the engine's scope: the step aborts with a message
+    instead of guessing (goals that stand still are covered by the `arrange*` parity scenarios)"""
+    code = ("import sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "import helpers as H\n"
+            "sc = H.scenarios()['arrange']\n"
+            "env, handles = sc.build(H.HIP_LIB)\n"
+            "n = env.get_num(handles[0])\n"
+            "env.set_action(handles[0], np.ones(n, np.int32))\n"
+            "env.step()\n" % os.path.join(ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert p.returncode != 0 and "magent-amd FATAL" in p.stderr and "can_absorb" in p.stderr
