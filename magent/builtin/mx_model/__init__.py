@@ -1,4 +1,4 @@
-"""the reference keeps MXNet models here; this build provides the same class on PyTorch-ROCm"""
-from magent_amd.builtin.torch_model import DeepQNetwork
+"""the reference keeps MXNet models here; this build provides the same classes on PyTorch-ROCm"""
+from magent_amd.builtin.torch_model import AdvantageActorCritic, DeepQNetwork
 
-__all__ = ["DeepQNetwork"]
+__all__ = ["DeepQNetwork", "AdvantageActorCritic"]

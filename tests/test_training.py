@@ -103,6 +103,44 @@ def test_dqn_learns_something_on_cpu(tmp_path):
     assert np.array_equal(fresh.infer_action((v, f), None, policy="greedy"), a1)
 
 
+def test_drqn_and_a2c_train_on_cpu(tmp_path):
+    """the other two model families of the reference (tf_model/drqn.py, a2c.py) behind the same call protocol"""
+    import torch
+    from magent_amd.builtin.torch_model import AdvantageActorCritic, DeepRecurrentQNetwork
+    from magent_amd.model import ProcessingModel
+    torch.manual_seed(0); np.random.seed(0)
+    env, handles = _tiny_env(H.ensure_oracle())
+    models = [ProcessingModel(env, handles[0], "rq", 20010, 100, DeepRecurrentQNetwork, batch_size=4, unroll_step=4,
+                              memory_size=200, target_update=5, train_freq=1, device="cpu"),
+              ProcessingModel(env, handles[1], "ac", 20011, 100, AdvantageActorCritic, use_comm=True, device="cpu")]
+    before = [[p.detach().clone() for p in net.parameters()] for net in (models[0].model.qnet, models[1].model.net)]
+    (loss, value), (losses, state_value) = _play_round(env, handles, models, steps=20)
+    assert np.isfinite(loss) and loss > 0 and np.isfinite(value)
+    assert len(losses) == 3 and all(np.isfinite(x) for x in losses) and np.isfinite(state_value)
+    for net, old in zip((models[0].model.qnet, models[1].model.net), before):
+        assert any(not torch.equal(a, b) for a, b in zip(net.parameters(), old))
+    # the recurrent state follows the agent ids: same observation, different history -> the state table tracks the callers
+    v, f = env.get_observation(handles[0])
+    ids = env.get_agent_id(handles[0])
+    drqn = models[0].model
+    a = drqn.infer_action((v, f), ids, policy="greedy")
+    assert a.dtype == np.int32 and len(a) == len(ids) and set(drqn.agent_states) == set(int(i) for i in ids)
+    drqn.infer_action((v[:3], f[:3]), ids[:3], policy="greedy")
+    assert set(drqn.agent_states) == set(int(i) for i in ids[:3])
+    # the policy head samples valid actions; checkpoints round-trip
+    a2c = models[1].model
+    v1, f1 = env.get_observation(handles[1])
+    acts = a2c.infer_action((v1, f1), None)
+    assert acts.dtype == np.int32 and acts.min() >= 0 and acts.max() < 21
+    for m, cls, kw in ((drqn, DeepRecurrentQNetwork, dict(memory_size=4)), (a2c, AdvantageActorCritic, dict(use_comm=True))):
+        m.save(str(tmp_path), 1)
+        fresh = cls(env, m.handle, m.name, device="cpu", **kw)
+        fresh.load(str(tmp_path), 1)
+        for p, q in zip((fresh.qnet if cls is DeepRecurrentQNetwork else fresh.net).parameters(),
+                        (m.qnet if cls is DeepRecurrentQNetwork else m.net).parameters()):
+            assert torch.equal(p, q)
+
+
 def test_magent_alias_exposes_the_reference_names():
     import magent
     from magent.builtin.tf_model import DeepQNetwork
@@ -113,10 +151,8 @@ def test_magent_alias_exposes_the_reference_names():
     cfg = magent.gridworld.Config()
     cfg.set({"map_width": 10, "map_height": 10})
     from magent.builtin.mx_model import DeepQNetwork as MX     # train_gather.py imports the MXNet name
-    from magent.builtin.tf_model import DeepRecurrentQNetwork   # train_trans.py imports it; constructing it is refused
-    assert MX is DeepQNetwork
-    with pytest.raises(NotImplementedError):
-        DeepRecurrentQNetwork()
+    from magent.builtin.tf_model import AdvantageActorCritic, DeepRecurrentQNetwork   # train_trans.py / train_against.py
+    assert MX is DeepQNetwork and DeepRecurrentQNetwork.__name__ == "DeepRecurrentQNetwork" and AdvantageActorCritic is not None
 
 
 @pytest.mark.skipif(not os.path.isfile("/root/reference/examples/train_battle.py"), reason="reference examples not present")
