@@ -185,7 +185,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)
     actions = [[torch.randint(n_actions[g], (n0[g],), dtype=torch.int32, device=dev, generator=gen) for g in range(G)]
-               for _ in range(total_steps)]
+               for _ in range(total_steps + (0 if args.no_profile else 5))]
     from magent_amd import replicas
     do_gather = args.gather == "obs" and world > 1
     torch.cuda.synchronize()
@@ -219,7 +219,9 @@ def main():
         one_step(s)
     env.sync()
     if not args.no_profile:
-        env.profile_enable(True)
+        # inside the timed region only the dominant kernel carries HIP events (an event pair costs ~10 us of stream time;
+        # timing every phase of every step would add ~10 % to the step); the phase breakdown is taken afterwards
+        env.profile_enable(2)
         for name in ("render", "features", "paint", "minimap", "attack", "move", "set_action", "starve", "rules", "clear_dead"):
             env.profile_read(name)
     rendered["view"] = rendered["feat"] = 0
@@ -243,6 +245,7 @@ def main():
         elapsed = replicas.max_over_replicas(elapsed, device=red_dev)
         agent_steps = replicas.sum_over_replicas(agent_steps, device=red_dev)
 
+    agents_at_end = [env.get_num(h) for h in handles]
     roofline, breakdown = None, {}
     if not args.no_profile:
         n_launch, ms = env.profile_read("render")
@@ -265,10 +268,19 @@ def main():
                         "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
                         "algorithmic_bytes_per_launch": int(obs_bytes / n_launch),
                         "obs_total_GBs": round((rendered["view"] + rendered["feat"]) / ((ms + ms_feat) * 1e-3) / 1e9, 1)}
-        for name in ("paint", "minimap", "attack", "move", "set_action", "starve", "rules", "clear_dead"):
-            k, t_ms = env.profile_read(name)
-            if k:
-                breakdown[name + "_ms_per_step"] = round(t_ms / args.steps, 4)
+        # phase breakdown: a few more steps of the same episode, OUTSIDE the timed region, with an event pair around every phase
+        extra = min(5, len(actions) - total_steps)
+        if extra > 0:
+            env.profile_enable(1)
+            for s in range(total_steps, total_steps + extra):
+                one_step(s)
+            env.sync()
+            for name in ("paint", "minimap", "attack", "move", "set_action", "starve", "rules", "clear_dead"):
+                k, t_ms = env.profile_read(name)
+                if k:
+                    breakdown[name + "_ms_per_step"] = round(t_ms / extra, 4)
+            breakdown["note"] = "%d extra steps after the timed region" % extra
+            env.profile_read("render"); env.profile_read("features")
         if roofline:
             breakdown["render_ms_per_step"] = round(ms / args.steps, 4)
             breakdown["features_ms_per_step"] = round(ms_feat / args.steps, 4)
@@ -296,7 +308,7 @@ def main():
                             args.map_size, args.map_size, args.agents, args.agents // 5) if args.workload == "gather" else
                         "battle %dx%d, 2x%d agents, random placement, random actions" % (args.map_size, args.map_size, args.agents)),
                        "envs": world, "parallelism": "replicas x%d" % world, "gather": args.gather,
-                       "agents_at_start": n0, "agents_at_end": [env.get_num(h) for h in handles],
+                       "agents_at_start": n0, "agents_at_end": agents_at_end,
                        "io": "device-resident (env_*_device C-ABI)"},
             "roofline": roofline,
             "breakdown": breakdown,

@@ -115,8 +115,9 @@ int env_sync(EnvHandle game);
 int env_get_stream(EnvHandle game, void **stream);
 
 /* Kernel timing with HIP events recorded on the environment's stream.
- * env_profile_enable(game, 1) starts recording one event pair per launch of each named kernel;
- * env_profile_read returns, for kernel `name` ("render", "paint", "minimap", "attack", "move", ...),
+ * env_profile_enable(game, 1) starts recording one event pair per launch of each named kernel; (game, 2) records
+ * only the observation render launches ("render", "features") -- an event pair costs ~10 us of stream time, so this
+ * is the level to leave on inside a timed region; (game, 0) stops.  env_profile_read returns, for kernel `name` ("render", "paint", "minimap", "attack", "move", ...),
  * the number of recorded launches and their total duration in milliseconds, and resets the counters. */
 int env_profile_enable(EnvHandle game, int on);
 int env_profile_read(EnvHandle game, const char *name, int *n_launches, float *total_ms);

@@ -94,6 +94,7 @@ constexpr int CTR_NEED_HOST = 10;   // 0 = the step ran through; 1 / 2 = attack 
 constexpr int CTR_PHASE_DONE = 11;  // the current fixed point has converged: further rounds of this phase return at once
 constexpr int CTR_RNG = 13;         // engine RNG state (minstd_rand0), advanced on the device by the attack shuffle
 constexpr int CTR_LAST_A = 14;      // attack-list length of the last step (host information)
+constexpr int CTR_ATTACK_BASE = 15; // CTR_ATTACK as it was when the current set_action launch began
 
 // observation render parameters for one get_observation(group) call
 struct RenderArgs {

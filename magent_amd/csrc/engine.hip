@@ -65,8 +65,8 @@ void HostRange::circle(float radius, float inner_radius, int parity) {
 // ------------------------------------------------------------------------------------------------ profiling
 struct Env::ProfScope {
     Env &e; Env::ProfSlot *slot = nullptr; hipEvent_t a{}, b{};
-    ProfScope(Env &env, const char *name) : e(env) {
-        if (!e.prof_on) return;
+    ProfScope(Env &env, const char *name, bool dominant = false) : e(env) {
+        if (!e.prof_level || (e.prof_level == 2 && !dominant)) return;   // an event pair costs ~10 us of stream time
         slot = &e.prof[name];
         a = e.prof_event(); b = e.prof_event();
         HIP_OK(hipEventRecord(a, e.stream));
@@ -740,11 +740,11 @@ void Env::observe_device(int g, float *view, float *feat) {
     const unsigned feat_q = (unsigned)R.n * (unsigned)R.F / 4;
     P.feat_blocks = aligned == feat_aligned ? (int)std::min<unsigned>((feat_q + 255) / 256 + 1, 16384) : 0;
     {
-        ProfScope p(*this, "render");
+        ProfScope p(*this, "render", true);
         launch_render(stream, W, R, P, aligned, aligned && nt_stores);
     }
     if (P.feat_blocks == 0) {
-        ProfScope p(*this, "features");
+        ProfScope p(*this, "features", true);
         launch_features(stream, W, R, P, feat_aligned);
     }
     HIP_OK(hipGetLastError());
@@ -823,8 +823,8 @@ void Env::attack_rounds_checked(const WorldView &W) {
     int iters = 0;
     while (true) {
         clear_changed();
-        launch_attack_iter(stream, W, d_gtab, d_ttab, 0, attack_kmax, 0);
-        launch_attack_iter(stream, W, d_gtab, d_ttab, 1, attack_kmax, 1);
+        launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, 0);
+        launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, 1);
         iters += 2;
         if (!read_changed()) break;
         if (iters > 1000000) fatal("attack resolution did not converge");
@@ -849,7 +849,7 @@ void Env::move_rounds_checked(const WorldView &W) {
 
 void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 = after move rounds */) {
     if (from == 0) {
-        launch_attack_apply(stream, W, d_gtab, d_ttab, 0, attack_kmax);
+        launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
         launch_starve(stream, W);
         if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);
         move_rounds_checked(W);
@@ -894,14 +894,15 @@ void Env::step_begin() {
             ProfScope p(*this, "attack");
             launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank);
             launch_attack_rank(stream, W, d_rank);
+            attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
             for (int pair = 0; pair < pairs; pair++) {
-                launch_attack_iter(stream, W, d_gtab, d_ttab, 0, attack_kmax, 0);
-                launch_attack_iter(stream, W, d_gtab, d_ttab, 1, attack_kmax, 1);   // only the pair's second round reports
+                launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, 0);
+                launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, 1);   // only the pair's second round reports
                 launch_gate(stream, d_counters, pair == pairs - 1 ? 1 : 0, 0);
             }
             if (pairs == 0) launch_gate(stream, d_counters, 1, 1);
-            launch_attack_apply(stream, W, d_gtab, d_ttab, 0, attack_kmax);
+            launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
         }
         {
             ProfScope p(*this, "starve");
@@ -957,17 +958,18 @@ void Env::step_begin() {
                 launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank);
             }
             launch_attack_rank(stream, W, d_rank);
+            attack_round = 0;
             attack_rounds_checked(W);
             if (!first_render) {   // attack events are recorded once rendering has started (GridWorld.cc:484,508)
                 grow(d_events, events_cap, (size_t)A, stream);
-                launch_attack_events(stream, W, 0, d_events);
+                launch_attack_events(stream, W, d_events);
                 std::vector<int4> ev(A);
                 HIP_OK(hipMemcpyAsync(ev.data(), d_events, sizeof(int4) * A, hipMemcpyDeviceToHost, stream));
                 HIP_OK(hipStreamSynchronize(stream));
                 attack_events.clear();
                 for (const int4 &e : ev) if (e.w) attack_events.push_back({e.x, e.y, e.z});
             }
-            launch_attack_apply(stream, W, d_gtab, d_ttab, 0, attack_kmax);
+            launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
         } else if (!first_render) attack_events.clear();
         {
             ProfScope p(*this, "starve");

@@ -113,7 +113,8 @@ public:
     void profile_read(const char *name, int *n, float *ms);
 
     hipStream_t stream{};
-    bool prof_on = false;
+    int attack_round = 0;        // rounds of the attack fixed point launched in the current step (k_attack_eval)
+    int prof_level = 0;          // 0 off, 1 every named phase, 2 only the observation render launches
     bool nt_stores = true;   // nontemporal stores keep the write-once output out of L2 (measured +15-20 %)
     int render_steps_per_span = 0;  // 0 = default
     int render_unroll = 1;

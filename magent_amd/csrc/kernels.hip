@@ -402,28 +402,20 @@ __device__ __forceinline__ int solo_rank(Pred pred, Emit emit, int n, int base) 
     return run;
 }
 
-// pass B: exclusive scan of block totals in place; counter[slot] is the running base and receives the new total
-__global__ void __launch_bounds__(1024) k_scan_blocks(int *sums, int nb, int *counter) {
-    __shared__ int s_w[16];
-    __shared__ int s_carry;
-    if (threadIdx.x == 0) s_carry = counter ? *counter : 0;
-    __syncthreads();
-    for (int start = 0; start < nb; start += 1024) {
-        int i = start + threadIdx.x;
-        int v = i < nb ? sums[i] : 0;
-        int x = v;  // inclusive scan inside the wave by shuffles
+// pass B, folded into pass C: every block adds up the totals of the blocks before it (a few hundred ints from L2 at a
+// million agents) -- one dependent launch less per scan than a separate scan of the block totals
+__device__ __forceinline__ int block_prefix(const int *sums, int b) {
+    __shared__ int s_p[16];
+    int t = 0;
+    for (int k = threadIdx.x; k < b; k += blockDim.x) t += sums[k];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d); if (lane_id() >= d) x += y; }
-        if (lane_id() == 63) s_w[threadIdx.x >> 6] = x;
-        __syncthreads();
-        int before = 0, all = 0;
-        for (int k = 0; k < 16; k++) { int t = s_w[k]; all += t; if (k < (int)(threadIdx.x >> 6)) before += t; }
-        if (i < nb) sums[i] = s_carry + before + x - v;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry += all;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && counter) *counter = s_carry;
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
+    if (lane_id() == 0) s_p[threadIdx.x >> 6] = t;
+    __syncthreads();
+    int tot = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) tot += s_p[w];
+    __syncthreads();
+    return tot;
 }
 
 // ------------------------------------------------------------------------------------------------ set_action
@@ -452,13 +444,18 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int 
         }
     }
     int tot = block_count([&](int i) { return actions[i] >= T.n_move; }, G.n);
-    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+    if (threadIdx.x == 0) {
+        sums[blockIdx.x] = tot;
+        if (blockIdx.x == 0) W.counters[CTR_ATTACK_BASE] = W.counters[CTR_ATTACK];   // nothing writes CTR_ATTACK in this launch
+    }
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_c(WorldView W, int g, const int *actions, const int *sums) {
     const GroupDev G = W.grp[g];
     const int n_move = W.type[g].n_move;
-    block_rank([&](int i) { return actions[i] >= n_move; }, [&](int i, int r) { G.key[i] = (unsigned)r; }, G.n, sums[blockIdx.x]);
+    const int before = W.counters[CTR_ATTACK_BASE] + block_prefix(sums, blockIdx.x);
+    block_rank([&](int i) { return actions[i] >= n_move; }, [&](int i, int r) { G.key[i] = (unsigned)r; }, G.n, before);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) W.counters[CTR_ATTACK] = before + sums[blockIdx.x];
 }
 
 __global__ void __launch_bounds__(SOLO_THREADS) k_set_action_solo(WorldView W, int g, const int *actions, int call_base) {
@@ -509,7 +506,7 @@ __global__ void __launch_bounds__(256) k_iscan_c(const int *in, int n, const int
     for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d); if (lane_id() >= d) x += y; }
     if (lane_id() == 63) s_w[threadIdx.x >> 6] = x;
     __syncthreads();
-    int run = sums[blockIdx.x] + x - t;
+    int run = block_prefix(sums, blockIdx.x) + x - t;
     for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += s_w[w];
 #pragma unroll
     for (int k = 0; k < ISCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
@@ -605,6 +602,7 @@ __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *ran
     const bool dead = G.dead[i];
     if (att) G.key[i] = (unsigned)rank[G.key[i]];
     G.drank_a[i] = dead ? -1 : RANK_INF;   // agents dead before the phase never act and are not on the map
+    G.drank_b[i] = 0;                      // "inputs changed in round 0": everybody is evaluated in round 1
     // push one bit per (attacker group, attack offset) onto the target's cell: targets then enumerate only the
     // hits they actually receive (one word per target instead of a scan of every attack offset around it)
     if (att && !dead) {
@@ -622,12 +620,15 @@ __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *ran
 // for every attacker group g' and attack offset d of g', the only agent that can hit t with d stands at
 // pos(t) - d; it hits iff its pending action is "attack with offset d".  Hits are sorted by rank (LDS) and replayed
 // in order: a hit counts iff its attacker is still alive at that rank (death_rank[attacker] > rank).  death_rank
-// is iterated to its fixed point; after k rounds every event of dependency depth <= k is final.
+// (drank_a) is iterated IN PLACE to its fixed point, which is unique because every event only depends on events of
+// lower rank: an agent is re-evaluated in round r only if one of its inputs changed in round r - 1 or earlier in
+// round r (drank_b holds the last round in which an input changed), so after the first round only the neighbourhood
+// of the deaths is touched; a round without any change leaves every agent consistent with its inputs.
 constexpr int ATT_THREADS = 64;   // one wave per workgroup: the hit lists (kmax x 64 x 8 B of LDS) bound the occupancy
 
 template <bool APPLY>
 __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab,
-                                                             int use_b /* read drank_b, write drank_a */,
+                                                             int round /* 1, 2, ... within this step */,
                                                              const unsigned *hitbits, int kmax, int set_flag) {
     if (W.counters[CTR_ATTACK] == 0 || (APPLY ? gate_after(W) : gate_round(W))) return;
     extern __shared__ unsigned s_hit[];               // [kmax][ATT_THREADS] ranks, then [kmax][ATT_THREADS] refs
@@ -638,10 +639,11 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     const TypeDev T = W.type[g];
     const int i = blockIdx.x * blockDim.x + tid;
     if (i >= G.n) return;
-    const int *dr_self_cur = use_b ? G.drank_b : G.drank_a;
-    int *dr_self_next = use_b ? G.drank_a : G.drank_b;
-    const int dr_me_cur = dr_self_cur[i];
-    if (dr_me_cur == -1) { if (!APPLY) dr_self_next[i] = -1; return; }   // dead before the phase
+    const int dr_me_cur = G.drank_a[i];
+    if (dr_me_cur == -1) return;                      // dead before the phase
+    if (!APPLY && G.drank_b[i] < round - 1) return;   // no input has changed since my last evaluation
+    const int pend = G.pend[i];
+    const bool attacker = (pend & ~PEND_ARG) == PEND_ATTACK;
 
     const int x = G.x[i], y = G.y[i];
     // ---- gather incoming hits: bit (attack_bit[ga] + k) of my cell's word is set iff the agent standing at
@@ -668,6 +670,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
                 }
             }
         }
+    // nobody hits me: I stay alive (RANK_INF, the initial value), and unless I attack there is nothing to apply either
+    if (nh == 0 && (!APPLY || !attacker)) return;
     // ---- insertion sort by rank (ranks are unique)
     for (int a = 1; a < nh; a++) {
         unsigned r = s_rank[a * ATT_THREADS + tid]; int f = s_ref[a * ATT_THREADS + tid];
@@ -680,8 +684,6 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
         s_rank[(b + 1) * ATT_THREADS + tid] = r; s_ref[(b + 1) * ATT_THREADS + tid] = f;
     }
     // ---- own attack (needed for kill_supply replay and, in APPLY, for the attacker-side results)
-    const int pend = G.pend[i];
-    const bool attacker = (pend & ~PEND_ARG) == PEND_ATTACK;
     unsigned my_rank = 0xFFFFFFFFu;
     int tgt = -1;          // packed ref of my target at phase start, -1 = blank / wall / out of board / same group
     if (attacker) {
@@ -695,7 +697,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     }
     // death rank of my target as of the current iterate
     int tgt_dr = RANK_INF;
-    if (tgt >= 0) { const GroupDev TG = gtab[ref_group(tgt)]; tgt_dr = (use_b ? TG.drank_b : TG.drank_a)[ref_index(tgt)]; }
+    if (tgt >= 0) tgt_dr = gtab[ref_group(tgt)].drank_a[ref_index(tgt)];
     const bool supply = W.any_kill_supply && tgt >= 0 && (unsigned)tgt_dr == my_rank;
 
     // ---- replay in rank order
@@ -707,7 +709,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
         if (!supplied && my_rank < r) { hp = fminf(T.hp, hp + ttab[ref_group(tgt)].kill_supply); supplied = true; }
         int a = s_ref[k * ATT_THREADS + tid];
         const GroupDev A = gtab[ref_group(a)];
-        int adr = (use_b ? A.drank_b : A.drank_a)[ref_index(a)];
+        int adr = A.drank_a[ref_index(a)];
         // the attacker is alive when its turn comes iff it did not die at an EARLIER rank.  adr == r happens only when
         // the attacker is this very agent hitting its own body (in-group attack of a body whose range covers its own
         // cells) and that hit is the fatal one: the attack did run (RANK_INF >= any rank)
@@ -722,8 +724,14 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     if (!supplied && (dr == RANK_INF || self_kill)) hp = fminf(T.hp, hp + ttab[ref_group(tgt)].kill_supply);
 
     if (!APPLY) {
-        dr_self_next[i] = dr;
-        if (set_flag && dr != dr_me_cur) W.counters[CTR_CHANGED] = 1;   // only the last round of a pair reports
+        if (dr != dr_me_cur) {
+            G.drank_a[i] = dr;
+            // who reads my death rank: my target (is its attacker alive at that rank?) and, for the kill supply, my attackers
+            if (tgt >= 0) gtab[ref_group(tgt)].drank_b[ref_index(tgt)] = round;
+            if (W.any_kill_supply)
+                for (int k = 0; k < nh; k++) { const int a = s_ref[k * ATT_THREADS + tid]; gtab[ref_group(a)].drank_b[ref_index(a)] = round; }
+            if (set_flag) W.counters[CTR_CHANGED] = 1;   // only the last round of a pair reports
+        }
         return;
     }
     // ---- APPLY (the iterate has converged: dr == dr_me_cur)
@@ -757,7 +765,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
 // render support: ev[rank] = {attacker id, target x, target y, 1} for every attack that was executed (attacker alive at
 // its turn), in the order the reference appends them (GridWorld.cc:483-485: before the blank-target test, so blank and
 // out-of-board targets are recorded too); {.,.,.,0} for list entries whose attacker was already dead
-__global__ void __launch_bounds__(256) k_attack_events(WorldView W, int use_b, int4 *ev) {
+__global__ void __launch_bounds__(256) k_attack_events(WorldView W, int4 *ev) {
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -765,7 +773,7 @@ __global__ void __launch_bounds__(256) k_attack_events(WorldView W, int use_b, i
     const int pend = G.pend[i];
     if ((pend & ~PEND_ARG) != PEND_ATTACK) return;
     const unsigned my_rank = G.key[i];
-    const int dr = (use_b ? G.drank_b : G.drank_a)[i];
+    const int dr = G.drank_a[i];
     int2 d = W.delta[W.type[g].attack_off + (pend & PEND_ARG)];
     const bool executed = dr != -1 && (unsigned)dr >= my_rank;
     ev[my_rank] = make_int4(G.id[i], G.x[i] + d.x, G.y[i] + d.y, executed ? 1 : 0);
@@ -773,12 +781,12 @@ __global__ void __launch_bounds__(256) k_attack_events(WorldView W, int use_b, i
 
 // removes the agents that died in this attack phase from the map (Map::remove_agent, Map.cc:272), after every
 // reader of the phase-start map is done
-__global__ void __launch_bounds__(256) k_attack_bury(WorldView W, int use_b) {
+__global__ void __launch_bounds__(256) k_attack_bury(WorldView W) {
     if (gate_after(W) || W.counters[CTR_ATTACK] == 0) return;
     const GroupDev G = W.grp[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
-    int dr = (use_b ? G.drank_b : G.drank_a)[i];
+    int dr = G.drank_a[i];
     if (dr != -1 && dr != RANK_INF) body_fill(W, G.x[i], G.y[i], W.type[blockIdx.y].bw, W.type[blockIdx.y].bl, OCC_EMPTY);
 }
 
@@ -1313,7 +1321,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_compact_c(WorldView W, int g, 
                    D.next_reward[r] = step_reward;
                    body_fill(W, x, y, bw, bl, ref_pack(g, r));
                },
-               G.n, sums[blockIdx.x]);
+               G.n, block_prefix(sums, blockIdx.x));
 }
 
 __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int g, GroupDev D) {
@@ -1405,7 +1413,6 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
     if (n <= SOLO_MAX) { hipLaunchKernelGGL(k_set_action_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, actions, call_base); return; }
     int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_set_action_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, call_base, sums);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, W.counters + CTR_ATTACK);
     hipLaunchKernelGGL(k_set_action_c, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, sums);
 }
 
@@ -1419,7 +1426,6 @@ void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count,
         hipLaunchKernelGGL(k_iscan_solo, dim3(1), dim3(SOLO_THREADS), 0, s, count, n_max, offset);
     } else {
         hipLaunchKernelGGL(k_iscan_a, dim3(nb), b, 0, s, count, n_max, sums);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, (int *)nullptr);
         hipLaunchKernelGGL(k_iscan_c, dim3(nb), b, 0, s, count, n_max, sums, offset);
     }
     hipLaunchKernelGGL(k_shuffle_fill, g, b, 0, s, counters, j, offset, cursor, list);
@@ -1434,17 +1440,17 @@ void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank) {
     (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);
     hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim);
 }
-void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax, int set_flag) {
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int set_flag) {
     size_t lds = (size_t)kmax * ATT_THREADS * 8;
-    hipLaunchKernelGGL((k_attack_eval<false>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, use_b, (const unsigned *)W.claim, kmax, set_flag);
+    hipLaunchKernelGGL((k_attack_eval<false>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, round, (const unsigned *)W.claim, kmax, set_flag);
 }
-void launch_attack_events(hipStream_t s, const WorldView &W, int use_b, int4 *ev) {
-    hipLaunchKernelGGL(k_attack_events, grid_all(W, 256), dim3(256), 0, s, W, use_b, ev);
+void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev) {
+    hipLaunchKernelGGL(k_attack_events, grid_all(W, 256), dim3(256), 0, s, W, ev);
 }
-void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax) {
+void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax) {
     size_t lds = (size_t)kmax * ATT_THREADS * 8;
-    hipLaunchKernelGGL((k_attack_eval<true>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, use_b, (const unsigned *)W.claim, kmax, 0);
-    hipLaunchKernelGGL(k_attack_bury, grid_all(W, 256), dim3(256), 0, s, W, use_b);
+    hipLaunchKernelGGL((k_attack_eval<true>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, 0, (const unsigned *)W.claim, kmax, 0);
+    hipLaunchKernelGGL(k_attack_bury, grid_all(W, 256), dim3(256), 0, s, W);
 }
 void launch_starve(hipStream_t s, const WorldView &W) { hipLaunchKernelGGL(k_starve, grid_all(W, 256), dim3(256), 0, s, W); }
 
@@ -1519,7 +1525,6 @@ void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D,
     } else {
         int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
         hipLaunchKernelGGL(k_compact_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W.grp[g], sums);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, nb, (int *)nullptr);
         hipLaunchKernelGGL(k_compact_c, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, D, sums);
     }
     hipLaunchKernelGGL(k_compact_reset, dim3((std::max(new_n, 1) + 255) / 256), dim3(256), 0, s, D, new_n, W.counters + CTR_DEAD + g);

@@ -53,9 +53,9 @@ void launch_step_reset(hipStream_t s, int *counters);
 void launch_gate(hipStream_t s, int *counters, int fail_code, int force);
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank);
-void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax, int set_flag);
-void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int use_b, int kmax);
-void launch_attack_events(hipStream_t s, const WorldView &W, int use_b, int4 *ev);
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int set_flag);
+void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);
+void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev);
 void launch_starve(hipStream_t s, const WorldView &W);
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_movg_prep(hipStream_t s, const WorldView &W);

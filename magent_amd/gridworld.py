@@ -347,8 +347,9 @@ class GridWorld(object):
         return self._device_id
 
     def profile_enable(self, on=True):
+        """on: False / 0 off, True / 1 every named phase, 2 only the observation render launches (cheap: for timed regions)"""
         self._require_device_api()
-        self._lib.env_profile_enable(self.game, int(bool(on)))
+        self._lib.env_profile_enable(self.game, int(on))
 
     def profile_read(self, name):
         """-> (n_launches, total_ms) measured with HIP events on the env stream since the last read"""
