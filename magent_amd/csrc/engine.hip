@@ -1057,31 +1057,48 @@ void Env::clear_dead() {
     use_device();
     ProfScope p(*this, "clear_dead");
     WorldView W = view();
-    bool any = false;
-    for (size_t g = 0; g < groups.size(); g++) {
-        HostGroup &G = groups[g];
-        G.group_reward = 0;
-        if (G.h_dead + G.h_taken > 0) {
-            int nb = (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
-            grow(d_sums, sums_cap, (size_t)nb, stream);
-            GroupDev D = G.cur;   // survivors: double-buffered arrays go to alt, the rest is reset in place
-            D.x = G.alt.x; D.y = G.alt.y; D.id = G.alt.id; D.hp = G.alt.hp; D.last_action = G.alt.last_action;
-            D.last_reward = G.alt.last_reward; D.next_reward = G.alt.next_reward; D.absorbed = G.alt.absorbed;
-            const int new_n = G.n - G.h_dead - G.h_taken;
-            launch_compact(stream, W, (int)g, D, new_n, d_sums);
-            std::swap(G.cur.x, G.alt.x); std::swap(G.cur.y, G.alt.y); std::swap(G.cur.id, G.alt.id);
-            std::swap(G.cur.hp, G.alt.hp); std::swap(G.cur.last_action, G.alt.last_action);
-            std::swap(G.cur.last_reward, G.alt.last_reward); std::swap(G.cur.next_reward, G.alt.next_reward);
-            std::swap(G.cur.absorbed, G.alt.absorbed);
-            G.n = new_n;
-            G.h_dead = 0; G.h_taken = 0;
-            any = true;
-        } else {
-            launch_init_reward(stream, W, (int)g);
+    bool any = false, all_solo = true;
+    for (auto &G : groups) { G.group_reward = 0; if (G.h_dead + G.h_taken > 0) { any = true; all_solo &= compact_is_solo(G.n); } }
+    auto swap_buffers = [](HostGroup &G) {     // survivors: double-buffered arrays went to alt, the rest is reset in place
+        std::swap(G.cur.x, G.alt.x); std::swap(G.cur.y, G.alt.y); std::swap(G.cur.id, G.alt.id);
+        std::swap(G.cur.hp, G.alt.hp); std::swap(G.cur.last_action, G.alt.last_action);
+        std::swap(G.cur.last_reward, G.alt.last_reward); std::swap(G.cur.next_reward, G.alt.next_reward);
+        std::swap(G.cur.absorbed, G.alt.absorbed);
+        G.n -= G.h_dead + G.h_taken;
+        G.h_dead = 0; G.h_taken = 0;
+    };
+    if (!any || all_solo) {      // small worlds: one workgroup per group does everything for that group
+        for (size_t g = 0; g < groups.size(); g++) {
+            HostGroup &G = groups[g];
+            if (G.h_dead + G.h_taken > 0) {
+                GroupDev D = G.cur;
+                D.x = G.alt.x; D.y = G.alt.y; D.id = G.alt.id; D.hp = G.alt.hp; D.last_action = G.alt.last_action;
+                D.last_reward = G.alt.last_reward; D.next_reward = G.alt.next_reward; D.absorbed = G.alt.absorbed;
+                launch_compact(stream, W, (int)g, D, G.n - G.h_dead - G.h_taken, d_sums);
+                swap_buffers(G);
+            } else {
+                launch_init_reward(stream, W, (int)g);
+            }
         }
+        if (any) tables_valid = false;
+    } else {                     // three launches for all groups together
+        ClearArgs A{};
+        size_t nb_total = 0;
+        for (size_t g = 0; g < groups.size(); g++) {
+            HostGroup &G = groups[g];
+            A.mode[g] = G.n == 0 ? 0 : (G.h_dead + G.h_taken > 0 ? 2 : 1);
+            A.sums_off[g] = (int)nb_total;
+            nb_total += (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
+            A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed};
+        }
+        grow(d_sums, sums_cap, nb_total, stream);
+        launch_clear_compact(stream, W, A, d_sums);
+        for (size_t g = 0; g < groups.size(); g++) if (A.mode[g] == 2) swap_buffers(groups[g]);
+        launch_clear_finish(stream, view(), A, d_gtab, d_ttab);   // also refreshes the device tables
+        tables_valid = true;
     }
     // (the death counters of the compacted groups were zeroed by the compaction kernels; the others were zero)
-    if (any) { tables_valid = false; h_occ_valid = false; mini_valid = false; }
+    if (any) { h_occ_valid = false; mini_valid = false; }
 }
 
 // ------------------------------------------------------------------------------------------------ info

@@ -72,6 +72,10 @@ __global__ void __launch_bounds__(256) k_fill32_gated(WorldView W, unsigned *p, 
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+__global__ void __launch_bounds__(256) k_fill32(unsigned *p, unsigned v, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 // ------------------------------------------------------------------------------------------------ device tables
 // copies the by-value group/type tables into device memory for kernels that index them per lane
 __global__ void k_set_tables(WorldView W, GroupDev *gtab, TypeDev *ttab) {
@@ -624,14 +628,13 @@ __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *ran
 // lower rank: an agent is re-evaluated in round r only if one of its inputs changed in round r - 1 or earlier in
 // round r (drank_b holds the last round in which an input changed), so after the first round only the neighbourhood
 // of the deaths is touched; a round without any change leaves every agent consistent with its inputs.
-constexpr int ATT_THREADS = 64;   // one wave per workgroup: the hit lists (kmax x 64 x 8 B of LDS) bound the occupancy
-
-template <bool APPLY>
-__global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab,
+// workgroup size: as large as the hit lists (kmax x threads x 8 B of LDS) allow, see att_threads()
+__global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab,
                                                              int round /* 1, 2, ... within this step */,
                                                              const unsigned *hitbits, int kmax, int set_flag) {
-    if (W.counters[CTR_ATTACK] == 0 || (APPLY ? gate_after(W) : gate_round(W))) return;
+    if (W.counters[CTR_ATTACK] == 0 || gate_round(W)) return;
     extern __shared__ unsigned s_hit[];               // [kmax][ATT_THREADS] ranks, then [kmax][ATT_THREADS] refs
+    const int ATT_THREADS = blockDim.x;
     unsigned *s_rank = s_hit;
     int *s_ref = (int *)(s_hit + kmax * ATT_THREADS);
     const int g = blockIdx.y, tid = threadIdx.x;
@@ -641,7 +644,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     if (i >= G.n) return;
     const int dr_me_cur = G.drank_a[i];
     if (dr_me_cur == -1) return;                      // dead before the phase
-    if (!APPLY && G.drank_b[i] < round - 1) return;   // no input has changed since my last evaluation
+    if (G.drank_b[i] < round - 1) return;             // no input has changed since my last evaluation
     const int pend = G.pend[i];
     const bool attacker = (pend & ~PEND_ARG) == PEND_ATTACK;
 
@@ -670,8 +673,7 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
                 }
             }
         }
-    // nobody hits me: I stay alive (RANK_INF, the initial value), and unless I attack there is nothing to apply either
-    if (nh == 0 && (!APPLY || !attacker)) return;
+    if (nh == 0) return;                              // nobody hits me: I stay alive (RANK_INF, the initial value)
     // ---- insertion sort by rank (ranks are unique)
     for (int a = 1; a < nh; a++) {
         unsigned r = s_rank[a * ATT_THREADS + tid]; int f = s_ref[a * ATT_THREADS + tid];
@@ -723,18 +725,55 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     const bool self_kill = tgt == ref_pack(g, i) && (unsigned)dr == my_rank;
     if (!supplied && (dr == RANK_INF || self_kill)) hp = fminf(T.hp, hp + ttab[ref_group(tgt)].kill_supply);
 
-    if (!APPLY) {
-        if (dr != dr_me_cur) {
-            G.drank_a[i] = dr;
-            // who reads my death rank: my target (is its attacker alive at that rank?) and, for the kill supply, my attackers
-            if (tgt >= 0) gtab[ref_group(tgt)].drank_b[ref_index(tgt)] = round;
-            if (W.any_kill_supply)
-                for (int k = 0; k < nh; k++) { const int a = s_ref[k * ATT_THREADS + tid]; gtab[ref_group(a)].drank_b[ref_index(a)] = round; }
-            if (set_flag) W.counters[CTR_CHANGED] = 1;   // only the last round of a pair reports
-        }
-        return;
+    G.mv[i] = __float_as_uint(hp);                    // for k_attack_apply: final once the death ranks are
+    if (dr != dr_me_cur) {
+        G.drank_a[i] = dr;
+        // who reads my death rank: my target (is its attacker alive at that rank?) and, for the kill supply, my attackers
+        if (tgt >= 0) gtab[ref_group(tgt)].drank_b[ref_index(tgt)] = round;
+        if (W.any_kill_supply)
+            for (int k = 0; k < nh; k++) { const int a = s_ref[k * ATT_THREADS + tid]; gtab[ref_group(a)].drank_b[ref_index(a)] = round; }
+        if (set_flag) W.counters[CTR_CHANGED] = 1;   // only the last round of a pair reports
     }
-    // ---- APPLY (the iterate has converged: dr == dr_me_cur)
+}
+
+// The converged phase applied: hp, death, rewards, last_op / op_obj.  Nothing is replayed here: every agent that is hit
+// left the hp of its LAST evaluation in `mv` (that evaluation saw the final death ranks -- otherwise the agent would
+// have been marked and evaluated again), and the attacker-side results only need the death ranks.
+__global__ void __launch_bounds__(256) k_attack_apply(WorldView W, const GroupDev *gtab, const TypeDev *ttab, const unsigned *hitbits) {
+    if (W.counters[CTR_ATTACK] == 0 || gate_after(W)) return;
+    const int g = blockIdx.y;
+    const GroupDev G = W.grp[g];
+    const TypeDev T = W.type[g];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.n) return;
+    const int dr = G.drank_a[i];
+    if (dr == -1) return;                             // dead before the phase
+    const int pend = G.pend[i];
+    const bool attacker = (pend & ~PEND_ARG) == PEND_ATTACK;
+    const int x = G.x[i], y = G.y[i];
+    bool hit = false;
+    for (int by = 0; by < T.bl; by++)
+        for (int bx = 0; bx < T.bw; bx++) hit |= hitbits[(y + by) * W.w + x + bx] != 0;
+    if (!hit && !attacker) return;
+    unsigned my_rank = 0xFFFFFFFFu;
+    int tgt = -1, tgt_dr = RANK_INF;
+    if (attacker) {
+        my_rank = G.key[i];
+        int2 d = W.delta[T.attack_off + (pend & PEND_ARG)];
+        int tx = x + d.x, ty = y + d.y;
+        if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
+            int o = W.occ[ty * W.w + tx];
+            if (o >= 0 && (T.attack_in_group || ref_group(o) != g)) tgt = o;
+        }
+        if (tgt >= 0) tgt_dr = gtab[ref_group(tgt)].drank_a[ref_index(tgt)];
+    }
+    float hp;
+    if (hit) hp = __uint_as_float(G.mv[i]);
+    else {                                            // nobody hit me: only my own kill can feed me (Map.cc:266-274)
+        hp = G.hp[i];
+        if (W.any_kill_supply && tgt >= 0 && (unsigned)tgt_dr == my_rank) hp = fminf(T.hp, hp + ttab[ref_group(tgt)].kill_supply);
+    }
+    const bool self_kill = tgt == ref_pack(g, i) && (unsigned)dr == my_rank;
     float nr = G.next_reward[i];
     float own = 0.0f;                                  // what my own attack adds to my reward
     bool acted = false;
@@ -753,8 +792,8 @@ __global__ void __launch_bounds__(ATT_THREADS) k_attack_eval(WorldView W, const 
     G.hp[i] = hp;
     if (dr != RANK_INF) {
         G.dead[i] = 1;
-        atomicAdd(&W.counters[CTR_DEAD + g], 1);       // the map cell is cleared by k_attack_bury: other lanes of THIS
-                                                       // launch still find their attackers through the map
+        atomicAdd(&W.counters[CTR_DEAD + g], 1);       // the map cells are cleared by k_starve: other lanes of THIS
+                                                       // launch still find their targets through the map
         // dead_penalty overwrites what was accumulated (GridWorld.h:207); only a self-inflicted death is followed by
         // the attacker's own add_reward (the overwrite happens inside do_attack, the add after it)
         nr = self_kill ? T.dead_penalty + own : T.dead_penalty;
@@ -779,17 +818,6 @@ __global__ void __launch_bounds__(256) k_attack_events(WorldView W, int4 *ev) {
     ev[my_rank] = make_int4(G.id[i], G.x[i] + d.x, G.y[i] + d.y, executed ? 1 : 0);
 }
 
-// removes the agents that died in this attack phase from the map (Map::remove_agent, Map.cc:272), after every
-// reader of the phase-start map is done
-__global__ void __launch_bounds__(256) k_attack_bury(WorldView W) {
-    if (gate_after(W) || W.counters[CTR_ATTACK] == 0) return;
-    const GroupDev G = W.grp[blockIdx.y];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n) return;
-    int dr = G.drank_a[i];
-    if (dr != -1 && dr != RANK_INF) body_fill(W, G.x[i], G.y[i], W.type[blockIdx.y].bw, W.type[blockIdx.y].bl, OCC_EMPTY);
-}
-
 // ------------------------------------------------------------------------------------------------ starve / recover
 __global__ void __launch_bounds__(256) k_starve(WorldView W) {
     if (gate_after(W)) return;
@@ -799,6 +827,12 @@ __global__ void __launch_bounds__(256) k_starve(WorldView W) {
     const TypeDev T = W.type[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool died = false;
+    // first: the agents that died in this step's attack phase leave the map (Map::remove_agent, Map.cc:272) -- here, in
+    // the launch after the attack's, because the attack kernels find attackers through the phase-start map
+    if (i < G.n && W.counters[CTR_ATTACK] != 0) {
+        const int dr = G.drank_a[i];
+        if (dr != -1 && dr != RANK_INF) body_fill(W, G.x[i], G.y[i], T.bw, T.bl, OCC_EMPTY);
+    }
     if (i < G.n && !G.dead[i]) {
         float hp = G.hp[i];
         if (T.step_recover > 0) hp = fminf(T.hp, hp + T.step_recover);
@@ -1302,15 +1336,31 @@ __global__ void __launch_bounds__(256) k_init_reward(WorldView W, int g) {
     G.op_obj[i] = -1;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) k_compact_a(GroupDev G, int *sums) {
+// all groups at once (blockIdx.y = group): block totals of the survivors ...
+__global__ void __launch_bounds__(SCAN_THREADS) k_clear_count(WorldView W, ClearArgs A, int *sums) {
+    const int g = blockIdx.y;
+    const GroupDev G = W.grp[g];
+    if (A.mode[g] != 2 || (int)(blockIdx.x * SCAN_TILE) >= G.n) return;
     int tot = block_count([&](int i) { return !G.dead[i]; }, G.n);
-    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+    if (threadIdx.x == 0) sums[A.sums_off[g] + blockIdx.x] = tot;
 }
 
-// stable compaction into the alternate buffers `D` + init_reward + re-index the map
-__global__ void __launch_bounds__(SCAN_THREADS) k_compact_c(WorldView W, int g, GroupDev D, const int *sums) {
+// ... then stable compaction into the alternate buffers + init_reward + re-index the map (groups with deaths), or
+// Agent::init_reward alone (groups without)
+__global__ void __launch_bounds__(SCAN_THREADS) k_clear_compact(WorldView W, ClearArgs A, const int *sums) {
+    const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
+    if ((int)(blockIdx.x * SCAN_TILE) >= G.n) return;
     const float step_reward = W.type[g].step_reward;
+    if (A.mode[g] == 1) {
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            const int i = blockIdx.x * SCAN_TILE + k * SCAN_THREADS + threadIdx.x;
+            if (i < G.n) { G.last_reward[i] = G.next_reward[i]; G.next_reward[i] = step_reward; G.last_op[i] = OP_NULL; G.op_obj[i] = -1; }
+        }
+        return;
+    }
+    if (A.mode[g] != 2) return;
+    const ClearArgs::Alt D = A.dst[g];
     const int bw = W.type[g].bw, bl = W.type[g].bl;
     block_rank([&](int i) { return !G.dead[i]; },
                [&](int i, int r) {
@@ -1321,7 +1371,19 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_compact_c(WorldView W, int g, 
                    D.next_reward[r] = step_reward;
                    body_fill(W, x, y, bw, bl, ref_pack(g, r));
                },
-               G.n, block_prefix(sums, blockIdx.x));
+               G.n, block_prefix(sums + A.sums_off[g], blockIdx.x));
+}
+
+// ... and, with the pointers swapped (Wn = the view after clear_dead): the single-buffered per-agent state of the
+// survivors, the death counters and the device copies of the group / type tables
+__global__ void __launch_bounds__(256) k_clear_finish(WorldView Wn, ClearArgs A, GroupDev *gtab, TypeDev *ttab) {
+    const int g = blockIdx.y;
+    if ((blockIdx.x | blockIdx.y) == 0 && threadIdx.x < MAXG) { gtab[threadIdx.x] = Wn.grp[threadIdx.x]; ttab[threadIdx.x] = Wn.type[threadIdx.x]; }
+    if (A.mode[g] != 2) return;
+    const GroupDev D = Wn.grp[g];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { Wn.counters[CTR_DEAD + g] = 0; Wn.counters[CTR_TAKEN + g] = 0; }
+    if (i < D.n) { D.dead[i] = 0; D.last_op[i] = OP_NULL; D.op_obj[i] = -1; D.pend[i] = PEND_NONE; }
 }
 
 __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int g, GroupDev D) {
@@ -1341,14 +1403,6 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int 
     // every read of the in-place arrays is done (solo_rank ends with a barrier): reset them for the survivors
     for (int r = threadIdx.x; r < alive; r += SOLO_THREADS) { D.dead[r] = 0; D.last_op[r] = OP_NULL; D.op_obj[r] = -1; D.pend[r] = PEND_NONE; }
     if (threadIdx.x == 0) { W.counters[CTR_DEAD + g] = 0; W.counters[CTR_TAKEN + g] = 0; }
-}
-
-// the non-double-buffered per-agent state of the survivors
-__global__ void __launch_bounds__(256) k_compact_reset(GroupDev D, int n, int *dead_counter) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { dead_counter[0] = 0; dead_counter[CTR_TAKEN - CTR_DEAD] = 0; }
-    if (i >= n) return;
-    D.dead[i] = 0; D.last_op[i] = OP_NULL; D.op_obj[i] = -1; D.pend[i] = PEND_NONE;
 }
 
 // ================================================================================================ launchers
@@ -1418,7 +1472,9 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
 
 // n_max = upper bound of the attack-list length (the number of agents); the actual length is read on the device
 void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank) {
-    (void)hipMemsetAsync(count, 0, sizeof(int) * 2 * (size_t)n_max, s);   // count and cursor are adjacent
+    // count and cursor are adjacent; one launch (the runtime's memset splits this size into three)
+    hipLaunchKernelGGL(k_fill32, dim3((unsigned)std::min<size_t>(((size_t)2 * n_max + 1023) / 1024, 2048)), dim3(256), 0, s,
+                       (unsigned *)count, 0u, (size_t)2 * n_max);
     dim3 g((n_max + 255) / 256), b(256);
     int nb = (n_max + ISCAN_TILE - 1) / ISCAN_TILE;
     hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, j, count);
@@ -1440,17 +1496,22 @@ void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank) {
     (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);
     hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim);
 }
+static int att_threads(int kmax) {
+    static const int forced = getenv("MAGENT_ATT_THREADS") ? atoi(getenv("MAGENT_ATT_THREADS")) : 0;
+    if (forced == 64 || forced == 128 || forced == 256) return forced;
+    return kmax <= 16 ? 256 : kmax <= 32 ? 128 : 64;     // <= 32 KB of hit lists per workgroup
+}
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int set_flag) {
+    const int ATT_THREADS = att_threads(kmax);
     size_t lds = (size_t)kmax * ATT_THREADS * 8;
-    hipLaunchKernelGGL((k_attack_eval<false>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, round, (const unsigned *)W.claim, kmax, set_flag);
+    hipLaunchKernelGGL(k_attack_eval, grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, round, (const unsigned *)W.claim, kmax, set_flag);
 }
 void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev) {
     hipLaunchKernelGGL(k_attack_events, grid_all(W, 256), dim3(256), 0, s, W, ev);
 }
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax) {
-    size_t lds = (size_t)kmax * ATT_THREADS * 8;
-    hipLaunchKernelGGL((k_attack_eval<true>), grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, 0, (const unsigned *)W.claim, kmax, 0);
-    hipLaunchKernelGGL(k_attack_bury, grid_all(W, 256), dim3(256), 0, s, W);
+    (void)kmax;
+    hipLaunchKernelGGL(k_attack_apply, grid_all(W, 256), dim3(256), 0, s, W, gtab, ttab, (const unsigned *)W.claim);
 }
 void launch_starve(hipStream_t s, const WorldView &W) { hipLaunchKernelGGL(k_starve, grid_all(W, 256), dim3(256), 0, s, W); }
 
@@ -1516,18 +1577,21 @@ void launch_init_reward(hipStream_t s, const WorldView &W, int g) {
     int n = W.grp[g].n;
     if (n > 0) hipLaunchKernelGGL(k_init_reward, dim3((n + 255) / 256), dim3(256), 0, s, W, g);
 }
-void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D, int new_n, int *sums) {
-    int n = W.grp[g].n;
-    if (n <= 0) return;
-    if (n <= SOLO_MAX) {
-        hipLaunchKernelGGL(k_compact_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, D);
-        return;
-    } else {
-        int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-        hipLaunchKernelGGL(k_compact_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W.grp[g], sums);
-        hipLaunchKernelGGL(k_compact_c, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, D, sums);
-    }
-    hipLaunchKernelGGL(k_compact_reset, dim3((std::max(new_n, 1) + 255) / 256), dim3(256), 0, s, D, new_n, W.counters + CTR_DEAD + g);
+bool compact_is_solo(int n) { return n <= SOLO_MAX; }
+void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D, int new_n, int *sums) {   // small groups: one workgroup
+    (void)new_n; (void)sums;
+    if (W.grp[g].n > 0) hipLaunchKernelGGL(k_compact_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, D);
+}
+void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A, int *sums) {
+    int mx = 1;
+    bool any = false;
+    for (int g = 0; g < W.G; g++) { mx = std::max(mx, W.grp[g].n); any |= A.mode[g] == 2; }
+    dim3 grid((mx + SCAN_TILE - 1) / SCAN_TILE, W.G);
+    if (any) hipLaunchKernelGGL(k_clear_count, grid, dim3(SCAN_THREADS), 0, s, W, A, sums);
+    hipLaunchKernelGGL(k_clear_compact, grid, dim3(SCAN_THREADS), 0, s, W, A, sums);
+}
+void launch_clear_finish(hipStream_t s, const WorldView &Wn, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab) {
+    hipLaunchKernelGGL(k_clear_finish, grid_all(Wn, 256), dim3(256), 0, s, Wn, A, gtab, ttab);
 }
 
 }  // namespace magent_amd

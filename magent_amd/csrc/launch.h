@@ -68,6 +68,15 @@ void launch_finish(hipStream_t s, const WorldView &W);
 void launch_get_reward(hipStream_t s, const GroupDev &G, float group_reward, float *out);
 void launch_get_pos(hipStream_t s, const GroupDev &G, int *out);
 void launch_get_alive(hipStream_t s, const GroupDev &G, unsigned char *out);
+// clear_dead for every group in three launches (count, compact / init_reward, reset + device tables)
+struct ClearArgs {
+    int mode[MAXG];        // 0 nothing (empty group), 1 Agent::init_reward only, 2 compaction of the survivors
+    int sums_off[MAXG];    // where the group's block totals start in `sums`
+    struct Alt { int *x, *y, *id, *last_action; float *hp, *next_reward, *last_reward; unsigned char *absorbed; } dst[MAXG];
+};
+void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A, int *sums);
+void launch_clear_finish(hipStream_t s, const WorldView &Wnew, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab);
+bool compact_is_solo(int n);
 void launch_init_reward(hipStream_t s, const WorldView &W, int g);
 void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D, int new_n, int *sums);
 
