@@ -1017,7 +1017,8 @@ void Env::step_end(int *done) {
 
     int live = 0;
     for (size_t g = 0; g < groups.size(); g++) {
-        groups[g].h_dead = c[CTR_DEAD + g];
+        groups[g].h_dead = 0;
+        for (int k = 0; k < DEAD_SLOTS; k++) groups[g].h_dead += c[dead_slot((int)g, k)];
         groups[g].h_taken = c[CTR_TAKEN + g];
         groups[g].acted = false;
         if (groups[g].n - groups[g].h_dead > 0) live++;

@@ -791,9 +791,8 @@ __global__ void __launch_bounds__(256) k_attack_apply(WorldView W, const GroupDe
     }
     G.hp[i] = hp;
     if (dr != RANK_INF) {
-        G.dead[i] = 1;
-        atomicAdd(&W.counters[CTR_DEAD + g], 1);       // the map cells are cleared by k_starve: other lanes of THIS
-                                                       // launch still find their targets through the map
+        G.dead[i] = 1;                                 // counted, and taken off the map, by k_starve: other lanes of
+                                                       // THIS launch still find their targets through the map
         // dead_penalty overwrites what was accumulated (GridWorld.h:207); only a self-inflicted death is followed by
         // the attacker's own add_reward (the overwrite happens inside do_attack, the add after it)
         nr = self_kill ? T.dead_penalty + own : T.dead_penalty;
@@ -829,9 +828,10 @@ __global__ void __launch_bounds__(256) k_starve(WorldView W) {
     bool died = false;
     // first: the agents that died in this step's attack phase leave the map (Map::remove_agent, Map.cc:272) -- here, in
     // the launch after the attack's, because the attack kernels find attackers through the phase-start map
+    // (and are counted here, one atomic per wave, together with the starved)
     if (i < G.n && W.counters[CTR_ATTACK] != 0) {
         const int dr = G.drank_a[i];
-        if (dr != -1 && dr != RANK_INF) body_fill(W, G.x[i], G.y[i], T.bw, T.bl, OCC_EMPTY);
+        if (dr != -1 && dr != RANK_INF) { died = true; body_fill(W, G.x[i], G.y[i], T.bw, T.bl, OCC_EMPTY); }
     }
     if (i < G.n && !G.dead[i]) {
         float hp = G.hp[i];
@@ -843,7 +843,7 @@ __global__ void __launch_bounds__(256) k_starve(WorldView W) {
         G.hp[i] = hp;
     }
     int wtot; wave_rank(died, wtot);
-    if (wtot && lane_id() == 0) atomicAdd(&W.counters[CTR_DEAD + g], wtot);
+    if (wtot && lane_id() == 0) atomicAdd(&W.counters[dead_slot(g, blockIdx.x % DEAD_SLOTS)], wtot);
 }
 
 // ------------------------------------------------------------------------------------------------ move phase
@@ -1382,7 +1382,8 @@ __global__ void __launch_bounds__(256) k_clear_finish(WorldView Wn, ClearArgs A,
     if (A.mode[g] != 2) return;
     const GroupDev D = Wn.grp[g];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { Wn.counters[CTR_DEAD + g] = 0; Wn.counters[CTR_TAKEN + g] = 0; }
+    if (i < DEAD_SLOTS) Wn.counters[dead_slot(g, i)] = 0;
+    if (i == 0) Wn.counters[CTR_TAKEN + g] = 0;
     if (i < D.n) { D.dead[i] = 0; D.last_op[i] = OP_NULL; D.op_obj[i] = -1; D.pend[i] = PEND_NONE; }
 }
 
@@ -1402,7 +1403,8 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int 
                                 G.n, 0);
     // every read of the in-place arrays is done (solo_rank ends with a barrier): reset them for the survivors
     for (int r = threadIdx.x; r < alive; r += SOLO_THREADS) { D.dead[r] = 0; D.last_op[r] = OP_NULL; D.op_obj[r] = -1; D.pend[r] = PEND_NONE; }
-    if (threadIdx.x == 0) { W.counters[CTR_DEAD + g] = 0; W.counters[CTR_TAKEN + g] = 0; }
+    if (threadIdx.x < DEAD_SLOTS) W.counters[dead_slot(g, threadIdx.x)] = 0;
+    if (threadIdx.x == 0) W.counters[CTR_TAKEN + g] = 0;
 }
 
 // ================================================================================================ launchers
