@@ -896,12 +896,11 @@ void Env::step_begin() {
             launch_attack_rank(stream, W, d_rank);
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
-            for (int pair = 0; pair < pairs; pair++) {
-                launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, 0);
-                launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, 1);   // only the pair's second round reports
-                launch_gate(stream, d_counters, pair == pairs - 1 ? 1 : 0, 0);
-            }
-            if (pairs == 0) launch_gate(stream, d_counters, 1, 1);
+            // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
+            // LAST one reports whether anything still moved (one gate for all of them)
+            for (int r = 0; r < 2 * pairs; r++)
+                launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1);
+            launch_gate(stream, d_counters, 1, pairs == 0);
             launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
         }
         {

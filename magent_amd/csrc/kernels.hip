@@ -1435,7 +1435,7 @@ void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int 
     int mx = 1;
     for (int g = 0; g < W.G; g++) mx = W.grp[g].n > mx ? W.grp[g].n : mx;
     int bx = (mx + 255) / 256;
-    if (bx > 512) bx = 512;
+    if (bx > 128) bx = 128;      // every block ends with one global atomic per non-empty bin: few, fat blocks
     hipLaunchKernelGGL(k_minimap, dim3(bx, W.G), dim3(256), VHW * sizeof(int), s, W, R, counts, left_out, skip);
     hipLaunchKernelGGL(k_minimap_norm, dim3((W.G * VHW + 255) / 256), dim3(256), 0, s, R, W.G, counts, mini, left_out, skip);
 }
