@@ -807,7 +807,12 @@ void Env::set_action_host(int g, const int *actions) {
 //     recording attack events, and with MAGENT_HOST_SHUFFLE / MAGENT_CHECKED_STEP for A/B runs).
 void Env::shuffle_buffers(int n_max) {
     grow(d_rank, rank_cap, (size_t)n_max, stream);
-    grow(d_shuf, shuf_cap, (size_t)n_max * 5, stream);
+    if ((size_t)n_max * 5 > shuf_cap) {   // five arrays at fixed fifths of the buffer: count | cursor | j | offset | list
+        grow(d_shuf, shuf_cap, (size_t)n_max * 5, stream);
+        shuf_cap -= shuf_cap % 5;
+        // count and cursor are kept zero between steps (k_attack_rank clears what a step used)
+        HIP_OK(hipMemsetAsync(d_shuf, 0, sizeof(int) * (shuf_cap / 5) * 2, stream));
+    }
     int nb = (n_max + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
     grow(d_sums, sums_cap, (size_t)nb, stream);
 }
@@ -850,12 +855,11 @@ void Env::move_rounds_checked(const WorldView &W) {
 void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 = after move rounds */) {
     if (from == 0) {
         launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
-        launch_starve(stream, W);
-        if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);
+        if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);   // (starve / recover first)
         move_rounds_checked(W);
     }
     if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
-    for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
+    launch_rules(stream, W, rule_args.data(), (int)rule_args.size());
     if (any_multicell) launch_finish(stream, W);   // (the 1x1 move commit already consumed the pending actions)
 }
 
@@ -888,12 +892,12 @@ void Env::step_begin() {
         // ---------------- single-sync driver
         shuffle_buffers(total_n);
         push_rng();
-        int *sj = d_shuf, *scount = d_shuf + total_n, *scur = d_shuf + 2 * (size_t)total_n, *soff = d_shuf + 3 * (size_t)total_n,
-            *slist = d_shuf + 4 * (size_t)total_n;
+        const size_t seg = shuf_cap / 5;
+        int *scount = d_shuf, *scur = d_shuf + seg, *sj = d_shuf + 2 * seg, *soff = d_shuf + 3 * seg, *slist = d_shuf + 4 * seg;
         {
             ProfScope p(*this, "attack");
-            launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank);
-            launch_attack_rank(stream, W, d_rank);
+            launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank, (unsigned *)d_claim, (size_t)width * height);
+            launch_attack_rank(stream, W, d_rank, scount, scur, false);
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
             // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
@@ -902,10 +906,6 @@ void Env::step_begin() {
                 launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1);
             launch_gate(stream, d_counters, 1, pairs == 0);
             launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
-        }
-        {
-            ProfScope p(*this, "starve");
-            launch_starve(stream, W);
         }
         {
             ProfScope p(*this, "move");
@@ -923,7 +923,7 @@ void Env::step_begin() {
         }
         {
             ProfScope p(*this, "rules");
-            for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
+            launch_rules(stream, W, rule_args.data(), (int)rule_args.size());
             if (any_multicell) launch_finish(stream, W);
         }
         enqueue_counters();
@@ -952,11 +952,11 @@ void Env::step_begin() {
                 rng_on_device = false;
             } else {              // exact parallel replay on the device
                 push_rng();
-                int *sj = d_shuf, *scount = d_shuf + total_n, *scur = d_shuf + 2 * (size_t)total_n,
-                    *soff = d_shuf + 3 * (size_t)total_n, *slist = d_shuf + 4 * (size_t)total_n;
-                launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank);
+                const size_t seg = shuf_cap / 5;
+                int *scount = d_shuf, *scur = d_shuf + seg, *sj = d_shuf + 2 * seg, *soff = d_shuf + 3 * seg, *slist = d_shuf + 4 * seg;
+                launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank, (unsigned *)d_claim, (size_t)width * height);
             }
-            launch_attack_rank(stream, W, d_rank);
+            launch_attack_rank(stream, W, d_rank, d_shuf, d_shuf + shuf_cap / 5, host_shuffle);
             attack_round = 0;
             attack_rounds_checked(W);
             if (!first_render) {   // attack events are recorded once rendering has started (GridWorld.cc:484,508)
@@ -971,10 +971,6 @@ void Env::step_begin() {
             launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
         } else if (!first_render) attack_events.clear();
         {
-            ProfScope p(*this, "starve");
-            launch_starve(stream, W);
-        }
-        {
             ProfScope p(*this, "move");
             if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);
             move_rounds_checked(W);
@@ -982,7 +978,7 @@ void Env::step_begin() {
         }
         {
             ProfScope p(*this, "rules");
-            for (const RuleArgs &a : rule_args) launch_rule(stream, W, a);
+            launch_rules(stream, W, rule_args.data(), (int)rule_args.size());
             if (any_multicell) launch_finish(stream, W);
         }
         enqueue_counters();
@@ -1067,7 +1063,11 @@ void Env::clear_dead() {
         G.n -= G.h_dead + G.h_taken;
         G.h_dead = 0; G.h_taken = 0;
     };
-    if (!any || all_solo) {      // small worlds: one workgroup per group does everything for that group
+    if (!any) {                  // Agent::init_reward for everybody: one launch
+        ClearArgs A{};
+        for (size_t g = 0; g < groups.size(); g++) A.mode[g] = groups[g].n > 0 ? 1 : 0;
+        launch_clear_compact(stream, W, A, d_sums);
+    } else if (all_solo) {       // small worlds: one workgroup per group does everything for that group
         for (size_t g = 0; g < groups.size(); g++) {
             HostGroup &G = groups[g];
             if (G.h_dead + G.h_taken > 0) {

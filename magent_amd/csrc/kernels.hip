@@ -551,9 +551,11 @@ __device__ __forceinline__ unsigned mulmod31(unsigned a, unsigned b) {
     return (unsigned)(r >= 0x7FFFFFFFull ? r - 0x7FFFFFFFull : r);
 }
 
-__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *count) {
+__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *count, unsigned *hitbits, size_t ncell) {
     const int A = counters[CTR_ATTACK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // the per-cell hit words of the coming attack phase start from zero (they share the move phase's claim array)
+    if (A > 0) for (size_t c = i; c < ncell; c += (size_t)gridDim.x * blockDim.x) hitbits[c] = 0u;
     if (i >= A) return;
     unsigned e = (unsigned)i + 1u, base = 16807u, acc = (unsigned)counters[CTR_RNG];
     while (e) { if (e & 1u) acc = mulmod31(acc, base); base = mulmod31(base, base); e >>= 1; }
@@ -593,9 +595,14 @@ __global__ void __launch_bounds__(256) k_shuffle_chase(const int *counters, cons
 
 // ------------------------------------------------------------------------------------------------ attack phase
 // rank[seq] = position of attack-list entry `seq` after the reference's shuffle (GridWorld.cc:464-468)
-__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits) {
+__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_count, int *shuf_cursor) {
     if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) { W.counters[CTR_PHASE_DONE] = 0; W.counters[CTR_CHANGED] = 0; }   // attack rounds start
-    if (W.counters[CTR_ATTACK] == 0) return;
+    const int A = W.counters[CTR_ATTACK];
+    if (A == 0) return;
+    // the shuffle's bucket counters have been read for the last time (k_shuffle_chase): back to zero for the next step
+    for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < A; k += gridDim.x * gridDim.y * blockDim.x) {
+        shuf_count[k] = 0; shuf_cursor[k] = 0;
+    }
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
@@ -818,13 +825,8 @@ __global__ void __launch_bounds__(256) k_attack_events(WorldView W, int4 *ev) {
 }
 
 // ------------------------------------------------------------------------------------------------ starve / recover
-__global__ void __launch_bounds__(256) k_starve(WorldView W) {
-    if (gate_after(W)) return;
-    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) { W.counters[CTR_PHASE_DONE] = 0; W.counters[CTR_CHANGED] = 0; }   // move rounds start
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    const TypeDev T = W.type[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// (device function: runs at the head of the move-preparation launch -- one dependent launch less per step)
+__device__ __forceinline__ void starve_body(const WorldView &W, int g, const GroupDev &G, const TypeDev &T, int i) {
     bool died = false;
     // first: the agents that died in this step's attack phase leave the map (Map::remove_agent, Map.cc:272) -- here, in
     // the launch after the attack's, because the attack kernels find attackers through the phase-start map
@@ -853,12 +855,17 @@ __global__ void __launch_bounds__(256) k_starve(WorldView W) {
 //   is static (64-bit atomic umin of {key, ref} per cell); whether O leaves is a chain of such dependencies that
 //   only points to lower keys, resolved by pointer jumping.
 // tgt (= drank_a, free after the attack phase): target cell of a move candidate, -1 otherwise.
-__global__ void __launch_bounds__(256) k_move_prep(WorldView W) {
+__global__ void __launch_bounds__(256) k_move_prep(WorldView W, unsigned *claim_words, size_t n_words) {
     if (gate_after(W)) return;
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) { W.counters[CTR_PHASE_DONE] = 0; W.counters[CTR_CHANGED] = 0; }   // move rounds start
+    // the claim words back to "nobody" (they held the attack phase's hit bits until now)
+    for (size_t k = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < n_words;
+         k += (size_t)gridDim.x * gridDim.y * blockDim.x) claim_words[k] = 0xFFFFFFFFu;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    starve_body(W, g, G, T, i);
     if (i >= G.n) return;
     int t = -1;
     int pend = G.pend[i];
@@ -1064,10 +1071,12 @@ __device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g,
 // candidates: alive movers with a non-zero delta whose target rectangle is inside the map (Map.cc:455)
 __global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted) {
     if (gate_after(W)) return;
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) { W.counters[CTR_PHASE_DONE] = 0; W.counters[CTR_CHANGED] = 0; }   // move rounds start
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    starve_body(W, g, G, T, i);
     if (i >= G.n) return;
     int t = -1;
     const int pend = G.pend[i];
@@ -1191,8 +1200,11 @@ __global__ void __launch_bounds__(256) k_movg_enter(WorldView W) {
 // op_obj is in group(b) triggers the rule once (RewardEngine.cc:373-414).  Receivers that are the subject are added
 // by the subject's own thread; receivers that are the object are counted with an int atomic and replayed as `hits`
 // sequential float adds of the same value -- order-independent, hence exact.
-__global__ void __launch_bounds__(256) k_rule(WorldView W, RuleArgs A) {
+struct RuleBatch { RuleArgs r[4]; };   // rules that pay different groups and no objects: one launch, blockIdx.y = rule
+
+__global__ void __launch_bounds__(256) k_rule(WorldView W, RuleBatch B) {
     if (gate_after(W)) return;
+    const RuleArgs &A = B.r[blockIdx.y];
     const GroupDev G = W.grp[A.ga];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool trig = false;
@@ -1473,13 +1485,12 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
 }
 
 // n_max = upper bound of the attack-list length (the number of agents); the actual length is read on the device
-void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank) {
-    // count and cursor are adjacent; one launch (the runtime's memset splits this size into three)
-    hipLaunchKernelGGL(k_fill32, dim3((unsigned)std::min<size_t>(((size_t)2 * n_max + 1023) / 1024, 2048)), dim3(256), 0, s,
-                       (unsigned *)count, 0u, (size_t)2 * n_max);
+void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank,
+                    unsigned *hitbits, size_t ncell) {
+    // count / cursor are zero here: zeroed when allocated, and again by k_attack_rank after every use
     dim3 g((n_max + 255) / 256), b(256);
     int nb = (n_max + ISCAN_TILE - 1) / ISCAN_TILE;
-    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, j, count);
+    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, j, count, hitbits, ncell);
     if (n_max <= SOLO_MAX) {
         hipLaunchKernelGGL(k_iscan_solo, dim3(1), dim3(SOLO_THREADS), 0, s, count, n_max, offset);
     } else {
@@ -1494,9 +1505,9 @@ void launch_set_rng(hipStream_t s, int *counters, unsigned x) { hipLaunchKernelG
 void launch_gate(hipStream_t s, int *counters, int fail_code, int force) { hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, counters, fail_code, force); }
 
 // hit bits live in the (then unused) claim array of the move phase
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank) {
-    (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);
-    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim);
+void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, int *shuf_count, int *shuf_cursor, bool clear_hitbits) {
+    if (clear_hitbits) (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);   // (else k_shuffle_draw did it)
+    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim, shuf_count, shuf_cursor);
 }
 static int att_threads(int kmax) {
     static const int forced = getenv("MAGENT_ATT_THREADS") ? atoi(getenv("MAGENT_ATT_THREADS")) : 0;
@@ -1515,13 +1526,11 @@ void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab
     (void)kmax;
     hipLaunchKernelGGL(k_attack_apply, grid_all(W, 256), dim3(256), 0, s, W, gtab, ttab, (const unsigned *)W.claim);
 }
-void launch_starve(hipStream_t s, const WorldView &W) { hipLaunchKernelGGL(k_starve, grid_all(W, 256), dim3(256), 0, s, W); }
 
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     const size_t words = 2 * (size_t)W.w * W.h;
-    hipLaunchKernelGGL(k_fill32_gated, dim3((unsigned)std::min<size_t>((words + 255) / 256, 2048)), dim3(256), 0, s, W, (unsigned *)W.claim, 0xFFFFFFFFu, words);
     dim3 g = grid_all(W, 256);
-    hipLaunchKernelGGL(k_move_prep, g, dim3(256), 0, s, W);
+    hipLaunchKernelGGL(k_move_prep, g, dim3(256), 0, s, W, (unsigned *)W.claim, words);   // starve + claim reset + candidates
     hipLaunchKernelGGL(k_move_claim, g, dim3(256), 0, s, W, gtab);
     hipLaunchKernelGGL(k_move_init, g, dim3(256), 0, s, W);
 }
@@ -1551,6 +1560,8 @@ void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) 
 
 void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A) {
     int na = W.grp[A.ga].n, nb = W.grp[A.gb].n;
+    RuleBatch one{};
+    one.r[0] = A;
     if (A.pair) {
         int ny = W.grp[A.gy].n;
         if (na <= 0 || ny <= 0 || nb <= 0) return;
@@ -1560,8 +1571,28 @@ void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A) {
         hipLaunchKernelGGL(k_pair_obj, dim3((nb + 255) / 256), dim3(256), 0, s, W, A);
         return;
     }
-    if (na > 0) hipLaunchKernelGGL(k_rule, dim3((na + 255) / 256), dim3(256), 0, s, W, A);
+    if (na > 0) hipLaunchKernelGGL(k_rule, dim3((na + 255) / 256), dim3(256), 0, s, W, one);
     if (A.n_obj && na > 0 && nb > 0) hipLaunchKernelGGL(k_rule_obj, dim3((nb + 255) / 256), dim3(256), 0, s, W, A);
+}
+// all rules of a step, in order.  Consecutive subject-only rules that pay different groups touch disjoint rewards: their
+// order among each other is not observable and they share one launch.
+void launch_rules(hipStream_t s, const WorldView &W, const RuleArgs *rules, int n) {
+    for (int k = 0; k < n;) {
+        RuleBatch B{};
+        int m = 0, mx = 0;
+        unsigned paid = 0;
+        while (k + m < n && m < 4) {
+            const RuleArgs &a = rules[k + m];
+            if (a.pair || a.n_obj || (paid >> a.ga & 1u)) break;
+            paid |= 1u << a.ga;
+            B.r[m++] = a;
+            mx = std::max(mx, W.grp[a.ga].n);
+        }
+        if (m >= 2) {
+            if (mx > 0) hipLaunchKernelGGL(k_rule, dim3((mx + 255) / 256, m), dim3(256), 0, s, W, B);
+            k += m;
+        } else launch_rule(s, W, rules[k++]);
+    }
 }
 void launch_finish(hipStream_t s, const WorldView &W) { hipLaunchKernelGGL(k_finish, grid_all(W, 256), dim3(256), 0, s, W); }
 

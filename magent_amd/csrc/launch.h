@@ -47,23 +47,24 @@ void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const
 void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts, float *mini);
 void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt);
 void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4);
-void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank);
+void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank,
+                    unsigned *hitbits, size_t ncell);
 void launch_set_rng(hipStream_t s, int *counters, unsigned x);
 void launch_step_reset(hipStream_t s, int *counters);
 void launch_gate(hipStream_t s, int *counters, int fail_code, int force);
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank);
+void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, int *shuf_count, int *shuf_cursor, bool clear_hitbits);
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int set_flag);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);
 void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev);
-void launch_starve(hipStream_t s, const WorldView &W);
-void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);
+void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);   // starve / recover, then the move candidates
 void launch_movg_prep(hipStream_t s, const WorldView &W);
 void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, int set_flag);
 void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, int set_flag);
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A);
+void launch_rules(hipStream_t s, const WorldView &W, const RuleArgs *rules, int n);
 void launch_finish(hipStream_t s, const WorldView &W);
 void launch_get_reward(hipStream_t s, const GroupDev &G, float group_reward, float *out);
 void launch_get_pos(hipStream_t s, const GroupDev &G, int *out);
