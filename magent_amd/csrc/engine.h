@@ -94,9 +94,11 @@ constexpr int CTR_TAKEN = 64, CTR_UNSUPPORTED = 72;
 // sum over slots of counters[dead_slot(g, slot)]; the host adds them up after its one readback per step.
 constexpr int DEAD_SLOTS = 16, CTR_DEAD_SPREAD = 128, CTR_TOTAL = CTR_DEAD_SPREAD + MAXG * DEAD_SLOTS * 16;
 __host__ __device__ inline int dead_slot(int g, int slot) { return CTR_DEAD_SPREAD + (g * DEAD_SLOTS + slot) * 16; }
-// single-sync step: fixed-point rounds are launched optimistically and gated on the device
-constexpr int CTR_NEED_HOST = 10;   // 0 = the step ran through; 1 / 2 = attack / move rounds ran out, host continues
-constexpr int CTR_PHASE_DONE = 11;  // the current fixed point has converged: further rounds of this phase return at once
+// single-sync step: the fixed-point rounds are launched optimistically; the LAST round of a phase reports whether
+// anything still changed.  A phase left open makes every later kernel of the step return at once, and the host
+// continues from exactly that state (adjacent: cleared together)
+constexpr int CTR_OPEN_ATTACK = 10; // the optimistic attack rounds ran out
+constexpr int CTR_OPEN_MOVE = 11;   // the optimistic move rounds ran out
 constexpr int CTR_RNG = 13;         // engine RNG state (minstd_rand0), advanced on the device by the attack shuffle
 constexpr int CTR_LAST_A = 14;      // attack-list length of the last step (host information)
 constexpr int CTR_ATTACK_BASE = 15; // CTR_ATTACK as it was when the current set_action launch began

@@ -828,8 +828,8 @@ void Env::attack_rounds_checked(const WorldView &W) {
     int iters = 0;
     while (true) {
         clear_changed();
-        launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, 0);
-        launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, 1);
+        launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, -1);
+        launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, CTR_CHANGED);
         iters += 2;
         if (!read_changed()) break;
         if (iters > 1000000) fatal("attack resolution did not converge");
@@ -843,8 +843,8 @@ void Env::move_rounds_checked(const WorldView &W) {
     do {
         clear_changed();
         for (int k = 0; k < move_jump_batch; k++) {
-            const int last = k == move_jump_batch - 1;
-            if (any_multicell) launch_movg_sweep(stream, W, d_gtab, last); else launch_move_jump(stream, W, d_gtab, last);
+            const int flag = k == move_jump_batch - 1 ? CTR_CHANGED : -1;
+            if (any_multicell) launch_movg_sweep(stream, W, d_gtab, flag); else launch_move_jump(stream, W, d_gtab, flag);
         }
         iters += move_jump_batch;
         if (iters > 1000000) fatal("move resolution did not converge");
@@ -903,22 +903,19 @@ void Env::step_begin() {
             // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
             // LAST one reports whether anything still moved (one gate for all of them)
             for (int r = 0; r < 2 * pairs; r++)
-                launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1);
-            launch_gate(stream, d_counters, 1, pairs == 0);
+                launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
+            if (pairs == 0) launch_set_counter(stream, d_counters, CTR_OPEN_ATTACK, 1, -1);   // tests: straight to the host
             launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
         }
         {
             ProfScope p(*this, "move");
             if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);
             const int batches = opt_fixed ? opt_move_batches : (boost_move > 0 ? 2 : 1);
-            for (int b = 0; b < batches; b++) {
-                for (int k = 0; k < move_jump_batch; k++) {
-                    const int last = k == move_jump_batch - 1;
-                    if (any_multicell) launch_movg_sweep(stream, W, d_gtab, last); else launch_move_jump(stream, W, d_gtab, last);
-                }
-                launch_gate(stream, d_counters, b == batches - 1 ? 2 : 0, 0);
+            for (int r = 0; r < batches * move_jump_batch; r++) {
+                const int flag = r == batches * move_jump_batch - 1 ? CTR_OPEN_MOVE : -1;   // the last round reports
+                if (any_multicell) launch_movg_sweep(stream, W, d_gtab, flag); else launch_move_jump(stream, W, d_gtab, flag);
             }
-            if (batches == 0) launch_gate(stream, d_counters, 2, 1);
+            if (batches == 0) launch_set_counter(stream, d_counters, CTR_OPEN_MOVE, 1, CTR_OPEN_ATTACK);   // tests
             if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
         }
         {
@@ -929,7 +926,7 @@ void Env::step_begin() {
         enqueue_counters();
     } else {
         // ---------------- checked driver
-        HIP_OK(hipMemsetAsync(d_counters + CTR_NEED_HOST, 0, 2 * sizeof(int), stream));
+        HIP_OK(hipMemsetAsync(d_counters + CTR_OPEN_ATTACK, 0, 2 * sizeof(int), stream));
         const int A = read_counters()[CTR_ATTACK];
         if (A > 0) {
             ProfScope p(*this, "attack");
@@ -994,12 +991,12 @@ void Env::step_end(int *done) {
     HIP_OK(hipStreamSynchronize(stream));
     const int *c = h_counters;
     if (step_was_fast) {
-        if (c[CTR_NEED_HOST]) {   // continue from exactly the device state the gates froze, host-checked
+        if (c[CTR_OPEN_ATTACK] | c[CTR_OPEN_MOVE]) {   // continue from exactly the device state the open phase froze, host-checked
             WorldView W = view();
-            const int phase = c[CTR_NEED_HOST];
+            const int phase = c[CTR_OPEN_ATTACK] ? 1 : 2;
             fallback_steps++;
             if (phase == 1) boost_attack = 64; else boost_move = 64;   // deeper dependency chains around: one more batch
-            HIP_OK(hipMemsetAsync(d_counters + CTR_NEED_HOST, 0, 2 * sizeof(int), stream));   // NEED_HOST, PHASE_DONE
+            HIP_OK(hipMemsetAsync(d_counters + CTR_OPEN_ATTACK, 0, 2 * sizeof(int), stream));   // both phase flags
             clear_changed();
             if (phase == 1) { attack_rounds_checked(W); phase_tail(W, 0); }
             else { move_rounds_checked(W); phase_tail(W, 1); }

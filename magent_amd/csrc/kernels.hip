@@ -45,18 +45,15 @@ __device__ __forceinline__ void body_fill(const WorldView &W, int x, int y, int 
 }
 
 // Gates of the single-sync step (engine.hip: Env::step).  Fixed-point rounds are launched without waiting for the
-// host; a round returns at once when its phase has already converged, and everything after a phase whose rounds ran
-// out returns at once so that the host can take over from exactly that state.
-__device__ __forceinline__ bool gate_round(const WorldView &W) { return (W.counters[CTR_PHASE_DONE] | W.counters[CTR_NEED_HOST]) != 0; }
-__device__ __forceinline__ bool gate_after(const WorldView &W) { return W.counters[CTR_NEED_HOST] != 0; }
+// host; rounds after convergence find nothing to do, and everything after a phase whose rounds ran out returns at
+// once so that the host can take over from exactly that state.  No gate kernel: the last round of a phase writes the
+// phase's flag itself (`flag` = counter index, < 0 = do not report).
+__device__ __forceinline__ bool attack_open(const WorldView &W) { return W.counters[CTR_OPEN_ATTACK] != 0; }
+__device__ __forceinline__ bool step_open(const WorldView &W) { return (W.counters[CTR_OPEN_ATTACK] | W.counters[CTR_OPEN_MOVE]) != 0; }
 
-// after a batch of rounds: converged iff the batch's last round changed nothing; `fail_code` != 0 marks the last batch
-__global__ void k_gate(int *counters, int fail_code, int force) {
-    if (threadIdx.x != 0) return;
-    if (force) { if (!counters[CTR_NEED_HOST]) counters[CTR_NEED_HOST] = fail_code; return; }   // tests: no optimistic round
-    if (!counters[CTR_PHASE_DONE] && !counters[CTR_CHANGED]) counters[CTR_PHASE_DONE] = 1;
-    counters[CTR_CHANGED] = 0;
-    if (fail_code && !counters[CTR_PHASE_DONE] && !counters[CTR_NEED_HOST]) counters[CTR_NEED_HOST] = fail_code;
+// tests only (MAGENT_OPT_ATTACK_PAIRS=0 / MAGENT_OPT_MOVE_BATCHES=0): leave a phase open without running a round
+__global__ void k_set_counter(int *counters, int index, int value, int unless_index) {
+    if (threadIdx.x == 0 && !(unless_index >= 0 && counters[unless_index])) counters[index] = value;
 }
 // per-step counters back to zero after the end-of-step readback (dead_ct lives until clear_dead)
 __global__ void k_step_reset(int *counters) {
@@ -68,7 +65,7 @@ __global__ void k_set_rng(int *counters, unsigned x) { if (threadIdx.x == 0) cou
 // memset that respects the gate: the claim array still holds the attack phase's hit bits when the host has to continue
 // the attack rounds
 __global__ void __launch_bounds__(256) k_fill32_gated(WorldView W, unsigned *p, unsigned v, size_t n) {
-    if (gate_after(W)) return;
+    if (attack_open(W)) return;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
@@ -596,7 +593,7 @@ __global__ void __launch_bounds__(256) k_shuffle_chase(const int *counters, cons
 // ------------------------------------------------------------------------------------------------ attack phase
 // rank[seq] = position of attack-list entry `seq` after the reference's shuffle (GridWorld.cc:464-468)
 __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_count, int *shuf_cursor) {
-    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) { W.counters[CTR_PHASE_DONE] = 0; W.counters[CTR_CHANGED] = 0; }   // attack rounds start
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // attack rounds start
     const int A = W.counters[CTR_ATTACK];
     if (A == 0) return;
     // the shuffle's bucket counters have been read for the last time (k_shuffle_chase): back to zero for the next step
@@ -638,8 +635,8 @@ __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *ran
 // workgroup size: as large as the hit lists (kmax x threads x 8 B of LDS) allow, see att_threads()
 __global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab,
                                                              int round /* 1, 2, ... within this step */,
-                                                             const unsigned *hitbits, int kmax, int set_flag) {
-    if (W.counters[CTR_ATTACK] == 0 || gate_round(W)) return;
+                                                             const unsigned *hitbits, int kmax, int flag) {
+    if (W.counters[CTR_ATTACK] == 0) return;
     extern __shared__ unsigned s_hit[];               // [kmax][ATT_THREADS] ranks, then [kmax][ATT_THREADS] refs
     const int ATT_THREADS = blockDim.x;
     unsigned *s_rank = s_hit;
@@ -739,7 +736,7 @@ __global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev
         if (tgt >= 0) gtab[ref_group(tgt)].drank_b[ref_index(tgt)] = round;
         if (W.any_kill_supply)
             for (int k = 0; k < nh; k++) { const int a = s_ref[k * ATT_THREADS + tid]; gtab[ref_group(a)].drank_b[ref_index(a)] = round; }
-        if (set_flag) W.counters[CTR_CHANGED] = 1;   // only the last round of a pair reports
+        if (flag >= 0) W.counters[flag] = 1;          // only the last round of a batch reports
     }
 }
 
@@ -747,7 +744,7 @@ __global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev
 // left the hp of its LAST evaluation in `mv` (that evaluation saw the final death ranks -- otherwise the agent would
 // have been marked and evaluated again), and the attacker-side results only need the death ranks.
 __global__ void __launch_bounds__(256) k_attack_apply(WorldView W, const GroupDev *gtab, const TypeDev *ttab, const unsigned *hitbits) {
-    if (W.counters[CTR_ATTACK] == 0 || gate_after(W)) return;
+    if (W.counters[CTR_ATTACK] == 0 || attack_open(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
@@ -856,8 +853,8 @@ __device__ __forceinline__ void starve_body(const WorldView &W, int g, const Gro
 //   only points to lower keys, resolved by pointer jumping.
 // tgt (= drank_a, free after the attack phase): target cell of a move candidate, -1 otherwise.
 __global__ void __launch_bounds__(256) k_move_prep(WorldView W, unsigned *claim_words, size_t n_words) {
-    if (gate_after(W)) return;
-    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) { W.counters[CTR_PHASE_DONE] = 0; W.counters[CTR_CHANGED] = 0; }   // move rounds start
+    if (attack_open(W)) return;
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // move rounds start
     // the claim words back to "nobody" (they held the attack phase's hit bits until now)
     for (size_t k = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < n_words;
          k += (size_t)gridDim.x * gridDim.y * blockDim.x) claim_words[k] = 0xFFFFFFFFu;
@@ -881,7 +878,7 @@ __global__ void __launch_bounds__(256) k_move_prep(WorldView W, unsigned *claim_
 }
 
 __global__ void __launch_bounds__(256) k_move_claim(WorldView W, const GroupDev *gtab) {
-    if (gate_after(W)) return;
+    if (attack_open(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -900,7 +897,7 @@ __global__ void __launch_bounds__(256) k_move_claim(WorldView W, const GroupDev 
 }
 
 __global__ void __launch_bounds__(256) k_move_init(WorldView W) {
-    if (gate_after(W)) return;
+    if (attack_open(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -914,8 +911,8 @@ __global__ void __launch_bounds__(256) k_move_init(WorldView W) {
     else G.mv[i] = (unsigned)o;                                    // succeeds iff the occupant o succeeds
 }
 
-__global__ void __launch_bounds__(256) k_move_jump(WorldView W, const GroupDev *gtab, int set_flag) {
-    if (gate_round(W)) return;
+__global__ void __launch_bounds__(256) k_move_jump(WorldView W, const GroupDev *gtab, int flag) {
+    if (attack_open(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -924,12 +921,12 @@ __global__ void __launch_bounds__(256) k_move_jump(WorldView W, const GroupDev *
     if (m >= MV_OK) return;
     unsigned s = gtab[ref_group((int)m)].mv[ref_index((int)m)];
     G.mv[i] = s;                                                   // OK / FAIL resolve me; otherwise jump
-    if (set_flag && s < MV_OK) W.counters[CTR_CHANGED] = 1;   // only the last round of a batch reports
+    if (flag >= 0 && s < MV_OK) W.counters[flag] = 1;           // only the last round of a batch reports
 }
 
 // collide bookkeeping for failed moves (Map.cc:334-353) + vacate the old cells of successful ones
 __global__ void __launch_bounds__(256) k_move_apply1(WorldView W, const GroupDev *gtab) {
-    if (gate_after(W)) return;
+    if (step_open(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -954,7 +951,7 @@ __global__ void __launch_bounds__(256) k_move_apply1(WorldView W, const GroupDev
 // either entered by the static winner of that cell (which succeeds exactly when the leaver does, and then writes the
 // cell itself) or by nobody (no claim on it: the leaver clears it) -- no cell is written by two agents
 __global__ void __launch_bounds__(256) k_move_commit(WorldView W) {
-    if (gate_after(W)) return;
+    if (step_open(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1070,8 +1067,8 @@ __device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g,
 
 // candidates: alive movers with a non-zero delta whose target rectangle is inside the map (Map.cc:455)
 __global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted) {
-    if (gate_after(W)) return;
-    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) { W.counters[CTR_PHASE_DONE] = 0; W.counters[CTR_CHANGED] = 0; }   // move rounds start
+    if (attack_open(W)) return;
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // move rounds start
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
@@ -1096,8 +1093,8 @@ __global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted
     }
 }
 
-__global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev *gtab, const unsigned *wanted, int set_flag) {
-    if (gate_round(W)) return;
+__global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev *gtab, const unsigned *wanted, int flag) {
+    if (attack_open(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1108,7 +1105,7 @@ __global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev 
         MoveProbe r = move_probe<0>(W, gtab, g, i, t, wanted);
         if (r.blocked) G.mv[i] = MV_FAIL;
         else if (!r.undecided) G.mv[i] = MV_OK;
-        else if (set_flag) W.counters[CTR_CHANGED] = 1;
+        else if (flag >= 0) W.counters[flag] = 1;
         return;
     }
     // Map::do_move with goals (Map.cc:334-353): the collide object is the first agent met; a goal that is still free
@@ -1145,12 +1142,12 @@ __global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev 
         }
     }
     if (st) G.mv[i] = st;
-    else if (set_flag) W.counters[CTR_CHANGED] = 1;
+    else if (flag >= 0) W.counters[flag] = 1;
 }
 
 // Map::get_collide for failed moves (Map.cc:334-353, 486-501): first agent met in the target rectangle
 __global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDev *gtab, const unsigned *wanted) {
-    if (gate_after(W)) return;
+    if (step_open(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1174,7 +1171,7 @@ __global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDe
 }
 
 __global__ void __launch_bounds__(256) k_movg_vacate(WorldView W) {
-    if (gate_after(W)) return;
+    if (step_open(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1183,7 +1180,7 @@ __global__ void __launch_bounds__(256) k_movg_vacate(WorldView W) {
 }
 
 __global__ void __launch_bounds__(256) k_movg_enter(WorldView W) {
-    if (gate_after(W)) return;
+    if (step_open(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1203,7 +1200,7 @@ __global__ void __launch_bounds__(256) k_movg_enter(WorldView W) {
 struct RuleBatch { RuleArgs r[4]; };   // rules that pay different groups and no objects: one launch, blockIdx.y = rule
 
 __global__ void __launch_bounds__(256) k_rule(WorldView W, RuleBatch B) {
-    if (gate_after(W)) return;
+    if (step_open(W)) return;
     const RuleArgs &A = B.r[blockIdx.y];
     const GroupDev G = W.grp[A.ga];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1224,7 +1221,7 @@ __global__ void __launch_bounds__(256) k_rule(WorldView W, RuleBatch B) {
 }
 
 __global__ void __launch_bounds__(256) k_rule_obj(WorldView W, RuleArgs A) {
-    if (gate_after(W)) return;
+    if (step_open(W)) return;
     const GroupDev G = W.grp[A.gb];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
@@ -1251,7 +1248,7 @@ __device__ __forceinline__ int pair_roles(const WorldView &W, const RuleArgs &A,
 }
 
 __global__ void __launch_bounds__(256) k_pair_link(WorldView W, RuleArgs A) {
-    if (gate_after(W)) return;
+    if (step_open(W)) return;
     const int g = blockIdx.y ? A.gy : A.ga;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1260,7 +1257,7 @@ __global__ void __launch_bounds__(256) k_pair_link(WorldView W, RuleArgs A) {
 }
 
 __global__ void __launch_bounds__(256) k_pair_pay(WorldView W, RuleArgs A) {
-    if (gate_after(W)) return;
+    if (step_open(W)) return;
     const int g = blockIdx.y ? A.gy : A.ga;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1292,7 +1289,7 @@ __global__ void __launch_bounds__(256) k_pair_pay(WorldView W, RuleArgs A) {
 
 // the object's share (one run of v_obj per ordered pair) and the reset of the list heads
 __global__ void __launch_bounds__(256) k_pair_obj(WorldView W, RuleArgs A) {
-    if (gate_after(W)) return;
+    if (step_open(W)) return;
     const GroupDev G = W.grp[A.gb];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
@@ -1316,7 +1313,7 @@ __global__ void __launch_bounds__(256) k_pair_obj(WorldView W, RuleArgs A) {
 
 // end of step: pending actions are consumed
 __global__ void __launch_bounds__(256) k_finish(WorldView W) {
-    if (gate_after(W)) return;
+    if (step_open(W)) return;
     const GroupDev G = W.grp[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < G.n) G.pend[i] = PEND_NONE;
@@ -1502,7 +1499,9 @@ void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count,
 }
 void launch_step_reset(hipStream_t s, int *counters) { hipLaunchKernelGGL(k_step_reset, dim3(1), dim3(64), 0, s, counters); }
 void launch_set_rng(hipStream_t s, int *counters, unsigned x) { hipLaunchKernelGGL(k_set_rng, dim3(1), dim3(64), 0, s, counters, x); }
-void launch_gate(hipStream_t s, int *counters, int fail_code, int force) { hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, counters, fail_code, force); }
+void launch_set_counter(hipStream_t s, int *counters, int index, int value, int unless_index) {
+    hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(64), 0, s, counters, index, value, unless_index);
+}
 
 // hit bits live in the (then unused) claim array of the move phase
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, int *shuf_count, int *shuf_cursor, bool clear_hitbits) {
@@ -1514,10 +1513,10 @@ static int att_threads(int kmax) {
     if (forced == 64 || forced == 128 || forced == 256) return forced;
     return kmax <= 16 ? 256 : kmax <= 32 ? 128 : 64;     // <= 32 KB of hit lists per workgroup
 }
-void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int set_flag) {
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag) {
     const int ATT_THREADS = att_threads(kmax);
     size_t lds = (size_t)kmax * ATT_THREADS * 8;
-    hipLaunchKernelGGL(k_attack_eval, grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, round, (const unsigned *)W.claim, kmax, set_flag);
+    hipLaunchKernelGGL(k_attack_eval, grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, round, (const unsigned *)W.claim, kmax, flag);
 }
 void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev) {
     hipLaunchKernelGGL(k_attack_events, grid_all(W, 256), dim3(256), 0, s, W, ev);
@@ -1540,8 +1539,8 @@ void launch_movg_prep(hipStream_t s, const WorldView &W) {
     hipLaunchKernelGGL(k_fill32_gated, dim3((unsigned)std::min<size_t>((words + 255) / 256, 2048)), dim3(256), 0, s, W, (unsigned *)W.claim, 0u, words);
     hipLaunchKernelGGL(k_movg_prep, grid_all(W, 256), dim3(256), 0, s, W, (unsigned *)W.claim);
 }
-void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, int set_flag) {
-    hipLaunchKernelGGL(k_movg_sweep, grid_all(W, 256), dim3(256), 0, s, W, gtab, (const unsigned *)W.claim, set_flag);
+void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag) {
+    hipLaunchKernelGGL(k_movg_sweep, grid_all(W, 256), dim3(256), 0, s, W, gtab, (const unsigned *)W.claim, flag);
 }
 void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     dim3 g = grid_all(W, 256);
@@ -1549,8 +1548,8 @@ void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) 
     hipLaunchKernelGGL(k_movg_vacate, g, dim3(256), 0, s, W);
     hipLaunchKernelGGL(k_movg_enter, g, dim3(256), 0, s, W);
 }
-void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, int set_flag) {
-    hipLaunchKernelGGL(k_move_jump, grid_all(W, 256), dim3(256), 0, s, W, gtab, set_flag);
+void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag) {
+    hipLaunchKernelGGL(k_move_jump, grid_all(W, 256), dim3(256), 0, s, W, gtab, flag);
 }
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     dim3 g = grid_all(W, 256);

@@ -51,17 +51,17 @@ void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count,
                     unsigned *hitbits, size_t ncell);
 void launch_set_rng(hipStream_t s, int *counters, unsigned x);
 void launch_step_reset(hipStream_t s, int *counters);
-void launch_gate(hipStream_t s, int *counters, int fail_code, int force);
+void launch_set_counter(hipStream_t s, int *counters, int index, int value, int unless_index);
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, int *shuf_count, int *shuf_cursor, bool clear_hitbits);
-void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int set_flag);
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);
 void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev);
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);   // starve / recover, then the move candidates
 void launch_movg_prep(hipStream_t s, const WorldView &W);
-void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, int set_flag);
+void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag);
 void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
-void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, int set_flag);
+void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag);
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A);
 void launch_rules(hipStream_t s, const WorldView &W, const RuleArgs *rules, int n);
