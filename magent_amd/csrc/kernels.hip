@@ -7,12 +7,12 @@
 //
 // Reference semantics each kernel restates (file:line into /root/reference/src/gridworld):
 //   k_paint / k_minimap / k_render   GridWorld::get_observation GridWorld.cc:292-401, Map::extract_view Map.cc:129-207
-//   k_set_action + scan trio         GridWorld::set_action GridWorld.cc:403-454
+//   k_set_action_*                   GridWorld::set_action GridWorld.cc:403-454
 //   k_attack_*                       GridWorld::step attack loop GridWorld.cc:475-506, Map.cc:209-310, GridWorld.h:203-209
-//   k_starve                         GridWorld.cc:519-542, GridWorld.h:194-201
+//   starve_body (in k_move*_prep)    GridWorld.cc:519-542, GridWorld.h:194-201
 //   k_move_*                         GridWorld.cc:574-613, Map::do_move Map.cc:313-358
 //   k_rule*                          GridWorld::calc_reward GridWorld.cc:681-692, RewardEngine.cc:216-443
-//   k_compact_* / k_init_reward      GridWorld::clear_dead GridWorld.cc:633-665, Agent::init_reward GridWorld.h:168-174
+//   k_clear_* / k_compact_solo       GridWorld::clear_dead GridWorld.cc:633-665, Agent::init_reward GridWorld.h:168-174
 #include "engine.h"
 #include "launch.h"
 #include <algorithm>
@@ -795,7 +795,7 @@ __global__ void __launch_bounds__(256) k_attack_apply(WorldView W, const GroupDe
     }
     G.hp[i] = hp;
     if (dr != RANK_INF) {
-        G.dead[i] = 1;                                 // counted, and taken off the map, by k_starve: other lanes of
+        G.dead[i] = 1;                                 // counted, and taken off the map, by starve_body: other lanes of
                                                        // THIS launch still find their targets through the map
         // dead_penalty overwrites what was accumulated (GridWorld.h:207); only a self-inflicted death is followed by
         // the attacker's own add_reward (the overwrite happens inside do_attack, the add after it)
