@@ -887,6 +887,7 @@ __global__ void __launch_bounds__(256) k_move_claim(WorldView W, const GroupDev 
     if (c < 0) return;
     unsigned key = G.key[i];
     int o = W.occ[c];
+    G.drank_b[i] = o;            // the phase-start content of my target cell, for k_move_commit (which rewrites the map)
     bool ok = o == OCC_EMPTY;
     if (o >= 0) {
         const GroupDev O = gtab[ref_group(o)];
@@ -924,48 +925,41 @@ __global__ void __launch_bounds__(256) k_move_jump(WorldView W, const GroupDev *
     if (flag >= 0 && s < MV_OK) W.counters[flag] = 1;           // only the last round of a batch reports
 }
 
-// collide bookkeeping for failed moves (Map.cc:334-353) + vacate the old cells of successful ones
-__global__ void __launch_bounds__(256) k_move_apply1(WorldView W, const GroupDev *gtab) {
+// End of the 1x1 move phase, one launch.
+// Successful moves: leave the old cell, enter the new one.  A cell that a successful mover leaves is either entered by
+// the static winner of that cell (which succeeds exactly when the leaver does, and then writes the cell itself) or by
+// nobody (no claim on it: the leaver clears it) -- no cell is written by two agents.
+// Failed moves: collide bookkeeping (Map.cc:334-353) from what k_move_claim saved of the phase-start map (drank_b),
+// the claims and the move states -- nothing that this launch writes.
+__global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev *gtab) {
     if (step_open(W)) return;
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G.n) return;
-    int c = G.drank_a[i];
-    if (c < 0) return;
-    if (G.mv[i] == MV_OK) return;   // old cell is vacated in apply2's first half (after every reader of occ is done)
-    int o = W.occ[c];
-    int blocker;
-    if (o == OCC_EMPTY) blocker = (int)(unsigned)W.claim[c];       // lost an empty cell to the lowest key
-    else {
-        const GroupDev O = gtab[ref_group(o)];
-        int oi = ref_index(o);
-        bool left_before = O.mv[oi] == MV_OK && O.key[oi] < G.key[i];
-        blocker = left_before ? (int)(unsigned)W.claim[c] : o;
-    }
-    G.last_op[i] = OP_COLLIDE;
-    G.op_obj[i] = blocker;
-}
-
-// successful 1x1 moves: leave the old cell, enter the new one.  One launch: a cell that a successful mover leaves is
-// either entered by the static winner of that cell (which succeeds exactly when the leaver does, and then writes the
-// cell itself) or by nobody (no claim on it: the leaver clears it) -- no cell is written by two agents
-__global__ void __launch_bounds__(256) k_move_commit(WorldView W) {
-    if (step_open(W)) return;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < G.n) {
-        const int c = G.drank_a[i];
-        if (c >= 0 && G.mv[i] == MV_OK) {
+    const int c = G.drank_a[i];
+    if (c >= 0) {
+        if (G.mv[i] == MV_OK) {
             const int old = G.y[i] * W.w + G.x[i];
             if (W.claim[old] == CLAIM_NONE) W.occ[old] = OCC_EMPTY;
             W.occ[c] = ref_pack(g, i);
             const int ny = c / W.w;
             G.x[i] = c - ny * W.w; G.y[i] = ny;
+        } else {
+            const int o = G.drank_b[i];
+            int blocker;
+            if (o == OCC_EMPTY) blocker = (int)(unsigned)W.claim[c];       // lost an empty cell to the lowest key
+            else {
+                const GroupDev O = gtab[ref_group(o)];
+                int oi = ref_index(o);
+                bool left_before = O.mv[oi] == MV_OK && O.key[oi] < G.key[i];
+                blocker = left_before ? (int)(unsigned)W.claim[c] : o;
+            }
+            G.last_op[i] = OP_COLLIDE;
+            G.op_obj[i] = blocker;
         }
-        G.pend[i] = PEND_NONE;   // end of step: pending actions are consumed (also done by k_finish for the generic path)
     }
+    G.pend[i] = PEND_NONE;   // end of step: pending actions are consumed (also done by k_finish for the generic path)
 }
 
 // ------------------------------------------------------------------------------------------------ move, generic bodies
@@ -1553,8 +1547,7 @@ void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, i
 }
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     dim3 g = grid_all(W, 256);
-    hipLaunchKernelGGL(k_move_apply1, g, dim3(256), 0, s, W, gtab);
-    hipLaunchKernelGGL(k_move_commit, g, dim3(256), 0, s, W);
+    hipLaunchKernelGGL(k_move_commit, g, dim3(256), 0, s, W, gtab);
 }
 
 void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A) {
