@@ -1,7 +1,10 @@
 // runtime_api.hip -- the C-ABI of libmagent.so (include/magent_runtime_api.h): thin trampolines onto Env.
 // Replaces reference src/runtime_api.cc:15-163 symbol for symbol; PART 2 adds the device-resident calls.
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -15,6 +18,57 @@ static inline Env *E(EnvHandle h) {
     if (!h) fatal("null environment handle");
     return (Env *)h;
 }
+
+// Worker threads of env_cycle_many: started once, parked on a condition variable between rounds (creating threads
+// per call cost more than a small world's whole step).  One round at a time (rounds are serialised by `round_mutex`).
+namespace {
+class CyclePool {
+public:
+    void run(int n_threads, int n_items, const std::function<void(int)> &fn) {
+        std::lock_guard<std::mutex> round(round_mutex);
+        {
+            std::unique_lock<std::mutex> lk(m);
+            while ((int)workers.size() < n_threads - 1) workers.emplace_back([this] { loop(); });
+            job = &fn; total = n_items; next = 0; pending = std::min(n_threads - 1, (int)workers.size()); active = pending; epoch++;
+        }
+        cv.notify_all();
+        for (int e; (e = next.fetch_add(1)) < n_items;) fn(e);     // the calling thread works too
+        std::unique_lock<std::mutex> lk(m);
+        done_cv.wait(lk, [this] { return pending == 0; });
+        job = nullptr;
+    }
+    ~CyclePool() {
+        { std::unique_lock<std::mutex> lk(m); quit = true; }
+        cv.notify_all();
+        for (auto &t : workers) t.join();
+    }
+private:
+    void loop() {
+        unsigned seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        while (true) {
+            cv.wait(lk, [&] { return quit || (epoch != seen && active > 0); });
+            if (quit) return;
+            seen = epoch; active--;
+            const std::function<void(int)> *fn = job;
+            const int n = total;
+            lk.unlock();
+            for (int e; (e = next.fetch_add(1)) < n;) (*fn)(e);
+            lk.lock();
+            if (--pending == 0) done_cv.notify_one();
+        }
+    }
+    std::mutex m, round_mutex;
+    std::condition_variable cv, done_cv;
+    std::vector<std::thread> workers;
+    const std::function<void(int)> *job = nullptr;
+    std::atomic<int> next{0};
+    int total = 0, pending = 0, active = 0;
+    unsigned epoch = 0;
+    bool quit = false;
+};
+CyclePool &cycle_pool() { static CyclePool *p = new CyclePool(); return *p; }   // never destroyed: no join at process exit
+}  // namespace
 
 extern "C" {
 
@@ -87,11 +141,7 @@ int env_cycle_many(EnvHandle *games, int n_env, int n_group, float **view, float
         env->clear_dead();
     };
     if (n_threads <= 1 || n_env <= 1) { for (int e = 0; e < n_env; e++) one(e); return 0; }
-    std::atomic<int> next{0};
-    std::vector<std::thread> pool;
-    const int nt = n_threads < n_env ? n_threads : n_env;
-    for (int t = 0; t < nt; t++) pool.emplace_back([&] { for (int e; (e = next.fetch_add(1)) < n_env;) one(e); });
-    for (auto &th : pool) th.join();
+    cycle_pool().run(n_threads < n_env ? n_threads : n_env, n_env, one);
     return 0;
 }
 int env_sync(EnvHandle game) { E(game)->sync(); return 0; }
