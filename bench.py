@@ -246,6 +246,7 @@ def main():
         agent_steps = replicas.sum_over_replicas(agent_steps, device=red_dev)
 
     agents_at_end = [env.get_num(h) for h in handles]
+    host_finished_steps = env.engine_stats()[0]   # steps whose optimistic rounds ran out (counted since reset, warm-up included)
     roofline, breakdown = None, {}
     if not args.no_profile:
         n_launch, ms = env.profile_read("render")
@@ -309,7 +310,7 @@ def main():
                         "battle %dx%d, 2x%d agents, random placement, random actions" % (args.map_size, args.map_size, args.agents)),
                        "envs": world, "parallelism": "replicas x%d" % world, "gather": args.gather,
                        "agents_at_start": n0, "agents_at_end": agents_at_end,
-                       "io": "device-resident (env_*_device C-ABI)"},
+                       "io": "device-resident (env_*_device C-ABI)", "steps_finished_by_host_driver": host_finished_steps},
             "roofline": roofline,
             "breakdown": breakdown,
         }

@@ -55,7 +55,9 @@ int env_get_reward(EnvHandle game, GroupHandle group, float *buffer);
 
 /* runtime_api.h:33 -> GridWorld::get_info (GridWorld.cc:709-894).  names: num,id,pos,alive,global_minimap,
  * walls_info,render_window_info,attack_event,action_space,view_space,feature_space,view2attack,attack_base,
- * groups_info,both_attack (mean_info: deprecated in the reference, FATAL here). */
+ * groups_info,both_attack (mean_info: deprecated in the reference, FATAL here).
+ * Additive name: engine_stats -> int32[4] = {steps whose optimistic fixed-point rounds ran out and were finished by the
+ * host-checked driver, attack rounds / move rounds of the last such continuation, attack rounds launched last step}. */
 int env_get_info(EnvHandle game, GroupHandle group, const char *name, void *buffer);
 
 /* runtime_api.h:36-37 -> RenderGenerator (text video dump; host-side, off the hot path) */

@@ -1118,6 +1118,10 @@ void Env::info_host(int g, const char *name, void *buf) {
     int *ib = (int *)buf; float *fb = (float *)buf;
     auto need_group = [&]() { if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_info(%s) : %d", name, g); };
     if (k == "num") { need_group(); ib[0] = groups[g].n; return; }
+    if (k == "engine_stats") {   // additive: steps whose optimistic rounds ran out (host continued), rounds of the last checked phases
+        ib[0] = fallback_steps; ib[1] = last_attack_iters; ib[2] = last_move_iters; ib[3] = attack_round;
+        return;
+    }
     if (k == "action_space") { need_group(); ib[0] = groups[g].type->n_action; return; }
     if (k == "view_space") { need_group(); ib[0] = groups[g].type->view.height; ib[1] = groups[g].type->view.width; ib[2] = n_channel(); return; }
     if (k == "feature_space") { need_group(); ib[0] = feature_size(g); return; }

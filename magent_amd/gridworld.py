@@ -346,6 +346,13 @@ class GridWorld(object):
     def device_id(self):
         return self._device_id
 
+    def engine_stats(self):
+        """additive: (steps finished by the host-checked driver, attack rounds, move rounds of the last such step, attack
+        rounds launched in the last step)"""
+        buf = np.zeros(4, dtype=np.int32)
+        self._lib.env_get_info(self.game, 0, b"engine_stats", buf.ctypes.data)
+        return tuple(int(v) for v in buf)
+
     def profile_enable(self, on=True):
         """on: False / 0 off, True / 1 every named phase, 2 only the observation render launches (cheap: for timed regions)"""
         self._require_device_api()
