@@ -41,7 +41,8 @@ def main():
         for line in open(log, errors="ignore"):
             if line.startswith("{") and '"roofline"' in line:
                 rec = json.loads(line)
-                lines += ["", "bench.py's own HIP-event timing in this very run (must agree with the k_render row above):",
+                lines += ["", "bench.py's own HIP-event timing in this very run (must agree with the k_render row above; the rocprof row also "
+                          "counts the warm-up launches and the 5 breakdown steps after the timed region, whose groups are smaller):",
                           "", "```", json.dumps(rec["roofline"]), "```",
                           "", "whole job in the profiled run: %.3e %s, %.3f ms/step" % (rec["value"], rec["unit"], rec["ms_per_step"])]
     if len(sys.argv) >= 5:
