@@ -20,6 +20,7 @@ constexpr int REF_SHIFT = 27;           // packed agent reference = (group << 27
 constexpr int REF_MASK = (1 << REF_SHIFT) - 1;
 constexpr int OCC_EMPTY = -1;
 constexpr int OCC_WALL = -2;
+constexpr int OCC_FOOD = -3;            // food_mode: what an agent killed by an attack leaves on the attacked cell (Map.cc:276-283)
 
 // pending action of an agent for the coming step: (kind << 16) | payload
 constexpr int PEND_NONE = 0;
@@ -46,6 +47,7 @@ __host__ __device__ inline int ref_index(int r) { return r & REF_MASK; }
 // per-type constants (reference AgentType.h:14-46), by group
 struct TypeDev {
     float hp, damage, step_recover, kill_supply, kill_reward, dead_penalty, attack_penalty, step_reward;
+    float food_supply, eat_ability;   // food_mode (AgentType.h:30)
     int attack_in_group;
     int can_absorb;              // a "goal": the first mover that bumps into it is taken in (Map.cc:341-350)
     int bw, bl;                  // body width (x) and length (y) in cells; the agent's position is its top-left cell
@@ -68,6 +70,10 @@ struct GroupDev {
     int *drank_a, *drank_b;      // attack fixed point: rank at which the agent dies (ping-pong)
     unsigned *mv;                // move resolution status / dependency
     int *hits;                   // reward rules: number of rule hits received as the object of an event
+    // food_mode scratch of the attack phase: what my attack eats (-1 = it eats nothing), written by the owner of the
+    // food; the cell on which I was killed and what is left of the food there (-1 = none)
+    float *eat, *fleft;
+    int *fcell;
 };
 
 struct WorldView {
@@ -83,6 +89,8 @@ struct WorldView {
     int any_kill_supply;
     int any_multicell;           // some group has a body larger than one cell (or can absorb): generic move resolution
     int any_absorb;              // some type is can_absorb
+    int food_mode;               // GridWorld.cc:131
+    float *food, *food_next;     // per cell: amount of food on OCC_FOOD cells; attack-phase scratch (-1 = eaten up)
     int large_map, bandwidth;    // reference large_map_mode striping (GridWorld.cc:75-85, 407-425)
 };
 
@@ -110,6 +118,7 @@ struct RenderArgs {
     int VH, VW, C, S;            // window, channels, S = VH*VW*C floats per agent
     int F, E, NA;                // feature size, embedding size, n_action
     int minimap;                 // minimap_mode
+    int food;                    // food_mode: channel 1 shows food, the group blocks start at 2 (GridWorld.cc:915-924)
     int scale_w, scale_h;
     int chan_desc[32];           // per output channel: (kind << 8) | (code & 0xff); kind 0 = has, 1 = hp, 2 = minimap
     int totals[MAXG];            // group sizes (minimap divisor)

@@ -202,7 +202,7 @@ Env::~Env() {
     use_device();
     (void)hipStreamSynchronize(stream);
     for (auto &g : groups) free_group(g);
-    dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_counters); dfree(d_gtab); dfree(d_ttab);
+    dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_food); dfree(d_counters); dfree(d_gtab); dfree(d_ttab);
     dfree(d_delta); dfree(d_mask); dfree(d_mini); dfree(d_minif); dfree(d_sums); dfree(d_rank); dfree(d_shuf); dfree(d_events); dfree(d_actions);
     dfree(d_stage_view); dfree(d_stage_feat); dfree(d_stage_small);
     if (pool) {
@@ -247,7 +247,8 @@ void Env::set_config(const char *key, void *p) {
     else if (k == "seed") { rng.seed((unsigned long)*(int *)p); rng_on_device = false; }
     else if (k == "device_id") { if (device_ready && *(int *)p != device_id) fatal("device_id must be set before env_reset"); device_id = *(int *)p; }
     else if (k == "render_dir") render_dir = (const char *)p;
-    else if (k == "food_mode" || k == "turn_mode" || k == "goal_mode") {
+    else if (k == "food_mode") food_mode = *(bool *)p;
+    else if (k == "turn_mode" || k == "goal_mode") {
         if (*(bool *)p) fatal("%s is outside the hot-path scope of this engine (SURVEY.md 8a)", key);
     } else fatal("invalid argument in GridWorld::set_config : %s", key);
 }
@@ -277,8 +278,9 @@ void Env::register_agent_type(const char *name, int n, const char **keys, float 
         else if (k == "kill_reward") t.kill_reward = v;
         else if (k == "dead_penalty") t.dead_penalty = v;
         else if (k == "attack_penalty") t.attack_penalty = v;
-        else if (k == "hear_radius" || k == "speak_radius" || k == "speak_ability" || k == "trace" || k == "eat_ability" ||
-                 k == "food_supply" || k == "view_x_offset" || k == "view_y_offset" || k == "att_x_offset" ||
+        else if (k == "food_supply") t.food_supply = v;
+        else if (k == "eat_ability") t.eat_ability = v;
+        else if (k == "hear_radius" || k == "speak_radius" || k == "speak_ability" || k == "trace" || k == "view_x_offset" || k == "view_y_offset" || k == "att_x_offset" ||
                  k == "att_y_offset" || k == "turn_x_offset" || k == "turn_y_offset") {
             // accepted like the reference; never read on this path (offsets are recomputed, AgentType.cc:106-108)
         } else fatal("invalid agent config in AgentType::AgentType : %s", keys[i]);
@@ -313,7 +315,7 @@ void Env::new_group(const char *type_name, int *handle) {
     groups.push_back(g);
 }
 
-int Env::n_channel() const { return 1 + (int)groups.size() * (minimap_mode ? 3 : 2); }  // GridWorld.cc:915-924
+int Env::n_channel() const { return 1 + (food_mode ? 1 : 0) + (int)groups.size() * (minimap_mode ? 3 : 2); }  // GridWorld.cc:915-924
 int Env::feature_size(int g) const { return embedding_size + groups[g].type->n_action + 1 + (minimap_mode ? 2 : 0); }
 
 // RewardEngine.cc:28-69
@@ -418,6 +420,7 @@ void Env::free_group(HostGroup &g) {
     dfree(c.x); dfree(c.y); dfree(c.id); dfree(c.last_action); dfree(c.op_obj); dfree(c.pend); dfree(c.hp);
     dfree(c.next_reward); dfree(c.last_reward); dfree(c.dead); dfree(c.last_op); dfree(c.key); dfree(c.drank_a);
     dfree(c.drank_b); dfree(c.mv); dfree(c.hits); dfree(c.absorbed); dfree(a.absorbed);
+    dfree(c.eat); dfree(c.fleft); dfree(c.fcell);
     dfree(a.x); dfree(a.y); dfree(a.id); dfree(a.last_action); dfree(a.hp); dfree(a.next_reward); dfree(a.last_reward);
     g.cap = 0; g.n = 0;
 }
@@ -443,6 +446,7 @@ void Env::ensure_capacity(HostGroup &g, int need) {
     regrow(c.drank_a, n, ncap); regrow(c.drank_b, n, ncap); regrow(c.mv, n, ncap); regrow(c.hits, n, ncap);
     HIP_OK(hipMemset(c.hits, 0, sizeof(int) * ncap));
     regrow(c.absorbed, n, ncap); regrow(a.absorbed, 0, ncap);
+    regrow(c.eat, 0, ncap); regrow(c.fleft, 0, ncap); regrow(c.fcell, 0, ncap);   // attack-phase scratch (food_mode)
     regrow(a.x, 0, ncap); regrow(a.y, 0, ncap); regrow(a.id, 0, ncap); regrow(a.last_action, 0, ncap);
     regrow(a.hp, 0, ncap); regrow(a.next_reward, 0, ncap); regrow(a.last_reward, 0, ncap);
     g.cap = (int)ncap;
@@ -456,6 +460,8 @@ WorldView Env::view() const {
     W.any_kill_supply = any_kill_supply;
     W.any_multicell = any_multicell;
     W.any_absorb = any_absorb;
+    W.food_mode = food_mode ? 1 : 0;
+    W.food = d_food; W.food_next = d_food ? d_food + (size_t)width * height : nullptr;
     W.large_map = large_map_mode; W.bandwidth = bandwidth;
     for (int g = 0; g < W.G; g++) {
         W.type[g] = groups[g].tdev;
@@ -504,8 +510,11 @@ void Env::reset() {
         HIP_OK(hipMalloc(&d_occ, sizeof(int) * ncell));
         HIP_OK(hipMalloc(&d_viewcell, sizeof(int2) * ncell));
         HIP_OK(hipMalloc(&d_claim, sizeof(unsigned long long) * ncell));
+        dfree(d_food);
         map_cells = ncell;
     }
+    if (food_mode && !d_food) HIP_OK(hipMalloc(&d_food, sizeof(float) * 2 * ncell));   // amounts, then the attack phase's scratch
+    if (d_food) HIP_OK(hipMemset(d_food, 0, sizeof(float) * 2 * ncell));
     h_occ.assign(ncell, OCC_EMPTY);
     for (int i = 0; i < width; i++) { h_occ[i] = OCC_WALL; h_occ[(size_t)(height - 1) * width + i] = OCC_WALL; }
     for (int i = 0; i < height; i++) { h_occ[(size_t)i * width] = OCC_WALL; h_occ[(size_t)i * width + width - 1] = OCC_WALL; }
@@ -523,6 +532,7 @@ void Env::reset() {
         d.hp = t.hp; d.damage = t.damage; d.step_recover = t.step_recover; d.kill_supply = t.kill_supply;
         d.kill_reward = t.kill_reward; d.dead_penalty = t.dead_penalty; d.attack_penalty = t.attack_penalty;
         d.step_reward = t.step_reward; d.attack_in_group = t.attack_in_group;
+        d.food_supply = t.food_supply; d.eat_ability = t.eat_ability;
         d.bw = t.width; d.bl = t.length;
         d.can_absorb = t.can_absorb;
         if (t.width * t.length > 1) any_multicell = 1;
@@ -547,10 +557,11 @@ void Env::reset() {
     for (size_t t = 0; t < groups.size(); t++) {
         int k = 0;
         for (size_t a = 0; a < groups.size(); a++)
-            if (a != t || groups[a].type->attack_in_group) k += groups[a].type->attack.count;
+            if (a != t || groups[a].type->attack_in_group || food_mode) k += groups[a].type->attack.count;
         k *= groups[t].type->width * groups[t].type->length;   // every body cell can be hit with every offset
         attack_kmax = std::max(attack_kmax, k);
     }
+    if (food_mode) attack_kmax = std::max(attack_kmax, total_attack);   // a food cell is hit by every group
     if (attack_kmax > 256) fatal("attack ranges x body size too large for the LDS hit lists (%d > 256)", attack_kmax);
     if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
     if (n_channel() > 32) fatal("too many observation channels");
@@ -610,7 +621,7 @@ void Env::add_agents(int group, int n, const char *method, const int *px, const 
     auto add_wall = [&](int x, int y) {  // Map::add_wall (Map.cc:108-115)
         if (x < 0 || x >= width || y < 0 || y >= height) fatal("wall position (%d, %d) out of the map", x, y);
         int &c = h_occ[(size_t)y * width + x];
-        if (c >= 0) return;              // occupied by an agent: ignored
+        if (c >= 0 || c == OCC_FOOD) return;   // occupied by an agent (or by food): ignored
         c = OCC_WALL;
     };
     if (group == -1) {
@@ -673,13 +684,14 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
     R.VH = t.view.height; R.VW = t.view.width; R.C = n_channel(); R.S = R.VH * R.VW * R.C;
     R.F = feature_size(g); R.E = embedding_size; R.NA = t.n_action;
     R.minimap = minimap_mode;
+    R.food = food_mode ? 1 : 0;
     R.scale_h = (height + R.VH - 1) / R.VH;   // GridWorld.cc:328-329
     R.scale_w = (width + R.VW - 1) / R.VW;
     // channel layout symmetric to every group (GridWorld.cc:897-913): block k belongs to group (g + k) % NG
     const int stride = minimap_mode ? 3 : 2;
     R.chan_desc[0] = (0 << 8) | (OCC_WALL & 0xff);
     for (int k = 0; k < NG; k++) {
-        int j = (g + k) % NG, base = 1 + k * stride;
+        int j = (g + k) % NG, base = 1 + (food_mode ? 1 : 0) + k * stride;
         R.chan_desc[base] = (0 << 8) | j;
         R.chan_desc[base + 1] = (1 << 8) | j;
         if (minimap_mode) R.chan_desc[base + 2] = (2 << 8) | j;

@@ -40,7 +40,7 @@ struct HostType {
     std::string name;
     int width = 1, length = 1;
     float speed = 1.0f, hp = 1.0f, view_radius = 1, view_angle = 360, attack_radius = 0, attack_angle = 0;
-    float damage = 0, step_recover = 0, kill_supply = 0;
+    float damage = 0, step_recover = 0, kill_supply = 0, food_supply = 0, eat_ability = 0;
     float step_reward = 0, kill_reward = 0, dead_penalty = 0, attack_penalty = 0;
     bool attack_in_group = false, can_absorb = false;
     int view_x_offset = 0, view_y_offset = 0, att_x_offset = 0, att_y_offset = 0;
@@ -162,7 +162,7 @@ private:
 
     // configuration
     int width = 0, height = 0, embedding_size = 0, device_id = 0;
-    bool minimap_mode = false, large_map_mode = false;
+    bool minimap_mode = false, large_map_mode = false, food_mode = false;
     int bandwidth = 1;
     std::string render_dir;
     // text video dump (reference RenderGenerator.{h,cc}); host-side, off the hot path
@@ -190,6 +190,7 @@ private:
     int *d_occ = nullptr;
     int2 *d_viewcell = nullptr;
     unsigned long long *d_claim = nullptr;
+    float *d_food = nullptr;     // food_mode: per cell amount | attack-phase scratch
     int *d_counters = nullptr, *h_counters = nullptr;
     GroupDev *d_gtab = nullptr;
     TypeDev *d_ttab = nullptr;

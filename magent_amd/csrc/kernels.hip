@@ -86,7 +86,7 @@ __global__ void k_set_tables(WorldView W, GroupDev *gtab, TypeDev *ttab) {
 // With at most 3 groups the record packs into ONE 32-bit word: hp / type.hp lies in [0, 1] (hp is capped at type.hp
 // and agents with hp < 0 are off the map), so the two top bits of its float pattern are free for the group; EMPTY and
 // WALL are the two all-ones-ish sentinels.  Half the footprint: the 1000 x 1000 map is 4 MB and lives in an XCD's L2.
-constexpr unsigned VC_EMPTY = 0xFFFFFFFFu, VC_WALL = 0xFFFFFFFEu;
+constexpr unsigned VC_EMPTY = 0xFFFFFFFFu, VC_WALL = 0xFFFFFFFEu, VC_FOOD = 0xFFFFFFFDu;
 
 template <bool PACKED>
 __global__ void __launch_bounds__(256) k_paint(WorldView W, const GroupDev *gtab, const TypeDev *ttab) {
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) k_paint(WorldView W, const GroupDev *gtab
             rec.y = __float_as_int(__fdiv_rn(gtab[g].hp[i], ttab[g].hp));
         }
         if (PACKED) {
-            unsigned v = o == OCC_EMPTY ? VC_EMPTY : o == OCC_WALL ? VC_WALL : (((unsigned)rec.x << 30) | (unsigned)rec.y);
+            unsigned v = o == OCC_EMPTY ? VC_EMPTY : o == OCC_WALL ? VC_WALL : o == OCC_FOOD ? VC_FOOD : (((unsigned)rec.x << 30) | (unsigned)rec.y);
             if (o >= 0 && ((unsigned)rec.y >> 30)) W.counters[CTR_PACK_OVERFLOW] = 1;   // ratio outside [0, 2): never expected
             ((unsigned *)W.viewcell)[c] = v;
         } else {
@@ -265,7 +265,8 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, Rende
             const bool in = valid[u] && mask[cellv[u]] && mx >= 0 && mx < W.w && my >= 0 && my < W.h;
             if (PACKED) {
                 const unsigned v = in ? ((const unsigned *)W.viewcell)[my * W.w + mx] : VC_EMPTY;
-                recv[u] = v >= VC_WALL ? make_int2(v == VC_WALL ? OCC_WALL : OCC_EMPTY, 0) : make_int2((int)(v >> 30), (int)(v & 0x3FFFFFFFu));
+                recv[u] = v >= VC_FOOD ? make_int2(v == VC_WALL ? OCC_WALL : v == VC_FOOD ? OCC_FOOD : OCC_EMPTY, 0)
+                                       : make_int2((int)(v >> 30), (int)(v & 0x3FFFFFFFu));
             } else {
                 recv[u] = in ? W.viewcell[my * W.w + mx] : make_int2(OCC_EMPTY, 0);
             }
@@ -289,14 +290,16 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, Rende
             // (GridWorld.cc:897-913); the loop is over wave-uniform values only -- no lane diverges, nothing is loaded
             float *dst = strip + lane * C;
             dst[0] = code == (OCC_WALL & 0xff) ? 1.0f : 0.0f;
+            if (R.food) dst[1] = code == (OCC_FOOD & 0xff) ? 1.0f : 0.0f;   // food has a presence channel only (Map.cc:190-196)
             {
                 int j = R.g;
                 const int stride = R.minimap ? 3 : 2;
+                float *blocks = dst + 1 + R.food;
 #pragma unroll
                 for (int b = 0; b < MAXG; b++)
                     if (b < G) {
                         const bool m = code == j;
-                        float *d = dst + 1 + b * stride;
+                        float *d = blocks + b * stride;
                         d[0] = m ? 1.0f : 0.0f;
                         d[1] = m ? hp : 0.0f;
                         if (R.minimap) {
@@ -619,9 +622,65 @@ __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *ran
         int tx = G.x[i] + d.x, ty = G.y[i] + d.y;
         if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
             int o = W.occ[ty * W.w + tx];
-            if (o >= 0 && (T.attack_in_group || ref_group(o) != g)) atomicOr(&hitbits[ty * W.w + tx], 1u << (T.attack_bit + k));
+            // Map::get_attack_obj (Map.cc:229-247).  In food_mode an attack aimed at a comrade is recorded too: it does no
+            // damage, but once the comrade has been killed the food it leaves can be eaten by anybody
+            if ((o >= 0 && (T.attack_in_group || ref_group(o) != g || W.food_mode)) || o == OCC_FOOD)
+                atomicOr(&hitbits[ty * W.w + tx], 1u << (T.attack_bit + k));
         }
     }
+    if (W.food_mode) { G.eat[i] = -1.0f; G.fcell[i] = -1; }
+}
+
+// The hits that land on cell (cx, cy), appended to a thread-private LDS list (stride NT): bit (attack_bit[ga] + k) of
+// the cell's word is set iff the agent standing at cell - delta(ga, k) attacks it with offset k.
+__device__ __forceinline__ int gather_hits(const WorldView &W, unsigned bits, int cx, int cy, unsigned *s_rank, int *s_ref, int NT, int tid, int nh) {
+    for (int ga = 0; ga < W.G; ga++) {
+        const TypeDev TA = W.type[ga];
+        if (TA.n_attack == 0) continue;
+        unsigned mine = (bits >> TA.attack_bit) & (TA.n_attack >= 32 ? 0xFFFFFFFFu : ((1u << TA.n_attack) - 1u));
+        const GroupDev A = W.grp[ga];
+        while (mine) {
+            int k = __ffs(mine) - 1;
+            mine &= mine - 1;
+            int2 d = W.delta[TA.attack_off + k];
+            int o = W.occ[(cy - d.y) * W.w + (cx - d.x)];   // the attacker's own top-left cell
+            int ai = ref_index(o);
+            s_rank[nh * NT + tid] = A.key[ai]; s_ref[nh * NT + tid] = o;
+            nh++;
+        }
+    }
+    return nh;
+}
+// insertion sort of the list by rank (ranks are unique)
+__device__ __forceinline__ void sort_hits(unsigned *s_rank, int *s_ref, int NT, int tid, int nh) {
+    for (int a = 1; a < nh; a++) {
+        unsigned r = s_rank[a * NT + tid]; int f = s_ref[a * NT + tid];
+        int b = a - 1;
+        while (b >= 0 && s_rank[b * NT + tid] > r) {
+            s_rank[(b + 1) * NT + tid] = s_rank[b * NT + tid];
+            s_ref[(b + 1) * NT + tid] = s_ref[b * NT + tid];
+            b--;
+        }
+        s_rank[(b + 1) * NT + tid] = r; s_ref[(b + 1) * NT + tid] = f;
+    }
+}
+// the cell an attacker aims at (its pending action is an attack)
+__device__ __forceinline__ int attack_cell(const WorldView &W, const GroupDev *gtab, int a) {
+    const GroupDev A = gtab[ref_group(a)];
+    const int ai = ref_index(a);
+    const int2 d = W.delta[W.type[ref_group(a)].attack_off + (A.pend[ai] & PEND_ARG)];
+    return (A.y[ai] + d.y) * W.w + A.x[ai] + d.x;
+}
+// food_mode: one attacker eats from what is left on a cell (Map.cc:292-303).  `eat` of an attacker is written by the
+// owner of its target cell only; a change sends the attacker back into evaluation.
+__device__ __forceinline__ bool set_eat(const WorldView &W, const GroupDev *gtab, int a, float e, int round, int flag) {
+    const GroupDev A = gtab[ref_group(a)];
+    const int ai = ref_index(a);
+    if (A.eat[ai] == e) return false;
+    A.eat[ai] = e;
+    A.drank_b[ai] = round;
+    if (flag >= 0) W.counters[flag] = 1;
+    return true;
 }
 
 // Exact parallel form of the sequential attack loop.  For a target t the incoming hits are found by PULLING:
@@ -660,84 +719,131 @@ __global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev
         for (int bx = 0; bx < T.bw; bx++) {      // an attacker hits ONE cell; a multi-cell body collects from all of its cells
             const int cx = x + bx, cy = y + by;
             unsigned bits = hitbits[cy * W.w + cx];
-            if (!bits) continue;
-            for (int ga = 0; ga < W.G; ga++) {
-                const TypeDev TA = W.type[ga];
-                if (TA.n_attack == 0) continue;
-                unsigned mine = (bits >> TA.attack_bit) & (TA.n_attack >= 32 ? 0xFFFFFFFFu : ((1u << TA.n_attack) - 1u));
-                const GroupDev A = W.grp[ga];
-                while (mine) {
-                    int k = __ffs(mine) - 1;
-                    mine &= mine - 1;
-                    int2 d = W.delta[TA.attack_off + k];
-                    int o = W.occ[(cy - d.y) * W.w + (cx - d.x)];   // the attacker's own top-left cell
-                    int ai = ref_index(o);
-                    s_rank[nh * ATT_THREADS + tid] = A.key[ai]; s_ref[nh * ATT_THREADS + tid] = o;
-                    nh++;
-                }
-            }
+            if (bits) nh = gather_hits(W, bits, cx, cy, s_rank, s_ref, ATT_THREADS, tid, nh);
         }
     if (nh == 0) return;                              // nobody hits me: I stay alive (RANK_INF, the initial value)
-    // ---- insertion sort by rank (ranks are unique)
-    for (int a = 1; a < nh; a++) {
-        unsigned r = s_rank[a * ATT_THREADS + tid]; int f = s_ref[a * ATT_THREADS + tid];
-        int b = a - 1;
-        while (b >= 0 && s_rank[b * ATT_THREADS + tid] > r) {
-            s_rank[(b + 1) * ATT_THREADS + tid] = s_rank[b * ATT_THREADS + tid];
-            s_ref[(b + 1) * ATT_THREADS + tid] = s_ref[b * ATT_THREADS + tid];
-            b--;
-        }
-        s_rank[(b + 1) * ATT_THREADS + tid] = r; s_ref[(b + 1) * ATT_THREADS + tid] = f;
-    }
+    sort_hits(s_rank, s_ref, ATT_THREADS, tid, nh);
     // ---- own attack (needed for kill_supply replay and, in APPLY, for the attacker-side results)
     unsigned my_rank = 0xFFFFFFFFu;
     int tgt = -1;          // packed ref of my target at phase start, -1 = blank / wall / out of board / same group
+    int aimed = -1;        // the agent on the cell I aim at, comrade or not (food_mode: it may leave food for me)
     if (attacker) {
         my_rank = G.key[i];
         int2 d = W.delta[T.attack_off + (pend & PEND_ARG)];
         int tx = x + d.x, ty = y + d.y;
         if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
             int o = W.occ[ty * W.w + tx];
+            if (o >= 0) aimed = o;
             if (o >= 0 && (T.attack_in_group || ref_group(o) != g)) tgt = o;
         }
     }
     // death rank of my target as of the current iterate
     int tgt_dr = RANK_INF;
     if (tgt >= 0) tgt_dr = gtab[ref_group(tgt)].drank_a[ref_index(tgt)];
-    const bool supply = W.any_kill_supply && tgt >= 0 && (unsigned)tgt_dr == my_rank;
+    const bool kill = W.any_kill_supply && tgt >= 0 && (unsigned)tgt_dr == my_rank;
+    // what my own attack feeds me at my rank (add_hp: capped at the type's hp even when it adds nothing): the kill supply,
+    // or in food_mode what I eat (the owner of the food says how much; -1 = my attack meets no food)
+    const float eaten = W.food_mode && attacker ? G.eat[i] : -1.0f;
+    const bool supply = kill || eaten >= 0.0f;
+    const float bonus = kill ? ttab[ref_group(tgt)].kill_supply : eaten;
 
     // ---- replay in rank order
     float hp = G.hp[i];
-    int dr = RANK_INF;
+    int dr = RANK_INF, kd = nh;                        // kd: which hit kills me
     bool supplied = !supply;
     for (int k = 0; k < nh; k++) {
         unsigned r = s_rank[k * ATT_THREADS + tid];
-        if (!supplied && my_rank < r) { hp = fminf(T.hp, hp + ttab[ref_group(tgt)].kill_supply); supplied = true; }
+        if (!supplied && my_rank < r) { hp = fminf(T.hp, hp + bonus); supplied = true; }
         int a = s_ref[k * ATT_THREADS + tid];
         const GroupDev A = gtab[ref_group(a)];
         int adr = A.drank_a[ref_index(a)];
         // the attacker is alive when its turn comes iff it did not die at an EARLIER rank.  adr == r happens only when
         // the attacker is this very agent hitting its own body (in-group attack of a body whose range covers its own
         // cells) and that hit is the fatal one: the attack did run (RANK_INF >= any rank)
-        if ((unsigned)adr >= r) {
+        if ((unsigned)adr >= r && (ref_group(a) != g || T.attack_in_group)) {   // (food_mode lists comrades' attacks too: no damage)
             hp -= ttab[ref_group(a)].damage;
-            if (hp < 0.0f) { dr = (int)r; break; }     // death iff hp < 0 strictly (GridWorld.h:205)
+            if (hp < 0.0f) { dr = (int)r; kd = k; break; }   // death iff hp < 0 strictly (GridWorld.h:205)
         }
     }
     // the kill supply of my own attack: normally skipped once I am dead -- except when I killed MYSELF, where
     // Map::do_attack still feeds the (dead) attacker (Map.cc:266-274)
     const bool self_kill = tgt == ref_pack(g, i) && (unsigned)dr == my_rank;
-    if (!supplied && (dr == RANK_INF || self_kill)) hp = fminf(T.hp, hp + ttab[ref_group(tgt)].kill_supply);
+    if (!supplied && (dr == RANK_INF || self_kill)) hp = fminf(T.hp, hp + bonus);
+
+    if (W.food_mode) {
+        // Killed: my food_supply lies on the cell the fatal hit landed on (the rest of my body is cleared), and the later
+        // hits on that cell eat from it, in rank order, until less than 0.1 is left (Map.cc:276-303).  Everybody else who
+        // hits me meets an agent or nothing: their `eat` goes back to -1.
+        int c_food = -1;
+        float food = 0.0f;
+        bool present = false;
+        if (kd < nh) { c_food = attack_cell(W, gtab, s_ref[kd * ATT_THREADS + tid]); food = T.food_supply; present = true; }
+        for (int k = 0; k < nh; k++) {
+            const int a = s_ref[k * ATT_THREADS + tid];
+            float e = -1.0f;
+            if (k > kd && present && attack_cell(W, gtab, a) == c_food) {
+                const unsigned r = s_rank[k * ATT_THREADS + tid];
+                if ((unsigned)gtab[ref_group(a)].drank_a[ref_index(a)] >= r) {       // alive at its turn
+                    e = fminf(ttab[ref_group(a)].eat_ability, food);
+                    food -= e;
+                    if ((double)food < 0.1) present = false;
+                }
+            }
+            set_eat(W, gtab, a, e, round, flag);
+        }
+        G.fcell[i] = present ? c_food : -1;
+        G.fleft[i] = food;
+    }
 
     G.mv[i] = __float_as_uint(hp);                    // for k_attack_apply: final once the death ranks are
     if (dr != dr_me_cur) {
         G.drank_a[i] = dr;
         // who reads my death rank: my target (is its attacker alive at that rank?) and, for the kill supply, my attackers
-        if (tgt >= 0) gtab[ref_group(tgt)].drank_b[ref_index(tgt)] = round;
+        const int reader = W.food_mode ? aimed : tgt;
+        if (reader >= 0) gtab[ref_group(reader)].drank_b[ref_index(reader)] = round;
         if (W.any_kill_supply)
             for (int k = 0; k < nh; k++) { const int a = s_ref[k * ATT_THREADS + tid]; gtab[ref_group(a)].drank_b[ref_index(a)] = round; }
         if (flag >= 0) W.counters[flag] = 1;          // only the last round of a batch reports
     }
+}
+
+// food_mode: the food that lay on the map before this step.  One thread per cell: the hits on a food cell eat from it
+// in rank order (Map.cc:292-303); evaluated in every round (an eater that turns out to be dead does not eat).
+__global__ void __launch_bounds__(256) k_food_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab, int round,
+                                                  const unsigned *hitbits, int kmax, int flag) {
+    if (W.counters[CTR_ATTACK] == 0) return;
+    extern __shared__ unsigned s_hit[];
+    const int NT = blockDim.x, tid = threadIdx.x;
+    unsigned *s_rank = s_hit;
+    int *s_ref = (int *)(s_hit + kmax * NT);
+    const int c = blockIdx.x * blockDim.x + tid;
+    if (c >= W.w * W.h || W.occ[c] != OCC_FOOD) return;
+    const unsigned bits = hitbits[c];
+    if (!bits) return;
+    const int cy = c / W.w, cx = c - cy * W.w;
+    const int nh = gather_hits(W, bits, cx, cy, s_rank, s_ref, NT, tid, 0);
+    sort_hits(s_rank, s_ref, NT, tid, nh);
+    float food = W.food[c];
+    bool present = true;
+    for (int k = 0; k < nh; k++) {
+        const int a = s_ref[k * NT + tid];
+        float e = -1.0f;
+        if (present && (unsigned)gtab[ref_group(a)].drank_a[ref_index(a)] >= s_rank[k * NT + tid]) {
+            e = fminf(ttab[ref_group(a)].eat_ability, food);
+            food -= e;
+            if ((double)food < 0.1) present = false;
+        }
+        set_eat(W, gtab, a, e, round, flag);
+    }
+    W.food_next[c] = present ? food : -1.0f;
+}
+
+__global__ void __launch_bounds__(256) k_food_apply(WorldView W, const unsigned *hitbits) {
+    if (W.counters[CTR_ATTACK] == 0 || attack_open(W)) return;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W.w * W.h || W.occ[c] != OCC_FOOD || !hitbits[c]) return;
+    const float left = W.food_next[c];
+    if (left < 0.0f) W.occ[c] = OCC_EMPTY; else W.food[c] = left;
 }
 
 // The converged phase applied: hp, death, rewards, last_op / op_obj.  Nothing is replayed here: every agent that is hit
@@ -771,11 +877,13 @@ __global__ void __launch_bounds__(256) k_attack_apply(WorldView W, const GroupDe
         }
         if (tgt >= 0) tgt_dr = gtab[ref_group(tgt)].drank_a[ref_index(tgt)];
     }
+    const float eaten = W.food_mode && attacker ? G.eat[i] : -1.0f;   // >= 0: my attack ate (food_mode)
     float hp;
     if (hit) hp = __uint_as_float(G.mv[i]);
-    else {                                            // nobody hit me: only my own kill can feed me (Map.cc:266-274)
+    else {                                            // nobody hit me: only my own kill, or what I eat, feeds me (Map.cc:266-303)
         hp = G.hp[i];
         if (W.any_kill_supply && tgt >= 0 && (unsigned)tgt_dr == my_rank) hp = fminf(T.hp, hp + ttab[ref_group(tgt)].kill_supply);
+        else if (eaten >= 0.0f) hp = fminf(T.hp, hp + eaten);
     }
     const bool self_kill = tgt == ref_pack(g, i) && (unsigned)dr == my_rank;
     float nr = G.next_reward[i];
@@ -783,7 +891,9 @@ __global__ void __launch_bounds__(256) k_attack_apply(WorldView W, const GroupDe
     bool acted = false;
     if (attacker && (unsigned)dr >= my_rank) {         // alive at my turn (GridWorld.cc:479-480)
         acted = true;
-        if (tgt < 0 || (unsigned)tgt_dr < my_rank) {   // blank, or the target died before my turn (Map.cc:229-231)
+        if (eaten >= 0.0f) {                           // food: do_attack returns 0.0 (Map.cc:292-303, GridWorld.cc:505)
+            own = 0.0f + T.attack_penalty;
+        } else if (tgt < 0 || (unsigned)tgt_dr < my_rank) {   // blank, or the target died before my turn (Map.cc:229-231)
             own = T.attack_penalty;
         } else {
             float reward = 0.0f;
@@ -830,7 +940,11 @@ __device__ __forceinline__ void starve_body(const WorldView &W, int g, const Gro
     // (and are counted here, one atomic per wave, together with the starved)
     if (i < G.n && W.counters[CTR_ATTACK] != 0) {
         const int dr = G.drank_a[i];
-        if (dr != -1 && dr != RANK_INF) { died = true; body_fill(W, G.x[i], G.y[i], T.bw, T.bl, OCC_EMPTY); }
+        if (dr != -1 && dr != RANK_INF) {
+            died = true;
+            body_fill(W, G.x[i], G.y[i], T.bw, T.bl, OCC_EMPTY);
+            if (W.food_mode && G.fcell[i] >= 0) { W.occ[G.fcell[i]] = OCC_FOOD; W.food[G.fcell[i]] = G.fleft[i]; }   // Map.cc:276-283
+        }
     }
     if (i < G.n && !G.dead[i]) {
         float hp = G.hp[i];
@@ -948,6 +1062,7 @@ __global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev
         } else {
             const int o = G.drank_b[i];
             int blocker;
+            if (o == OCC_FOOD) { G.pend[i] = PEND_NONE; return; }          // food blocks, but get_collide only sees agents (Map.cc:493)
             if (o == OCC_EMPTY) blocker = (int)(unsigned)W.claim[c];       // lost an empty cell to the lowest key
             else {
                 const GroupDev O = gtab[ref_group(o)];
@@ -1020,7 +1135,7 @@ __device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g,
             int occupant = -1;                       // who holds the cell when m's turn comes
             bool unknown = false;
             const int o = W.occ[c];
-            if (o == OCC_WALL) { r.blocked = true; continue; }   // walls block but are never a collide object
+            if (o == OCC_WALL || o == OCC_FOOD) { r.blocked = true; continue; }   // walls and food block but are never a collide object
             if (o >= 0 && o != self) {
                 const GroupDev O = gtab[ref_group(o)];
                 const int oi = ref_index(o);
@@ -1511,6 +1626,12 @@ void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab,
     const int ATT_THREADS = att_threads(kmax);
     size_t lds = (size_t)kmax * ATT_THREADS * 8;
     hipLaunchKernelGGL(k_attack_eval, grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, round, (const unsigned *)W.claim, kmax, flag);
+    if (W.food_mode) launch_food_iter(s, W, gtab, ttab, round, kmax, flag);   // the food cells are part of the same fixed point
+}
+void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag) {
+    const int NT = att_threads(kmax);
+    hipLaunchKernelGGL(k_food_eval, dim3((W.w * W.h + NT - 1) / NT), dim3(NT), (size_t)kmax * NT * 8, s, W, gtab, ttab, round,
+                       (const unsigned *)W.claim, kmax, flag);
 }
 void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev) {
     hipLaunchKernelGGL(k_attack_events, grid_all(W, 256), dim3(256), 0, s, W, ev);
@@ -1518,6 +1639,7 @@ void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev) {
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax) {
     (void)kmax;
     hipLaunchKernelGGL(k_attack_apply, grid_all(W, 256), dim3(256), 0, s, W, gtab, ttab, (const unsigned *)W.claim);
+    if (W.food_mode) hipLaunchKernelGGL(k_food_apply, dim3((W.w * W.h + 255) / 256), dim3(256), 0, s, W, (const unsigned *)W.claim);
 }
 
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab) {

@@ -56,6 +56,7 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, int *shuf_count, int *shuf_cursor, bool clear_hitbits);
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);
+void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag);
 void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev);
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);   // starve / recover, then the move candidates
 void launch_movg_prep(hipStream_t s, const WorldView &W);

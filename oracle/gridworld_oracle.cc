@@ -13,7 +13,7 @@
 // State is kept as per-group struct-of-arrays + a packed occupancy grid; the *order* of every loop that the
 // reference executes sequentially is kept literally, because the results depend on it.
 //
-// Scope: what SURVEY.md section 8 puts on the path -- no food_mode / turn_mode / goal_mode.  Reward rules
+// Scope: what SURVEY.md section 8 puts on the path -- no turn_mode / goal_mode.  Reward rules
 // are evaluated by the reference's recursive search over symbol bindings, literally (and/or/not over attack, kill,
 // collide, die, at, in; 'any', 'all' and fixed-index symbols); align / in_a_line abort with a message.
 #include <algorithm>
@@ -116,11 +116,12 @@ struct Rule {
 };
 struct Pending { int g, i, act; };
 
-const int EMPTY = -1, WALL = -2;
+const int EMPTY = -1, WALL = -2, FOOD = -3;   // FOOD: what a killed agent leaves behind in food_mode (Map.cc:276-283)
 
 struct World {
     int w = 0, h = 0, embedding = 0;
-    bool minimap = false, large_map = false;
+    bool minimap = false, large_map = false, food_mode = false;
+    std::vector<float> food;        // per cell: what is left of the food (cells whose occ_g is FOOD)
     int n_sep = 1;
     MinStd rng;
     std::map<std::string, AgentType> types;
@@ -132,7 +133,7 @@ struct World {
     int id_counter = 0;
 
     int cell(int x, int y) const { return y * w + x; }
-    int g2c(int g) const { return 1 + g * (minimap ? 3 : 2); }  // GridWorld.cc:915-924 (no food_mode)
+    int g2c(int g) const { return 1 + (food_mode ? 1 : 0) + g * (minimap ? 3 : 2); }  // GridWorld.cc:915-924
     int feature_size(int g) const { return embedding + groups[g].type->n_action + 1 + (minimap ? 2 : 0); }
 
     // Map.cc:454-470
@@ -141,7 +142,7 @@ struct World {
         for (int i = 0; i < bw; i++)
             for (int j = 0; j < bh; j++) {
                 int c = cell(x + i, y + j);
-                if (occ_g[c] == WALL) return false;
+                if (occ_g[c] == WALL || occ_g[c] == FOOD) return false;   // food is an occupier too
                 if (occ_g[c] >= 0 && !(occ_g[c] == self_g && occ_i[c] == self_i)) return false;
             }
         return true;
@@ -152,7 +153,7 @@ struct World {
     // Map.cc:108-115
     int add_wall(int x, int y) {
         int c = cell(x, y);
-        if (occ_g[c] >= 0) return 1;
+        if (occ_g[c] >= 0 || occ_g[c] == FOOD) return 1;
         occ_g[c] = WALL;
         return 0;
     }
@@ -194,7 +195,8 @@ int env_config_game(void *game, const char *key, void *p) {
     else if (k == "minimap_mode") e.minimap = *(bool *)p;
     else if (k == "embedding_size") e.embedding = *(int *)p;
     else if (k == "seed") e.rng.seed((unsigned long)*(int *)p);
-    else if (k == "food_mode" || k == "turn_mode" || k == "goal_mode") { if (*(bool *)p) fatal("%s is outside the hot-path scope", key); }
+    else if (k == "food_mode") e.food_mode = *(bool *)p;
+    else if (k == "turn_mode" || k == "goal_mode") { if (*(bool *)p) fatal("%s is outside the hot-path scope", key); }
     else if (k == "render_dir") {}
     else fatal("invalid argument in set_config: %s", key);
     return 0;
@@ -260,6 +262,7 @@ int env_reset(void *game) {
     e.move_sep.assign(e.n_sep, {});
     e.move_bound.clear(); e.attack_buf.clear();
     e.occ_g.assign((size_t)e.w * e.h, EMPTY); e.occ_i.assign((size_t)e.w * e.h, 0);
+    e.food.assign((size_t)e.w * e.h, 0.0f);
     for (int i = 0; i < e.w; i++) { e.add_wall(i, 0); e.add_wall(i, e.h - 1); }
     for (int i = 0; i < e.h; i++) { e.add_wall(0, i); e.add_wall(e.w - 1, i); }
     for (auto &g : e.groups) g.clear();
@@ -368,7 +371,7 @@ int env_get_observation(void *game, int group, float **bufs) {
             for (int y = sy; y <= ey; y++) {
                 const int vx = x - x1, vy = y - y1, c = e.cell(x, y), og = e.occ_g[c];
                 if (og == EMPTY || !t.view.in[vy * VW + vx]) continue;
-                const int ch = trans[og == WALL ? 0 : e.g2c(og)];
+                const int ch = trans[og == WALL ? 0 : og == FOOD ? 1 : e.g2c(og)];   // Map.h:35 wall 0, food 1
                 out[(vy * VW + vx) * C + ch] = 1;
                 if (og >= 0) out[(vy * VW + vx) * C + ch + 1] = e.groups[og].hp[e.occ_i[c]] / e.groups[og].type->hp;
             }
@@ -426,6 +429,15 @@ int env_step(void *game, int *done) {
         const int ox = A.x[p.i] + at.att_x_offset + at.attack.dx[p.act], oy = A.y[p.i] + at.att_y_offset + at.attack.dy[p.act];
         int tg = EMPTY, ti = 0;
         if (ox >= 0 && ox < e.w && oy >= 0 && oy < e.h) { tg = e.occ_g[e.cell(ox, oy)]; ti = e.occ_i[e.cell(ox, oy)]; }
+        if (tg == FOOD) {   // Map.cc:292-303: eat; the attack counts as one on an object (reward 0.0 + attack_penalty)
+            float &food = e.food[e.cell(ox, oy)];
+            const float add = std::min(at.eat_ability, food);
+            A.hp[p.i] = std::min(at.hp, A.hp[p.i] + add);
+            food -= add;
+            if (food < 0.1) e.occ_g[e.cell(ox, oy)] = EMPTY;
+            A.next_reward[p.i] += 0.0f + at.attack_penalty;
+            continue;
+        }
         if (tg < 0 || (!at.attack_in_group && tg == p.g)) { A.next_reward[p.i] += at.attack_penalty; continue; }
         Group &T = e.groups[tg]; AgentType &tt = *T.type;
         float reward = 0.0f;
@@ -436,6 +448,7 @@ int env_step(void *game, int *done) {
             e.remove_agent(tg, ti);
             T.dead_ct++;
             A.hp[p.i] = std::min(at.hp, A.hp[p.i] + tt.kill_supply);
+            if (e.food_mode) { e.occ_g[e.cell(ox, oy)] = FOOD; e.food[e.cell(ox, oy)] = tt.food_supply; }   // on the attacked cell only
             reward = tt.kill_reward;
         } else {
             A.last_op[p.i] = OP_ATTACK; A.op_obj[p.i] = ((int64_t)tg << 32) | (uint32_t)ti;

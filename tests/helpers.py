@@ -184,8 +184,9 @@ class Scenario(object):
                stream continues across reset, GridWorld.cc:72-118)"""
 
     def __init__(self, name, game, map_size, seed=12345, place=(), steps=10, action_seed=0, walls=0,
-                 acting=None, over=None, clear_every=1, obs_every=1, events=None):
+                 acting=None, over=None, clear_every=1, obs_every=1, events=None, settings=None):
         self.name, self.game, self.map_size, self.seed = name, game, map_size, seed
+        self.settings = settings or {}      # extra GridWorld settings (food_mode, ...) and, for custom games, type overrides
         self.place, self.steps, self.action_seed, self.walls = list(place), steps, action_seed, walls
         self.acting, self.over, self.clear_every, self.obs_every = acting, over or {}, clear_every, obs_every
         self.events = events or {}
@@ -194,8 +195,14 @@ class Scenario(object):
         if callable(self.game):
             return self.game()
         if isinstance(self.game, tuple):
-            return CUSTOM[self.game[0]](*self.game[1:])
-        return config_for(self.game, self.map_size, **self.over)
+            cfg = CUSTOM[self.game[0]](*self.game[1:])
+            for tname, attrs in self.over.items():
+                cfg.agent_type_dict[tname].update(attrs)
+        else:
+            cfg = config_for(self.game, self.map_size, **self.over)
+        if self.settings:
+            cfg.set(dict(self.settings))
+        return cfg
 
     def populate(self, env, place, walls):
         if walls:
@@ -284,13 +291,14 @@ _ATTACK_COUNT = {0: 0, 1: 4, 1.5: 8, 2: 12, 2.5: 20}
 def fuzz_scenario(seed):
     """a random game inside the engine's scope: 2-4 groups, random body sizes / ranges / hp / damage / recover /
     kill_supply / in-group attack, random rules (subject and object receivers, attack | kill | collide, pairs of events
-    joined by `&`), random map
+    joined by `&`), food_mode, random map
     shape, walls, densities, clear_dead cadence and non-acting groups -- for differential testing"""
     rs = np.random.RandomState(seed)
     G = int(rs.choice([2, 2, 2, 3, 3, 4]))
     w = int(rs.randint(12, 150))
     h = w if rs.rand() < 0.5 else int(rs.randint(12, 150))
     minimap, emb = bool(rs.rand() < 0.6), int(rs.choice([0, 3, 10]))
+    food_mode = False
     frac = lambda lo, hi: float(rs.randint(int(lo * 16), int(hi * 16) + 1)) / 16.0
     while True:
         specs = []
@@ -329,6 +337,8 @@ def fuzz_scenario(seed):
     def make():
         cfg = gw.Config()
         cfg.set({"map_width": w, "map_height": h, "minimap_mode": minimap, "embedding_size": emb})
+        if food_mode:
+            cfg.set({"food_mode": True})
         names = []
         for g, t in enumerate(specs):
             t = dict(t)
@@ -360,6 +370,11 @@ def fuzz_scenario(seed):
                                       "size": (int(rs.randint(2, w // 5 + 3)), int(rs.randint(2, h // 5 + 3)))}))
         place.append((g, "random", {"n": min(n, 4000)}))
     acting = [g for g in range(G) if rs.rand() < 0.85] or [0]
+    if rs.rand() < 0.3:           # food_mode: the killed leave food, attackers eat it
+        food_mode = True
+        for t in specs:
+            t["food_supply"] = float(rs.choice([0, 0.05, 1, 2.5, 6]))
+            t["eat_ability"] = float(rs.choice([0, 0.5, 1, 3]))
     if rs.rand() < 0.15:          # one group of goals (can_absorb); goals are never given actions (engine scope)
         goal = int(rs.randint(G))
         specs[goal]["can_absorb"] = True
@@ -455,6 +470,11 @@ def scenarios():
                  acting=[1, 2], action_seed=36, clear_every=2),
         Scenario("arrange_large", ("arrange", 125, True), 0, place=[rnd(0, 2500), rnd(1, 3500), rnd(2, 300)], steps=10,
                  acting=[1, 2], action_seed=37),
+        Scenario("battle_food", "battle", 24, place=[rnd(0, 160), rnd(1, 160)], steps=30, action_seed=38, settings={"food_mode": True},
+                 over={"small": {"hp": 4, "damage": 3, "step_recover": -0.05, "food_supply": 2.5, "eat_ability": 1}}),
+        Scenario("bodies_food", ("bodies", 48, 37), 0, walls=40, place=[rnd(0, 60), rnd(1, 90), rnd(2, 150)], steps=30, action_seed=39,
+                 settings={"food_mode": True},
+                 over={"big": {"food_supply": 6, "eat_ability": 2}, "mid": {"food_supply": 0.05, "eat_ability": 0.5}, "tiny": {"food_supply": 1, "eat_ability": 3}}),
         Scenario("battle_one_side", "battle", 12, place=[rnd(0, 60), rnd(1, 3)], steps=40, action_seed=14,
                  over={"small": {"damage": 12}}),
     ]
