@@ -160,3 +160,22 @@ def test_reference_wrapper_binds_to_the_new_library(hip_lib, tmp_path):
                        env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert p.returncode == 0, p.stderr
     assert p.stdout.strip() == "(13, 13, 7) (34,) (21,) 13"
+
+
+def test_font_provider_and_random_actor(tmp_path):
+    """small callers of the path: the 8x8 font of the arrange game's goal layouts, the random policy on numpy observations"""
+    from magent_amd.utility import FontProvider
+    from magent_amd.builtin.rule_model import RandomActor
+    path = tmp_path / "font.txt"
+    path.write_text("0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80\n" + "\n".join(["0x00, 0, 0, 0, 0, 0, 0, 0xFF"] * 2) + "\n")
+    font = FontProvider(str(path))
+    assert len(font.data) == 3 and [row.index(1) for row in font.get(0)] == list(range(8))     # bit j of row i = pixel (i, j)
+    assert font.get(chr(1))[7] == [1] * 8 and font.get(1)[0] == [0] * 8
+
+    class Env(object):
+        def get_action_space(self, handle):
+            return (9,)
+    a, b = RandomActor(Env(), 0, seed=3), RandomActor(Env(), 0, seed=3)
+    obs = (np.zeros((50, 3, 3, 2), np.float32), np.zeros((50, 4), np.float32))
+    x, y = a.infer_action(obs), b.infer_action(obs)
+    assert x.dtype == np.int32 and x.shape == (50,) and x.min() >= 0 and x.max() < 9 and np.array_equal(x, y)
