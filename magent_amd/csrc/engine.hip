@@ -202,7 +202,7 @@ Env::~Env() {
     use_device();
     (void)hipStreamSynchronize(stream);
     for (auto &g : groups) free_group(g);
-    dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_food); dfree(d_counters); dfree(d_gtab); dfree(d_ttab);
+    dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_food); dfree(d_powtab); dfree(d_counters); dfree(d_gtab); dfree(d_ttab);
     dfree(d_delta); dfree(d_mask); dfree(d_mini); dfree(d_minif); dfree(d_sums); dfree(d_rank); dfree(d_shuf); dfree(d_events); dfree(d_actions);
     dfree(d_stage_view); dfree(d_stage_feat); dfree(d_stage_small);
     if (pool) {
@@ -827,6 +827,19 @@ void Env::shuffle_buffers(int n_max) {
     }
     int nb = (n_max + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
     grow(d_sums, sums_cap, (size_t)nb, stream);
+    // powers of the minstd_rand0 multiplier for k_shuffle_draw: 16807^t (t < 256), then 16807^(256 h) up to h = n_max / 256 + 1
+    const size_t need = 256 + (size_t)n_max / 256 + 2;
+    if (need > powtab_cap) {
+        grow(d_powtab, powtab_cap, need, stream);
+        std::vector<unsigned> tab(powtab_cap);
+        const unsigned long long P = 2147483647ull;
+        tab[0] = 1;
+        for (int t = 1; t < 256; t++) tab[t] = (unsigned)(tab[t - 1] * 16807ull % P);
+        const unsigned long long step = tab[255] * 16807ull % P;
+        tab[256] = 1;
+        for (size_t h = 257; h < powtab_cap; h++) tab[h] = (unsigned)(tab[h - 1] * step % P);
+        HIP_OK(hipMemcpy(d_powtab, tab.data(), sizeof(unsigned) * powtab_cap, hipMemcpyHostToDevice));
+    }
 }
 
 void Env::push_rng() {
@@ -908,7 +921,7 @@ void Env::step_begin() {
         int *scount = d_shuf, *scur = d_shuf + seg, *sj = d_shuf + 2 * seg, *soff = d_shuf + 3 * seg, *slist = d_shuf + 4 * seg;
         {
             ProfScope p(*this, "attack");
-            launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank, (unsigned *)d_claim, (size_t)width * height);
+            launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
             launch_attack_rank(stream, W, d_rank, scount, scur, false);
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
@@ -963,7 +976,7 @@ void Env::step_begin() {
                 push_rng();
                 const size_t seg = shuf_cap / 5;
                 int *scount = d_shuf, *scur = d_shuf + seg, *sj = d_shuf + 2 * seg, *soff = d_shuf + 3 * seg, *slist = d_shuf + 4 * seg;
-                launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank, (unsigned *)d_claim, (size_t)width * height);
+                launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
             }
             launch_attack_rank(stream, W, d_rank, d_shuf, d_shuf + shuf_cap / 5, host_shuffle);
             attack_round = 0;

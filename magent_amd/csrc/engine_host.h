@@ -201,6 +201,7 @@ private:
     int *d_sums = nullptr; size_t sums_cap = 0;
     int *d_rank = nullptr, *h_rank = nullptr; size_t rank_cap = 0, hrank_cap = 0;
     int *d_shuf = nullptr; size_t shuf_cap = 0;
+    unsigned *d_powtab = nullptr; size_t powtab_cap = 0;   // powers of 16807 for the shuffle draws
     int *d_actions = nullptr; size_t actions_cap = 0;
     float *d_stage_view = nullptr, *d_stage_feat = nullptr; size_t stage_view_cap = 0, stage_feat_cap = 0;
     unsigned char *d_stage_small = nullptr; size_t stage_small_cap = 0;

@@ -551,14 +551,16 @@ __device__ __forceinline__ unsigned mulmod31(unsigned a, unsigned b) {
     return (unsigned)(r >= 0x7FFFFFFFull ? r - 0x7FFFFFFFull : r);
 }
 
-__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *count, unsigned *hitbits, size_t ncell) {
+// powtab: 16807^t mod (2^31 - 1) for t = 0..255, then 16807^(256 h) for h = 0, 1, ... (host-computed, engine.hip)
+__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *count, unsigned *hitbits, size_t ncell,
+                                                     const unsigned *powtab) {
     const int A = counters[CTR_ATTACK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     // the per-cell hit words of the coming attack phase start from zero (they share the move phase's claim array)
     if (A > 0) for (size_t c = i; c < ncell; c += (size_t)gridDim.x * blockDim.x) hitbits[c] = 0u;
     if (i >= A) return;
-    unsigned e = (unsigned)i + 1u, base = 16807u, acc = (unsigned)counters[CTR_RNG];
-    while (e) { if (e & 1u) acc = mulmod31(acc, base); base = mulmod31(base, base); e >>= 1; }
+    const unsigned e = (unsigned)i + 1u;               // the i-th draw is x0 * 16807^(i+1): two table factors
+    const unsigned acc = mulmod31(mulmod31((unsigned)counters[CTR_RNG], powtab[256 + (e >> 8)]), powtab[e & 255u]);
     int ji = (int)(acc % (unsigned)(i + 1));   // (int)rng() % (i + 1): outputs are in [1, 2^31 - 2]
     j[i] = ji;
     atomicAdd(&count[ji], 1);
@@ -1592,11 +1594,11 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
 
 // n_max = upper bound of the attack-list length (the number of agents); the actual length is read on the device
 void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank,
-                    unsigned *hitbits, size_t ncell) {
+                    unsigned *hitbits, size_t ncell, const unsigned *powtab) {
     // count / cursor are zero here: zeroed when allocated, and again by k_attack_rank after every use
     dim3 g((n_max + 255) / 256), b(256);
     int nb = (n_max + ISCAN_TILE - 1) / ISCAN_TILE;
-    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, j, count, hitbits, ncell);
+    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, j, count, hitbits, ncell, powtab);
     if (n_max <= SOLO_MAX) {
         hipLaunchKernelGGL(k_iscan_solo, dim3(1), dim3(SOLO_THREADS), 0, s, count, n_max, offset);
     } else {
