@@ -141,12 +141,23 @@ void CopyPool::copy(void *d, const void *s, size_t b) {
 // Device buffer -> the caller's pageable host buffer (the reference ABI hands numpy arrays).  A plain hipMemcpy to
 // pageable memory measured 11 GB/s; here 32 MiB chunks are DMA'd into a ring of pinned buffers on a second stream
 // while worker threads drain the previous chunk into the destination.
-void Env::copy_out(void *host_dst, const void *dev_src, size_t bytes) {
-    if (bytes < (8u << 20)) {
-        HIP_OK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipStreamSynchronize(stream));
-        return;
+// Small read-backs go through a pinned bounce buffer of the engine's own and are handed to the caller's (pageable)
+// memory by the calling thread, after the stream has been waited for: nothing outside this function ever writes into
+// the caller's buffer, and nothing writes into it after the call has returned.
+void Env::read_back(void *host_dst, const void *dev_src, size_t bytes) {
+    if (bytes == 0) return;
+    if (bytes > h_small_cap) {
+        if (h_small) HIP_OK(hipHostFree(h_small));
+        h_small_cap = std::max<size_t>(bytes, std::max<size_t>(h_small_cap * 2, 1u << 16));
+        HIP_OK(hipHostMalloc((void **)&h_small, h_small_cap, hipHostMallocDefault));
     }
+    HIP_OK(hipMemcpyAsync(h_small, dev_src, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    std::memcpy(host_dst, h_small, bytes);
+}
+
+void Env::copy_out(void *host_dst, const void *dev_src, size_t bytes) {
+    if (bytes < (8u << 20)) { read_back(host_dst, dev_src, bytes); return; }
     if (!pool) {
         unsigned hw = std::thread::hardware_concurrency();
         int nt = (int)std::max(2u, std::min(16u, hw / 4));
@@ -211,6 +222,7 @@ Env::~Env() {
         (void)hipStreamDestroy(copy_stream);
     }
     if (h_counters) (void)hipHostFree(h_counters);
+    if (h_small) (void)hipHostFree(h_small);
     if (h_rank) (void)hipHostFree(h_rank);
     for (auto &kv : prof) for (auto &p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto ev : prof_pool) (void)hipEventDestroy(ev);
@@ -338,7 +350,8 @@ void Env::add_reward_rule(int on, int *recv, float *val, int n, bool terminal) {
 // translate the accepted rule shapes into kernel arguments; anything else is refused loudly
 void Env::compile_rules() {
     rule_args.clear();
-    if ((int)rules.size() > CTR_TOTAL - CTR_TRIGGER) fatal("too many reward rules");
+    rule_progs.clear();
+    if ((int)rules.size() > CTR_TRIGGER_END - CTR_TRIGGER) fatal("too many reward rules");
     for (size_t k = 0; k < rules.size(); k++) {
         const HostRule &r = rules[k];
         if (r.on < 0 || r.on >= (int)nodes.size()) fatal("reward rule %zu refers to an undefined event", k);
@@ -355,10 +368,13 @@ void Env::compile_rules() {
             on.raw[1] < (int)nodes.size() && binary(nodes[on.raw[0]]) && binary(nodes[on.raw[1]])) {
             // Event(a, p, c) & Event(b, q, c): "two agents act on the same third" (builtin/config/double_attack.py:33-40)
             const HostNode *e1 = &nodes[on.raw[0]], *e2 = &nodes[on.raw[1]];
-            if (e1->raw[1] != e2->raw[1] || e1->raw[0] == e2->raw[0] || e1->raw[0] == e1->raw[1] || e2->raw[0] == e2->raw[1])
-                fatal("reward rule %zu: `&` is on the GPU path for Event(a, p, c) & Event(b, q, c) with distinct symbols a, b, c", k);
+            if (e1->raw[1] != e2->raw[1] || e1->raw[0] == e2->raw[0] || e1->raw[0] == e1->raw[1] || e2->raw[0] == e2->raw[1]) {
+                compile_rule_program(k);   // not "two agents on one object": a general expression, if its search iterates one symbol
+                continue;
+            }
             if (e2->raw[0] < e1->raw[0]) std::swap(e1, e2);   // the search binds symbols in ascending number (RewardEngine.cc:155-189)
             RuleArgs a{};
+            a.prog = -1;
             a.pair = 1; a.rule_no = (int)k;
             a.ga = any_sym(e1->raw[0]); a.op = e1->op;
             a.gy = any_sym(e2->raw[0]); a.op_y = e2->op;
@@ -377,9 +393,10 @@ void Env::compile_rules() {
             rule_args.push_back(a);
             continue;
         }
-        if (!binary(on))
-            fatal("reward rule %zu: only Event(a, attack|kill|collide, b) and Event(a, p, c) & Event(b, q, c) are on the GPU path "
-                  "(SURVEY.md 8a row a8)", k);
+        if (!binary(on)) {   // a general expression: on the GPU path when its search iterates a single symbol
+            compile_rule_program(k);
+            continue;
+        }
         const HostSymbol &sa = symbols[on.raw[0]], &sb = symbols[on.raw[1]];
         if (sa.index != -1 || sb.index != -1) fatal("reward rule %zu: only 'any' agent symbols are on the GPU path", k);
         if (sa.group < 0 || sa.group >= (int)groups.size() || sb.group < 0 || sb.group >= (int)groups.size())
@@ -388,6 +405,7 @@ void Env::compile_rules() {
         // (RewardEngine.cc:17-24, 405-408) and then tests the target against itself -- the rule can never fire
         if (on.raw[0] == on.raw[1]) continue;
         RuleArgs a{};
+        a.prog = -1;
         a.ga = sa.group; a.gb = sb.group; a.op = on.op; a.rule_no = (int)k;
         for (size_t i = 0; i < r.recv.size(); i++) {
             if (r.recv[i] == on.raw[0]) { if (a.n_subj == 4) fatal("too many receivers"); a.v_subj[a.n_subj++] = r.val[i]; }
@@ -398,6 +416,90 @@ void Env::compile_rules() {
             fatal("reward rule %zu: subject and object receivers in the same group interleave float adds; not on the GPU path", k);
         rule_args.push_back(a);
     }
+}
+
+// A rule whose event is a general expression (and / or / not over attack, kill, collide, die, at, in).  The reference
+// plans its search per rule (GridWorld::init_reward_description, RewardEngine.cc:105-214): the symbols of the expression
+// in ascending number; a symbol that is the subject of a binary event brings that event's object along ("inferred":
+// bound to the subject's op_obj instead of being iterated).  The GPU path takes the rules whose plan iterates ONE
+// symbol -- every other symbol is its inferred object -- and evaluates the expression per agent (k_rule_prog).
+void Env::compile_rule_program(size_t k) {
+    const HostRule &r = rules[k];
+    struct Info { std::vector<int> related; std::vector<std::pair<int, int>> infer; };
+    std::function<Info(int)> collect = [&](int no) -> Info {
+        if (no < 0 || no >= (int)nodes.size()) fatal("reward rule %zu refers to an undefined event", k);
+        const HostNode &n = nodes[no];
+        Info I;
+        auto add_sym = [&](int s2) { if (std::find(I.related.begin(), I.related.end(), s2) == I.related.end()) I.related.push_back(s2); };
+        auto add_inf = [&](std::pair<int, int> p) { for (auto &q : I.infer) if (q.first == p.first) return; I.infer.push_back(p); };
+        if (n.op == 0 || n.op == 1 || n.op == 2) {
+            const size_t kids = n.op == 2 ? 1 : 2;
+            if (n.raw.size() < kids) fatal("reward rule %zu: malformed event node", k);
+            for (size_t c = 0; c < kids; c++) {
+                Info C = collect(n.raw[c]);
+                for (int s2 : C.related) add_sym(s2);
+                for (auto &p : C.infer) add_inf(p);
+            }
+        } else if (n.op == OP_KILL || n.op == OP_COLLIDE || n.op == OP_ATTACK) {
+            add_sym(n.raw[0]); add_sym(n.raw[1]); add_inf({n.raw[0], n.raw[1]});
+        } else if (n.op == 4 || n.op == 5 || n.op == 8) {   // at, in, die
+            add_sym(n.raw[0]);
+        } else fatal("reward rule %zu: event predicate %d (in_a_line / align) is not on the GPU path", k, n.op);
+        std::sort(I.related.begin(), I.related.end());
+        std::sort(I.infer.begin(), I.infer.end());
+        return I;
+    };
+    const Info I = collect(r.on);
+    std::vector<int> iterated, inferred, added;
+    auto has = [&](int s2) { return std::find(added.begin(), added.end(), s2) != added.end(); };
+    for (int s2 : I.related) {
+        if (has(s2)) continue;
+        for (auto &p : I.infer) if (p.first == s2) { iterated.push_back(s2); inferred.push_back(p.second); added.push_back(s2); added.push_back(p.second); break; }
+    }
+    for (int s2 : I.related) if (!has(s2)) { iterated.push_back(s2); inferred.push_back(-1); }
+    if (iterated.size() != 1)
+        fatal("reward rule %zu: its search iterates %zu agent symbols; the GPU path takes rules that iterate one symbol "
+              "(plus Event(a, p, c) & Event(b, q, c))", k, iterated.size());
+    const int sx = iterated[0], sy = inferred[0];
+    if (sy == sx) fatal("reward rule %zu: an event whose subject is its own object is not on the GPU path", k);
+    auto group_of = [&](int no) {
+        if (no < 0 || no >= (int)symbols.size()) fatal("reward rule %zu refers to an undefined agent symbol", k);
+        if (symbols[no].index != -1) fatal("reward rule %zu: only 'any' agent symbols are on the GPU path", k);
+        if (symbols[no].group < 0 || symbols[no].group >= (int)groups.size()) fatal("reward rule %zu: invalid group in agent symbol", k);
+        return symbols[no].group;
+    };
+    RuleProg P{};
+    P.ga = group_of(sx); P.has_obj = sy >= 0; P.gb = sy >= 0 ? group_of(sy) : 0; P.rule_no = (int)k;
+    auto slot = [&](int no) { if (no == sx) return 0; if (no == sy) return 1; fatal("reward rule %zu: internal: unplanned symbol", k); return 0; };
+    std::function<void(int)> emit = [&](int no) {
+        const HostNode &n = nodes[no];
+        if (n.op == 0 || n.op == 1) { emit(n.raw[0]); emit(n.raw[1]); }
+        else if (n.op == 2) emit(n.raw[0]);
+        if (P.n == 24) fatal("reward rule %zu: expression too long", k);
+        P.op[P.n] = n.op;
+        if (n.op == OP_KILL || n.op == OP_COLLIDE || n.op == OP_ATTACK) { P.a[P.n][0] = slot(n.raw[0]); P.a[P.n][1] = slot(n.raw[1]); }
+        else if (n.op == 4 || n.op == 5 || n.op == 8) {
+            P.a[P.n][0] = slot(n.raw[0]);
+            const size_t want = n.op == 4 ? 3 : n.op == 5 ? 5 : 1;
+            if (n.raw.size() < want) fatal("reward rule %zu: malformed event node", k);
+            for (size_t q = 1; q < want; q++) P.a[P.n][q] = n.raw[q];
+        }
+        P.n++;
+    };
+    emit(r.on);
+    RuleArgs a{};
+    a.prog = (int)rule_progs.size(); a.rule_no = (int)k; a.ga = P.ga; a.gb = P.gb;
+    for (size_t i = 0; i < r.recv.size(); i++) {
+        if (r.recv[i] == sx) { if (P.n_subj == 4) fatal("too many receivers"); P.v_subj[P.n_subj++] = r.val[i]; }
+        else if (r.recv[i] == sy && sy >= 0) { if (P.n_obj == 4) fatal("too many receivers"); P.v_obj[P.n_obj++] = r.val[i]; }
+        else fatal("reward rule %zu: a receiver must be a symbol of the event", k);
+    }
+    if (P.n_subj && P.n_obj && P.ga == P.gb)
+        fatal("reward rule %zu: subject and object receivers in the same group interleave float adds; not on the GPU path", k);
+    a.n_obj = P.n_obj;
+    for (int q = 0; q < P.n_obj; q++) a.v_obj[q] = P.v_obj[q];
+    rule_progs.push_back(P);
+    rule_args.push_back(a);
 }
 
 // ------------------------------------------------------------------------------------------------ device buffers
@@ -884,7 +986,7 @@ void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 
         move_rounds_checked(W);
     }
     if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
-    launch_rules(stream, W, rule_args.data(), (int)rule_args.size());
+    launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
     if (any_multicell) launch_finish(stream, W);   // (the 1x1 move commit already consumed the pending actions)
 }
 
@@ -945,7 +1047,7 @@ void Env::step_begin() {
         }
         {
             ProfScope p(*this, "rules");
-            launch_rules(stream, W, rule_args.data(), (int)rule_args.size());
+            launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
             if (any_multicell) launch_finish(stream, W);
         }
         enqueue_counters();
@@ -985,8 +1087,7 @@ void Env::step_begin() {
                 grow(d_events, events_cap, (size_t)A, stream);
                 launch_attack_events(stream, W, d_events);
                 std::vector<int4> ev(A);
-                HIP_OK(hipMemcpyAsync(ev.data(), d_events, sizeof(int4) * A, hipMemcpyDeviceToHost, stream));
-                HIP_OK(hipStreamSynchronize(stream));
+                read_back(ev.data(), d_events, sizeof(int4) * A);
                 attack_events.clear();
                 for (const int4 &e : ev) if (e.w) attack_events.push_back({e.x, e.y, e.z});
             }
@@ -1000,7 +1101,7 @@ void Env::step_begin() {
         }
         {
             ProfScope p(*this, "rules");
-            launch_rules(stream, W, rule_args.data(), (int)rule_args.size());
+            launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
             if (any_multicell) launch_finish(stream, W);
         }
         enqueue_counters();
@@ -1065,8 +1166,7 @@ void Env::get_reward_host(int g, float *out) {
     if (n == 0) return;
     grow(d_stage_small, stage_small_cap, (size_t)n * 8, stream);
     get_reward_device(g, (float *)d_stage_small);
-    HIP_OK(hipMemcpyAsync(out, d_stage_small, sizeof(float) * n, hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
+    read_back(out, d_stage_small, sizeof(float) * n);
 }
 
 // GridWorld::clear_dead (GridWorld.cc:633-665)
@@ -1177,8 +1277,7 @@ void Env::info_host(int g, const char *name, void *buf) {
         size_t bytes = k == "pos" ? sizeof(int) * 2 * n : k == "alive" ? (size_t)n : sizeof(int) * n;
         grow(d_stage_small, stage_small_cap, (size_t)n * 8, stream);
         info_device(g, name, d_stage_small);
-        HIP_OK(hipMemcpyAsync(buf, d_stage_small, bytes, hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipStreamSynchronize(stream));
+        read_back(buf, d_stage_small, bytes);
         return;
     }
     if (k == "walls_info") {

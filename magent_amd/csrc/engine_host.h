@@ -143,6 +143,7 @@ private:
     bool read_changed();
     void clear_changed();
     void compile_rules();
+    void compile_rule_program(size_t k);
     void enqueue_counters();
     bool step_pending = false, step_was_fast = false;
     void shuffle_buffers(int n_max);
@@ -157,6 +158,8 @@ private:
     void host_random_blank(int bw, int bl, int &ox, int &oy);
     void plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *feat);
     void copy_out(void *host_dst, const void *dev_src, size_t bytes);
+    void read_back(void *host_dst, const void *dev_src, size_t bytes);
+    char *h_small = nullptr; size_t h_small_cap = 0;   // pinned bounce buffer of read_back
     int n_channel() const;
     int feature_size(int g) const;
 
@@ -179,6 +182,7 @@ private:
     std::vector<HostNode> nodes;
     std::vector<HostRule> rules;
     std::vector<RuleArgs> rule_args;
+    std::vector<RuleProg> rule_progs;   // general single-iterator expressions (compile_rule_program)
     bool rules_compiled = false;
     int id_counter = 0, any_kill_supply = 0, any_multicell = 0, any_absorb = 0, move_seq_base = 0, attack_kmax = 1;
 

@@ -1344,6 +1344,62 @@ __global__ void __launch_bounds__(256) k_rule_obj(WorldView W, RuleArgs A) {
     G.hits[i] = 0;
 }
 
+// General single-iterator rule (launch.h RuleProg): agent i of group ga is bound to x; if the expression has a second
+// symbol y, it is bound to i's op_obj, and i is skipped when it has none or one of another group
+// (RewardEngine.cc:246-262).  The expression is evaluated on that binding; receivers: x adds in place, y is counted
+// and replayed by k_rule_obj.
+__global__ void __launch_bounds__(256) k_rule_prog(WorldView W, const GroupDev *gtab, RuleProg P) {
+    if (step_open(W)) return;
+    const GroupDev G = W.grp[P.ga];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool trig = false;
+    if (i < G.n) {
+        int ent[2] = {ref_pack(P.ga, i), -1};
+        bool bound = true;
+        if (P.has_obj) {
+            const int o = G.op_obj[i];
+            bound = o >= 0 && ref_group(o) == P.gb;
+            ent[1] = o;
+        }
+        if (bound) {
+            unsigned stack = 0;                       // bit k = value k of the evaluation stack
+            int sp = 0;
+            for (int k = 0; k < P.n; k++) {
+                const int op = P.op[k];
+                bool v;
+                if (op == 0 || op == 1) {              // and / or
+                    const bool b1 = (stack >> (sp - 1)) & 1u, b0 = (stack >> (sp - 2)) & 1u;
+                    sp -= 2;
+                    v = op == 0 ? (b0 && b1) : (b0 || b1);
+                } else if (op == 2) {                  // not
+                    sp -= 1;
+                    v = !((stack >> sp) & 1u);
+                } else {
+                    const int e = ent[P.a[k][0]];
+                    const GroupDev S = gtab[ref_group(e)];
+                    const int si = ref_index(e);
+                    if (op == 8) v = S.dead[si] != 0;                                                  // die
+                    else if (op == 4) v = S.x[si] == P.a[k][1] && S.y[si] == P.a[k][2];                // at
+                    else if (op == 5) v = S.x[si] > P.a[k][1] && S.x[si] < P.a[k][3] && S.y[si] > P.a[k][2] && S.y[si] < P.a[k][4];   // in
+                    else v = S.last_op[si] == op && S.op_obj[si] == ent[P.a[k][1]];                    // kill / collide / attack
+                }
+                stack = (stack & ~(1u << sp)) | ((v ? 1u : 0u) << sp);
+                sp++;
+            }
+            if (stack & 1u) {
+                trig = true;
+                if (P.n_subj) {
+                    float nr = G.next_reward[i];
+                    for (int k = 0; k < P.n_subj; k++) nr += P.v_subj[k];
+                    G.next_reward[i] = nr;
+                }
+                if (P.n_obj) atomicAdd(&gtab[P.gb].hits[ref_index(ent[1])], 1);
+            }
+        }
+    }
+    if (__ballot(trig) && lane_id() == 0) W.counters[CTR_TRIGGER + P.rule_no] = 1;
+}
+
 // Event(x, op, c) & Event(y, op_y, c): the reference's search (RewardEngine.cc:216-306) binds x over its group, then y
 // over its group skipping the agent bound to x, re-binds c to y's target, and pays the receivers once per ordered
 // pair (i, j) with  last_op[i] == op, last_op[j] == op_y, op_obj[i] == op_obj[j] in c's group.  Per agent t that is
@@ -1692,14 +1748,23 @@ void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A) {
 }
 // all rules of a step, in order.  Consecutive subject-only rules that pay different groups touch disjoint rewards: their
 // order among each other is not observable and they share one launch.
-void launch_rules(hipStream_t s, const WorldView &W, const RuleArgs *rules, int n) {
+void launch_rules(hipStream_t s, const WorldView &W, const RuleArgs *rules, int n, const RuleProg *progs, const GroupDev *gtab) {
     for (int k = 0; k < n;) {
+        if (rules[k].prog >= 0) {
+            const RuleProg &P = progs[rules[k].prog];
+            const int na = W.grp[P.ga].n;
+            if (na > 0) hipLaunchKernelGGL(k_rule_prog, dim3((na + 255) / 256), dim3(256), 0, s, W, gtab, P);
+            if (P.n_obj && na > 0 && W.grp[P.gb].n > 0)
+                hipLaunchKernelGGL(k_rule_obj, dim3((W.grp[P.gb].n + 255) / 256), dim3(256), 0, s, W, rules[k]);
+            k++;
+            continue;
+        }
         RuleBatch B{};
         int m = 0, mx = 0;
         unsigned paid = 0;
         while (k + m < n && m < 4) {
             const RuleArgs &a = rules[k + m];
-            if (a.pair || a.n_obj || (paid >> a.ga & 1u)) break;
+            if (a.pair || a.prog >= 0 || a.n_obj || (paid >> a.ga & 1u)) break;
             paid |= 1u << a.ga;
             B.r[m++] = a;
             mx = std::max(mx, W.grp[a.ga].n);

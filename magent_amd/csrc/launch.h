@@ -40,6 +40,17 @@ struct RuleArgs {
     float v_subj[4], v_obj[4];
     int pair, gy, op_y, n_y;
     float v_y[4];
+    int prog;                     // >= 0: index of the rule's RuleProg (a general single-iterator expression), else -1
+};
+
+// A rule whose search iterates ONE 'any' symbol x (group ga); a second symbol y, if any, is inferred as x's op_obj
+// (group gb).  The event expression in postfix: leaves test x (slot 0) or y (slot 1), and / or / not combine them.
+struct RuleProg {
+    int ga, gb, has_obj, rule_no, n_subj, n_obj;
+    float v_subj[4], v_obj[4];
+    int n;
+    int op[24];                   // EventOp: 0 and, 1 or, 2 not, 3 kill, 4 at, 5 in, 6 collide, 7 attack, 8 die
+    int a[24][5];                 // kill / collide / attack: {subject slot, object slot}; at: {slot, x, y}; in: {slot, x1, y1, x2, y2}; die: {slot}
 };
 
 void launch_set_tables(hipStream_t s, const WorldView &W, GroupDev *gtab, TypeDev *ttab);
@@ -65,7 +76,7 @@ void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag);
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A);
-void launch_rules(hipStream_t s, const WorldView &W, const RuleArgs *rules, int n);
+void launch_rules(hipStream_t s, const WorldView &W, const RuleArgs *rules, int n, const RuleProg *progs, const GroupDev *gtab);
 void launch_finish(hipStream_t s, const WorldView &W);
 void launch_get_reward(hipStream_t s, const GroupDev &G, float group_reward, float *out);
 void launch_get_pos(hipStream_t s, const GroupDev &G, int *out);

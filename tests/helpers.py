@@ -172,7 +172,31 @@ def custom_arrange(map_size, live):
     return cfg
 
 
-CUSTOM = {"arrange": custom_arrange, "duo": custom_duo, "trans": custom_trans, "tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
+def custom_rules(map_size):
+    """rule expressions beyond Event(a, p, b): die / at / in leaves and and / or / not over them, for searches that iterate a
+    single symbol (the partner of a binary event is inferred from the subject's op_obj); one rule ends the game"""
+    cfg = gw.Config()
+    cfg.set({"map_width": map_size, "map_height": map_size, "minimap_mode": True, "embedding_size": 6})
+    t = cfg.register_agent_type("r", dict(width=1, length=1, hp=3, speed=2, view_range=gw.CircleRange(4), attack_range=gw.CircleRange(1.5),
+                                          damage=2, step_recover=-0.02, step_reward=-0.01, kill_reward=1, dead_penalty=-0.5, attack_penalty=-0.05))
+    big = cfg.register_agent_type("b", dict(width=2, length=2, hp=9, speed=1, view_range=gw.CircleRange(3), attack_range=gw.CircleRange(2),
+                                            damage=1.5, attack_in_group=1))
+    g0, g1, g2 = cfg.add_group(t), cfg.add_group(t), cfg.add_group(big)
+    a, b, c = gw.AgentSymbol(g0, "any"), gw.AgentSymbol(g1, "any"), gw.AgentSymbol(g2, "any")
+    b2, c2 = gw.AgentSymbol(g1, "any"), gw.AgentSymbol(g2, "any")
+    ev = gw.Event
+    half = map_size // 2
+    cfg.add_reward_rule(ev(a, "die"), receiver=a, value=-0.7)
+    cfg.add_reward_rule(ev(a, "in", ((1, 1), (half, half))) & ~ev(a, "die"), receiver=a, value=0.11)
+    cfg.add_reward_rule(ev(a, "attack", b) & ev(b, "attack", a), receiver=[a, b], value=[0.9, -0.3])         # duel
+    cfg.add_reward_rule(ev(b2, "kill", c) | ev(b2, "collide", c), receiver=[b2, c, b2], value=[0.4, -0.2, 0.05])
+    cfg.add_reward_rule(~ev(c2, "attack", a) & ev(c2, "in", ((half, 0), (map_size, map_size))), receiver=c2, value=0.021)
+    cfg.add_reward_rule(ev(b, "at", (half, half)), receiver=b, value=5, terminal=True)
+    cfg.add_reward_rule(ev(a, "kill", c) & ev(c, "die"), receiver=[c, a], value=[-1.5, 2.5])
+    return cfg
+
+
+CUSTOM = {"rules": custom_rules, "arrange": custom_arrange, "duo": custom_duo, "trans": custom_trans, "tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
 
 
 class Scenario(object):
@@ -334,6 +358,73 @@ def fuzz_scenario(seed):
         pair_rules.append((a, b, str(rs.choice(["attack", "attack", "kill"])), str(rs.choice(["attack", "attack", "kill"])), c,
                            who, [frac(-1, 1) for _ in who], bool(rs.rand() < 0.5)))
 
+    # expressions the engine takes: and / or / not over die / at / in / attack / kill / collide whose search iterates ONE symbol x
+    # (a second symbol y only as the partner of a binary event with x)
+    prog_rules = []
+    for _ in range(int(rs.choice([0, 0, 1, 1, 2]))):
+        gx, gy = int(rs.randint(G)), int(rs.randint(G))
+        two = bool(rs.rand() < 0.6)
+        def pleaf(force_binary=False):
+            kind = "bin" if force_binary else str(rs.choice(["die", "at", "in", "bin", "bin"] if two else ["die", "at", "in"]))
+            who = int(rs.randint(2)) if two else 0
+            if kind == "die":
+                return ("die", who)
+            if kind == "at":
+                return ("at", who, (int(rs.randint(1, w - 1)), int(rs.randint(1, h - 1))))
+            if kind == "in":
+                return ("in", who, ((int(rs.randint(0, w)), int(rs.randint(0, h))), (int(rs.randint(0, w)), int(rs.randint(0, h)))))
+            return (str(rs.choice(["attack", "kill", "collide"])), who, 1 - who)
+        def ptree(depth):
+            if depth == 0 or rs.rand() < 0.4:
+                return pleaf()
+            op = str(rs.choice(["and", "or", "not"]))
+            return (op, ptree(depth - 1)) if op == "not" else (op, ptree(depth - 1), ptree(depth - 1))
+        expr = ptree(2)
+        def has_binary(e):
+            return e[0] in ("attack", "kill", "collide") or (e[0] in ("and", "or", "not") and any(has_binary(c) for c in e[1:]))
+        if two and not has_binary(expr):
+            expr = (str(rs.choice(["and", "or"])), expr, pleaf(force_binary=True))
+        who = str(rs.choice(["x", "x", "y", "xy", "yx", "xx"])) if two else str(rs.choice(["x", "xx"]))
+        if two and gx == gy and "x" in who and "y" in who:
+            who = "x"
+        prog_rules.append((gx, gy, two, expr, who, [frac(-1, 1) for _ in who], bool(rs.rand() < 0.05)))
+
+    # FUZZ_RULES=1 (oracle-vs-reference runs only: the engine refuses these shapes): random expressions over die / at / in and
+    # the binary events, joined by & | ~ -- they pin the oracle's literal restatement of the recursive rule search
+    tree_rules = []
+    if os.environ.get("FUZZ_RULES", "0") == "1":
+        for _ in range(int(rs.randint(1, 4))):
+            syms = [int(rs.randint(G)) for _ in range(int(rs.randint(1, 4)))]      # group of each symbol
+            def leaf():
+                kind = str(rs.choice(["die", "at", "in", "bin", "bin"]))
+                a = int(rs.randint(len(syms)))
+                if kind == "die":
+                    return ("die", a)
+                if kind == "at":
+                    return ("at", a, (int(rs.randint(1, w - 1)), int(rs.randint(1, h - 1))))
+                if kind == "in":
+                    return ("in", a, ((int(rs.randint(0, w)), int(rs.randint(0, h))), (int(rs.randint(0, w)), int(rs.randint(0, h)))))
+                b = int(rs.randint(len(syms)))
+                return (str(rs.choice(["attack", "kill", "collide"])), a, b)
+            def tree(depth):
+                if depth == 0 or rs.rand() < 0.4:
+                    return leaf()
+                op = str(rs.choice(["and", "or", "not"]))
+                return (op, tree(depth - 1)) if op == "not" else (op, tree(depth - 1), tree(depth - 1))
+            expr = tree(2)
+            used = set()
+            def collect(e):
+                if e[0] in ("and", "or", "not"):
+                    for c in e[1:]:
+                        collect(c)
+                else:
+                    used.add(e[1])
+                    if e[0] in ("attack", "kill", "collide"):
+                        used.add(e[2])
+            collect(expr)
+            recv = [k for k in sorted(used) if rs.rand() < 0.7] or [sorted(used)[0]]
+            tree_rules.append((syms, expr, recv, [frac(-1, 1) for _ in recv], bool(rs.rand() < 0.1)))
+
     def make():
         cfg = gw.Config()
         cfg.set({"map_width": w, "map_height": h, "minimap_mode": minimap, "embedding_size": emb})
@@ -356,6 +447,36 @@ def fuzz_scenario(seed):
             sc_ = gw.AgentSymbol(hs[c], "any")
             cfg.add_reward_rule(gw.Event(sa, opa, sc_) & gw.Event(sb, opb, sc_),
                                 receiver=[{"a": sa, "b": sb, "c": sc_}[k] for k in who], value=vals)
+        def build_expr(S, e):
+            if e[0] == "and":
+                return build_expr(S, e[1]) & build_expr(S, e[2])
+            if e[0] == "or":
+                return build_expr(S, e[1]) | build_expr(S, e[2])
+            if e[0] == "not":
+                return ~build_expr(S, e[1])
+            if e[0] == "die":
+                return gw.Event(S[e[1]], "die")
+            if e[0] in ("at", "in"):
+                return gw.Event(S[e[1]], e[0], e[2])
+            return gw.Event(S[e[1]], e[0], S[e[2]])
+        for gx, gy, two, expr, who, vals, terminal in prog_rules:
+            S = [gw.AgentSymbol(hs[gx], "any"), gw.AgentSymbol(hs[gy], "any")]
+            cfg.add_reward_rule(build_expr(S, expr), receiver=[S["xy".index(c)] for c in who], value=vals, terminal=terminal)
+        for syms, expr, recv, vals, terminal in tree_rules:
+            S = [gw.AgentSymbol(hs[g], "any") for g in syms]
+            def build(e):
+                if e[0] == "and":
+                    return build(e[1]) & build(e[2])
+                if e[0] == "or":
+                    return build(e[1]) | build(e[2])
+                if e[0] == "not":
+                    return ~build(e[1])
+                if e[0] == "die":
+                    return gw.Event(S[e[1]], "die")
+                if e[0] in ("at", "in"):
+                    return gw.Event(S[e[1]], e[0], e[2])
+                return gw.Event(S[e[1]], e[0], S[e[2]])
+            cfg.add_reward_rule(build(expr), receiver=[S[k] for k in recv], value=vals, terminal=terminal)
         return cfg
 
     area = (w - 2) * (h - 2)
@@ -475,6 +596,8 @@ def scenarios():
         Scenario("bodies_food", ("bodies", 48, 37), 0, walls=40, place=[rnd(0, 60), rnd(1, 90), rnd(2, 150)], steps=30, action_seed=39,
                  settings={"food_mode": True},
                  over={"big": {"food_supply": 6, "eat_ability": 2}, "mid": {"food_supply": 0.05, "eat_ability": 0.5}, "tiny": {"food_supply": 1, "eat_ability": 3}}),
+        Scenario("rules_mix", ("rules", 30), 0, place=[rnd(0, 140), rnd(1, 140), rnd(2, 25)], walls=20, steps=30, action_seed=40),
+        Scenario("rules_mix_large", ("rules", 110), 0, place=[rnd(0, 2500), rnd(1, 2500), rnd(2, 300)], steps=8, action_seed=41),
         Scenario("battle_one_side", "battle", 12, place=[rnd(0, 60), rnd(1, 3)], steps=40, action_seed=14,
                  over={"small": {"damage": 12}}),
     ]
