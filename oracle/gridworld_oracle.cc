@@ -13,7 +13,7 @@
 // State is kept as per-group struct-of-arrays + a packed occupancy grid; the *order* of every loop that the
 // reference executes sequentially is kept literally, because the results depend on it.
 //
-// Scope: what SURVEY.md section 8 puts on the path -- no turn_mode / goal_mode.  Reward rules
+// Scope: what SURVEY.md section 8 puts on the path -- no goal_mode; turn_mode is restated too (the engine refuses it).  Reward rules
 // are evaluated by the reference's recursive search over symbol bindings, literally (and/or/not over attack, kill,
 // collide, die, at, in; 'any', 'all' and fixed-index symbols); align / in_a_line abort with a message.
 #include <algorithm>
@@ -88,8 +88,29 @@ struct AgentType {
 enum { OP_AND = 0, OP_OR = 1, OP_NOT = 2, OP_KILL = 3, OP_AT = 4, OP_IN = 5, OP_COLLIDE = 6, OP_ATTACK = 7, OP_DIE = 8,
        OP_IN_A_LINE = 9, OP_ALIGN = 10, OP_NULL = 11 };  // grid_def.h:18-24
 
+enum { EAST = 0, SOUTH = 1, WEST = 2, NORTH = 3, DIR_NUM = 4 };   // grid_def.h:15
+
+// Map.cc:515-551: relative (agent frame) <-> absolute (map) coordinates around (cx, cy)
+static void rela_to_abs(int cx, int cy, int dir, int rx, int ry, int &ax, int &ay) {
+    switch (dir) {
+        case NORTH: ax = cx + rx; ay = cy + ry; break;
+        case SOUTH: ax = cx - rx; ay = cy - ry; break;
+        case WEST:  ax = cx + ry; ay = cy - rx; break;
+        default:    ax = cx - ry; ay = cy + rx; break;   // EAST
+    }
+}
+static void abs_to_rela(int cx, int cy, int dir, int ax, int ay, int &rx, int &ry) {
+    switch (dir) {
+        case NORTH: rx = ax - cx; ry = ay - cy; break;
+        case SOUTH: rx = cx - ax; ry = cy - ay; break;
+        case WEST:  ry = ax - cx; rx = cy - ay; break;
+        default:    ry = cx - ax; rx = ay - cy; break;   // EAST
+    }
+}
+
 struct Group {
     AgentType *type = nullptr;
+    std::vector<int> dir;             // turn_mode: EAST / SOUTH / WEST / NORTH; NORTH otherwise
     // one entry per agent, in the reference's vector<Agent*> order
     std::vector<int> x, y, id, last_action, last_op;
     std::vector<float> hp, next_reward, last_reward;
@@ -100,7 +121,7 @@ struct Group {
     int size() const { return (int)x.size(); }
     void clear() {
         x.clear(); y.clear(); id.clear(); last_action.clear(); last_op.clear(); hp.clear(); next_reward.clear();
-        last_reward.clear(); dead.clear(); absorbed.clear(); op_obj.clear(); dead_ct = 0;
+        last_reward.clear(); dead.clear(); absorbed.clear(); op_obj.clear(); dir.clear(); dead_ct = 0;
     }
 };
 
@@ -120,7 +141,9 @@ const int EMPTY = -1, WALL = -2, FOOD = -3;   // FOOD: what a killed agent leave
 
 struct World {
     int w = 0, h = 0, embedding = 0;
-    bool minimap = false, large_map = false, food_mode = false;
+    bool minimap = false, large_map = false, food_mode = false, turn_mode = false;
+    std::vector<Pending> turn_bound;
+    std::vector<std::vector<Pending>> turn_sep;
     std::vector<float> food;        // per cell: what is left of the food (cells whose occ_g is FOOD)
     int n_sep = 1;
     MinStd rng;
@@ -167,9 +190,26 @@ struct World {
             if (tries++ > w * h) fatal("cannot find a blank position in a filled map");
         }
     }
+    // Map.cc:589-599 get_size_for_dir: the footprint of a body lying east-west is transposed
+    void footprint(int g, int i, int &bw, int &bh) const {
+        const Group &G = groups[g];
+        const bool upright = G.dir[i] == NORTH || G.dir[i] == SOUTH;
+        bw = upright ? G.type->width : G.type->length; bh = upright ? G.type->length : G.type->width;
+    }
+    // Map.cc:553-571 save_to_real: the stored top-left cell -> the body's reference corner in the agent frame
+    void real_pos(int g, int i, int &rx, int &ry) const {
+        const Group &G = groups[g]; const int wd = G.type->width, ln = G.type->length;
+        switch (G.dir[i]) {
+            case NORTH: rx = G.x[i]; ry = G.y[i]; break;
+            case SOUTH: rx = G.x[i] + wd - 1; ry = G.y[i] + ln - 1; break;
+            case WEST:  rx = G.x[i]; ry = G.y[i] + wd - 1; break;
+            default:    rx = G.x[i] + ln - 1; ry = G.y[i]; break;   // EAST
+        }
+    }
     void remove_agent(int g, int i) {
         Group &G = groups[g];
-        fill(G.x[i], G.y[i], G.type->width, G.type->length, EMPTY, 0);
+        int bw, bh; footprint(g, i, bw, bh);
+        fill(G.x[i], G.y[i], bw, bh, EMPTY, 0);
     }
 };
 
@@ -196,7 +236,8 @@ int env_config_game(void *game, const char *key, void *p) {
     else if (k == "embedding_size") e.embedding = *(int *)p;
     else if (k == "seed") e.rng.seed((unsigned long)*(int *)p);
     else if (k == "food_mode") e.food_mode = *(bool *)p;
-    else if (k == "turn_mode" || k == "goal_mode") { if (*(bool *)p) fatal("%s is outside the hot-path scope", key); }
+    else if (k == "turn_mode") e.turn_mode = *(bool *)p;
+    else if (k == "goal_mode") { if (*(bool *)p) fatal("%s is outside the hot-path scope", key); }
     else if (k == "render_dir") {}
     else fatal("invalid argument in set_config: %s", key);
     return 0;
@@ -237,7 +278,7 @@ int gridworld_register_agent_type(void *game, const char *name, int n, const cha
     t.move.circle(t.speed, 0, 1);
     t.view_x_offset = t.att_x_offset = t.width / 2;
     t.view_y_offset = t.att_y_offset = t.length / 2;
-    t.move_base = 0; t.turn_base = t.move.count; t.attack_base = t.turn_base;
+    t.move_base = 0; t.turn_base = t.move.count; t.attack_base = t.turn_base + (e.turn_mode ? 2 : 0);   // AgentType.cc:110-118
     t.n_action = t.attack_base + t.attack.count;
     e.types[name] = t;
     return 0;
@@ -260,6 +301,7 @@ int env_reset(void *game) {
     e.large_map = e.w * e.h > 99 * 99;
     e.n_sep = e.large_map ? (e.w * e.h > 1000 * 1000 ? 16 : 8) : 1;
     e.move_sep.assign(e.n_sep, {});
+    e.turn_sep.assign(e.n_sep, {}); e.turn_bound.clear();
     e.move_bound.clear(); e.attack_buf.clear();
     e.occ_g.assign((size_t)e.w * e.h, EMPTY); e.occ_i.assign((size_t)e.w * e.h, 0);
     e.food.assign((size_t)e.w * e.h, 0.0f);
@@ -303,17 +345,19 @@ int env_reset(void *game) {
 }
 
 // GridWorld.cc:171-290
-static void place(World &e, int g, int x, int y) {
+static void place(World &e, int g, int x, int y, int dir) {
     Group &G = e.groups[g]; AgentType &t = *G.type;
-    if (!e.blank_area(x, y, t.width, t.length)) return;  // silently ignored (LOG(WARNING) compiled out)
+    const bool upright = dir == NORTH || dir == SOUTH;
+    const int bw = upright ? t.width : t.length, bh = upright ? t.length : t.width;
+    if (!e.blank_area(x, y, bw, bh)) return;  // silently ignored (LOG(WARNING) compiled out)
     int i = G.size();
-    G.x.push_back(x); G.y.push_back(y); G.id.push_back(e.id_counter++);
+    G.x.push_back(x); G.y.push_back(y); G.id.push_back(e.id_counter++); G.dir.push_back(dir);
     G.hp.push_back(t.hp); G.last_action.push_back(t.n_action); G.last_op.push_back(OP_NULL); G.op_obj.push_back(-1);
     G.last_reward.push_back(0.0f); G.next_reward.push_back(t.step_reward); G.dead.push_back(0); G.absorbed.push_back(0);
-    e.fill(x, y, t.width, t.length, g, i);
+    e.fill(x, y, bw, bh, g, i);
 }
 
-int gridworld_add_agents(void *game, int group, int n, const char *method, const int *px, const int *py, const int *) {
+int gridworld_add_agents(void *game, int group, int n, const char *method, const int *px, const int *py, const int *pdir) {
     World &e = *W(game);
     std::string m(method);
     if (group == -1) {
@@ -325,15 +369,28 @@ int gridworld_add_agents(void *game, int group, int n, const char *method, const
     }
     if (group < 0 || group >= (int)e.groups.size()) fatal("invalid group handle in add_agents");
     AgentType &t = *e.groups[group].type;
-    if (m == "random") { for (int i = 0; i < n; i++) { int x, y; e.random_blank(t.width, t.length, x, y); place(e, group, x, y); } }
-    else if (m == "custom") { for (int i = 0; i < n; i++) place(e, group, px[i], py[i]); }
-    else if (m == "fill") {
-        for (int x = px[0]; x < px[0] + px[2]; x += t.width) for (int y = px[1]; y < px[1] + px[3]; y += t.length) place(e, group, x, y);
+    if (m == "random") {
+        for (int i = 0; i < n; i++) {
+            const int dir = e.turn_mode ? (int)(e.rng() % DIR_NUM) : NORTH;     // drawn before the position (GridWorld.cc:230)
+            const bool upright = dir == NORTH || dir == SOUTH;
+            int x, y; e.random_blank(upright ? t.width : t.length, upright ? t.length : t.width, x, y);
+            place(e, group, x, y, dir);
+        }
+    } else if (m == "custom") {
+        for (int i = 0; i < n; i++) {
+            if (e.turn_mode && pdir[i] >= DIR_NUM) fatal("invalid direction in add_agents");
+            place(e, group, px[i], py[i], e.turn_mode ? pdir[i] : NORTH);
+        }
+    } else if (m == "fill") {
+        const int dir = e.turn_mode ? px[4] : NORTH;
+        const bool upright = dir == NORTH || dir == SOUTH;
+        const int bw = upright ? t.width : t.length, bh = upright ? t.length : t.width;
+        for (int x = px[0]; x < px[0] + px[2]; x += bw) for (int y = px[1]; y < px[1] + px[3]; y += bh) place(e, group, x, y, dir);
     } else fatal("unsupported method in add_agents: %s", method);
     return 0;
 }
 
-// GridWorld.cc:292-401 + Map.cc:129-207 (dir == NORTH always: no turn_mode)
+// GridWorld.cc:292-401 + Map.cc:129-207
 int env_get_observation(void *game, int group, float **bufs) {
     World &e = *W(game);
     Group &G = e.groups[group]; AgentType &t = *G.type;
@@ -364,17 +421,39 @@ int env_get_observation(void *game, int group, float **bufs) {
     }
     for (int i = 0; i < n; i++) {
         float *out = view + (size_t)i * VH * VW * C;
-        const int eye_x = G.x[i] + t.view_x_offset, eye_y = G.y[i] + t.view_y_offset;
-        const int x1 = eye_x + t.view.x1, y1 = eye_y + t.view.y1, x2 = eye_x + t.view.x2, y2 = eye_y + t.view.y2;
-        const int sx = std::max(x1, 0), ex = std::min(x2, e.w - 1), sy = std::max(y1, 0), ey = std::min(y2, e.h - 1);
-        for (int x = sx; x <= ex; x++)
+        // Map::extract_view, literally: the window is laid out in the agent's frame and scanned in map order
+        const int dir = G.dir[i];
+        int ax, ay, eye_x, eye_y, wx1, wy1, wx2, wy2;
+        e.real_pos(group, i, ax, ay);
+        rela_to_abs(ax, ay, dir, t.view_x_offset, t.view_y_offset, eye_x, eye_y);
+        rela_to_abs(eye_x, eye_y, dir, t.view.x1, t.view.y1, wx1, wy1);
+        rela_to_abs(eye_x, eye_y, dir, t.view.x2, t.view.y2, wx2, wy2);
+        const int sx = std::max(std::min(wx1, wx2), 0), ex = std::min(std::max(wx1, wx2), e.w - 1);
+        const int sy = std::max(std::min(wy1, wy2), 0), ey = std::min(std::max(wy1, wy2), e.h - 1);
+        int vrx, vry;
+        abs_to_rela(eye_x, eye_y, dir, sx, sy, vrx, vry);
+        int view_x = vrx - t.view.x1, view_y = vry - t.view.y1;
+        int *inner, *outer, d_inner, d_outer;
+        switch (dir) {
+            case NORTH: inner = &view_y; outer = &view_x; d_inner = 1; d_outer = 1; break;
+            case SOUTH: inner = &view_y; outer = &view_x; d_inner = -1; d_outer = -1; break;
+            case EAST:  inner = &view_x; outer = &view_y; d_inner = 1; d_outer = -1; break;
+            default:    inner = &view_x; outer = &view_y; d_inner = -1; d_outer = 1; break;   // WEST
+        }
+        const int start_inner = *inner;
+        for (int x = sx; x <= ex; x++) {
             for (int y = sy; y <= ey; y++) {
-                const int vx = x - x1, vy = y - y1, c = e.cell(x, y), og = e.occ_g[c];
-                if (og == EMPTY || !t.view.in[vy * VW + vx]) continue;
-                const int ch = trans[og == WALL ? 0 : og == FOOD ? 1 : e.g2c(og)];   // Map.h:35 wall 0, food 1
-                out[(vy * VW + vx) * C + ch] = 1;
-                if (og >= 0) out[(vy * VW + vx) * C + ch + 1] = e.groups[og].hp[e.occ_i[c]] / e.groups[og].type->hp;
+                const int c = e.cell(x, y), og = e.occ_g[c];
+                if (og != EMPTY && t.view.in[view_y * VW + view_x]) {
+                    const int ch = trans[og == WALL ? 0 : og == FOOD ? 1 : e.g2c(og)];   // Map.h:35 wall 0, food 1
+                    out[(view_y * VW + view_x) * C + ch] = 1;
+                    if (og >= 0) out[(view_y * VW + view_x) * C + ch + 1] = e.groups[og].hp[e.occ_i[c]] / e.groups[og].type->hp;
+                }
+                *inner += d_inner;
             }
+            *inner = start_inner;
+            *outer += d_outer;
+        }
         if (e.minimap) {  // GridWorld.cc:371-384: unmasked copy + self marker on EVERY group's minimap channel
             const int self_x = G.x[i] / scale_w, self_y = G.y[i] / scale_h;
             for (int j = 0; j < NG; j++) {
@@ -403,12 +482,15 @@ int env_set_action(void *game, int group, const int *actions) {
     for (int i = 0; i < G.size(); i++) {
         int act = actions[i];
         G.last_action[i] = act;
-        if (act < t.attack_base) {  // move (turn_base == attack_base without turn_mode)
+        if (act < t.attack_base) {  // move, or (turn_mode) turn: the turn's payload is taken from move_base too (GridWorld.cc:430,433)
+            const bool turn = act >= t.turn_base;
+            std::vector<Pending> &bound = turn ? e.turn_bound : e.move_bound;
+            std::vector<std::vector<Pending>> &sep = turn ? e.turn_sep : e.move_sep;
             if (e.large_map) {
                 int x_ = G.x[i] % bandwidth;
-                if (x_ < 4 || x_ > bandwidth - 4) e.move_bound.push_back({group, i, act - t.move_base});
-                else e.move_sep[G.x[i] / bandwidth].push_back({group, i, act - t.move_base});
-            } else e.move_bound.push_back({group, i, act - t.move_base});
+                if (x_ < 4 || x_ > bandwidth - 4) bound.push_back({group, i, act - t.move_base});
+                else sep[G.x[i] / bandwidth].push_back({group, i, act - t.move_base});
+            } else bound.push_back({group, i, act - t.move_base});
         } else e.attack_buf.push_back({group, i, act - t.attack_base});
     }
     return 0;
@@ -426,7 +508,9 @@ int env_step(void *game, int *done) {
     for (const Pending &p : e.attack_buf) {
         Group &A = e.groups[p.g]; AgentType &at = *A.type;
         if (A.dead[p.i]) continue;
-        const int ox = A.x[p.i] + at.att_x_offset + at.attack.dx[p.act], oy = A.y[p.i] + at.att_y_offset + at.attack.dy[p.act];
+        int ax, ay, ox, oy;                                    // Map::get_attack_obj (Map.cc:209-226)
+        e.real_pos(p.g, p.i, ax, ay);
+        rela_to_abs(ax, ay, A.dir[p.i], at.att_x_offset + at.attack.dx[p.act], at.att_y_offset + at.attack.dy[p.act], ox, oy);
         int tg = EMPTY, ti = 0;
         if (ox >= 0 && ox < e.w && oy >= 0 && oy < e.h) { tg = e.occ_g[e.cell(ox, oy)]; ti = e.occ_i[e.cell(ox, oy)]; }
         if (tg == FOOD) {   // Map.cc:292-303: eat; the attack counts as one on an object (reward 0.0 + attack_penalty)
@@ -469,20 +553,62 @@ int env_step(void *game, int *done) {
             if (G.dead[i]) { e.remove_agent(g, i); G.dead_ct++; }
         }
     }
+    // turn (GridWorld.cc:544-571, Map::do_turn Map.cc:361-406): stripes in index order, then the boundary list.  The
+    // payload was taken from move_base, so `wise` = 2 * (n_move + {0, 1}) - 1 is never -1: the direction changes by
+    // +1 / -1 (mod 4) but the position is always rotated about the anchor the clockwise way.
+    if (e.turn_mode) {
+        auto turn = [&](std::vector<Pending> &buf) {
+            for (const Pending &p : buf) {
+                Group &G = e.groups[p.g]; AgentType &t = *G.type;
+                if (G.dead[p.i]) continue;
+                const int wise = p.act * 2 - 1, dir = G.dir[p.i], new_dir = (dir + wise + DIR_NUM) % DIR_NUM;
+                int bw, bh; e.footprint(p.g, p.i, bw, bh);
+                int ax, ay, anchor_x, anchor_y, new_x, new_y;
+                e.real_pos(p.g, p.i, ax, ay);
+                rela_to_abs(ax, ay, dir, 0, 0, anchor_x, anchor_y);          // turn_x_offset = turn_y_offset = 0 (AgentType.cc:108)
+                const int dx = ax - anchor_x, dy = ay - anchor_y;
+                if (wise == -1) { new_x = anchor_x - dy; new_y = anchor_y + dx; } else { new_x = anchor_x + dy; new_y = anchor_y - dx; }
+                int sx, sy;                                                   // real_to_save (Map.cc:573-587)
+                switch (new_dir) {
+                    case NORTH: sx = new_x; sy = new_y; break;
+                    case SOUTH: sx = new_x - t.width + 1; sy = new_y - t.length + 1; break;
+                    case WEST:  sx = new_x; sy = new_y - t.width + 1; break;
+                    default:    sx = new_x - t.length + 1; sy = new_y; break;
+                }
+                if (e.blank_area(sx, sy, bh, bw, p.g, p.i)) {
+                    e.fill(G.x[p.i], G.y[p.i], bw, bh, EMPTY, 0);
+                    G.dir[p.i] = new_dir;
+                    e.fill(sx, sy, bh, bw, p.g, p.i);
+                    G.x[p.i] = sx; G.y[p.i] = sy;
+                }
+            }
+            buf.clear();
+        };
+        for (auto &b : e.turn_sep) turn(b);
+        turn(e.turn_bound);
+    }
     // move: stripes in index order, then the boundary list (GridWorld.cc:574-613, Map.cc:313-358)
     auto run = [&](std::vector<Pending> &buf) {
         for (const Pending &p : buf) {
             Group &G = e.groups[p.g]; AgentType &t = *G.type;
             if (G.dead[p.i] || G.absorbed[p.i]) continue;
-            const int nx = G.x[p.i] + t.move.dx[p.act], ny = G.y[p.i] + t.move.dy[p.act];
-            if (e.blank_area(nx, ny, t.width, t.length, p.g, p.i)) {
-                e.fill(G.x[p.i], G.y[p.i], t.width, t.length, EMPTY, 0);
-                e.fill(nx, ny, t.width, t.length, p.g, p.i);
+            int mdx = t.move.dx[p.act], mdy = t.move.dy[p.act], ddx, ddy;     // the move is given in the agent's frame (GridWorld.cc:585-598)
+            switch (G.dir[p.i]) {
+                case NORTH: ddx = mdx; ddy = mdy; break;
+                case SOUTH: ddx = -mdx; ddy = -mdy; break;
+                case WEST:  ddx = mdy; ddy = -mdx; break;
+                default:    ddx = -mdy; ddy = mdx; break;   // EAST
+            }
+            int bw, bh; e.footprint(p.g, p.i, bw, bh);
+            const int nx = G.x[p.i] + ddx, ny = G.y[p.i] + ddy;
+            if (e.blank_area(nx, ny, bw, bh, p.g, p.i)) {
+                e.fill(G.x[p.i], G.y[p.i], bw, bh, EMPTY, 0);
+                e.fill(nx, ny, bw, bh, p.g, p.i);
                 G.x[p.i] = nx; G.y[p.i] = ny;
-            } else if (!(nx < 0 || ny < 0 || nx + t.width >= e.w || ny + t.length >= e.h)) {  // Map.cc:486-501
-                for (int a = 0; a < t.width; a++) {
+            } else if (!(nx < 0 || ny < 0 || nx + bw >= e.w || ny + bh >= e.h)) {  // Map.cc:486-501
+                for (int a = 0; a < bw; a++) {
                     bool found = false;
-                    for (int b = 0; b < t.length; b++) {
+                    for (int b = 0; b < bh; b++) {
                         int c = e.cell(nx + a, ny + b);
                         if (e.occ_g[c] >= 0 && !(e.occ_g[c] == p.g && e.occ_i[c] == p.i)) {
                             found = true;
@@ -608,12 +734,12 @@ int gridworld_clear_dead(void *game) {
             if (G.dead[j]) continue;
             G.x[pt] = G.x[j]; G.y[pt] = G.y[j]; G.id[pt] = G.id[j]; G.hp[pt] = G.hp[j]; G.last_action[pt] = G.last_action[j];
             G.last_reward[pt] = G.next_reward[j]; G.next_reward[pt] = t.step_reward; G.last_op[pt] = OP_NULL; G.op_obj[pt] = -1;
-            G.dead[pt] = 0; G.absorbed[pt] = G.absorbed[j];
-            e.fill(G.x[pt], G.y[pt], t.width, t.length, g, pt);
+            G.dead[pt] = 0; G.absorbed[pt] = G.absorbed[j]; G.dir[pt] = G.dir[j];
+            { int bw, bh; e.footprint(g, pt, bw, bh); e.fill(G.x[pt], G.y[pt], bw, bh, g, pt); }
             pt++;
         }
         G.x.resize(pt); G.y.resize(pt); G.id.resize(pt); G.hp.resize(pt); G.last_action.resize(pt); G.last_reward.resize(pt);
-        G.next_reward.resize(pt); G.last_op.resize(pt); G.op_obj.resize(pt); G.dead.resize(pt); G.absorbed.resize(pt);
+        G.next_reward.resize(pt); G.last_op.resize(pt); G.op_obj.resize(pt); G.dead.resize(pt); G.absorbed.resize(pt); G.dir.resize(pt);
         G.dead_ct = 0;
     }
     return 0;

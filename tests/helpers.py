@@ -208,8 +208,9 @@ class Scenario(object):
                stream continues across reset, GridWorld.cc:72-118)"""
 
     def __init__(self, name, game, map_size, seed=12345, place=(), steps=10, action_seed=0, walls=0,
-                 acting=None, over=None, clear_every=1, obs_every=1, events=None, settings=None):
+                 acting=None, over=None, clear_every=1, obs_every=1, events=None, settings=None, engine=True):
         self.name, self.game, self.map_size, self.seed = name, game, map_size, seed
+        self.engine = engine                # False: the engine refuses this game (turn_mode); the oracle is pinned on it all the same
         self.settings = settings or {}      # extra GridWorld settings (food_mode, ...) and, for custom games, type overrides
         self.place, self.steps, self.action_seed, self.walls = list(place), steps, action_seed, walls
         self.acting, self.over, self.clear_every, self.obs_every = acting, over or {}, clear_every, obs_every
@@ -323,6 +324,7 @@ def fuzz_scenario(seed):
     h = w if rs.rand() < 0.5 else int(rs.randint(12, 150))
     minimap, emb = bool(rs.rand() < 0.6), int(rs.choice([0, 3, 10]))
     food_mode = False
+    turn_mode = os.environ.get("FUZZ_TURN", "0") == "1" and bool(rs.rand() < 0.6)   # oracle-vs-reference runs only (the engine refuses it)
     frac = lambda lo, hi: float(rs.randint(int(lo * 16), int(hi * 16) + 1)) / 16.0
     while True:
         specs = []
@@ -430,6 +432,8 @@ def fuzz_scenario(seed):
         cfg.set({"map_width": w, "map_height": h, "minimap_mode": minimap, "embedding_size": emb})
         if food_mode:
             cfg.set({"food_mode": True})
+        if turn_mode:
+            cfg.set({"turn_mode": True})
         names = []
         for g, t in enumerate(specs):
             t = dict(t)
@@ -598,6 +602,10 @@ def scenarios():
                  over={"big": {"food_supply": 6, "eat_ability": 2}, "mid": {"food_supply": 0.05, "eat_ability": 0.5}, "tiny": {"food_supply": 1, "eat_ability": 3}}),
         Scenario("rules_mix", ("rules", 30), 0, place=[rnd(0, 140), rnd(1, 140), rnd(2, 25)], walls=20, steps=30, action_seed=40),
         Scenario("rules_mix_large", ("rules", 110), 0, place=[rnd(0, 2500), rnd(1, 2500), rnd(2, 300)], steps=8, action_seed=41),
+        Scenario("battle_turn", "battle", 26, place=[rnd(0, 120), rnd(1, 120), (0, "custom", {"pos": [(1, 1, 0), (3, 1, 1), (1, 3, 2), (3, 3, 3)]})],
+                 steps=25, action_seed=42, settings={"turn_mode": True}, engine=False),
+        Scenario("bodies_turn", ("bodies", 48, 37), 0, walls=40, place=[rnd(0, 50), rnd(1, 80), rnd(2, 150),
+                 (0, "fill", {"pos": (30, 20), "size": (8, 9), "dir": 2})], steps=25, action_seed=43, settings={"turn_mode": True}, engine=False),
         Scenario("battle_one_side", "battle", 12, place=[rnd(0, 60), rnd(1, 3)], steps=40, action_seed=14,
                  over={"small": {"damage": 12}}),
     ]

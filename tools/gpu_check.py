@@ -10,7 +10,7 @@ import torch  # noqa: F401,E402  (first, so the engine shares torch's HIP runtim
 import helpers as H  # noqa: E402
 
 H.ensure_oracle()
-names = sys.argv[1:] or sorted(H.scenarios())
+names = sys.argv[1:] or sorted(k for k, sc in H.scenarios().items() if sc.engine)
 bad = 0
 for name in names:
     sc = H.scenarios()[name]
