@@ -292,6 +292,49 @@ def run(sc, lib, record=None):
     return out
 
 
+def run_hashed(sc, lib):
+    """run(sc, lib) for sizes whose trajectories do not fit in memory: every array of every step is reduced to its
+    xxh3-128 (10 GB/s on one core; SHA-256 would cost more than the engines) as soon as the step is over.
+    Returns [{key: hex digest} per step]."""
+    import xxhash
+    steps = []
+
+    def keep(step, rec):
+        steps.append({k: xxhash.xxh3_128(np.ascontiguousarray(v).reshape(-1).view(np.uint8)).hexdigest()
+                      for k, v in rec.items()})
+        rec.clear()
+
+    run(sc, lib, record=keep)
+    return steps
+
+
+def assert_same_hashed(want, got, what=""):
+    assert len(want) == len(got), "%s: step counts differ %d vs %d" % (what, len(want), len(got))
+    for s, (a, b) in enumerate(zip(want, got)):
+        assert sorted(a) == sorted(b), "%s step %d: keys differ" % (what, s)
+        for k in sorted(a):
+            assert a[k] == b[k], "%s step %d: %s differs" % (what, s, k)
+
+
+def fullsize_scenarios():
+    """BASELINE.json's configurations at their stated sizes.  Too large for full trajectories in memory:
+    compared through per-step hashes (run_hashed); goldens from the compiled reference in tests/golden/digests_fullsize.json"""
+    rnd = lambda g, n: (g, "random", {"n": n})
+    S = [
+        # C2: battle 200x200, 2x2000 agents placed by add_agents("random"), 40 steps
+        Scenario("c2_battle200", "battle", 200, place=[rnd(0, 2000), rnd(1, 2000)], steps=40),
+        # C3(i) with hp 4 / damage 3: deaths from the first step on -- kills, dead_penalty, compaction and the shuffle of
+        # ~300k attack-list entries compared bit for bit at 2 x 400k
+        Scenario("c3_battle1000_deaths", "battle", 1000, place=[rnd(0, 400000), rnd(1, 400000)], steps=6,
+                 over={"small": {"hp": 4, "damage": 3}}),
+        # C4: gather 500x500 (train_gather.py), 20k food + 100k agents, only the agents act
+        Scenario("c4_gather500", "gather", 500, place=[rnd(0, 20000), rnd(1, 100000)], acting=[1], steps=8),
+        # the reference's own 1M harness (scripts/test/test_1m.py:62-71): map sqrt(20 N), N/10 walls, N/2 2x2 predators, N/2 prey
+        Scenario("test_1m", "pursuit", 4472, walls=100000, place=[rnd(0, 500000), rnd(1, 500000)], steps=2),
+    ]
+    return {s.name: s for s in S}
+
+
 def render_episode(lib, out_dir, steps=6):
     """a short battle with the text video dump on: returns {file name: bytes} of what env.render() wrote"""
     sc = Scenario("render", "battle", 16, place=[(0, "random", {"n": 30}), (1, "random", {"n": 30})], steps=steps, action_seed=4,
