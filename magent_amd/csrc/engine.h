@@ -92,11 +92,27 @@ struct WorldView {
     int food_mode;               // GridWorld.cc:131
     float *food, *food_next;     // per cell: amount of food on OCC_FOOD cells; attack-phase scratch (-1 = eaten up)
     int large_map, bandwidth;    // reference large_map_mode striping (GridWorld.cc:75-85, 407-425)
+    int vc_packed;               // viewcell holds one 32-bit word per cell (<= 3 groups, no goals), else an int2
+    int live_paint;              // the step keeps `viewcell` current itself (vacated cells, then every live agent's body)
+};
+
+// What a step reports to the host.  The one-launch step (k_step_solo) writes it straight into pinned host memory and
+// publishes `seq` last; the host spins on `seq` instead of synchronising the stream.
+struct StepRecord {
+    int dead[MAXG], taken[MAXG]; // dead_ct per group as of this step (accumulated until clear_dead); movers taken in by goals
+    unsigned long long triggers; // bit k: reward rule k fired in this step
+    unsigned rng;                // engine RNG state after the step
+    int last_a;                  // attack-list length
+    int unsupported, pack_overflow, error, bad_action;
+    int rounds_attack, rounds_move;
+    int n_marks; unsigned long long marks[40];   // wall_clock64 (100 MHz) at the phase boundaries of k_step_solo (tuning aid)
+    volatile int seq;            // == the step's sequence number once everything above is visible
 };
 
 constexpr int CTR_CHANGED = 0, CTR_ATTACK = 1, CTR_DEAD = 2 /* unused: see CTR_DEAD_SPREAD */, CTR_PACK_OVERFLOW = 12, CTR_TRIGGER = 16, CTR_TRIGGER_END = 64;
 // movers taken in by goals, per group: dead, but not counted in the reference's dead_ct (Map.cc:345); cleared with CTR_DEAD
 constexpr int CTR_TAKEN = 64, CTR_UNSUPPORTED = 72;
+constexpr int CTR_BAD_ACTION = 73;   // set_action met an action outside [0, n_action): reported at the end of the step (the reference: UB)
 // Deaths are counted in DEAD_SLOTS counters per group, each on its own cache line: device-scope atomics on ONE address
 // serialise at ~15 ns apiece on this part (measured: 4.8k of them cost a 800k-agent step 70 us).  dead_ct of group g =
 // sum over slots of counters[dead_slot(g, slot)]; the host adds them up after its one readback per step.

@@ -7,6 +7,7 @@
 // the reference defines as sequential rejection sampling on the engine RNG) and, in this round, the attack
 // shuffle's permutation (a function of the RNG state and the attack count only).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -201,6 +202,8 @@ Env::Env() {
     if (const char *v = std::getenv("MAGENT_OPT_ATTACK_PAIRS")) { opt_attack_pairs = std::max(0, std::atoi(v)); opt_fixed = true; }
     if (const char *v = std::getenv("MAGENT_OPT_MOVE_BATCHES")) { opt_move_batches = std::max(0, std::atoi(v)); opt_fixed = true; }
     if (const char *v = std::getenv("MAGENT_RENDER_NT")) nt_stores = std::atoi(v) != 0;
+    if (const char *v = std::getenv("MAGENT_SOLO_STEP")) solo_enabled = std::atoi(v) != 0;
+    if (const char *v = std::getenv("MAGENT_SOLO_MAX")) solo_max_agents = std::max(0, std::atoi(v));
 }
 
 template <class T>
@@ -216,6 +219,8 @@ Env::~Env() {
     dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_food); dfree(d_powtab); dfree(d_counters); dfree(d_gtab); dfree(d_ttab);
     dfree(d_delta); dfree(d_mask); dfree(d_mini); dfree(d_minif); dfree(d_sums); dfree(d_rank); dfree(d_shuf); dfree(d_events); dfree(d_actions);
     dfree(d_stage_view); dfree(d_stage_feat); dfree(d_stage_small);
+    dfree(d_hit); dfree(d_rule_args); dfree(d_rule_progs);
+    if (h_rec) (void)hipHostFree(h_rec);
     if (pool) {
         delete pool;
         for (int i = 0; i < COPY_RING; i++) { (void)hipHostFree(h_ring[i]); (void)hipEventDestroy(ring_ev[i]); }
@@ -245,6 +250,8 @@ void Env::init_device() {
     HIP_OK(hipMalloc(&d_gtab, sizeof(GroupDev) * MAXG));
     HIP_OK(hipMalloc(&d_ttab, sizeof(TypeDev) * MAXG));
     HIP_OK(hipHostMalloc((void **)&h_counters, sizeof(int) * CTR_TOTAL, hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void **)&h_rec, sizeof(StepRecord), hipHostMallocDefault));   // (default = coherent, device-visible)
+    std::memset(h_rec, 0, sizeof(StepRecord));
     device_ready = true;
 }
 
@@ -397,16 +404,13 @@ void Env::compile_rules() {
             compile_rule_program(k);
             continue;
         }
-        const HostSymbol &sa = symbols[on.raw[0]], &sb = symbols[on.raw[1]];
-        if (sa.index != -1 || sb.index != -1) fatal("reward rule %zu: only 'any' agent symbols are on the GPU path", k);
-        if (sa.group < 0 || sa.group >= (int)groups.size() || sb.group < 0 || sb.group >= (int)groups.size())
-            fatal("reward rule %zu: invalid group in agent symbol", k);
+        const int group_a = any_sym(on.raw[0]), group_b = any_sym(on.raw[1]);
         // one symbol as subject AND object: the reference binds the object over the subject's entity
         // (RewardEngine.cc:17-24, 405-408) and then tests the target against itself -- the rule can never fire
         if (on.raw[0] == on.raw[1]) continue;
         RuleArgs a{};
         a.prog = -1;
-        a.ga = sa.group; a.gb = sb.group; a.op = on.op; a.rule_no = (int)k;
+        a.ga = group_a; a.gb = group_b; a.op = on.op; a.rule_no = (int)k;
         for (size_t i = 0; i < r.recv.size(); i++) {
             if (r.recv[i] == on.raw[0]) { if (a.n_subj == 4) fatal("too many receivers"); a.v_subj[a.n_subj++] = r.val[i]; }
             else if (r.recv[i] == on.raw[1]) { if (a.n_obj == 4) fatal("too many receivers"); a.v_obj[a.n_obj++] = r.val[i]; }
@@ -565,6 +569,8 @@ WorldView Env::view() const {
     W.food_mode = food_mode ? 1 : 0;
     W.food = d_food; W.food_next = d_food ? d_food + (size_t)width * height : nullptr;
     W.large_map = large_map_mode; W.bandwidth = bandwidth;
+    W.vc_packed = (groups.size() <= 3 && !any_absorb) ? 1 : 0;
+    W.live_paint = 0;
     for (int g = 0; g < W.G; g++) {
         W.type[g] = groups[g].tdev;
         W.grp[g] = groups[g].cur;
@@ -608,13 +614,16 @@ void Env::reset() {
     bandwidth = (width + n_sep - 1) / n_sep;
     const size_t ncell = (size_t)width * height;
     if (ncell != map_cells) {
-        dfree(d_occ); dfree(d_viewcell); dfree(d_claim);
+        dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_hit);
         HIP_OK(hipMalloc(&d_occ, sizeof(int) * ncell));
         HIP_OK(hipMalloc(&d_viewcell, sizeof(int2) * ncell));
         HIP_OK(hipMalloc(&d_claim, sizeof(unsigned long long) * ncell));
+        HIP_OK(hipMalloc(&d_hit, sizeof(unsigned) * ncell));
         dfree(d_food);
         map_cells = ncell;
     }
+    HIP_OK(hipMemset(d_hit, 0, sizeof(unsigned) * ncell));
+    claim_clean = false;
     if (food_mode && !d_food) HIP_OK(hipMalloc(&d_food, sizeof(float) * 2 * ncell));   // amounts, then the attack phase's scratch
     if (d_food) HIP_OK(hipMemset(d_food, 0, sizeof(float) * 2 * ncell));
     h_occ.assign(ncell, OCC_EMPTY);
@@ -665,6 +674,7 @@ void Env::reset() {
     }
     if (food_mode) attack_kmax = std::max(attack_kmax, total_attack);   // a food cell is hit by every group
     if (attack_kmax > 256) fatal("attack ranges x body size too large for the LDS hit lists (%d > 256)", attack_kmax);
+    if (!attack_lds_ok(attack_kmax)) fatal("attack ranges x body size (%d hits per target) need more LDS per workgroup than this device grants", attack_kmax);
     if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
     if (n_channel() > 32) fatal("too many observation channels");
     dfree(d_delta); dfree(d_mask);
@@ -675,7 +685,25 @@ void Env::reset() {
     HIP_OK(hipMemset(d_counters, 0, sizeof(int) * CTR_TOTAL));
     rng_on_device = false;
     move_seq_base = 0;
-    if (!rules_compiled) { compile_rules(); rules_compiled = true; }  // once, like init_reward_description
+    if (!rules_compiled) {   // once, like init_reward_description
+        compile_rules();
+        rules_compiled = true;
+        dfree(d_rule_args); dfree(d_rule_progs);
+        HIP_OK(hipMalloc(&d_rule_args, sizeof(RuleArgs) * std::max<size_t>(rule_args.size(), 1)));
+        HIP_OK(hipMalloc(&d_rule_progs, sizeof(RuleProg) * std::max<size_t>(rule_progs.size(), 1)));
+        if (!rule_args.empty()) HIP_OK(hipMemcpy(d_rule_args, rule_args.data(), sizeof(RuleArgs) * rule_args.size(), hipMemcpyHostToDevice));
+        if (!rule_progs.empty()) HIP_OK(hipMemcpy(d_rule_progs, rule_progs.data(), sizeof(RuleProg) * rule_progs.size(), hipMemcpyHostToDevice));
+    }
+    // threads of the one-launch step that evaluate hit lists: as many as kmax x threads x 8 B of LDS allow
+    {
+        int dev_lds = 0;
+        HIP_OK(hipDeviceGetAttribute(&dev_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id));
+        const int budget = std::max(0, dev_lds - solo_step_static_lds() - 256);
+        solo_nt_eval = std::min(1024, budget / (attack_kmax * 8) / 64 * 64);
+        if (solo_nt_eval >= 64 && (size_t)attack_kmax * solo_nt_eval * 8 > (48u << 10) && !solo_step_allow_lds((size_t)attack_kmax * solo_nt_eval * 8)) {
+            solo_nt_eval = std::min(1024, (48 << 10) / (attack_kmax * 8) / 64 * 64);   // stay under the default limit
+        }
+    }
     tables_valid = false;
     paint_valid = false; mini_valid = false;
 }
@@ -806,7 +834,9 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
     if ((long long)R.n * R.VH * R.VW >= (1ll << 31) || (long long)R.n * R.F >= (1ll << 32))
         fatal("observation too large for 32-bit cell indexing");
     const long long steps = ((long long)R.n * R.VH * R.VW + 63) / 64;
-    int per = render_steps_per_span > 0 ? render_steps_per_span : 32;
+    // 32 steps per workgroup at scale; a small observation is cut finer so that it still spreads over the chip (a wave's
+    // steps run one after the other: a step is ~1 us of latency)
+    int per = render_steps_per_span > 0 ? render_steps_per_span : (int)std::min<long long>(32, std::max<long long>(4, steps / 2048));
     P.steps_per_span = per;
     P.spans = (int)((steps + per - 1) / per);
     P.xcd_chunk = P.spans >= 64 ? P.spans / 8 : 0;
@@ -816,20 +846,22 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
     P.div_scale_w = make_fastdiv(R.scale_w); P.div_scale_h = make_fastdiv(R.scale_h);
 }
 
-// GridWorld::get_observation (GridWorld.cc:292-401) into DEVICE buffers, asynchronous on the env stream
-void Env::observe_device(int g, float *view, float *feat) {
-    if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_observation : %d", g);
-    use_device();
+long long Env::mini_population(bool skip) const {
+    long long pop = 0;
+    for (auto &gr : groups) pop = pop * 1000003ll + gr.n;
+    return pop * 2 + (skip ? 1 : 0);   // the observing type decides whether absorbed agents count
+}
+
+// everything a render launch of group g needs: the painted map and the minimap brought up to date (launches only when they
+// are stale), the launch plan.  Returns whether the view pointer allows 16-byte stores.
+bool Env::prepare_render(int g, const WorldView &W, RenderArgs &R, RenderPlan &P, float *view, float *feat) {
     HostGroup &G = groups[g];
-    if (G.n == 0) return;   // the reference dereferences agents[0] here (UB); nothing to write for n = 0
-    ensure_tables();
-    WorldView W = this->view();
     if (!paint_valid) {
+        ensure_tables();
         ProfScope p(*this, "paint");
         launch_paint(stream, W, d_gtab, d_ttab);
         paint_valid = true;
     }
-    RenderArgs R; RenderPlan P;
     plan_render(g, R, P, view, feat);
     if (minimap_mode) {
         size_t need = (size_t)W.G * R.VH * R.VW;
@@ -840,9 +872,7 @@ void Env::observe_device(int g, float *view, float *feat) {
         }
         grow(d_minif, minif_cap, need, stream);
         R.mini = d_minif;
-        long long pop = 0;
-        for (auto &gr : groups) pop = pop * 1000003ll + gr.n;
-        pop = pop * 2 + (G.type->can_absorb ? 1 : 0);   // the observing type decides whether absorbed agents count
+        const long long pop = mini_population(G.type->can_absorb);
         if (!(mini_valid && mini_vh == R.VH && mini_vw == R.VW && mini_pop == pop)) {
             ProfScope p(*this, "minimap");
             launch_minimap(stream, W, R, d_mini, d_minif);
@@ -853,6 +883,18 @@ void Env::observe_device(int g, float *view, float *feat) {
     // the feature rows ride in the render launch (its trailing workgroups) when both pointers have the same alignment
     const unsigned feat_q = (unsigned)R.n * (unsigned)R.F / 4;
     P.feat_blocks = aligned == feat_aligned ? (int)std::min<unsigned>((feat_q + 255) / 256 + 1, 16384) : 0;
+    return aligned;
+}
+
+// GridWorld::get_observation (GridWorld.cc:292-401) into DEVICE buffers, asynchronous on the env stream
+void Env::observe_device(int g, float *view, float *feat) {
+    if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_observation : %d", g);
+    use_device();
+    if (groups[g].n == 0) return;   // the reference dereferences agents[0] here (UB); nothing to write for n = 0
+    WorldView W = this->view();
+    RenderArgs R; RenderPlan P;
+    const bool aligned = prepare_render(g, W, R, P, view, feat);
+    const bool feat_aligned = (((uintptr_t)feat) & 15) == 0;
     {
         ProfScope p(*this, "render", true);
         launch_render(stream, W, R, P, aligned, aligned && nt_stores);
@@ -887,7 +929,6 @@ void Env::set_action_device(int g, const int *d_act) {
     if (G.acted) fatal("set_action called twice for group %d before step: the reference would execute both action lists; unsupported", g);
     G.acted = true;
     if (G.n == 0) return;
-    ensure_tables();
     int nb = (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
     grow(d_sums, sums_cap, (size_t)nb, stream);
     ProfScope p(*this, "set_action");
@@ -995,6 +1036,31 @@ void Env::step(int *done) {
     step_end(done);
 }
 
+// Worlds of up to `solo_max_agents` agents step in ONE launch (k_step_solo).  Not taken: food_mode (its per-cell food
+// evaluation sweeps the map), hit lists that do not fit one workgroup's LDS, the A/B drivers, and steps that record attack
+// events for the text render.
+bool Env::solo_ok(int total_n) {
+    return solo_enabled && !checked_step && !host_shuffle && !opt_fixed && first_render && !food_mode && total_n > 0 &&
+           total_n <= solo_max_agents && solo_nt_eval >= 64;
+}
+
+// the host side of k_step_solo's report: spin on the sequence number in pinned memory (a stream synchronisation costs
+// several times the PCIe write it waits for); the stream is polled now and then so that a failed launch cannot hang us
+void Env::wait_record(int seq) {
+    for (unsigned spins = 0;; spins++) {
+        if (h_rec->seq == seq) break;
+        if ((spins & 0x3FFF) == 0x3FFF) {
+            hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) {
+                if (h_rec->seq == seq) break;
+                fatal("the one-launch step finished without publishing its record");
+            }
+            if (q != hipErrorNotReady) fatal("step kernel failed: %s", hipGetErrorString(q));
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+}
+
 void Env::enqueue_counters() {
     HIP_OK(hipMemcpyAsync(h_counters, d_counters, sizeof(int) * CTR_TOTAL, hipMemcpyDeviceToHost, stream));
 }
@@ -1011,10 +1077,32 @@ void Env::step_begin() {
     const bool fast = !checked_step && !host_shuffle && first_render;
     step_pending = true;
     step_was_fast = false;
+    step_was_solo = false;
 
     if (total_n == 0) {
         enqueue_counters();
+    } else if (solo_ok(total_n)) {
+        // ---------------- one launch for the whole step
+        step_was_solo = true;
+        shuffle_buffers(total_n);
+        push_rng();
+        if (!claim_clean) {    // (after a multi-launch step or a reset: once)
+            HIP_OK(hipMemsetAsync(d_claim, 0xFF, sizeof(unsigned long long) * (size_t)width * height, stream));
+            claim_clean = true;
+        }
+        step_live_paint = paint_valid;      // the painted map is current: the step keeps it so
+        W.live_paint = step_live_paint ? 1 : 0;
+        const size_t seg = shuf_cap / 5;
+        SoloStep S{};
+        S.scount = d_shuf; S.scur = d_shuf + seg; S.sj = d_shuf + 2 * seg; S.soff = d_shuf + 3 * seg; S.slist = d_shuf + 4 * seg;
+        S.rank = d_rank; S.powtab = d_powtab; S.hit = d_hit;
+        S.rules = d_rule_args; S.progs = d_rule_progs; S.n_rules = (int)rule_args.size();
+        S.kmax = attack_kmax; S.nt_eval = solo_nt_eval; S.max_rounds = 1 << 20;
+        S.rec = h_rec; S.seq = ++step_seq;
+        ProfScope p(*this, "step");
+        launch_step_solo(stream, W, S);
     } else if (fast) {
+        claim_clean = false;
         step_was_fast = true;
         // ---------------- single-sync driver
         shuffle_buffers(total_n);
@@ -1053,6 +1141,7 @@ void Env::step_begin() {
         enqueue_counters();
     } else {
         // ---------------- checked driver
+        claim_clean = false;
         HIP_OK(hipMemsetAsync(d_counters + CTR_OPEN_ATTACK, 0, 2 * sizeof(int), stream));
         const int A = read_counters()[CTR_ATTACK];
         if (A > 0) {
@@ -1114,6 +1203,29 @@ void Env::step_end(int *done) {
     if (!step_pending) fatal("step_end without step_begin");
     step_pending = false;
     use_device();
+    if (step_was_solo) {
+        wait_record(step_seq);
+        const StepRecord &r = *h_rec;
+        if (r.error) fatal("%s resolution did not converge", r.error == 1 ? "attack" : "move");
+        if (r.unsupported) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
+        if (r.pack_overflow) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
+        if (r.bad_action) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
+        if (rng_on_device) rng.x = r.rng;
+        last_attack_iters = r.rounds_attack; last_move_iters = r.rounds_move; attack_round = r.rounds_attack;
+        int live = 0;
+        for (size_t g = 0; g < groups.size(); g++) {
+            groups[g].h_dead = r.dead[g];
+            groups[g].h_taken = r.taken[g];
+            groups[g].acted = false;
+            if (groups[g].n - groups[g].h_dead > 0) live++;
+        }
+        *done = live < (int)groups.size();   // GridWorld.cc:619-624
+        for (size_t k = 0; k < rules.size(); k++) if (((r.triggers >> k) & 1ull) && rules[k].terminal) *done = 1;
+        move_seq_base = 0;
+        h_occ_valid = false;
+        paint_valid = step_live_paint; mini_valid = false;
+        return;
+    }
     HIP_OK(hipStreamSynchronize(stream));
     const int *c = h_counters;
     if (step_was_fast) {
@@ -1143,6 +1255,7 @@ void Env::step_end(int *done) {
     }
     if (c[CTR_UNSUPPORTED]) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
     if (c[CTR_PACK_OVERFLOW]) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
+    if (c[CTR_BAD_ACTION]) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
     *done = live < (int)groups.size();   // GridWorld.cc:619-624
     for (size_t k = 0; k < rules.size(); k++) if (c[CTR_TRIGGER + k] && rules[k].terminal) *done = 1;
     // attack count and rule triggers are per step; dead_ct lives until clear_dead
@@ -1151,6 +1264,128 @@ void Env::step_end(int *done) {
     move_seq_base = 0;
     h_occ_valid = false;
     paint_valid = false; mini_valid = false;
+}
+
+// ------------------------------------------------------------------------------------------------ one cycle, two launches
+void Env::cycle(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, int *done) {
+    if (!device_ready) fatal("cycle called before reset");
+    use_device();
+    const int NG = (int)groups.size();
+    if (n_group != NG) fatal("env_cycle_many: n_group (%d) differs from the number of groups (%d)", n_group, NG);
+    int total_n = 0;
+    for (auto &g : groups) total_n += g.n;
+    bool fused = solo_ok(total_n) && !step_pending;
+    // the observed groups must share one minimap (same window, same "skip absorbed" rule) to be rendered by one launch
+    int n_obs = 0, first_obs = -1;
+    for (int g = 0; g < NG && fused; g++) {
+        if (!(view && view[g]) || groups[g].n == 0) continue;
+        if (!feat || !feat[g] || (((uintptr_t)view[g]) & 15) || (((uintptr_t)feat[g]) & 15)) fused = false;
+        if (first_obs < 0) first_obs = g;
+        else if (minimap_mode && (groups[g].type->view.height != groups[first_obs].type->view.height ||
+                                  groups[g].type->view.width != groups[first_obs].type->view.width ||
+                                  groups[g].type->can_absorb != groups[first_obs].type->can_absorb)) fused = false;
+        n_obs++;
+    }
+    if (n_obs > RENDER_MULTI_MAX) fused = false;
+    if (!fused) {   // the general path: the same calls one after the other
+        for (int g = 0; g < NG; g++) {
+            if (view && view[g]) observe_device(g, view[g], feat[g]);
+            if (actions && actions[g]) set_action_device(g, actions[g]);
+        }
+        step(done);
+        for (int g = 0; g < NG; g++) if (rewards && rewards[g]) get_reward_device(g, rewards[g]);
+        clear_dead();
+        return;
+    }
+    WorldView W = this->view();
+    // ---- launch 1: the observations of every observed group
+    if (n_obs > 0) {
+        RenderMulti M{};
+        for (int g = 0; g < NG; g++) {
+            if (!(view && view[g]) || groups[g].n == 0) continue;
+            const int k = M.n++;
+            prepare_render(g, W, M.R[k], M.P[k], view[g], feat[g]);
+            M.blocks[k] = M.P[k].spans + M.P[k].feat_blocks;
+        }
+        ProfScope p(*this, "render", true);
+        launch_render_multi(stream, W, M);
+    }
+    // ---- launch 2: set_action, step, get_reward, clear_dead, the next minimap
+    shuffle_buffers(total_n);
+    push_rng();
+    if (!claim_clean) {
+        HIP_OK(hipMemsetAsync(d_claim, 0xFF, sizeof(unsigned long long) * (size_t)width * height, stream));
+        claim_clean = true;
+    }
+    step_live_paint = paint_valid;
+    W.live_paint = step_live_paint ? 1 : 0;
+    const size_t seg = shuf_cap / 5;
+    SoloStep S{};
+    S.scount = d_shuf; S.scur = d_shuf + seg; S.sj = d_shuf + 2 * seg; S.soff = d_shuf + 3 * seg; S.slist = d_shuf + 4 * seg;
+    S.rank = d_rank; S.powtab = d_powtab; S.hit = d_hit;
+    S.rules = d_rule_args; S.progs = d_rule_progs; S.n_rules = (int)rule_args.size();
+    S.kmax = attack_kmax; S.nt_eval = solo_nt_eval; S.max_rounds = 1 << 20;
+    S.rec = h_rec; S.seq = ++step_seq;
+    for (int g = 0; g < NG; g++) {
+        HostGroup &G = groups[g];
+        if (actions && actions[g]) {
+            if (G.acted) fatal("set_action called twice for group %d before step: the reference would execute both action lists; unsupported", g);
+            G.acted = true;
+            if (G.n > 0) { S.actions[g] = actions[g]; S.call_base[g] = move_seq_base; move_seq_base += G.n; }
+        }
+        if (rewards && rewards[g] && G.n > 0) { S.rewards[g] = rewards[g]; S.group_reward[g] = G.group_reward; }
+        S.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed};
+    }
+    S.do_clear = 1;
+    S.gtab_out = d_gtab; S.ttab_out = d_ttab;
+    bool next_mini = false;
+    if (minimap_mode && first_obs >= 0) {   // the next cycle observes the same groups: its minimap is made here
+        const HostType &t = *groups[first_obs].type;
+        S.mini_vh = t.view.height; S.mini_vw = t.view.width;
+        S.mini_scale_h = (height + S.mini_vh - 1) / S.mini_vh; S.mini_scale_w = (width + S.mini_vw - 1) / S.mini_vw;
+        S.mini_skip = t.can_absorb ? 1 : 0;
+        grow(d_minif, minif_cap, (size_t)NG * S.mini_vh * S.mini_vw, stream);
+        S.mini_out = d_minif;
+        next_mini = true;
+    }
+    {
+        ProfScope p(*this, "step");
+        launch_step_solo(stream, W, S);
+    }
+    HIP_OK(hipGetLastError());
+    // ---- the report: done, deaths; the survivors' arrays have changed places
+    wait_record(step_seq);
+    const StepRecord &r = *h_rec;
+    if (r.error) fatal("%s resolution did not converge", r.error == 1 ? "attack" : "move");
+    if (r.unsupported) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
+    if (r.pack_overflow) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
+    if (r.bad_action) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
+    if (rng_on_device) rng.x = r.rng;
+    last_attack_iters = r.rounds_attack; last_move_iters = r.rounds_move; attack_round = r.rounds_attack;
+    int live = 0;
+    for (int g = 0; g < NG; g++) {
+        HostGroup &G = groups[g];
+        G.acted = false;
+        G.group_reward = 0;
+        if (G.n - r.dead[g] > 0) live++;
+        const int gone = r.dead[g] + r.taken[g];
+        if (gone > 0 && G.n > 0) {
+            std::swap(G.cur.x, G.alt.x); std::swap(G.cur.y, G.alt.y); std::swap(G.cur.id, G.alt.id);
+            std::swap(G.cur.hp, G.alt.hp); std::swap(G.cur.last_action, G.alt.last_action);
+            std::swap(G.cur.last_reward, G.alt.last_reward); std::swap(G.cur.next_reward, G.alt.next_reward);
+            std::swap(G.cur.absorbed, G.alt.absorbed);
+            G.n -= gone;
+        }
+        G.h_dead = 0; G.h_taken = 0;
+    }
+    *done = live < NG;   // GridWorld.cc:619-624
+    for (size_t k = 0; k < rules.size(); k++) if (((r.triggers >> k) & 1ull) && rules[k].terminal) *done = 1;
+    move_seq_base = 0;
+    h_occ_valid = false;
+    tables_valid = true;
+    paint_valid = step_live_paint;
+    mini_valid = next_mini;
+    if (next_mini) { mini_vh = S.mini_vh; mini_vw = S.mini_vw; mini_pop = mini_population(S.mini_skip != 0); }
 }
 
 // ------------------------------------------------------------------------------------------------ reward / clear_dead
@@ -1162,6 +1397,7 @@ void Env::get_reward_device(int g, float *out) {
 }
 
 void Env::get_reward_host(int g, float *out) {
+    if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_reward : %d", g);
     int n = groups[g].n;
     if (n == 0) return;
     grow(d_stage_small, stage_small_cap, (size_t)n * 8, stream);
@@ -1185,7 +1421,19 @@ void Env::clear_dead() {
         G.n -= G.h_dead + G.h_taken;
         G.h_dead = 0; G.h_taken = 0;
     };
-    if (!any) {                  // Agent::init_reward for everybody: one launch
+    bool small_world = solo_enabled;
+    for (auto &G : groups) small_world &= compact_is_solo(G.n);
+    if (small_world) {           // one launch of one workgroup: compaction / init_reward of every group + the device tables
+        ClearArgs A{};
+        for (size_t g = 0; g < groups.size(); g++) {
+            HostGroup &G = groups[g];
+            A.mode[g] = G.n == 0 ? 0 : (G.h_dead + G.h_taken > 0 ? 2 : 1);
+            A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed};
+        }
+        launch_clear_solo_all(stream, W, A, d_gtab, d_ttab);
+        for (size_t g = 0; g < groups.size(); g++) if (A.mode[g] == 2) swap_buffers(groups[g]);
+        tables_valid = true;
+    } else if (!any) {                  // Agent::init_reward for everybody: one launch
         ClearArgs A{};
         for (size_t g = 0; g < groups.size(); g++) A.mode[g] = groups[g].n > 0 ? 1 : 0;
         launch_clear_compact(stream, W, A, d_sums);
@@ -1245,6 +1493,12 @@ void Env::info_host(int g, const char *name, void *buf) {
     if (k == "num") { need_group(); ib[0] = groups[g].n; return; }
     if (k == "engine_stats") {   // additive: steps whose optimistic rounds ran out (host continued), rounds of the last checked phases
         ib[0] = fallback_steps; ib[1] = last_attack_iters; ib[2] = last_move_iters; ib[3] = attack_round;
+        return;
+    }
+    if (k == "step_marks") {     // additive (tuning): ns since the first mark at every phase boundary of the last one-launch step
+        const int n = h_rec ? h_rec->n_marks : 0;
+        ib[0] = n;
+        for (int q = 0; q < n; q++) ib[1 + q] = (int)((h_rec->marks[q] - h_rec->marks[0]) * 10ull);
         return;
     }
     if (k == "action_space") { need_group(); ib[0] = groups[g].type->n_action; return; }

@@ -109,6 +109,9 @@ public:
     void set_action_device(int g, const int *d_act);
     void get_reward_device(int g, float *out);
     void info_device(int g, const char *name, void *out);
+    // one environment cycle -- observe + set_action per group, step, rewards, clear_dead (examples/train_battle.py:61-109) --
+    // in two launches for small worlds (k_render_multi, k_step_solo); NULL entries skip that call for that group
+    void cycle(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, int *done);
     void sync();
     void profile_read(const char *name, int *n, float *ms);
 
@@ -125,6 +128,9 @@ public:
     // optimistic rounds of the single-sync driver: one pair / batch, two for 64 steps after a run-out (or fixed by env)
     int opt_attack_pairs = 1, opt_move_batches = 1, boost_attack = 0, boost_move = 0;
     bool opt_fixed = false;
+    // one-launch step of small worlds (k_step_solo): on by default, MAGENT_SOLO_STEP=0 keeps the multi-launch drivers
+    bool solo_enabled = true;
+    int solo_max_agents = 16384;
 
 private:
     struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
@@ -145,7 +151,15 @@ private:
     void compile_rules();
     void compile_rule_program(size_t k);
     void enqueue_counters();
-    bool step_pending = false, step_was_fast = false;
+    bool step_pending = false, step_was_fast = false, step_was_solo = false, step_live_paint = false;
+    bool solo_ok(int total_n);
+    void wait_record(int seq);
+    StepRecord *h_rec = nullptr;          // pinned: written by k_step_solo, spun on by step_end
+    int step_seq = 0;
+    int solo_nt_eval = 0;
+    unsigned *d_hit = nullptr;            // per cell: hit bits / wanted counters of the one-launch step, zero between phases
+    bool claim_clean = false;             // every claim word is CLAIM_NONE (the one-launch step keeps it so)
+    RuleArgs *d_rule_args = nullptr; RuleProg *d_rule_progs = nullptr;
     void shuffle_buffers(int n_max);
     void push_rng();
     void attack_rounds_checked(const WorldView &W);
@@ -157,6 +171,8 @@ private:
     bool host_blank(int x, int y, int bw, int bl) const;
     void host_random_blank(int bw, int bl, int &ox, int &oy);
     void plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *feat);
+    bool prepare_render(int g, const WorldView &W, RenderArgs &R, RenderPlan &P, float *view, float *feat);
+    long long mini_population(bool skip) const;
     void copy_out(void *host_dst, const void *dev_src, size_t bytes);
     void read_back(void *host_dst, const void *dev_src, size_t bytes);
     char *h_small = nullptr; size_t h_small_cap = 0;   // pinned bounce buffer of read_back

@@ -109,6 +109,31 @@ __global__ void __launch_bounds__(256) k_paint(WorldView W, const GroupDev *gtab
     }
 }
 
+// one cell of the painted copy, in whichever format the game uses (must match k_paint)
+__device__ __forceinline__ void vc_store(const WorldView &W, int c, int code, unsigned hpbits) {
+    if (W.vc_packed) {
+        ((unsigned *)W.viewcell)[c] = code == OCC_EMPTY ? VC_EMPTY : code == OCC_WALL ? VC_WALL : code == OCC_FOOD ? VC_FOOD : (((unsigned)code << 30) | hpbits);
+        if (code >= 0 && (hpbits >> 30)) W.counters[CTR_PACK_OVERFLOW] = 1;
+    } else W.viewcell[c] = make_int2(code, (int)hpbits);
+}
+// Map::clear_area; with live_paint the painted copy follows at once (the step keeps it current: cells are emptied where
+// they are vacated, and at the end of the step every live agent paints its own body -- repaint_body)
+__device__ __forceinline__ void cells_clear(const WorldView &W, int x, int y, int bw, int bl) {
+    for (int by = 0; by < bl; by++)
+        for (int bx = 0; bx < bw; bx++) {
+            const int c = (y + by) * W.w + x + bx;
+            W.occ[c] = OCC_EMPTY;
+            if (W.live_paint) vc_store(W, c, OCC_EMPTY, 0u);
+        }
+}
+__device__ __forceinline__ void repaint_body(const WorldView &W, const GroupDev &G, const TypeDev &T, int g, int i) {
+    if (G.dead[i]) return;
+    const unsigned bits = __float_as_uint(__fdiv_rn(G.hp[i], T.hp));   // the reference's `get_hp() / get_type().hp` (Map.cc:197)
+    const int x = G.x[i], y = G.y[i];
+    for (int by = 0; by < T.bl; by++)
+        for (int bx = 0; bx < T.bw; bx++) vc_store(W, (y + by) * W.w + x + bx, g, bits);
+}
+
 // ------------------------------------------------------------------------------------------------ minimap histogram
 // counts[j][cell] = number of agents of group j whose (x / scale_w, y / scale_h) is cell (GridWorld.cc:341-352;
 // dead-but-not-cleared agents are counted, as in the reference).  LDS int atomics per block, then one global
@@ -220,18 +245,19 @@ __global__ void __launch_bounds__(256) k_features(WorldView W, RenderArgs R, Ren
 // in its own L2.
 constexpr int RENDER_WAVES = 4;
 
+// (bx of nb workgroups of the launch work on this group: the render spans first, then the feature rows)
 template <bool VEC4, bool NT, int U, bool PACKED>
-__global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, RenderArgs R, RenderPlan P) {
+__device__ __forceinline__ void render_block(const WorldView &W, const RenderArgs &R, const RenderPlan &P, int bx, int nb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int VHW = R.VH * R.VW, C = R.C, G = W.G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *strip = (float *)smem + (size_t)wave * P.strip_floats;      // [64][C], wave-private
 
-    if ((int)blockIdx.x >= P.spans) {   // the trailing workgroups write the group's feature rows (3 % of the bytes)
-        features_body<VEC4>(W, R, P, blockIdx.x - P.spans, gridDim.x - P.spans);
+    if (bx >= P.spans) {   // the trailing workgroups write the group's feature rows (3 % of the bytes)
+        features_body<VEC4>(W, R, P, bx - P.spans, nb - P.spans);
         return;
     }
-    int span = blockIdx.x;
+    int span = bx;
     if (P.xcd_chunk > 0 && span < P.xcd_chunk * 8) span = (span & 7) * P.xcd_chunk + (span >> 3);
     const GroupDev Gd = W.grp[R.g];
     const TypeDev T = W.type[R.g];
@@ -339,6 +365,18 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, Rende
     }
 }
 
+template <bool VEC4, bool NT, int U, bool PACKED>
+__global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, RenderArgs R, RenderPlan P) {
+    render_block<VEC4, NT, U, PACKED>(W, R, P, blockIdx.x, gridDim.x);
+}
+// several groups of a small world in one launch (blockIdx.y = slot): small worlds are bound by the number of launches
+template <bool PACKED>
+__global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_multi(WorldView W, RenderMulti M) {
+    const int k = blockIdx.y;
+    if ((int)blockIdx.x >= M.blocks[k]) return;
+    render_block<true, true, 1, PACKED>(W, M.R[k], M.P[k], blockIdx.x, M.blocks[k]);
+}
+
 // ------------------------------------------------------------------------------------------------ block scan trio
 // Exclusive prefix sum of a per-agent predicate over one group, SCAN_ITEMS elements per thread:
 //   pass A  per-block totals            pass B  one block scans the totals (+ base)      pass C  per-element ranks
@@ -437,7 +475,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int 
         if (i < G.n) {
             int act = actions[i];
             G.last_action[i] = act;
-            if (act < T.n_move) {
+            if (act < 0 || act >= T.n_move + T.n_attack) {   // outside the action space: no action, reported at the end of the step
+                W.counters[CTR_BAD_ACTION] = 1;
+                G.pend[i] = PEND_NONE;
+            } else if (act < T.n_move) {
                 unsigned bound = 0;
                 if (W.large_map) { int x_ = G.x[i] % W.bandwidth; bound = (x_ < 4 || x_ > W.bandwidth - 4) ? 1u : 0u; }
                 G.pend[i] = PEND_MOVE | act;
@@ -462,14 +503,17 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_c(WorldView W, int 
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) W.counters[CTR_ATTACK] = before + sums[blockIdx.x];
 }
 
-__global__ void __launch_bounds__(SOLO_THREADS) k_set_action_solo(WorldView W, int g, const int *actions, int call_base) {
-    const GroupDev G = W.grp[g];
-    const TypeDev T = W.type[g];
+__device__ __forceinline__ void set_action_solo_body(const WorldView &W, int g, const int *actions, int call_base) {
+    const GroupDev &G = W.grp[g];
+    const TypeDev &T = W.type[g];
     const int base = W.counters[CTR_ATTACK];
     for (int i = threadIdx.x; i < G.n; i += SOLO_THREADS) {
         int act = actions[i];
         G.last_action[i] = act;
-        if (act < T.n_move) {
+        if (act < 0 || act >= T.n_move + T.n_attack) {
+            W.counters[CTR_BAD_ACTION] = 1;
+            G.pend[i] = PEND_NONE;
+        } else if (act < T.n_move) {
             unsigned bound = 0;
             if (W.large_map) { int x_ = G.x[i] % W.bandwidth; bound = (x_ < 4 || x_ > W.bandwidth - 4) ? 1u : 0u; }
             G.pend[i] = PEND_MOVE | act;
@@ -481,6 +525,9 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_set_action_solo(WorldView W, i
     __syncthreads();   // base was read by every thread before the total is written back
     int total = solo_rank([&](int i) { return actions[i] >= T.n_move; }, [&](int i, int r) { G.key[i] = (unsigned)r; }, G.n, base);
     if (threadIdx.x == 0) W.counters[CTR_ATTACK] = total;
+}
+__global__ void __launch_bounds__(SOLO_THREADS) k_set_action_solo(WorldView W, int g, const int *actions, int call_base) {
+    set_action_solo_body(W, g, actions, call_base);
 }
 
 // ------------------------------------------------------------------------------------------------ generic int scan
@@ -516,7 +563,7 @@ __global__ void __launch_bounds__(256) k_iscan_c(const int *in, int n, const int
     for (int k = 0; k < ISCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
 }
 
-__global__ void __launch_bounds__(SOLO_THREADS) k_iscan_solo(const int *in, int n, int *out) {
+__device__ __forceinline__ void iscan_solo_body(const int *in, int n, int *out) {
     __shared__ int s_w[SOLO_THREADS / 64];
     const int wave = threadIdx.x >> 6;
     int run = 0;
@@ -535,6 +582,7 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_iscan_solo(const int *in, int 
         __syncthreads();
     }
 }
+__global__ void __launch_bounds__(SOLO_THREADS) k_iscan_solo(const int *in, int n, int *out) { iscan_solo_body(in, n, out); }
 
 // ------------------------------------------------------------------------------------------------ attack shuffle
 // The reference shuffles the attack list with `for i: j = (int)rng() % (i + 1); swap(buf[i], buf[j])`
@@ -552,38 +600,24 @@ __device__ __forceinline__ unsigned mulmod31(unsigned a, unsigned b) {
 }
 
 // powtab: 16807^t mod (2^31 - 1) for t = 0..255, then 16807^(256 h) for h = 0, 1, ... (host-computed, engine.hip)
-__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *count, unsigned *hitbits, size_t ncell,
-                                                     const unsigned *powtab) {
-    const int A = counters[CTR_ATTACK];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    // the per-cell hit words of the coming attack phase start from zero (they share the move phase's claim array)
-    if (A > 0) for (size_t c = i; c < ncell; c += (size_t)gridDim.x * blockDim.x) hitbits[c] = 0u;
-    if (i >= A) return;
+__device__ __forceinline__ void shuffle_draw_body(unsigned x0, int i, int *j, int *count, const unsigned *powtab) {
     const unsigned e = (unsigned)i + 1u;               // the i-th draw is x0 * 16807^(i+1): two table factors
-    const unsigned acc = mulmod31(mulmod31((unsigned)counters[CTR_RNG], powtab[256 + (e >> 8)]), powtab[e & 255u]);
+    const unsigned acc = mulmod31(mulmod31(x0, powtab[256 + (e >> 8)]), powtab[e & 255u]);
     int ji = (int)(acc % (unsigned)(i + 1));   // (int)rng() % (i + 1): outputs are in [1, 2^31 - 2]
     j[i] = ji;
     atomicAdd(&count[ji], 1);
 }
-
-__global__ void __launch_bounds__(256) k_shuffle_fill(int *counters, const int *j, const int *offset, int *cursor, int *list) {
-    const int A = counters[CTR_ATTACK];
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) {   // the engine state after the shuffle's A draws: x <- 16807^A x (every draw has read the old state:
-        unsigned e = (unsigned)A, base = 16807u, acc = (unsigned)counters[CTR_RNG];   // k_shuffle_draw ran before)
-        counters[CTR_LAST_A] = A;
-        while (e) { if (e & 1u) acc = mulmod31(acc, base); base = mulmod31(base, base); e >>= 1; }
-        counters[CTR_RNG] = (int)acc;   // the host mirror is refreshed at the end-of-step readback
-    }
-    if (k >= A) return;
+// the engine state after the shuffle's A draws: x <- 16807^A x
+__device__ __forceinline__ unsigned rng_skip(unsigned x, unsigned n) {
+    unsigned base = 16807u;
+    while (n) { if (n & 1u) x = mulmod31(x, base); base = mulmod31(base, base); n >>= 1; }
+    return x;
+}
+__device__ __forceinline__ void shuffle_fill_body(int k, const int *j, const int *offset, int *cursor, int *list) {
     int v = j[k];
     list[offset[v] + atomicAdd(&cursor[v], 1)] = k;
 }
-
-__global__ void __launch_bounds__(256) k_shuffle_chase(const int *counters, const int *j, const int *offset, const int *count, const int *list, int *rank) {
-    const int A = counters[CTR_ATTACK];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A) return;
+__device__ __forceinline__ void shuffle_chase_body(int i, const int *j, const int *offset, const int *count, const int *list, int *rank) {
     int p = j[i], t = i;
     while (true) {
         const int *b = list + offset[p];
@@ -595,21 +629,39 @@ __global__ void __launch_bounds__(256) k_shuffle_chase(const int *counters, cons
     rank[i] = p;
 }
 
+__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *count, unsigned *hitbits, size_t ncell,
+                                                     const unsigned *powtab) {
+    const int A = counters[CTR_ATTACK];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // the per-cell hit words of the coming attack phase start from zero (they share the move phase's claim array)
+    if (A > 0) for (size_t c = i; c < ncell; c += (size_t)gridDim.x * blockDim.x) hitbits[c] = 0u;
+    if (i >= A) return;
+    shuffle_draw_body((unsigned)counters[CTR_RNG], i, j, count, powtab);
+}
+
+__global__ void __launch_bounds__(256) k_shuffle_fill(int *counters, const int *j, const int *offset, int *cursor, int *list) {
+    const int A = counters[CTR_ATTACK];
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) {   // (every draw has read the old state: k_shuffle_draw ran before)
+        counters[CTR_LAST_A] = A;
+        counters[CTR_RNG] = (int)rng_skip((unsigned)counters[CTR_RNG], (unsigned)A);   // the host mirror is refreshed at the end-of-step readback
+    }
+    if (k >= A) return;
+    shuffle_fill_body(k, j, offset, cursor, list);
+}
+
+__global__ void __launch_bounds__(256) k_shuffle_chase(const int *counters, const int *j, const int *offset, const int *count, const int *list, int *rank) {
+    const int A = counters[CTR_ATTACK];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A) return;
+    shuffle_chase_body(i, j, offset, count, list, rank);
+}
+
 // ------------------------------------------------------------------------------------------------ attack phase
 // rank[seq] = position of attack-list entry `seq` after the reference's shuffle (GridWorld.cc:464-468)
-__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_count, int *shuf_cursor) {
-    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // attack rounds start
-    const int A = W.counters[CTR_ATTACK];
-    if (A == 0) return;
-    // the shuffle's bucket counters have been read for the last time (k_shuffle_chase): back to zero for the next step
-    for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < A; k += gridDim.x * gridDim.y * blockDim.x) {
-        shuf_count[k] = 0; shuf_cursor[k] = 0;
-    }
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    const TypeDev T = W.type[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n) return;
+__device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int i, const int *rank, unsigned *hitbits) {
+    const GroupDev &G = W.grp[g];
+    const TypeDev &T = W.type[g];
     const int pend = G.pend[i];
     const bool att = (pend & ~PEND_ARG) == PEND_ATTACK;
     const bool dead = G.dead[i];
@@ -631,6 +683,19 @@ __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *ran
         }
     }
     if (W.food_mode) { G.eat[i] = -1.0f; G.fcell[i] = -1; }
+}
+__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_count, int *shuf_cursor) {
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // attack rounds start
+    const int A = W.counters[CTR_ATTACK];
+    if (A == 0) return;
+    // the shuffle's bucket counters have been read for the last time (k_shuffle_chase): back to zero for the next step
+    for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < A; k += gridDim.x * gridDim.y * blockDim.x) {
+        shuf_count[k] = 0; shuf_cursor[k] = 0;
+    }
+    const int g = blockIdx.y;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W.grp[g].n) return;
+    attack_rank_body(W, g, i, rank, hitbits);
 }
 
 // The hits that land on cell (cx, cy), appended to a thread-private LDS list (stride NT): bit (attack_bit[ga] + k) of
@@ -675,13 +740,13 @@ __device__ __forceinline__ int attack_cell(const WorldView &W, const GroupDev *g
 }
 // food_mode: one attacker eats from what is left on a cell (Map.cc:292-303).  `eat` of an attacker is written by the
 // owner of its target cell only; a change sends the attacker back into evaluation.
-__device__ __forceinline__ bool set_eat(const WorldView &W, const GroupDev *gtab, int a, float e, int round, int flag) {
+__device__ __forceinline__ bool set_eat(const WorldView &W, const GroupDev *gtab, int a, float e, int round, int *flagp) {
     const GroupDev A = gtab[ref_group(a)];
     const int ai = ref_index(a);
     if (A.eat[ai] == e) return false;
     A.eat[ai] = e;
     A.drank_b[ai] = round;
-    if (flag >= 0) W.counters[flag] = 1;
+    if (flagp) *flagp = 1;
     return true;
 }
 
@@ -693,20 +758,12 @@ __device__ __forceinline__ bool set_eat(const WorldView &W, const GroupDev *gtab
 // lower rank: an agent is re-evaluated in round r only if one of its inputs changed in round r - 1 or earlier in
 // round r (drank_b holds the last round in which an input changed), so after the first round only the neighbourhood
 // of the deaths is touched; a round without any change leaves every agent consistent with its inputs.
-// workgroup size: as large as the hit lists (kmax x threads x 8 B of LDS) allow, see att_threads()
-__global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab,
-                                                             int round /* 1, 2, ... within this step */,
-                                                             const unsigned *hitbits, int kmax, int flag) {
-    if (W.counters[CTR_ATTACK] == 0) return;
-    extern __shared__ unsigned s_hit[];               // [kmax][ATT_THREADS] ranks, then [kmax][ATT_THREADS] refs
-    const int ATT_THREADS = blockDim.x;
-    unsigned *s_rank = s_hit;
-    int *s_ref = (int *)(s_hit + kmax * ATT_THREADS);
-    const int g = blockIdx.y, tid = threadIdx.x;
-    const GroupDev G = W.grp[g];
-    const TypeDev T = W.type[g];
-    const int i = blockIdx.x * blockDim.x + tid;
-    if (i >= G.n) return;
+// (s_rank / s_ref: the thread's hit list, stride ATT_THREADS, slot tid; flagp: where to report a change, or null)
+__device__ __forceinline__ void attack_eval_body(const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int g, int i,
+                                                 int round /* 1, 2, ... within this step */, const unsigned *hitbits,
+                                                 unsigned *s_rank, int *s_ref, int ATT_THREADS, int tid, int *flagp) {
+    const GroupDev &G = W.grp[g];
+    const TypeDev &T = W.type[g];
     const int dr_me_cur = G.drank_a[i];
     if (dr_me_cur == -1) return;                      // dead before the phase
     if (G.drank_b[i] < round - 1) return;             // no input has changed since my last evaluation
@@ -791,7 +848,7 @@ __global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev
                     if ((double)food < 0.1) present = false;
                 }
             }
-            set_eat(W, gtab, a, e, round, flag);
+            set_eat(W, gtab, a, e, round, flagp);
         }
         G.fcell[i] = present ? c_food : -1;
         G.fleft[i] = food;
@@ -805,8 +862,20 @@ __global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev
         if (reader >= 0) gtab[ref_group(reader)].drank_b[ref_index(reader)] = round;
         if (W.any_kill_supply)
             for (int k = 0; k < nh; k++) { const int a = s_ref[k * ATT_THREADS + tid]; gtab[ref_group(a)].drank_b[ref_index(a)] = round; }
-        if (flag >= 0) W.counters[flag] = 1;          // only the last round of a batch reports
+        if (flagp) *flagp = 1;                        // (multi-launch driver: only the last round of a batch reports)
     }
+}
+// workgroup size: as large as the hit lists (kmax x threads x 8 B of LDS) allow, see att_threads()
+__global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab, int round,
+                                                     const unsigned *hitbits, int kmax, int flag) {
+    if (W.counters[CTR_ATTACK] == 0) return;
+    extern __shared__ unsigned s_hit[];               // [kmax][ATT_THREADS] ranks, then [kmax][ATT_THREADS] refs
+    const int ATT_THREADS = blockDim.x;
+    const int g = blockIdx.y, tid = threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + tid;
+    if (i >= W.grp[g].n) return;
+    attack_eval_body(W, gtab, ttab, g, i, round, hitbits, s_hit, (int *)(s_hit + kmax * ATT_THREADS), ATT_THREADS, tid,
+                     flag >= 0 ? &W.counters[flag] : nullptr);
 }
 
 // food_mode: the food that lay on the map before this step.  One thread per cell: the hits on a food cell eat from it
@@ -835,7 +904,7 @@ __global__ void __launch_bounds__(256) k_food_eval(WorldView W, const GroupDev *
             food -= e;
             if ((double)food < 0.1) present = false;
         }
-        set_eat(W, gtab, a, e, round, flag);
+        set_eat(W, gtab, a, e, round, flag >= 0 ? &W.counters[flag] : nullptr);
     }
     W.food_next[c] = present ? food : -1.0f;
 }
@@ -851,13 +920,9 @@ __global__ void __launch_bounds__(256) k_food_apply(WorldView W, const unsigned 
 // The converged phase applied: hp, death, rewards, last_op / op_obj.  Nothing is replayed here: every agent that is hit
 // left the hp of its LAST evaluation in `mv` (that evaluation saw the final death ranks -- otherwise the agent would
 // have been marked and evaluated again), and the attacker-side results only need the death ranks.
-__global__ void __launch_bounds__(256) k_attack_apply(WorldView W, const GroupDev *gtab, const TypeDev *ttab, const unsigned *hitbits) {
-    if (W.counters[CTR_ATTACK] == 0 || attack_open(W)) return;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    const TypeDev T = W.type[g];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n) return;
+__device__ __forceinline__ void attack_apply_body(const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int g, int i, const unsigned *hitbits) {
+    const GroupDev &G = W.grp[g];
+    const TypeDev &T = W.type[g];
     const int dr = G.drank_a[i];
     if (dr == -1) return;                             // dead before the phase
     const int pend = G.pend[i];
@@ -915,6 +980,13 @@ __global__ void __launch_bounds__(256) k_attack_apply(WorldView W, const GroupDe
     } else if (acted) nr += own;
     G.next_reward[i] = nr;
 }
+__global__ void __launch_bounds__(256) k_attack_apply(WorldView W, const GroupDev *gtab, const TypeDev *ttab, const unsigned *hitbits) {
+    if (W.counters[CTR_ATTACK] == 0 || attack_open(W)) return;
+    const int g = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W.grp[g].n) return;
+    attack_apply_body(W, gtab, ttab, g, i, hitbits);
+}
 
 // render support: ev[rank] = {attacker id, target x, target y, 1} for every attack that was executed (attacker alive at
 // its turn), in the order the reference appends them (GridWorld.cc:483-485: before the blank-target test, so blank and
@@ -935,7 +1007,7 @@ __global__ void __launch_bounds__(256) k_attack_events(WorldView W, int4 *ev) {
 
 // ------------------------------------------------------------------------------------------------ starve / recover
 // (device function: runs at the head of the move-preparation launch -- one dependent launch less per step)
-__device__ __forceinline__ void starve_body(const WorldView &W, int g, const GroupDev &G, const TypeDev &T, int i) {
+__device__ __forceinline__ void starve_body(const WorldView &W, int g, const GroupDev &G, const TypeDev &T, int i, int slot) {
     bool died = false;
     // first: the agents that died in this step's attack phase leave the map (Map::remove_agent, Map.cc:272) -- here, in
     // the launch after the attack's, because the attack kernels find attackers through the phase-start map
@@ -944,7 +1016,7 @@ __device__ __forceinline__ void starve_body(const WorldView &W, int g, const Gro
         const int dr = G.drank_a[i];
         if (dr != -1 && dr != RANK_INF) {
             died = true;
-            body_fill(W, G.x[i], G.y[i], T.bw, T.bl, OCC_EMPTY);
+            cells_clear(W, G.x[i], G.y[i], T.bw, T.bl);
             if (W.food_mode && G.fcell[i] >= 0) { W.occ[G.fcell[i]] = OCC_FOOD; W.food[G.fcell[i]] = G.fleft[i]; }   // Map.cc:276-283
         }
     }
@@ -953,12 +1025,12 @@ __device__ __forceinline__ void starve_body(const WorldView &W, int g, const Gro
         if (T.step_recover > 0) hp = fminf(T.hp, hp + T.step_recover);
         else {
             hp -= -T.step_recover;
-            if (hp < 0.0f) { died = true; G.dead[i] = 1; G.next_reward[i] = T.dead_penalty; body_fill(W, G.x[i], G.y[i], T.bw, T.bl, OCC_EMPTY); }
+            if (hp < 0.0f) { died = true; G.dead[i] = 1; G.next_reward[i] = T.dead_penalty; cells_clear(W, G.x[i], G.y[i], T.bw, T.bl); }
         }
         G.hp[i] = hp;
     }
     int wtot; wave_rank(died, wtot);
-    if (wtot && lane_id() == 0) atomicAdd(&W.counters[dead_slot(g, blockIdx.x % DEAD_SLOTS)], wtot);
+    if (wtot && lane_id() == 0) atomicAdd(&W.counters[dead_slot(g, slot)], wtot);
 }
 
 // ------------------------------------------------------------------------------------------------ move phase
@@ -968,17 +1040,11 @@ __device__ __forceinline__ void starve_body(const WorldView &W, int g, const Gro
 //   is static (64-bit atomic umin of {key, ref} per cell); whether O leaves is a chain of such dependencies that
 //   only points to lower keys, resolved by pointer jumping.
 // tgt (= drank_a, free after the attack phase): target cell of a move candidate, -1 otherwise.
-__global__ void __launch_bounds__(256) k_move_prep(WorldView W, unsigned *claim_words, size_t n_words) {
-    if (attack_open(W)) return;
-    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // move rounds start
-    // the claim words back to "nobody" (they held the attack phase's hit bits until now)
-    for (size_t k = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < n_words;
-         k += (size_t)gridDim.x * gridDim.y * blockDim.x) claim_words[k] = 0xFFFFFFFFu;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    const TypeDev T = W.type[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    starve_body(W, g, G, T, i);
+// (every lane of a wave calls this, i >= n included: starve_body counts the dead with a wave ballot)
+__device__ __forceinline__ void move_prep_body(const WorldView &W, int g, int i, int slot) {
+    const GroupDev &G = W.grp[g];
+    const TypeDev &T = W.type[g];
+    starve_body(W, g, G, T, i, slot);
     if (i >= G.n) return;
     int t = -1;
     int pend = G.pend[i];
@@ -992,13 +1058,17 @@ __global__ void __launch_bounds__(256) k_move_prep(WorldView W, unsigned *claim_
     G.drank_a[i] = t;
     G.mv[i] = MV_FAIL;
 }
-
-__global__ void __launch_bounds__(256) k_move_claim(WorldView W, const GroupDev *gtab) {
+__global__ void __launch_bounds__(256) k_move_prep(WorldView W, unsigned *claim_words, size_t n_words) {
     if (attack_open(W)) return;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n) return;
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // move rounds start
+    // the claim words back to "nobody" (they held the attack phase's hit bits until now)
+    for (size_t k = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < n_words;
+         k += (size_t)gridDim.x * gridDim.y * blockDim.x) claim_words[k] = 0xFFFFFFFFu;
+    move_prep_body(W, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.x % DEAD_SLOTS);
+}
+
+__device__ __forceinline__ void move_claim_body(const WorldView &W, const GroupDev *gtab, int g, int i) {
+    const GroupDev &G = W.grp[g];
     int c = G.drank_a[i];
     if (c < 0) return;
     unsigned key = G.key[i];
@@ -1012,13 +1082,14 @@ __global__ void __launch_bounds__(256) k_move_claim(WorldView W, const GroupDev 
     }
     if (ok) atomicMin(&W.claim[c], ((unsigned long long)key << 32) | (unsigned)ref_pack(g, i));
 }
-
-__global__ void __launch_bounds__(256) k_move_init(WorldView W) {
+__global__ void __launch_bounds__(256) k_move_claim(WorldView W, const GroupDev *gtab) {
     if (attack_open(W)) return;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.grp[g].n) move_claim_body(W, gtab, g, i);
+}
+
+__device__ __forceinline__ void move_init_body(const WorldView &W, int g, int i) {
+    const GroupDev &G = W.grp[g];
     int c = G.drank_a[i];
     if (c < 0) return;
     unsigned long long cl = W.claim[c];
@@ -1027,18 +1098,24 @@ __global__ void __launch_bounds__(256) k_move_init(WorldView W) {
     if (o == OCC_EMPTY) G.mv[i] = MV_OK;
     else G.mv[i] = (unsigned)o;                                    // succeeds iff the occupant o succeeds
 }
-
-__global__ void __launch_bounds__(256) k_move_jump(WorldView W, const GroupDev *gtab, int flag) {
+__global__ void __launch_bounds__(256) k_move_init(WorldView W) {
     if (attack_open(W)) return;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.grp[g].n) move_init_body(W, g, i);
+}
+
+__device__ __forceinline__ void move_jump_body(const WorldView &W, const GroupDev *gtab, int g, int i, int *flagp) {
+    const GroupDev &G = W.grp[g];
     unsigned m = G.mv[i];
     if (m >= MV_OK) return;
     unsigned s = gtab[ref_group((int)m)].mv[ref_index((int)m)];
     G.mv[i] = s;                                                   // OK / FAIL resolve me; otherwise jump
-    if (flag >= 0 && s < MV_OK) W.counters[flag] = 1;           // only the last round of a batch reports
+    if (flagp && s < MV_OK) *flagp = 1;                            // (multi-launch driver: only the last round of a batch reports)
+}
+__global__ void __launch_bounds__(256) k_move_jump(WorldView W, const GroupDev *gtab, int flag) {
+    if (attack_open(W)) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.grp[g].n) move_jump_body(W, gtab, g, i, flag >= 0 ? &W.counters[flag] : nullptr);
 }
 
 // End of the 1x1 move phase, one launch.
@@ -1047,17 +1124,13 @@ __global__ void __launch_bounds__(256) k_move_jump(WorldView W, const GroupDev *
 // nobody (no claim on it: the leaver clears it) -- no cell is written by two agents.
 // Failed moves: collide bookkeeping (Map.cc:334-353) from what k_move_claim saved of the phase-start map (drank_b),
 // the claims and the move states -- nothing that this launch writes.
-__global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev *gtab) {
-    if (step_open(W)) return;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n) return;
+__device__ __forceinline__ void move_commit_body(const WorldView &W, const GroupDev *gtab, int g, int i) {
+    const GroupDev &G = W.grp[g];
     const int c = G.drank_a[i];
     if (c >= 0) {
         if (G.mv[i] == MV_OK) {
             const int old = G.y[i] * W.w + G.x[i];
-            if (W.claim[old] == CLAIM_NONE) W.occ[old] = OCC_EMPTY;
+            if (W.claim[old] == CLAIM_NONE) { W.occ[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }
             W.occ[c] = ref_pack(g, i);
             const int ny = c / W.w;
             G.x[i] = c - ny * W.w; G.y[i] = ny;
@@ -1077,6 +1150,11 @@ __global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev
         }
     }
     G.pend[i] = PEND_NONE;   // end of step: pending actions are consumed (also done by k_finish for the generic path)
+}
+__global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev *gtab) {
+    if (step_open(W)) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.grp[g].n) move_commit_body(W, gtab, g, i);
 }
 
 // ------------------------------------------------------------------------------------------------ move, generic bodies
@@ -1124,7 +1202,7 @@ __device__ __forceinline__ void for_each_entrant(const WorldView &W, int cx, int
 // collide object?   MODE 2 (can_absorb types present): the outcome depends on WHICH agent is met first, so the scan
 // stops at the first cell that holds an agent or whose state is still unknown
 template <int MODE>
-__device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g, int i, int tgt_cell, const unsigned *wanted) {
+__device__ __forceinline__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g, int i, int tgt_cell, const unsigned *wanted) {
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
     const unsigned key = G.key[i];
@@ -1177,14 +1255,10 @@ __device__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g,
 }
 
 // candidates: alive movers with a non-zero delta whose target rectangle is inside the map (Map.cc:455)
-__global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted) {
-    if (attack_open(W)) return;
-    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // move rounds start
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    const TypeDev T = W.type[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    starve_body(W, g, G, T, i);
+__device__ __forceinline__ void movg_prep_body(const WorldView &W, int g, int i, unsigned *wanted, int slot) {
+    const GroupDev &G = W.grp[g];
+    const TypeDev &T = W.type[g];
+    starve_body(W, g, G, T, i, slot);
     if (i >= G.n) return;
     int t = -1;
     const int pend = G.pend[i];
@@ -1203,20 +1277,21 @@ __global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted
             for (int bx = 0; bx < T.bw; bx++) atomicAdd(&wanted[(ny + by) * W.w + nx + bx], 1u);
     }
 }
-
-__global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev *gtab, const unsigned *wanted, int flag) {
+__global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted) {
     if (attack_open(W)) return;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n) return;
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // move rounds start
+    movg_prep_body(W, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, wanted, blockIdx.x % DEAD_SLOTS);
+}
+
+__device__ __forceinline__ void movg_sweep_body(const WorldView &W, const GroupDev *gtab, int g, int i, const unsigned *wanted, int *flagp) {
+    const GroupDev &G = W.grp[g];
     const int t = G.drank_a[i];
     if (t < 0 || G.mv[i] != 0) return;
     if (!W.any_absorb) {
         MoveProbe r = move_probe<0>(W, gtab, g, i, t, wanted);
         if (r.blocked) G.mv[i] = MV_FAIL;
         else if (!r.undecided) G.mv[i] = MV_OK;
-        else if (flag >= 0) W.counters[flag] = 1;
+        else if (flagp) *flagp = 1;
         return;
     }
     // Map::do_move with goals (Map.cc:334-353): the collide object is the first agent met; a goal that is still free
@@ -1253,16 +1328,17 @@ __global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev 
         }
     }
     if (st) G.mv[i] = st;
-    else if (flag >= 0) W.counters[flag] = 1;
+    else if (flagp) *flagp = 1;
+}
+__global__ void __launch_bounds__(256) k_movg_sweep(WorldView W, const GroupDev *gtab, const unsigned *wanted, int flag) {
+    if (attack_open(W)) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.grp[g].n) movg_sweep_body(W, gtab, g, i, wanted, flag >= 0 ? &W.counters[flag] : nullptr);
 }
 
 // Map::get_collide for failed moves (Map.cc:334-353, 486-501): first agent met in the target rectangle
-__global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDev *gtab, const unsigned *wanted) {
-    if (step_open(W)) return;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n) return;
+__device__ __forceinline__ void movg_collide_body(const WorldView &W, const GroupDev *gtab, int g, int i, const unsigned *wanted) {
+    const GroupDev &G = W.grp[g];
     const int t = G.drank_a[i];
     if (t < 0) return;
     const unsigned st = G.mv[i];
@@ -1280,27 +1356,35 @@ __global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDe
         atomicAdd(&W.counters[CTR_TAKEN + g], 1);
     }
 }
-
-__global__ void __launch_bounds__(256) k_movg_vacate(WorldView W) {
+__global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDev *gtab, const unsigned *wanted) {
     if (step_open(W)) return;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n || G.drank_a[i] < 0 || !(G.mv[i] == MV_OK || mv_taken(G.mv[i]))) return;
-    body_fill(W, G.x[i], G.y[i], W.type[g].bw, W.type[g].bl, OCC_EMPTY);
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.grp[g].n) movg_collide_body(W, gtab, g, i, wanted);
 }
 
-__global__ void __launch_bounds__(256) k_movg_enter(WorldView W) {
+__device__ __forceinline__ void movg_vacate_body(const WorldView &W, int g, int i) {
+    const GroupDev &G = W.grp[g];
+    if (G.drank_a[i] < 0 || !(G.mv[i] == MV_OK || mv_taken(G.mv[i]))) return;
+    cells_clear(W, G.x[i], G.y[i], W.type[g].bw, W.type[g].bl);
+}
+__global__ void __launch_bounds__(256) k_movg_vacate(WorldView W) {
     if (step_open(W)) return;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.grp[g].n) movg_vacate_body(W, g, i);
+}
+
+__device__ __forceinline__ void movg_enter_body(const WorldView &W, int g, int i) {
+    const GroupDev &G = W.grp[g];
     const int c = G.drank_a[i];
     if (c < 0 || G.mv[i] != MV_OK) return;
     const int ny = c / W.w, nx = c - ny * W.w;
     body_fill(W, nx, ny, W.type[g].bw, W.type[g].bl, ref_pack(g, i));
     G.x[i] = nx; G.y[i] = ny;
+}
+__global__ void __launch_bounds__(256) k_movg_enter(WorldView W) {
+    if (step_open(W)) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.grp[g].n) movg_enter_body(W, g, i);
 }
 
 // ------------------------------------------------------------------------------------------------ reward rules
@@ -1310,11 +1394,9 @@ __global__ void __launch_bounds__(256) k_movg_enter(WorldView W) {
 // sequential float adds of the same value -- order-independent, hence exact.
 struct RuleBatch { RuleArgs r[4]; };   // rules that pay different groups and no objects: one launch, blockIdx.y = rule
 
-__global__ void __launch_bounds__(256) k_rule(WorldView W, RuleBatch B) {
-    if (step_open(W)) return;
-    const RuleArgs &A = B.r[blockIdx.y];
-    const GroupDev G = W.grp[A.ga];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// (bodies with a wave ballot at the end are called by every lane, i >= n included)
+__device__ __forceinline__ void rule_body(const WorldView &W, const RuleArgs &A, int i) {
+    const GroupDev &G = W.grp[A.ga];
     bool trig = false;
     if (i < G.n) {
         int o = G.op_obj[i];
@@ -1330,11 +1412,13 @@ __global__ void __launch_bounds__(256) k_rule(WorldView W, RuleBatch B) {
     }
     if (__ballot(trig) && lane_id() == 0) W.counters[CTR_TRIGGER + A.rule_no] = 1;
 }
-
-__global__ void __launch_bounds__(256) k_rule_obj(WorldView W, RuleArgs A) {
+__global__ void __launch_bounds__(256) k_rule(WorldView W, RuleBatch B) {
     if (step_open(W)) return;
-    const GroupDev G = W.grp[A.gb];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    rule_body(W, B.r[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__device__ __forceinline__ void rule_obj_body(const WorldView &W, const RuleArgs &A, int i) {
+    const GroupDev &G = W.grp[A.gb];
     if (i >= G.n) return;
     int h = G.hits[i];
     if (!h) return;
@@ -1343,15 +1427,17 @@ __global__ void __launch_bounds__(256) k_rule_obj(WorldView W, RuleArgs A) {
     G.next_reward[i] = nr;
     G.hits[i] = 0;
 }
+__global__ void __launch_bounds__(256) k_rule_obj(WorldView W, RuleArgs A) {
+    if (step_open(W)) return;
+    rule_obj_body(W, A, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // General single-iterator rule (launch.h RuleProg): agent i of group ga is bound to x; if the expression has a second
 // symbol y, it is bound to i's op_obj, and i is skipped when it has none or one of another group
 // (RewardEngine.cc:246-262).  The expression is evaluated on that binding; receivers: x adds in place, y is counted
 // and replayed by k_rule_obj.
-__global__ void __launch_bounds__(256) k_rule_prog(WorldView W, const GroupDev *gtab, RuleProg P) {
-    if (step_open(W)) return;
-    const GroupDev G = W.grp[P.ga];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void rule_prog_body(const WorldView &W, const GroupDev *gtab, const RuleProg &P, int i) {
+    const GroupDev &G = W.grp[P.ga];
     bool trig = false;
     if (i < G.n) {
         int ent[2] = {ref_pack(P.ga, i), -1};
@@ -1399,6 +1485,10 @@ __global__ void __launch_bounds__(256) k_rule_prog(WorldView W, const GroupDev *
     }
     if (__ballot(trig) && lane_id() == 0) W.counters[CTR_TRIGGER + P.rule_no] = 1;
 }
+__global__ void __launch_bounds__(256) k_rule_prog(WorldView W, const GroupDev *gtab, RuleProg P) {
+    if (step_open(W)) return;
+    rule_prog_body(W, gtab, P, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // Event(x, op, c) & Event(y, op_y, c): the reference's search (RewardEngine.cc:216-306) binds x over its group, then y
 // over its group skipping the agent bound to x, re-binds c to y's target, and pays the receivers once per ordered
@@ -1414,20 +1504,18 @@ __device__ __forceinline__ int pair_roles(const WorldView &W, const RuleArgs &A,
     return ((g == A.ga && op == A.op) ? 1 : 0) | ((g == A.gy && op == A.op_y) ? 2 : 0);
 }
 
-__global__ void __launch_bounds__(256) k_pair_link(WorldView W, RuleArgs A) {
-    if (step_open(W)) return;
-    const int g = blockIdx.y ? A.gy : A.ga;
-    const GroupDev G = W.grp[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pair_link_body(const WorldView &W, const RuleArgs &A, int g, int i) {
+    const GroupDev &G = W.grp[g];
     if (i >= G.n || !pair_roles(W, A, g, i)) return;
     G.mv[i] = (unsigned)atomicExch(&W.grp[A.gb].hits[ref_index(G.op_obj[i])], ref_pack(g, i) + 1);
 }
-
-__global__ void __launch_bounds__(256) k_pair_pay(WorldView W, RuleArgs A) {
+__global__ void __launch_bounds__(256) k_pair_link(WorldView W, RuleArgs A) {
     if (step_open(W)) return;
-    const int g = blockIdx.y ? A.gy : A.ga;
-    const GroupDev G = W.grp[g];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    pair_link_body(W, A, blockIdx.y ? A.gy : A.ga, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__device__ __forceinline__ void pair_pay_body(const WorldView &W, const RuleArgs &A, int g, int i) {
+    const GroupDev &G = W.grp[g];
     bool trig = false;
     if (i < G.n) {
         const int mine = pair_roles(W, A, g, i);
@@ -1453,12 +1541,14 @@ __global__ void __launch_bounds__(256) k_pair_pay(WorldView W, RuleArgs A) {
     }
     if (__ballot(trig) && lane_id() == 0) W.counters[CTR_TRIGGER + A.rule_no] = 1;
 }
+__global__ void __launch_bounds__(256) k_pair_pay(WorldView W, RuleArgs A) {
+    if (step_open(W)) return;
+    pair_pay_body(W, A, blockIdx.y ? A.gy : A.ga, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // the object's share (one run of v_obj per ordered pair) and the reset of the list heads
-__global__ void __launch_bounds__(256) k_pair_obj(WorldView W, RuleArgs A) {
-    if (step_open(W)) return;
-    const GroupDev G = W.grp[A.gb];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pair_obj_body(const WorldView &W, const RuleArgs &A, int i) {
+    const GroupDev &G = W.grp[A.gb];
     if (i >= G.n) return;
     int r = G.hits[i];
     if (!r) return;
@@ -1476,6 +1566,10 @@ __global__ void __launch_bounds__(256) k_pair_obj(WorldView W, RuleArgs A) {
     float nr = G.next_reward[i];
     for (; pairs > 0; pairs--) for (int k = 0; k < A.n_obj; k++) nr += A.v_obj[k];
     G.next_reward[i] = nr;
+}
+__global__ void __launch_bounds__(256) k_pair_obj(WorldView W, RuleArgs A) {
+    if (step_open(W)) return;
+    pair_obj_body(W, A, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // end of step: pending actions are consumed
@@ -1583,6 +1677,352 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int 
     if (threadIdx.x == 0) W.counters[CTR_TAKEN + g] = 0;
 }
 
+// ================================================================================================ one-launch step
+// Small worlds are bound by the CHAIN of dependent launches, not by bandwidth: a 4000-agent step was 29 launches of
+// 2-5 us each.  k_step_solo runs the whole of GridWorld::step (GridWorld.cc:456-631) as ONE workgroup of 1024 threads on
+// one CU: the same phase bodies as the multi-launch driver, separated by workgroup barriers instead of kernel
+// boundaries, with the fixed-point loops of the attack and move phases iterated to convergence inside the kernel (no
+// optimistic rounds, no continuation on the host).  Per-cell scratch is never swept: the hit words / `wanted` counters
+// (`S.hit`) and the claim words are zero / CLAIM_NONE between phases because whoever set a word resets it (O(agents),
+// not O(cells)); with `live_paint` the painted map follows the step (vacated cells at once, live bodies at the end), so
+// the next observation needs no k_paint.  The result goes straight to a pinned host record the host spins on.
+constexpr int SOLO_STEP_THREADS = 1024;
+
+#define SOLO_EACH(g_, i_) for (int g_ = 0; g_ < NG; g_++) for (int i_ = tid, n_##i_ = W.grp[g_].n; i_ < n_##i_; i_ += SOLO_STEP_THREADS)
+// (uniform trip count: bodies that end in a wave ballot take every lane, i >= n included)
+#define SOLO_EACH_UNIFORM(g_, i_) \
+    for (int g_ = 0; g_ < NG; g_++) for (int i0_ = 0, n_##i_ = W.grp[g_].n, i_ = tid; i0_ < n_##i_; i0_ += SOLO_STEP_THREADS, i_ += SOLO_STEP_THREADS)
+
+__global__ void __launch_bounds__(SOLO_STEP_THREADS) k_step_solo(WorldView W_kernarg, SoloStep S) {
+    extern __shared__ unsigned s_dyn[];               // hit lists of the attack evaluation: [kmax][nt_eval] ranks, then refs
+    __shared__ WorldView s_W;
+    // "something changed in round r" lives in s_flags[r % 3]: while round r runs, thread 0 re-arms the flag of round r + 1,
+    // which was last read after the closing barrier of round r - 2 -- and everybody has passed the barrier of round r - 1 since
+    __shared__ int s_flags[3];
+    __shared__ unsigned long long s_marks[40];
+    int n_marks = 0;
+#define SOLO_MARK() do { if (tid == 0 && n_marks < 40) s_marks[n_marks] = wall_clock64(); n_marks++; } while (0)
+    const int tid = threadIdx.x;
+    // The world description is indexed by a loop variable here (group g): as a by-value kernel argument that would make
+    // the compiler keep a private copy of it in scratch memory, per lane.  It is copied to LDS once instead, word by word
+    // from the kernarg segment (it is the first argument: offset 0), and every phase body reads it there.
+    {
+        typedef const __attribute__((address_space(4))) unsigned *kernarg_words;
+        kernarg_words ka = (kernarg_words)__builtin_amdgcn_kernarg_segment_ptr();
+        for (int k = tid; k < (int)(sizeof(WorldView) / 4); k += SOLO_STEP_THREADS) ((unsigned *)&s_W)[k] = ka[k];
+    }
+    __syncthreads();
+    const WorldView &W = s_W;
+    const int NG = W.G;
+    const GroupDev *gtab = W.grp;
+    const TypeDev *ttab = W.type;
+    SOLO_MARK();
+    // ---- (cycle) set_action of the groups that act, in handle order (GridWorld::set_action: the order of the calls is the
+    // order of the lists)
+    for (int g = 0; g < NG; g++)
+        if (S.actions[g] && W.grp[g].n > 0) { set_action_solo_body(W, g, S.actions[g], S.call_base[g]); __syncthreads(); }
+    const int A = W.counters[CTR_ATTACK];
+    const unsigned x0 = (unsigned)W.counters[CTR_RNG];
+    int rounds_attack = 0, rounds_move = 0, error = 0;
+    __syncthreads();
+    SOLO_MARK();
+
+    if (A > 0) {
+        // ---- shuffle (exact replay of the reference's Fisher-Yates, see k_shuffle_*)
+        for (int i = tid; i < A; i += SOLO_STEP_THREADS) shuffle_draw_body(x0, i, S.sj, S.scount, S.powtab);
+        __syncthreads();
+        if (tid == 0) W.counters[CTR_RNG] = (int)rng_skip(x0, (unsigned)A);
+        SOLO_MARK();   // 1: draw
+        iscan_solo_body(S.scount, A, S.soff);
+        SOLO_MARK();   // 2: scan
+        for (int k = tid; k < A; k += SOLO_STEP_THREADS) shuffle_fill_body(k, S.sj, S.soff, S.scur, S.slist);
+        __syncthreads();
+        SOLO_MARK();   // 3: fill
+        for (int i = tid; i < A; i += SOLO_STEP_THREADS) shuffle_chase_body(i, S.sj, S.soff, S.scount, S.slist, S.rank);
+        __syncthreads();
+        SOLO_MARK();   // 4: chase
+        // ---- ranks, hit bits; the shuffle's bucket counters go back to zero
+        for (int k = tid; k < A; k += SOLO_STEP_THREADS) { S.scount[k] = 0; S.scur[k] = 0; }
+        SOLO_EACH(g, i) attack_rank_body(W, g, i, S.rank, S.hit);
+        __syncthreads();
+        SOLO_MARK();   // 5: rank
+        // ---- death ranks: in-place fixed point, one round per barrier pair
+        unsigned *s_rank = s_dyn;
+        int *s_ref = (int *)(s_dyn + S.kmax * S.nt_eval);
+        if (tid < 3) s_flags[tid] = 0;
+        __syncthreads();
+        while (true) {
+            rounds_attack++;
+            int *flag = &s_flags[rounds_attack % 3];
+            if (tid == 0) s_flags[(rounds_attack + 1) % 3] = 0;
+            if (tid < S.nt_eval)
+                for (int g = 0; g < NG; g++)
+                    for (int i = tid, n = W.grp[g].n; i < n; i += S.nt_eval)
+                        attack_eval_body(W, gtab, ttab, g, i, rounds_attack, S.hit, s_rank, s_ref, S.nt_eval, tid, flag);
+            __syncthreads();
+            const int changed = *flag;
+            if (!changed) break;
+            if (rounds_attack > S.max_rounds) { error = 1; break; }
+        }
+        SOLO_MARK();   // 6: eval rounds
+        SOLO_EACH(g, i) attack_apply_body(W, gtab, ttab, g, i, S.hit);
+        __syncthreads();
+        SOLO_MARK();   // 7: apply
+        // ---- the hit words back to zero: every attacker resets the word it may have set
+        SOLO_EACH(g, i) {
+            const int pend = W.grp[g].pend[i];
+            if ((pend & ~PEND_ARG) == PEND_ATTACK) {
+                const int2 d = W.delta[W.type[g].attack_off + (pend & PEND_ARG)];
+                const int tx = W.grp[g].x[i] + d.x, ty = W.grp[g].y[i] + d.y;
+                if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) S.hit[ty * W.w + tx] = 0u;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) W.counters[CTR_LAST_A] = A;
+    SOLO_MARK();       // 8: hit words reset
+
+    // ---- starve / recover, then the moves
+    if (!W.any_multicell) {
+        SOLO_EACH_UNIFORM(g, i) move_prep_body(W, g, i, 0);
+        __syncthreads();
+        SOLO_MARK();   // 9: starve + move candidates
+        SOLO_EACH(g, i) move_claim_body(W, gtab, g, i);
+        __syncthreads();
+        SOLO_MARK();   // 10: claim
+        SOLO_EACH(g, i) move_init_body(W, g, i);
+        if (tid < 3) s_flags[tid] = 0;
+        __syncthreads();
+        SOLO_MARK();   // 11: init
+        while (true) {
+            rounds_move++;
+            int *flag = &s_flags[rounds_move % 3];
+            if (tid == 0) s_flags[(rounds_move + 1) % 3] = 0;
+            SOLO_EACH(g, i) move_jump_body(W, gtab, g, i, flag);
+            __syncthreads();
+            const int open = *flag;
+            if (!open) break;
+            if (rounds_move > S.max_rounds) { error = 2; break; }
+        }
+        SOLO_MARK();   // 12: jump rounds
+        SOLO_EACH(g, i) move_commit_body(W, gtab, g, i);
+        __syncthreads();
+        SOLO_MARK();   // 13: commit
+    } else {
+        SOLO_EACH_UNIFORM(g, i) movg_prep_body(W, g, i, S.hit, 0);
+        if (tid < 3) s_flags[tid] = 0;
+        __syncthreads();
+        while (true) {
+            rounds_move++;
+            int *flag = &s_flags[rounds_move % 3];
+            if (tid == 0) s_flags[(rounds_move + 1) % 3] = 0;
+            SOLO_EACH(g, i) movg_sweep_body(W, gtab, g, i, S.hit, flag);
+            __syncthreads();
+            const int open = *flag;
+            if (!open) break;
+            if (rounds_move > S.max_rounds) { error = 2; break; }
+        }
+        SOLO_EACH(g, i) movg_collide_body(W, gtab, g, i, S.hit);
+        __syncthreads();
+        SOLO_EACH(g, i) movg_vacate_body(W, g, i);
+        __syncthreads();
+        SOLO_EACH(g, i) movg_enter_body(W, g, i);
+        __syncthreads();
+    }
+
+    // ---- reward rules, in order (GridWorld::calc_reward)
+    for (int r = 0; r < S.n_rules; r++) {
+        const RuleArgs &R = S.rules[r];
+        if (R.prog >= 0) {
+            const RuleProg &P = S.progs[R.prog];
+            for (int i0 = 0, n = W.grp[P.ga].n; i0 < n; i0 += SOLO_STEP_THREADS) rule_prog_body(W, gtab, P, i0 + tid);
+            __syncthreads();
+            if (P.n_obj) { for (int i = tid, n = W.grp[P.gb].n; i < n; i += SOLO_STEP_THREADS) rule_obj_body(W, R, i); __syncthreads(); }
+        } else if (R.pair) {
+            const int parts = R.ga == R.gy ? 1 : 2;
+            if (W.grp[R.ga].n > 0 && W.grp[R.gy].n > 0 && W.grp[R.gb].n > 0) {
+                for (int q = 0; q < parts; q++) { const int g = q ? R.gy : R.ga; for (int i = tid, n = W.grp[g].n; i < n; i += SOLO_STEP_THREADS) pair_link_body(W, R, g, i); }
+                __syncthreads();
+                for (int q = 0; q < parts; q++) { const int g = q ? R.gy : R.ga; for (int i0 = 0, n = W.grp[g].n; i0 < n; i0 += SOLO_STEP_THREADS) pair_pay_body(W, R, g, i0 + tid); }
+                __syncthreads();
+                for (int i = tid, n = W.grp[R.gb].n; i < n; i += SOLO_STEP_THREADS) pair_obj_body(W, R, i);
+                __syncthreads();
+            }
+        } else {
+            for (int i0 = 0, n = W.grp[R.ga].n; i0 < n; i0 += SOLO_STEP_THREADS) rule_body(W, R, i0 + tid);
+            __syncthreads();
+            if (R.n_obj) { for (int i = tid, n = W.grp[R.gb].n; i < n; i += SOLO_STEP_THREADS) rule_obj_body(W, R, i); __syncthreads(); }
+        }
+    }
+
+    SOLO_MARK();       // rules (generic moves: + the move phase)
+    // ---- end of step: pending actions are consumed; the claim words / wanted counters this step touched go back to
+    // their rest state; every live agent paints its body (the vacated cells were emptied when they were left)
+    SOLO_EACH(g, i) {
+        const GroupDev &G = W.grp[g];
+        const TypeDev &T = W.type[g];
+        G.pend[i] = PEND_NONE;
+        const int t = G.drank_a[i];            // the move candidate's target cell (both move paths), -1 otherwise
+        if (t >= 0) {
+            if (!W.any_multicell) W.claim[t] = CLAIM_NONE;
+            else {
+                const int ny = t / W.w, nx = t - ny * W.w;
+                for (int by = 0; by < T.bl; by++)
+                    for (int bx = 0; bx < T.bw; bx++) S.hit[(ny + by) * W.w + nx + bx] = 0u;
+            }
+        }
+        if (W.live_paint) repaint_body(W, G, T, g, i);
+    }
+    __syncthreads();
+    SOLO_MARK();       // finish + repaint
+
+    // ---- (cycle) get_reward
+    for (int g = 0; g < NG; g++)
+        if (S.rewards[g]) {
+            const GroupDev &G = W.grp[g];
+            for (int i = tid; i < G.n; i += SOLO_STEP_THREADS) S.rewards[g][i] = G.next_reward[i] + S.group_reward[g];
+        }
+    // ---- (cycle) clear_dead: as k_clear_solo_all, the mode of a group decided here from its death counters
+    int dead_ct = 0, taken_ct = 0;                    // thread g < NG: this step's report for group g
+    if (tid < NG) {
+        for (int k = 0; k < DEAD_SLOTS; k++) dead_ct += __hip_atomic_load(&W.counters[dead_slot(tid, k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        taken_ct = __hip_atomic_load(&W.counters[CTR_TAKEN + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (S.do_clear) {
+        __shared__ int s_gone[MAXG], s_alive[MAXG];
+        if (tid < NG) s_gone[tid] = dead_ct + taken_ct;
+        __syncthreads();                              // (also: the rewards above have read next_reward)
+        for (int g = 0; g < NG; g++) {
+            const GroupDev &G = W.grp[g];
+            const float step_reward = W.type[g].step_reward;
+            if (G.n == 0) { if (tid == 0) s_alive[g] = 0; continue; }
+            if (s_gone[g] == 0) {
+                for (int i = tid; i < G.n; i += SOLO_STEP_THREADS) { G.last_reward[i] = G.next_reward[i]; G.next_reward[i] = step_reward; G.last_op[i] = OP_NULL; G.op_obj[i] = -1; }
+                if (tid == 0) s_alive[g] = G.n;
+                continue;
+            }
+            const AltArrays D = S.dst[g];
+            const int bw = W.type[g].bw, bl = W.type[g].bl;
+            const int alive = solo_rank([&](int i) { return !G.dead[i]; },
+                                        [&](int i, int r) {
+                                            int x = G.x[i], y = G.y[i];
+                                            D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
+                                            D.absorbed[r] = G.absorbed[i];
+                                            D.last_reward[r] = G.next_reward[i];
+                                            D.next_reward[r] = step_reward;
+                                            body_fill(W, x, y, bw, bl, ref_pack(g, r));
+                                        },
+                                        G.n, 0);
+            for (int r = tid; r < alive; r += SOLO_STEP_THREADS) { G.dead[r] = 0; G.last_op[r] = OP_NULL; G.op_obj[r] = -1; G.pend[r] = PEND_NONE; }
+            if (tid < DEAD_SLOTS) W.counters[dead_slot(g, tid)] = 0;
+            if (tid == 0) { W.counters[CTR_TAKEN + g] = 0; s_alive[g] = alive; }
+        }
+        __syncthreads();
+        if (tid < NG && s_gone[tid] > 0 && s_W.grp[tid].n > 0) {   // the double-buffered arrays change places
+            GroupDev &N = s_W.grp[tid];
+            const AltArrays D = S.dst[tid];
+            N.x = D.x; N.y = D.y; N.id = D.id; N.last_action = D.last_action; N.hp = D.hp; N.next_reward = D.next_reward;
+            N.last_reward = D.last_reward; N.absorbed = D.absorbed;
+            N.n = s_alive[tid];
+        }
+        __syncthreads();
+        if (tid < MAXG) { S.gtab_out[tid] = s_W.grp[tid]; S.ttab_out[tid] = s_W.type[tid]; }
+        // ---- (cycle) the minimap of the next observations: LDS histogram of every group, then count / total exactly as the
+        // reference divides (k_minimap, k_minimap_norm)
+        if (S.mini_vh > 0) {
+            int *s_hist = (int *)s_dyn;               // [NG][VHW] counts, then [NG] agents left out (the hit lists are done with)
+            const int VHW = S.mini_vh * S.mini_vw;
+            for (int k = tid; k < NG * VHW + NG; k += SOLO_STEP_THREADS) s_hist[k] = 0;
+            __syncthreads();
+            for (int g = 0; g < NG; g++) {
+                const GroupDev &G = W.grp[g];
+                for (int i = tid; i < G.n; i += SOLO_STEP_THREADS) {
+                    if (S.mini_skip && G.absorbed[i]) { atomicAdd(&s_hist[NG * VHW + g], 1); continue; }
+                    atomicAdd(&s_hist[g * VHW + (G.y[i] / S.mini_scale_h) * S.mini_vw + G.x[i] / S.mini_scale_w], 1);
+                }
+            }
+            __syncthreads();
+            for (int k = tid; k < NG * VHW; k += SOLO_STEP_THREADS) {
+                const int g = k / VHW;
+                const int tot = W.grp[g].n - (S.mini_skip ? s_hist[NG * VHW + g] : 0);
+                S.mini_out[k] = tot == 0 ? __int_as_float(0xFFC00000) : __fdiv_rn((float)min(s_hist[k], 1 << 24), (float)(unsigned)tot);
+            }
+        }
+    }
+    SOLO_MARK();       // (cycle) rewards, clear_dead, minimap
+
+    // ---- the step's report, straight into pinned host memory; per-step counters back to zero
+    if (tid < 64) {
+        const bool trig = tid < CTR_TRIGGER_END - CTR_TRIGGER && __hip_atomic_load(&W.counters[CTR_TRIGGER + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        const unsigned long long mask = __ballot(trig);
+        if (tid < CTR_TRIGGER_END - CTR_TRIGGER) W.counters[CTR_TRIGGER + tid] = 0;
+        if (tid < NG) { S.rec->dead[tid] = dead_ct; S.rec->taken[tid] = taken_ct; }
+        if (tid == 0) {
+            S.rec->triggers = mask;
+            S.rec->rng = (unsigned)W.counters[CTR_RNG];
+            S.rec->last_a = A;
+            S.rec->unsupported = __hip_atomic_load(&W.counters[CTR_UNSUPPORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            S.rec->pack_overflow = __hip_atomic_load(&W.counters[CTR_PACK_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            S.rec->bad_action = __hip_atomic_load(&W.counters[CTR_BAD_ACTION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            S.rec->error = error;
+            S.rec->rounds_attack = rounds_attack; S.rec->rounds_move = rounds_move;
+            S.rec->n_marks = n_marks < 40 ? n_marks : 40;
+            for (int k = 0; k < S.rec->n_marks; k++) S.rec->marks[k] = s_marks[k];
+            W.counters[CTR_ATTACK] = 0;
+        }
+        __threadfence_system();                       // (wave 0 only: lanes 1..NG-1 wrote their part above)
+        if (tid == 0) __hip_atomic_store((int *)&S.rec->seq, S.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+#undef SOLO_EACH
+#undef SOLO_EACH_UNIFORM
+#undef SOLO_MARK
+
+// clear_dead for every group of a small world in ONE launch of one workgroup (GridWorld::clear_dead, GridWorld.cc:633-665):
+// stable compaction of the survivors into the alternate buffers + Agent::init_reward + re-indexing of the map (groups with
+// deaths), Agent::init_reward alone (groups without); then the death counters and the device copy of the group table
+// (the double-buffered arrays have changed places: ClearArgs::dst become the current ones).
+__global__ void __launch_bounds__(SOLO_THREADS) k_clear_solo_all(WorldView W, ClearArgs A, GroupDev *gtab, TypeDev *ttab) {
+    __shared__ int s_alive[MAXG];
+    for (int g = 0; g < W.G; g++) {
+        const GroupDev &G = W.grp[g];
+        const float step_reward = W.type[g].step_reward;
+        if (A.mode[g] == 1) {
+            for (int i = threadIdx.x; i < G.n; i += SOLO_THREADS) { G.last_reward[i] = G.next_reward[i]; G.next_reward[i] = step_reward; G.last_op[i] = OP_NULL; G.op_obj[i] = -1; }
+            if (threadIdx.x == 0) s_alive[g] = G.n;
+        } else if (A.mode[g] == 2) {
+            const ClearArgs::Alt D = A.dst[g];
+            const int bw = W.type[g].bw, bl = W.type[g].bl;
+            const int alive = solo_rank([&](int i) { return !G.dead[i]; },
+                                        [&](int i, int r) {
+                                            int x = G.x[i], y = G.y[i];
+                                            D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
+                                            D.absorbed[r] = G.absorbed[i];
+                                            D.last_reward[r] = G.next_reward[i];
+                                            D.next_reward[r] = step_reward;
+                                            body_fill(W, x, y, bw, bl, ref_pack(g, r));
+                                        },
+                                        G.n, 0);
+            // every read of the in-place arrays is done (solo_rank ends with a barrier): reset them for the survivors
+            for (int r = threadIdx.x; r < alive; r += SOLO_THREADS) { G.dead[r] = 0; G.last_op[r] = OP_NULL; G.op_obj[r] = -1; G.pend[r] = PEND_NONE; }
+            if (threadIdx.x < DEAD_SLOTS) W.counters[dead_slot(g, threadIdx.x)] = 0;
+            if (threadIdx.x == 0) { W.counters[CTR_TAKEN + g] = 0; s_alive[g] = alive; }
+        } else if (threadIdx.x == 0) s_alive[g] = G.n;
+    }
+    __syncthreads();
+    if (threadIdx.x < MAXG) {
+        const int g = threadIdx.x;
+        GroupDev N = W.grp[g];
+        if (g < W.G && A.mode[g] == 2) {
+            const ClearArgs::Alt D = A.dst[g];
+            N.x = D.x; N.y = D.y; N.id = D.id; N.last_action = D.last_action; N.hp = D.hp; N.next_reward = D.next_reward;
+            N.last_reward = D.last_reward; N.absorbed = D.absorbed;
+            N.n = s_alive[g];
+        }
+        gtab[g] = N; ttab[g] = W.type[g];
+    }
+}
+
 // ================================================================================================ launchers
 static inline dim3 grid_all(const WorldView &W, int threads) {
     int mx = 1;
@@ -1598,7 +2038,7 @@ void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const
     int ncell = W.w * W.h;
     int blocks = (ncell + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    if (W.G <= 3 && !W.any_absorb) hipLaunchKernelGGL(k_paint<true>, dim3(blocks), dim3(256), 0, s, W, gtab, ttab);
+    if (W.vc_packed) hipLaunchKernelGGL(k_paint<true>, dim3(blocks), dim3(256), 0, s, W, gtab, ttab);
     else hipLaunchKernelGGL(k_paint<false>, dim3(blocks), dim3(256), 0, s, W, gtab, ttab);
 }
 
@@ -1620,7 +2060,7 @@ void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const
     if (R.n <= 0) return;
     size_t lds = (size_t)RENDER_WAVES * P.strip_floats * sizeof(float);
     dim3 grid(P.spans + P.feat_blocks), block(64 * RENDER_WAVES);
-    const bool packed = W.G <= 3 && !W.any_absorb;   // must match launch_paint
+    const bool packed = W.vc_packed != 0;   // must match launch_paint
 #define RENDER_LAUNCH(V, N, UU, PK) hipLaunchKernelGGL((k_render<V, N, UU, PK>), grid, block, lds, s, W, R, P)
 #define RENDER_PK(V, N, UU) do { if (packed) RENDER_LAUNCH(V, N, UU, true); else RENDER_LAUNCH(V, N, UU, false); } while (0)
     if (!vec4) RENDER_PK(false, false, 1);
@@ -1629,6 +2069,16 @@ void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const
     else { if (nt) RENDER_PK(true, true, 1); else RENDER_PK(true, false, 1); }
 #undef RENDER_PK
 #undef RENDER_LAUNCH
+}
+
+void launch_render_multi(hipStream_t s, const WorldView &W, const RenderMulti &M) {
+    size_t lds = 0;
+    int mx = 0;
+    for (int k = 0; k < M.n; k++) { lds = std::max(lds, (size_t)RENDER_WAVES * M.P[k].strip_floats * sizeof(float)); mx = std::max(mx, M.blocks[k]); }
+    if (M.n <= 0 || mx <= 0) return;
+    dim3 grid(mx, M.n), block(64 * RENDER_WAVES);
+    if (W.vc_packed) hipLaunchKernelGGL((k_render_multi<true>), grid, block, lds, s, W, M);
+    else hipLaunchKernelGGL((k_render_multi<false>), grid, block, lds, s, W, M);
 }
 
 void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4) {
@@ -1679,6 +2129,13 @@ static int att_threads(int kmax) {
     static const int forced = getenv("MAGENT_ATT_THREADS") ? atoi(getenv("MAGENT_ATT_THREADS")) : 0;
     if (forced == 64 || forced == 128 || forced == 256) return forced;
     return kmax <= 16 ? 256 : kmax <= 32 ? 128 : 64;     // <= 32 KB of hit lists per workgroup
+}
+// hit lists above the default dynamic-LDS limit have to be asked for (checked once, at reset)
+bool attack_lds_ok(int kmax) {
+    const size_t lds = (size_t)kmax * att_threads(kmax) * 8;
+    if (lds <= (48u << 10)) return true;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_attack_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void *>(k_food_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
 }
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag) {
     const int ATT_THREADS = att_threads(kmax);
@@ -1803,6 +2260,22 @@ void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A,
     dim3 grid((mx + SCAN_TILE - 1) / SCAN_TILE, W.G);
     if (any) hipLaunchKernelGGL(k_clear_count, grid, dim3(SCAN_THREADS), 0, s, W, A, sums);
     hipLaunchKernelGGL(k_clear_compact, grid, dim3(SCAN_THREADS), 0, s, W, A, sums);
+}
+void launch_step_solo(hipStream_t s, const WorldView &W, const SoloStep &S) {
+    size_t lds = (size_t)S.kmax * S.nt_eval * 8;
+    if (S.mini_vh > 0) lds = std::max(lds, sizeof(int) * ((size_t)W.G * S.mini_vh * S.mini_vw + W.G));
+    hipLaunchKernelGGL(k_step_solo, dim3(1), dim3(SOLO_STEP_THREADS), lds, s, W, S);
+}
+void launch_clear_solo_all(hipStream_t s, const WorldView &W, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab) {
+    hipLaunchKernelGGL(k_clear_solo_all, dim3(1), dim3(SOLO_THREADS), 0, s, W, A, gtab, ttab);
+}
+int solo_step_static_lds() {   // static LDS of k_step_solo (tables, scan scratch): taken off the budget of the hit lists
+    hipFuncAttributes a{};
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_step_solo)) != hipSuccess) return 8192;
+    return (int)a.sharedSizeBytes;
+}
+bool solo_step_allow_lds(size_t bytes) {   // dynamic LDS above the default limit has to be asked for
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_solo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 void launch_clear_finish(hipStream_t s, const WorldView &Wn, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab) {
     hipLaunchKernelGGL(k_clear_finish, grid_all(Wn, 256), dim3(256), 0, s, Wn, A, gtab, ttab);

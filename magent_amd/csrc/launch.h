@@ -31,6 +31,15 @@ struct RenderPlan {
     FastDiv div_vhw, div_vw, div_f, div_scale_w, div_scale_h;
 };
 
+// the observations of several groups of a small world in one launch (k_render_multi)
+constexpr int RENDER_MULTI_MAX = 4;
+struct RenderMulti {
+    int n;
+    int blocks[RENDER_MULTI_MAX];          // workgroups of slot k: spans + feature blocks
+    RenderArgs R[RENDER_MULTI_MAX];
+    RenderPlan P[RENDER_MULTI_MAX];
+};
+
 // one reward rule, symbols 'any':  Event(a, op, b)                        -- pair == 0: ga/op = subject, gb = object
 //                                   Event(x, op, c) & Event(y, op_y, c)     -- pair == 1: ga/op = x (the symbol the reference's
 //                                       search binds first = the lower-numbered one), gy/op_y = y, gb = c
@@ -53,10 +62,38 @@ struct RuleProg {
     int a[24][5];                 // kill / collide / attack: {subject slot, object slot}; at: {slot, x, y}; in: {slot, x1, y1, x2, y2}; die: {slot}
 };
 
+// alternate copies of the arrays that survive clear_dead (compaction is a stable scatter into them, then they change places)
+struct AltArrays { int *x, *y, *id, *last_action; float *hp, *next_reward, *last_reward; unsigned char *absorbed; };
+
+// the one-launch step of small worlds (k_step_solo)
+struct SoloStep {
+    int *sj, *scount, *soff, *scur, *slist, *rank;   // shuffle scratch (count / cursor zero between steps)
+    const unsigned *powtab;
+    unsigned *hit;                 // per cell: attack hit bits, then the generic move's `wanted` counters; zero between phases
+    const RuleArgs *rules;         // device copies of the compiled reward rules
+    const RuleProg *progs;
+    int n_rules;
+    int kmax, nt_eval;             // hit-list depth; threads that evaluate (kmax * nt_eval * 8 bytes of dynamic LDS)
+    int max_rounds;                // bound of the fixed-point loops (reported as an error, never silently cut)
+    StepRecord *rec;               // pinned host memory
+    int seq;
+    // ---- the rest of an environment cycle in the same launch (env_cycle_many); all optional
+    const int *actions[MAXG];      // set_action(g) before the step, groups in ascending order (null: not in this launch)
+    int call_base[MAXG];           // ... its insertion-order base (agents given actions by earlier calls of this step)
+    float *rewards[MAXG];          // get_reward(g) after the step (null: skip)
+    float group_reward[MAXG];
+    int do_clear;                  // clear_dead after that, into `dst`; the device tables are refreshed
+    AltArrays dst[MAXG];
+    GroupDev *gtab_out; TypeDev *ttab_out;
+    int mini_vh, mini_vw, mini_scale_w, mini_scale_h, mini_skip;   // mini_vh > 0: the minimap of the next observations ...
+    float *mini_out;                                               // ... float[G][mini_vh * mini_vw]
+};
+
 void launch_set_tables(hipStream_t s, const WorldView &W, GroupDev *gtab, TypeDev *ttab);
 void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab);
 void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts, float *mini);
 void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt);
+void launch_render_multi(hipStream_t s, const WorldView &W, const RenderMulti &M);
 void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4);
 void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank,
                     unsigned *hitbits, size_t ncell, const unsigned *powtab);
@@ -85,11 +122,17 @@ void launch_get_alive(hipStream_t s, const GroupDev &G, unsigned char *out);
 struct ClearArgs {
     int mode[MAXG];        // 0 nothing (empty group), 1 Agent::init_reward only, 2 compaction of the survivors
     int sums_off[MAXG];    // where the group's block totals start in `sums`
-    struct Alt { int *x, *y, *id, *last_action; float *hp, *next_reward, *last_reward; unsigned char *absorbed; } dst[MAXG];
+    typedef AltArrays Alt;
+    Alt dst[MAXG];
 };
 void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A, int *sums);
 void launch_clear_finish(hipStream_t s, const WorldView &Wnew, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab);
+void launch_clear_solo_all(hipStream_t s, const WorldView &W, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab);
 bool compact_is_solo(int n);
+bool attack_lds_ok(int kmax);
+void launch_step_solo(hipStream_t s, const WorldView &W, const SoloStep &S);
+int solo_step_static_lds();
+bool solo_step_allow_lds(size_t bytes);
 void launch_init_reward(hipStream_t s, const WorldView &W, int g);
 void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D, int new_n, int *sums);
 

@@ -127,18 +127,9 @@ int env_step_many(EnvHandle *games, int n, int *done) {
 int env_cycle_many(EnvHandle *games, int n_env, int n_group, float **view, float **feat, const int **actions,
                    float **rewards, int *done, int n_threads) {
     auto one = [&](int e) {
-        Env *env = E(games[e]);
-        for (int g = 0; g < n_group; g++) {
-            const int k = e * n_group + g;
-            if (view && view[k]) env->observe_device(g, view[k], feat[k]);
-            if (actions && actions[k]) env->set_action_device(g, actions[k]);
-        }
-        env->step(&done[e]);
-        for (int g = 0; g < n_group; g++) {
-            const int k = e * n_group + g;
-            if (rewards && rewards[k]) env->get_reward_device(g, rewards[k]);
-        }
-        env->clear_dead();
+        const int o = e * n_group;
+        E(games[e])->cycle(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
+                           rewards ? rewards + o : nullptr, &done[e]);
     };
     if (n_threads <= 1 || n_env <= 1) { for (int e = 0; e < n_env; e++) one(e); return 0; }
     cycle_pool().run(n_threads < n_env ? n_threads : n_env, n_env, one);

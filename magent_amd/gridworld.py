@@ -179,16 +179,23 @@ class GridWorld(object):
                 buf = self._dev_cache[which][g] = torch.empty((n,) + space, dtype=torch.float32,
                                                               device=torch.device("cuda", self._device_id))
             out.append(buf[:n])
+        # The cached buffers are written on the engine's own stream.  Work still queued on torch's current stream may be
+        # reading their previous contents (an episode buffer cloning rows, a policy forward): the render has to wait for
+        # it, and torch's stream for the render -- stream-to-stream, the host does not block.
+        self.order_after_torch()
         self.get_observation_device(g, out[0], out[1])
-        self.sync()
+        self.order_torch_after()
         return out[0], out[1]
 
     def set_action(self, handle, actions):
         if not isinstance(actions, np.ndarray):   # a torch int32 tensor on the engine's device
             import torch
             assert isinstance(actions, torch.Tensor) and actions.dtype == torch.int32 and actions.is_cuda
-            torch.cuda.current_stream(actions.device).synchronize()   # the producer of `actions` has finished
-            return self.set_action_device(handle, actions.contiguous())
+            actions = actions.contiguous()            # (a copy, if any, is queued on torch's stream: before the hand-over)
+            self.order_after_torch()                  # the producer of `actions` runs on torch's stream
+            self.set_action_device(handle, actions)
+            actions.record_stream(self.stream)        # the caching allocator must not recycle it under the engine's kernel
+            return
         assert isinstance(actions, np.ndarray) and actions.dtype == np.int32
         actions = np.ascontiguousarray(actions)
         self._lib.env_set_action(self.game, _gid(handle), _i32(actions))
@@ -302,7 +309,13 @@ class GridWorld(object):
             raise RuntimeError("this library does not export the device-resident API")
 
     def get_observation_device(self, handle, view=None, feature=None):
-        """Render observations straight into torch CUDA(HIP) tensors; asynchronous on the env stream."""
+        """Render observations straight into torch CUDA(HIP) tensors.
+
+        Asynchronous contract of every *_device call: the work is queued on the engine's own (non-blocking) HIP stream
+        and the call returns at once -- the outputs are valid after env.sync(), or for torch's stream after
+        env.order_torch_after(); inputs / output buffers that torch's stream still produces or reads must be handed
+        over with env.order_after_torch() first.  Buffers allocated inside these calls (view / feature / out = None)
+        come from torch's caching allocator: keep them alive until the engine's work on them is done."""
         import torch
         self._require_device_api()
         g = _gid(handle)
@@ -341,6 +354,28 @@ class GridWorld(object):
     def sync(self):
         self._require_device_api()
         self._lib.env_sync(self.game)
+
+    @property
+    def stream(self):
+        """the engine's HIP stream as a torch.cuda.ExternalStream (every *_device call is asynchronous on it)"""
+        st = getattr(self, "_ext_stream", None)
+        if st is None:
+            import torch
+            self._require_device_api()
+            ptr = ctypes.c_void_p()
+            self._lib.env_get_stream(self.game, ctypes.byref(ptr))
+            st = self._ext_stream = torch.cuda.ExternalStream(ptr.value, device=torch.device("cuda", self.device_id))
+        return st
+
+    def order_after_torch(self):
+        """engine work queued from now on waits for what is queued on torch's current stream (no host blocking)"""
+        import torch
+        self.stream.wait_stream(torch.cuda.current_stream(self.stream.device))
+
+    def order_torch_after(self):
+        """torch's current stream waits for the engine work queued so far (no host blocking)"""
+        import torch
+        torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
 
     @property
     def device_id(self):

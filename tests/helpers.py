@@ -292,6 +292,64 @@ def run(sc, lib, record=None):
     return out
 
 
+def run_cycle(sc, lib, fused):
+    """Play `sc` one environment CYCLE at a time (observe + set_action per group, step, rewards, clear_dead) and record what a
+    caller of magent_amd.EnvBatch.cycle can see: observations, ids, rewards, done, and the state AFTER clear_dead.
+
+    fused=True : the HIP engine through env_cycle_many (EnvBatch.cycle: two launches per cycle for small worlds), device buffers
+    fused=False: any library, the same calls one after the other through the reference API (the CPU checkers take this leg)"""
+    assert sc.clear_every == 1
+    env, handles = sc.build(lib)
+    rs = np.random.RandomState(sc.action_seed)
+    acting = sc.acting if sc.acting is not None else list(range(len(handles)))
+    if fused:
+        import torch
+        dev = torch.device("cuda", env.device_id)
+        batch = magent_amd.EnvBatch([env], n_threads=1)
+    out = []
+    for step in range(sc.steps):
+        rec = {}
+        sc.apply_events(env, step)
+        nums = [env.get_num(h) for h in handles]
+        acts = [rs.randint(env.get_action_space(h)[0], size=nums[g]).astype(np.int32) if g in acting else None for g, h in enumerate(handles)]
+        observe = [step % sc.obs_every == 0 and nums[g] > 0 for g in range(len(handles))]
+        for g, h in enumerate(handles):
+            rec["id%d" % g] = env.get_agent_id(h)
+        if fused:
+            views = [torch.empty((nums[g],) + env.get_view_space(h), device=dev) if observe[g] else None for g, h in enumerate(handles)]
+            feats = [torch.empty((nums[g],) + env.get_feature_space(h), device=dev) if observe[g] else None for g, h in enumerate(handles)]
+            d_acts = [torch.from_numpy(a).to(dev) if a is not None else None for a in acts]
+            rews = [torch.empty(nums[g], device=dev) for g in range(len(handles))]
+            torch.cuda.synchronize()
+            done = batch.cycle([views], [feats], [d_acts], [rews])[0]
+            env.sync()
+            for g in range(len(handles)):
+                if observe[g]:
+                    rec["view%d" % g], rec["feat%d" % g] = views[g].cpu().numpy(), feats[g].cpu().numpy()
+                rec["reward%d" % g] = rews[g].cpu().numpy()
+        else:
+            for g, h in enumerate(handles):
+                if observe[g]:
+                    v, f = env.get_observation(h)
+                    rec["view%d" % g], rec["feat%d" % g] = v.copy(), f.copy()
+                if acts[g] is not None:
+                    env.set_action(h, acts[g])
+            done = env.step()
+            for g, h in enumerate(handles):
+                rec["reward%d" % g] = env.get_reward(h)
+            env.clear_dead()
+        rec["done"] = np.array([done], dtype=np.int32)
+        for g, h in enumerate(handles):       # the state after clear_dead
+            rec["num%d" % g] = np.array([env.get_num(h)], dtype=np.int32)
+            rec["pos%d" % g] = env.get_pos(h)
+            rec["alive%d" % g] = env.get_alive(h).astype(np.uint8)
+            rec["ids_after%d" % g] = env.get_agent_id(h)
+        out.append(rec)
+        if all(env.get_num(h) == 0 for h in handles) and not any(k > step for k in sc.events):
+            break
+    return out
+
+
 def run_hashed(sc, lib):
     """run(sc, lib) for sizes whose trajectories do not fit in memory: every array of every step is reduced to its
     xxh3-128 (10 GB/s on one core; SHA-256 would cost more than the engines) as soon as the step is over.

@@ -32,6 +32,15 @@ def test_hip_matches_oracle_and_golden(name, oracle):
     assert H.digest(got) == DIGESTS[name]["sha256"]     # the committed vectors from the compiled reference
 
 
+@pytest.mark.parametrize("name", sorted(k for k in SCENARIOS if SCENARIOS[k].engine and SCENARIOS[k].clear_every == 1))
+def test_fused_cycle_matches_oracle(name, oracle):
+    """env_cycle_many / EnvBatch.cycle: a whole environment cycle in two launches for small worlds (k_render_multi, then
+    set_action + step + get_reward + clear_dead + the next minimap inside k_step_solo) -- against the oracle driven call by call"""
+    got = H.run_cycle(SCENARIOS[name], H.HIP_LIB, fused=True)
+    want = H.run_cycle(SCENARIOS[name], oracle, fused=False)
+    H.assert_same(want, got, name + " (cycle)")
+
+
 @pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) did not travel")
 @pytest.mark.parametrize("name", ["battle_brawl", "battle_largemap", "gather"])
 def test_hip_matches_compiled_reference(name):

@@ -69,8 +69,10 @@ def test_full_size_invariants():
             assert np.array_equal(feat[:, 32].cpu().numpy(), fx) and np.array_equal(feat[:, 33].cpu().numpy(), fy)
             cells_all.append(ys * W + xs)
             n_alive_all += n
-            env.set_action_device(h, torch.randint(21, (n,), dtype=torch.int32, device=dev, generator=gen))
-            torch.cuda.synchronize()
+            acts = torch.randint(21, (n,), dtype=torch.int32, device=dev, generator=gen)
+            env.order_after_torch()          # the engine's stream waits for torch's stream to have produced `acts`
+            env.set_action_device(h, acts)
+            torch.cuda.synchronize(); env.sync()
         # no two agents share a cell
         cells = torch.cat(cells_all)
         assert torch.unique(cells).numel() == cells.numel() == n_alive_all
@@ -114,8 +116,10 @@ def test_host_and_device_abi_agree():
             env.sync()
             assert v_dev.cpu().numpy().tobytes() == v_host.tobytes() and f_dev.cpu().numpy().tobytes() == f_host.tobytes()
         acts = rs.randint(33, size=env.get_num(handles[1])).astype(np.int32)
-        env.set_action_device(handles[1], torch.from_numpy(acts).to(dev))
-        torch.cuda.synchronize()
+        d_acts = torch.from_numpy(acts).to(dev)
+        torch.cuda.synchronize()                 # (the copy runs on torch's stream: before the hand-over)
+        env.set_action_device(handles[1], d_acts)
+        env.sync()
         env.step()
         for h in handles:
             r_dev = env.get_reward_device(h)

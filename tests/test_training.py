@@ -185,8 +185,9 @@ def test_training_round_on_gpu():
     env.sync()
     acts = models[0].model.infer_action((view, feat), None, policy="greedy")
     assert isinstance(acts, torch.Tensor) and acts.dtype == torch.int32 and acts.is_cuda
+    env.order_after_torch()              # `acts` is produced on torch's stream
     env.set_action_device(handles[0], acts)
-    torch.cuda.synchronize()
+    env.sync()
 
 
 @pytest.mark.gpu
