@@ -15,6 +15,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -219,7 +220,8 @@ Env::~Env() {
     dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_food); dfree(d_powtab); dfree(d_counters); dfree(d_gtab); dfree(d_ttab);
     dfree(d_delta); dfree(d_mask); dfree(d_mini); dfree(d_minif); dfree(d_sums); dfree(d_rank); dfree(d_shuf); dfree(d_events); dfree(d_actions);
     dfree(d_stage_view); dfree(d_stage_feat); dfree(d_stage_small);
-    dfree(d_hit); dfree(d_rule_args); dfree(d_rule_progs);
+    dfree(d_hit); dfree(d_rule_args); dfree(d_rule_progs); dfree(batch_d);
+    if (batch_h) (void)hipHostFree(batch_h);
     if (h_rec) (void)hipHostFree(h_rec);
     if (pool) {
         delete pool;
@@ -231,7 +233,7 @@ Env::~Env() {
     if (h_rank) (void)hipHostFree(h_rank);
     for (auto &kv : prof) for (auto &p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto ev : prof_pool) (void)hipEventDestroy(ev);
-    (void)hipStreamDestroy(stream);
+    stream_owner.reset();   // (the stream goes when its last user does)
 }
 
 void Env::use_device() { HIP_OK(hipSetDevice(device_id)); }
@@ -245,6 +247,7 @@ void Env::init_device() {
     if (device_id >= count) fatal("device_id %d out of range (%d devices)", device_id, count);
     use_device();
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    stream_owner = std::shared_ptr<void>((void *)stream, [](void *p) { (void)hipStreamDestroy((hipStream_t)p); });
     HIP_OK(hipMalloc(&d_counters, sizeof(int) * CTR_TOTAL));
     HIP_OK(hipMemset(d_counters, 0, sizeof(int) * CTR_TOTAL));
     HIP_OK(hipMalloc(&d_gtab, sizeof(GroupDev) * MAXG));
@@ -1267,7 +1270,11 @@ void Env::step_end(int *done) {
 }
 
 // ------------------------------------------------------------------------------------------------ one cycle, two launches
-void Env::cycle(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, int *done) {
+// Splits in three so that env_cycle_many can put MANY environments into one pair of launches:
+//   cycle_prepare : eligibility, stale paint / minimap brought up to date, the launch descriptions of this environment
+//   (the launches : Env::cycle for one environment, launch_cycle_batch for many)
+//   cycle_finish  : the step record, the host mirror of what clear_dead did on the device
+bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, BatchItem &item) {
     if (!device_ready) fatal("cycle called before reset");
     use_device();
     const int NG = (int)groups.size();
@@ -1287,28 +1294,17 @@ void Env::cycle(int n_group, float *const *view, float *const *feat, const int *
         n_obs++;
     }
     if (n_obs > RENDER_MULTI_MAX) fused = false;
-    if (!fused) {   // the general path: the same calls one after the other
-        for (int g = 0; g < NG; g++) {
-            if (view && view[g]) observe_device(g, view[g], feat[g]);
-            if (actions && actions[g]) set_action_device(g, actions[g]);
-        }
-        step(done);
-        for (int g = 0; g < NG; g++) if (rewards && rewards[g]) get_reward_device(g, rewards[g]);
-        clear_dead();
-        return;
-    }
-    WorldView W = this->view();
+    if (!fused) return false;
+    WorldView &W = item.W;
+    W = this->view();
     // ---- launch 1: the observations of every observed group
-    if (n_obs > 0) {
-        RenderMulti M{};
-        for (int g = 0; g < NG; g++) {
-            if (!(view && view[g]) || groups[g].n == 0) continue;
-            const int k = M.n++;
-            prepare_render(g, W, M.R[k], M.P[k], view[g], feat[g]);
-            M.blocks[k] = M.P[k].spans + M.P[k].feat_blocks;
-        }
-        ProfScope p(*this, "render", true);
-        launch_render_multi(stream, W, M);
+    RenderMulti &M = item.M;
+    M = RenderMulti{};
+    for (int g = 0; g < NG; g++) {
+        if (!(view && view[g]) || groups[g].n == 0) continue;
+        const int k = M.n++;
+        prepare_render(g, W, M.R[k], M.P[k], view[g], feat[g]);
+        M.blocks[k] = M.P[k].spans + M.P[k].feat_blocks;
     }
     // ---- launch 2: set_action, step, get_reward, clear_dead, the next minimap
     shuffle_buffers(total_n);
@@ -1320,7 +1316,8 @@ void Env::cycle(int n_group, float *const *view, float *const *feat, const int *
     step_live_paint = paint_valid;
     W.live_paint = step_live_paint ? 1 : 0;
     const size_t seg = shuf_cap / 5;
-    SoloStep S{};
+    SoloStep &S = item.S;
+    S = SoloStep{};
     S.scount = d_shuf; S.scur = d_shuf + seg; S.sj = d_shuf + 2 * seg; S.soff = d_shuf + 3 * seg; S.slist = d_shuf + 4 * seg;
     S.rank = d_rank; S.powtab = d_powtab; S.hit = d_hit;
     S.rules = d_rule_args; S.progs = d_rule_progs; S.n_rules = (int)rule_args.size();
@@ -1338,7 +1335,7 @@ void Env::cycle(int n_group, float *const *view, float *const *feat, const int *
     }
     S.do_clear = 1;
     S.gtab_out = d_gtab; S.ttab_out = d_ttab;
-    bool next_mini = false;
+    cyc_next_mini = false;
     if (minimap_mode && first_obs >= 0) {   // the next cycle observes the same groups: its minimap is made here
         const HostType &t = *groups[first_obs].type;
         S.mini_vh = t.view.height; S.mini_vw = t.view.width;
@@ -1346,14 +1343,14 @@ void Env::cycle(int n_group, float *const *view, float *const *feat, const int *
         S.mini_skip = t.can_absorb ? 1 : 0;
         grow(d_minif, minif_cap, (size_t)NG * S.mini_vh * S.mini_vw, stream);
         S.mini_out = d_minif;
-        next_mini = true;
+        cyc_next_mini = true; cyc_mini_vh = S.mini_vh; cyc_mini_vw = S.mini_vw; cyc_mini_skip = S.mini_skip != 0;
     }
-    {
-        ProfScope p(*this, "step");
-        launch_step_solo(stream, W, S);
-    }
-    HIP_OK(hipGetLastError());
-    // ---- the report: done, deaths; the survivors' arrays have changed places
+    return true;
+}
+
+void Env::cycle_finish(int *done) {
+    use_device();
+    const int NG = (int)groups.size();
     wait_record(step_seq);
     const StepRecord &r = *h_rec;
     if (r.error) fatal("%s resolution did not converge", r.error == 1 ? "attack" : "move");
@@ -1369,7 +1366,7 @@ void Env::cycle(int n_group, float *const *view, float *const *feat, const int *
         G.group_reward = 0;
         if (G.n - r.dead[g] > 0) live++;
         const int gone = r.dead[g] + r.taken[g];
-        if (gone > 0 && G.n > 0) {
+        if (gone > 0 && G.n > 0) {   // the survivors' arrays have changed places
             std::swap(G.cur.x, G.alt.x); std::swap(G.cur.y, G.alt.y); std::swap(G.cur.id, G.alt.id);
             std::swap(G.cur.hp, G.alt.hp); std::swap(G.cur.last_action, G.alt.last_action);
             std::swap(G.cur.last_reward, G.alt.last_reward); std::swap(G.cur.next_reward, G.alt.next_reward);
@@ -1384,8 +1381,88 @@ void Env::cycle(int n_group, float *const *view, float *const *feat, const int *
     h_occ_valid = false;
     tables_valid = true;
     paint_valid = step_live_paint;
-    mini_valid = next_mini;
-    if (next_mini) { mini_vh = S.mini_vh; mini_vw = S.mini_vw; mini_pop = mini_population(S.mini_skip != 0); }
+    mini_valid = cyc_next_mini;
+    if (cyc_next_mini) { mini_vh = cyc_mini_vh; mini_vw = cyc_mini_vw; mini_pop = mini_population(cyc_mini_skip); }
+}
+
+void Env::cycle(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, int *done) {
+    static thread_local BatchItem item;
+    if (!cycle_prepare(n_group, view, feat, actions, rewards, item)) {   // the general path: the same calls one after the other
+        const int NG = (int)groups.size();
+        for (int g = 0; g < NG; g++) {
+            if (view && view[g]) observe_device(g, view[g], feat[g]);
+            if (actions && actions[g]) set_action_device(g, actions[g]);
+        }
+        step(done);
+        for (int g = 0; g < NG; g++) if (rewards && rewards[g]) get_reward_device(g, rewards[g]);
+        clear_dead();
+        return;
+    }
+    {
+        ProfScope p(*this, "render", true);
+        launch_render_multi(stream, item.W, item.M);
+    }
+    {
+        ProfScope p(*this, "step");
+        launch_step_solo(stream, item.W, item.S);
+    }
+    HIP_OK(hipGetLastError());
+    cycle_finish(done);
+}
+
+// many small environments, one pair of launches: every environment that can take the two-launch cycle is described in an
+// item of a device array (one workgroup of k_step_solo_batch each); the others go one by one
+void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **feat, const int **actions, float **rewards, int *done) {
+    Env &lead = *envs[0];
+    lead.use_device();
+    for (int e = 1; e < n_env; e++) envs[e]->adopt_stream(lead);   // one stream for the batch: launches need no cross-stream events
+    if ((size_t)n_env > lead.batch_cap) {
+        HIP_OK(hipStreamSynchronize(lead.stream));
+        if (lead.batch_h) HIP_OK(hipHostFree(lead.batch_h));
+        dfree(lead.batch_d);
+        lead.batch_cap = std::max<size_t>((size_t)n_env, lead.batch_cap * 2);
+        HIP_OK(hipHostMalloc((void **)&lead.batch_h, sizeof(BatchItem) * lead.batch_cap, hipHostMallocDefault));
+        HIP_OK(hipMalloc(&lead.batch_d, sizeof(BatchItem) * lead.batch_cap));
+    }
+    std::vector<int> in_batch, alone;
+    for (int e = 0; e < n_env; e++) {
+        const int o = e * n_group;
+        if (envs[e]->device_id == lead.device_id &&
+            envs[e]->cycle_prepare(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
+                                   rewards ? rewards + o : nullptr, lead.batch_h[in_batch.size()]))
+            in_batch.push_back(e);
+        else alone.push_back(e);
+    }
+    if (!in_batch.empty()) {
+        int slots = 0, max_blocks = 0;
+        size_t render_lds = 0, step_lds = 0;
+        for (size_t k = 0; k < in_batch.size(); k++) {
+            const BatchItem &it = lead.batch_h[k];
+            slots = std::max(slots, it.M.n);
+            for (int q = 0; q < it.M.n; q++) { max_blocks = std::max(max_blocks, it.M.blocks[q]); render_lds = std::max(render_lds, render_strip_lds(it.M.P[q])); }
+            step_lds = std::max(step_lds, solo_step_lds(it.W, it.S));
+        }
+        HIP_OK(hipMemcpyAsync(lead.batch_d, lead.batch_h, sizeof(BatchItem) * in_batch.size(), hipMemcpyHostToDevice, lead.stream));
+        launch_cycle_batch(lead.stream, lead.batch_d, (int)in_batch.size(), slots, max_blocks, render_lds, step_lds);
+        HIP_OK(hipGetLastError());
+    }
+    for (int e : alone) {
+        const int o = e * n_group;
+        envs[e]->cycle(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
+                       rewards ? rewards + o : nullptr, &done[e]);
+    }
+    for (int e : in_batch) envs[e]->cycle_finish(&done[e]);
+}
+
+// every environment of a batch shares the first one's stream (kept alive by whoever still uses it)
+void Env::adopt_stream(Env &lead) {
+    if (stream == lead.stream) return;
+    if (!device_ready || !lead.device_ready) fatal("env_cycle_many called before reset");
+    if (device_id != lead.device_id) return;
+    use_device();
+    HIP_OK(hipStreamSynchronize(stream));
+    stream_owner = lead.stream_owner;
+    stream = lead.stream;
 }
 
 // ------------------------------------------------------------------------------------------------ reward / clear_dead

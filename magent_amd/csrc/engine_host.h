@@ -3,6 +3,7 @@
 #include <condition_variable>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -112,10 +113,13 @@ public:
     // one environment cycle -- observe + set_action per group, step, rewards, clear_dead (examples/train_battle.py:61-109) --
     // in two launches for small worlds (k_render_multi, k_step_solo); NULL entries skip that call for that group
     void cycle(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, int *done);
+    // ... and for many small environments in ONE pair of launches (one workgroup of k_step_solo_batch per environment)
+    static void cycle_many(Env **envs, int n_env, int n_group, float **view, float **feat, const int **actions, float **rewards, int *done);
     void sync();
     void profile_read(const char *name, int *n, float *ms);
 
     hipStream_t stream{};
+    std::shared_ptr<void> stream_owner;   // environments cycled together share one stream (Env::adopt_stream)
     int attack_round = 0;        // rounds of the attack fixed point launched in the current step (k_attack_eval)
     int prof_level = 0;          // 0 off, 1 every named phase, 2 only the observation render launches
     bool nt_stores = true;   // nontemporal stores keep the write-once output out of L2 (measured +15-20 %)
@@ -153,6 +157,11 @@ private:
     void enqueue_counters();
     bool step_pending = false, step_was_fast = false, step_was_solo = false, step_live_paint = false;
     bool solo_ok(int total_n);
+    bool cycle_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, BatchItem &item);
+    void cycle_finish(int *done);
+    void adopt_stream(Env &lead);
+    bool cyc_next_mini = false, cyc_mini_skip = false; int cyc_mini_vh = 0, cyc_mini_vw = 0;
+    BatchItem *batch_h = nullptr, *batch_d = nullptr; size_t batch_cap = 0;   // (lead environment of a batch)
     void wait_record(int seq);
     StepRecord *h_rec = nullptr;          // pinned: written by k_step_solo, spun on by step_end
     int step_seq = 0;

@@ -16,6 +16,7 @@
 #include "engine.h"
 #include "launch.h"
 #include <algorithm>
+#include <cstddef>
 
 namespace magent_amd {
 
@@ -173,7 +174,20 @@ __global__ void __launch_bounds__(256) k_minimap_norm(RenderArgs R, int G, int *
 // feature rows [id bits x E | one-hot last_action x NA | last_reward | x / w | y / h] (GridWorld.cc:386-396)
 struct AgentFeat { int id, la; float lr, fx, fy; };
 
-__device__ __forceinline__ AgentFeat load_feat(const WorldView &W, const GroupDev &Gd, int i) {
+// what the observation kernels read of the world: scalars, the painted map, the observing group
+struct RenderWorld {
+    int w, h, G;
+    const int2 *viewcell;
+    const unsigned char *mask;
+    GroupDev grp;
+    TypeDev type;
+};
+__device__ __forceinline__ RenderWorld render_world(const WorldView &W, int g) {
+    RenderWorld V;
+    V.w = W.w; V.h = W.h; V.G = W.G; V.viewcell = W.viewcell; V.mask = W.mask; V.grp = W.grp[g]; V.type = W.type[g];
+    return V;
+}
+__device__ __forceinline__ AgentFeat load_feat(const RenderWorld &W, const GroupDev &Gd, int i) {
     AgentFeat a;
     a.id = Gd.id[i]; a.la = Gd.last_action[i]; a.lr = Gd.last_reward[i];
     a.fx = __fdiv_rn((float)Gd.x[i], (float)W.w);
@@ -194,8 +208,8 @@ __device__ __forceinline__ float feature_value(const RenderArgs &R, const AgentF
 
 // the feature tensor of the group, as float4 where the pointer allows; `block` of `n_blocks` workgroups of 256 threads
 template <bool VEC4>
-__device__ __forceinline__ void features_body(const WorldView &W, const RenderArgs &R, const RenderPlan &P, unsigned block, unsigned n_blocks) {
-    const GroupDev Gd = W.grp[R.g];
+__device__ __forceinline__ void features_body(const RenderWorld &W, const RenderArgs &R, const RenderPlan &P, unsigned block, unsigned n_blocks) {
+    const GroupDev Gd = W.grp;
     const unsigned total = (unsigned)R.n * (unsigned)R.F;
     const unsigned nq = VEC4 ? total >> 2 : 0;
     for (unsigned q = block * 256u + threadIdx.x; q < nq; q += n_blocks * 256u) {
@@ -225,7 +239,7 @@ __device__ __forceinline__ void features_body(const WorldView &W, const RenderAr
 // stand-alone launch, used when the feature pointer is not 16-byte aligned while the view pointer is (or vice versa)
 template <bool VEC4>
 __global__ void __launch_bounds__(256) k_features(WorldView W, RenderArgs R, RenderPlan P) {
-    features_body<VEC4>(W, R, P, blockIdx.x, gridDim.x);
+    features_body<VEC4>(render_world(W, R.g), R, P, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------ observation render
@@ -247,7 +261,7 @@ constexpr int RENDER_WAVES = 4;
 
 // (bx of nb workgroups of the launch work on this group: the render spans first, then the feature rows)
 template <bool VEC4, bool NT, int U, bool PACKED>
-__device__ __forceinline__ void render_block(const WorldView &W, const RenderArgs &R, const RenderPlan &P, int bx, int nb) {
+__device__ __forceinline__ void render_block(const RenderWorld &W, const RenderArgs &R, const RenderPlan &P, int bx, int nb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int VHW = R.VH * R.VW, C = R.C, G = W.G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -259,8 +273,8 @@ __device__ __forceinline__ void render_block(const WorldView &W, const RenderArg
     }
     int span = bx;
     if (P.xcd_chunk > 0 && span < P.xcd_chunk * 8) span = (span & 7) * P.xcd_chunk + (span >> 3);
-    const GroupDev Gd = W.grp[R.g];
-    const TypeDev T = W.type[R.g];
+    const GroupDev Gd = W.grp;
+    const TypeDev T = W.type;
     const unsigned char *mask = W.mask + T.mask_off;
     const unsigned total_cells = (unsigned)R.n * (unsigned)VHW;
     const size_t total_floats = (size_t)total_cells * C;
@@ -367,14 +381,14 @@ __device__ __forceinline__ void render_block(const WorldView &W, const RenderArg
 
 template <bool VEC4, bool NT, int U, bool PACKED>
 __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, RenderArgs R, RenderPlan P) {
-    render_block<VEC4, NT, U, PACKED>(W, R, P, blockIdx.x, gridDim.x);
+    render_block<VEC4, NT, U, PACKED>(render_world(W, R.g), R, P, blockIdx.x, gridDim.x);
 }
 // several groups of a small world in one launch (blockIdx.y = slot): small worlds are bound by the number of launches
 template <bool PACKED>
 __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_multi(WorldView W, RenderMulti M) {
     const int k = blockIdx.y;
     if ((int)blockIdx.x >= M.blocks[k]) return;
-    render_block<true, true, 1, PACKED>(W, M.R[k], M.P[k], blockIdx.x, M.blocks[k]);
+    render_block<true, true, 1, PACKED>(render_world(W, M.R[k].g), M.R[k], M.P[k], blockIdx.x, M.blocks[k]);
 }
 
 // ------------------------------------------------------------------------------------------------ block scan trio
@@ -1693,9 +1707,8 @@ constexpr int SOLO_STEP_THREADS = 1024;
 #define SOLO_EACH_UNIFORM(g_, i_) \
     for (int g_ = 0; g_ < NG; g_++) for (int i0_ = 0, n_##i_ = W.grp[g_].n, i_ = tid; i0_ < n_##i_; i0_ += SOLO_STEP_THREADS, i_ += SOLO_STEP_THREADS)
 
-__global__ void __launch_bounds__(SOLO_STEP_THREADS) k_step_solo(WorldView W_kernarg, SoloStep S) {
+__device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S) {
     extern __shared__ unsigned s_dyn[];               // hit lists of the attack evaluation: [kmax][nt_eval] ranks, then refs
-    __shared__ WorldView s_W;
     // "something changed in round r" lives in s_flags[r % 3]: while round r runs, thread 0 re-arms the flag of round r + 1,
     // which was last read after the closing barrier of round r - 2 -- and everybody has passed the barrier of round r - 1 since
     __shared__ int s_flags[3];
@@ -1703,15 +1716,6 @@ __global__ void __launch_bounds__(SOLO_STEP_THREADS) k_step_solo(WorldView W_ker
     int n_marks = 0;
 #define SOLO_MARK() do { if (tid == 0 && n_marks < 40) s_marks[n_marks] = wall_clock64(); n_marks++; } while (0)
     const int tid = threadIdx.x;
-    // The world description is indexed by a loop variable here (group g): as a by-value kernel argument that would make
-    // the compiler keep a private copy of it in scratch memory, per lane.  It is copied to LDS once instead, word by word
-    // from the kernarg segment (it is the first argument: offset 0), and every phase body reads it there.
-    {
-        typedef const __attribute__((address_space(4))) unsigned *kernarg_words;
-        kernarg_words ka = (kernarg_words)__builtin_amdgcn_kernarg_segment_ptr();
-        for (int k = tid; k < (int)(sizeof(WorldView) / 4); k += SOLO_STEP_THREADS) ((unsigned *)&s_W)[k] = ka[k];
-    }
-    __syncthreads();
     const WorldView &W = s_W;
     const int NG = W.G;
     const GroupDev *gtab = W.grp;
@@ -1977,6 +1981,44 @@ __global__ void __launch_bounds__(SOLO_STEP_THREADS) k_step_solo(WorldView W_ker
 #undef SOLO_EACH
 #undef SOLO_EACH_UNIFORM
 #undef SOLO_MARK
+
+// The world description is indexed by a loop variable in the step (group g): as a by-value kernel argument that would make
+// the compiler keep a private copy of it in scratch memory, per lane.  It is copied to LDS once instead and every phase
+// body reads it there -- word by word from the kernarg segment (one environment per launch: W is the first argument, S
+// follows it), or from a device array of items (many environments per launch, one workgroup each: env_cycle_many).
+static_assert(sizeof(WorldView) % 8 == 0 && sizeof(SoloStep) % 4 == 0, "kernarg layout of k_step_solo");
+__global__ void __launch_bounds__(SOLO_STEP_THREADS) k_step_solo(WorldView W_kernarg, SoloStep S_kernarg) {
+    __shared__ WorldView s_W;
+    __shared__ SoloStep s_S;
+    typedef const __attribute__((address_space(4))) unsigned *kernarg_words;
+    kernarg_words ka = (kernarg_words)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int k = threadIdx.x; k < (int)(sizeof(WorldView) / 4); k += SOLO_STEP_THREADS) ((unsigned *)&s_W)[k] = ka[k];
+    for (int k = threadIdx.x; k < (int)(sizeof(SoloStep) / 4); k += SOLO_STEP_THREADS) ((unsigned *)&s_S)[k] = ka[sizeof(WorldView) / 4 + k];
+    __syncthreads();
+    solo_step_main(s_W, s_S);
+}
+__global__ void __launch_bounds__(SOLO_STEP_THREADS) k_step_solo_batch(const BatchItem *items) {
+    __shared__ WorldView s_W;
+    __shared__ SoloStep s_S;
+    const unsigned *src = (const unsigned *)&items[blockIdx.x];
+    static_assert(offsetof(BatchItem, W) == 0 && offsetof(BatchItem, S) == sizeof(WorldView), "BatchItem layout");
+    for (int k = threadIdx.x; k < (int)(sizeof(WorldView) / 4); k += SOLO_STEP_THREADS) ((unsigned *)&s_W)[k] = src[k];
+    for (int k = threadIdx.x; k < (int)(sizeof(SoloStep) / 4); k += SOLO_STEP_THREADS) ((unsigned *)&s_S)[k] = src[sizeof(WorldView) / 4 + k];
+    __syncthreads();
+    solo_step_main(s_W, s_S);
+}
+// the observations of many small environments in one launch: blockIdx.y = environment * slots + slot
+__global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_batch(const BatchItem *items, int slots) {
+    const int e = blockIdx.y / slots, k = blockIdx.y - e * slots;
+    const BatchItem &it = items[e];
+    if (k >= it.M.n || (int)blockIdx.x >= it.M.blocks[k]) return;
+    const RenderArgs R = it.M.R[k];
+    const RenderPlan P = it.M.P[k];
+    RenderWorld V;
+    V.w = it.W.w; V.h = it.W.h; V.G = it.W.G; V.viewcell = it.W.viewcell; V.mask = it.W.mask; V.grp = it.W.grp[R.g]; V.type = it.W.type[R.g];
+    if (it.W.vc_packed) render_block<true, true, 1, true>(V, R, P, blockIdx.x, it.M.blocks[k]);
+    else render_block<true, true, 1, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
+}
 
 // clear_dead for every group of a small world in ONE launch of one workgroup (GridWorld::clear_dead, GridWorld.cc:633-665):
 // stable compaction of the survivors into the alternate buffers + Agent::init_reward + re-indexing of the map (groups with
@@ -2262,12 +2304,21 @@ void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A,
     hipLaunchKernelGGL(k_clear_compact, grid, dim3(SCAN_THREADS), 0, s, W, A, sums);
 }
 void launch_step_solo(hipStream_t s, const WorldView &W, const SoloStep &S) {
-    size_t lds = (size_t)S.kmax * S.nt_eval * 8;
-    if (S.mini_vh > 0) lds = std::max(lds, sizeof(int) * ((size_t)W.G * S.mini_vh * S.mini_vw + W.G));
-    hipLaunchKernelGGL(k_step_solo, dim3(1), dim3(SOLO_STEP_THREADS), lds, s, W, S);
+    hipLaunchKernelGGL(k_step_solo, dim3(1), dim3(SOLO_STEP_THREADS), solo_step_lds(W, S), s, W, S);
 }
 void launch_clear_solo_all(hipStream_t s, const WorldView &W, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab) {
     hipLaunchKernelGGL(k_clear_solo_all, dim3(1), dim3(SOLO_THREADS), 0, s, W, A, gtab, ttab);
+}
+void launch_cycle_batch(hipStream_t s, const BatchItem *d_items, int n_env, int slots, int max_blocks, size_t render_lds, size_t step_lds) {
+    if (slots > 0 && max_blocks > 0)
+        hipLaunchKernelGGL(k_render_batch, dim3(max_blocks, n_env * slots), dim3(64 * RENDER_WAVES), render_lds, s, d_items, slots);
+    hipLaunchKernelGGL(k_step_solo_batch, dim3(n_env), dim3(SOLO_STEP_THREADS), step_lds, s, d_items);
+}
+size_t render_strip_lds(const RenderPlan &P) { return (size_t)RENDER_WAVES * P.strip_floats * sizeof(float); }
+size_t solo_step_lds(const WorldView &W, const SoloStep &S) {
+    size_t lds = (size_t)S.kmax * S.nt_eval * 8;
+    if (S.mini_vh > 0) lds = std::max(lds, sizeof(int) * ((size_t)W.G * S.mini_vh * S.mini_vw + W.G));
+    return lds;
 }
 int solo_step_static_lds() {   // static LDS of k_step_solo (tables, scan scratch): taken off the budget of the hit lists
     hipFuncAttributes a{};
@@ -2275,7 +2326,8 @@ int solo_step_static_lds() {   // static LDS of k_step_solo (tables, scan scratc
     return (int)a.sharedSizeBytes;
 }
 bool solo_step_allow_lds(size_t bytes) {   // dynamic LDS above the default limit has to be asked for
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_solo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_solo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_solo_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 void launch_clear_finish(hipStream_t s, const WorldView &Wn, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab) {
     hipLaunchKernelGGL(k_clear_finish, grid_all(Wn, 256), dim3(256), 0, s, Wn, A, gtab, ttab);

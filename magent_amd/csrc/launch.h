@@ -89,6 +89,16 @@ struct SoloStep {
     float *mini_out;                                               // ... float[G][mini_vh * mini_vw]
 };
 
+// one environment of a batched cycle launch (env_cycle_many: one workgroup of k_step_solo_batch per environment)
+struct BatchItem {
+    WorldView W;
+    SoloStep S;
+    RenderMulti M;
+};
+void launch_cycle_batch(hipStream_t s, const BatchItem *d_items, int n_env, int slots, int max_blocks, size_t render_lds, size_t step_lds);
+size_t render_strip_lds(const RenderPlan &P);
+size_t solo_step_lds(const WorldView &W, const SoloStep &S);
+
 void launch_set_tables(hipStream_t s, const WorldView &W, GroupDev *gtab, TypeDev *ttab);
 void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab);
 void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts, float *mini);

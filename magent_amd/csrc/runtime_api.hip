@@ -2,6 +2,7 @@
 // Replaces reference src/runtime_api.cc:15-163 symbol for symbol; PART 2 adds the device-resident calls.
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -131,6 +132,14 @@ int env_cycle_many(EnvHandle *games, int n_env, int n_group, float **view, float
         E(games[e])->cycle(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
                            rewards ? rewards + o : nullptr, &done[e]);
     };
+    // several environments: one pair of launches for all that are small enough (MAGENT_BATCH_CYCLE=0: one by one, by threads)
+    static const bool batch = !(std::getenv("MAGENT_BATCH_CYCLE") && std::atoi(std::getenv("MAGENT_BATCH_CYCLE")) == 0);
+    if (n_env >= 2 && batch) {
+        std::vector<Env *> envs(n_env);
+        for (int e = 0; e < n_env; e++) envs[e] = E(games[e]);
+        Env::cycle_many(envs.data(), n_env, n_group, view, feat, actions, rewards, done);
+        return 0;
+    }
     if (n_threads <= 1 || n_env <= 1) { for (int e = 0; e < n_env; e++) one(e); return 0; }
     cycle_pool().run(n_threads < n_env ? n_threads : n_env, n_env, one);
     return 0;

@@ -561,6 +561,7 @@ class EnvBatch(object):
         n = len(self.envs)
         self._handles = (ctypes.c_void_p * n)(*[e.game for e in self.envs])
         self._done = (ctypes.c_int32 * n)()
+        self._adopted = False
 
     def _ptrs(self, tensors):
         n = len(self.envs) * self.n_group
@@ -575,6 +576,10 @@ class EnvBatch(object):
         """each argument: list (per env) of lists (per group) of CUDA tensors or None; returns the done flags"""
         self._lib.env_cycle_many(self._handles, len(self.envs), self.n_group, self._ptrs(views), self._ptrs(feats),
                                  self._ptrs(actions), self._ptrs(rewards), self._done, self.n_threads)
+        if not self._adopted:      # environments cycled together share the first one's stream from now on
+            self._adopted = True
+            for e in self.envs:
+                e._ext_stream = None
         return [bool(d) for d in self._done]
 
 
