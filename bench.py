@@ -42,8 +42,9 @@ def cpu_baseline_worker(args):
     """child process: time the CPU engine on a bounded sample of the same workload; prints one JSON line"""
     import numpy as np
     import magent_amd
-    lib = args.cpu_lib
-    env = magent_amd.GridWorld("battle", lib=lib, map_size=args.map_size)
+    # the CPU checker behind the same wrapper (cpu_baseline leg only; the product class never loads anything else than the HIP engine)
+    CpuWorld = type("CpuWorld", (magent_amd.GridWorld,), {"_engine_path": args.cpu_lib})
+    env = CpuWorld("battle", map_size=args.map_size)
     env.set_seed(12345)
     env.reset()
     handles = env.get_handles()

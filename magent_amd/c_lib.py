@@ -1,8 +1,9 @@
 """Loader for the engine's C-ABI library (host-side mirror of reference python/magent/c_lib.py:11-42).
 
 The product library is magent_amd/lib/libmagent.so, built by ``__graft_entry__.build()`` from
-magent_amd/csrc (HIP, gfx950).  There is NO CPU fallback: if the library is missing, loading fails loudly.
-Tests may pass an explicit path to drive one of the CPU checkers under oracle/ through the same wrapper.
+magent_amd/csrc (HIP, gfx950).  There is NO CPU fallback: if the library is missing, loading fails loudly.  `load()` takes no environment override;
+`load(path)` loads the named library -- the tests use it (tests/helpers.py: `world_on`) to drive the CPU checkers under
+oracle/ through the same ctypes declarations.
 """
 import ctypes
 import os
@@ -64,7 +65,7 @@ def _load(path=None):
 
     RTLD_LOCAL on purpose: the CPU checkers under oracle/ export the same names and must be loadable
     next to the product in one test process."""
-    path = os.path.abspath(path or os.environ.get("MAGENT_AMD_LIB", DEFAULT_LIB))
+    path = os.path.abspath(path or DEFAULT_LIB)
     if path in _cache:
         return _cache[path]
     if not os.path.exists(path):

@@ -5,8 +5,9 @@ Same class / method names, argument meaning and return shapes as reference pytho
 of the C-ABI declared in include/magent_runtime_api.h.  On top of the reference surface it adds the
 device-resident calls (``*_device``) of the MI355X engine.
 
-The ``lib`` argument exists for the tests: the same wrapper can drive the CPU checkers under oracle/.
-The product path never does that -- by default the HIP library is loaded, and loading fails if it is absent.
+The engine library is always magent_amd/lib/libmagent.so (the HIP engine); loading fails if it is absent.  The class
+attribute ``_engine_path`` is what the tests override in a subclass of their own (tests/helpers.py) to drive the CPU
+checkers under oracle/ through the same wrapper -- nothing in the package sets it.
 """
 import ctypes
 import importlib
@@ -45,12 +46,14 @@ class GridWorld(object):
     OBS_INDEX_VIEW = 0
     OBS_INDEX_HP = 1
 
-    def __init__(self, config, lib=None, device_obs=None, **kwargs):
+    _engine_path = None      # None: the product library (c_lib.DEFAULT_LIB)
+
+    def __init__(self, config, device_obs=None, **kwargs):
         """config: name of a built-in game ("battle", "gather", "pursuit", kwargs -> its get_config) or a Config
         device_obs: get_observation() returns torch tensors living on the engine's GPU instead of numpy arrays (the
                     same reused buffers, no PCIe); default from the environment variable MAGENT_DEVICE_OBS=1.  Lets an
                     unmodified training script keep observations, policy and replay memory on the device."""
-        self._lib = c_lib.load(lib) if (lib is None or isinstance(lib, str)) else lib
+        self._lib = c_lib.load(type(self)._engine_path)
         L = self._lib
         if device_obs is None:
             device_obs = os.environ.get("MAGENT_DEVICE_OBS", "0") == "1"

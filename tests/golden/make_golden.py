@@ -29,7 +29,7 @@ FULL = ["battle_tiny", "battle_one_side"]
 
 def appendix_b(lib):
     """scripted duel of SURVEY.md Appendix B: g0 agent 0 attacks its +x neighbour until it dies"""
-    env = magent_amd.GridWorld("battle", lib=lib, map_size=30)
+    env = H.gridworld("battle", lib=lib, map_size=30)
     env.reset()
     h0, h1 = env.get_handles()
     env.add_agents(h0, "custom", pos=[(10, 12), (3, 3)])

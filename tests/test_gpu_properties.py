@@ -23,7 +23,7 @@ def _torch():
 
 def _make(game, size, n, seed=12345, over=None):
     import magent_amd
-    env = magent_amd.GridWorld(H.config_for(game, size, **(over or {})), lib=H.HIP_LIB)
+    env = H.gridworld(H.config_for(game, size, **(over or {})), lib=H.HIP_LIB)
     env.set_seed(seed)
     env.reset()
     for h in env.get_handles():
@@ -210,7 +210,7 @@ def test_env_batch_equals_standalone_environments():
     K, N, STEPS = 5, 300, 8
 
     def make(k):
-        env = magent_amd.GridWorld(H.config_for("battle", 36, small={"hp": 4, "damage": 3}), lib=H.HIP_LIB)
+        env = H.gridworld(H.config_for("battle", 36, small={"hp": 4, "damage": 3}), lib=H.HIP_LIB)
         env.set_seed(100 + k); env.reset()
         for h in env.get_handles():
             env.add_agents(h, "random", n=N)

@@ -64,8 +64,8 @@ def test_pre_reset_infos_match_oracle(hip_lib, game, size):
     """spaces, action layout and the view2attack table are host-side tables (Range.h / AgentType.cc restated):
     the product must agree with the oracle without ever touching a device"""
     import magent_amd
-    a = magent_amd.GridWorld(game, lib=hip_lib, map_size=size)
-    b = magent_amd.GridWorld(game, lib=H.ensure_oracle(), map_size=size)
+    a = H.gridworld(game, lib=hip_lib, map_size=size)
+    b = H.gridworld(game, lib=H.ensure_oracle(), map_size=size)
     for ha, hb in zip(a.get_handles(), b.get_handles()):
         assert a.get_view_space(ha) == b.get_view_space(hb)
         assert a.get_feature_space(ha) == b.get_feature_space(hb)
@@ -76,7 +76,7 @@ def test_pre_reset_infos_match_oracle(hip_lib, game, size):
 
 def test_battle_spaces_known_answers(hip_lib):
     import magent_amd
-    env = magent_amd.GridWorld("battle", lib=hip_lib, map_size=100)
+    env = H.gridworld("battle", lib=hip_lib, map_size=100)
     h = env.get_handles()[0]
     assert env.get_view_space(h) == (13, 13, 7) and env.get_feature_space(h) == (34,) and env.get_action_space(h) == (21,)
 
@@ -87,7 +87,7 @@ def test_unsupported_features_fail_loudly(hip_lib):
             "from magent_amd.builtin.config import _games\n"
             "cfg = _games.make('battle', 40)\n"
             "cfg.set({'turn_mode': True})\n"
-            "magent_amd.GridWorld(cfg, lib=%r)\n" % hip_lib)
+            "magent_amd.GridWorld(cfg)\n")
     env = dict(os.environ, MAGENT_AMD_NO_TORCH="1", PYTHONPATH=ROOT)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert p.returncode != 0 and "magent-amd FATAL" in p.stderr and "turn_mode" in p.stderr
@@ -99,8 +99,8 @@ def test_no_cpu_fallback_without_gpu(hip_lib):
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     code = ("import magent_amd\n"
-            "env = magent_amd.GridWorld('battle', lib=%r, map_size=30)\n"
-            "env.reset()\n" % hip_lib)
+            "env = magent_amd.GridWorld('battle', map_size=30)\n"
+            "env.reset()\n")
     env = dict(os.environ, MAGENT_AMD_NO_TORCH="1", PYTHONPATH=ROOT)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert p.returncode != 0 and "no HIP device" in p.stderr

@@ -47,7 +47,7 @@ def test_oracle_matches_compiled_reference(name):
 def test_appendix_b_known_answers():
     """SURVEY.md Appendix B, values hand-checked against the reference semantics"""
     import magent_amd
-    env = magent_amd.GridWorld("battle", lib=ORACLE, map_size=30)
+    env = H.gridworld("battle", lib=ORACLE, map_size=30)
     env.reset()
     h0, h1 = env.get_handles()
     env.add_agents(h0, "custom", pos=[(10, 12), (3, 3)])

@@ -29,7 +29,7 @@ def _worker(rank, world, port, oracle, out_dir):
     import magent_amd
     from magent_amd import replicas
     assert replicas.replica_info() == (rank, rank, world)
-    env = magent_amd.GridWorld("battle", lib=oracle, map_size=30)
+    env = H.gridworld("battle", lib=oracle, map_size=30)
     env.set_seed(replicas.replica_seed(12345, rank))
     env.reset()
     h0, h1 = env.get_handles()

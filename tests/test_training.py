@@ -42,9 +42,68 @@ def test_episodes_buffer_tracks_a_capped_random_subset():
     assert len(buf.buffer) == 5
 
 
+def _np_qnet(params, view, feature, use_dueling=True):
+    """NumPy fp32 restatement of the reference network (tf_model/dqn.py:151-189): conv3x3(32) -> conv3x3(32), both VALID, NHWC,
+    relu -> flatten (h, w, c order) -> dense 256 relu || dense 256 relu on the features -> concat -> dueling head
+    (value + advantage(no bias) - mean advantage).  Weights in TensorFlow layout: conv kernels HWIO, dense kernels [in, out]."""
+    def conv_valid(x, k, b):                       # x [N,H,W,C], k [3,3,C,O]
+        n, h, w, c = x.shape
+        out = np.zeros((n, h - 2, w - 2, k.shape[3]), dtype=np.float32)
+        for dy in range(3):
+            for dx in range(3):
+                out += np.tensordot(x[:, dy:dy + h - 2, dx:dx + w - 2, :], k[dy, dx], axes=([3], [0])).astype(np.float32)
+        return np.maximum(out + b, 0).astype(np.float32)
+    h1 = conv_valid(view, params["conv1/kernel"], params["conv1/bias"])
+    h2 = conv_valid(h1, params["conv2/kernel"], params["conv2/bias"])
+    flat = h2.reshape(h2.shape[0], -1)
+    h_view = np.maximum(flat @ params["dense_view/kernel"] + params["dense_view/bias"], 0)
+    h_emb = np.maximum(feature @ params["dense_emb/kernel"] + params["dense_emb/bias"], 0)
+    dense = np.concatenate([h_view, h_emb], axis=1).astype(np.float32)
+    if not use_dueling:
+        return dense @ params["value/kernel"] + params["value/bias"]
+    value = dense @ params["value/kernel"] + params["value/bias"]
+    adv = dense @ params["advantage/kernel"]
+    return value + adv - adv.mean(axis=1, keepdims=True)
+
+
+def test_dqn_network_is_the_reference_network():
+    """the PyTorch Q-network against a NumPy restatement of tf_model/dqn.py:151-189: parameter shapes (in TensorFlow's layout)
+    and a forward pass on battle-shaped inputs, rtol 1e-4 (fp32 accumulation order differs)"""
+    import torch
+    from magent_amd.builtin.torch_model.dqn import _QNet
+    torch.manual_seed(3)
+    view_space, feature_space, n_action = (13, 13, 7), (34,), 21
+    net = _QNet(view_space, feature_space, n_action, use_dueling=True, use_conv=True)
+    sd = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    tf_params = {   # torch conv weights are OIHW, TensorFlow's HWIO; torch Linear is [out, in], tf.layers.dense [in, out]
+        "conv1/kernel": sd["conv1.weight"].transpose(2, 3, 1, 0), "conv1/bias": sd["conv1.bias"],
+        "conv2/kernel": sd["conv2.weight"].transpose(2, 3, 1, 0), "conv2/bias": sd["conv2.bias"],
+        "dense_view/kernel": sd["dense_view.weight"].T, "dense_view/bias": sd["dense_view.bias"],
+        "dense_emb/kernel": sd["dense_emb.weight"].T, "dense_emb/bias": sd["dense_emb.bias"],
+        "value/kernel": sd["value.weight"].T, "value/bias": sd["value.bias"],
+        "advantage/kernel": sd["advantage.weight"].T,
+    }
+    shapes = {k: v.shape for k, v in tf_params.items()}
+    assert shapes == {"conv1/kernel": (3, 3, 7, 32), "conv1/bias": (32,), "conv2/kernel": (3, 3, 32, 32), "conv2/bias": (32,),
+                      "dense_view/kernel": (9 * 9 * 32, 256), "dense_view/bias": (256,), "dense_emb/kernel": (34, 256),
+                      "dense_emb/bias": (256,), "value/kernel": (512, 1), "value/bias": (1,), "advantage/kernel": (512, 21)}
+    assert "advantage.bias" not in sd                   # use_bias=False (dqn.py:182)
+    rs = np.random.RandomState(0)
+    view = rs.rand(17, *view_space).astype(np.float32)
+    feature = rs.rand(17, *feature_space).astype(np.float32)
+    with torch.no_grad():
+        got = net(torch.from_numpy(view), torch.from_numpy(feature)).numpy()
+    want = _np_qnet(tf_params, view, feature)
+    assert got.shape == (17, 21) and np.allclose(got, want, rtol=1e-4, atol=1e-5)
+    assert np.array_equal(got.argmax(1), want.argmax(1))
+    # the plain head (use_dueling=False, dqn.py:186) and the fully connected trunk (use_conv=False, dqn.py:171-173) exist too
+    plain = _QNet(view_space, feature_space, n_action, use_dueling=False, use_conv=False)
+    assert plain.value.weight.shape == (21, 512) and plain.dense_view.weight.shape == (256, 13 * 13 * 7)
+
+
 def _tiny_env(lib):
     import magent_amd
-    env = magent_amd.GridWorld("battle", lib=lib, map_size=20)
+    env = H.gridworld("battle", lib=lib, map_size=20)
     env.reset()
     h0, h1 = env.get_handles()
     env.add_agents(h0, "random", n=20)
@@ -160,9 +219,15 @@ def test_reference_train_battle_runs_unmodified(tmp_path):
     """examples/train_battle.py, byte for byte the reference's file, against `import magent` = this repository.
     Engine = CPU oracle here (no GPU in this container); on a GPU box the same command runs the HIP engine."""
     (tmp_path / "build").mkdir()
-    env = dict(os.environ, PYTHONPATH=ROOT, MAGENT_AMD_LIB=H.ensure_oracle(), OMP_NUM_THREADS="1")
-    p = subprocess.run([sys.executable, "/root/reference/examples/train_battle.py", "--train", "--n_round", "1", "--map_size", "20"],
-                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    # the script is run as it is; the launcher in front of it only names the engine library the way every test does
+    # (the class attribute the test suite overrides -- the product has no environment switch for it)
+    launcher = ("import sys, runpy\n"
+                "import magent_amd.gridworld as gw\n"
+                "gw.GridWorld._engine_path = %r\n"
+                "sys.argv = ['train_battle.py', '--train', '--n_round', '1', '--map_size', '20']\n"
+                "runpy.run_path('/root/reference/examples/train_battle.py', run_name='__main__')\n" % H.ensure_oracle())
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, "-c", launcher], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "===== train =====" in p.stdout and "round time" in p.stdout
 
@@ -198,14 +263,14 @@ def test_device_resident_training_round_on_gpu():
     import magent_amd
     from magent_amd.builtin.torch_model import DeepQNetwork
     from magent_amd.model import ProcessingModel
-    env = magent_amd.GridWorld("battle", lib=H.HIP_LIB, map_size=24, device_obs=True)
+    env = H.gridworld("battle", lib=H.HIP_LIB, map_size=24, device_obs=True)
     env.reset()
     handles = env.get_handles()
     for h in handles:
         env.add_agents(h, "random", n=40)
     v, f = env.get_observation(handles[0])
     assert isinstance(v, torch.Tensor) and v.is_cuda and tuple(v.shape) == (40, 13, 13, 7)
-    ref = magent_amd.GridWorld("battle", lib=H.HIP_LIB, map_size=24)       # host-buffer twin: same bits
+    ref = H.gridworld("battle", lib=H.HIP_LIB, map_size=24)       # host-buffer twin: same bits
     ref.reset()
     for h in ref.get_handles():
         ref.add_agents(h, "random", n=40)
