@@ -58,9 +58,11 @@ struct HostGroup {
     bool acted = false;          // set_action seen since the last step
     int h_dead = 0;              // dead_ct as of the last step (GridWorld.h Group::dead_ct)
     int h_taken = 0;             // movers taken in by goals: dead, but never counted in dead_ct (Map.cc:345)
+    int indexed = 0;             // agents [0, indexed) have been through a clear_dead: Agent::index == position, else 0
 };
 
-struct HostSymbol { int group = 0, index = 0; };
+struct HostSymbol { int group = 0, index = 0; int ent_g = -1, ent_i = -1; };   // ent_*: the agent the host rule search last bound it to
+struct HostRulePlan { std::vector<int> order, brings; };   // RewardRule::input_symbols / infer_obj (RewardEngine.cc:155-189); -1 = none
 struct HostNode { int op = OP_NULL; std::vector<int> raw; };
 struct HostRule { int on = 0; std::vector<int> recv; std::vector<float> val; bool terminal = false; };
 
@@ -153,6 +155,12 @@ private:
     bool read_changed();
     void clear_changed();
     void compile_rules();
+    void compile_rules_gpu();
+    void plan_host_rules();
+    void eval_rules_host();
+    bool rules_on_host = false;           // some rule has a shape the kernels do not take: all rules run on the host
+    std::vector<HostRulePlan> host_plans;
+    std::vector<unsigned char> host_triggers;
     void compile_rule_program(size_t k);
     void enqueue_counters();
     bool step_pending = false, step_was_fast = false, step_was_solo = false, step_live_paint = false;

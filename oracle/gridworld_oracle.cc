@@ -15,7 +15,7 @@
 //
 // Scope: what SURVEY.md section 8 puts on the path -- no goal_mode; turn_mode is restated too (the engine refuses it).  Reward rules
 // are evaluated by the reference's recursive search over symbol bindings, literally (and/or/not over attack, kill,
-// collide, die, at, in; 'any', 'all' and fixed-index symbols); align / in_a_line abort with a message.
+// collide, die, at, in, in_a_line; 'any', 'all' and fixed-index symbols); align aborts with a message (undefined in the reference).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -118,10 +118,14 @@ struct Group {
     std::vector<int64_t> op_obj;  // packed (group<<32 | index) or -1
     int dead_ct = 0;
     float reward = 0;             // Group::next_reward
+    // Agent::index (GridWorld.h:136,212-213) is 0 from the constructor and only set by clear_dead (GridWorld.cc:655): the agents
+    // in front of `indexed` have been through a clear_dead and carry their position, the ones added since carry 0.
+    // Only AgentSymbol::bind_with_check reads it (RewardEngine.cc:19).
+    int indexed = 0;
     int size() const { return (int)x.size(); }
     void clear() {
         x.clear(); y.clear(); id.clear(); last_action.clear(); last_op.clear(); hp.clear(); next_reward.clear();
-        last_reward.clear(); dead.clear(); absorbed.clear(); op_obj.clear(); dir.clear(); dead_ct = 0;
+        last_reward.clear(); dead.clear(); absorbed.clear(); op_obj.clear(); dir.clear(); dead_ct = 0; indexed = 0;
     }
 };
 
@@ -323,8 +327,8 @@ int env_reset(void *game) {
                 }
                 break;
             case OP_KILL: case OP_COLLIDE: case OP_ATTACK: add_sym(n.raw[0]); add_sym(n.raw[1]); add_inf({n.raw[0], n.raw[1]}); break;
-            case OP_AT: case OP_IN: case OP_DIE: add_sym(n.raw[0]); break;
-            default: fatal("reward rule event outside the hot-path scope (align / in_a_line)");
+            case OP_AT: case OP_IN: case OP_DIE: case OP_IN_A_LINE: add_sym(n.raw[0]); break;
+            default: fatal("reward rule event 'align': the reference reads counters it never fills (GridWorld.cc:94-95, 955-968); no defined result");
         }
         std::sort(n.related.begin(), n.related.end());
         std::sort(n.infer.begin(), n.infer.end());
@@ -640,7 +644,7 @@ int env_step(void *game, int *done) {
         Symbol &sy = e.symbols[sym];
         int g = (int)(ent >> 32), i = (int)(uint32_t)ent;
         if (sy.group != g) return false;
-        if (sy.index != -1 && sy.index != i) return false;
+        if (sy.index != -1 && sy.index != (i < e.groups[g].indexed ? i : 0)) return false;   // agent->get_index(): see Group::indexed
         sy.entity = ent;
         return true;
     };
@@ -666,6 +670,25 @@ int env_step(void *game, int *done) {
                 };
                 if (s0.index == -2) { Group &G = e.groups[s0.group]; for (int i = 0; i < G.size(); i++) if (!one(G, i)) return false; return true; }
                 return one(e.groups[(int)(s0.entity >> 32)], (int)(uint32_t)s0.entity);
+            }
+            case OP_IN_A_LINE: {   // RewardEngine.cc:263-296 (the symbol is 'all': asserted there)
+                Group &G = e.groups[e.symbols[n.raw[0]].group];
+                if (G.size() < 2) return true;
+                bool ret = false;
+                int dx = G.x[0] - G.x[1], dy = G.y[0] - G.y[1];
+                bool in_line = true;
+                if (dx == 0 && dy != 0) {
+                    int min_y, max_y, base_x = G.x[0];
+                    min_y = max_y = G.y[0];
+                    for (int i = 1; i < G.size() && in_line; i++) { min_y = std::min(G.y[i], min_y); max_y = std::max(G.y[i], max_y); in_line = (base_x == G.x[i]); }
+                    ret = in_line && max_y - min_y + 1 == G.size();
+                } else if (dx != 0 && dy == 0) {
+                    int min_x, max_x, base_y = G.y[0];
+                    min_x = max_x = G.x[0];
+                    for (int i = 1; i < G.size() && in_line; i++) { min_x = std::min(G.x[i], min_x); max_x = std::max(G.x[i], max_x); in_line = (base_y == G.y[i]); }
+                    ret = in_line && max_x - min_x + 1 == G.size();
+                }
+                return ret;
             }
             case OP_AND: return holds(e.nodes[n.raw[0]]) && holds(e.nodes[n.raw[1]]);
             case OP_OR: return holds(e.nodes[n.raw[0]]) || holds(e.nodes[n.raw[1]]);
@@ -741,6 +764,7 @@ int gridworld_clear_dead(void *game) {
         G.x.resize(pt); G.y.resize(pt); G.id.resize(pt); G.hp.resize(pt); G.last_action.resize(pt); G.last_reward.resize(pt);
         G.next_reward.resize(pt); G.last_op.resize(pt); G.op_obj.resize(pt); G.dead.resize(pt); G.absorbed.resize(pt); G.dir.resize(pt);
         G.dead_ct = 0;
+        G.indexed = pt;
     }
     return 0;
 }

@@ -214,7 +214,37 @@ def custom_rules(map_size):
     return cfg
 
 
-CUSTOM = {"rules": custom_rules, "arrange": custom_arrange, "duo": custom_duo, "trans": custom_trans, "tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
+def custom_search(map_size):
+    """rule shapes only the reference's recursive search takes (RewardEngine.cc:373-443) -- on the HIP engine they send ALL rules
+    of the game to the host evaluation: two iterated symbols (O(N^2) bindings), 'all' symbols as subject and as receiver (group
+    reward), a fixed-index symbol (with the reference's Agent::index quirk: 0 until the agent has been through a clear_dead),
+    in_a_line, subject and object paid in one group"""
+    cfg = gw.Config()
+    cfg.set({"map_width": map_size, "map_height": map_size, "minimap_mode": True, "embedding_size": 4})
+    t = cfg.register_agent_type("s", dict(width=1, length=1, hp=3, speed=2, view_range=gw.CircleRange(4), attack_range=gw.CircleRange(1.5),
+                                          damage=2, step_recover=-0.02, step_reward=-0.01, kill_reward=1, dead_penalty=-0.5, attack_penalty=-0.05,
+                                          attack_in_group=1))
+    post = cfg.register_agent_type("post", dict(width=1, length=1, hp=2, speed=0, view_range=gw.CircleRange(2), attack_range=gw.CircleRange(0)))
+    g0, g1, g2 = cfg.add_group(t), cfg.add_group(t), cfg.add_group(post)
+    ev, sym = gw.Event, gw.AgentSymbol
+    a, b, c, d = sym(g0, "any"), sym(g1, "any"), sym(g0, "any"), sym(g1, "any")
+    cfg.add_reward_rule(ev(a, "attack", b) & ev(c, "attack", d), receiver=[a, d], value=[0.0625, -0.03125])          # two subjects, two objects
+    e, f = sym(g0, "any"), sym(g1, "any")
+    cfg.add_reward_rule(ev(e, "attack", f) & ev(d, "die"), receiver=[e, d, f], value=[0.5, -0.25, 0.125])          # a binding per (attacker, dead agent)
+    all1, all2 = sym(g1, "all"), sym(g2, "all")
+    cfg.add_reward_rule(ev(all1, "in", ((0, 0), (map_size, map_size))), receiver=all1, value=0.015625)              # group reward
+    first = sym(g0, 0)
+    cfg.add_reward_rule(ev(first, "attack", b), receiver=[first, b], value=[1.5, -0.75])                             # a fixed agent
+    third = sym(g1, 3)
+    cfg.add_reward_rule(ev(a, "attack", third), receiver=[a, third], value=[0.3, -0.7])                              # ... as the object
+    cfg.add_reward_rule(ev(all2, "in_a_line"), receiver=[all2], value=[0.2])
+    x, y = sym(g0, "any"), sym(g0, "any")
+    cfg.add_reward_rule(ev(x, "attack", y), receiver=[x, y], value=[0.11, -0.13])                                    # subject and object in one group
+    cfg.add_reward_rule(ev(a, "kill", b) & ev(c, "kill", d), receiver=[a, c], value=[2, 3], terminal=True)
+    return cfg
+
+
+CUSTOM = {"search": custom_search, "rules": custom_rules, "arrange": custom_arrange, "duo": custom_duo, "trans": custom_trans, "tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
 
 
 class Scenario(object):
@@ -513,19 +543,32 @@ def fuzz_scenario(seed):
     # FUZZ_RULES=1 (oracle-vs-reference runs only: the engine refuses these shapes): random expressions over die / at / in and
     # the binary events, joined by & | ~ -- they pin the oracle's literal restatement of the recursive rule search
     tree_rules = []
-    if os.environ.get("FUZZ_RULES", "0") == "1":
+    fuzz_rules = int(os.environ.get("FUZZ_RULES", "0"))
+    if fuzz_rules >= 1:
+        # FUZZ_RULES=2 adds what only the recursive search handles: 'all' and fixed-index symbols, in_a_line.  Kept inside what
+        # the reference defines: the object of a binary event is never 'all', in_a_line only takes 'all' (it asserts both)
         for _ in range(int(rs.randint(1, 4))):
-            syms = [int(rs.randint(G)) for _ in range(int(rs.randint(1, 4)))]      # group of each symbol
+            n_sym = int(rs.randint(1, 4))
+            syms = [int(rs.randint(G)) for _ in range(n_sym)]      # group of each symbol
+            kinds = ["any"] * n_sym
+            if fuzz_rules >= 2:
+                kinds = [str(rs.choice(["any", "any", "any", "any", "all", "idx"])) for _ in range(n_sym)]
+                kinds = [int(rs.randint(0, 4)) if k == "idx" else k for k in kinds]
             def leaf():
-                kind = str(rs.choice(["die", "at", "in", "bin", "bin"]))
                 a = int(rs.randint(len(syms)))
+                kind = str(rs.choice(["die", "at", "in", "bin", "bin"] + (["line"] if kinds[a] == "all" else [])))
+                if kind == "line":
+                    return ("in_a_line", a)
                 if kind == "die":
                     return ("die", a)
                 if kind == "at":
                     return ("at", a, (int(rs.randint(1, w - 1)), int(rs.randint(1, h - 1))))
                 if kind == "in":
                     return ("in", a, ((int(rs.randint(0, w)), int(rs.randint(0, h))), (int(rs.randint(0, w)), int(rs.randint(0, h)))))
-                b = int(rs.randint(len(syms)))
+                objs = [k for k in range(len(syms)) if kinds[k] != "all"]
+                if not objs:
+                    return ("die", a)
+                b = int(rs.choice(objs))
                 return (str(rs.choice(["attack", "kill", "collide"])), a, b)
             def tree(depth):
                 if depth == 0 or rs.rand() < 0.4:
@@ -544,7 +587,7 @@ def fuzz_scenario(seed):
                         used.add(e[2])
             collect(expr)
             recv = [k for k in sorted(used) if rs.rand() < 0.7] or [sorted(used)[0]]
-            tree_rules.append((syms, expr, recv, [frac(-1, 1) for _ in recv], bool(rs.rand() < 0.1)))
+            tree_rules.append((syms, kinds, expr, recv, [frac(-1, 1) for _ in recv], bool(rs.rand() < 0.1)))
 
     def make():
         cfg = gw.Config()
@@ -585,8 +628,8 @@ def fuzz_scenario(seed):
         for gx, gy, two, expr, who, vals, terminal in prog_rules:
             S = [gw.AgentSymbol(hs[gx], "any"), gw.AgentSymbol(hs[gy], "any")]
             cfg.add_reward_rule(build_expr(S, expr), receiver=[S["xy".index(c)] for c in who], value=vals, terminal=terminal)
-        for syms, expr, recv, vals, terminal in tree_rules:
-            S = [gw.AgentSymbol(hs[g], "any") for g in syms]
+        for syms, kinds, expr, recv, vals, terminal in tree_rules:
+            S = [gw.AgentSymbol(hs[g], kinds[q]) for q, g in enumerate(syms)]
             def build(e):
                 if e[0] == "and":
                     return build(e[1]) & build(e[2])
@@ -594,8 +637,8 @@ def fuzz_scenario(seed):
                     return build(e[1]) | build(e[2])
                 if e[0] == "not":
                     return ~build(e[1])
-                if e[0] == "die":
-                    return gw.Event(S[e[1]], "die")
+                if e[0] in ("die", "in_a_line"):
+                    return gw.Event(S[e[1]], e[0])
                 if e[0] in ("at", "in"):
                     return gw.Event(S[e[1]], e[0], e[2])
                 return gw.Event(S[e[1]], e[0], S[e[2]])
@@ -721,6 +764,11 @@ def scenarios():
                  over={"big": {"food_supply": 6, "eat_ability": 2}, "mid": {"food_supply": 0.05, "eat_ability": 0.5}, "tiny": {"food_supply": 1, "eat_ability": 3}}),
         Scenario("rules_mix", ("rules", 30), 0, place=[rnd(0, 140), rnd(1, 140), rnd(2, 25)], walls=20, steps=30, action_seed=40),
         Scenario("rules_mix_large", ("rules", 110), 0, place=[rnd(0, 2500), rnd(1, 2500), rnd(2, 300)], steps=8, action_seed=41),
+        Scenario("rules_search", ("search", 26), 0, place=[rnd(0, 60), rnd(1, 60), (2, "custom", {"pos": [(5, 3), (5, 4), (5, 5), (5, 6)]})],
+                 walls=10, steps=30, action_seed=44),
+        Scenario("rules_search_grow", ("search", 30), 0, place=[rnd(0, 40), rnd(1, 40), (2, "custom", {"pos": [(8, 20), (9, 20), (10, 20)]})],
+                 steps=20, action_seed=45, clear_every=2,
+                 events={4: [("add", 0, "random", {"n": 30})], 9: [("add", 1, "random", {"n": 25}), ("add", 2, "custom", {"pos": [(11, 20)]})]}),
         Scenario("battle_turn", "battle", 26, place=[rnd(0, 120), rnd(1, 120), (0, "custom", {"pos": [(1, 1, 0), (3, 1, 1), (1, 3, 2), (3, 3, 3)]})],
                  steps=25, action_seed=42, settings={"turn_mode": True}, engine=False),
         Scenario("bodies_turn", ("bodies", 48, 37), 0, walls=40, place=[rnd(0, 50), rnd(1, 80), rnd(2, 150),

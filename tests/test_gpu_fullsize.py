@@ -61,3 +61,12 @@ def test_step_driver_variants(variant):
                          text=True, timeout=900)
     assert out.returncode == 0 and "failures: 0" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
     assert out.stdout.count("OK  ") == len(DENSE)
+
+
+def test_fuzz_rule_search_on_the_host_path():
+    """reward rules whose shape the kernels do not take ('all' / fixed-index symbols, several iterated symbols, in_a_line) run
+    through the engine's host evaluation (Env::eval_rules_host): random games with random such rules (FUZZ_RULES=2), HIP == oracle"""
+    env = dict(os.environ, OMP_NUM_THREADS="1", FUZZ_RULES="2")
+    out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "120"], env=env,
+                         capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and "120 seeds, 0 failures" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])

@@ -104,3 +104,14 @@ def test_oracle_matches_compiled_reference_on_random_games():
     for seed in range(60):
         sc = H.fuzz_scenario(seed)
         H.assert_same(H.run(sc, H.REF_LIB), H.run(sc, ORACLE), sc.name)
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) not present")
+def test_oracle_rule_search_matches_compiled_reference(monkeypatch):
+    """random rule expressions over 'any' / 'all' / fixed-index symbols, in_a_line, several iterated symbols (FUZZ_RULES=2): the
+    restated recursive search (RewardEngine.cc:216-443), the reference's Agent::index quirk included
+    (tools/fuzz_parity.py ref oracle ran 6000 such seeds clean in the build container)"""
+    monkeypatch.setenv("FUZZ_RULES", "2")
+    for seed in list(range(40)) + [223, 358, 366, 688, 1024, 1131]:    # (the six that found the Agent::index quirk)
+        sc = H.fuzz_scenario(seed)
+        H.assert_same(H.run(sc, H.REF_LIB), H.run(sc, ORACLE), sc.name)
