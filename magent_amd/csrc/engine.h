@@ -26,6 +26,7 @@ constexpr int OCC_FOOD = -3;            // food_mode: what an agent killed by an
 constexpr int PEND_NONE = 0;
 constexpr int PEND_MOVE = 1 << 16;
 constexpr int PEND_ATTACK = 2 << 16;
+constexpr int PEND_TURN = 3 << 16;      // turn_mode: payload = the action number itself (the reference subtracts move_base, GridWorld.cc:430-433)
 constexpr int PEND_ARG = 0xFFFF;
 
 // EventOp values the engine stores in last_op (reference grid_def.h:18-24)
@@ -40,6 +41,19 @@ __host__ __device__ inline bool mv_taken(unsigned s) { return (s >> 30) == 2u; }
 __host__ __device__ inline int mv_taken_by(unsigned s) { return (int)(s & 0x3FFFFFFFu); }
 constexpr unsigned long long CLAIM_NONE = ~0ull;
 
+// turn_mode: the way an agent faces (grid_def.h:15); moves, attack offsets and the observation window are given in the
+// agent's frame.  NORTH is the frame of the map -- every agent faces north when turn_mode is off.
+constexpr int DIR_EAST = 0, DIR_SOUTH = 1, DIR_WEST = 2, DIR_NORTH = 3, DIR_NUM = 4;
+// Map::rela_to_abs without the centre (Map.cc:515-532): an offset in the agent's frame -> an offset on the map
+__host__ __device__ inline void dir_rotate(int dir, int rx, int ry, int &ax, int &ay) {
+    switch (dir) {
+        case DIR_NORTH: ax = rx; ay = ry; break;
+        case DIR_SOUTH: ax = -rx; ay = -ry; break;
+        case DIR_WEST: ax = ry; ay = -rx; break;
+        default: ax = -ry; ay = rx; break;   // EAST
+    }
+}
+
 __host__ __device__ inline int ref_pack(int g, int i) { return (g << REF_SHIFT) | i; }
 __host__ __device__ inline int ref_group(int r) { return r >> REF_SHIFT; }
 __host__ __device__ inline int ref_index(int r) { return r & REF_MASK; }
@@ -51,7 +65,8 @@ struct TypeDev {
     int attack_in_group;
     int can_absorb;              // a "goal": the first mover that bumps into it is taken in (Map.cc:341-350)
     int bw, bl;                  // body width (x) and length (y) in cells; the agent's position is its top-left cell
-    int n_move, n_attack;        // action layout: [0, n_move) moves, [n_move, n_move + n_attack) attacks
+    int n_move, n_attack;        // action layout: [0, n_move) moves, (turn_mode: n_turn = 2 turns,) then n_attack attacks
+    int n_turn;
     int move_off, attack_off;    // offsets into WorldView::delta (int2 {dx,dy} per action payload)
     int attack_bit;              // first bit of this group's attack offsets in the per-cell hit word
     int view_w, view_h;          // observation window
@@ -66,6 +81,7 @@ struct GroupDev {
     float *hp, *next_reward, *last_reward;
     unsigned char *dead, *last_op;
     unsigned char *absorbed;     // can_absorb types: this goal has taken a mover in (GridWorld.h:191-192)
+    int *dir;                    // turn_mode: the way the agent faces (null when turn_mode is off: everybody faces north)
     unsigned *key;               // attack: sequence number -> rank after the shuffle; move: order key
     int *drank_a, *drank_b;      // attack fixed point: rank at which the agent dies (ping-pong)
     unsigned *mv;                // move resolution status / dependency
@@ -92,6 +108,7 @@ struct WorldView {
     int food_mode;               // GridWorld.cc:131
     float *food, *food_next;     // per cell: amount of food on OCC_FOOD cells; attack-phase scratch (-1 = eaten up)
     int large_map, bandwidth;    // reference large_map_mode striping (GridWorld.cc:75-85, 407-425)
+    int turn_mode;               // GridWorld.cc:134
     int vc_packed;               // viewcell holds one 32-bit word per cell (<= 3 groups, no goals), else an int2
     int live_paint;              // the step keeps `viewcell` current itself (vacated cells, then every live agent's body)
 };
@@ -134,6 +151,7 @@ struct RenderArgs {
     int VH, VW, C, S;            // window, channels, S = VH*VW*C floats per agent
     int F, E, NA;                // feature size, embedding size, n_action
     int minimap;                 // minimap_mode
+    int turn;                    // turn_mode: the window is laid out in the agent's frame
     int food;                    // food_mode: channel 1 shows food, the group blocks start at 2 (GridWorld.cc:915-924)
     int scale_w, scale_h;
     int chan_desc[32];           // per output channel: (kind << 8) | (code & 0xff); kind 0 = has, 1 = hp, 2 = minimap

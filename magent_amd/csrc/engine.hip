@@ -271,7 +271,10 @@ void Env::set_config(const char *key, void *p) {
     else if (k == "device_id") { if (device_ready && *(int *)p != device_id) fatal("device_id must be set before env_reset"); device_id = *(int *)p; }
     else if (k == "render_dir") render_dir = (const char *)p;
     else if (k == "food_mode") food_mode = *(bool *)p;
-    else if (k == "turn_mode" || k == "goal_mode") {
+    else if (k == "turn_mode") {
+        if (!types.empty() && *(bool *)p != turn_mode) fatal("turn_mode must be configured before the agent types are registered (it changes their action layout)");
+        turn_mode = *(bool *)p;
+    } else if (k == "goal_mode") {
         if (*(bool *)p) fatal("%s is outside the hot-path scope of this engine (SURVEY.md 8a)", key);
     } else fatal("invalid argument in GridWorld::set_config : %s", key);
 }
@@ -322,7 +325,7 @@ void Env::register_agent_type(const char *name, int n, const char **keys, float 
     t.move.circle(t.speed, 0, 1);
     t.view_x_offset = t.att_x_offset = t.width / 2;
     t.view_y_offset = t.att_y_offset = t.length / 2;
-    t.attack_base = t.move.count;  // no turn_mode: move | attack
+    t.attack_base = t.move.count + (turn_mode ? 2 : 0);  // move | (turn_mode: turn left, turn right) | attack (AgentType.cc:110-118)
     t.n_action = t.attack_base + t.attack.count;
     if (t.n_action > PEND_ARG) fatal("action space too large");
     types[name] = t;
@@ -731,7 +734,7 @@ void Env::free_group(HostGroup &g) {
     GroupDev &c = g.cur, &a = g.alt;
     dfree(c.x); dfree(c.y); dfree(c.id); dfree(c.last_action); dfree(c.op_obj); dfree(c.pend); dfree(c.hp);
     dfree(c.next_reward); dfree(c.last_reward); dfree(c.dead); dfree(c.last_op); dfree(c.key); dfree(c.drank_a);
-    dfree(c.drank_b); dfree(c.mv); dfree(c.hits); dfree(c.absorbed); dfree(a.absorbed);
+    dfree(c.drank_b); dfree(c.mv); dfree(c.hits); dfree(c.absorbed); dfree(a.absorbed); dfree(c.dir); dfree(a.dir);
     dfree(c.eat); dfree(c.fleft); dfree(c.fcell);
     dfree(a.x); dfree(a.y); dfree(a.id); dfree(a.last_action); dfree(a.hp); dfree(a.next_reward); dfree(a.last_reward);
     g.cap = 0; g.n = 0;
@@ -758,6 +761,7 @@ void Env::ensure_capacity(HostGroup &g, int need) {
     regrow(c.drank_a, n, ncap); regrow(c.drank_b, n, ncap); regrow(c.mv, n, ncap); regrow(c.hits, n, ncap);
     HIP_OK(hipMemset(c.hits, 0, sizeof(int) * ncap));
     regrow(c.absorbed, n, ncap); regrow(a.absorbed, 0, ncap);
+    if (turn_mode) { regrow(c.dir, n, ncap); regrow(a.dir, 0, ncap); }
     regrow(c.eat, 0, ncap); regrow(c.fleft, 0, ncap); regrow(c.fcell, 0, ncap);   // attack-phase scratch (food_mode)
     regrow(a.x, 0, ncap); regrow(a.y, 0, ncap); regrow(a.id, 0, ncap); regrow(a.last_action, 0, ncap);
     regrow(a.hp, 0, ncap); regrow(a.next_reward, 0, ncap); regrow(a.last_reward, 0, ncap);
@@ -775,6 +779,7 @@ WorldView Env::view() const {
     W.food_mode = food_mode ? 1 : 0;
     W.food = d_food; W.food_next = d_food ? d_food + (size_t)width * height : nullptr;
     W.large_map = large_map_mode; W.bandwidth = bandwidth;
+    W.turn_mode = turn_mode ? 1 : 0;
     W.vc_packed = (groups.size() <= 3 && !any_absorb) ? 1 : 0;
     W.live_paint = 0;
     for (int g = 0; g < W.G; g++) {
@@ -854,7 +859,7 @@ void Env::reset() {
         d.can_absorb = t.can_absorb;
         if (t.width * t.length > 1) any_multicell = 1;
         if (t.can_absorb) any_absorb = any_multicell = 1;   // goals: the generic move resolution knows how movers are taken in
-        d.n_move = t.move.count; d.n_attack = t.attack.count;
+        d.n_move = t.move.count; d.n_attack = t.attack.count; d.n_turn = turn_mode ? 2 : 0;
         d.move_off = (int)delta.size();
         for (int k = 0; k < t.move.count; k++) delta.push_back(make_int2(t.move.dx[k], t.move.dy[k]));
         d.attack_bit = total_attack;
@@ -879,6 +884,13 @@ void Env::reset() {
         attack_kmax = std::max(attack_kmax, k);
     }
     if (food_mode) attack_kmax = std::max(attack_kmax, total_attack);   // a food cell is hit by every group
+    if (turn_mode) {
+        // bodies of one cell turn about their own cell: nothing can be in the way.  Larger bodies re-lay their footprint when
+        // they turn (an order-dependent conflict like a move) and take part in the generic move resolution with a footprint that
+        // depends on the way they face: not on the GPU path yet -- refused, never approximated
+        if (any_multicell) fatal("turn_mode with bodies larger than one cell (or with goals) is not on the GPU path yet");
+        attack_kmax *= DIR_NUM;   // an attack bit may stand for one attacker per direction
+    }
     if (attack_kmax > 256) fatal("attack ranges x body size too large for the LDS hit lists (%d > 256)", attack_kmax);
     if (!attack_lds_ok(attack_kmax)) fatal("attack ranges x body size (%d hits per target) need more LDS per workgroup than this device grants", attack_kmax);
     if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
@@ -949,7 +961,6 @@ void Env::host_random_blank(int bw, int bl, int &ox, int &oy) {
 
 // GridWorld::add_agents (GridWorld.cc:180-290).  Cold path: placement is defined sequentially by the reference.
 void Env::add_agents(int group, int n, const char *method, const int *px, const int *py, const int *pdir) {
-    (void)pdir;
     if (!device_ready) fatal("add_agents called before reset");
     use_device();
     download_occ();
@@ -970,18 +981,37 @@ void Env::add_agents(int group, int n, const char *method, const int *px, const 
     }
     if (group < 0 || group >= (int)groups.size()) fatal("invalid group handle in GridWorld::add_agents : %d", group);
     HostGroup &G = groups[group];
-    std::vector<int> sx, sy, sid;
-    const int bw = G.type->width, bl = G.type->length;
-    auto place = [&](int x, int y) {     // add_or_error: occupied positions are silently skipped, the id is reused
+    std::vector<int> sx, sy, sid, sdir;
+    // turn_mode: every agent faces a direction of its own; a body lying east-west has its footprint transposed (Map.cc:589-599)
+    auto place = [&](int x, int y, int dir) {     // add_or_error: occupied positions are silently skipped, the id is reused
+        const bool upright = dir == DIR_NORTH || dir == DIR_SOUTH;
+        const int bw = upright ? G.type->width : G.type->length, bl = upright ? G.type->length : G.type->width;
         if (!host_blank(x, y, bw, bl)) return;
         const int ref = ref_pack(group, G.n + (int)sx.size());
         for (int i = 0; i < bw; i++) for (int j = 0; j < bl; j++) h_occ[(size_t)(y + j) * width + x + i] = ref;
-        sx.push_back(x); sy.push_back(y); sid.push_back(id_counter++);
+        sx.push_back(x); sy.push_back(y); sid.push_back(id_counter++); sdir.push_back(dir);
     };
-    if (m == "random") { for (int i = 0; i < n; i++) { int x, y; host_random_blank(bw, bl, x, y); place(x, y); } }
-    else if (m == "custom") { for (int i = 0; i < n; i++) place(px[i], py[i]); }
-    else if (m == "fill") { for (int x = px[0]; x < px[0] + px[2]; x += bw) for (int y = px[1]; y < px[1] + px[3]; y += bl) place(x, y); }
-    else fatal("unsupported method in GridWorld::add_agents : %s", method);
+    if (m == "random") {
+        for (int i = 0; i < n; i++) {
+            rng_on_device = false;
+            const int dir = turn_mode ? (int)(rng() % DIR_NUM) : DIR_NORTH;   // drawn before the position (GridWorld.cc:230)
+            const bool upright = dir == DIR_NORTH || dir == DIR_SOUTH;
+            int x, y;
+            host_random_blank(upright ? G.type->width : G.type->length, upright ? G.type->length : G.type->width, x, y);
+            place(x, y, dir);
+        }
+    } else if (m == "custom") {
+        for (int i = 0; i < n; i++) {
+            if (pdir && pdir[i] >= DIR_NUM) fatal("invalid direction in GridWorld::add_agent");
+            place(px[i], py[i], turn_mode && pdir ? pdir[i] : DIR_NORTH);
+        }
+    } else if (m == "fill") {
+        const int dir = turn_mode ? px[4] : DIR_NORTH;
+        if (dir < 0 || dir >= DIR_NUM) fatal("invalid direction in GridWorld::add_agent");
+        const bool upright = dir == DIR_NORTH || dir == DIR_SOUTH;
+        const int bw = upright ? G.type->width : G.type->length, bl = upright ? G.type->length : G.type->width;
+        for (int x = px[0]; x < px[0] + px[2]; x += bw) for (int y = px[1]; y < px[1] + px[3]; y += bl) place(x, y, dir);
+    } else fatal("unsupported method in GridWorld::add_agents : %s", method);
 
     const int k = (int)sx.size();
     if (G.n + k > REF_MASK) fatal("too many agents in one group");
@@ -1003,6 +1033,7 @@ void Env::add_agents(int group, int n, const char *method, const int *px, const 
         up(c.pend, std::vector<int>(k, PEND_NONE));
         up(c.dead, std::vector<unsigned char>(k, 0));
         up(c.absorbed, std::vector<unsigned char>(k, 0));
+        if (turn_mode) up(c.dir, sdir);
         up(c.last_op, std::vector<unsigned char>(k, (unsigned char)OP_NULL));
         G.n += k;
         tables_valid = false;
@@ -1020,6 +1051,7 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
     R.VH = t.view.height; R.VW = t.view.width; R.C = n_channel(); R.S = R.VH * R.VW * R.C;
     R.F = feature_size(g); R.E = embedding_size; R.NA = t.n_action;
     R.minimap = minimap_mode;
+    R.turn = turn_mode ? 1 : 0;
     R.food = food_mode ? 1 : 0;
     R.scale_h = (height + R.VH - 1) / R.VH;   // GridWorld.cc:328-329
     R.scale_w = (width + R.VW - 1) / R.VW;
@@ -1536,7 +1568,7 @@ bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, con
             if (G.n > 0) { S.actions[g] = actions[g]; S.call_base[g] = move_seq_base; move_seq_base += G.n; }
         }
         if (rewards && rewards[g] && G.n > 0) { S.rewards[g] = rewards[g]; S.group_reward[g] = G.group_reward; }
-        S.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed};
+        S.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed, G.alt.dir};
     }
     S.do_clear = 1;
     S.gtab_out = d_gtab; S.ttab_out = d_ttab;
@@ -1575,7 +1607,7 @@ void Env::cycle_finish(int *done) {
             std::swap(G.cur.x, G.alt.x); std::swap(G.cur.y, G.alt.y); std::swap(G.cur.id, G.alt.id);
             std::swap(G.cur.hp, G.alt.hp); std::swap(G.cur.last_action, G.alt.last_action);
             std::swap(G.cur.last_reward, G.alt.last_reward); std::swap(G.cur.next_reward, G.alt.next_reward);
-            std::swap(G.cur.absorbed, G.alt.absorbed);
+            std::swap(G.cur.absorbed, G.alt.absorbed); std::swap(G.cur.dir, G.alt.dir);
             G.n -= gone;
         }
         G.h_dead = 0; G.h_taken = 0;
@@ -1700,7 +1732,7 @@ void Env::clear_dead() {
         std::swap(G.cur.x, G.alt.x); std::swap(G.cur.y, G.alt.y); std::swap(G.cur.id, G.alt.id);
         std::swap(G.cur.hp, G.alt.hp); std::swap(G.cur.last_action, G.alt.last_action);
         std::swap(G.cur.last_reward, G.alt.last_reward); std::swap(G.cur.next_reward, G.alt.next_reward);
-        std::swap(G.cur.absorbed, G.alt.absorbed);
+        std::swap(G.cur.absorbed, G.alt.absorbed); std::swap(G.cur.dir, G.alt.dir);
         G.n -= G.h_dead + G.h_taken;
         G.h_dead = 0; G.h_taken = 0;
     };
@@ -1711,7 +1743,7 @@ void Env::clear_dead() {
         for (size_t g = 0; g < groups.size(); g++) {
             HostGroup &G = groups[g];
             A.mode[g] = G.n == 0 ? 0 : (G.h_dead + G.h_taken > 0 ? 2 : 1);
-            A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed};
+            A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed, G.alt.dir};
         }
         launch_clear_solo_all(stream, W, A, d_gtab, d_ttab);
         for (size_t g = 0; g < groups.size(); g++) if (A.mode[g] == 2) swap_buffers(groups[g]);
@@ -1726,7 +1758,7 @@ void Env::clear_dead() {
             if (G.h_dead + G.h_taken > 0) {
                 GroupDev D = G.cur;
                 D.x = G.alt.x; D.y = G.alt.y; D.id = G.alt.id; D.hp = G.alt.hp; D.last_action = G.alt.last_action;
-                D.last_reward = G.alt.last_reward; D.next_reward = G.alt.next_reward; D.absorbed = G.alt.absorbed;
+                D.last_reward = G.alt.last_reward; D.next_reward = G.alt.next_reward; D.absorbed = G.alt.absorbed; D.dir = G.alt.dir;
                 launch_compact(stream, W, (int)g, D, G.n - G.h_dead - G.h_taken, d_sums);
                 swap_buffers(G);
             } else {
@@ -1742,7 +1774,7 @@ void Env::clear_dead() {
             A.mode[g] = G.n == 0 ? 0 : (G.h_dead + G.h_taken > 0 ? 2 : 1);
             A.sums_off[g] = (int)nb_total;
             nb_total += (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
-            A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed};
+            A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed, G.alt.dir};
         }
         grow(d_sums, sums_cap, nb_total, stream);
         launch_clear_compact(stream, W, A, d_sums);
@@ -1935,11 +1967,13 @@ void Env::render() {
         HIP_OK(hipMemcpy(ys.data(), groups[i].cur.y, sizeof(int) * n, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(ids.data(), groups[i].cur.id, sizeof(int) * n, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(hp.data(), groups[i].cur.hp, sizeof(float) * n, hipMemcpyDeviceToHost));
+        std::vector<int> dirs(n, DIR_NORTH);
+        if (turn_mode) HIP_OK(hipMemcpy(dirs.data(), groups[i].cur.dir, sizeof(int) * n, hipMemcpyDeviceToHost));
         const float type_hp = groups[i].type->hp;
         for (int j = 0; j < n; j++) {
             if (!taken[i][j]) continue;
             int pct = std::min(std::max(0, int(100 * hp[j] / type_hp)), 100);
-            fout << ids[j] << " " << pct << " " << 270 << " " << xs[j] << " " << ys[j] << " " << i << std::endl;  // dir NORTH
+            fout << ids[j] << " " << pct << " " << 90 * dirs[j] << " " << xs[j] << " " << ys[j] << " " << i << std::endl;  // dir2angle (RenderGenerator.cc:148)
         }
     }
     for (const AttackEvent &e : attack_events) fout << 0 << " " << e.id << " " << e.x << " " << e.y << std::endl;

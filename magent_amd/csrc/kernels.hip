@@ -45,6 +45,14 @@ __device__ __forceinline__ void body_fill(const WorldView &W, int x, int y, int 
         for (int bx = 0; bx < bw; bx++) W.occ[(y + by) * W.w + x + bx] = v;
 }
 
+// the offset of action payload `k` of table `off` as the agent (g, i) means it: given in the agent's frame, turned by the way
+// it faces when turn_mode is on (Map.cc:209-226, GridWorld.cc:585-598)
+__device__ __forceinline__ int2 agent_delta(const WorldView &W, const GroupDev &G, int i, int table_off, int k) {
+    int2 d = W.delta[table_off + k];
+    if (W.turn_mode) { int ax, ay; dir_rotate(G.dir[i], d.x, d.y, ax, ay); d = make_int2(ax, ay); }
+    return d;
+}
+
 // Gates of the single-sync step (engine.hip: Env::step).  Fixed-point rounds are launched without waiting for the
 // host; rounds after convergence find nothing to do, and everything after a phase whose rounds ran out returns at
 // once so that the host can take over from exactly that state.  No gate kernel: the last round of a phase writes the
@@ -285,7 +293,7 @@ __device__ __forceinline__ void render_block(const RenderWorld &W, const RenderA
     for (int it = wave * U; it < P.steps_per_span; it += RENDER_WAVES * U) {
         const unsigned step0 = (unsigned)span * P.steps_per_span + it;
         if (step0 * 64u >= total_cells) break;
-        int cellv[U], xv[U], yv[U];
+        int cellv[U], xv[U], yv[U], dirv[U];
         bool valid[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -294,6 +302,7 @@ __device__ __forceinline__ void render_block(const RenderWorld &W, const RenderA
             const int a = valid[u] ? (int)fdiv_u32(k, P.div_vhw) : 0;
             cellv[u] = valid[u] ? (int)(k - a * VHW) : 0;
             xv[u] = Gd.x[a]; yv[u] = Gd.y[a];
+            dirv[u] = R.turn ? Gd.dir[a] : DIR_NORTH;
         }
         int2 recv[U];
         float miniv[U][MAXG];   // minimap value of this window position for channel block b (group (g + b) % G)
@@ -301,7 +310,9 @@ __device__ __forceinline__ void render_block(const RenderWorld &W, const RenderA
         for (int u = 0; u < U; u++) {
             const int vy = fdiv_u32(cellv[u], P.div_vw);
             const int vx = cellv[u] - vy * R.VW;
-            const int mx = xv[u] + T.view_x1 + vx, my = yv[u] + T.view_y1 + vy;
+            int ox = T.view_x1 + vx, oy = T.view_y1 + vy;            // window cell -> offset in the agent's frame ...
+            if (R.turn) dir_rotate(dirv[u], ox, oy, ox, oy);          // ... -> offset on the map (Map.cc:129-207)
+            const int mx = xv[u] + ox, my = yv[u] + oy;
             const bool in = valid[u] && mask[cellv[u]] && mx >= 0 && mx < W.w && my >= 0 && my < W.h;
             if (PACKED) {
                 const unsigned v = in ? ((const unsigned *)W.viewcell)[my * W.w + mx] : VC_EMPTY;
@@ -489,20 +500,20 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int 
         if (i < G.n) {
             int act = actions[i];
             G.last_action[i] = act;
-            if (act < 0 || act >= T.n_move + T.n_attack) {   // outside the action space: no action, reported at the end of the step
+            if (act < 0 || act >= T.n_move + T.n_turn + T.n_attack) {   // outside the action space: no action, reported at the end of the step
                 W.counters[CTR_BAD_ACTION] = 1;
                 G.pend[i] = PEND_NONE;
-            } else if (act < T.n_move) {
+            } else if (act < T.n_move + T.n_turn) {   // moves and (turn_mode) turns: ordered by stripe class, then insertion
                 unsigned bound = 0;
                 if (W.large_map) { int x_ = G.x[i] % W.bandwidth; bound = (x_ < 4 || x_ > W.bandwidth - 4) ? 1u : 0u; }
-                G.pend[i] = PEND_MOVE | act;
+                G.pend[i] = (act < T.n_move ? PEND_MOVE : PEND_TURN) | act;
                 G.key[i] = (bound << 31) | (unsigned)(call_base + i);
             } else {
-                G.pend[i] = PEND_ATTACK | (act - T.n_move);
+                G.pend[i] = PEND_ATTACK | (act - T.n_move - T.n_turn);
             }
         }
     }
-    int tot = block_count([&](int i) { return actions[i] >= T.n_move; }, G.n);
+    int tot = block_count([&](int i) { return actions[i] >= T.n_move + T.n_turn; }, G.n);
     if (threadIdx.x == 0) {
         sums[blockIdx.x] = tot;
         if (blockIdx.x == 0) W.counters[CTR_ATTACK_BASE] = W.counters[CTR_ATTACK];   // nothing writes CTR_ATTACK in this launch
@@ -511,7 +522,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int 
 
 __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_c(WorldView W, int g, const int *actions, const int *sums) {
     const GroupDev G = W.grp[g];
-    const int n_move = W.type[g].n_move;
+    const int n_move = W.type[g].n_move + W.type[g].n_turn;   // (the first attack action)
     const int before = W.counters[CTR_ATTACK_BASE] + block_prefix(sums, blockIdx.x);
     block_rank([&](int i) { return actions[i] >= n_move; }, [&](int i, int r) { G.key[i] = (unsigned)r; }, G.n, before);
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) W.counters[CTR_ATTACK] = before + sums[blockIdx.x];
@@ -524,20 +535,20 @@ __device__ __forceinline__ void set_action_solo_body(const WorldView &W, int g, 
     for (int i = threadIdx.x; i < G.n; i += SOLO_THREADS) {
         int act = actions[i];
         G.last_action[i] = act;
-        if (act < 0 || act >= T.n_move + T.n_attack) {
+        if (act < 0 || act >= T.n_move + T.n_turn + T.n_attack) {
             W.counters[CTR_BAD_ACTION] = 1;
             G.pend[i] = PEND_NONE;
-        } else if (act < T.n_move) {
+        } else if (act < T.n_move + T.n_turn) {
             unsigned bound = 0;
             if (W.large_map) { int x_ = G.x[i] % W.bandwidth; bound = (x_ < 4 || x_ > W.bandwidth - 4) ? 1u : 0u; }
-            G.pend[i] = PEND_MOVE | act;
+            G.pend[i] = (act < T.n_move ? PEND_MOVE : PEND_TURN) | act;
             G.key[i] = (bound << 31) | (unsigned)(call_base + i);
         } else {
-            G.pend[i] = PEND_ATTACK | (act - T.n_move);
+            G.pend[i] = PEND_ATTACK | (act - T.n_move - T.n_turn);
         }
     }
     __syncthreads();   // base was read by every thread before the total is written back
-    int total = solo_rank([&](int i) { return actions[i] >= T.n_move; }, [&](int i, int r) { G.key[i] = (unsigned)r; }, G.n, base);
+    int total = solo_rank([&](int i) { return actions[i] >= T.n_move + T.n_turn; }, [&](int i, int r) { G.key[i] = (unsigned)r; }, G.n, base);
     if (threadIdx.x == 0) W.counters[CTR_ATTACK] = total;
 }
 __global__ void __launch_bounds__(SOLO_THREADS) k_set_action_solo(WorldView W, int g, const int *actions, int call_base) {
@@ -686,7 +697,7 @@ __device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int 
     // hits they actually receive (one word per target instead of a scan of every attack offset around it)
     if (att && !dead) {
         const int k = pend & PEND_ARG;
-        int2 d = W.delta[T.attack_off + k];
+        int2 d = agent_delta(W, G, i, T.attack_off, k);
         int tx = G.x[i] + d.x, ty = G.y[i] + d.y;
         if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
             int o = W.occ[ty * W.w + tx];
@@ -724,10 +735,27 @@ __device__ __forceinline__ int gather_hits(const WorldView &W, unsigned bits, in
             int k = __ffs(mine) - 1;
             mine &= mine - 1;
             int2 d = W.delta[TA.attack_off + k];
-            int o = W.occ[(cy - d.y) * W.w + (cx - d.x)];   // the attacker's own top-left cell
-            int ai = ref_index(o);
-            s_rank[nh * NT + tid] = A.key[ai]; s_ref[nh * NT + tid] = o;
-            nh++;
+            if (!W.turn_mode) {
+                int o = W.occ[(cy - d.y) * W.w + (cx - d.x)];   // the attacker's own top-left cell
+                int ai = ref_index(o);
+                s_rank[nh * NT + tid] = A.key[ai]; s_ref[nh * NT + tid] = o;
+                nh++;
+                continue;
+            }
+            // turn_mode: the bit does not say which way the attacker faces -- one candidate per direction, each checked
+            // (several of them can be real: two agents facing different ways reach one cell with the same offset number)
+            for (int dir = 0; dir < DIR_NUM; dir++) {
+                int ax, ay;
+                dir_rotate(dir, d.x, d.y, ax, ay);
+                const int px = cx - ax, py = cy - ay;
+                if (px < 0 || py < 0 || px >= W.w || py >= W.h) continue;
+                const int o = W.occ[py * W.w + px];
+                if (o < 0 || ref_group(o) != ga) continue;
+                const int ai = ref_index(o);
+                if (A.dir[ai] != dir || A.pend[ai] != (PEND_ATTACK | k) || A.x[ai] != px || A.y[ai] != py) continue;
+                s_rank[nh * NT + tid] = A.key[ai]; s_ref[nh * NT + tid] = o;
+                nh++;
+            }
         }
     }
     return nh;
@@ -749,7 +777,7 @@ __device__ __forceinline__ void sort_hits(unsigned *s_rank, int *s_ref, int NT, 
 __device__ __forceinline__ int attack_cell(const WorldView &W, const GroupDev *gtab, int a) {
     const GroupDev A = gtab[ref_group(a)];
     const int ai = ref_index(a);
-    const int2 d = W.delta[W.type[ref_group(a)].attack_off + (A.pend[ai] & PEND_ARG)];
+    const int2 d = agent_delta(W, A, ai, W.type[ref_group(a)].attack_off, A.pend[ai] & PEND_ARG);
     return (A.y[ai] + d.y) * W.w + A.x[ai] + d.x;
 }
 // food_mode: one attacker eats from what is left on a cell (Map.cc:292-303).  `eat` of an attacker is written by the
@@ -802,7 +830,7 @@ __device__ __forceinline__ void attack_eval_body(const WorldView &W, const Group
     int aimed = -1;        // the agent on the cell I aim at, comrade or not (food_mode: it may leave food for me)
     if (attacker) {
         my_rank = G.key[i];
-        int2 d = W.delta[T.attack_off + (pend & PEND_ARG)];
+        int2 d = agent_delta(W, G, i, T.attack_off, pend & PEND_ARG);
         int tx = x + d.x, ty = y + d.y;
         if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
             int o = W.occ[ty * W.w + tx];
@@ -950,7 +978,7 @@ __device__ __forceinline__ void attack_apply_body(const WorldView &W, const Grou
     int tgt = -1, tgt_dr = RANK_INF;
     if (attacker) {
         my_rank = G.key[i];
-        int2 d = W.delta[T.attack_off + (pend & PEND_ARG)];
+        int2 d = agent_delta(W, G, i, T.attack_off, pend & PEND_ARG);
         int tx = x + d.x, ty = y + d.y;
         if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
             int o = W.occ[ty * W.w + tx];
@@ -1014,7 +1042,7 @@ __global__ void __launch_bounds__(256) k_attack_events(WorldView W, int4 *ev) {
     if ((pend & ~PEND_ARG) != PEND_ATTACK) return;
     const unsigned my_rank = G.key[i];
     const int dr = G.drank_a[i];
-    int2 d = W.delta[W.type[g].attack_off + (pend & PEND_ARG)];
+    int2 d = agent_delta(W, G, i, W.type[g].attack_off, pend & PEND_ARG);
     const bool executed = dr != -1 && (unsigned)dr >= my_rank;
     ev[my_rank] = make_int4(G.id[i], G.x[i] + d.x, G.y[i] + d.y, executed ? 1 : 0);
 }
@@ -1062,8 +1090,13 @@ __device__ __forceinline__ void move_prep_body(const WorldView &W, int g, int i,
     if (i >= G.n) return;
     int t = -1;
     int pend = G.pend[i];
+    // turn_mode, 1x1 bodies (GridWorld.cc:544-571, Map::do_turn Map.cc:361-406): the body turns about its own cell, nothing
+    // can be in the way.  The reference takes the turn's payload from move_base, so `wise` = 2 * action - 1 is an odd number
+    // >= 1: the direction changes by wise (mod 4).  Turns come after starvation and before the moves; a mover does not turn.
+    if (W.turn_mode && !G.dead[i] && (pend & ~PEND_ARG) == PEND_TURN)
+        G.dir[i] = (G.dir[i] + (pend & PEND_ARG) * 2 - 1 + DIR_NUM) % DIR_NUM;
     if (!G.dead[i] && (pend & ~PEND_ARG) == PEND_MOVE) {
-        int2 d = W.delta[T.move_off + (pend & PEND_ARG)];
+        int2 d = agent_delta(W, G, i, T.move_off, pend & PEND_ARG);
         int nx = G.x[i] + d.x, ny = G.y[i] + d.y;
         // is_blank_area bounds (Map.cc:455) for a 1x1 body; a zero move "succeeds" in place and never vacates
         if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + 1 < W.w && ny + 1 < W.h && W.occ[ny * W.w + nx] != OCC_WALL)
@@ -1651,6 +1684,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_clear_compact(WorldView W, Cle
                    int x = G.x[i], y = G.y[i];
                    D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
                    D.absorbed[r] = G.absorbed[i];
+                   if (G.dir) D.dir[r] = G.dir[i];
                    D.last_reward[r] = G.next_reward[i];
                    D.next_reward[r] = step_reward;
                    body_fill(W, x, y, bw, bl, ref_pack(g, r));
@@ -1680,6 +1714,7 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int 
                                     int x = G.x[i], y = G.y[i];
                                     D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
                    D.absorbed[r] = G.absorbed[i];
+                   if (G.dir) D.dir[r] = G.dir[i];
                                     D.last_reward[r] = G.next_reward[i];
                                     D.next_reward[r] = step_reward;
                                     body_fill(W, x, y, bw, bl, ref_pack(g, r));
@@ -1776,7 +1811,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
         SOLO_EACH(g, i) {
             const int pend = W.grp[g].pend[i];
             if ((pend & ~PEND_ARG) == PEND_ATTACK) {
-                const int2 d = W.delta[W.type[g].attack_off + (pend & PEND_ARG)];
+                const int2 d = agent_delta(W, W.grp[g], i, W.type[g].attack_off, pend & PEND_ARG);
                 const int tx = W.grp[g].x[i] + d.x, ty = W.grp[g].y[i] + d.y;
                 if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) S.hit[ty * W.w + tx] = 0u;
             }
@@ -1912,6 +1947,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
                                             int x = G.x[i], y = G.y[i];
                                             D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
                                             D.absorbed[r] = G.absorbed[i];
+                   if (G.dir) D.dir[r] = G.dir[i];
                                             D.last_reward[r] = G.next_reward[i];
                                             D.next_reward[r] = step_reward;
                                             body_fill(W, x, y, bw, bl, ref_pack(g, r));
@@ -1926,7 +1962,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
             GroupDev &N = s_W.grp[tid];
             const AltArrays D = S.dst[tid];
             N.x = D.x; N.y = D.y; N.id = D.id; N.last_action = D.last_action; N.hp = D.hp; N.next_reward = D.next_reward;
-            N.last_reward = D.last_reward; N.absorbed = D.absorbed;
+            N.last_reward = D.last_reward; N.absorbed = D.absorbed; N.dir = D.dir;
             N.n = s_alive[tid];
         }
         __syncthreads();
@@ -2040,6 +2076,7 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_clear_solo_all(WorldView W, Cl
                                             int x = G.x[i], y = G.y[i];
                                             D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
                                             D.absorbed[r] = G.absorbed[i];
+                   if (G.dir) D.dir[r] = G.dir[i];
                                             D.last_reward[r] = G.next_reward[i];
                                             D.next_reward[r] = step_reward;
                                             body_fill(W, x, y, bw, bl, ref_pack(g, r));
@@ -2058,7 +2095,7 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_clear_solo_all(WorldView W, Cl
         if (g < W.G && A.mode[g] == 2) {
             const ClearArgs::Alt D = A.dst[g];
             N.x = D.x; N.y = D.y; N.id = D.id; N.last_action = D.last_action; N.hp = D.hp; N.next_reward = D.next_reward;
-            N.last_reward = D.last_reward; N.absorbed = D.absorbed;
+            N.last_reward = D.last_reward; N.absorbed = D.absorbed; N.dir = D.dir;
             N.n = s_alive[g];
         }
         gtab[g] = N; ttab[g] = W.type[g];

@@ -63,7 +63,7 @@ struct RuleProg {
 };
 
 // alternate copies of the arrays that survive clear_dead (compaction is a stable scatter into them, then they change places)
-struct AltArrays { int *x, *y, *id, *last_action; float *hp, *next_reward, *last_reward; unsigned char *absorbed; };
+struct AltArrays { int *x, *y, *id, *last_action; float *hp, *next_reward, *last_reward; unsigned char *absorbed; int *dir; };
 
 // the one-launch step of small worlds (k_step_solo)
 struct SoloStep {

@@ -460,6 +460,7 @@ def render_episode(lib, out_dir, steps=6):
 
 
 _ATTACK_COUNT = {0: 0, 1: 4, 1.5: 8, 2: 12, 2.5: 20}
+TURN_MULTICELL_ON_ENGINE = False      # turn_mode with bodies larger than one cell / goals: refused by the engine so far
 
 
 def fuzz_scenario(seed):
@@ -473,7 +474,10 @@ def fuzz_scenario(seed):
     h = w if rs.rand() < 0.5 else int(rs.randint(12, 150))
     minimap, emb = bool(rs.rand() < 0.6), int(rs.choice([0, 3, 10]))
     food_mode = False
-    turn_mode = os.environ.get("FUZZ_TURN", "0") == "1" and bool(rs.rand() < 0.6)   # oracle-vs-reference runs only (the engine refuses it)
+    # FUZZ_TURN=1: turn_mode in 60 % of the games; FUZZ_TURN=2: the same draws, but turn_mode only stays on in games the engine
+    # takes today (see Env::reset)
+    fuzz_turn = int(os.environ.get("FUZZ_TURN", "0"))
+    turn_mode = fuzz_turn >= 1 and bool(rs.rand() < 0.6)
     frac = lambda lo, hi: float(rs.randint(int(lo * 16), int(hi * 16) + 1)) / 16.0
     while True:
         specs = []
@@ -490,7 +494,7 @@ def fuzz_scenario(seed):
             continue
         kmax = max(t["width"] * t["length"] * sum(_ATTACK_COUNT[a["attack_range"]] for j, a in enumerate(specs)
                                                   if j != i or a["attack_in_group"]) for i, t in enumerate(specs))
-        if kmax <= 256 and all(max(t["width"], t["length"]) + 2 < min(w, h) for t in specs):
+        if kmax * (4 if turn_mode else 1) <= 256 and all(max(t["width"], t["length"]) + 2 < min(w, h) for t in specs):
             break
     rules = []
     for _ in range(int(rs.randint(0, 5))):
@@ -666,6 +670,8 @@ def fuzz_scenario(seed):
         goal = int(rs.randint(G))
         specs[goal]["can_absorb"] = True
         acting = [g for g in acting if g != goal]
+    if fuzz_turn == 2 and turn_mode and not TURN_MULTICELL_ON_ENGINE and any(t["width"] * t["length"] > 1 or t.get("can_absorb") for t in specs):
+        turn_mode = False
     return Scenario("fuzz%d" % seed, make, 0, seed=int(rs.randint(1, 1 << 20)), place=place, steps=int(rs.randint(6, 14)),
                     action_seed=seed, walls=int(area * float(rs.choice([0, 0, 0.02, 0.08]))), acting=acting,
                     clear_every=int(rs.choice([1, 1, 1, 2])), obs_every=int(rs.choice([1, 1, 2])))
@@ -770,7 +776,12 @@ def scenarios():
                  steps=20, action_seed=45, clear_every=2,
                  events={4: [("add", 0, "random", {"n": 30})], 9: [("add", 1, "random", {"n": 25}), ("add", 2, "custom", {"pos": [(11, 20)]})]}),
         Scenario("battle_turn", "battle", 26, place=[rnd(0, 120), rnd(1, 120), (0, "custom", {"pos": [(1, 1, 0), (3, 1, 1), (1, 3, 2), (3, 3, 3)]})],
-                 steps=25, action_seed=42, settings={"turn_mode": True}, engine=False),
+                 steps=25, action_seed=42, settings={"turn_mode": True}),
+        Scenario("battle_turn_large", "battle", 130, place=[rnd(0, 3500), rnd(1, 3500)], steps=10, action_seed=46, settings={"turn_mode": True},
+                 over={"small": {"hp": 4, "damage": 3}}),
+        Scenario("gather_turn", "gather", 50, place=[rnd(0, 200), rnd(1, 700)], acting=[1], steps=20, action_seed=47, settings={"turn_mode": True}),
+        Scenario("tri_turn", ("tri", 60, 41), 0, place=[rnd(0, 400), rnd(1, 300), rnd(2, 350)], walls=60, steps=25, action_seed=48,
+                 settings={"turn_mode": True}),
         Scenario("bodies_turn", ("bodies", 48, 37), 0, walls=40, place=[rnd(0, 50), rnd(1, 80), rnd(2, 150),
                  (0, "fill", {"pos": (30, 20), "size": (8, 9), "dir": 2})], steps=25, action_seed=43, settings={"turn_mode": True}, engine=False),
         Scenario("battle_one_side", "battle", 12, place=[rnd(0, 60), rnd(1, 3)], steps=40, action_seed=14,

@@ -86,11 +86,11 @@ def test_unsupported_features_fail_loudly(hip_lib):
     code = ("import magent_amd, sys\n"
             "from magent_amd.builtin.config import _games\n"
             "cfg = _games.make('battle', 40)\n"
-            "cfg.set({'turn_mode': True})\n"
+            "cfg.set({'goal_mode': True})\n"
             "magent_amd.GridWorld(cfg)\n")
     env = dict(os.environ, MAGENT_AMD_NO_TORCH="1", PYTHONPATH=ROOT)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
-    assert p.returncode != 0 and "magent-amd FATAL" in p.stderr and "turn_mode" in p.stderr
+    assert p.returncode != 0 and "magent-amd FATAL" in p.stderr and "goal_mode" in p.stderr
 
 
 def test_no_cpu_fallback_without_gpu(hip_lib):
