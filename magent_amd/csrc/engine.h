@@ -54,6 +54,25 @@ __host__ __device__ inline void dir_rotate(int dir, int rx, int ry, int &ax, int
     }
 }
 
+// Map::save_to_real / real_to_save (Map.cc:553-587): the stored top-left cell of a wd x ln body <-> its reference corner, the
+// cell the agent-frame offsets (attack, view) are counted from
+__host__ __device__ inline void saved_to_real(int dir, int wd, int ln, int x, int y, int &rx, int &ry) {
+    switch (dir) {
+        case DIR_NORTH: rx = x; ry = y; break;
+        case DIR_SOUTH: rx = x + wd - 1; ry = y + ln - 1; break;
+        case DIR_WEST: rx = x; ry = y + wd - 1; break;
+        default: rx = x + ln - 1; ry = y; break;   // EAST
+    }
+}
+__host__ __device__ inline void real_to_saved(int dir, int wd, int ln, int rx, int ry, int &x, int &y) {
+    switch (dir) {
+        case DIR_NORTH: x = rx; y = ry; break;
+        case DIR_SOUTH: x = rx - wd + 1; y = ry - ln + 1; break;
+        case DIR_WEST: x = rx; y = ry - wd + 1; break;
+        default: x = rx - ln + 1; y = ry; break;   // EAST
+    }
+}
+
 __host__ __device__ inline int ref_pack(int g, int i) { return (g << REF_SHIFT) | i; }
 __host__ __device__ inline int ref_group(int r) { return r >> REF_SHIFT; }
 __host__ __device__ inline int ref_index(int r) { return r & REF_MASK; }
@@ -109,6 +128,7 @@ struct WorldView {
     float *food, *food_next;     // per cell: amount of food on OCC_FOOD cells; attack-phase scratch (-1 = eaten up)
     int large_map, bandwidth;    // reference large_map_mode striping (GridWorld.cc:75-85, 407-425)
     int turn_mode;               // GridWorld.cc:134
+    int reach;                   // turn_mode: how far (in cells, per axis) the top-left cell of a body can be from a cell its move or turn enters
     int vc_packed;               // viewcell holds one 32-bit word per cell (<= 3 groups, no goals), else an int2
     int live_paint;              // the step keeps `viewcell` current itself (vacated cells, then every live agent's body)
 };
@@ -120,7 +140,7 @@ struct StepRecord {
     unsigned long long triggers; // bit k: reward rule k fired in this step
     unsigned rng;                // engine RNG state after the step
     int last_a;                  // attack-list length
-    int unsupported, pack_overflow, error, bad_action;
+    int unsupported, pack_overflow, error, bad_action, hit_overflow;
     int rounds_attack, rounds_move;
     int n_marks; unsigned long long marks[40];   // wall_clock64 (100 MHz) at the phase boundaries of k_step_solo (tuning aid)
     volatile int seq;            // == the step's sequence number once everything above is visible
@@ -129,6 +149,7 @@ struct StepRecord {
 constexpr int CTR_CHANGED = 0, CTR_ATTACK = 1, CTR_DEAD = 2 /* unused: see CTR_DEAD_SPREAD */, CTR_PACK_OVERFLOW = 12, CTR_TRIGGER = 16, CTR_TRIGGER_END = 64;
 // movers taken in by goals, per group: dead, but not counted in the reference's dead_ct (Map.cc:345); cleared with CTR_DEAD
 constexpr int CTR_TAKEN = 64, CTR_UNSUPPORTED = 72;
+constexpr int CTR_HIT_OVERFLOW = 74;  // turn_mode: a target collected more hits than its list holds (the list is sized for the worst case otherwise)
 constexpr int CTR_BAD_ACTION = 73;   // set_action met an action outside [0, n_action): reported at the end of the step (the reference: UB)
 // Deaths are counted in DEAD_SLOTS counters per group, each on its own cache line: device-scope atomics on ONE address
 // serialise at ~15 ns apiece on this part (measured: 4.8k of them cost a 800k-agent step 70 us).  dead_ct of group g =

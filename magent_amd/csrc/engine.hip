@@ -780,6 +780,7 @@ WorldView Env::view() const {
     W.food = d_food; W.food_next = d_food ? d_food + (size_t)width * height : nullptr;
     W.large_map = large_map_mode; W.bandwidth = bandwidth;
     W.turn_mode = turn_mode ? 1 : 0;
+    W.reach = map_reach;
     W.vc_packed = (groups.size() <= 3 && !any_absorb) ? 1 : 0;
     W.live_paint = 0;
     for (int g = 0; g < W.G; g++) {
@@ -884,12 +885,21 @@ void Env::reset() {
         attack_kmax = std::max(attack_kmax, k);
     }
     if (food_mode) attack_kmax = std::max(attack_kmax, total_attack);   // a food cell is hit by every group
+    map_reach = 0;
     if (turn_mode) {
-        // bodies of one cell turn about their own cell: nothing can be in the way.  Larger bodies re-lay their footprint when
-        // they turn (an order-dependent conflict like a move) and take part in the generic move resolution with a footprint that
-        // depends on the way they face: not on the GPU path yet -- refused, never approximated
-        if (any_multicell) fatal("turn_mode with bodies larger than one cell (or with goals) is not on the GPU path yet");
-        attack_kmax *= DIR_NUM;   // an attack bit may stand for one attacker per direction
+        // an attack bit may stand for one attacker per direction.  The lists hold at most 256 hits: beyond that the worst case is not
+        // covered by construction any more, and an overflow is reported at the end of the step (CTR_HIT_OVERFLOW) instead
+        attack_kmax = std::min(attack_kmax * DIR_NUM, 256);
+        // how far the top-left cell of a body can be from a cell its move or its turn enters (neighbourhood scans, kernels.hip)
+        for (auto &g : groups) {
+            const HostType &t = *g.type;
+            int far = 0;
+            for (int k = 0; k < t.move.count; k++) far = std::max(far, std::max(std::abs(t.move.dx[k]), std::abs(t.move.dy[k])));
+            // a move shifts the top-left cell by `far`, a turn by up to M - 1 (the body is re-laid about its reference corner);
+            // the entered cell lies up to M - 1 further inside the new rectangle
+            const int M = std::max(t.width, t.length);
+            map_reach = std::max(map_reach, std::max(far, M - 1) + M - 1);
+        }
     }
     if (attack_kmax > 256) fatal("attack ranges x body size too large for the LDS hit lists (%d > 256)", attack_kmax);
     if (!attack_lds_ok(attack_kmax)) fatal("attack ranges x body size (%d hits per target) need more LDS per workgroup than this device grants", attack_kmax);
@@ -1261,7 +1271,7 @@ void Env::move_rounds_checked(const WorldView &W) {
 void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 = after move rounds */) {
     if (from == 0) {
         launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
-        if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);   // (starve / recover first)
+        if (any_multicell) launch_movg_prep(stream, W, true); else launch_move_prep(stream, W, d_gtab);   // (starve / recover first)
         move_rounds_checked(W);
     }
     if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
@@ -1312,7 +1322,10 @@ void Env::step_begin() {
     WorldView W = view();
     int total_n = 0;
     for (auto &g : groups) total_n += g.n;
-    const bool fast = !checked_step && !host_shuffle && first_render;
+    // (turn_mode with generic bodies: a third fixed point -- the turns -- between starvation and the moves; it runs under the
+    // host-checked driver, or inside the one-launch step)
+    const bool generic_turns = turn_mode && any_multicell;
+    const bool fast = !checked_step && !host_shuffle && first_render && !generic_turns;
     step_pending = true;
     step_was_fast = false;
     step_was_solo = false;
@@ -1362,7 +1375,7 @@ void Env::step_begin() {
         }
         {
             ProfScope p(*this, "move");
-            if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);
+            if (any_multicell) launch_movg_prep(stream, W, true); else launch_move_prep(stream, W, d_gtab);
             const int batches = opt_fixed ? opt_move_batches : (boost_move > 0 ? 2 : 1);
             for (int r = 0; r < batches * move_jump_batch; r++) {
                 const int flag = r == batches * move_jump_batch - 1 ? CTR_OPEN_MOVE : -1;   // the last round reports
@@ -1420,9 +1433,21 @@ void Env::step_begin() {
             }
             launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
         } else if (!first_render) attack_events.clear();
+        if (generic_turns) {
+            ProfScope p(*this, "turn");
+            launch_turn_prep(stream, W);        // (starvation first)
+            int iters = 0;
+            do {
+                clear_changed();
+                for (int k = 0; k < move_jump_batch; k++) launch_turn_sweep(stream, W, d_gtab, k == move_jump_batch - 1 ? CTR_CHANGED : -1);
+                iters += move_jump_batch;
+                if (iters > 1000000) fatal("turn resolution did not converge");
+            } while (read_changed());
+            launch_turn_apply(stream, W);
+        }
         {
             ProfScope p(*this, "move");
-            if (any_multicell) launch_movg_prep(stream, W); else launch_move_prep(stream, W, d_gtab);
+            if (any_multicell) launch_movg_prep(stream, W, !generic_turns); else launch_move_prep(stream, W, d_gtab);
             move_rounds_checked(W);
             if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
         }
@@ -1444,10 +1469,12 @@ void Env::step_end(int *done) {
     if (step_was_solo) {
         wait_record(step_seq);
         const StepRecord &r = *h_rec;
-        if (r.error) fatal("%s resolution did not converge", r.error == 1 ? "attack" : "move");
+        if (r.error) fatal("%s resolution did not converge", r.error == 1 ? "attack" : r.error == 2 ? "move" : "turn");
         if (r.unsupported) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
         if (r.pack_overflow) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
         if (r.bad_action) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
+    if (r.hit_overflow) fatal("a target collected more attack hits than the engine's hit lists hold (256)");
+        if (r.hit_overflow) fatal("a target collected more attack hits than the engine's hit lists hold (256)");
         if (rng_on_device) rng.x = r.rng;
         last_attack_iters = r.rounds_attack; last_move_iters = r.rounds_move; attack_round = r.rounds_attack;
         int live = 0;
@@ -1495,6 +1522,7 @@ void Env::step_end(int *done) {
     if (c[CTR_UNSUPPORTED]) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
     if (c[CTR_PACK_OVERFLOW]) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
     if (c[CTR_BAD_ACTION]) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
+    if (c[CTR_HIT_OVERFLOW]) fatal("a target collected more attack hits than the engine's hit lists hold (256)");
     *done = live < (int)groups.size();   // GridWorld.cc:619-624
     for (size_t k = 0; k < rules.size(); k++)
         if ((rules_on_host ? host_triggers[k] != 0 : c[CTR_TRIGGER + k] != 0) && rules[k].terminal) *done = 1;
@@ -1594,6 +1622,7 @@ void Env::cycle_finish(int *done) {
     if (r.unsupported) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
     if (r.pack_overflow) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
     if (r.bad_action) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
+    if (r.hit_overflow) fatal("a target collected more attack hits than the engine's hit lists hold (256)");
     if (rng_on_device) rng.x = r.rng;
     last_attack_iters = r.rounds_attack; last_move_iters = r.rounds_move; attack_round = r.rounds_attack;
     int live = 0;

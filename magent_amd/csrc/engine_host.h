@@ -199,7 +199,7 @@ private:
     // configuration
     int width = 0, height = 0, embedding_size = 0, device_id = 0;
     bool minimap_mode = false, large_map_mode = false, food_mode = false, turn_mode = false;
-    int bandwidth = 1;
+    int bandwidth = 1, map_reach = 0;
     std::string render_dir;
     // text video dump (reference RenderGenerator.{h,cc}); host-side, off the hot path
     bool first_render = true;

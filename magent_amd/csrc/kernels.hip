@@ -53,6 +53,25 @@ __device__ __forceinline__ int2 agent_delta(const WorldView &W, const GroupDev &
     return d;
 }
 
+// the footprint of a body on the map: a body lying east-west is transposed (Map.cc:589-599)
+__device__ __forceinline__ int2 dims_for_dir(const TypeDev &T, int dir) {
+    return (dir == DIR_NORTH || dir == DIR_SOUTH) ? make_int2(T.bw, T.bl) : make_int2(T.bl, T.bw);
+}
+__device__ __forceinline__ int2 body_dims(const WorldView &W, const GroupDev &G, const TypeDev &T, int i) {
+    return W.turn_mode ? dims_for_dir(T, G.dir[i]) : make_int2(T.bw, T.bl);
+}
+// the cell attack offset `k` of agent (g, i) points at (possibly outside the map): counted from the body's reference corner,
+// in the agent's frame (Map::get_attack_obj, Map.cc:209-226)
+__device__ __forceinline__ int2 attack_target(const WorldView &W, const GroupDev &G, const TypeDev &T, int i, int k) {
+    const int2 d = W.delta[T.attack_off + k];
+    if (!W.turn_mode) return make_int2(G.x[i] + d.x, G.y[i] + d.y);
+    const int dir = G.dir[i];
+    int rx, ry, ax, ay;
+    saved_to_real(dir, T.bw, T.bl, G.x[i], G.y[i], rx, ry);
+    dir_rotate(dir, d.x, d.y, ax, ay);
+    return make_int2(rx + ax, ry + ay);
+}
+
 // Gates of the single-sync step (engine.hip: Env::step).  Fixed-point rounds are launched without waiting for the
 // host; rounds after convergence find nothing to do, and everything after a phase whose rounds ran out returns at
 // once so that the host can take over from exactly that state.  No gate kernel: the last round of a phase writes the
@@ -139,8 +158,9 @@ __device__ __forceinline__ void repaint_body(const WorldView &W, const GroupDev 
     if (G.dead[i]) return;
     const unsigned bits = __float_as_uint(__fdiv_rn(G.hp[i], T.hp));   // the reference's `get_hp() / get_type().hp` (Map.cc:197)
     const int x = G.x[i], y = G.y[i];
-    for (int by = 0; by < T.bl; by++)
-        for (int bx = 0; bx < T.bw; bx++) vc_store(W, (y + by) * W.w + x + bx, g, bits);
+    const int2 fp = body_dims(W, G, T, i);
+    for (int by = 0; by < fp.y; by++)
+        for (int bx = 0; bx < fp.x; bx++) vc_store(W, (y + by) * W.w + x + bx, g, bits);
 }
 
 // ------------------------------------------------------------------------------------------------ minimap histogram
@@ -311,8 +331,12 @@ __device__ __forceinline__ void render_block(const RenderWorld &W, const RenderA
             const int vy = fdiv_u32(cellv[u], P.div_vw);
             const int vx = cellv[u] - vy * R.VW;
             int ox = T.view_x1 + vx, oy = T.view_y1 + vy;            // window cell -> offset in the agent's frame ...
-            if (R.turn) dir_rotate(dirv[u], ox, oy, ox, oy);          // ... -> offset on the map (Map.cc:129-207)
-            const int mx = xv[u] + ox, my = yv[u] + oy;
+            int bx = xv[u], by = yv[u];                               // ... counted from the body's reference corner
+            if (R.turn) {                                             // ... -> offset on the map (Map.cc:129-207)
+                dir_rotate(dirv[u], ox, oy, ox, oy);
+                saved_to_real(dirv[u], T.bw, T.bl, xv[u], yv[u], bx, by);
+            }
+            const int mx = bx + ox, my = by + oy;
             const bool in = valid[u] && mask[cellv[u]] && mx >= 0 && mx < W.w && my >= 0 && my < W.h;
             if (PACKED) {
                 const unsigned v = in ? ((const unsigned *)W.viewcell)[my * W.w + mx] : VC_EMPTY;
@@ -697,8 +721,8 @@ __device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int 
     // hits they actually receive (one word per target instead of a scan of every attack offset around it)
     if (att && !dead) {
         const int k = pend & PEND_ARG;
-        int2 d = agent_delta(W, G, i, T.attack_off, k);
-        int tx = G.x[i] + d.x, ty = G.y[i] + d.y;
+        const int2 tc = attack_target(W, G, T, i, k);
+        int tx = tc.x, ty = tc.y;
         if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
             int o = W.occ[ty * W.w + tx];
             // Map::get_attack_obj (Map.cc:229-247).  In food_mode an attack aimed at a comrade is recorded too: it does no
@@ -725,7 +749,7 @@ __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *ran
 
 // The hits that land on cell (cx, cy), appended to a thread-private LDS list (stride NT): bit (attack_bit[ga] + k) of
 // the cell's word is set iff the agent standing at cell - delta(ga, k) attacks it with offset k.
-__device__ __forceinline__ int gather_hits(const WorldView &W, unsigned bits, int cx, int cy, unsigned *s_rank, int *s_ref, int NT, int tid, int nh) {
+__device__ __forceinline__ int gather_hits(const WorldView &W, unsigned bits, int cx, int cy, unsigned *s_rank, int *s_ref, int NT, int tid, int nh, int kmax) {
     for (int ga = 0; ga < W.G; ga++) {
         const TypeDev TA = W.type[ga];
         if (TA.n_attack == 0) continue;
@@ -745,14 +769,15 @@ __device__ __forceinline__ int gather_hits(const WorldView &W, unsigned bits, in
             // turn_mode: the bit does not say which way the attacker faces -- one candidate per direction, each checked
             // (several of them can be real: two agents facing different ways reach one cell with the same offset number)
             for (int dir = 0; dir < DIR_NUM; dir++) {
-                int ax, ay;
+                int ax, ay, px, py;
                 dir_rotate(dir, d.x, d.y, ax, ay);
-                const int px = cx - ax, py = cy - ay;
+                real_to_saved(dir, TA.bw, TA.bl, cx - ax, cy - ay, px, py);    // reference corner -> the body's top-left cell
                 if (px < 0 || py < 0 || px >= W.w || py >= W.h) continue;
                 const int o = W.occ[py * W.w + px];
                 if (o < 0 || ref_group(o) != ga) continue;
                 const int ai = ref_index(o);
                 if (A.dir[ai] != dir || A.pend[ai] != (PEND_ATTACK | k) || A.x[ai] != px || A.y[ai] != py) continue;
+                if (nh >= kmax) { W.counters[CTR_HIT_OVERFLOW] = 1; continue; }   // (reported at the end of the step, never silent)
                 s_rank[nh * NT + tid] = A.key[ai]; s_ref[nh * NT + tid] = o;
                 nh++;
             }
@@ -777,8 +802,8 @@ __device__ __forceinline__ void sort_hits(unsigned *s_rank, int *s_ref, int NT, 
 __device__ __forceinline__ int attack_cell(const WorldView &W, const GroupDev *gtab, int a) {
     const GroupDev A = gtab[ref_group(a)];
     const int ai = ref_index(a);
-    const int2 d = agent_delta(W, A, ai, W.type[ref_group(a)].attack_off, A.pend[ai] & PEND_ARG);
-    return (A.y[ai] + d.y) * W.w + A.x[ai] + d.x;
+    const int2 tc = attack_target(W, A, W.type[ref_group(a)], ai, A.pend[ai] & PEND_ARG);
+    return tc.y * W.w + tc.x;
 }
 // food_mode: one attacker eats from what is left on a cell (Map.cc:292-303).  `eat` of an attacker is written by the
 // owner of its target cell only; a change sends the attacker back into evaluation.
@@ -803,7 +828,7 @@ __device__ __forceinline__ bool set_eat(const WorldView &W, const GroupDev *gtab
 // (s_rank / s_ref: the thread's hit list, stride ATT_THREADS, slot tid; flagp: where to report a change, or null)
 __device__ __forceinline__ void attack_eval_body(const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int g, int i,
                                                  int round /* 1, 2, ... within this step */, const unsigned *hitbits,
-                                                 unsigned *s_rank, int *s_ref, int ATT_THREADS, int tid, int *flagp) {
+                                                 unsigned *s_rank, int *s_ref, int ATT_THREADS, int tid, int *flagp, int kmax) {
     const GroupDev &G = W.grp[g];
     const TypeDev &T = W.type[g];
     const int dr_me_cur = G.drank_a[i];
@@ -816,11 +841,12 @@ __device__ __forceinline__ void attack_eval_body(const WorldView &W, const Group
     // ---- gather incoming hits: bit (attack_bit[ga] + k) of my cell's word is set iff the agent standing at
     // pos - delta(ga, k) attacks me with offset k
     int nh = 0;
-    for (int by = 0; by < T.bl; by++)
-        for (int bx = 0; bx < T.bw; bx++) {      // an attacker hits ONE cell; a multi-cell body collects from all of its cells
+    const int2 fp = body_dims(W, G, T, i);
+    for (int by = 0; by < fp.y; by++)
+        for (int bx = 0; bx < fp.x; bx++) {      // an attacker hits ONE cell; a multi-cell body collects from all of its cells
             const int cx = x + bx, cy = y + by;
             unsigned bits = hitbits[cy * W.w + cx];
-            if (bits) nh = gather_hits(W, bits, cx, cy, s_rank, s_ref, ATT_THREADS, tid, nh);
+            if (bits) nh = gather_hits(W, bits, cx, cy, s_rank, s_ref, ATT_THREADS, tid, nh, kmax);
         }
     if (nh == 0) return;                              // nobody hits me: I stay alive (RANK_INF, the initial value)
     sort_hits(s_rank, s_ref, ATT_THREADS, tid, nh);
@@ -830,8 +856,8 @@ __device__ __forceinline__ void attack_eval_body(const WorldView &W, const Group
     int aimed = -1;        // the agent on the cell I aim at, comrade or not (food_mode: it may leave food for me)
     if (attacker) {
         my_rank = G.key[i];
-        int2 d = agent_delta(W, G, i, T.attack_off, pend & PEND_ARG);
-        int tx = x + d.x, ty = y + d.y;
+        const int2 tc = attack_target(W, G, T, i, pend & PEND_ARG);
+        int tx = tc.x, ty = tc.y;
         if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
             int o = W.occ[ty * W.w + tx];
             if (o >= 0) aimed = o;
@@ -917,7 +943,7 @@ __global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev
     const int i = blockIdx.x * blockDim.x + tid;
     if (i >= W.grp[g].n) return;
     attack_eval_body(W, gtab, ttab, g, i, round, hitbits, s_hit, (int *)(s_hit + kmax * ATT_THREADS), ATT_THREADS, tid,
-                     flag >= 0 ? &W.counters[flag] : nullptr);
+                     flag >= 0 ? &W.counters[flag] : nullptr, kmax);
 }
 
 // food_mode: the food that lay on the map before this step.  One thread per cell: the hits on a food cell eat from it
@@ -934,7 +960,7 @@ __global__ void __launch_bounds__(256) k_food_eval(WorldView W, const GroupDev *
     const unsigned bits = hitbits[c];
     if (!bits) return;
     const int cy = c / W.w, cx = c - cy * W.w;
-    const int nh = gather_hits(W, bits, cx, cy, s_rank, s_ref, NT, tid, 0);
+    const int nh = gather_hits(W, bits, cx, cy, s_rank, s_ref, NT, tid, 0, kmax);
     sort_hits(s_rank, s_ref, NT, tid, nh);
     float food = W.food[c];
     bool present = true;
@@ -971,15 +997,16 @@ __device__ __forceinline__ void attack_apply_body(const WorldView &W, const Grou
     const bool attacker = (pend & ~PEND_ARG) == PEND_ATTACK;
     const int x = G.x[i], y = G.y[i];
     bool hit = false;
-    for (int by = 0; by < T.bl; by++)
-        for (int bx = 0; bx < T.bw; bx++) hit |= hitbits[(y + by) * W.w + x + bx] != 0;
+    const int2 fp = body_dims(W, G, T, i);
+    for (int by = 0; by < fp.y; by++)
+        for (int bx = 0; bx < fp.x; bx++) hit |= hitbits[(y + by) * W.w + x + bx] != 0;
     if (!hit && !attacker) return;
     unsigned my_rank = 0xFFFFFFFFu;
     int tgt = -1, tgt_dr = RANK_INF;
     if (attacker) {
         my_rank = G.key[i];
-        int2 d = agent_delta(W, G, i, T.attack_off, pend & PEND_ARG);
-        int tx = x + d.x, ty = y + d.y;
+        const int2 tc = attack_target(W, G, T, i, pend & PEND_ARG);
+        int tx = tc.x, ty = tc.y;
         if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
             int o = W.occ[ty * W.w + tx];
             if (o >= 0 && (T.attack_in_group || ref_group(o) != g)) tgt = o;
@@ -1042,9 +1069,9 @@ __global__ void __launch_bounds__(256) k_attack_events(WorldView W, int4 *ev) {
     if ((pend & ~PEND_ARG) != PEND_ATTACK) return;
     const unsigned my_rank = G.key[i];
     const int dr = G.drank_a[i];
-    int2 d = agent_delta(W, G, i, W.type[g].attack_off, pend & PEND_ARG);
+    const int2 tc = attack_target(W, G, W.type[g], i, pend & PEND_ARG);
     const bool executed = dr != -1 && (unsigned)dr >= my_rank;
-    ev[my_rank] = make_int4(G.id[i], G.x[i] + d.x, G.y[i] + d.y, executed ? 1 : 0);
+    ev[my_rank] = make_int4(G.id[i], tc.x, tc.y, executed ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------ starve / recover
@@ -1058,7 +1085,8 @@ __device__ __forceinline__ void starve_body(const WorldView &W, int g, const Gro
         const int dr = G.drank_a[i];
         if (dr != -1 && dr != RANK_INF) {
             died = true;
-            cells_clear(W, G.x[i], G.y[i], T.bw, T.bl);
+            const int2 fp = body_dims(W, G, T, i);
+            cells_clear(W, G.x[i], G.y[i], fp.x, fp.y);
             if (W.food_mode && G.fcell[i] >= 0) { W.occ[G.fcell[i]] = OCC_FOOD; W.food[G.fcell[i]] = G.fleft[i]; }   // Map.cc:276-283
         }
     }
@@ -1067,7 +1095,11 @@ __device__ __forceinline__ void starve_body(const WorldView &W, int g, const Gro
         if (T.step_recover > 0) hp = fminf(T.hp, hp + T.step_recover);
         else {
             hp -= -T.step_recover;
-            if (hp < 0.0f) { died = true; G.dead[i] = 1; G.next_reward[i] = T.dead_penalty; cells_clear(W, G.x[i], G.y[i], T.bw, T.bl); }
+            if (hp < 0.0f) {
+                died = true; G.dead[i] = 1; G.next_reward[i] = T.dead_penalty;
+                const int2 fp = body_dims(W, G, T, i);
+                cells_clear(W, G.x[i], G.y[i], fp.x, fp.y);
+            }
         }
         G.hp[i] = hp;
     }
@@ -1245,6 +1277,45 @@ __device__ __forceinline__ void for_each_entrant(const WorldView &W, int cx, int
     }
 }
 
+// turn_mode: the rectangle a candidate enters depends on the way it faces, so candidates are found by scanning the
+// neighbourhood of the cell for bodies (each met once, at its top-left cell): f(packed ref) -> true stops the search
+template <class F>
+__device__ __forceinline__ void for_each_body_near(const WorldView &W, const GroupDev *gtab, int cx, int cy, F f) {
+    const int y0 = max(0, cy - W.reach), y1 = min(W.h - 1, cy + W.reach), x0 = max(0, cx - W.reach), x1 = min(W.w - 1, cx + W.reach);
+    for (int py = y0; py <= y1; py++)
+        for (int px = x0; px <= x1; px++) {
+            const int e = W.occ[py * W.w + px];
+            if (e < 0) continue;
+            const GroupDev &A = gtab[ref_group(e)];
+            const int ei = ref_index(e);
+            if (A.x[ei] != px || A.y[ei] != py) continue;                  // not that body's top-left cell
+            if (f(e)) return;
+        }
+}
+// every candidate of kind `kind` (PEND_MOVE / PEND_TURN), other than `self`, with a lower key whose target rectangle
+// (top-left cell in drank_a, dimensions `transposed` or not with respect to the way it faces now) covers cell (cx, cy)
+template <class F>
+__device__ __forceinline__ void for_each_candidate_onto(const WorldView &W, const GroupDev *gtab, int cx, int cy, unsigned key, int self,
+                                                        int kind, bool transposed, F f) {
+    for_each_body_near(W, gtab, cx, cy, [&](int e) {
+        if (e == self) return false;
+        const GroupDev &A = gtab[ref_group(e)];
+        const int ei = ref_index(e);
+        const int t = A.drank_a[ei];
+        if ((A.pend[ei] & ~PEND_ARG) != kind || t < 0 || A.key[ei] >= key) return false;
+        int2 dm = dims_for_dir(W.type[ref_group(e)], A.dir[ei]);
+        if (transposed) dm = make_int2(dm.y, dm.x);
+        const int ty = t / W.w, tx = t - ty * W.w;
+        if (cx < tx || cx >= tx + dm.x || cy < ty || cy >= ty + dm.y) return false;
+        return f(e, A.mv[ei]);
+    });
+}
+template <class F>
+__device__ __forceinline__ void for_each_mover_onto(const WorldView &W, const GroupDev *gtab, int cx, int cy, unsigned key, int self, F f) {
+    if (W.turn_mode) for_each_candidate_onto(W, gtab, cx, cy, key, self, PEND_MOVE, false, f);
+    else for_each_entrant(W, cx, cy, key, self, f);
+}
+
 // MODE 0: is the move blocked? (stops at the first definite obstacle)   MODE 1: all moves are decided -- who is the
 // collide object?   MODE 2 (can_absorb types present): the outcome depends on WHICH agent is met first, so the scan
 // stops at the first cell that holds an agent or whose state is still unknown
@@ -1256,8 +1327,9 @@ __device__ __forceinline__ MoveProbe move_probe(const WorldView &W, const GroupD
     const int ny = tgt_cell / W.w, nx = tgt_cell - ny * W.w;
     const int self = ref_pack(g, i);
     MoveProbe r{false, false, -1};
-    for (int bx = 0; bx < T.bw; bx++)
-        for (int by = 0; by < T.bl; by++) {
+    const int2 fp = body_dims(W, G, T, i);
+    for (int bx = 0; bx < fp.x; bx++)
+        for (int by = 0; by < fp.y; by++) {
             const int cx = nx + bx, cy = ny + by, c = cy * W.w + cx;
             int occupant = -1;                       // who holds the cell when m's turn comes
             bool unknown = false;
@@ -1270,8 +1342,9 @@ __device__ __forceinline__ MoveProbe move_probe(const WorldView &W, const GroupD
                 bool gone = false;
                 if (ot >= 0 && O.key[oi] < key) {
                     const TypeDev TO = W.type[ref_group(o)];
+                    const int2 od = body_dims(W, O, TO, oi);
                     const int oy = ot / W.w, ox = ot - oy * W.w;
-                    const bool covers_again = cx >= ox && cx < ox + TO.bw && cy >= oy && cy < oy + TO.bl;
+                    const bool covers_again = cx >= ox && cx < ox + od.x && cy >= oy && cy < oy + od.y;
                     const unsigned st = O.mv[oi];
                     if (mv_taken(st)) gone = true;                       // taken in by a goal: off the map
                     else if (st == 0) unknown = !covers_again || W.any_absorb;
@@ -1282,7 +1355,7 @@ __device__ __forceinline__ MoveProbe move_probe(const WorldView &W, const GroupD
             // entrants with lower keys -- only where some OTHER candidate's target rectangle covers the cell at all
             // (wanted[c] counts the candidates whose rectangle covers c; mine is one of them)
             if ((occupant < 0 || unknown) && wanted[c] > 1)
-                for_each_entrant(W, cx, cy, key, self, [&](int e, unsigned st) {
+                for_each_mover_onto(W, gtab, cx, cy, key, self, [&](int e, unsigned st) {
                     if (st == MV_OK) { occupant = e; return true; }
                     if (st == 0) unknown = true;
                     return false;
@@ -1302,17 +1375,19 @@ __device__ __forceinline__ MoveProbe move_probe(const WorldView &W, const GroupD
 }
 
 // candidates: alive movers with a non-zero delta whose target rectangle is inside the map (Map.cc:455)
-__device__ __forceinline__ void movg_prep_body(const WorldView &W, int g, int i, unsigned *wanted, int slot) {
+// (starve: false when the turn phase of this step has already run starvation -- turn_prep_body)
+__device__ __forceinline__ void movg_prep_body(const WorldView &W, int g, int i, unsigned *wanted, int slot, bool starve) {
     const GroupDev &G = W.grp[g];
     const TypeDev &T = W.type[g];
-    starve_body(W, g, G, T, i, slot);
+    if (starve) starve_body(W, g, G, T, i, slot);
     if (i >= G.n) return;
     int t = -1;
     const int pend = G.pend[i];
+    const int2 fp = body_dims(W, G, T, i);
     if (!G.dead[i] && (pend & ~PEND_ARG) == PEND_MOVE) {
-        int2 d = W.delta[T.move_off + (pend & PEND_ARG)];
+        int2 d = agent_delta(W, G, i, T.move_off, pend & PEND_ARG);
         int nx = G.x[i] + d.x, ny = G.y[i] + d.y;
-        if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + T.bw < W.w && ny + T.bl < W.h) t = ny * W.w + nx;
+        if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + fp.x < W.w && ny + fp.y < W.h) t = ny * W.w + nx;
     }
     // goals that move themselves are outside the engine's scope (no shipped game gives them actions): reported, not guessed
     if (t >= 0 && T.can_absorb) { W.counters[CTR_UNSUPPORTED] = 1; t = -1; }
@@ -1320,14 +1395,14 @@ __device__ __forceinline__ void movg_prep_body(const WorldView &W, int g, int i,
     G.mv[i] = t >= 0 ? 0u : MV_FAIL;      // 0 = undecided (the packed-dependency encoding of the 1x1 path is not used here)
     if (t >= 0) {
         const int ny = t / W.w, nx = t - ny * W.w;
-        for (int by = 0; by < T.bl; by++)
-            for (int bx = 0; bx < T.bw; bx++) atomicAdd(&wanted[(ny + by) * W.w + nx + bx], 1u);
+        for (int by = 0; by < fp.y; by++)
+            for (int bx = 0; bx < fp.x; bx++) atomicAdd(&wanted[(ny + by) * W.w + nx + bx], 1u);
     }
 }
-__global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted) {
+__global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted, int starve) {
     if (attack_open(W)) return;
     if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // move rounds start
-    movg_prep_body(W, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, wanted, blockIdx.x % DEAD_SLOTS);
+    movg_prep_body(W, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, wanted, blockIdx.x % DEAD_SLOTS, starve != 0);
 }
 
 __device__ __forceinline__ void movg_sweep_body(const WorldView &W, const GroupDev *gtab, int g, int i, const unsigned *wanted, int *flagp) {
@@ -1356,14 +1431,15 @@ __device__ __forceinline__ void movg_sweep_body(const WorldView &W, const GroupD
                 const TypeDev TB = W.type[bg];
                 const unsigned key = G.key[i];
                 const int self = ref_pack(g, i), goal = r.blocker;
+                const int2 gd = body_dims(W, B, TB, bi), md = body_dims(W, G, W.type[g], i);
                 bool lost = false, unknown = false;
-                for (int bx = 0; bx < TB.bw && !lost; bx++)
-                    for (int by = 0; by < TB.bl && !lost; by++) {
+                for (int bx = 0; bx < gd.x && !lost; bx++)
+                    for (int by = 0; by < gd.y && !lost; by++) {
                         const int cx = B.x[bi] + bx, cy = B.y[bi] + by;
                         const int ty = t / W.w, tx = t - ty * W.w;
-                        const bool mine = cx >= tx && cx < tx + W.type[g].bw && cy >= ty && cy < ty + W.type[g].bl;
+                        const bool mine = cx >= tx && cx < tx + md.x && cy >= ty && cy < ty + md.y;
                         if (wanted[cy * W.w + cx] <= (mine ? 1u : 0u)) continue;   // no other candidate reaches this cell
-                        for_each_entrant(W, cx, cy, key, self, [&](int, unsigned s2) {
+                        for_each_mover_onto(W, gtab, cx, cy, key, self, [&](int, unsigned s2) {
                             if (mv_taken(s2) && mv_taken_by(s2) == goal) { lost = true; return true; }
                             if (s2 == 0) unknown = true;
                             return false;
@@ -1412,7 +1488,8 @@ __global__ void __launch_bounds__(256) k_movg_collide(WorldView W, const GroupDe
 __device__ __forceinline__ void movg_vacate_body(const WorldView &W, int g, int i) {
     const GroupDev &G = W.grp[g];
     if (G.drank_a[i] < 0 || !(G.mv[i] == MV_OK || mv_taken(G.mv[i]))) return;
-    cells_clear(W, G.x[i], G.y[i], W.type[g].bw, W.type[g].bl);
+    const int2 fp = body_dims(W, G, W.type[g], i);
+    cells_clear(W, G.x[i], G.y[i], fp.x, fp.y);
 }
 __global__ void __launch_bounds__(256) k_movg_vacate(WorldView W) {
     if (step_open(W)) return;
@@ -1425,13 +1502,134 @@ __device__ __forceinline__ void movg_enter_body(const WorldView &W, int g, int i
     const int c = G.drank_a[i];
     if (c < 0 || G.mv[i] != MV_OK) return;
     const int ny = c / W.w, nx = c - ny * W.w;
-    body_fill(W, nx, ny, W.type[g].bw, W.type[g].bl, ref_pack(g, i));
+    const int2 fp = body_dims(W, G, W.type[g], i);
+    body_fill(W, nx, ny, fp.x, fp.y, ref_pack(g, i));
     G.x[i] = nx; G.y[i] = ny;
 }
 __global__ void __launch_bounds__(256) k_movg_enter(WorldView W) {
     if (step_open(W)) return;
     const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < W.grp[g].n) movg_enter_body(W, g, i);
+}
+
+// ------------------------------------------------------------------------------------------------ turn, generic bodies
+// turn_mode with bodies larger than one cell (GridWorld.cc:544-571, Map::do_turn Map.cc:361-406).  A body turns about its
+// reference corner (turn_x/y_offset are 0, AgentType.cc:108: the corner cell stays where it is) and its footprint is
+// transposed; the turn happens iff the new rectangle is inside the map and, at the turner's place in the order (stripe lists,
+// then the boundary list, each in insertion order -- the same key as for moves), free of everybody but itself.  Like the
+// generic move: every cell of the new rectangle outside the own body must be free of its phase-start occupant (which must
+// have turned away earlier, successfully, without covering the cell again) and of every lower-key turner that turned onto
+// it.  The recursion only looks at lower keys; sweeps decide whoever has its dependencies decided.
+// drank_a: top-left cell of the new rectangle (turn candidates), -1 otherwise;  mv: 0 undecided, MV_OK, MV_FAIL.
+__device__ __forceinline__ int turned_dir(int dir, int pend) { return (dir + (pend & PEND_ARG) * 2 - 1 + DIR_NUM) % DIR_NUM; }
+
+__device__ __forceinline__ void turn_prep_body(const WorldView &W, int g, int i, unsigned *wanted, int slot) {
+    const GroupDev &G = W.grp[g];
+    const TypeDev &T = W.type[g];
+    starve_body(W, g, G, T, i, slot);        // starvation comes before the turns (GridWorld.cc:519-542)
+    if (i >= G.n) return;
+    int t = -1;
+    const int pend = G.pend[i];
+    if (!G.dead[i] && (pend & ~PEND_ARG) == PEND_TURN) {
+        const int dir = G.dir[i], ndir = turned_dir(dir, pend);
+        int rx, ry, nx, ny;
+        saved_to_real(dir, T.bw, T.bl, G.x[i], G.y[i], rx, ry);
+        real_to_saved(ndir, T.bw, T.bl, rx, ry, nx, ny);
+        const int2 nd = dims_for_dir(T, ndir);
+        if (nx >= 0 && ny >= 0 && nx + nd.x < W.w && ny + nd.y < W.h) {   // is_blank_area's bounds (Map.cc:455)
+            t = ny * W.w + nx;
+            for (int by = 0; by < nd.y; by++)
+                for (int bx = 0; bx < nd.x; bx++) atomicAdd(&wanted[(ny + by) * W.w + nx + bx], 1u);
+        }
+    }
+    G.drank_a[i] = t;
+    G.mv[i] = t >= 0 ? 0u : MV_FAIL;
+}
+
+__device__ __forceinline__ void turn_sweep_body(const WorldView &W, const GroupDev *gtab, int g, int i, const unsigned *wanted, int *flagp) {
+    const GroupDev &G = W.grp[g];
+    const TypeDev &T = W.type[g];
+    const int t = G.drank_a[i];
+    if (t < 0 || G.mv[i] != 0) return;
+    const unsigned key = G.key[i];
+    const int self = ref_pack(g, i);
+    const int dir = G.dir[i];
+    const int2 od = dims_for_dir(T, dir), nd = make_int2(od.y, od.x);
+    const int ox = G.x[i], oy = G.y[i], ny = t / W.w, nx = t - ny * W.w;
+    bool blocked = false, unknown = false;
+    for (int by = 0; by < nd.y && !blocked; by++)
+        for (int bx = 0; bx < nd.x && !blocked; bx++) {
+            const int cx = nx + bx, cy = ny + by, c = cy * W.w + cx;
+            if (cx >= ox && cx < ox + od.x && cy >= oy && cy < oy + od.y) continue;     // my own body
+            const int o = W.occ[c];
+            if (o == OCC_WALL || o == OCC_FOOD) { blocked = true; break; }
+            if (o >= 0) {                      // the phase-start occupant: gone iff it turned away before me
+                const GroupDev &X = gtab[ref_group(o)];
+                const int xi = ref_index(o), xt = X.drank_a[xi];
+                if (!((X.pend[xi] & ~PEND_ARG) == PEND_TURN && xt >= 0 && X.key[xi] < key)) { blocked = true; break; }
+                const unsigned st = X.mv[xi];
+                if (st == MV_FAIL) { blocked = true; break; }
+                const int2 xd = dims_for_dir(W.type[ref_group(o)], X.dir[xi]);            // (its footprint now; the new one is transposed)
+                const int ty = xt / W.w, tx = xt - ty * W.w;
+                const bool covers_again = cx >= tx && cx < tx + xd.y && cy >= ty && cy < ty + xd.x;
+                if (st == MV_OK) { if (covers_again) { blocked = true; break; } }
+                else unknown = true;
+                // (a decided turner has ALREADY re-laid its body when the sweeps of a later launch read `dir`: decisions are
+                //  only committed after the sweeps converge -- turn_vacate / turn_enter -- so `dir` is the phase-start one here)
+            }
+            if (wanted[c] > 1)                 // somebody else's new rectangle covers the cell too
+                for_each_candidate_onto(W, gtab, cx, cy, key, self, PEND_TURN, true, [&](int e, unsigned st) {
+                    if (e == o) return false;                                   // (the occupant was dealt with above)
+                    if (st == MV_OK) { blocked = true; return true; }
+                    if (st == 0) unknown = true;
+                    return false;
+                });
+        }
+    if (blocked) G.mv[i] = MV_FAIL;
+    else if (!unknown) G.mv[i] = MV_OK;
+    else if (flagp) *flagp = 1;
+}
+
+__device__ __forceinline__ void turn_vacate_body(const WorldView &W, int g, int i) {
+    const GroupDev &G = W.grp[g];
+    if (G.drank_a[i] < 0 || G.mv[i] != MV_OK) return;
+    const int2 od = dims_for_dir(W.type[g], G.dir[i]);
+    cells_clear(W, G.x[i], G.y[i], od.x, od.y);
+}
+// (wanted: the counters of the cells this candidate asked for go back to zero -- the move phase uses the same array)
+__device__ __forceinline__ void turn_enter_body(const WorldView &W, int g, int i, unsigned *wanted) {
+    const GroupDev &G = W.grp[g];
+    const int t = G.drank_a[i];
+    if (t < 0) return;
+    const int2 od = dims_for_dir(W.type[g], G.dir[i]), nd = make_int2(od.y, od.x);
+    const int ny = t / W.w, nx = t - ny * W.w;
+    if (wanted)
+        for (int by = 0; by < nd.y; by++)
+            for (int bx = 0; bx < nd.x; bx++) wanted[(ny + by) * W.w + nx + bx] = 0u;
+    if (G.mv[i] != MV_OK) return;
+    body_fill(W, nx, ny, nd.x, nd.y, ref_pack(g, i));
+    G.dir[i] = turned_dir(G.dir[i], G.pend[i]);
+    G.x[i] = nx; G.y[i] = ny;
+}
+__global__ void __launch_bounds__(256) k_turn_prep(WorldView W, unsigned *wanted) {
+    if (attack_open(W)) return;
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;
+    turn_prep_body(W, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, wanted, blockIdx.x % DEAD_SLOTS);
+}
+__global__ void __launch_bounds__(256) k_turn_sweep(WorldView W, const GroupDev *gtab, const unsigned *wanted, int flag) {
+    if (attack_open(W)) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.grp[g].n) turn_sweep_body(W, gtab, g, i, wanted, flag >= 0 ? &W.counters[flag] : nullptr);
+}
+__global__ void __launch_bounds__(256) k_turn_vacate(WorldView W) {
+    if (attack_open(W)) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.grp[g].n) turn_vacate_body(W, g, i);
+}
+__global__ void __launch_bounds__(256) k_turn_enter(WorldView W) {
+    if (attack_open(W)) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.grp[g].n) turn_enter_body(W, g, i, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ reward rules
@@ -1687,7 +1885,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_clear_compact(WorldView W, Cle
                    if (G.dir) D.dir[r] = G.dir[i];
                    D.last_reward[r] = G.next_reward[i];
                    D.next_reward[r] = step_reward;
-                   body_fill(W, x, y, bw, bl, ref_pack(g, r));
+                   { const int2 fp = W.turn_mode ? dims_for_dir(W.type[g], G.dir[i]) : make_int2(bw, bl); body_fill(W, x, y, fp.x, fp.y, ref_pack(g, r)); }
                },
                G.n, block_prefix(sums + A.sums_off[g], blockIdx.x));
 }
@@ -1717,7 +1915,7 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int 
                    if (G.dir) D.dir[r] = G.dir[i];
                                     D.last_reward[r] = G.next_reward[i];
                                     D.next_reward[r] = step_reward;
-                                    body_fill(W, x, y, bw, bl, ref_pack(g, r));
+                                    { const int2 fp = W.turn_mode ? dims_for_dir(W.type[g], G.dir[i]) : make_int2(bw, bl); body_fill(W, x, y, fp.x, fp.y, ref_pack(g, r)); }
                                 },
                                 G.n, 0);
     // every read of the in-place arrays is done (solo_rank ends with a barrier): reset them for the survivors
@@ -1797,7 +1995,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
             if (tid < S.nt_eval)
                 for (int g = 0; g < NG; g++)
                     for (int i = tid, n = W.grp[g].n; i < n; i += S.nt_eval)
-                        attack_eval_body(W, gtab, ttab, g, i, rounds_attack, S.hit, s_rank, s_ref, S.nt_eval, tid, flag);
+                        attack_eval_body(W, gtab, ttab, g, i, rounds_attack, S.hit, s_rank, s_ref, S.nt_eval, tid, flag, S.kmax);
             __syncthreads();
             const int changed = *flag;
             if (!changed) break;
@@ -1811,8 +2009,8 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
         SOLO_EACH(g, i) {
             const int pend = W.grp[g].pend[i];
             if ((pend & ~PEND_ARG) == PEND_ATTACK) {
-                const int2 d = agent_delta(W, W.grp[g], i, W.type[g].attack_off, pend & PEND_ARG);
-                const int tx = W.grp[g].x[i] + d.x, ty = W.grp[g].y[i] + d.y;
+                const int2 tc = attack_target(W, W.grp[g], W.type[g], i, pend & PEND_ARG);
+                const int tx = tc.x, ty = tc.y;
                 if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) S.hit[ty * W.w + tx] = 0u;
             }
         }
@@ -1848,7 +2046,27 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
         __syncthreads();
         SOLO_MARK();   // 13: commit
     } else {
-        SOLO_EACH_UNIFORM(g, i) movg_prep_body(W, g, i, S.hit, 0);
+        if (W.turn_mode) {   // starvation, then the turns of this step (bodies re-lay their footprints), then the moves
+            SOLO_EACH_UNIFORM(g, i) turn_prep_body(W, g, i, S.hit, 0);
+            if (tid < 3) s_flags[tid] = 0;
+            __syncthreads();
+            int rounds_turn = 0;
+            while (true) {
+                rounds_turn++;
+                int *flag = &s_flags[rounds_turn % 3];
+                if (tid == 0) s_flags[(rounds_turn + 1) % 3] = 0;
+                SOLO_EACH(g, i) turn_sweep_body(W, gtab, g, i, S.hit, flag);
+                __syncthreads();
+                const int open = *flag;
+                if (!open) break;
+                if (rounds_turn > S.max_rounds) { error = 3; break; }
+            }
+            SOLO_EACH(g, i) turn_vacate_body(W, g, i);
+            __syncthreads();
+            SOLO_EACH(g, i) turn_enter_body(W, g, i, S.hit);
+            __syncthreads();
+        }
+        SOLO_EACH_UNIFORM(g, i) movg_prep_body(W, g, i, S.hit, 0, !W.turn_mode);
         if (tid < 3) s_flags[tid] = 0;
         __syncthreads();
         while (true) {
@@ -1906,8 +2124,9 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
             if (!W.any_multicell) W.claim[t] = CLAIM_NONE;
             else {
                 const int ny = t / W.w, nx = t - ny * W.w;
-                for (int by = 0; by < T.bl; by++)
-                    for (int bx = 0; bx < T.bw; bx++) S.hit[(ny + by) * W.w + nx + bx] = 0u;
+                const int2 fp = body_dims(W, G, T, i);
+                for (int by = 0; by < fp.y; by++)
+                    for (int bx = 0; bx < fp.x; bx++) S.hit[(ny + by) * W.w + nx + bx] = 0u;
             }
         }
         if (W.live_paint) repaint_body(W, G, T, g, i);
@@ -1950,7 +2169,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
                    if (G.dir) D.dir[r] = G.dir[i];
                                             D.last_reward[r] = G.next_reward[i];
                                             D.next_reward[r] = step_reward;
-                                            body_fill(W, x, y, bw, bl, ref_pack(g, r));
+                                            { const int2 fp = W.turn_mode ? dims_for_dir(W.type[g], G.dir[i]) : make_int2(bw, bl); body_fill(W, x, y, fp.x, fp.y, ref_pack(g, r)); }
                                         },
                                         G.n, 0);
             for (int r = tid; r < alive; r += SOLO_STEP_THREADS) { G.dead[r] = 0; G.last_op[r] = OP_NULL; G.op_obj[r] = -1; G.pend[r] = PEND_NONE; }
@@ -2004,6 +2223,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
             S.rec->unsupported = __hip_atomic_load(&W.counters[CTR_UNSUPPORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             S.rec->pack_overflow = __hip_atomic_load(&W.counters[CTR_PACK_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             S.rec->bad_action = __hip_atomic_load(&W.counters[CTR_BAD_ACTION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            S.rec->hit_overflow = __hip_atomic_load(&W.counters[CTR_HIT_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             S.rec->error = error;
             S.rec->rounds_attack = rounds_attack; S.rec->rounds_move = rounds_move;
             S.rec->n_marks = n_marks < 40 ? n_marks : 40;
@@ -2079,7 +2299,7 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_clear_solo_all(WorldView W, Cl
                    if (G.dir) D.dir[r] = G.dir[i];
                                             D.last_reward[r] = G.next_reward[i];
                                             D.next_reward[r] = step_reward;
-                                            body_fill(W, x, y, bw, bl, ref_pack(g, r));
+                                            { const int2 fp = W.turn_mode ? dims_for_dir(W.type[g], G.dir[i]) : make_int2(bw, bl); body_fill(W, x, y, fp.x, fp.y, ref_pack(g, r)); }
                                         },
                                         G.n, 0);
             // every read of the in-place arrays is done (solo_rank ends with a barrier): reset them for the survivors
@@ -2244,10 +2464,23 @@ void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     hipLaunchKernelGGL(k_move_init, g, dim3(256), 0, s, W);
 }
 // the per-cell "wanted" counters live in the claim array (unused by the generic path otherwise)
-void launch_movg_prep(hipStream_t s, const WorldView &W) {
+void launch_movg_prep(hipStream_t s, const WorldView &W, bool starve) {
     const size_t words = (size_t)W.w * W.h;
     hipLaunchKernelGGL(k_fill32_gated, dim3((unsigned)std::min<size_t>((words + 255) / 256, 2048)), dim3(256), 0, s, W, (unsigned *)W.claim, 0u, words);
-    hipLaunchKernelGGL(k_movg_prep, grid_all(W, 256), dim3(256), 0, s, W, (unsigned *)W.claim);
+    hipLaunchKernelGGL(k_movg_prep, grid_all(W, 256), dim3(256), 0, s, W, (unsigned *)W.claim, starve ? 1 : 0);
+}
+// turn_mode with generic bodies: starvation + turn candidates, sweeps (host-checked), commit
+void launch_turn_prep(hipStream_t s, const WorldView &W) {
+    const size_t words = (size_t)W.w * W.h;
+    hipLaunchKernelGGL(k_fill32_gated, dim3((unsigned)std::min<size_t>((words + 255) / 256, 2048)), dim3(256), 0, s, W, (unsigned *)W.claim, 0u, words);
+    hipLaunchKernelGGL(k_turn_prep, grid_all(W, 256), dim3(256), 0, s, W, (unsigned *)W.claim);
+}
+void launch_turn_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag) {
+    hipLaunchKernelGGL(k_turn_sweep, grid_all(W, 256), dim3(256), 0, s, W, gtab, (const unsigned *)W.claim, flag);
+}
+void launch_turn_apply(hipStream_t s, const WorldView &W) {
+    hipLaunchKernelGGL(k_turn_vacate, grid_all(W, 256), dim3(256), 0, s, W);
+    hipLaunchKernelGGL(k_turn_enter, grid_all(W, 256), dim3(256), 0, s, W);
 }
 void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag) {
     hipLaunchKernelGGL(k_movg_sweep, grid_all(W, 256), dim3(256), 0, s, W, gtab, (const unsigned *)W.claim, flag);

@@ -117,7 +117,10 @@ void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab
 void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag);
 void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev);
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);   // starve / recover, then the move candidates
-void launch_movg_prep(hipStream_t s, const WorldView &W);
+void launch_movg_prep(hipStream_t s, const WorldView &W, bool starve);
+void launch_turn_prep(hipStream_t s, const WorldView &W);
+void launch_turn_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag);
+void launch_turn_apply(hipStream_t s, const WorldView &W);
 void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag);
 void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag);

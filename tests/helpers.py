@@ -460,7 +460,7 @@ def render_episode(lib, out_dir, steps=6):
 
 
 _ATTACK_COUNT = {0: 0, 1: 4, 1.5: 8, 2: 12, 2.5: 20}
-TURN_MULTICELL_ON_ENGINE = False      # turn_mode with bodies larger than one cell / goals: refused by the engine so far
+TURN_MULTICELL_ON_ENGINE = True       # turn_mode with bodies larger than one cell / goals (the generic turn phase)
 
 
 def fuzz_scenario(seed):
@@ -783,7 +783,12 @@ def scenarios():
         Scenario("tri_turn", ("tri", 60, 41), 0, place=[rnd(0, 400), rnd(1, 300), rnd(2, 350)], walls=60, steps=25, action_seed=48,
                  settings={"turn_mode": True}),
         Scenario("bodies_turn", ("bodies", 48, 37), 0, walls=40, place=[rnd(0, 50), rnd(1, 80), rnd(2, 150),
-                 (0, "fill", {"pos": (30, 20), "size": (8, 9), "dir": 2})], steps=25, action_seed=43, settings={"turn_mode": True}, engine=False),
+                 (0, "fill", {"pos": (30, 20), "size": (8, 9), "dir": 2})], steps=25, action_seed=43, settings={"turn_mode": True}),
+        Scenario("pursuit_turn", "pursuit", 36, walls=40, place=[rnd(0, 50), rnd(1, 100)], steps=30, action_seed=49, settings={"turn_mode": True}),
+        Scenario("bodies_turn_large", ("bodies", 120, 101), 0, walls=250, place=[rnd(0, 450), rnd(1, 800), rnd(2, 1300)], steps=10, action_seed=50,
+                 settings={"turn_mode": True}),
+        Scenario("arrange_turn", ("arrange", 40, True), 0, place=[rnd(0, 200), rnd(1, 300), rnd(2, 35)], walls=30, steps=25, acting=[1, 2], action_seed=51,
+                 settings={"turn_mode": True}),
         Scenario("battle_one_side", "battle", 12, place=[rnd(0, 60), rnd(1, 3)], steps=40, action_seed=14,
                  over={"small": {"damage": 12}}),
     ]

@@ -44,7 +44,7 @@ def test_fullsize_matches_reference_digest_and_oracle(name):
 # (read once per process) and must reproduce the oracle on dense scenarios: long attack chains, conga lines of movers,
 # multi-cell bodies, goals, three groups.
 DENSE = ["battle_brawl", "battle_brawl_big", "battle_brawl_dense_big", "battle_fill_full", "bodies_large", "tri_rect_large",
-         "arrange_live", "battle_food"]
+         "arrange_live", "battle_food", "battle_turn_large", "bodies_turn", "bodies_turn_large", "arrange_turn"]
 VARIANTS = {
     "checked_step": {"MAGENT_CHECKED_STEP": "1"},
     "attack_runs_out": {"MAGENT_OPT_ATTACK_PAIRS": "0"},
@@ -70,3 +70,14 @@ def test_fuzz_rule_search_on_the_host_path():
     out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "120"], env=env,
                          capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0 and "120 seeds, 0 failures" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
+
+
+def test_fuzz_turn_mode():
+    """turn_mode (agents face a direction; moves, attack offsets and the observation window live in the agent's frame; bodies larger
+    than one cell re-lay their footprint when they turn -- an order-dependent fixed point of its own): random games, 60 % of them with
+    turn_mode on (FUZZ_TURN=2), on both step drivers, HIP == oracle"""
+    for extra in ({}, {"MAGENT_SOLO_STEP": "0"}):
+        env = dict(os.environ, OMP_NUM_THREADS="1", FUZZ_TURN="2", **extra)
+        out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "150"], env=env,
+                             capture_output=True, text=True, timeout=1200)
+        assert out.returncode == 0 and "150 seeds, 0 failures" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
