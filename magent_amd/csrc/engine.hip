@@ -65,6 +65,30 @@ void HostRange::circle(float radius, float inner_radius, int parity) {
     x2 = y2 = width - center - 1;
 }
 
+// SectorRange of the reference (Range.h:104-144): the rectangle in front of the agent -- rows -height .. -1 of its frame -- under
+// a sector mask; float / double mix and constants as there (the window shape and the in-range test are part of the observable result)
+void HostRange::sector(float angle, float radius, int parity) {
+    static const double PI = 3.1415926536;
+    height = (int)(radius + 0.5);
+    width = (int)(2 * radius * std::sin(angle / 2 * (PI / 180)) + 0.5);
+    if (width % 2 != parity) width--;
+    if (width < 0 || (width == 0 && height > 0)) fatal("sector range (angle %g, radius %g) too narrow: the reference allocates a non-positive array here", angle, radius);
+    in.assign((size_t)width * height, 0);
+    dx.clear(); dy.clear(); count = 0;
+    const double eps = 0.00001;
+    for (int i = 0; i < height; i++)
+        for (int j = 0; j < width; j++) {
+            const double dis_x = std::fabs(j - (width - 1) / 2.0), dis_y = std::fabs(height - i);
+            const double dis = std::sqrt(dis_x * dis_x + dis_y * dis_y);
+            if (dis < radius + 0.2 + eps && dis_x / dis_y < std::tan(angle / 2 * PI / 180) + eps) {
+                in[(size_t)i * width + j] = 1;
+                dx.push_back(j - width / 2); dy.push_back(i - height); count++;
+            }
+        }
+    x1 = -width / 2; y1 = -height;
+    x2 = (width - 1) / 2; y2 = -1;
+}
+
 // ------------------------------------------------------------------------------------------------ profiling
 struct Env::ProfScope {
     Env &e; Env::ProfSlot *slot = nullptr; hipEvent_t a{}, b{};
@@ -312,16 +336,18 @@ void Env::register_agent_type(const char *name, int n, const char **keys, float 
         } else fatal("invalid agent config in AgentType::AgentType : %s", keys[i]);
     }
     if (t.width < 1 || t.length < 1 || t.width > 16 || t.length > 16) fatal("agent type %s: body %dx%d out of range", name, t.width, t.length);
-    // A type registered without an attack range keeps the defaults attack_radius = 0, attack_angle = 0 and gets
-    // SectorRange(0, 0): height = (int)(0 + 0.5) = 0 rows, i.e. no attack action at all (Range.h:106-139,
-    // AgentType.cc:95-102; examples/train_trans.py).  Real sectors stay outside the hot-path scope.
-    const bool no_attack = t.attack_angle < 180 && (int)(t.attack_radius + 0.5) == 0;
-    if (t.view_angle < 180 || (t.attack_angle < 180 && !no_attack)) fatal("agent type %s: sector ranges are outside the hot-path scope", name);
-    if (std::fabs(t.view_angle - 360) > 1e-5 || (!no_attack && std::fabs(t.attack_angle - 360) > 1e-5))
-        fatal("only supports ranges with angle = 360, when angle > 180.");
+    // AgentType.cc:84-104: a circle for angle 360, a sector below 180.  (A type registered without an attack range keeps the
+    // defaults attack_radius = 0, attack_angle = 0 and gets SectorRange(0, 0): 0 rows, no attack action -- examples/train_trans.py)
     const int parity = t.width % 2;
-    t.view.circle(t.view_radius, 0, parity);
-    if (!no_attack) t.attack.circle(t.attack_radius, t.width / 2.0f, parity);
+    if (t.view_angle >= 180) {
+        if (std::fabs(t.view_angle - 360) > 1e-5) fatal("only supports ranges with angle = 360, when angle > 180.");
+        t.view.circle(t.view_radius, 0, parity);
+    } else t.view.sector(t.view_angle, t.view_radius, parity);
+    if (t.attack_angle >= 180) {
+        if (std::fabs(t.attack_angle - 360) > 1e-5) fatal("only supports ranges with angle = 360, when angle > 180.");
+        t.attack.circle(t.attack_radius, t.width / 2.0f, parity);
+    } else t.attack.sector(t.attack_angle, t.attack_radius, parity);
+    if (t.view.width < 1 || t.view.height < 1) fatal("agent type %s: empty view range", name);
     t.move.circle(t.speed, 0, 1);
     t.view_x_offset = t.att_x_offset = t.width / 2;
     t.view_y_offset = t.att_y_offset = t.length / 2;
@@ -1854,7 +1880,10 @@ void Env::info_host(int g, const char *name, void *buf) {
         need_group();
         const HostType &t = *groups[g].type;
         std::fill(ib, ib + t.view.height * t.view.width, -1);
-        for (int i = 0; i < t.attack.count; i++) ib[(t.attack.dy[i] - t.view.y1) * t.view.width + (t.attack.dx[i] - t.view.x1)] = i;
+        for (int i = 0; i < t.attack.count; i++) {   // (an offset outside the view window has no cell in the table: the reference writes out of bounds there)
+            const int vy = t.attack.dy[i] - t.view.y1, vx = t.attack.dx[i] - t.view.x1;
+            if (vy >= 0 && vy < t.view.height && vx >= 0 && vx < t.view.width) ib[vy * t.view.width + vx] = i;
+        }
         return;
     }
     if (k == "groups_info") {

@@ -35,6 +35,7 @@ struct HostRange {
     std::vector<unsigned char> in;
     std::vector<int> dx, dy;
     void circle(float radius, float inner_radius, int parity);
+    void sector(float angle, float radius, int parity);
 };
 
 struct HostType {

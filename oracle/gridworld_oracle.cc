@@ -69,6 +69,28 @@ struct Range {
         x1 = y1 = -center;
         x2 = y2 = width - center - 1;
     }
+    // Range.h:104-144 (SectorRange): a rectangle in FRONT of the agent (rows -height .. -1) with a sector mask
+    void sector(float angle, float radius, int parity) {
+        static const double PI = 3.1415926536;   // Range.h:16
+        height = (int)(radius + 0.5);
+        width = (int)(2 * radius * sin(angle / 2 * (PI / 180)) + 0.5);
+        if (width % 2 != parity) width--;
+        if (width < 0 || (width == 0 && height > 0)) fatal("sector range too narrow: the reference allocates a non-positive array here");
+        in.assign((size_t)width * height, 0);
+        dx.clear(); dy.clear(); count = 0;
+        const double eps = 0.00001;
+        for (int i = 0; i < height; i++)
+            for (int j = 0; j < width; j++) {
+                double dis_x = std::fabs(j - (width - 1) / 2.0), dis_y = std::fabs(height - i);
+                double dis = sqrt(dis_x * dis_x + dis_y * dis_y);
+                if (dis < radius + 0.2 + eps && dis_x / dis_y < tan(angle / 2 * PI / 180) + eps) {
+                    in[i * width + j] = 1;
+                    dx.push_back(j - width / 2); dy.push_back(i - height); count++;
+                }
+            }
+        x1 = -width / 2; y1 = -height;
+        x2 = (width - 1) / 2; y2 = -1;
+    }
 };
 
 // AgentType.cc:30-123
@@ -271,14 +293,16 @@ int gridworld_register_agent_type(void *game, const char *name, int n, const cha
         else fatal("invalid agent config %s", keys[i]);
     }
     int parity = t.width % 2;
-    // A type registered without an attack range keeps the defaults attack_radius = 0, attack_angle = 0 and gets
-    // SectorRange(0, 0): height = (int)(0 + 0.5) = 0 rows, i.e. no attack action at all (Range.h:106-139,
-    // AgentType.cc:95-102; examples/train_trans.py).  Real sectors stay outside the hot-path scope.
-    const bool no_attack = t.attack_angle < 180 && (int)(t.attack_radius + 0.5) == 0;
-    if (t.view_angle < 180 || (t.attack_angle < 180 && !no_attack)) fatal("sector ranges are outside the hot-path scope");
-    if (std::fabs(t.view_angle - 360) > 1e-5 || (!no_attack && std::fabs(t.attack_angle - 360) > 1e-5)) fatal("only angle = 360 is supported");
-    t.view.circle(t.view_radius, 0, parity);
-    if (!no_attack) t.attack.circle(t.attack_radius, t.width / 2.0f, parity);
+    // (a type registered without an attack range keeps the defaults attack_radius = 0, attack_angle = 0 and gets
+    // SectorRange(0, 0): 0 rows, no attack action at all -- examples/train_trans.py)
+    if (t.view_angle >= 180) {      // AgentType.cc:86-104
+        if (std::fabs(t.view_angle - 360) > 1e-5) fatal("only supports ranges with angle = 360, when angle > 180.");
+        t.view.circle(t.view_radius, 0, parity);
+    } else t.view.sector(t.view_angle, t.view_radius, parity);
+    if (t.attack_angle >= 180) {
+        if (std::fabs(t.attack_angle - 360) > 1e-5) fatal("only supports ranges with angle = 360, when angle > 180.");
+        t.attack.circle(t.attack_radius, t.width / 2.0f, parity);
+    } else t.attack.sector(t.attack_angle, t.attack_radius, parity);
     t.move.circle(t.speed, 0, 1);
     t.view_x_offset = t.att_x_offset = t.width / 2;
     t.view_y_offset = t.att_y_offset = t.length / 2;

@@ -244,7 +244,26 @@ def custom_search(map_size):
     return cfg
 
 
-CUSTOM = {"search": custom_search, "rules": custom_rules, "arrange": custom_arrange, "duo": custom_duo, "trans": custom_trans, "tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
+def custom_sector(map_w, map_h):
+    """sector ranges (Range.h:104-144): the view is a wedge in front of the agent (a window that does not contain the agent itself,
+    wider than high or higher than wide), attacks reach forward only; a 2x2 body among them.  With turn_mode the wedge turns with
+    the agent; without it everybody looks north"""
+    cfg = gw.Config()
+    cfg.set({"map_width": map_w, "map_height": map_h, "minimap_mode": True, "embedding_size": 6})
+    scout = cfg.register_agent_type("scout", dict(width=1, length=1, hp=5, speed=2, view_range=gw.SectorRange(7, 100), attack_range=gw.SectorRange(2.5, 120),
+                                                  damage=2, step_recover=0.1, step_reward=-0.01, kill_reward=2, dead_penalty=-0.3, attack_penalty=-0.05))
+    guard = cfg.register_agent_type("guard", dict(width=2, length=2, hp=9, speed=1, view_range=gw.SectorRange(4, 60), attack_range=gw.CircleRange(2),
+                                                  damage=1.5, step_recover=-0.05, kill_supply=1, attack_in_group=1))
+    lurker = cfg.register_agent_type("lurker", dict(width=1, length=1, hp=3, speed=1, view_range=gw.CircleRange(3), attack_range=gw.SectorRange(3, 40),
+                                                    damage=3, dead_penalty=-1))
+    g0, g1, g2 = cfg.add_group(scout), cfg.add_group(guard), cfg.add_group(lurker)
+    a, b, c = gw.AgentSymbol(g0, "any"), gw.AgentSymbol(g1, "any"), gw.AgentSymbol(g2, "any")
+    cfg.add_reward_rule(gw.Event(a, "attack", b), receiver=[a, b], value=[0.25, -0.125])
+    cfg.add_reward_rule(gw.Event(c, "kill", a), receiver=c, value=1.5)
+    return cfg
+
+
+CUSTOM = {"sector": custom_sector, "search": custom_search, "rules": custom_rules, "arrange": custom_arrange, "duo": custom_duo, "trans": custom_trans, "tri": custom_tri, "chase": custom_chase, "quad": custom_quad, "bodies": custom_bodies}
 
 
 class Scenario(object):
@@ -460,6 +479,25 @@ def render_episode(lib, out_dir, steps=6):
 
 
 _ATTACK_COUNT = {0: 0, 1: 4, 1.5: 8, 2: 12, 2.5: 20}
+
+
+def sector_shape(radius, angle, parity):
+    """(width, height, count) of the reference's SectorRange (Range.h:104-144), float32 inputs as the C-ABI passes them"""
+    import math
+    PI = 3.1415926536
+    radius, angle = np.float32(radius), np.float32(angle)
+    height = int(float(radius) + 0.5)
+    width = int(float(np.float32(2) * radius) * math.sin(float(angle / np.float32(2)) * (PI / 180)) + 0.5)
+    if width % 2 != parity:
+        width -= 1
+    count = 0
+    for i in range(height):
+        for j in range(max(width, 0)):
+            dx, dy = abs(j - (width - 1) / 2.0), abs(height - i)
+            if math.sqrt(dx * dx + dy * dy) < float(radius) + 0.2 + 0.00001 and dx / dy < math.tan(float(angle / np.float32(2)) * PI / 180) + 0.00001:
+                count += 1
+    return width, height, count
+
 TURN_MULTICELL_ON_ENGINE = True       # turn_mode with bodies larger than one cell / goals (the generic turn phase)
 
 
@@ -489,10 +527,24 @@ def fuzz_scenario(seed):
                               kill_supply=float(rs.choice([0, 0, 0, 2.5, 8])), attack_in_group=int(rs.rand() < 0.3),
                               step_reward=frac(-0.25, 0.25), kill_reward=frac(0, 5), dead_penalty=frac(-2, 0),
                               attack_penalty=frac(-0.5, 0)))
+        # FUZZ_SECTOR=1: sector ranges (a wedge in front of the agent) for some views and attacks
+        for t in specs:
+            t["n_attack"] = _ATTACK_COUNT[t["attack_range"]]
+            if os.environ.get("FUZZ_SECTOR", "0") == "1":
+                parity = t["width"] % 2
+                if rs.rand() < 0.35:
+                    r, a = float(rs.choice([3, 4, 5, 6, 7])), float(rs.choice([40, 60, 90, 120, 150]))
+                    if sector_shape(r, a, parity)[0] >= 1:
+                        t["view_sector"] = (r, a)
+                if rs.rand() < 0.35:
+                    r, a = float(rs.choice([1, 1.5, 2, 2.5, 3])), float(rs.choice([40, 60, 90, 120, 150]))
+                    wd, ht, cnt = sector_shape(r, a, parity)
+                    if wd >= 1:
+                        t["attack_sector"], t["n_attack"] = (r, a), cnt
         # engine limits: the attack offsets of all groups share a 32-bit word; hit lists are bounded
-        if sum(_ATTACK_COUNT[t["attack_range"]] for t in specs) > 32:
+        if sum(t["n_attack"] for t in specs) > 32:
             continue
-        kmax = max(t["width"] * t["length"] * sum(_ATTACK_COUNT[a["attack_range"]] for j, a in enumerate(specs)
+        kmax = max(t["width"] * t["length"] * sum(a["n_attack"] for j, a in enumerate(specs)
                                                   if j != i or a["attack_in_group"]) for i, t in enumerate(specs))
         if kmax * (4 if turn_mode else 1) <= 256 and all(max(t["width"], t["length"]) + 2 < min(w, h) for t in specs):
             break
@@ -603,7 +655,10 @@ def fuzz_scenario(seed):
         names = []
         for g, t in enumerate(specs):
             t = dict(t)
-            t["view_range"], t["attack_range"] = gw.CircleRange(t["view_range"]), gw.CircleRange(t["attack_range"])
+            t["view_range"] = gw.SectorRange(*t["view_sector"]) if "view_sector" in t else gw.CircleRange(t["view_range"])
+            t["attack_range"] = gw.SectorRange(*t["attack_sector"]) if "attack_sector" in t else gw.CircleRange(t["attack_range"])
+            for k in ("view_sector", "attack_sector", "n_attack"):
+                t.pop(k, None)
             names.append(cfg.register_agent_type("t%d" % g, t))
         hs = [cfg.add_group(n) for n in names]
         for a, op, b, who, vals in rules:
@@ -770,6 +825,11 @@ def scenarios():
                  over={"big": {"food_supply": 6, "eat_ability": 2}, "mid": {"food_supply": 0.05, "eat_ability": 0.5}, "tiny": {"food_supply": 1, "eat_ability": 3}}),
         Scenario("rules_mix", ("rules", 30), 0, place=[rnd(0, 140), rnd(1, 140), rnd(2, 25)], walls=20, steps=30, action_seed=40),
         Scenario("rules_mix_large", ("rules", 110), 0, place=[rnd(0, 2500), rnd(1, 2500), rnd(2, 300)], steps=8, action_seed=41),
+        Scenario("sector", ("sector", 44, 37), 0, walls=40, place=[rnd(0, 150), rnd(1, 40), rnd(2, 120)], steps=25, action_seed=52),
+        Scenario("sector_turn", ("sector", 50, 41), 0, walls=50, place=[rnd(0, 180), rnd(1, 45), rnd(2, 150)], steps=25, action_seed=53,
+                 settings={"turn_mode": True}),
+        Scenario("sector_turn_large", ("sector", 130, 105), 0, walls=300, place=[rnd(0, 1800), rnd(1, 350), rnd(2, 1500)], steps=8, action_seed=54,
+                 settings={"turn_mode": True}),
         Scenario("rules_search", ("search", 26), 0, place=[rnd(0, 60), rnd(1, 60), (2, "custom", {"pos": [(5, 3), (5, 4), (5, 5), (5, 6)]})],
                  walls=10, steps=30, action_seed=44),
         Scenario("rules_search_grow", ("search", 30), 0, place=[rnd(0, 40), rnd(1, 40), (2, "custom", {"pos": [(8, 20), (9, 20), (10, 20)]})],
