@@ -100,6 +100,55 @@ def run_cpu_baseline(map_size=MAP_SIZE, agents=N_PER_GROUP, steps=2):
     return best
 
 
+def small_world_extras(torch, magent_amd, dev, steps=200, warmup=20):
+    """secondary lines for BASELINE config 2 (battle 200x200, 2x2000): the same cycle through the reference call sequence, through
+    env_cycle_many (EnvBatch: two launches per cycle) for one environment, and for 8 / 32 environments on this one GPU"""
+    from magent_amd.builtin.config import _games
+    MAP, N = 200, 2000
+    out = {}
+
+    def make(seed):
+        env = magent_amd.GridWorld(_games.make("battle", MAP))
+        env.set_seed(seed); env.reset()
+        for h in env.get_handles():
+            env.add_agents(h, "random", n=N)
+        return env
+
+    gen = torch.Generator(device=dev); gen.manual_seed(99)
+    for label, K, batched in (("calls", 1, False), ("cycle_1env", 1, True), ("cycle_8env", 8, True), ("cycle_32env", 32, True)):
+        envs = [make(5000 + k) for k in range(K)]
+        views = [[torch.empty((N, 13, 13, 7), device=dev) for _ in range(2)] for _ in envs]
+        feats = [[torch.empty((N, 34), device=dev) for _ in range(2)] for _ in envs]
+        rews = [[torch.empty(N, device=dev) for _ in range(2)] for _ in envs]
+        acts = [[[torch.randint(21, (N,), dtype=torch.int32, device=dev, generator=gen) for _ in range(2)] for _ in envs] for _ in range(4)]
+        torch.cuda.synchronize()
+        batch = magent_amd.EnvBatch(envs, n_threads=8)
+        total, t0 = 0, 0.0
+        for s in range(steps + warmup):
+            if s == warmup:
+                for e in envs:
+                    e.sync()
+                total, t0 = 0, time.perf_counter()
+            total += sum(e.get_num(h) for e in envs for h in e.get_handles())
+            if batched:
+                batch.cycle(views, feats, acts[s % 4], rews)
+            else:
+                e = envs[0]
+                for g, h in enumerate(e.get_handles()):
+                    e.get_observation_device(h, views[0][g], feats[0][g])
+                    e.set_action_device(h, acts[s % 4][0][g])
+                e.step()
+                for g, h in enumerate(e.get_handles()):
+                    e.get_reward_device(h, rews[0][g])
+                e.clear_dead()
+        for e in envs:
+            e.sync()
+        dt = time.perf_counter() - t0
+        out[label] = {"agent_steps_per_s": total / dt, "ms_per_cycle": dt / steps * 1e3, "envs": K}
+        del batch, envs
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,17 +156,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--map-size", type=int, default=MAP_SIZE)
     ap.add_argument("--agents", type=int, default=N_PER_GROUP, help="agents per group")
-    ap.add_argument("--workload", choices=["battle", "test_1m", "gather"], default="battle",
-                    help="test_1m: the reference's own harness (scripts/test/test_1m.py): pursuit-like game, map sqrt(20 N), "
+    ap.add_argument("--workload", choices=["battle", "battle_fill", "test_1m", "gather"], default="battle",
+                    help="battle_fill: SURVEY.md 8d C3(ii), the map filled to capacity by add_agents('fill') (2 x 498,002 at 1000 x 1000; nobody can "
+                         "move); test_1m: the reference's own harness (scripts/test/test_1m.py): pursuit-like game, map sqrt(20 N), "
                          "N/10 walls, N/2 prey + N/2 2x2 predators, N = 2 * --agents; "
                          "gather: BASELINE config 4 (examples/train_gather.py: --agents agents + agents/5 food, only agents act)")
-    ap.add_argument("--gather", choices=["none", "obs"], default="none",
-                    help="obs: all_gather the observation tensors of every replica over RCCL each step")
+    ap.add_argument("--gather", choices=["none", "obs", "obs-padded"], default="none",
+                    help="obs: exchange the observation tensors of every replica over RCCL each step (counts first, then sends / receives "
+                         "sized by count, on a side stream under the step); obs-padded: one all_gather_into_tensor of capacity rows")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to dry-run the N > 1 "
                          "code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (capacity fill, test_1m, small worlds)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-lib", default="")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -144,151 +196,184 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-
-    from magent_amd.builtin.config import _games
-    if args.workload == "test_1m":
-        args.map_size = int((2 * args.agents * 20) ** 0.5)
-        cfg = _games.make("pursuit", args.map_size)
-    elif args.workload == "gather":
-        cfg = _games.make("gather", args.map_size)
-    else:
-        cfg = _games.make("battle", args.map_size)
-    cfg.set({"device_id": local_rank})
-    env = magent_amd.GridWorld(cfg)
-    env.set_seed(12345 + rank)
-    env.reset()
-    handles = env.get_handles()
-    acting = list(range(len(handles)))
-    if args.workload == "test_1m":
-        env.add_walls(method="random", n=2 * args.agents // 10)
-        for h in reversed(handles):
-            env.add_agents(h, "random", n=args.agents)
-    elif args.workload == "gather":   # group 0 = food (never observed, never acts), group 1 = agents
-        env.add_agents(handles[0], "random", n=args.agents // 5)
-        env.add_agents(handles[1], "random", n=args.agents)
-        acting = [1]
-    else:
-        for h in handles:
-            env.add_agents(h, "random", n=args.agents)
-    n0 = [env.get_num(h) for h in handles]
-    G = len(handles)
-    vss = [env.get_view_space(h) for h in handles]
-    fss = [env.get_feature_space(h) for h in handles]
-    n_actions = [env.get_action_space(h)[0] for h in handles]
-    view_bytes = [4 * v[0] * v[1] * v[2] for v in vss]   # per agent: what k_render writes (the dominant kernel)
-    feat_bytes = [4 * f[0] for f in fss]                 # per agent: what k_features writes
-
-    # caller-owned device buffers (the reference's ownership convention), sized once for the initial population
-    views = [torch.empty((n0[g],) + vss[g], dtype=torch.float32, device=dev) for g in range(G)]
-    feats = [torch.empty((n0[g],) + fss[g], dtype=torch.float32, device=dev) for g in range(G)]
-    rewards = [torch.empty(n0[g], dtype=torch.float32, device=dev) for g in range(G)]
-    total_steps = args.steps + args.warmup
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(rank)
-    actions = [[torch.randint(n_actions[g], (n0[g],), dtype=torch.int32, device=dev, generator=gen) for g in range(G)]
-               for _ in range(total_steps + (0 if args.no_profile else 5))]
     from magent_amd import replicas
-    do_gather = args.gather == "obs" and world > 1
-    torch.cuda.synchronize()
 
-    rendered = {"view": 0, "feat": 0}
+    def measure(workload, map_size, agents, steps, warmup, profile, gather="none", seed=12345 + rank):
+        """K timed steps of `workload`; returns the fields of the bench line that depend on the run"""
+        from magent_amd.builtin.config import _games
+        if workload == "test_1m":
+            map_size = int((2 * agents * 20) ** 0.5)
+            cfg = _games.make("pursuit", map_size)
+        elif workload == "gather":
+            cfg = _games.make("gather", map_size)
+        else:
+            cfg = _games.make("battle", map_size)
+        cfg.set({"device_id": local_rank})
+        env = magent_amd.GridWorld(cfg)
+        env.set_seed(seed)
+        env.reset()
+        handles = env.get_handles()
+        acting = list(range(len(handles)))
+        if workload == "test_1m":
+            env.add_walls(method="random", n=2 * agents // 10)
+            for h in reversed(handles):
+                env.add_agents(h, "random", n=agents)
+        elif workload == "gather":   # group 0 = food (never observed, never acts), group 1 = agents
+            env.add_agents(handles[0], "random", n=agents // 5)
+            env.add_agents(handles[1], "random", n=agents)
+            acting = [1]
+        elif workload == "battle_fill":   # the two halves of the inner map, every cell taken (SURVEY.md 8d C3(ii))
+            half = (map_size - 2) // 2
+            env.add_agents(handles[0], "fill", pos=(1, 1), size=(half, map_size - 2))
+            env.add_agents(handles[1], "fill", pos=(1 + half, 1), size=(map_size - 2 - half, map_size - 2))
+        else:
+            for h in handles:
+                env.add_agents(h, "random", n=agents)
+        n0 = [env.get_num(h) for h in handles]
+        G = len(handles)
+        vss = [env.get_view_space(h) for h in handles]
+        fss = [env.get_feature_space(h) for h in handles]
+        n_actions = [env.get_action_space(h)[0] for h in handles]
+        view_bytes = [4 * v[0] * v[1] * v[2] for v in vss]   # per agent: what k_render writes (the dominant kernel)
+        feat_bytes = [4 * f[0] for f in fss]                 # per agent: the feature rows (they ride in the render launch)
 
-    def one_step(s):
-        n_now = 0
-        for g, h in enumerate(handles):
-            if g not in acting:
-                continue
-            n = env.get_num(h)
-            n_now += n
-            rendered["view"] += n * view_bytes[g]
-            rendered["feat"] += n * feat_bytes[g]
-            env.get_observation_device(h, views[g], feats[g])
-            env.set_action_device(h, actions[s][g])
-        if do_gather:   # the north star's batched-observation gather: every replica's view tensor to every rank
-            env.sync()
+        # caller-owned device buffers (the reference's ownership convention), sized once for the initial population
+        views = [torch.empty((n0[g],) + vss[g], dtype=torch.float32, device=dev) for g in range(G)]
+        feats = [torch.empty((n0[g],) + fss[g], dtype=torch.float32, device=dev) for g in range(G)]
+        rewards = [torch.empty(n0[g], dtype=torch.float32, device=dev) for g in range(G)]
+        total_steps = steps + warmup
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(rank)
+        n_sets = min(total_steps + (5 if profile else 0), 32)   # action sets are recycled: 32 x 3.2 MB is enough entropy
+        actions = [[torch.randint(n_actions[g], (n0[g],), dtype=torch.int32, device=dev, generator=gen) for g in range(G)] for _ in range(n_sets)]
+        gathers = None
+        if gather != "none" and world > 1:   # the north star's batched-observation gather: every replica's view tensor to every rank
+            gdev = dev if args.backend == "nccl" else torch.device("cpu")
+            gathers = [replicas.ObservationGather(vss[g], capacity=n0[g], device=gdev, mode="padded" if gather == "obs-padded" else "exact")
+                       if g in acting else None for g in range(G)]
+        torch.cuda.synchronize()
+        rendered = {"view": 0, "feat": 0, "launches": 0}
+        step_ends = []
+
+        def one_step(s):
+            n_now = 0
             for g, h in enumerate(handles):
-                src = views[g] if args.backend == "nccl" else views[g].cpu()
-                replicas.gather_observations(src, env.get_num(h), capacity=n0[g])
-        env.step()
-        for g, h in enumerate(handles):
-            if g in acting:
-                env.get_reward_device(h, rewards[g])
-        env.clear_dead()
-        return n_now
+                if g not in acting:
+                    continue
+                n = env.get_num(h)
+                n_now += n
+                rendered["view"] += n * view_bytes[g]
+                rendered["feat"] += n * feat_bytes[g]
+                rendered["launches"] += 1
+                if gathers:                      # the previous exchange still reads the tensor the render is about to overwrite
+                    gathers[g].wait(env.stream if args.backend == "nccl" else None)
+                env.get_observation_device(h, views[g], feats[g])
+                env.set_action_device(h, actions[s % n_sets][g])
+                if gathers:                      # counts now (behind the render, on the side stream); the rows follow below
+                    src = views[g] if args.backend == "nccl" else views[g][:n].cpu()
+                    if args.backend != "nccl":
+                        env.sync()
+                    gathers[g].launch(src, n, producer_stream=env.stream if args.backend == "nccl" else None)
+            if gathers:                          # the rows travel on the side stream while the step kernels run on the engine's
+                for g in acting:
+                    gathers[g].post()
+            env.step()
+            for g, h in enumerate(handles):
+                if g in acting:
+                    env.get_reward_device(h, rewards[g])
+            env.clear_dead()
+            step_ends.append(time.perf_counter())
+            return n_now
 
-    for s in range(args.warmup):
-        one_step(s)
-    env.sync()
-    if not args.no_profile:
-        # inside the timed region only the dominant kernel carries HIP events (an event pair costs ~10 us of stream time;
-        # timing every phase of every step would add ~10 % to the step); the phase breakdown is taken afterwards
-        env.profile_enable(2)
-        for name in ("render", "features", "paint", "minimap", "attack", "move", "set_action", "starve", "rules", "clear_dead"):
-            env.profile_read(name)
-    rendered["view"] = rendered["feat"] = 0
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    agent_steps = 0
-    for s in range(args.warmup, total_steps):
-        n_now = one_step(s)
-        agent_steps += n_now
-    env.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        for s in range(warmup):
+            one_step(s)
+        env.sync()
+        if profile:
+            # inside the timed region only the dominant kernel carries HIP events (an event pair costs ~10 us of stream time;
+            # timing every phase of every step would add ~10 % to the step); the phase breakdown is taken afterwards
+            env.profile_enable(2)
+            for name in ("render", "features", "paint", "minimap", "attack", "move", "turn", "set_action", "step", "rules", "clear_dead"):
+                env.profile_read(name)
+        rendered["view"] = rendered["feat"] = rendered["launches"] = 0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        del step_ends[:]
+        t0 = time.perf_counter()
+        agent_steps = 0
+        for s in range(warmup, total_steps):
+            agent_steps += one_step(s)
+        if gathers:
+            for g in acting:
+                gathers[g].wait()
+        env.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        per_step = sorted(b - a for a, b in zip([t0] + step_ends[:-1], step_ends))
+        median_ms = per_step[len(per_step) // 2] * 1e3 if per_step else None
 
-    if world > 1:   # whole-job aggregate over the slowest replica's time
-        elapsed = replicas.max_over_replicas(elapsed, device=red_dev)
-        agent_steps = replicas.sum_over_replicas(agent_steps, device=red_dev)
-
-    agents_at_end = [env.get_num(h) for h in handles]
-    host_finished_steps = env.engine_stats()[0]   # steps whose optimistic rounds ran out (counted since reset, warm-up included)
-    roofline, breakdown = None, {}
-    if not args.no_profile:
-        n_launch, ms = env.profile_read("render")
-        n_feat, ms_feat = env.profile_read("features")
-        if n_launch and ms > 0:
-            # algorithmic bytes of the dominant kernel: every element of the observation written exactly once
-            # (B_obs = 4*(VH*VW*C + F) per agent; the feature rows ride in the render launch)
-            fused = n_feat == 0
-            obs_bytes = rendered["view"] + (rendered["feat"] if fused else 0)
-            achieved = obs_bytes / (ms * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "render_pmc.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
-                        "algorithmic_bytes_per_launch": int(obs_bytes / n_launch),
-                        "obs_total_GBs": round((rendered["view"] + rendered["feat"]) / ((ms + ms_feat) * 1e-3) / 1e9, 1)}
-        # phase breakdown: a few more steps of the same episode, OUTSIDE the timed region, with an event pair around every phase
-        extra = min(5, len(actions) - total_steps)
-        if extra > 0:
+        res = {"elapsed": elapsed, "agent_steps": agent_steps, "median_ms": median_ms, "n0": n0, "agents_at_end": [env.get_num(h) for h in handles],
+               "host_finished_steps": env.engine_stats()[0], "roofline": None, "breakdown": {}, "map_size": map_size}
+        if profile:
+            n_launch, ms = env.profile_read("render")
+            n_feat, ms_feat = env.profile_read("features")
+            if n_launch and ms > 0:
+                # algorithmic bytes of the dominant kernel: every element of the observation written exactly once
+                # (SURVEY.md 8d: B_obs = 4*(VH*VW*C + F) per agent; the feature rows ride in the render launch)
+                fused = n_feat == 0
+                obs_bytes = rendered["view"] + (rendered["feat"] if fused else 0)
+                achieved = obs_bytes / (ms * 1e-3) / 1e9
+                traffic, traffic_note = None, None
+                pmc = os.path.join(ROOT, "profiles", "render_pmc.json")
+                if os.path.exists(pmc):
+                    try:     # PMC bytes per rendered AGENT (separate rocprofv3 --pmc passes, profiles/), scaled to this run's launches
+                        rec = json.load(open(pmc))
+                        agents_per_launch = (rendered["view"] / view_bytes[acting[0]]) / n_launch
+                        traffic = rec["hbm_bytes_per_agent"] * agents_per_launch
+                        traffic_note = "PMC FETCH_SIZE + WRITE_SIZE per rendered agent (%s) x %.0f agents per launch of this run" % (rec.get("source", "profiles/"), agents_per_launch)
+                    except Exception:
+                        traffic = None
+                res["roofline"] = {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                                   "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
+                                   "algorithmic_bytes_per_launch": int(obs_bytes / n_launch)}
+            # phase breakdown: a few more steps of the same episode, OUTSIDE the timed region, with an event pair around every phase
+            extra = 5
             env.profile_enable(1)
             for s in range(total_steps, total_steps + extra):
                 one_step(s)
             env.sync()
-            for name in ("paint", "minimap", "attack", "move", "set_action", "starve", "rules", "clear_dead"):
+            for name in ("paint", "minimap", "attack", "move", "turn", "set_action", "step", "rules", "clear_dead"):
                 k, t_ms = env.profile_read(name)
                 if k:
-                    breakdown[name + "_ms_per_step"] = round(t_ms / extra, 4)
-            breakdown["note"] = "%d extra steps after the timed region" % extra
+                    res["breakdown"][name + "_ms_per_step"] = round(t_ms / extra, 4)
+            res["breakdown"]["note"] = "%d extra steps after the timed region" % extra
             env.profile_read("render"); env.profile_read("features")
-        if roofline:
-            breakdown["render_ms_per_step"] = round(ms / args.steps, 4)
-            breakdown["features_ms_per_step"] = round(ms_feat / args.steps, 4)
-        env.profile_enable(False)
+            if res["roofline"]:
+                res["breakdown"]["render_ms_per_step"] = round(ms / steps, 4)
+            env.profile_enable(False)
+        if gathers:
+            res["gather"] = {"mode": gathers[acting[0]].mode, "payload_bytes_sent_per_step": sum(gathers[g].bytes_sent for g in acting)}
+        del env
+        return res
+
+    R = measure(args.workload, args.map_size, args.agents, args.steps, args.warmup, not args.no_profile, gather=args.gather)
+    elapsed, agent_steps = R["elapsed"], R["agent_steps"]
+    if world > 1:   # whole-job aggregate over the slowest replica's time
+        elapsed = replicas.max_over_replicas(elapsed, device=red_dev)
+        agent_steps = replicas.sum_over_replicas(agent_steps, device=red_dev)
 
     if rank == 0:
+        is_default = (args.workload, args.map_size, args.agents) == ("battle", MAP_SIZE, N_PER_GROUP)
+        names = {"test_1m": "reference test_1m.py harness: pursuit-like %dx%d, %d walls, %d prey + %d 2x2 predators" % (
+                     R["map_size"], R["map_size"], 2 * args.agents // 10, args.agents, args.agents),
+                 "gather": "gather %dx%d (train_gather.py), %d agents + %d food, only the agents act" % (args.map_size, args.map_size, args.agents, args.agents // 5),
+                 "battle_fill": "battle %dx%d filled to capacity by add_agents('fill'): %s agents (SURVEY.md 8d C3(ii)), random actions" % (args.map_size, args.map_size, R["n0"]),
+                 "battle": "battle %dx%d, 2x%d agents, random placement, random actions" % (args.map_size, args.map_size, args.agents)}
         rec = {
             "metric": "agent-steps/sec (step+obs) on battle map; bit-exact vs CPU ref",
             "value": agent_steps / elapsed,
@@ -297,30 +382,39 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_median": R["median_ms"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": WORKLOAD if (args.workload, args.map_size, args.agents) == ("battle", MAP_SIZE, N_PER_GROUP) else
-                       ("reference test_1m.py harness: pursuit-like %dx%d, %d walls, %d prey + %d 2x2 predators" % (
-                           args.map_size, args.map_size, 2 * args.agents // 10, args.agents, args.agents)
-                        if args.workload == "test_1m" else
-                        "gather %dx%d (train_gather.py), %d agents + %d food, only the agents act" % (
-                            args.map_size, args.map_size, args.agents, args.agents // 5) if args.workload == "gather" else
-                        "battle %dx%d, 2x%d agents, random placement, random actions" % (args.map_size, args.map_size, args.agents)),
+            "config": {"workload": WORKLOAD if is_default else names[args.workload],
                        "envs": world, "parallelism": "replicas x%d" % world, "gather": args.gather,
-                       "agents_at_start": n0, "agents_at_end": agents_at_end,
-                       "io": "device-resident (env_*_device C-ABI)", "steps_finished_by_host_driver": host_finished_steps},
-            "roofline": roofline,
-            "breakdown": breakdown,
+                       "agents_at_start": R["n0"], "agents_at_end": R["agents_at_end"],
+                       "io": "device-resident (env_*_device C-ABI)", "steps_finished_by_host_driver": R["host_finished_steps"]},
+            "roofline": R["roofline"],
+            "breakdown": R["breakdown"],
         }
+        if "gather" in R:
+            rec["config"]["gather_detail"] = R["gather"]
         if world == 1 and not args.no_cpu_baseline:
             small = args.map_size * args.map_size <= 250000
             rec["cpu_baseline"] = run_cpu_baseline(args.map_size, args.agents, steps=200 if small else 2) \
                 if args.workload == "battle" else None
         else:
             rec["cpu_baseline"] = None
+        if world == 1 and is_default and not args.no_extras:
+            # the other readings of "battle 1000x1000 / 1M agents" the survey sanctions, and BASELINE config 2, each a short run
+            extra = {}
+            try:
+                F = measure("battle_fill", MAP_SIZE, 0, 10, 3, False)
+                extra["battle_fill_2x498002"] = {"agent_steps_per_s": F["agent_steps"] / F["elapsed"], "ms_per_step": F["elapsed"] / 10 * 1e3, "agents": F["n0"]}
+                T = measure("test_1m", 0, 500000, 10, 3, False)
+                extra["test_1m_2x500k"] = {"agent_steps_per_s": T["agent_steps"] / T["elapsed"], "ms_per_step": T["elapsed"] / 10 * 1e3, "agents": T["n0"], "map": T["map_size"]}
+                extra["battle_200_2x2000"] = small_world_extras(torch, magent_amd, dev)
+            except Exception as e:     # secondary lines never fail the bench
+                extra["error"] = repr(e)
+            rec["extra"] = extra
         print(json.dumps(rec))
     if world > 1:
         dist.destroy_process_group()

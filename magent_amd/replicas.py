@@ -4,6 +4,21 @@ One environment is a single coupled grid, so the hot path does no
 The only cross-GPU traffic the north star asks for is an optional gather of the batched observation tensor, so that
 one policy batch can see every replica.  `torch.distributed` backend "nccl" is RCCL on ROCm (xGMI inside a node); the
 same code runs on "gloo" CPU tensors, which is how the CPU tests cover it.
+
+`ObservationGather` is the exchange SURVEY.md 8e describes:
+  * counts first -- replicas differ in size after deaths: one `all_gather_into_tensor` of a single int64 per rank;
+  * then the rows, sized by count: every rank posts one send to and one receive from each peer (`batch_isend_irecv`, on
+    RCCL a single group of ncclSend / ncclRecv).  On the 8 x MI355X full mesh every pair of GPUs has its own xGMI link
+    (~153 GB/s per direction), so the seven transfers of a rank run side by side and the exchange takes
+    max_shard_bytes / 153 GB/s -- a ring all-gather would pay seven hops on one link each.  Nothing is padded: exactly
+    n_r rows travel from rank r;
+  * every buffer is allocated once (receive area sized for `capacity` rows per replica, count tensors, events): a call
+    allocates nothing on the device;
+  * on GPUs the exchange is issued on a side stream behind an event recorded on the producer's stream, so the engine's
+    step kernels (which do not touch the observation) run under it; `wait()` orders a consumer stream after it.
+
+`mode="padded"` is the one-collective alternative (`all_gather_into_tensor` of `capacity` rows per rank): no host
+round trip for the counts before the payload is posted, at the price of sending the padding.
 """
 import os
 
@@ -22,40 +37,122 @@ def replica_seed(base_seed, rank):
     return base_seed + rank
 
 
-def gather_counts(n, device=None):
-    """all-gather the per-replica agent counts (they differ after deaths); returns a python list"""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
-        return [int(n)]
-    mine = torch.tensor([int(n)], dtype=torch.int64, device=device)
-    out = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(out, mine)
-    return [int(t.item()) for t in out]
+class ObservationGather(object):
+    """All-gather of a per-replica observation tensor whose row count differs between replicas.
 
-
-def gather_observations(view, n, capacity=None):
-    """All-gather the first `n` rows of this replica's observation tensor.
-
-    view     : [capacity_local, ...] tensor whose first n rows are valid (device tensor for nccl, CPU for gloo)
-    capacity : common row capacity of the exchange buffers (default: max n over replicas).  RCCL all_gather needs
-               equal shapes, so shards are exchanged padded and trimmed afterwards; on the 8 x MI355X full mesh
-               every pair has its own xGMI link, so the all-gather is one hop per peer.
-    returns  : (list of per-replica tensors trimmed to their own n, list of counts)
+    row_shape : shape of one agent's observation, e.g. (13, 13, 7)
+    capacity  : rows reserved per replica in the receive area (>= the largest population any replica will hold)
+    device    : where the tensors live ("cpu" for gloo); mode: "exact" (counts, then sized sends / receives) | "padded"
     """
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    counts = gather_counts(n, device=view.device)
-    if world == 1:
-        return [view[:n]], counts
-    cap = int(capacity) if capacity is not None else max(counts)
-    assert cap >= max(counts), "capacity smaller than a replica's agent count"
-    if view.shape[0] >= cap:
-        send = view[:cap].contiguous()
-    else:
-        send = torch.zeros((cap,) + tuple(view.shape[1:]), dtype=view.dtype, device=view.device)
-        send[:n] = view[:n]
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send)
-    return [r[:c] for r, c in zip(recv, counts)], counts
+
+    def __init__(self, row_shape, capacity, dtype=torch.float32, device="cpu", mode="exact", group=None):
+        assert mode in ("exact", "padded")
+        self.mode, self.group = mode, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.capacity, self.row_shape = int(capacity), tuple(row_shape)
+        self.device = torch.device(device)
+        self.recv = torch.empty((self.world, self.capacity) + self.row_shape, dtype=dtype, device=self.device)
+        self._count_send = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._count_recv = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        self._count_host = torch.zeros(self.world, dtype=torch.int64).pin_memory() if self.device.type == "cuda" else None
+        self.counts = [0] * self.world
+        self.row_bytes = self.recv[0, 0].numel() * self.recv.element_size()
+        self.bytes_sent = self.bytes_received = 0          # of the last exchange, payload only
+        if self.device.type == "cuda":
+            self.stream = torch.cuda.Stream(device=self.device)
+            self._ready = torch.cuda.Event()
+            self._counted = torch.cuda.Event()
+            self._done = torch.cuda.Event()
+        else:
+            self.stream = None
+        self._posted = True
+
+    # -- step 1: the counts (and, for GPUs, the hand-over from the producer's stream)
+    def launch(self, view, n, producer_stream=None):
+        """`view[:n]` are this replica's rows (a preallocated tensor of at least n rows on self.device; in padded mode of at
+        least `capacity` rows).  Starts the exchange of the counts; `post()` sends the rows.  producer_stream: the CUDA
+        stream that fills `view` (default: the current one)"""
+        assert view.shape[1:] == self.row_shape and view.is_contiguous() and n <= self.capacity and view.shape[0] >= n
+        self._view, self._n, self._posted = view, int(n), False
+        if self.world == 1:
+            self.counts = [self._n]
+            return
+        if self.stream is not None:
+            (producer_stream or torch.cuda.current_stream(self.device)).record_event(self._ready)
+            self.stream.wait_event(self._ready)
+            with torch.cuda.stream(self.stream):
+                self._count_send.fill_(self._n)
+                dist.all_gather_into_tensor(self._count_recv, self._count_send, group=self.group)
+                self._count_host.copy_(self._count_recv, non_blocking=True)
+                self._counted.record(self.stream)
+        else:
+            self._count_send.fill_(self._n)
+            dist.all_gather_into_tensor(self._count_recv, self._count_send, group=self.group)
+
+    # -- step 2: the rows
+    def post(self):
+        """posts the payload (call it after the work that should run under the exchange has been enqueued)"""
+        if self._posted:
+            return
+        self._posted = True
+        if self.world == 1:
+            return
+        if self.stream is not None:
+            self._counted.synchronize()                    # 8 * world bytes: the only host wait of the exchange
+            self.counts = self._count_host.tolist()
+        else:
+            self.counts = self._count_recv.tolist()
+        assert max(self.counts) <= self.capacity, "capacity smaller than a replica's agent count"
+        view, n = self._view, self._n
+
+        def exchange():
+            if self.mode == "padded":
+                assert view.shape[0] >= self.capacity, "padded mode sends `capacity` rows: the send tensor must hold them"
+                dist.all_gather_into_tensor(self.recv.view(self.world * self.capacity, *self.row_shape), view[:self.capacity], group=self.group)
+                self.bytes_sent = self.capacity * self.row_bytes * (self.world - 1)
+                self.bytes_received = self.bytes_sent
+                return
+            ops = []
+            for peer in range(self.world):          # sized by count, no padding; every pair has its own link on the full mesh
+                if peer == self.rank:
+                    continue
+                if self.counts[peer] > 0:
+                    ops.append(dist.P2POp(dist.irecv, self.recv[peer, :self.counts[peer]], peer, group=self.group))
+                if n > 0:
+                    ops.append(dist.P2POp(dist.isend, view[:n], peer, group=self.group))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    if self.stream is None:
+                        req.wait()
+            self.bytes_sent = n * self.row_bytes * (self.world - 1)
+            self.bytes_received = (sum(self.counts) - n) * self.row_bytes
+
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                exchange()
+                self._done.record(self.stream)
+        else:
+            exchange()
+
+    def wait(self, consumer_stream=None):
+        """orders `consumer_stream` (default: the current CUDA stream) after the exchange; returns the shards"""
+        self.post()
+        if self.stream is not None and self.world > 1:
+            (consumer_stream or torch.cuda.current_stream(self.device)).wait_event(self._done)
+        return self.shards()
+
+    def shards(self):
+        """per-replica views of the gathered rows, trimmed to each replica's count (own rows: the send tensor itself)"""
+        out = []
+        for r in range(self.world):
+            out.append(self._view[:self._n] if r == self.rank else self.recv[r, :self.counts[r]])
+        return out
+
+    def gather(self, view, n):
+        """the whole exchange in one call"""
+        self.launch(view, n)
+        return self.wait(), list(self.counts)
 
 
 def max_over_replicas(seconds, device=None):

@@ -1,8 +1,9 @@
 """CPU test of the N > 1 path: two processes on gloo, each owning its own environment replica.
 
 The replicas here are driven by the CPU oracle (no GPU in this test); what is under test is the host logic of
-magent_amd/replicas.py that bench.py uses on RCCL: per-replica seeds, variable-size observation gather,
-max-over-ranks timing, whole-job aggregation."""
+magent_amd/replicas.py that bench.py uses on RCCL: per-replica seeds, the observation gather (counts first, then sends /
+receives sized by count into buffers allocated once -- or the padded one-collective form), max-over-ranks timing,
+whole-job aggregation."""
 import os
 import socket
 
@@ -37,9 +38,26 @@ def _worker(rank, world, port, oracle, out_dir):
     env.add_agents(h1, "random", n=40)
     view, _ = env.get_observation(h0)
     n = env.get_num(h0)
-    shards, counts = replicas.gather_observations(torch.from_numpy(view.copy()), n)
-    assert counts == [40, 50] and [s.shape[0] for s in shards] == counts
-    assert torch.equal(shards[rank], torch.from_numpy(view))
+    # the observation gather of SURVEY.md 8e: counts first, then rows sized by count; every buffer allocated once
+    send = torch.zeros((64,) + tuple(view.shape[1:]))                  # the replica's (preallocated) observation tensor
+    send[:n] = torch.from_numpy(view)
+    for mode in ("exact", "padded"):
+        g = replicas.ObservationGather(view.shape[1:], capacity=64, mode=mode)
+        ptrs = (g.recv.data_ptr(), g._count_recv.data_ptr(), g._count_send.data_ptr())
+        for it, m in enumerate((n, n - 7 - 3 * rank, n - 20, 0 if rank == 1 else 5)):     # populations shrink, unevenly; one replica dies out
+            shards, counts = g.gather(send, m)
+            other = 1 - rank
+            n_other = 40 + 10 * other
+            want = [n_other, n_other - 7 - 3 * other, n_other - 20, 0 if other == 1 else 5][it]
+            assert counts[rank] == m and counts[other] == want and [s.shape[0] for s in shards] == counts
+            assert torch.equal(shards[rank], send[:m])
+            assert shards[other].untyped_storage().data_ptr() == g.recv.untyped_storage().data_ptr()   # a view of the receive area
+            assert (g.recv.data_ptr(), g._count_recv.data_ptr(), g._count_send.data_ptr()) == ptrs      # nothing was re-allocated
+            if mode == "exact":
+                assert g.bytes_sent == m * g.row_bytes and g.bytes_received == want * g.row_bytes       # no padding travels
+            if it == 0:
+                first = [s.clone() for s in shards]
+    shards, counts = first, [40, 50]
     t = replicas.max_over_replicas(1.0 + rank)
     total = replicas.sum_over_replicas(n)
     assert t == 2.0 and total == 90.0

@@ -57,8 +57,20 @@ def main():
         rk = [k for k in fetch if "k_render" in k]
         if rk:
             k = rk[0]
+            # agents per k_render launch of the PMC runs (the populations shrink as agents die): mean of start / end, from the runs' own bench lines
+            agents = []
+            for d in (sys.argv[3], sys.argv[4]):
+                lg = d.rstrip("/") + ".log"
+                if os.path.exists(lg):
+                    for line in open(lg, errors="ignore"):
+                        if line.startswith("{") and '"agents_at_start"' in line:
+                            c = json.loads(line)["config"]
+                            agents.append((sum(c["agents_at_start"]) + sum(c["agents_at_end"])) / (2.0 * len(c["agents_at_start"])))
+            per_launch = sum(agents) / len(agents) if agents else None
             rec = {"kernel": k.split("(")[0], "fetch_bytes_per_launch": fetch[k] * 1024, "write_bytes_per_launch": write.get(k, 0) * 1024,
                    "hbm_bytes_per_launch": (fetch[k] + write.get(k, 0)) * 1024,
+                   "agents_per_launch": per_launch,
+                   "hbm_bytes_per_agent": (fetch[k] + write.get(k, 0)) * 1024 / per_launch if per_launch else None,
                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB*1024; WRITE_SIZE calibrated on k_paint "
                            "(it writes exactly w*h*4 bytes packed / w*h*8 unpacked); FETCH_SIZE is uncalibrated for 8-byte gathers on gfx950 and counts "
                            "Infinity-Cache hits (MI355X_MICROARCH.md, HBM section) -- an upper bound on HBM reads",
