@@ -72,8 +72,9 @@ void HostRange::sector(float angle, float radius, int parity) {
     height = (int)(radius + 0.5);
     width = (int)(2 * radius * std::sin(angle / 2 * (PI / 180)) + 0.5);
     if (width % 2 != parity) width--;
-    if (width < 0 || (width == 0 && height > 0)) fatal("sector range (angle %g, radius %g) too narrow: the reference allocates a non-positive array here", angle, radius);
-    in.assign((size_t)width * height, 0);
+    // (radius 0 -- a type without attack range: height 0, width -1 after the parity step; no cell, no action)
+    if (height > 0 && width <= 0) fatal("sector range (angle %g, radius %g) too narrow: the reference allocates a non-positive array here", angle, radius);
+    in.assign(height > 0 ? (size_t)width * height : 0, 0);
     dx.clear(); dy.clear(); count = 0;
     const double eps = 0.00001;
     for (int i = 0; i < height; i++)
@@ -1120,6 +1121,16 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
     P.div_scale_w = make_fastdiv(R.scale_w); P.div_scale_h = make_fastdiv(R.scale_h);
 }
 
+// the minimap of a vh x vw window into d_minif (grown if needed)
+MiniArgs Env::mini_args(int vh, int vw, bool skip) {
+    MiniArgs M{};
+    M.vh = vh; M.vw = vw; M.skip = skip ? 1 : 0;
+    M.scale_h = (height + vh - 1) / vh; M.scale_w = (width + vw - 1) / vw;   // GridWorld.cc:328-329
+    grow(d_minif, minif_cap, groups.size() * (size_t)vh * vw, stream);
+    M.out = d_minif;
+    return M;
+}
+
 long long Env::mini_population(bool skip) const {
     long long pop = 0;
     for (auto &gr : groups) pop = pop * 1000003ll + gr.n;
@@ -1150,7 +1161,7 @@ bool Env::prepare_render(int g, const WorldView &W, RenderArgs &R, RenderPlan &P
         if (!(mini_valid && mini_vh == R.VH && mini_vw == R.VW && mini_pop == pop)) {
             ProfScope p(*this, "minimap");
             launch_minimap(stream, W, R, d_mini, d_minif);
-            mini_valid = true; mini_vh = R.VH; mini_vw = R.VW; mini_pop = pop;
+            mini_valid = true; mini_vh = R.VH; mini_vw = R.VW; mini_pop = pop; mini_skip = G.type->can_absorb;
         }
     }
     const bool aligned = (((uintptr_t)view) & 15) == 0, feat_aligned = (((uintptr_t)feat) & 15) == 0;
@@ -1629,12 +1640,8 @@ bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, con
     cyc_next_mini = false;
     if (minimap_mode && first_obs >= 0) {   // the next cycle observes the same groups: its minimap is made here
         const HostType &t = *groups[first_obs].type;
-        S.mini_vh = t.view.height; S.mini_vw = t.view.width;
-        S.mini_scale_h = (height + S.mini_vh - 1) / S.mini_vh; S.mini_scale_w = (width + S.mini_vw - 1) / S.mini_vw;
-        S.mini_skip = t.can_absorb ? 1 : 0;
-        grow(d_minif, minif_cap, (size_t)NG * S.mini_vh * S.mini_vw, stream);
-        S.mini_out = d_minif;
-        cyc_next_mini = true; cyc_mini_vh = S.mini_vh; cyc_mini_vw = S.mini_vw; cyc_mini_skip = S.mini_skip != 0;
+        S.mini = mini_args(t.view.height, t.view.width, t.can_absorb);
+        cyc_next_mini = true; cyc_mini_vh = S.mini.vh; cyc_mini_vw = S.mini.vw; cyc_mini_skip = S.mini.skip != 0;
     }
     return true;
 }
@@ -1675,7 +1682,7 @@ void Env::cycle_finish(int *done) {
     tables_valid = true;
     paint_valid = step_live_paint;
     mini_valid = cyc_next_mini;
-    if (cyc_next_mini) { mini_vh = cyc_mini_vh; mini_vw = cyc_mini_vw; mini_pop = mini_population(cyc_mini_skip); }
+    if (cyc_next_mini) { mini_vh = cyc_mini_vh; mini_vw = cyc_mini_vw; mini_skip = cyc_mini_skip; mini_pop = mini_population(cyc_mini_skip); }
 }
 
 void Env::cycle(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, int *done) {
@@ -1800,9 +1807,14 @@ void Env::clear_dead() {
             A.mode[g] = G.n == 0 ? 0 : (G.h_dead + G.h_taken > 0 ? 2 : 1);
             A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed, G.alt.dir};
         }
-        launch_clear_solo_all(stream, W, A, d_gtab, d_ttab);
+        // the observations that follow will want the minimap of the window they used last: made here, by the same launch
+        const bool next_mini = minimap_mode && mini_vh > 0;
+        MiniArgs M{};
+        if (next_mini) M = mini_args(mini_vh, mini_vw, mini_skip);
+        launch_clear_solo_all(stream, W, A, d_gtab, d_ttab, M);
         for (size_t g = 0; g < groups.size(); g++) if (A.mode[g] == 2) swap_buffers(groups[g]);
         tables_valid = true;
+        solo_mini = next_mini;
     } else if (!any) {                  // Agent::init_reward for everybody: one launch
         ClearArgs A{};
         for (size_t g = 0; g < groups.size(); g++) A.mode[g] = groups[g].n > 0 ? 1 : 0;
@@ -1840,6 +1852,7 @@ void Env::clear_dead() {
     // (the death counters of the compacted groups were zeroed by the compaction kernels; the others were zero)
     if (any) { h_occ_valid = false; mini_valid = false; }
     for (auto &G : groups) G.indexed = G.n;   // Agent::set_index (GridWorld.cc:655)
+    if (solo_mini) { mini_valid = true; mini_pop = mini_population(mini_skip); solo_mini = false; }
 }
 
 // ------------------------------------------------------------------------------------------------ info

@@ -191,6 +191,8 @@ private:
     void plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *feat);
     bool prepare_render(int g, const WorldView &W, RenderArgs &R, RenderPlan &P, float *view, float *feat);
     long long mini_population(bool skip) const;
+    MiniArgs mini_args(int vh, int vw, bool skip);
+    bool mini_skip = false, solo_mini = false;
     void copy_out(void *host_dst, const void *dev_src, size_t bytes);
     void read_back(void *host_dst, const void *dev_src, size_t bytes);
     char *h_small = nullptr; size_t h_small_cap = 0;   // pinned bounce buffer of read_back

@@ -288,7 +288,8 @@ __global__ void __launch_bounds__(256) k_features(WorldView W, RenderArgs R, Ren
 constexpr int RENDER_WAVES = 4;
 
 // (bx of nb workgroups of the launch work on this group: the render spans first, then the feature rows)
-template <bool VEC4, bool NT, int U, bool PACKED>
+// (TURN: turn_mode -- the window is laid out in the agent's frame; a template parameter so that the ordinary kernel carries none of it)
+template <bool VEC4, bool NT, int U, bool PACKED, bool TURN>
 __device__ __forceinline__ void render_block(const RenderWorld &W, const RenderArgs &R, const RenderPlan &P, int bx, int nb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int VHW = R.VH * R.VW, C = R.C, G = W.G;
@@ -322,7 +323,7 @@ __device__ __forceinline__ void render_block(const RenderWorld &W, const RenderA
             const int a = valid[u] ? (int)fdiv_u32(k, P.div_vhw) : 0;
             cellv[u] = valid[u] ? (int)(k - a * VHW) : 0;
             xv[u] = Gd.x[a]; yv[u] = Gd.y[a];
-            dirv[u] = R.turn ? Gd.dir[a] : DIR_NORTH;
+            dirv[u] = TURN ? Gd.dir[a] : DIR_NORTH;
         }
         int2 recv[U];
         float miniv[U][MAXG];   // minimap value of this window position for channel block b (group (g + b) % G)
@@ -332,7 +333,7 @@ __device__ __forceinline__ void render_block(const RenderWorld &W, const RenderA
             const int vx = cellv[u] - vy * R.VW;
             int ox = T.view_x1 + vx, oy = T.view_y1 + vy;            // window cell -> offset in the agent's frame ...
             int bx = xv[u], by = yv[u];                               // ... counted from the body's reference corner
-            if (R.turn) {                                             // ... -> offset on the map (Map.cc:129-207)
+            if (TURN) {                                               // ... -> offset on the map (Map.cc:129-207)
                 dir_rotate(dirv[u], ox, oy, ox, oy);
                 saved_to_real(dirv[u], T.bw, T.bl, xv[u], yv[u], bx, by);
             }
@@ -414,16 +415,17 @@ __device__ __forceinline__ void render_block(const RenderWorld &W, const RenderA
     }
 }
 
-template <bool VEC4, bool NT, int U, bool PACKED>
+template <bool VEC4, bool NT, int U, bool PACKED, bool TURN>
 __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, RenderArgs R, RenderPlan P) {
-    render_block<VEC4, NT, U, PACKED>(render_world(W, R.g), R, P, blockIdx.x, gridDim.x);
+    render_block<VEC4, NT, U, PACKED, TURN>(render_world(W, R.g), R, P, blockIdx.x, gridDim.x);
 }
 // several groups of a small world in one launch (blockIdx.y = slot): small worlds are bound by the number of launches
 template <bool PACKED>
 __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_multi(WorldView W, RenderMulti M) {
     const int k = blockIdx.y;
     if ((int)blockIdx.x >= M.blocks[k]) return;
-    render_block<true, true, 1, PACKED>(render_world(W, M.R[k].g), M.R[k], M.P[k], blockIdx.x, M.blocks[k]);
+    if (W.turn_mode) render_block<true, true, 1, PACKED, true>(render_world(W, M.R[k].g), M.R[k], M.P[k], blockIdx.x, M.blocks[k]);
+    else render_block<true, true, 1, PACKED, false>(render_world(W, M.R[k].g), M.R[k], M.P[k], blockIdx.x, M.blocks[k]);
 }
 
 // ------------------------------------------------------------------------------------------------ block scan trio
@@ -552,19 +554,20 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_c(WorldView W, int 
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) W.counters[CTR_ATTACK] = before + sums[blockIdx.x];
 }
 
-__device__ __forceinline__ void set_action_solo_body(const WorldView &W, int g, const int *actions, int call_base) {
-    const GroupDev &G = W.grp[g];
-    const TypeDev &T = W.type[g];
-    const int base = W.counters[CTR_ATTACK];
+// (takes the group and the type, not the world: indexing the by-value kernel argument with a run-time group number would make
+// the compiler keep a per-lane copy of the whole world description in scratch memory)
+__device__ __forceinline__ void set_action_solo_body(const GroupDev &G, const TypeDev &T, int *counters, int large_map, int bandwidth,
+                                                     const int *actions, int call_base) {
+    const int base = counters[CTR_ATTACK];
     for (int i = threadIdx.x; i < G.n; i += SOLO_THREADS) {
         int act = actions[i];
         G.last_action[i] = act;
         if (act < 0 || act >= T.n_move + T.n_turn + T.n_attack) {
-            W.counters[CTR_BAD_ACTION] = 1;
+            counters[CTR_BAD_ACTION] = 1;
             G.pend[i] = PEND_NONE;
         } else if (act < T.n_move + T.n_turn) {
             unsigned bound = 0;
-            if (W.large_map) { int x_ = G.x[i] % W.bandwidth; bound = (x_ < 4 || x_ > W.bandwidth - 4) ? 1u : 0u; }
+            if (large_map) { int x_ = G.x[i] % bandwidth; bound = (x_ < 4 || x_ > bandwidth - 4) ? 1u : 0u; }
             G.pend[i] = (act < T.n_move ? PEND_MOVE : PEND_TURN) | act;
             G.key[i] = (bound << 31) | (unsigned)(call_base + i);
         } else {
@@ -573,10 +576,12 @@ __device__ __forceinline__ void set_action_solo_body(const WorldView &W, int g, 
     }
     __syncthreads();   // base was read by every thread before the total is written back
     int total = solo_rank([&](int i) { return actions[i] >= T.n_move + T.n_turn; }, [&](int i, int r) { G.key[i] = (unsigned)r; }, G.n, base);
-    if (threadIdx.x == 0) W.counters[CTR_ATTACK] = total;
+    if (threadIdx.x == 0) counters[CTR_ATTACK] = total;
 }
 __global__ void __launch_bounds__(SOLO_THREADS) k_set_action_solo(WorldView W, int g, const int *actions, int call_base) {
-    set_action_solo_body(W, g, actions, call_base);
+    const GroupDev G = W.grp[g];
+    const TypeDev T = W.type[g];
+    set_action_solo_body(G, T, W.counters, W.large_map, W.bandwidth, actions, call_base);
 }
 
 // ------------------------------------------------------------------------------------------------ generic int scan
@@ -1924,6 +1929,27 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int 
     if (threadIdx.x == 0) W.counters[CTR_TAKEN + g] = 0;
 }
 
+// The minimap of the next observations in one workgroup: an LDS histogram of every group (s_hist: [NG][VHW] counts, then
+// [NG] agents left out), then count / total exactly as the reference divides (k_minimap, k_minimap_norm; GridWorld.cc:331-360)
+__device__ __forceinline__ void minimap_one_workgroup(const GroupDev *grp, int NG, const MiniArgs &M, int *s_hist, int nthreads) {
+    const int tid = threadIdx.x, VHW = M.vh * M.vw;
+    for (int k = tid; k < NG * VHW + NG; k += nthreads) s_hist[k] = 0;
+    __syncthreads();
+    for (int g = 0; g < NG; g++) {
+        const GroupDev &G = grp[g];
+        for (int i = tid; i < G.n; i += nthreads) {
+            if (M.skip && G.absorbed[i]) { atomicAdd(&s_hist[NG * VHW + g], 1); continue; }
+            atomicAdd(&s_hist[g * VHW + (G.y[i] / M.scale_h) * M.vw + G.x[i] / M.scale_w], 1);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < NG * VHW; k += nthreads) {
+        const int g = k / VHW;
+        const int tot = grp[g].n - (M.skip ? s_hist[NG * VHW + g] : 0);
+        M.out[k] = tot == 0 ? __int_as_float(0xFFC00000) : __fdiv_rn((float)min(s_hist[k], 1 << 24), (float)(unsigned)tot);
+    }
+}
+
 // ================================================================================================ one-launch step
 // Small worlds are bound by the CHAIN of dependent launches, not by bandwidth: a 4000-agent step was 29 launches of
 // 2-5 us each.  k_step_solo runs the whole of GridWorld::step (GridWorld.cc:456-631) as ONE workgroup of 1024 threads on
@@ -1957,7 +1983,10 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
     // ---- (cycle) set_action of the groups that act, in handle order (GridWorld::set_action: the order of the calls is the
     // order of the lists)
     for (int g = 0; g < NG; g++)
-        if (S.actions[g] && W.grp[g].n > 0) { set_action_solo_body(W, g, S.actions[g], S.call_base[g]); __syncthreads(); }
+        if (S.actions[g] && W.grp[g].n > 0) {
+            set_action_solo_body(W.grp[g], W.type[g], W.counters, W.large_map, W.bandwidth, S.actions[g], S.call_base[g]);
+            __syncthreads();
+        }
     const int A = W.counters[CTR_ATTACK];
     const unsigned x0 = (unsigned)W.counters[CTR_RNG];
     int rounds_attack = 0, rounds_move = 0, error = 0;
@@ -2188,25 +2217,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
         if (tid < MAXG) { S.gtab_out[tid] = s_W.grp[tid]; S.ttab_out[tid] = s_W.type[tid]; }
         // ---- (cycle) the minimap of the next observations: LDS histogram of every group, then count / total exactly as the
         // reference divides (k_minimap, k_minimap_norm)
-        if (S.mini_vh > 0) {
-            int *s_hist = (int *)s_dyn;               // [NG][VHW] counts, then [NG] agents left out (the hit lists are done with)
-            const int VHW = S.mini_vh * S.mini_vw;
-            for (int k = tid; k < NG * VHW + NG; k += SOLO_STEP_THREADS) s_hist[k] = 0;
-            __syncthreads();
-            for (int g = 0; g < NG; g++) {
-                const GroupDev &G = W.grp[g];
-                for (int i = tid; i < G.n; i += SOLO_STEP_THREADS) {
-                    if (S.mini_skip && G.absorbed[i]) { atomicAdd(&s_hist[NG * VHW + g], 1); continue; }
-                    atomicAdd(&s_hist[g * VHW + (G.y[i] / S.mini_scale_h) * S.mini_vw + G.x[i] / S.mini_scale_w], 1);
-                }
-            }
-            __syncthreads();
-            for (int k = tid; k < NG * VHW; k += SOLO_STEP_THREADS) {
-                const int g = k / VHW;
-                const int tot = W.grp[g].n - (S.mini_skip ? s_hist[NG * VHW + g] : 0);
-                S.mini_out[k] = tot == 0 ? __int_as_float(0xFFC00000) : __fdiv_rn((float)min(s_hist[k], 1 << 24), (float)(unsigned)tot);
-            }
-        }
+        if (S.mini.vh > 0) minimap_one_workgroup(W.grp, NG, S.mini, (int *)s_dyn, SOLO_STEP_THREADS);   // (the hit lists are done with)
     }
     SOLO_MARK();       // (cycle) rewards, clear_dead, minimap
 
@@ -2272,16 +2283,21 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_batch(const BatchI
     const RenderPlan P = it.M.P[k];
     RenderWorld V;
     V.w = it.W.w; V.h = it.W.h; V.G = it.W.G; V.viewcell = it.W.viewcell; V.mask = it.W.mask; V.grp = it.W.grp[R.g]; V.type = it.W.type[R.g];
-    if (it.W.vc_packed) render_block<true, true, 1, true>(V, R, P, blockIdx.x, it.M.blocks[k]);
-    else render_block<true, true, 1, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
+    if (it.W.turn_mode) {
+        if (it.W.vc_packed) render_block<true, true, 1, true, true>(V, R, P, blockIdx.x, it.M.blocks[k]);
+        else render_block<true, true, 1, false, true>(V, R, P, blockIdx.x, it.M.blocks[k]);
+    } else if (it.W.vc_packed) render_block<true, true, 1, true, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
+    else render_block<true, true, 1, false, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
 }
 
 // clear_dead for every group of a small world in ONE launch of one workgroup (GridWorld::clear_dead, GridWorld.cc:633-665):
 // stable compaction of the survivors into the alternate buffers + Agent::init_reward + re-indexing of the map (groups with
 // deaths), Agent::init_reward alone (groups without); then the death counters and the device copy of the group table
 // (the double-buffered arrays have changed places: ClearArgs::dst become the current ones).
-__global__ void __launch_bounds__(SOLO_THREADS) k_clear_solo_all(WorldView W, ClearArgs A, GroupDev *gtab, TypeDev *ttab) {
+__global__ void __launch_bounds__(SOLO_THREADS) k_clear_solo_all(WorldView W, ClearArgs A, GroupDev *gtab, TypeDev *ttab, MiniArgs M) {
+    extern __shared__ int s_hist[];
     __shared__ int s_alive[MAXG];
+    __shared__ GroupDev s_new[MAXG];
     for (int g = 0; g < W.G; g++) {
         const GroupDev &G = W.grp[g];
         const float step_reward = W.type[g].step_reward;
@@ -2319,6 +2335,11 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_clear_solo_all(WorldView W, Cl
             N.n = s_alive[g];
         }
         gtab[g] = N; ttab[g] = W.type[g];
+        s_new[g] = N;
+    }
+    if (M.vh > 0) {      // the minimap of the next observations (they will find it made)
+        __syncthreads();
+        minimap_one_workgroup(s_new, W.G, M, s_hist, SOLO_THREADS);
     }
 }
 
@@ -2360,9 +2381,14 @@ void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const
     size_t lds = (size_t)RENDER_WAVES * P.strip_floats * sizeof(float);
     dim3 grid(P.spans + P.feat_blocks), block(64 * RENDER_WAVES);
     const bool packed = W.vc_packed != 0;   // must match launch_paint
-#define RENDER_LAUNCH(V, N, UU, PK) hipLaunchKernelGGL((k_render<V, N, UU, PK>), grid, block, lds, s, W, R, P)
+#define RENDER_LAUNCH(V, N, UU, PK) hipLaunchKernelGGL((k_render<V, N, UU, PK, false>), grid, block, lds, s, W, R, P)
 #define RENDER_PK(V, N, UU) do { if (packed) RENDER_LAUNCH(V, N, UU, true); else RENDER_LAUNCH(V, N, UU, false); } while (0)
-    if (!vec4) RENDER_PK(false, false, 1);
+    if (R.turn) {      // turn_mode: one step per wave iteration, scalar or 16-byte stores
+        if (vec4 && packed) hipLaunchKernelGGL((k_render<true, true, 1, true, true>), grid, block, lds, s, W, R, P);
+        else if (vec4) hipLaunchKernelGGL((k_render<true, true, 1, false, true>), grid, block, lds, s, W, R, P);
+        else if (packed) hipLaunchKernelGGL((k_render<false, false, 1, true, true>), grid, block, lds, s, W, R, P);
+        else hipLaunchKernelGGL((k_render<false, false, 1, false, true>), grid, block, lds, s, W, R, P);
+    } else if (!vec4) RENDER_PK(false, false, 1);
     else if (P.unroll == 2) { if (nt) RENDER_PK(true, true, 2); else RENDER_PK(true, false, 2); }
     else if (P.unroll == 4) { if (nt) RENDER_PK(true, true, 4); else RENDER_PK(true, false, 4); }
     else { if (nt) RENDER_PK(true, true, 1); else RENDER_PK(true, false, 1); }
@@ -2576,8 +2602,9 @@ void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A,
 void launch_step_solo(hipStream_t s, const WorldView &W, const SoloStep &S) {
     hipLaunchKernelGGL(k_step_solo, dim3(1), dim3(SOLO_STEP_THREADS), solo_step_lds(W, S), s, W, S);
 }
-void launch_clear_solo_all(hipStream_t s, const WorldView &W, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab) {
-    hipLaunchKernelGGL(k_clear_solo_all, dim3(1), dim3(SOLO_THREADS), 0, s, W, A, gtab, ttab);
+void launch_clear_solo_all(hipStream_t s, const WorldView &W, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab, const MiniArgs &M) {
+    const size_t lds = M.vh > 0 ? sizeof(int) * ((size_t)W.G * M.vh * M.vw + W.G) : 0;
+    hipLaunchKernelGGL(k_clear_solo_all, dim3(1), dim3(SOLO_THREADS), lds, s, W, A, gtab, ttab, M);
 }
 void launch_cycle_batch(hipStream_t s, const BatchItem *d_items, int n_env, int slots, int max_blocks, size_t render_lds, size_t step_lds) {
     if (slots > 0 && max_blocks > 0)
@@ -2587,7 +2614,7 @@ void launch_cycle_batch(hipStream_t s, const BatchItem *d_items, int n_env, int 
 size_t render_strip_lds(const RenderPlan &P) { return (size_t)RENDER_WAVES * P.strip_floats * sizeof(float); }
 size_t solo_step_lds(const WorldView &W, const SoloStep &S) {
     size_t lds = (size_t)S.kmax * S.nt_eval * 8;
-    if (S.mini_vh > 0) lds = std::max(lds, sizeof(int) * ((size_t)W.G * S.mini_vh * S.mini_vw + W.G));
+    if (S.mini.vh > 0) lds = std::max(lds, sizeof(int) * ((size_t)W.G * S.mini.vh * S.mini.vw + W.G));
     return lds;
 }
 int solo_step_static_lds() {   // static LDS of k_step_solo (tables, scan scratch): taken off the budget of the hit lists

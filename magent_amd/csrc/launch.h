@@ -65,6 +65,12 @@ struct RuleProg {
 // alternate copies of the arrays that survive clear_dead (compaction is a stable scatter into them, then they change places)
 struct AltArrays { int *x, *y, *id, *last_action; float *hp, *next_reward, *last_reward; unsigned char *absorbed; int *dir; };
 
+// the minimap of the next observations, made by the launch that ends a cycle (vh == 0: not asked for)
+struct MiniArgs {
+    int vh, vw, scale_w, scale_h, skip;
+    float *out;                    // float[G][vh * vw]
+};
+
 // the one-launch step of small worlds (k_step_solo)
 struct SoloStep {
     int *sj, *scount, *soff, *scur, *slist, *rank;   // shuffle scratch (count / cursor zero between steps)
@@ -85,8 +91,7 @@ struct SoloStep {
     int do_clear;                  // clear_dead after that, into `dst`; the device tables are refreshed
     AltArrays dst[MAXG];
     GroupDev *gtab_out; TypeDev *ttab_out;
-    int mini_vh, mini_vw, mini_scale_w, mini_scale_h, mini_skip;   // mini_vh > 0: the minimap of the next observations ...
-    float *mini_out;                                               // ... float[G][mini_vh * mini_vw]
+    MiniArgs mini;                 // the minimap of the next observations
 };
 
 // one environment of a batched cycle launch (env_cycle_many: one workgroup of k_step_solo_batch per environment)
@@ -140,7 +145,7 @@ struct ClearArgs {
 };
 void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A, int *sums);
 void launch_clear_finish(hipStream_t s, const WorldView &Wnew, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab);
-void launch_clear_solo_all(hipStream_t s, const WorldView &W, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab);
+void launch_clear_solo_all(hipStream_t s, const WorldView &W, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab, const MiniArgs &M);
 bool compact_is_solo(int n);
 bool attack_lds_ok(int kmax);
 void launch_step_solo(hipStream_t s, const WorldView &W, const SoloStep &S);

@@ -66,7 +66,7 @@ class ObservationGather(object):
             self._done = torch.cuda.Event()
         else:
             self.stream = None
-        self._posted = True
+        self._posted, self._view, self._n = True, None, 0
 
     # -- step 1: the counts (and, for GPUs, the hand-over from the producer's stream)
     def launch(self, view, n, producer_stream=None):
@@ -144,6 +144,8 @@ class ObservationGather(object):
 
     def shards(self):
         """per-replica views of the gathered rows, trimmed to each replica's count (own rows: the send tensor itself)"""
+        if self._view is None:         # nothing has been exchanged yet
+            return []
         out = []
         for r in range(self.world):
             out.append(self._view[:self._n] if r == self.rank else self.recv[r, :self.counts[r]])

@@ -75,8 +75,9 @@ struct Range {
         height = (int)(radius + 0.5);
         width = (int)(2 * radius * sin(angle / 2 * (PI / 180)) + 0.5);
         if (width % 2 != parity) width--;
-        if (width < 0 || (width == 0 && height > 0)) fatal("sector range too narrow: the reference allocates a non-positive array here");
-        in.assign((size_t)width * height, 0);
+        // (radius 0 -- a type without attack range: height 0, width -1 after the parity step; no cell, no action)
+        if (height > 0 && width <= 0) fatal("sector range too narrow: the reference allocates a non-positive array here");
+        in.assign(height > 0 ? (size_t)width * height : 0, 0);
         dx.clear(); dy.clear(); count = 0;
         const double eps = 0.00001;
         for (int i = 0; i < height; i++)

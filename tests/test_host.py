@@ -179,3 +179,21 @@ def test_font_provider_and_random_actor(tmp_path):
     obs = (np.zeros((50, 3, 3, 2), np.float32), np.zeros((50, 4), np.float32))
     x, y = a.infer_action(obs), b.infer_action(obs)
     assert x.dtype == np.int32 and x.shape == (50,) and x.min() >= 0 and x.max() < 9 and np.array_equal(x, y)
+
+
+def test_no_kernel_keeps_the_world_in_scratch(hip_lib):
+    """the compiler's resource report of the build (magent_amd/lib/kernel_resources.txt): indexing the by-value world description
+    with a per-lane value makes it keep a private copy in scratch memory, 2 KB per lane -- a 15x slowdown that no parity test
+    sees.  Every kernel stays within a few bytes of scratch, and the render kernel within its register budget."""
+    import re
+    path = os.path.join(os.path.dirname(hip_lib), "kernel_resources.txt")
+    assert os.path.exists(path), "run __graft_entry__.build()"
+    text = open(path).read()
+    names = re.findall(r"Function Name: (\S+)", text)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]
+    vgprs = [int(x) for x in re.findall(r"remark:\s+VGPRs: (\d+)", text)]
+    assert len(names) == len(scratch) == len(vgprs) and len(names) > 60
+    for n, sc in zip(names, scratch):
+        assert sc <= 16, (n, sc)
+    render = [v for n, v in zip(names, vgprs) if "k_renderILb1ELb1ELi1ELb1ELb0" in n]
+    assert render and max(render) <= 96, render      # 5 waves per SIMD (the measured sweet spot of the store-bound kernel)
