@@ -41,6 +41,42 @@ namespace magent_amd {
         if (e_ != hipSuccess) fatal("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// ------------------------------------------------------------------------------------------------ device memory
+// Small device arrays are carved from a few large blocks per environment instead of one hipMalloc each: an environment has
+// ~100 of them (30 per group, the map arrays, tables, scratch) -- one allocation call instead of a hundred when a world is
+// created, and the state of a small world contiguous in memory.  (Requests above 1 MiB keep their own hipMalloc.)
+void *DevArena::take(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (used + bytes > BLOCK) {
+        char *blk = nullptr;
+        HIP_OK(hipMalloc(&blk, BLOCK));
+        blocks.push_back(blk);
+        used = 0;
+    }
+    void *p = blocks.back() + used;
+    used += bytes;
+    return p;
+}
+bool DevArena::owns(const void *p) const {
+    for (char *b : blocks) if ((const char *)p >= b && (const char *)p < b + BLOCK) return true;
+    return false;
+}
+void DevArena::release() {
+    for (char *b : blocks) (void)hipFree(b);
+    blocks.clear();
+    used = BLOCK;
+}
+static thread_local DevArena *g_arena = nullptr;   // the arena of the environment the calling thread is working on (Env::use_device)
+template <class T>
+static hipError_t dev_malloc(T **p, size_t bytes) {
+    if (g_arena && bytes <= DevArena::SMALL) { *p = (T *)g_arena->take(bytes ? bytes : 1); return hipSuccess; }
+    return hipMalloc(p, bytes);
+}
+static void dev_free(void *p) {
+    if (g_arena && g_arena->owns(p)) return;      // (arena memory goes back with the environment)
+    (void)hipFree(p);
+}
+
 // ------------------------------------------------------------------------------------------------ ranges / types
 // CircleRange of the reference (Range.h:149-190): double arithmetic and eps constants reproduced exactly
 void HostRange::circle(float radius, float inner_radius, int parity) {
@@ -235,7 +271,7 @@ Env::Env() {
 
 template <class T>
 static void dfree(T *&p) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { dev_free(p); p = nullptr; }
 }
 
 Env::~Env() {
@@ -260,9 +296,11 @@ Env::~Env() {
     for (auto &kv : prof) for (auto &p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto ev : prof_pool) (void)hipEventDestroy(ev);
     stream_owner.reset();   // (the stream goes when its last user does)
+    arena.release();
+    g_arena = nullptr;
 }
 
-void Env::use_device() { HIP_OK(hipSetDevice(device_id)); }
+void Env::use_device() { HIP_OK(hipSetDevice(device_id)); g_arena = &arena; }
 
 void Env::init_device() {
     if (device_ready) return;
@@ -274,10 +312,10 @@ void Env::init_device() {
     use_device();
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     stream_owner = std::shared_ptr<void>((void *)stream, [](void *p) { (void)hipStreamDestroy((hipStream_t)p); });
-    HIP_OK(hipMalloc(&d_counters, sizeof(int) * CTR_TOTAL));
+    HIP_OK(dev_malloc(&d_counters, sizeof(int) * CTR_TOTAL));
     HIP_OK(hipMemset(d_counters, 0, sizeof(int) * CTR_TOTAL));
-    HIP_OK(hipMalloc(&d_gtab, sizeof(GroupDev) * MAXG));
-    HIP_OK(hipMalloc(&d_ttab, sizeof(TypeDev) * MAXG));
+    HIP_OK(dev_malloc(&d_gtab, sizeof(GroupDev) * MAXG));
+    HIP_OK(dev_malloc(&d_ttab, sizeof(TypeDev) * MAXG));
     HIP_OK(hipHostMalloc((void **)&h_counters, sizeof(int) * CTR_TOTAL, hipHostMallocDefault));
     HIP_OK(hipHostMalloc((void **)&h_rec, sizeof(StepRecord), hipHostMallocDefault));   // (default = coherent, device-visible)
     std::memset(h_rec, 0, sizeof(StepRecord));
@@ -748,11 +786,11 @@ static void grow(T *&p, size_t &cap, size_t need, hipStream_t stream, bool keep 
     if (need <= cap) return;
     size_t ncap = std::max(need, cap * 2);
     T *q = nullptr;
-    HIP_OK(hipMalloc(&q, sizeof(T) * ncap));
+    HIP_OK(dev_malloc(&q, sizeof(T) * ncap));
     if (p) {
         HIP_OK(hipStreamSynchronize(stream));
         if (keep && keep_n) HIP_OK(hipMemcpy(q, p, sizeof(T) * keep_n, hipMemcpyDeviceToDevice));
-        HIP_OK(hipFree(p));
+        dev_free(p);
     }
     p = q; cap = ncap;
 }
@@ -770,9 +808,9 @@ void Env::free_group(HostGroup &g) {
 template <class T>
 static void regrow(T *&p, size_t old_n, size_t ncap) {
     T *q = nullptr;
-    HIP_OK(hipMalloc(&q, sizeof(T) * ncap));
+    HIP_OK(dev_malloc(&q, sizeof(T) * ncap));
     if (p && old_n) HIP_OK(hipMemcpy(q, p, sizeof(T) * old_n, hipMemcpyDeviceToDevice));
-    if (p) HIP_OK(hipFree(p));
+    if (p) dev_free(p);
     p = q;
 }
 
@@ -854,16 +892,16 @@ void Env::reset() {
     const size_t ncell = (size_t)width * height;
     if (ncell != map_cells) {
         dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_hit);
-        HIP_OK(hipMalloc(&d_occ, sizeof(int) * ncell));
-        HIP_OK(hipMalloc(&d_viewcell, sizeof(int2) * ncell));
-        HIP_OK(hipMalloc(&d_claim, sizeof(unsigned long long) * ncell));
-        HIP_OK(hipMalloc(&d_hit, sizeof(unsigned) * ncell));
+        HIP_OK(dev_malloc(&d_occ, sizeof(int) * ncell));
+        HIP_OK(dev_malloc(&d_viewcell, sizeof(int2) * ncell));
+        HIP_OK(dev_malloc(&d_claim, sizeof(unsigned long long) * ncell));
+        HIP_OK(dev_malloc(&d_hit, sizeof(unsigned) * ncell));
         dfree(d_food);
         map_cells = ncell;
     }
     HIP_OK(hipMemset(d_hit, 0, sizeof(unsigned) * ncell));
     claim_clean = false;
-    if (food_mode && !d_food) HIP_OK(hipMalloc(&d_food, sizeof(float) * 2 * ncell));   // amounts, then the attack phase's scratch
+    if (food_mode && !d_food) HIP_OK(dev_malloc(&d_food, sizeof(float) * 2 * ncell));   // amounts, then the attack phase's scratch
     if (d_food) HIP_OK(hipMemset(d_food, 0, sizeof(float) * 2 * ncell));
     h_occ.assign(ncell, OCC_EMPTY);
     for (int i = 0; i < width; i++) { h_occ[i] = OCC_WALL; h_occ[(size_t)(height - 1) * width + i] = OCC_WALL; }
@@ -933,8 +971,8 @@ void Env::reset() {
     if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
     if (n_channel() > 32) fatal("too many observation channels");
     dfree(d_delta); dfree(d_mask);
-    HIP_OK(hipMalloc(&d_delta, sizeof(int2) * std::max<size_t>(delta.size(), 1)));
-    HIP_OK(hipMalloc(&d_mask, std::max<size_t>(mask.size(), 1)));
+    HIP_OK(dev_malloc(&d_delta, sizeof(int2) * std::max<size_t>(delta.size(), 1)));
+    HIP_OK(dev_malloc(&d_mask, std::max<size_t>(mask.size(), 1)));
     if (!delta.empty()) HIP_OK(hipMemcpy(d_delta, delta.data(), sizeof(int2) * delta.size(), hipMemcpyHostToDevice));
     if (!mask.empty()) HIP_OK(hipMemcpy(d_mask, mask.data(), mask.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemset(d_counters, 0, sizeof(int) * CTR_TOTAL));
@@ -944,8 +982,8 @@ void Env::reset() {
         compile_rules();
         rules_compiled = true;
         dfree(d_rule_args); dfree(d_rule_progs);
-        HIP_OK(hipMalloc(&d_rule_args, sizeof(RuleArgs) * std::max<size_t>(rule_args.size(), 1)));
-        HIP_OK(hipMalloc(&d_rule_progs, sizeof(RuleProg) * std::max<size_t>(rule_progs.size(), 1)));
+        HIP_OK(dev_malloc(&d_rule_args, sizeof(RuleArgs) * std::max<size_t>(rule_args.size(), 1)));
+        HIP_OK(dev_malloc(&d_rule_progs, sizeof(RuleProg) * std::max<size_t>(rule_progs.size(), 1)));
         if (!rule_args.empty()) HIP_OK(hipMemcpy(d_rule_args, rule_args.data(), sizeof(RuleArgs) * rule_args.size(), hipMemcpyHostToDevice));
         if (!rule_progs.empty()) HIP_OK(hipMemcpy(d_rule_progs, rule_progs.data(), sizeof(RuleProg) * rule_progs.size(), hipMemcpyHostToDevice));
     }
@@ -1722,7 +1760,7 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         dfree(lead.batch_d);
         lead.batch_cap = std::max<size_t>((size_t)n_env, lead.batch_cap * 2);
         HIP_OK(hipHostMalloc((void **)&lead.batch_h, sizeof(BatchItem) * lead.batch_cap, hipHostMallocDefault));
-        HIP_OK(hipMalloc(&lead.batch_d, sizeof(BatchItem) * lead.batch_cap));
+        HIP_OK(dev_malloc(&lead.batch_d, sizeof(BatchItem) * lead.batch_cap));
     }
     std::vector<int> in_batch, alone;
     for (int e = 0; e < n_env; e++) {

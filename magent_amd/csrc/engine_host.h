@@ -30,6 +30,16 @@ struct MinStd {
     }
 };
 
+// bump allocator over large device blocks for the many small arrays of an environment (engine.hip: "device memory")
+struct DevArena {
+    static constexpr size_t BLOCK = 8u << 20, SMALL = 1u << 20;   // requests up to 1 MiB are carved from 8 MiB blocks
+    std::vector<char *> blocks;
+    size_t used = BLOCK;
+    void *take(size_t bytes);
+    bool owns(const void *p) const;
+    void release();
+};
+
 struct HostRange {
     int width = 0, height = 0, count = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0;
     std::vector<unsigned char> in;
@@ -122,6 +132,7 @@ public:
     void profile_read(const char *name, int *n, float *ms);
 
     hipStream_t stream{};
+    DevArena arena;
     std::shared_ptr<void> stream_owner;   // environments cycled together share one stream (Env::adopt_stream)
     int attack_round = 0;        // rounds of the attack fixed point launched in the current step (k_attack_eval)
     int prof_level = 0;          // 0 off, 1 every named phase, 2 only the observation render launches

@@ -713,7 +713,10 @@ __global__ void __launch_bounds__(256) k_shuffle_chase(const int *counters, cons
 
 // ------------------------------------------------------------------------------------------------ attack phase
 // rank[seq] = position of attack-list entry `seq` after the reference's shuffle (GridWorld.cc:464-468)
-__device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int i, const int *rank, unsigned *hitbits) {
+// (tlist / n_tlist, one-launch step with one-cell bodies: the attacker that sets the FIRST bit of a cell appends the agent standing
+// there -- every target exactly once -- and the evaluation rounds visit the targets instead of scanning every agent)
+__device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int i, const int *rank, unsigned *hitbits, int *tlist = nullptr,
+                                                 int *n_tlist = nullptr) {
     const GroupDev &G = W.grp[g];
     const TypeDev &T = W.type[g];
     const int pend = G.pend[i];
@@ -732,8 +735,10 @@ __device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int 
             int o = W.occ[ty * W.w + tx];
             // Map::get_attack_obj (Map.cc:229-247).  In food_mode an attack aimed at a comrade is recorded too: it does no
             // damage, but once the comrade has been killed the food it leaves can be eaten by anybody
-            if ((o >= 0 && (T.attack_in_group || ref_group(o) != g || W.food_mode)) || o == OCC_FOOD)
-                atomicOr(&hitbits[ty * W.w + tx], 1u << (T.attack_bit + k));
+            if ((o >= 0 && (T.attack_in_group || ref_group(o) != g || W.food_mode)) || o == OCC_FOOD) {
+                if (!tlist) atomicOr(&hitbits[ty * W.w + tx], 1u << (T.attack_bit + k));
+                else if (atomicOr(&hitbits[ty * W.w + tx], 1u << (T.attack_bit + k)) == 0u) tlist[atomicAdd(n_tlist, 1)] = o;
+            }
         }
     }
     if (W.food_mode) { G.eat[i] = -1.0f; G.fcell[i] = -1; }
@@ -2009,7 +2014,12 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
         SOLO_MARK();   // 4: chase
         // ---- ranks, hit bits; the shuffle's bucket counters go back to zero
         for (int k = tid; k < A; k += SOLO_STEP_THREADS) { S.scount[k] = 0; S.scur[k] = 0; }
-        SOLO_EACH(g, i) attack_rank_body(W, g, i, S.rank, S.hit);
+        // (one-cell bodies: the targets are listed as they are hit -- in the shuffle's list array, free by now)
+        __shared__ int s_ntgt;
+        const bool listed = !W.any_multicell;
+        if (tid == 0) s_ntgt = 0;
+        __syncthreads();
+        SOLO_EACH(g, i) attack_rank_body(W, g, i, S.rank, S.hit, listed ? S.slist : nullptr, &s_ntgt);
         __syncthreads();
         SOLO_MARK();   // 5: rank
         // ---- death ranks: in-place fixed point, one round per barrier pair
@@ -2021,7 +2031,13 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
             rounds_attack++;
             int *flag = &s_flags[rounds_attack % 3];
             if (tid == 0) s_flags[(rounds_attack + 1) % 3] = 0;
-            if (tid < S.nt_eval)
+            if (listed) {
+                if (tid < S.nt_eval)
+                    for (int j = tid, n = s_ntgt; j < n; j += S.nt_eval) {
+                        const int o = S.slist[j];
+                        attack_eval_body(W, gtab, ttab, ref_group(o), ref_index(o), rounds_attack, S.hit, s_rank, s_ref, S.nt_eval, tid, flag, S.kmax);
+                    }
+            } else if (tid < S.nt_eval)
                 for (int g = 0; g < NG; g++)
                     for (int i = tid, n = W.grp[g].n; i < n; i += S.nt_eval)
                         attack_eval_body(W, gtab, ttab, g, i, rounds_attack, S.hit, s_rank, s_ref, S.nt_eval, tid, flag, S.kmax);
@@ -2034,8 +2050,9 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
         SOLO_EACH(g, i) attack_apply_body(W, gtab, ttab, g, i, S.hit);
         __syncthreads();
         SOLO_MARK();   // 7: apply
-        // ---- the hit words back to zero: every attacker resets the word it may have set
-        SOLO_EACH(g, i) {
+        // ---- the hit words back to zero: every attacker resets the word it may have set (one-cell bodies: in the next phase's loop;
+        // generic bodies use the same array for their `wanted` counters there, so they need it clean first)
+        if (W.any_multicell) SOLO_EACH(g, i) {
             const int pend = W.grp[g].pend[i];
             if ((pend & ~PEND_ARG) == PEND_ATTACK) {
                 const int2 tc = attack_target(W, W.grp[g], W.type[g], i, pend & PEND_ARG);
@@ -2043,14 +2060,23 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
                 if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) S.hit[ty * W.w + tx] = 0u;
             }
         }
-        __syncthreads();
+        if (W.any_multicell) __syncthreads();
     }
     if (tid == 0) W.counters[CTR_LAST_A] = A;
     SOLO_MARK();       // 8: hit words reset
 
     // ---- starve / recover, then the moves
     if (!W.any_multicell) {
-        SOLO_EACH_UNIFORM(g, i) move_prep_body(W, g, i, 0);
+        SOLO_EACH_UNIFORM(g, i) {
+            if (A > 0 && i < W.grp[g].n) {      // (the attack phase's hit word of this agent's own attack)
+                const int pend = W.grp[g].pend[i];
+                if ((pend & ~PEND_ARG) == PEND_ATTACK) {
+                    const int2 tc = attack_target(W, W.grp[g], W.type[g], i, pend & PEND_ARG);
+                    if (tc.x >= 0 && tc.x < W.w && tc.y >= 0 && tc.y < W.h) S.hit[tc.y * W.w + tc.x] = 0u;
+                }
+            }
+            move_prep_body(W, g, i, 0);
+        }
         __syncthreads();
         SOLO_MARK();   // 9: starve + move candidates
         SOLO_EACH(g, i) move_claim_body(W, gtab, g, i);
