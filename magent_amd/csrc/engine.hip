@@ -847,7 +847,7 @@ WorldView Env::view() const {
     W.turn_mode = turn_mode ? 1 : 0;
     W.reach = map_reach;
     W.vc_packed = (groups.size() <= 3 && !any_absorb) ? 1 : 0;
-    W.live_paint = 0;
+    W.live_paint = live_paint_now ? 1 : 0;   // (set for the length of a step whose painted map was current at its start)
     for (int g = 0; g < W.G; g++) {
         W.type[g] = groups[g].tdev;
         W.grp[g] = groups[g].cur;
@@ -1394,6 +1394,7 @@ void Env::step_begin() {
     if (step_pending) fatal("step_begin called twice without step_end");
     use_device();
     ensure_tables();
+    step_live_paint = live_paint_now = paint_valid;   // the painted map is current: every driver of the step keeps it so
     WorldView W = view();
     int total_n = 0;
     for (auto &g : groups) total_n += g.n;
@@ -1416,8 +1417,6 @@ void Env::step_begin() {
             HIP_OK(hipMemsetAsync(d_claim, 0xFF, sizeof(unsigned long long) * (size_t)width * height, stream));
             claim_clean = true;
         }
-        step_live_paint = paint_valid;      // the painted map is current: the step keeps it so
-        W.live_paint = step_live_paint ? 1 : 0;
         const size_t seg = shuf_cap / 5;
         SoloStep S{};
         S.scount = d_shuf; S.scur = d_shuf + seg; S.sj = d_shuf + 2 * seg; S.soff = d_shuf + 3 * seg; S.slist = d_shuf + 4 * seg;
@@ -1564,6 +1563,7 @@ void Env::step_end(int *done) {
         move_seq_base = 0;
         h_occ_valid = false;
         paint_valid = step_live_paint; mini_valid = false;
+        live_paint_now = false;
         return;
     }
     HIP_OK(hipStreamSynchronize(stream));
@@ -1606,7 +1606,8 @@ void Env::step_end(int *done) {
     HIP_OK(hipGetLastError());
     move_seq_base = 0;
     h_occ_valid = false;
-    paint_valid = false; mini_valid = false;
+    paint_valid = step_live_paint; mini_valid = false;
+    live_paint_now = false;
 }
 
 // ------------------------------------------------------------------------------------------------ one cycle, two launches
@@ -1653,7 +1654,7 @@ bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, con
         HIP_OK(hipMemsetAsync(d_claim, 0xFF, sizeof(unsigned long long) * (size_t)width * height, stream));
         claim_clean = true;
     }
-    step_live_paint = paint_valid;
+    step_live_paint = live_paint_now = paint_valid;
     W.live_paint = step_live_paint ? 1 : 0;
     const size_t seg = shuf_cap / 5;
     SoloStep &S = item.S;
@@ -1719,6 +1720,7 @@ void Env::cycle_finish(int *done) {
     h_occ_valid = false;
     tables_valid = true;
     paint_valid = step_live_paint;
+    live_paint_now = false;
     mini_valid = cyc_next_mini;
     if (cyc_next_mini) { mini_vh = cyc_mini_vh; mini_vw = cyc_mini_vw; mini_skip = cyc_mini_skip; mini_pop = mini_population(cyc_mini_skip); }
 }

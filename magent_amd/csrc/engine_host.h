@@ -175,7 +175,7 @@ private:
     std::vector<unsigned char> host_triggers;
     void compile_rule_program(size_t k);
     void enqueue_counters();
-    bool step_pending = false, step_was_fast = false, step_was_solo = false, step_live_paint = false;
+    bool step_pending = false, step_was_fast = false, step_was_solo = false, step_live_paint = false, live_paint_now = false;
     bool solo_ok(int total_n);
     bool cycle_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, BatchItem &item);
     void cycle_finish(int *done);

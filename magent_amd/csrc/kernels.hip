@@ -992,7 +992,7 @@ __global__ void __launch_bounds__(256) k_food_apply(WorldView W, const unsigned 
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= W.w * W.h || W.occ[c] != OCC_FOOD || !hitbits[c]) return;
     const float left = W.food_next[c];
-    if (left < 0.0f) W.occ[c] = OCC_EMPTY; else W.food[c] = left;
+    if (left < 0.0f) { W.occ[c] = OCC_EMPTY; if (W.live_paint) vc_store(W, c, OCC_EMPTY, 0u); } else W.food[c] = left;
 }
 
 // The converged phase applied: hp, death, rewards, last_op / op_obj.  Nothing is replayed here: every agent that is hit
@@ -1097,7 +1097,10 @@ __device__ __forceinline__ void starve_body(const WorldView &W, int g, const Gro
             died = true;
             const int2 fp = body_dims(W, G, T, i);
             cells_clear(W, G.x[i], G.y[i], fp.x, fp.y);
-            if (W.food_mode && G.fcell[i] >= 0) { W.occ[G.fcell[i]] = OCC_FOOD; W.food[G.fcell[i]] = G.fleft[i]; }   // Map.cc:276-283
+            if (W.food_mode && G.fcell[i] >= 0) {   // Map.cc:276-283
+                W.occ[G.fcell[i]] = OCC_FOOD; W.food[G.fcell[i]] = G.fleft[i];
+                if (W.live_paint) vc_store(W, G.fcell[i], OCC_FOOD, 0u);
+            }
         }
     }
     if (i < G.n && !G.dead[i]) {
@@ -1240,10 +1243,15 @@ __device__ __forceinline__ void move_commit_body(const WorldView &W, const Group
     }
     G.pend[i] = PEND_NONE;   // end of step: pending actions are consumed (also done by k_finish for the generic path)
 }
+// (multi-launch driver: the last launch of the move phase also keeps the painted map current -- every live agent paints its
+// cell; the cells that were left were emptied where they were left.  No cell has two writers: a cell somebody enters is not
+// emptied by the one who left it, see above)
 __global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev *gtab) {
     if (step_open(W)) return;
     const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < W.grp[g].n) move_commit_body(W, gtab, g, i);
+    if (i >= W.grp[g].n) return;
+    move_commit_body(W, gtab, g, i);
+    if (W.live_paint) repaint_body(W, W.grp[g], W.type[g], g, i);
 }
 
 // ------------------------------------------------------------------------------------------------ move, generic bodies
@@ -1832,7 +1840,9 @@ __global__ void __launch_bounds__(256) k_finish(WorldView W) {
     if (step_open(W)) return;
     const GroupDev G = W.grp[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < G.n) G.pend[i] = PEND_NONE;
+    if (i >= G.n) return;
+    G.pend[i] = PEND_NONE;
+    if (W.live_paint) repaint_body(W, G, W.type[blockIdx.y], blockIdx.y, i);   // (generic bodies: after every enter / absorb of the step)
 }
 
 // ------------------------------------------------------------------------------------------------ small gathers
