@@ -66,14 +66,14 @@ void DevArena::release() {
     blocks.clear();
     used = BLOCK;
 }
-static thread_local DevArena *g_arena = nullptr;   // the arena of the environment the calling thread is working on (Env::use_device)
+// (every allocation names the arena of the environment it belongs to: an environment only ever frees what it allocated)
 template <class T>
-static hipError_t dev_malloc(T **p, size_t bytes) {
-    if (g_arena && bytes <= DevArena::SMALL) { *p = (T *)g_arena->take(bytes ? bytes : 1); return hipSuccess; }
+static hipError_t dev_malloc(DevArena &arena, T **p, size_t bytes) {
+    if (bytes <= DevArena::SMALL) { *p = (T *)arena.take(bytes ? bytes : 1); return hipSuccess; }
     return hipMalloc(p, bytes);
 }
-static void dev_free(void *p) {
-    if (g_arena && g_arena->owns(p)) return;      // (arena memory goes back with the environment)
+static void dev_free(DevArena &arena, void *p) {
+    if (arena.owns(p)) return;      // (arena memory goes back with the environment)
     (void)hipFree(p);
 }
 
@@ -270,8 +270,8 @@ Env::Env() {
 }
 
 template <class T>
-static void dfree(T *&p) {
-    if (p) { dev_free(p); p = nullptr; }
+static void dfree(DevArena &arena, T *&p) {
+    if (p) { dev_free(arena, p); p = nullptr; }
 }
 
 Env::~Env() {
@@ -279,10 +279,10 @@ Env::~Env() {
     use_device();
     (void)hipStreamSynchronize(stream);
     for (auto &g : groups) free_group(g);
-    dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_food); dfree(d_powtab); dfree(d_counters); dfree(d_gtab); dfree(d_ttab);
-    dfree(d_delta); dfree(d_mask); dfree(d_mini); dfree(d_minif); dfree(d_sums); dfree(d_rank); dfree(d_shuf); dfree(d_events); dfree(d_actions);
-    dfree(d_stage_view); dfree(d_stage_feat); dfree(d_stage_small);
-    dfree(d_hit); dfree(d_rule_args); dfree(d_rule_progs); dfree(batch_d);
+    dfree(arena, d_occ); dfree(arena, d_viewcell); dfree(arena, d_claim); dfree(arena, d_food); dfree(arena, d_powtab); dfree(arena, d_counters); dfree(arena, d_gtab); dfree(arena, d_ttab);
+    dfree(arena, d_delta); dfree(arena, d_mask); dfree(arena, d_mini); dfree(arena, d_minif); dfree(arena, d_sums); dfree(arena, d_rank); dfree(arena, d_shuf); dfree(arena, d_events); dfree(arena, d_actions);
+    dfree(arena, d_stage_view); dfree(arena, d_stage_feat); dfree(arena, d_stage_small);
+    dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d);
     if (batch_h) (void)hipHostFree(batch_h);
     if (h_rec) (void)hipHostFree(h_rec);
     if (pool) {
@@ -297,10 +297,9 @@ Env::~Env() {
     for (auto ev : prof_pool) (void)hipEventDestroy(ev);
     stream_owner.reset();   // (the stream goes when its last user does)
     arena.release();
-    g_arena = nullptr;
 }
 
-void Env::use_device() { HIP_OK(hipSetDevice(device_id)); g_arena = &arena; }
+void Env::use_device() { HIP_OK(hipSetDevice(device_id)); }
 
 void Env::init_device() {
     if (device_ready) return;
@@ -312,10 +311,10 @@ void Env::init_device() {
     use_device();
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     stream_owner = std::shared_ptr<void>((void *)stream, [](void *p) { (void)hipStreamDestroy((hipStream_t)p); });
-    HIP_OK(dev_malloc(&d_counters, sizeof(int) * CTR_TOTAL));
+    HIP_OK(dev_malloc(arena, &d_counters, sizeof(int) * CTR_TOTAL));
     HIP_OK(hipMemset(d_counters, 0, sizeof(int) * CTR_TOTAL));
-    HIP_OK(dev_malloc(&d_gtab, sizeof(GroupDev) * MAXG));
-    HIP_OK(dev_malloc(&d_ttab, sizeof(TypeDev) * MAXG));
+    HIP_OK(dev_malloc(arena, &d_gtab, sizeof(GroupDev) * MAXG));
+    HIP_OK(dev_malloc(arena, &d_ttab, sizeof(TypeDev) * MAXG));
     HIP_OK(hipHostMalloc((void **)&h_counters, sizeof(int) * CTR_TOTAL, hipHostMallocDefault));
     HIP_OK(hipHostMalloc((void **)&h_rec, sizeof(StepRecord), hipHostMallocDefault));   // (default = coherent, device-visible)
     std::memset(h_rec, 0, sizeof(StepRecord));
@@ -782,35 +781,35 @@ void Env::eval_rules_host() {
 
 // ------------------------------------------------------------------------------------------------ device buffers
 template <class T>
-static void grow(T *&p, size_t &cap, size_t need, hipStream_t stream, bool keep = false, size_t keep_n = 0) {
+static void grow(DevArena &arena, T *&p, size_t &cap, size_t need, hipStream_t stream, bool keep = false, size_t keep_n = 0) {
     if (need <= cap) return;
     size_t ncap = std::max(need, cap * 2);
     T *q = nullptr;
-    HIP_OK(dev_malloc(&q, sizeof(T) * ncap));
+    HIP_OK(dev_malloc(arena, &q, sizeof(T) * ncap));
     if (p) {
         HIP_OK(hipStreamSynchronize(stream));
         if (keep && keep_n) HIP_OK(hipMemcpy(q, p, sizeof(T) * keep_n, hipMemcpyDeviceToDevice));
-        dev_free(p);
+        dev_free(arena, p);
     }
     p = q; cap = ncap;
 }
 
 void Env::free_group(HostGroup &g) {
     GroupDev &c = g.cur, &a = g.alt;
-    dfree(c.x); dfree(c.y); dfree(c.id); dfree(c.last_action); dfree(c.op_obj); dfree(c.pend); dfree(c.hp);
-    dfree(c.next_reward); dfree(c.last_reward); dfree(c.dead); dfree(c.last_op); dfree(c.key); dfree(c.drank_a);
-    dfree(c.drank_b); dfree(c.mv); dfree(c.hits); dfree(c.absorbed); dfree(a.absorbed); dfree(c.dir); dfree(a.dir);
-    dfree(c.eat); dfree(c.fleft); dfree(c.fcell);
-    dfree(a.x); dfree(a.y); dfree(a.id); dfree(a.last_action); dfree(a.hp); dfree(a.next_reward); dfree(a.last_reward);
+    dfree(arena, c.x); dfree(arena, c.y); dfree(arena, c.id); dfree(arena, c.last_action); dfree(arena, c.op_obj); dfree(arena, c.pend); dfree(arena, c.hp);
+    dfree(arena, c.next_reward); dfree(arena, c.last_reward); dfree(arena, c.dead); dfree(arena, c.last_op); dfree(arena, c.key); dfree(arena, c.drank_a);
+    dfree(arena, c.drank_b); dfree(arena, c.mv); dfree(arena, c.hits); dfree(arena, c.absorbed); dfree(arena, a.absorbed); dfree(arena, c.dir); dfree(arena, a.dir);
+    dfree(arena, c.eat); dfree(arena, c.fleft); dfree(arena, c.fcell);
+    dfree(arena, a.x); dfree(arena, a.y); dfree(arena, a.id); dfree(arena, a.last_action); dfree(arena, a.hp); dfree(arena, a.next_reward); dfree(arena, a.last_reward);
     g.cap = 0; g.n = 0;
 }
 
 template <class T>
-static void regrow(T *&p, size_t old_n, size_t ncap) {
+static void regrow(DevArena &arena, T *&p, size_t old_n, size_t ncap) {
     T *q = nullptr;
-    HIP_OK(dev_malloc(&q, sizeof(T) * ncap));
+    HIP_OK(dev_malloc(arena, &q, sizeof(T) * ncap));
     if (p && old_n) HIP_OK(hipMemcpy(q, p, sizeof(T) * old_n, hipMemcpyDeviceToDevice));
-    if (p) dev_free(p);
+    if (p) dev_free(arena, p);
     p = q;
 }
 
@@ -820,16 +819,16 @@ void Env::ensure_capacity(HostGroup &g, int need) {
     size_t ncap = std::max<size_t>(std::max<size_t>(need, (size_t)g.cap * 2), 1024);
     size_t n = g.n;
     GroupDev &c = g.cur, &a = g.alt;
-    regrow(c.x, n, ncap); regrow(c.y, n, ncap); regrow(c.id, n, ncap); regrow(c.last_action, n, ncap);
-    regrow(c.op_obj, n, ncap); regrow(c.pend, n, ncap); regrow(c.hp, n, ncap); regrow(c.next_reward, n, ncap);
-    regrow(c.last_reward, n, ncap); regrow(c.dead, n, ncap); regrow(c.last_op, n, ncap); regrow(c.key, n, ncap);
-    regrow(c.drank_a, n, ncap); regrow(c.drank_b, n, ncap); regrow(c.mv, n, ncap); regrow(c.hits, n, ncap);
+    regrow(arena, c.x, n, ncap); regrow(arena, c.y, n, ncap); regrow(arena, c.id, n, ncap); regrow(arena, c.last_action, n, ncap);
+    regrow(arena, c.op_obj, n, ncap); regrow(arena, c.pend, n, ncap); regrow(arena, c.hp, n, ncap); regrow(arena, c.next_reward, n, ncap);
+    regrow(arena, c.last_reward, n, ncap); regrow(arena, c.dead, n, ncap); regrow(arena, c.last_op, n, ncap); regrow(arena, c.key, n, ncap);
+    regrow(arena, c.drank_a, n, ncap); regrow(arena, c.drank_b, n, ncap); regrow(arena, c.mv, n, ncap); regrow(arena, c.hits, n, ncap);
     HIP_OK(hipMemset(c.hits, 0, sizeof(int) * ncap));
-    regrow(c.absorbed, n, ncap); regrow(a.absorbed, 0, ncap);
-    if (turn_mode) { regrow(c.dir, n, ncap); regrow(a.dir, 0, ncap); }
-    regrow(c.eat, 0, ncap); regrow(c.fleft, 0, ncap); regrow(c.fcell, 0, ncap);   // attack-phase scratch (food_mode)
-    regrow(a.x, 0, ncap); regrow(a.y, 0, ncap); regrow(a.id, 0, ncap); regrow(a.last_action, 0, ncap);
-    regrow(a.hp, 0, ncap); regrow(a.next_reward, 0, ncap); regrow(a.last_reward, 0, ncap);
+    regrow(arena, c.absorbed, n, ncap); regrow(arena, a.absorbed, 0, ncap);
+    if (turn_mode) { regrow(arena, c.dir, n, ncap); regrow(arena, a.dir, 0, ncap); }
+    regrow(arena, c.eat, 0, ncap); regrow(arena, c.fleft, 0, ncap); regrow(arena, c.fcell, 0, ncap);   // attack-phase scratch (food_mode)
+    regrow(arena, a.x, 0, ncap); regrow(arena, a.y, 0, ncap); regrow(arena, a.id, 0, ncap); regrow(arena, a.last_action, 0, ncap);
+    regrow(arena, a.hp, 0, ncap); regrow(arena, a.next_reward, 0, ncap); regrow(arena, a.last_reward, 0, ncap);
     g.cap = (int)ncap;
     tables_valid = false;
 }
@@ -891,17 +890,17 @@ void Env::reset() {
     bandwidth = (width + n_sep - 1) / n_sep;
     const size_t ncell = (size_t)width * height;
     if (ncell != map_cells) {
-        dfree(d_occ); dfree(d_viewcell); dfree(d_claim); dfree(d_hit);
-        HIP_OK(dev_malloc(&d_occ, sizeof(int) * ncell));
-        HIP_OK(dev_malloc(&d_viewcell, sizeof(int2) * ncell));
-        HIP_OK(dev_malloc(&d_claim, sizeof(unsigned long long) * ncell));
-        HIP_OK(dev_malloc(&d_hit, sizeof(unsigned) * ncell));
-        dfree(d_food);
+        dfree(arena, d_occ); dfree(arena, d_viewcell); dfree(arena, d_claim); dfree(arena, d_hit);
+        HIP_OK(dev_malloc(arena, &d_occ, sizeof(int) * ncell));
+        HIP_OK(dev_malloc(arena, &d_viewcell, sizeof(int2) * ncell));
+        HIP_OK(dev_malloc(arena, &d_claim, sizeof(unsigned long long) * ncell));
+        HIP_OK(dev_malloc(arena, &d_hit, sizeof(unsigned) * ncell));
+        dfree(arena, d_food);
         map_cells = ncell;
     }
     HIP_OK(hipMemset(d_hit, 0, sizeof(unsigned) * ncell));
     claim_clean = false;
-    if (food_mode && !d_food) HIP_OK(dev_malloc(&d_food, sizeof(float) * 2 * ncell));   // amounts, then the attack phase's scratch
+    if (food_mode && !d_food) HIP_OK(dev_malloc(arena, &d_food, sizeof(float) * 2 * ncell));   // amounts, then the attack phase's scratch
     if (d_food) HIP_OK(hipMemset(d_food, 0, sizeof(float) * 2 * ncell));
     h_occ.assign(ncell, OCC_EMPTY);
     for (int i = 0; i < width; i++) { h_occ[i] = OCC_WALL; h_occ[(size_t)(height - 1) * width + i] = OCC_WALL; }
@@ -970,9 +969,9 @@ void Env::reset() {
     if (!attack_lds_ok(attack_kmax)) fatal("attack ranges x body size (%d hits per target) need more LDS per workgroup than this device grants", attack_kmax);
     if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
     if (n_channel() > 32) fatal("too many observation channels");
-    dfree(d_delta); dfree(d_mask);
-    HIP_OK(dev_malloc(&d_delta, sizeof(int2) * std::max<size_t>(delta.size(), 1)));
-    HIP_OK(dev_malloc(&d_mask, std::max<size_t>(mask.size(), 1)));
+    dfree(arena, d_delta); dfree(arena, d_mask);
+    HIP_OK(dev_malloc(arena, &d_delta, sizeof(int2) * std::max<size_t>(delta.size(), 1)));
+    HIP_OK(dev_malloc(arena, &d_mask, std::max<size_t>(mask.size(), 1)));
     if (!delta.empty()) HIP_OK(hipMemcpy(d_delta, delta.data(), sizeof(int2) * delta.size(), hipMemcpyHostToDevice));
     if (!mask.empty()) HIP_OK(hipMemcpy(d_mask, mask.data(), mask.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemset(d_counters, 0, sizeof(int) * CTR_TOTAL));
@@ -981,9 +980,9 @@ void Env::reset() {
     if (!rules_compiled) {   // once, like init_reward_description
         compile_rules();
         rules_compiled = true;
-        dfree(d_rule_args); dfree(d_rule_progs);
-        HIP_OK(dev_malloc(&d_rule_args, sizeof(RuleArgs) * std::max<size_t>(rule_args.size(), 1)));
-        HIP_OK(dev_malloc(&d_rule_progs, sizeof(RuleProg) * std::max<size_t>(rule_progs.size(), 1)));
+        dfree(arena, d_rule_args); dfree(arena, d_rule_progs);
+        HIP_OK(dev_malloc(arena, &d_rule_args, sizeof(RuleArgs) * std::max<size_t>(rule_args.size(), 1)));
+        HIP_OK(dev_malloc(arena, &d_rule_progs, sizeof(RuleProg) * std::max<size_t>(rule_progs.size(), 1)));
         if (!rule_args.empty()) HIP_OK(hipMemcpy(d_rule_args, rule_args.data(), sizeof(RuleArgs) * rule_args.size(), hipMemcpyHostToDevice));
         if (!rule_progs.empty()) HIP_OK(hipMemcpy(d_rule_progs, rule_progs.data(), sizeof(RuleProg) * rule_progs.size(), hipMemcpyHostToDevice));
     }
@@ -1164,7 +1163,7 @@ MiniArgs Env::mini_args(int vh, int vw, bool skip) {
     MiniArgs M{};
     M.vh = vh; M.vw = vw; M.skip = skip ? 1 : 0;
     M.scale_h = (height + vh - 1) / vh; M.scale_w = (width + vw - 1) / vw;   // GridWorld.cc:328-329
-    grow(d_minif, minif_cap, groups.size() * (size_t)vh * vw, stream);
+    grow(arena, d_minif, minif_cap, groups.size() * (size_t)vh * vw, stream);
     M.out = d_minif;
     return M;
 }
@@ -1190,10 +1189,10 @@ bool Env::prepare_render(int g, const WorldView &W, RenderArgs &R, RenderPlan &P
         size_t need = (size_t)W.G * R.VH * R.VW;
         const size_t need_counts = need + MAXG;      // + the per-group count of agents left out (k_minimap, skip mode)
         if (need_counts > mini_cap) {   // the histogram buffer is kept zero between uses (k_minimap_norm zeroes what it reads)
-            grow(d_mini, mini_cap, need_counts, stream);
+            grow(arena, d_mini, mini_cap, need_counts, stream);
             HIP_OK(hipMemsetAsync(d_mini, 0, sizeof(int) * mini_cap, stream));
         }
-        grow(d_minif, minif_cap, need, stream);
+        grow(arena, d_minif, minif_cap, need, stream);
         R.mini = d_minif;
         const long long pop = mini_population(G.type->can_absorb);
         if (!(mini_valid && mini_vh == R.VH && mini_vw == R.VW && mini_pop == pop)) {
@@ -1237,8 +1236,8 @@ void Env::observe_host(int g, float *view, float *feat) {
     if (G.n == 0) return;
     const HostType &t = *G.type;
     size_t nv = (size_t)G.n * t.view.height * t.view.width * n_channel(), nf = (size_t)G.n * feature_size(g);
-    grow(d_stage_view, stage_view_cap, nv, stream);
-    grow(d_stage_feat, stage_feat_cap, nf, stream);
+    grow(arena, d_stage_view, stage_view_cap, nv, stream);
+    grow(arena, d_stage_feat, stage_feat_cap, nf, stream);
     observe_device(g, d_stage_view, d_stage_feat);
     copy_out(view, d_stage_view, sizeof(float) * nv);
     copy_out(feat, d_stage_feat, sizeof(float) * nf);
@@ -1253,7 +1252,7 @@ void Env::set_action_device(int g, const int *d_act) {
     G.acted = true;
     if (G.n == 0) return;
     int nb = (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
-    grow(d_sums, sums_cap, (size_t)nb, stream);
+    grow(arena, d_sums, sums_cap, (size_t)nb, stream);
     ProfScope p(*this, "set_action");
     launch_set_action(stream, view(), g, d_act, move_seq_base, d_sums);
     move_seq_base += G.n;
@@ -1264,7 +1263,7 @@ void Env::set_action_host(int g, const int *actions) {
     use_device();
     HostGroup &G = groups[g];
     if (G.n > 0) {
-        grow(d_actions, actions_cap, (size_t)G.n, stream);
+        grow(arena, d_actions, actions_cap, (size_t)G.n, stream);
         HIP_OK(hipMemcpyAsync(d_actions, actions, sizeof(int) * G.n, hipMemcpyHostToDevice, stream));
     }
     set_action_device(g, d_actions);
@@ -1284,19 +1283,19 @@ void Env::set_action_host(int g, const int *actions) {
 //   * checked: the host reads the convergence flag after every pair / batch (also used while the text render is
 //     recording attack events, and with MAGENT_HOST_SHUFFLE / MAGENT_CHECKED_STEP for A/B runs).
 void Env::shuffle_buffers(int n_max) {
-    grow(d_rank, rank_cap, (size_t)n_max, stream);
+    grow(arena, d_rank, rank_cap, (size_t)n_max, stream);
     if ((size_t)n_max * 5 > shuf_cap) {   // five arrays at fixed fifths of the buffer: count | cursor | j | offset | list
-        grow(d_shuf, shuf_cap, (size_t)n_max * 5, stream);
+        grow(arena, d_shuf, shuf_cap, (size_t)n_max * 5, stream);
         shuf_cap -= shuf_cap % 5;
         // count and cursor are kept zero between steps (k_attack_rank clears what a step used)
         HIP_OK(hipMemsetAsync(d_shuf, 0, sizeof(int) * (shuf_cap / 5) * 2, stream));
     }
     int nb = (n_max + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
-    grow(d_sums, sums_cap, (size_t)nb, stream);
+    grow(arena, d_sums, sums_cap, (size_t)nb, stream);
     // powers of the minstd_rand0 multiplier for k_shuffle_draw: 16807^t (t < 256), then 16807^(256 h) up to h = n_max / 256 + 1
     const size_t need = 256 + (size_t)n_max / 256 + 2;
     if (need > powtab_cap) {
-        grow(d_powtab, powtab_cap, need, stream);
+        grow(arena, d_powtab, powtab_cap, need, stream);
         std::vector<unsigned> tab(powtab_cap);
         const unsigned long long P = 2147483647ull;
         tab[0] = 1;
@@ -1498,7 +1497,7 @@ void Env::step_begin() {
             attack_round = 0;
             attack_rounds_checked(W);
             if (!first_render) {   // attack events are recorded once rendering has started (GridWorld.cc:484,508)
-                grow(d_events, events_cap, (size_t)A, stream);
+                grow(arena, d_events, events_cap, (size_t)A, stream);
                 launch_attack_events(stream, W, d_events);
                 std::vector<int4> ev(A);
                 read_back(ev.data(), d_events, sizeof(int4) * A);
@@ -1759,10 +1758,10 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
     if ((size_t)n_env > lead.batch_cap) {
         HIP_OK(hipStreamSynchronize(lead.stream));
         if (lead.batch_h) HIP_OK(hipHostFree(lead.batch_h));
-        dfree(lead.batch_d);
+        dfree(lead.arena, lead.batch_d);
         lead.batch_cap = std::max<size_t>((size_t)n_env, lead.batch_cap * 2);
         HIP_OK(hipHostMalloc((void **)&lead.batch_h, sizeof(BatchItem) * lead.batch_cap, hipHostMallocDefault));
-        HIP_OK(dev_malloc(&lead.batch_d, sizeof(BatchItem) * lead.batch_cap));
+        HIP_OK(dev_malloc(lead.arena, &lead.batch_d, sizeof(BatchItem) * lead.batch_cap));
     }
     std::vector<int> in_batch, alone;
     for (int e = 0; e < n_env; e++) {
@@ -1817,7 +1816,7 @@ void Env::get_reward_host(int g, float *out) {
     if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_reward : %d", g);
     int n = groups[g].n;
     if (n == 0) return;
-    grow(d_stage_small, stage_small_cap, (size_t)n * 8, stream);
+    grow(arena, d_stage_small, stage_small_cap, (size_t)n * 8, stream);
     get_reward_device(g, (float *)d_stage_small);
     read_back(out, d_stage_small, sizeof(float) * n);
 }
@@ -1883,7 +1882,7 @@ void Env::clear_dead() {
             nb_total += (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
             A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed, G.alt.dir};
         }
-        grow(d_sums, sums_cap, nb_total, stream);
+        grow(arena, d_sums, sums_cap, nb_total, stream);
         launch_clear_compact(stream, W, A, d_sums);
         for (size_t g = 0; g < groups.size(); g++) if (A.mode[g] == 2) swap_buffers(groups[g]);
         launch_clear_finish(stream, view(), A, d_gtab, d_ttab);   // also refreshes the device tables
@@ -1956,7 +1955,7 @@ void Env::info_host(int g, const char *name, void *buf) {
         int n = groups[g].n;
         if (n == 0) return;
         size_t bytes = k == "pos" ? sizeof(int) * 2 * n : k == "alive" ? (size_t)n : sizeof(int) * n;
-        grow(d_stage_small, stage_small_cap, (size_t)n * 8, stream);
+        grow(arena, d_stage_small, stage_small_cap, (size_t)n * 8, stream);
         info_device(g, name, d_stage_small);
         read_back(buf, d_stage_small, bytes);
         return;

@@ -9,9 +9,11 @@ The engine library is always magent_amd/lib/libmagent.so (the HIP engine); loadi
 attribute ``_engine_path`` is what the tests override in a subclass of their own (tests/helpers.py) to drive the CPU
 checkers under oracle/ through the same wrapper -- nothing in the package sets it.
 """
+import atexit
 import ctypes
 import importlib
 import os
+import weakref
 
 import numpy as np
 
@@ -42,6 +44,17 @@ _CONFIG_KINDS = {
 }
 
 
+_live_worlds = weakref.WeakSet()
+
+
+@atexit.register
+def _close_worlds():
+    """environments still alive at interpreter exit are closed while the HIP runtime is still up (afterwards their streams and
+    device memory cannot be returned any more)"""
+    for env in list(_live_worlds):
+        env.close()
+
+
 class GridWorld(object):
     OBS_INDEX_VIEW = 0
     OBS_INDEX_HP = 1
@@ -64,6 +77,7 @@ class GridWorld(object):
 
         self.game = ctypes.c_void_p()
         L.env_new_game(ctypes.byref(self.game), b"GridWorld")
+        _live_worlds.add(self)
 
         self._device_id = int(config.config_dict.get(
             "device_id", os.environ.get("MAGENT_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
@@ -197,7 +211,7 @@ class GridWorld(object):
             actions = actions.contiguous()            # (a copy, if any, is queued on torch's stream: before the hand-over)
             self.order_after_torch()                  # the producer of `actions` runs on torch's stream
             self.set_action_device(handle, actions)
-            actions.record_stream(self.stream)        # the caching allocator must not recycle it under the engine's kernel
+            self.order_torch_after()                  # ... and whatever torch's stream does with that memory next comes after the read
             return
         assert isinstance(actions, np.ndarray) and actions.dtype == np.int32
         actions = np.ascontiguousarray(actions)
@@ -298,13 +312,19 @@ class GridWorld(object):
             raise NotImplementedError
         self._lib.gridworld_set_goal(self.game, _gid(handle), b"random", None)
 
-    def __del__(self):
+    def close(self):
+        """gives the engine's resources back (device memory, stream); the object is unusable afterwards"""
         game, self.game = getattr(self, "game", None), None
+        self._ext_stream = None
+        self._dev_cache = ({}, {})
         if game:
             try:
                 self._lib.env_delete_game(game)
             except Exception:   # interpreter shutdown: ctypes / the library may already be gone
                 pass
+
+    def __del__(self):
+        self.close()
 
     # ------------------------------------------------------------------ MI355X extensions (device buffers)
     def _require_device_api(self):
