@@ -123,15 +123,18 @@ def small_world_extras(torch, magent_amd, dev, steps=200, warmup=20):
         acts = [[[torch.randint(21, (N,), dtype=torch.int32, device=dev, generator=gen) for _ in range(2)] for _ in envs] for _ in range(4)]
         torch.cuda.synchronize()
         batch = magent_amd.EnvBatch(envs, n_threads=8)
+        if batched:      # fixed buffers: the device-pointer arrays are built once, not 8 x K data_ptr() calls per cycle
+            views_p, feats_p, rews_p = batch.pointers(views), batch.pointers(feats), batch.pointers(rews)
+            acts_p = [batch.pointers(a) for a in acts]
         total, t0 = 0, 0.0
         for s in range(steps + warmup):
             if s == warmup:
                 for e in envs:
                     e.sync()
                 total, t0 = 0, time.perf_counter()
-            total += sum(e.get_num(h) for e in envs for h in e.get_handles())
+            total += sum(map(sum, batch.nums()))
             if batched:
-                batch.cycle(views, feats, acts[s % 4], rews)
+                batch.cycle(views_p, feats_p, acts_p[s % 4], rews_p)
             else:
                 e = envs[0]
                 for g, h in enumerate(e.get_handles()):

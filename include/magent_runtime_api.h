@@ -38,6 +38,8 @@ int env_new_game(EnvHandle *game, const char *name);
 int env_delete_game(EnvHandle game);
 /* runtime_api.h:23 -> GridWorld::set_config (GridWorld.cc:120-149).  keys: map_width,map_height (int*),
  * food_mode,turn_mode,minimap_mode,goal_mode (bool*), embedding_size (int*), render_dir (char*), seed (int*).
+ * (turn_mode and food_mode are implemented; goal_mode = true -- "deprecated" at GridWorld.cc:137, set by no shipped
+ * game -- is FATAL.)
  * Additive key: device_id (int*) selects the HIP device (before env_reset). */
 int env_config_game(EnvHandle game, const char *name, void *p_value);
 
@@ -46,7 +48,11 @@ int env_reset(EnvHandle game);
 /* runtime_api.h:27 -> GridWorld::get_observation (GridWorld.cc:292-401)
  * buffer[0] = view   float[n][view_h][view_w][n_channel], buffer[1] = feature float[n][feature_size] */
 int env_get_observation(EnvHandle game, GroupHandle group, float **buffer);
-/* runtime_api.h:28 -> GridWorld::set_action (GridWorld.cc:403-454); actions int32[n] */
+/* runtime_api.h:28 -> GridWorld::set_action (GridWorld.cc:403-454); actions int32[n].
+ * One deliberate strictness: a SECOND set_action for the same group before env_step is FATAL.  The reference appends
+ * the second call's actions to the same lists and would execute both for every agent (two moves, two attacks); no
+ * caller in the reference does that, and reproducing it would put a variable-length action list per agent on the hot
+ * path.  An action outside [0, n_action) is FATAL too (checked on the device, reported at env_step). */
 int env_set_action(EnvHandle game, GroupHandle group, const int *actions);
 /* runtime_api.h:29 -> GridWorld::step (GridWorld.cc:456-631) */
 int env_step(EnvHandle game, int *done);
@@ -106,11 +112,21 @@ int env_get_info_device(EnvHandle game, GroupHandle group, const char *name, voi
 /* env_step for n independent environments at once: all steps are enqueued (each on its environment's stream) before
  * the first is waited for, so their device work overlaps; done[i] as env_step */
 int env_step_many(EnvHandle *games, int n, int *done);
-/* One full cycle (per group: observe -> set_action; step; rewards; clear_dead) of n_env independent environments,
- * driven by n_threads host threads inside the library.  Device pointer arrays are indexed [e * n_group + g]; a NULL
- * entry skips that call for that group.  Small worlds are launch-latency bound: concurrent environments fill the GPU. */
+/* One full cycle of n_env independent environments, exactly the call sequence
+ *   for g: env_get_observation_device(e, g, {view, feat});   for g: env_set_action_device(e, g, actions);
+ *   env_step(e, &done[e]);   for g: env_get_reward_device(e, g, rewards);   gridworld_clear_dead(e)
+ * Device pointer arrays are indexed [e * n_group + g]; a NULL entry skips that call for that group.
+ * Worlds small enough for the one-launch step (<= 16384 agents) run the whole cycle in TWO launches
+ * (observation render of all groups; everything else), and with n_env >= 2 ALL such environments share one pair of
+ * launches on the first environment's stream (one workgroup per environment for the step): small worlds are
+ * launch-latency bound, many of them fill the GPU.  Larger worlds run the calls one after the other on n_threads host
+ * threads inside the library.  `actions` must hold the actions BEFORE the call (they are read by the second launch, in
+ * stream order after the render -- the caller's policy reads the observation of the PREVIOUS cycle, or orders its own
+ * stream with env_get_stream); the outputs are complete when the call returns (the host has waited for `done`). */
 int env_cycle_many(EnvHandle *games, int n_env, int n_group, float **view, float **feat, const int **actions,
                    float **rewards, int *done, int n_threads);
+/* out[e * n_group + g] = number of agents of group g in environment e (env_get_info "num" for a whole batch; host only) */
+int env_num_many(EnvHandle *games, int n_env, int n_group, int *out);
 /* wait until everything enqueued on the environment's stream has finished */
 int env_sync(EnvHandle game);
 /* the environment's hipStream_t, as an opaque pointer (for event timing / interop by the caller) */

@@ -45,6 +45,7 @@ DEVICE_ABI = [
     ("env_get_info_device", [_vp, _i, _cp, _vp]),
     ("env_step_many", [_c.POINTER(_vp), _i, _ip]),
     ("env_cycle_many", [_c.POINTER(_vp), _i, _i, _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp), _ip, _i]),
+    ("env_num_many", [_c.POINTER(_vp), _i, _i, _ip]),
     ("env_sync", [_vp]),
     ("env_get_stream", [_vp, _c.POINTER(_vp)]),
     ("env_profile_enable", [_vp, _i]),

@@ -7,6 +7,7 @@
 // the reference defines as sequential rejection sampling on the engine RNG) and, in this round, the attack
 // shuffle's permutation (a function of the RNG state and the attack count only).
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -1148,7 +1149,8 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
     const long long steps = ((long long)R.n * R.VH * R.VW + 63) / 64;
     // 32 steps per workgroup at scale; a small observation is cut finer so that it still spreads over the chip (a wave's
     // steps run one after the other: a step is ~1 us of latency)
-    int per = render_steps_per_span > 0 ? render_steps_per_span : (int)std::min<long long>(32, std::max<long long>(4, steps / 2048));
+    // (`batch_width` environments share the launch under env_cycle_many)
+    int per = render_steps_per_span > 0 ? render_steps_per_span : (int)std::min<long long>(32, std::max<long long>(4, steps * batch_width / 2048));
     P.steps_per_span = per;
     P.spans = (int)((steps + per - 1) / per);
     P.xcd_chunk = P.spans >= 64 ? P.spans / 8 : 0;
@@ -1754,6 +1756,7 @@ void Env::cycle(int n_group, float *const *view, float *const *feat, const int *
 void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **feat, const int **actions, float **rewards, int *done) {
     Env &lead = *envs[0];
     lead.use_device();
+    const auto t0 = std::chrono::steady_clock::now();
     for (int e = 1; e < n_env; e++) envs[e]->adopt_stream(lead);   // one stream for the batch: launches need no cross-stream events
     if ((size_t)n_env > lead.batch_cap) {
         HIP_OK(hipStreamSynchronize(lead.stream));
@@ -1763,34 +1766,54 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         HIP_OK(hipHostMalloc((void **)&lead.batch_h, sizeof(BatchItem) * lead.batch_cap, hipHostMallocDefault));
         HIP_OK(dev_malloc(lead.arena, &lead.batch_d, sizeof(BatchItem) * lead.batch_cap));
     }
-    std::vector<int> in_batch, alone;
+    // item e describes environment e (an environment that cannot take the two-launch cycle leaves a skip marker and goes alone
+    // below).  A description costs ~0.2 us of host time (measured: 28 us for 128 environments) -- sharing them out over threads
+    // cost more than it saved.
+    std::vector<char> in_batch(n_env, 0);
     for (int e = 0; e < n_env; e++) {
         const int o = e * n_group;
-        if (envs[e]->device_id == lead.device_id &&
-            envs[e]->cycle_prepare(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
-                                   rewards ? rewards + o : nullptr, lead.batch_h[in_batch.size()]))
-            in_batch.push_back(e);
-        else alone.push_back(e);
+        envs[e]->batch_width = n_env;
+        BatchItem &it = lead.batch_h[e];
+        in_batch[e] = envs[e]->device_id == lead.device_id &&
+                      envs[e]->cycle_prepare(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
+                                             rewards ? rewards + o : nullptr, it);
+        if (!in_batch[e]) { it.M.n = 0; it.S.rec = nullptr; }
     }
-    if (!in_batch.empty()) {
-        int slots = 0, max_blocks = 0;
-        size_t render_lds = 0, step_lds = 0;
-        for (size_t k = 0; k < in_batch.size(); k++) {
-            const BatchItem &it = lead.batch_h[k];
-            slots = std::max(slots, it.M.n);
-            for (int q = 0; q < it.M.n; q++) { max_blocks = std::max(max_blocks, it.M.blocks[q]); render_lds = std::max(render_lds, render_strip_lds(it.M.P[q])); }
-            step_lds = std::max(step_lds, solo_step_lds(it.W, it.S));
-        }
-        HIP_OK(hipMemcpyAsync(lead.batch_d, lead.batch_h, sizeof(BatchItem) * in_batch.size(), hipMemcpyHostToDevice, lead.stream));
-        launch_cycle_batch(lead.stream, lead.batch_d, (int)in_batch.size(), slots, max_blocks, render_lds, step_lds);
+    const auto t1 = std::chrono::steady_clock::now();
+    int slots = 0, max_blocks = 0, n_in = 0;
+    size_t render_lds = 0, step_lds = 0;
+    for (int e = 0; e < n_env; e++) {
+        if (!in_batch[e]) continue;
+        n_in++;
+        const BatchItem &it = lead.batch_h[e];
+        slots = std::max(slots, it.M.n);
+        for (int q = 0; q < it.M.n; q++) { max_blocks = std::max(max_blocks, it.M.blocks[q]); render_lds = std::max(render_lds, render_strip_lds(it.M.P[q])); }
+        step_lds = std::max(step_lds, solo_step_lds(it.W, it.S));
+    }
+    if (n_in > 0) {
+        lead.use_device();
+        HIP_OK(hipMemcpyAsync(lead.batch_d, lead.batch_h, sizeof(BatchItem) * (size_t)n_env, hipMemcpyHostToDevice, lead.stream));
+        launch_cycle_batch(lead.stream, lead.batch_d, n_env, slots, max_blocks, render_lds, step_lds);
         HIP_OK(hipGetLastError());
     }
-    for (int e : alone) {
+    for (int e = 0; e < n_env; e++) {
+        if (in_batch[e]) continue;
         const int o = e * n_group;
         envs[e]->cycle(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
                        rewards ? rewards + o : nullptr, &done[e]);
     }
-    for (int e : in_batch) envs[e]->cycle_finish(&done[e]);
+    const auto t2 = std::chrono::steady_clock::now();
+    auto t3 = t2;
+    bool first = true;
+    for (int e = 0; e < n_env; e++) {
+        if (!in_batch[e]) continue;
+        envs[e]->cycle_finish(&done[e]);
+        if (first) { t3 = std::chrono::steady_clock::now(); first = false; }
+    }
+    const auto t4 = std::chrono::steady_clock::now();
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    lead.batch_us[0] += us(t0, t1); lead.batch_us[1] += us(t1, t2); lead.batch_us[2] += us(t2, t3); lead.batch_us[3] += us(t3, t4);
+    lead.batch_rounds++;
 }
 
 // every environment of a batch shares the first one's stream (kept alive by whoever still uses it)
@@ -1916,6 +1939,12 @@ void Env::info_host(int g, const char *name, void *buf) {
     if (k == "num") { need_group(); ib[0] = groups[g].n; return; }
     if (k == "engine_stats") {   // additive: steps whose optimistic rounds ran out (host continued), rounds of the last checked phases
         ib[0] = fallback_steps; ib[1] = last_attack_iters; ib[2] = last_move_iters; ib[3] = attack_round;
+        return;
+    }
+    if (k == "batch_host_us") {  // additive (tuning): host microseconds per env_cycle_many round since the last read:
+        // prepare | copy + launches | wait for the first record | the other records
+        for (int q = 0; q < 4; q++) { fb[q] = batch_rounds ? (float)(batch_us[q] / batch_rounds) : 0.f; batch_us[q] = 0; }
+        batch_rounds = 0;
         return;
     }
     if (k == "step_marks") {     // additive (tuning): ns since the first mark at every phase boundary of the last one-launch step

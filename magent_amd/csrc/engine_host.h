@@ -127,6 +127,7 @@ public:
     // in two launches for small worlds (k_render_multi, k_step_solo); NULL entries skip that call for that group
     void cycle(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, int *done);
     // ... and for many small environments in ONE pair of launches (one workgroup of k_step_solo_batch per environment)
+    int group_count(int g) const { return g >= 0 && g < (int)groups.size() ? groups[g].n : 0; }
     static void cycle_many(Env **envs, int n_env, int n_group, float **view, float **feat, const int **actions, float **rewards, int *done);
     void sync();
     void profile_read(const char *name, int *n, float *ms);
@@ -149,6 +150,9 @@ public:
     // one-launch step of small worlds (k_step_solo): on by default, MAGENT_SOLO_STEP=0 keeps the multi-launch drivers
     bool solo_enabled = true;
     int solo_max_agents = 16384;
+    double batch_us[4] = {0, 0, 0, 0};   // host time of env_cycle_many rounds led by this environment (info "batch_host_us")
+    long batch_rounds = 0;
+    int batch_width = 1;                 // environments rendered by the launch this one is part of (plan_render)
 
 private:
     struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };

@@ -2303,6 +2303,7 @@ __global__ void __launch_bounds__(SOLO_STEP_THREADS) k_step_solo(WorldView W_ker
 __global__ void __launch_bounds__(SOLO_STEP_THREADS) k_step_solo_batch(const BatchItem *items) {
     __shared__ WorldView s_W;
     __shared__ SoloStep s_S;
+    if (items[blockIdx.x].S.rec == nullptr) return;   // an environment of the round that does not take this path
     const unsigned *src = (const unsigned *)&items[blockIdx.x];
     static_assert(offsetof(BatchItem, W) == 0 && offsetof(BatchItem, S) == sizeof(WorldView), "BatchItem layout");
     for (int k = threadIdx.x; k < (int)(sizeof(WorldView) / 4); k += SOLO_STEP_THREADS) ((unsigned *)&s_W)[k] = src[k];

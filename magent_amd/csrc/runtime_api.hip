@@ -144,6 +144,14 @@ int env_cycle_many(EnvHandle *games, int n_env, int n_group, float **view, float
     cycle_pool().run(n_threads < n_env ? n_threads : n_env, n_env, one);
     return 0;
 }
+// agent counts of n_env environments x n_group groups in one call (the host mirror: no device work)
+int env_num_many(EnvHandle *games, int n_env, int n_group, int *out) {
+    for (int e = 0; e < n_env; e++) {
+        Env *env = E(games[e]);
+        for (int g = 0; g < n_group; g++) out[e * n_group + g] = env->group_count(g);
+    }
+    return 0;
+}
 int env_sync(EnvHandle game) { E(game)->sync(); return 0; }
 int env_get_stream(EnvHandle game, void **stream) { *stream = (void *)E(game)->stream; return 0; }
 int env_profile_enable(EnvHandle game, int on) { E(game)->prof_level = on < 0 ? 0 : on > 2 ? 1 : on; return 0; }

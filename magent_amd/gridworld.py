@@ -586,7 +586,10 @@ class EnvBatch(object):
         self._done = (ctypes.c_int32 * n)()
         self._adopted = False
 
-    def _ptrs(self, tensors):
+    def pointers(self, tensors):
+        """the device-pointer array of a list (per env) of lists (per group) of CUDA tensors (None entries allowed).  cycle()
+        takes such an array in place of the nested list: a caller that reuses its buffers builds it once -- at 8 small
+        environments the 64 data_ptr() calls per cycle cost as much as the step itself.  The tensors must stay alive."""
         n = len(self.envs) * self.n_group
         arr = (ctypes.c_void_p * n)()
         if tensors is not None:
@@ -595,8 +598,18 @@ class EnvBatch(object):
                     arr[e * self.n_group + g] = None if t is None else t.data_ptr()
         return arr
 
+    def _ptrs(self, tensors):
+        return tensors if isinstance(tensors, ctypes.Array) else self.pointers(tensors)
+
+    def nums(self):
+        """agent counts [env][group] (host mirror, no device work)"""
+        out = (ctypes.c_int32 * (len(self.envs) * self.n_group))()
+        self._lib.env_num_many(self._handles, len(self.envs), self.n_group, out)
+        return [list(out[e * self.n_group:(e + 1) * self.n_group]) for e in range(len(self.envs))]
+
     def cycle(self, views=None, feats=None, actions=None, rewards=None):
-        """each argument: list (per env) of lists (per group) of CUDA tensors or None; returns the done flags"""
+        """each argument: list (per env) of lists (per group) of CUDA tensors or None, or the result of pointers();
+        returns the done flags"""
         self._lib.env_cycle_many(self._handles, len(self.envs), self.n_group, self._ptrs(views), self._ptrs(feats),
                                  self._ptrs(actions), self._ptrs(rewards), self._done, self.n_threads)
         if not self._adopted:      # environments cycled together share the first one's stream from now on

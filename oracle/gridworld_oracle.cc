@@ -13,7 +13,7 @@
 // State is kept as per-group struct-of-arrays + a packed occupancy grid; the *order* of every loop that the
 // reference executes sequentially is kept literally, because the results depend on it.
 //
-// Scope: what SURVEY.md section 8 puts on the path -- no goal_mode; turn_mode is restated too (the engine refuses it).  Reward rules
+// Scope: what SURVEY.md section 8 puts on the path -- no goal_mode; turn_mode, sector ranges and the general rule search are restated too.  Reward rules
 // are evaluated by the reference's recursive search over symbol bindings, literally (and/or/not over attack, kill,
 // collide, die, at, in, in_a_line; 'any', 'all' and fixed-index symbols); align aborts with a message (undefined in the reference).
 #include <algorithm>

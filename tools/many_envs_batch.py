@@ -2,6 +2,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np
 import torch
 import magent_amd
 
@@ -21,14 +22,20 @@ feats = [[torch.empty((N, 34), device=dev) for _ in range(2)] for _ in envs]
 rews = [[torch.empty(N, device=dev) for _ in range(2)] for _ in envs]
 acts = [[[torch.randint(21, (N,), dtype=torch.int32, device=dev) for _ in range(2)] for _ in envs] for _ in range(4)]
 batch = magent_amd.EnvBatch(envs, n_threads=T)
+us = np.zeros(4, dtype=np.float32)
+view_p, feat_p, rew_p = batch.pointers(views), batch.pointers(feats), batch.pointers(rews)      # fixed buffers: pointer arrays built once (the tensors stay alive)
+act_ptrs = [batch.pointers(a) for a in acts]
 torch.cuda.synchronize()
 total, t0 = 0, time.perf_counter()
 for s in range(STEPS + 10):
     if s == 10:
         for e in envs: e.sync()
+        envs[0]._lib.env_get_info(envs[0].game, 0, b"batch_host_us", us.ctypes.data)      # reset: warm-up rounds allocate
         t0 = time.perf_counter(); total = 0
-    total += sum(e.get_num(h) for e in envs for h in e.get_handles())
-    batch.cycle(views, feats, acts[s % 4], rews)
+    total += sum(map(sum, batch.nums()))
+    batch.cycle(view_p, feat_p, act_ptrs[s % 4], rew_p)
 for e in envs: e.sync()
 dt = time.perf_counter() - t0
+envs[0]._lib.env_get_info(envs[0].game, 0, b"batch_host_us", us.ctypes.data)
+print("   host us per round: prepare %.1f, copy + launches %.1f, wait for the first record %.1f, other records %.1f" % tuple(us))
 print("K=%d envs, %d library threads: %.2fM agent-steps/s aggregate, %.3f ms per round" % (K, T, total / dt / 1e6, dt / STEPS * 1e3))
