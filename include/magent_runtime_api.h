@@ -131,6 +131,12 @@ int env_num_many(EnvHandle *games, int n_env, int n_group, int *out);
 int env_sync(EnvHandle game);
 /* the environment's hipStream_t, as an opaque pointer (for event timing / interop by the caller) */
 int env_get_stream(EnvHandle game, void **stream);
+/* the hipStream_t on which the NEXT env_set_action_device will read its actions.  Worlds too large for the one-launch step
+ * run set_action and the read-only head of env_step (attack shuffle, hit gather, death-rank fixed point) on a second
+ * stream, beside the observation renders on env_get_stream's stream; a caller that produces actions
+ * asynchronously on a stream of its own orders THIS stream behind it.  Equal to env_get_stream's for small worlds or
+ * with MAGENT_OVERLAP=0.  All outputs (observations, rewards, infos) are ordered on env_get_stream's stream as before. */
+int env_get_action_stream(EnvHandle game, void **stream);
 
 /* Kernel timing with HIP events recorded on the environment's stream.
  * env_profile_enable(game, 1) starts recording one event pair per launch of each named kernel; (game, 2) records

@@ -129,16 +129,16 @@ void HostRange::sector(float angle, float radius, int parity) {
 
 // ------------------------------------------------------------------------------------------------ profiling
 struct Env::ProfScope {
-    Env &e; Env::ProfSlot *slot = nullptr; hipEvent_t a{}, b{};
-    ProfScope(Env &env, const char *name, bool dominant = false) : e(env) {
+    Env &e; Env::ProfSlot *slot = nullptr; hipEvent_t a{}, b{}; hipStream_t s{};
+    ProfScope(Env &env, const char *name, bool dominant = false, hipStream_t on = nullptr) : e(env), s(on ? on : env.stream) {
         if (!e.prof_level || (e.prof_level == 2 && !dominant)) return;   // an event pair costs ~10 us of stream time
         slot = &e.prof[name];
         a = e.prof_event(); b = e.prof_event();
-        HIP_OK(hipEventRecord(a, e.stream));
+        HIP_OK(hipEventRecord(a, s));
     }
     ~ProfScope() {
         if (!slot) return;
-        HIP_OK(hipEventRecord(b, e.stream));
+        HIP_OK(hipEventRecord(b, s));
         slot->pending.emplace_back(a, b);
     }
 };
@@ -151,7 +151,7 @@ hipEvent_t Env::prof_event() {
 }
 
 void Env::profile_read(const char *name, int *n, float *ms) {
-    use_device();
+    enter();
     HIP_OK(hipStreamSynchronize(stream));
     ProfSlot &s = prof[name];
     *n = (int)s.pending.size();
@@ -267,6 +267,7 @@ Env::Env() {
     if (const char *v = std::getenv("MAGENT_OPT_MOVE_BATCHES")) { opt_move_batches = std::max(0, std::atoi(v)); opt_fixed = true; }
     if (const char *v = std::getenv("MAGENT_RENDER_NT")) nt_stores = std::atoi(v) != 0;
     if (const char *v = std::getenv("MAGENT_SOLO_STEP")) solo_enabled = std::atoi(v) != 0;
+    if (const char *v = std::getenv("MAGENT_OVERLAP")) { overlap_level = std::atoi(v); overlap_enabled = overlap_level != 0; }
     if (const char *v = std::getenv("MAGENT_SOLO_MAX")) solo_max_agents = std::max(0, std::atoi(v));
 }
 
@@ -278,6 +279,7 @@ static void dfree(DevArena &arena, T *&p) {
 Env::~Env() {
     if (!device_ready) return;
     use_device();
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_state); (void)hipEventDestroy(ev_side); }
     (void)hipStreamSynchronize(stream);
     for (auto &g : groups) free_group(g);
     dfree(arena, d_occ); dfree(arena, d_viewcell); dfree(arena, d_claim); dfree(arena, d_food); dfree(arena, d_powtab); dfree(arena, d_counters); dfree(arena, d_gtab); dfree(arena, d_ttab);
@@ -301,6 +303,62 @@ Env::~Env() {
 }
 
 void Env::use_device() { HIP_OK(hipSetDevice(device_id)); }
+
+// ------------------------------------------------------------------------------------------------ the side stream
+// At 800k agents a step + observation is ~1 ms of which the two observation renders are 0.64 ms of pure HBM writing, while
+// set_action, the attack shuffle, the hit gather and the death-rank fixed point (~0.18 ms of latency-bound launches) only READ
+// the world the renders read, and write scratch the renders never look at (pend, key, the hit words, ranks; last_action is
+// stored later, see k_set_action_a).  They run on a second stream, under the renders:
+//   stream : ... clear_dead | render g0 | render g1 ............| (waits for side) attack_apply, move, rules, finish
+//   side   :   (waits for the state)   set_action g0, g1, shuffle, rank, eval rounds |
+// MEASURED (MI355X, bench workload, profiles/r02_overlap.txt): 0.952 -> 0.896 ms per step (+6 %), but the renders stretch from
+// 0.303 to 0.347 ms each -- the side work is random 4-byte traffic that costs whole HBM transactions, so it takes back more
+// than half of what it hides.  OFF by default (MAGENT_OVERLAP=3 turns all of it on, 2 the shuffle only, 1 set_action only):
+// the render stays at its roofline fraction and the step's head stays the thing to make cheaper.  The GPU suite runs the
+// dense scenarios both ways (tests/test_gpu_fullsize.py: multi_launch_step / multi_launch_one_stream).
+// Rules that keep this exact whatever the caller does:
+//   * every call that changes the world, or must see all of it, starts with enter(): `stream` waits for what `side` still
+//     has in flight, and the state epoch moves on;
+//   * `side` waits for an event recorded on `stream` behind the last state-changing call (mark_state: recorded lazily, by the
+//     first observation or side-stream use after such a call, i.e. BEFORE any render is enqueued behind it);
+//   * an observation of a group whose actions are already set joins and commits last_action first (the feature rows show it).
+bool Env::side_wanted() {
+    if (!overlap_enabled || checked_step || host_shuffle || !first_render || (turn_mode && any_multicell)) return false;
+    int total_n = 0;
+    for (auto &g : groups) total_n += g.n;
+    return total_n > 0 && !solo_ok(total_n);
+}
+void Env::mark_state() {
+    if (!side || marked_epoch == state_epoch) return;
+    HIP_OK(hipEventRecord(ev_state, stream));
+    marked_epoch = state_epoch;
+}
+hipStream_t Env::side_stream() {
+    if (!side) {
+        HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&ev_state, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+    }
+    mark_state();
+    if (side_epoch != marked_epoch) {
+        HIP_OK(hipStreamWaitEvent(side, ev_state, 0));
+        side_epoch = marked_epoch;
+    }
+    side_dirty = true;
+    return side;
+}
+void Env::join_side() {
+    if (!side_dirty) return;
+    HIP_OK(hipEventRecord(ev_side, side));
+    HIP_OK(hipStreamWaitEvent(stream, ev_side, 0));
+    side_dirty = false;
+}
+void Env::enter() {
+    use_device();
+    join_side();
+    state_epoch++;
+}
+hipStream_t Env::action_stream() { return device_ready && side_wanted() ? side_stream() : stream; }
 
 void Env::init_device() {
     if (device_ready) return;
@@ -882,7 +940,7 @@ void Env::reset() {
     if (width <= 2 || height <= 2) fatal("map_width / map_height must be configured before reset");
     if ((long long)width * height > (1ll << 30)) fatal("map too large");
     init_device();
-    use_device();
+    enter();
     HIP_OK(hipStreamSynchronize(stream));
     id_counter = 0;
     file_ct++; frame_ct = 0;   // RenderGenerator::next_file (GridWorld.cc:97)
@@ -1037,7 +1095,7 @@ void Env::host_random_blank(int bw, int bl, int &ox, int &oy) {
 // GridWorld::add_agents (GridWorld.cc:180-290).  Cold path: placement is defined sequentially by the reference.
 void Env::add_agents(int group, int n, const char *method, const int *px, const int *py, const int *pdir) {
     if (!device_ready) fatal("add_agents called before reset");
-    use_device();
+    enter();
     download_occ();
     std::string m(method);
     auto add_wall = [&](int x, int y) {  // Map::add_wall (Map.cc:108-115)
@@ -1215,6 +1273,12 @@ void Env::observe_device(int g, float *view, float *feat) {
     if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_observation : %d", g);
     use_device();
     if (groups[g].n == 0) return;   // the reference dereferences agents[0] here (UB); nothing to write for n = 0
+    if (groups[g].acted) {          // set_action came first: the feature rows show the new last_action (GridWorld.cc:386-396)
+        join_side();
+        GroupDev G = groups[g].cur; G.n = groups[g].n;
+        launch_commit_action(stream, G, groups[g].tdev);
+    }
+    mark_state();                   // (the side stream waits for the world as it is before this render, not for the render)
     WorldView W = this->view();
     RenderArgs R; RenderPlan P;
     const bool aligned = prepare_render(g, W, R, P, view, feat);
@@ -1254,9 +1318,10 @@ void Env::set_action_device(int g, const int *d_act) {
     G.acted = true;
     if (G.n == 0) return;
     int nb = (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
-    grow(arena, d_sums, sums_cap, (size_t)nb, stream);
-    ProfScope p(*this, "set_action");
-    launch_set_action(stream, view(), g, d_act, move_seq_base, d_sums);
+    if ((size_t)nb > sums_cap) { enter(); grow(arena, d_sums, sums_cap, (size_t)nb, stream); }
+    hipStream_t s = action_stream();    // large worlds: beside the observation renders (see side_stream)
+    ProfScope p(*this, "set_action", false, s);
+    launch_set_action(s, view(), g, d_act, move_seq_base, d_sums);
     move_seq_base += G.n;
 }
 
@@ -1264,12 +1329,14 @@ void Env::set_action_host(int g, const int *actions) {
     if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in set_action : %d", g);
     use_device();
     HostGroup &G = groups[g];
+    hipStream_t s = stream;
     if (G.n > 0) {
-        grow(arena, d_actions, actions_cap, (size_t)G.n, stream);
-        HIP_OK(hipMemcpyAsync(d_actions, actions, sizeof(int) * G.n, hipMemcpyHostToDevice, stream));
+        if ((size_t)G.n > actions_cap) { enter(); grow(arena, d_actions, actions_cap, (size_t)G.n, stream); }
+        s = action_stream();
+        HIP_OK(hipMemcpyAsync(d_actions, actions, sizeof(int) * G.n, hipMemcpyHostToDevice, s));
     }
     set_action_device(g, d_actions);
-    HIP_OK(hipStreamSynchronize(stream));   // d_actions is reused by the next call
+    HIP_OK(hipStreamSynchronize(s));   // d_actions is reused by the next call
 }
 
 // ------------------------------------------------------------------------------------------------ step
@@ -1394,7 +1461,7 @@ void Env::step_begin() {
     if (!device_ready) fatal("step called before reset");
     if (step_pending) fatal("step_begin called twice without step_end");
     use_device();
-    ensure_tables();
+    if (!tables_valid) { ensure_tables(); state_epoch++; }   // (enqueued on `stream`: the side stream has to see it)
     step_live_paint = live_paint_now = paint_valid;   // the painted map is current: every driver of the step keeps it so
     WorldView W = view();
     int total_n = 0;
@@ -1407,6 +1474,8 @@ void Env::step_begin() {
     step_was_fast = false;
     step_was_solo = false;
 
+    const bool beside = total_n > 0 && fast && side_wanted() && overlap_level >= 2;   // the read-only head of the step goes beside the renders
+    if (!beside) join_side();
     if (total_n == 0) {
         enqueue_counters();
     } else if (solo_ok(total_n)) {
@@ -1431,21 +1500,33 @@ void Env::step_begin() {
         claim_clean = false;
         step_was_fast = true;
         // ---------------- single-sync driver
-        shuffle_buffers(total_n);
-        push_rng();
+        {
+            const size_t caps = rank_cap + shuf_cap + sums_cap + powtab_cap;
+            const bool rng_here = !rng_on_device;
+            shuffle_buffers(total_n);
+            push_rng();
+            if (rng_here || caps != rank_cap + shuf_cap + sums_cap + powtab_cap) state_epoch++;   // (something was enqueued on `stream`)
+        }
         const size_t seg = shuf_cap / 5;
         int *scount = d_shuf, *scur = d_shuf + seg, *sj = d_shuf + 2 * seg, *soff = d_shuf + 3 * seg, *slist = d_shuf + 4 * seg;
+        // shuffle, hit gather and the death-rank fixed point only read the world (and write scratch no render looks at)
+        hipStream_t a = beside ? side_stream() : stream;
         {
-            ProfScope p(*this, "attack");
-            launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
-            launch_attack_rank(stream, W, d_rank, scount, scur, false);
+            ProfScope p(*this, "attack", false, a);
+            launch_shuffle(a, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
+            if (overlap_level == 2 && a != stream) { join_side(); a = stream; }
+            launch_attack_rank(a, W, d_rank, scount, scur, false);
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
             // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
             // LAST one reports whether anything still moved (one gate for all of them)
             for (int r = 0; r < 2 * pairs; r++)
-                launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
-            if (pairs == 0) launch_set_counter(stream, d_counters, CTR_OPEN_ATTACK, 1, -1);   // tests: straight to the host
+                launch_attack_iter(a, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
+            if (pairs == 0) launch_set_counter(a, d_counters, CTR_OPEN_ATTACK, 1, -1);   // tests: straight to the host
+        }
+        join_side();      // from here on the world changes: behind every render enqueued so far
+        {
+            ProfScope p(*this, "attack");
             launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
         }
         {
@@ -1533,6 +1614,7 @@ void Env::step_begin() {
         }
         enqueue_counters();
     }
+    state_epoch++;
 }
 
 // the one host synchronisation of the step: `done`, death counts, RNG state, and the (rare) continuation when a
@@ -1548,7 +1630,6 @@ void Env::step_end(int *done) {
         if (r.unsupported) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
         if (r.pack_overflow) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
         if (r.bad_action) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
-    if (r.hit_overflow) fatal("a target collected more attack hits than the engine's hit lists hold (256)");
         if (r.hit_overflow) fatal("a target collected more attack hits than the engine's hit lists hold (256)");
         if (rng_on_device) rng.x = r.rng;
         last_attack_iters = r.rounds_attack; last_move_iters = r.rounds_move; attack_round = r.rounds_attack;
@@ -1618,7 +1699,7 @@ void Env::step_end(int *done) {
 //   cycle_finish  : the step record, the host mirror of what clear_dead did on the device
 bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, BatchItem &item) {
     if (!device_ready) fatal("cycle called before reset");
-    use_device();
+    enter();
     const int NG = (int)groups.size();
     if (n_group != NG) fatal("env_cycle_many: n_group (%d) differs from the number of groups (%d)", n_group, NG);
     int total_n = 0;
@@ -1830,7 +1911,7 @@ void Env::adopt_stream(Env &lead) {
 // ------------------------------------------------------------------------------------------------ reward / clear_dead
 void Env::get_reward_device(int g, float *out) {
     if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_reward : %d", g);
-    use_device();
+    enter();
     GroupDev G = groups[g].cur; G.n = groups[g].n;
     launch_get_reward(stream, G, groups[g].group_reward, out);
 }
@@ -1847,7 +1928,7 @@ void Env::get_reward_host(int g, float *out) {
 // GridWorld::clear_dead (GridWorld.cc:633-665)
 void Env::clear_dead() {
     if (!device_ready) fatal("clear_dead called before reset");
-    use_device();
+    enter();
     ProfScope p(*this, "clear_dead");
     WorldView W = view();
     bool any = false, all_solo = true;
@@ -2073,7 +2154,7 @@ void Env::gen_render_config() {
 // GridWorld::render (GridWorld.cc:939-949) + RenderGenerator::render_a_frame (RenderGenerator.cc:108-185)
 void Env::render() {
     if (!device_ready) fatal("render called before reset");
-    use_device();
+    enter();
     if (first_render) {
         first_render = false;
         if (!render_dir.empty()) gen_render_config();
@@ -2121,7 +2202,7 @@ void Env::render() {
 
 void Env::sync() {
     if (!device_ready) return;
-    use_device();
+    enter();
     HIP_OK(hipStreamSynchronize(stream));
 }
 

@@ -135,6 +135,20 @@ public:
     hipStream_t stream{};
     DevArena arena;
     std::shared_ptr<void> stream_owner;   // environments cycled together share one stream (Env::adopt_stream)
+    // Side stream (large worlds): set_action and the part of the step that only READS the world -- the attack shuffle, the hit
+    // gather and the death-rank fixed point -- run here, beside the observation renders on `stream` (engine.hip: side_stream)
+    hipStream_t side{};
+    hipEvent_t ev_state{}, ev_side{};
+    bool overlap_enabled = false;         // MAGENT_OVERLAP=1..3 turns it on (default: everything on `stream`, see engine.hip)
+    int overlap_level = 3;                // (tuning) 1: set_action beside the renders, 2: + the attack shuffle, 3: + hit gather and death ranks
+    bool side_dirty = false;              // work on `side` that `stream` has not waited for yet
+    unsigned state_epoch = 1, marked_epoch = 0, side_epoch = 0;   // state-changing calls | ... covered by ev_state | ... waited for by `side`
+    void enter();                         // head of every call that changes (or must see) the whole state: join + epoch
+    void join_side();
+    void mark_state();
+    hipStream_t side_stream();
+    bool side_wanted();
+    hipStream_t action_stream();          // where the next set_action will read its actions
     int attack_round = 0;        // rounds of the attack fixed point launched in the current step (k_attack_eval)
     int prof_level = 0;          // 0 off, 1 every named phase, 2 only the observation render launches
     bool nt_stores = true;   // nontemporal stores keep the write-once output out of L2 (measured +15-20 %)

@@ -512,7 +512,11 @@ __device__ __forceinline__ int block_prefix(const int *sums, int b) {
 }
 
 // ------------------------------------------------------------------------------------------------ set_action
-// Stores last_action, classifies the action (move | attack) and computes the agent's order key.
+// Classifies the action (move | turn | attack) and computes the agent's order key.  Agent::last_action (an input of the
+// feature rows only) is NOT written here: `pend` holds the action until the step's first per-agent pass (starve_body) stores
+// it, so that set_action -- and the attack resolution behind it -- may run on a side stream while the observation of another
+// group is still being rendered from last_action (engine.hip: Env::side_stream).  An observation asked for between
+// set_action and step gets it through k_commit_action first.
 //   move  : key = (boundary << 31) | insertion index.  Reference: moves run stripe lists 0..S-1 then the boundary
 //           list, each in insertion order (GridWorld.cc:605-613); interior moves of different stripes cannot
 //           interact (margin 4 > max speed 3), so only "boundary after interior" + insertion order is observable.
@@ -525,7 +529,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int 
         int i = tile0 + k * SCAN_THREADS + threadIdx.x;
         if (i < G.n) {
             int act = actions[i];
-            G.last_action[i] = act;
             if (act < 0 || act >= T.n_move + T.n_turn + T.n_attack) {   // outside the action space: no action, reported at the end of the step
                 W.counters[CTR_BAD_ACTION] = 1;
                 G.pend[i] = PEND_NONE;
@@ -561,7 +564,6 @@ __device__ __forceinline__ void set_action_solo_body(const GroupDev &G, const Ty
     const int base = counters[CTR_ATTACK];
     for (int i = threadIdx.x; i < G.n; i += SOLO_THREADS) {
         int act = actions[i];
-        G.last_action[i] = act;
         if (act < 0 || act >= T.n_move + T.n_turn + T.n_attack) {
             counters[CTR_BAD_ACTION] = 1;
             G.pend[i] = PEND_NONE;
@@ -582,6 +584,17 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_set_action_solo(WorldView W, i
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
     set_action_solo_body(G, T, W.counters, W.large_map, W.bandwidth, actions, call_base);
+}
+
+__device__ __forceinline__ int pend_action(int pend, const TypeDev &T) {   // the action number a pending action came from
+    return (pend & PEND_ARG) + ((pend & ~PEND_ARG) == PEND_ATTACK ? T.n_move + T.n_turn : 0);
+}
+// last_action of a group whose actions are set but not stepped yet (an observation between set_action and step)
+__global__ void __launch_bounds__(256) k_commit_action(GroupDev G, TypeDev T) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.n) return;
+    const int pend = G.pend[i];
+    if (pend != PEND_NONE) G.last_action[i] = pend_action(pend, T);
 }
 
 // ------------------------------------------------------------------------------------------------ generic int scan
@@ -1088,6 +1101,10 @@ __global__ void __launch_bounds__(256) k_attack_events(WorldView W, int4 *ev) {
 // (device function: runs at the head of the move-preparation launch -- one dependent launch less per step)
 __device__ __forceinline__ void starve_body(const WorldView &W, int g, const GroupDev &G, const TypeDev &T, int i, int slot) {
     bool died = false;
+    if (i < G.n) {      // Agent::set_action's `last_action = act` (see k_set_action_a)
+        const int pend = G.pend[i];
+        if (pend != PEND_NONE) G.last_action[i] = pend_action(pend, T);
+    }
     // first: the agents that died in this step's attack phase leave the map (Map::remove_agent, Map.cc:272) -- here, in
     // the launch after the attack's, because the attack kernels find attackers through the phase-start map
     // (and are counted here, one atomic per wave, together with the starved)
@@ -2441,6 +2458,10 @@ void launch_render_multi(hipStream_t s, const WorldView &W, const RenderMulti &M
     dim3 grid(mx, M.n), block(64 * RENDER_WAVES);
     if (W.vc_packed) hipLaunchKernelGGL((k_render_multi<true>), grid, block, lds, s, W, M);
     else hipLaunchKernelGGL((k_render_multi<false>), grid, block, lds, s, W, M);
+}
+
+void launch_commit_action(hipStream_t s, const GroupDev &G, const TypeDev &T) {
+    if (G.n > 0) hipLaunchKernelGGL(k_commit_action, dim3((G.n + 255) / 256), dim3(256), 0, s, G, T);
 }
 
 void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4) {

@@ -100,6 +100,7 @@ struct BatchItem {
     SoloStep S;
     RenderMulti M;
 };
+void launch_commit_action(hipStream_t s, const GroupDev &G, const TypeDev &T);
 void launch_cycle_batch(hipStream_t s, const BatchItem *d_items, int n_env, int slots, int max_blocks, size_t render_lds, size_t step_lds);
 size_t render_strip_lds(const RenderPlan &P);
 size_t solo_step_lds(const WorldView &W, const SoloStep &S);

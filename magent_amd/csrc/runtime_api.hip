@@ -154,6 +154,7 @@ int env_num_many(EnvHandle *games, int n_env, int n_group, int *out) {
 }
 int env_sync(EnvHandle game) { E(game)->sync(); return 0; }
 int env_get_stream(EnvHandle game, void **stream) { *stream = (void *)E(game)->stream; return 0; }
+int env_get_action_stream(EnvHandle game, void **stream) { *stream = (void *)E(game)->action_stream(); return 0; }
 int env_profile_enable(EnvHandle game, int on) { E(game)->prof_level = on < 0 ? 0 : on > 2 ? 1 : on; return 0; }
 int env_profile_read(EnvHandle game, const char *name, int *n_launches, float *total_ms) { E(game)->profile_read(name, n_launches, total_ms); return 0; }
 

@@ -315,7 +315,7 @@ class GridWorld(object):
     def close(self):
         """gives the engine's resources back (device memory, stream); the object is unusable afterwards"""
         game, self.game = getattr(self, "game", None), None
-        self._ext_stream = None
+        self._ext_stream = self._ext_side = None
         self._dev_cache = ({}, {})
         if game:
             try:
@@ -390,15 +390,31 @@ class GridWorld(object):
             st = self._ext_stream = torch.cuda.ExternalStream(ptr.value, device=torch.device("cuda", self.device_id))
         return st
 
+    def _streams(self):
+        """the engine's stream(s): large worlds read their actions (and run the read-only head of the step) on a second stream
+        beside the observation renders -- env_get_action_stream (include/magent_runtime_api.h)"""
+        main = self.stream
+        ptr = ctypes.c_void_p()
+        self._lib.env_get_action_stream(self.game, ctypes.byref(ptr))
+        if not ptr.value or ptr.value == main.cuda_stream:
+            return (main,)
+        side = getattr(self, "_ext_side", None)
+        if side is None or side.cuda_stream != ptr.value:
+            import torch
+            side = self._ext_side = torch.cuda.ExternalStream(ptr.value, device=main.device)
+        return (main, side)
+
     def order_after_torch(self):
         """engine work queued from now on waits for what is queued on torch's current stream (no host blocking)"""
         import torch
-        self.stream.wait_stream(torch.cuda.current_stream(self.stream.device))
+        for st in self._streams():
+            st.wait_stream(torch.cuda.current_stream(st.device))
 
     def order_torch_after(self):
         """torch's current stream waits for the engine work queued so far (no host blocking)"""
         import torch
-        torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+        for st in self._streams():
+            torch.cuda.current_stream(st.device).wait_stream(st)
 
     @property
     def device_id(self):

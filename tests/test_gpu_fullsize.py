@@ -51,6 +51,7 @@ VARIANTS = {
     "move_runs_out": {"MAGENT_OPT_MOVE_BATCHES": "0"},
     "host_shuffle": {"MAGENT_HOST_SHUFFLE": "1"},
     "multi_launch_step": {"MAGENT_SOLO_STEP": "0"},
+    "multi_launch_side_stream": {"MAGENT_SOLO_STEP": "0", "MAGENT_OVERLAP": "3"},   # set_action and the head of the step beside the renders
 }
 
 

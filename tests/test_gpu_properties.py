@@ -274,6 +274,61 @@ def test_env_batch_equals_standalone_environments():
     assert dones == [False, False]
 
 
+def _play_actions_first(lib, map_size, n, steps, device_api):
+    """set_action for every group BEFORE the observations of the step are asked for (a legal order: the reference's feature rows
+    then already show the new last_action, GridWorld.cc:386-396 / Agent::set_action); the attack list's order does not depend on it"""
+    env = H.gridworld(H.config_for("battle", map_size, small={"hp": 4, "damage": 3}), lib=lib)
+    env.set_seed(77); env.reset()
+    handles = env.get_handles()
+    for h in handles:
+        env.add_agents(h, "random", n=n)
+    rs = np.random.RandomState(5)
+    out = []
+    for step in range(steps):
+        rec = {}
+        for g, h in enumerate(handles):
+            acts = rs.randint(21, size=env.get_num(h)).astype(np.int32)
+            if device_api:
+                torch = _torch()
+                d = torch.from_numpy(acts).to(torch.device("cuda", env.device_id))
+                torch.cuda.synchronize()
+                env.set_action_device(h, d)
+            else:
+                env.set_action(h, acts)
+        for g, h in enumerate(handles):
+            if device_api:
+                v, f = env.get_observation_device(h)
+                env.sync()
+                rec["view%d" % g], rec["feat%d" % g] = v.cpu().numpy(), f.cpu().numpy()
+            else:
+                v, f = env.get_observation(h)
+                rec["view%d" % g], rec["feat%d" % g] = v.copy(), f.copy()
+        rec["done"] = np.array([env.step()], dtype=np.int32)
+        for g, h in enumerate(handles):
+            rec["reward%d" % g] = env.get_reward(h)
+            rec["alive%d" % g] = env.get_alive(h).astype(np.uint8)
+        env.clear_dead()
+        for g, h in enumerate(handles):
+            rec["pos%d" % g] = env.get_pos(h)
+        out.append(rec)
+    return out
+
+
+@pytest.mark.parametrize("map_size,n", [(40, 300), (160, 9000)])
+def test_observation_between_set_action_and_step(map_size, n):
+    """the engine stores last_action lazily (with MAGENT_OVERLAP set_action runs on a side stream under the renders of large
+    worlds): an observation asked for after set_action must still show it.  Small world (one-launch step) and large world, host and
+    device API; the large world once more in a process with the side stream on."""
+    want = _play_actions_first(H.ensure_oracle(), map_size, n, 5, False)
+    H.assert_same(want, _play_actions_first(H.HIP_LIB, map_size, n, 5, False), "actions first, host API")
+    H.assert_same(want, _play_actions_first(H.HIP_LIB, map_size, n, 5, True), "actions first, device API")
+    if n > 8192 and os.environ.get("MAGENT_OVERLAP") is None:
+        env = dict(os.environ, MAGENT_OVERLAP="3")
+        out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k", "test_observation_between_set_action_and_step"],
+                             env=env, capture_output=True, text=True, timeout=900, cwd=H.ROOT)
+        assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-2000:])
+
+
 def test_moving_goals_are_refused_loudly():
     """a can_absorb agent that is given a move action is outside the engine's scope: the step aborts with a message
     instead of guessing (goals that stand still are covered by the `arrange*` parity scenarios)"""
