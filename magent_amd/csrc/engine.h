@@ -142,6 +142,7 @@ struct StepRecord {
     int last_a;                  // attack-list length
     int unsupported, pack_overflow, error, bad_action, hit_overflow;
     int rounds_attack, rounds_move;
+    int open_attack, open_move;  // multi-launch step: the optimistic rounds of a phase ran out (the host continues from that state)
     int n_marks; unsigned long long marks[40];   // wall_clock64 (100 MHz) at the phase boundaries of k_step_solo (tuning aid)
     volatile int seq;            // == the step's sequence number once everything above is visible
 };
@@ -177,7 +178,7 @@ struct RenderArgs {
     int scale_w, scale_h;
     int chan_desc[32];           // per output channel: (kind << 8) | (code & 0xff); kind 0 = has, 1 = hp, 2 = minimap
     int totals[MAXG];            // group sizes (minimap divisor)
-    const float *mini;           // float[G][VH*VW]: count / total per group (k_minimap_norm)
+    const float *mini;           // float[G][VH*VW]: count / total per group (k_minimap)
     float *view, *feat;
 };
 

@@ -1248,7 +1248,7 @@ bool Env::prepare_render(int g, const WorldView &W, RenderArgs &R, RenderPlan &P
     if (minimap_mode) {
         size_t need = (size_t)W.G * R.VH * R.VW;
         const size_t need_counts = need + MAXG;      // + the per-group count of agents left out (k_minimap, skip mode)
-        if (need_counts > mini_cap) {   // the histogram buffer is kept zero between uses (k_minimap_norm zeroes what it reads)
+        if (need_counts > mini_cap) {   // the histogram buffer is kept zero between uses (k_minimap's last block zeroes what it reads)
             grow(arena, d_mini, mini_cap, need_counts, stream);
             HIP_OK(hipMemsetAsync(d_mini, 0, sizeof(int) * mini_cap, stream));
         }
@@ -1353,11 +1353,11 @@ void Env::set_action_host(int g, const int *actions) {
 //     recording attack events, and with MAGENT_HOST_SHUFFLE / MAGENT_CHECKED_STEP for A/B runs).
 void Env::shuffle_buffers(int n_max) {
     grow(arena, d_rank, rank_cap, (size_t)n_max, stream);
-    if ((size_t)n_max * 5 > shuf_cap) {   // five arrays at fixed fifths of the buffer: count | cursor | j | offset | list
-        grow(arena, d_shuf, shuf_cap, (size_t)n_max * 5, stream);
-        shuf_cap -= shuf_cap % 5;
-        // count and cursor are kept zero between steps (k_attack_rank clears what a step used)
-        HIP_OK(hipMemsetAsync(d_shuf, 0, sizeof(int) * (shuf_cap / 5) * 2, stream));
+    if ((size_t)n_max * 4 > shuf_cap) {   // four arrays at fixed quarters of the buffer: head | first | j | link
+        grow(arena, d_shuf, shuf_cap, (size_t)n_max * 4, stream);
+        shuf_cap -= shuf_cap % 4;
+        // head and first are kept zero between steps (k_attack_rank clears what a step used)
+        HIP_OK(hipMemsetAsync(d_shuf, 0, sizeof(int) * (shuf_cap / 4) * 2, stream));
     }
     int nb = (n_max + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
     grow(arena, d_sums, sums_cap, (size_t)nb, stream);
@@ -1374,6 +1374,11 @@ void Env::shuffle_buffers(int n_max) {
         for (size_t h = 257; h < powtab_cap; h++) tab[h] = (unsigned)(tab[h - 1] * step % P);
         HIP_OK(hipMemcpy(d_powtab, tab.data(), sizeof(unsigned) * powtab_cap, hipMemcpyHostToDevice));
     }
+}
+
+ShuffleBufs Env::shuffle_bufs() const {
+    const size_t seg = shuf_cap / 4;
+    return ShuffleBufs{d_shuf, d_shuf + seg, d_shuf + 2 * seg, d_shuf + 3 * seg};
 }
 
 void Env::push_rng() {
@@ -1487,9 +1492,9 @@ void Env::step_begin() {
             HIP_OK(hipMemsetAsync(d_claim, 0xFF, sizeof(unsigned long long) * (size_t)width * height, stream));
             claim_clean = true;
         }
-        const size_t seg = shuf_cap / 5;
+        const ShuffleBufs B = shuffle_bufs();
         SoloStep S{};
-        S.scount = d_shuf; S.scur = d_shuf + seg; S.sj = d_shuf + 2 * seg; S.soff = d_shuf + 3 * seg; S.slist = d_shuf + 4 * seg;
+        S.shead = B.head; S.sfirst = B.first; S.sj = B.j; S.slink = B.link;
         S.rank = d_rank; S.powtab = d_powtab; S.hit = d_hit;
         S.rules = d_rule_args; S.progs = d_rule_progs; S.n_rules = (int)rule_args.size();
         S.kmax = attack_kmax; S.nt_eval = solo_nt_eval; S.max_rounds = 1 << 20;
@@ -1507,15 +1512,14 @@ void Env::step_begin() {
             push_rng();
             if (rng_here || caps != rank_cap + shuf_cap + sums_cap + powtab_cap) state_epoch++;   // (something was enqueued on `stream`)
         }
-        const size_t seg = shuf_cap / 5;
-        int *scount = d_shuf, *scur = d_shuf + seg, *sj = d_shuf + 2 * seg, *soff = d_shuf + 3 * seg, *slist = d_shuf + 4 * seg;
+        const ShuffleBufs B = shuffle_bufs();
         // shuffle, hit gather and the death-rank fixed point only read the world (and write scratch no render looks at)
         hipStream_t a = beside ? side_stream() : stream;
         {
             ProfScope p(*this, "attack", false, a);
-            launch_shuffle(a, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
+            launch_shuffle(a, total_n, d_counters, B, d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
             if (overlap_level == 2 && a != stream) { join_side(); a = stream; }
-            launch_attack_rank(a, W, d_rank, scount, scur, false);
+            launch_attack_rank(a, W, d_rank, B, false);
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
             // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
@@ -1545,7 +1549,7 @@ void Env::step_begin() {
             if (!rules_on_host) launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
             if (any_multicell) launch_finish(stream, W);
         }
-        enqueue_counters();
+        launch_step_report(stream, d_counters, h_rec, ++step_seq, (int)groups.size());
     } else {
         // ---------------- checked driver
         claim_clean = false;
@@ -1572,11 +1576,9 @@ void Env::step_begin() {
                 rng_on_device = false;
             } else {              // exact parallel replay on the device
                 push_rng();
-                const size_t seg = shuf_cap / 5;
-                int *scount = d_shuf, *scur = d_shuf + seg, *sj = d_shuf + 2 * seg, *soff = d_shuf + 3 * seg, *slist = d_shuf + 4 * seg;
-                launch_shuffle(stream, total_n, d_counters, sj, scount, soff, scur, slist, d_sums, d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
+                launch_shuffle(stream, total_n, d_counters, shuffle_bufs(), d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
             }
-            launch_attack_rank(stream, W, d_rank, d_shuf, d_shuf + shuf_cap / 5, host_shuffle);
+            launch_attack_rank(stream, W, d_rank, shuffle_bufs(), host_shuffle);
             attack_round = 0;
             attack_rounds_checked(W);
             if (!first_render) {   // attack events are recorded once rendering has started (GridWorld.cc:484,508)
@@ -1623,30 +1625,40 @@ void Env::step_end(int *done) {
     if (!step_pending) fatal("step_end without step_begin");
     step_pending = false;
     use_device();
-    if (step_was_solo) {
+    // the one-launch step and the single-sync driver both report through the pinned record
+    if (step_was_solo || step_was_fast) {
         wait_record(step_seq);
         const StepRecord &r = *h_rec;
-        if (r.error) fatal("%s resolution did not converge", r.error == 1 ? "attack" : r.error == 2 ? "move" : "turn");
-        if (r.unsupported) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
-        if (r.pack_overflow) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
-        if (r.bad_action) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
-        if (r.hit_overflow) fatal("a target collected more attack hits than the engine's hit lists hold (256)");
-        if (rng_on_device) rng.x = r.rng;
-        last_attack_iters = r.rounds_attack; last_move_iters = r.rounds_move; attack_round = r.rounds_attack;
-        int live = 0;
-        for (size_t g = 0; g < groups.size(); g++) {
-            groups[g].h_dead = r.dead[g];
-            groups[g].h_taken = r.taken[g];
-            groups[g].acted = false;
-            if (groups[g].n - groups[g].h_dead > 0) live++;
+        if (!(r.open_attack | r.open_move)) {
+            if (r.error) fatal("%s resolution did not converge", r.error == 1 ? "attack" : r.error == 2 ? "move" : "turn");
+            if (r.unsupported) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
+            if (r.pack_overflow) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
+            if (r.bad_action) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
+            if (r.hit_overflow) fatal("a target collected more attack hits than the engine's hit lists hold (256)");
+            if (rng_on_device) rng.x = r.rng;
+            if (step_was_solo) { last_attack_iters = r.rounds_attack; last_move_iters = r.rounds_move; attack_round = r.rounds_attack; }
+            else {
+                if (boost_attack > 0) boost_attack--;
+                if (boost_move > 0) boost_move--;
+                if (rules_on_host) eval_rules_host();
+            }
+            int live = 0;
+            for (size_t g = 0; g < groups.size(); g++) {
+                groups[g].h_dead = r.dead[g];
+                groups[g].h_taken = r.taken[g];
+                groups[g].acted = false;
+                if (groups[g].n - groups[g].h_dead > 0) live++;
+            }
+            *done = live < (int)groups.size();   // GridWorld.cc:619-624
+            for (size_t k = 0; k < rules.size(); k++)
+                if ((rules_on_host ? host_triggers[k] != 0 : ((r.triggers >> k) & 1ull) != 0) && rules[k].terminal) *done = 1;
+            move_seq_base = 0;
+            h_occ_valid = false;
+            paint_valid = step_live_paint; mini_valid = false;
+            live_paint_now = false;
+            return;
         }
-        *done = live < (int)groups.size();   // GridWorld.cc:619-624
-        for (size_t k = 0; k < rules.size(); k++) if (((r.triggers >> k) & 1ull) && rules[k].terminal) *done = 1;
-        move_seq_base = 0;
-        h_occ_valid = false;
-        paint_valid = step_live_paint; mini_valid = false;
-        live_paint_now = false;
-        return;
+        read_counters();     // a phase ran out of optimistic rounds: the whole counter block, for the continuation below
     }
     HIP_OK(hipStreamSynchronize(stream));
     const int *c = h_counters;
@@ -1738,10 +1750,10 @@ bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, con
     }
     step_live_paint = live_paint_now = paint_valid;
     W.live_paint = step_live_paint ? 1 : 0;
-    const size_t seg = shuf_cap / 5;
+    const ShuffleBufs B = shuffle_bufs();
     SoloStep &S = item.S;
     S = SoloStep{};
-    S.scount = d_shuf; S.scur = d_shuf + seg; S.sj = d_shuf + 2 * seg; S.soff = d_shuf + 3 * seg; S.slist = d_shuf + 4 * seg;
+    S.shead = B.head; S.sfirst = B.first; S.sj = B.j; S.slink = B.link;
     S.rank = d_rank; S.powtab = d_powtab; S.hit = d_hit;
     S.rules = d_rule_args; S.progs = d_rule_progs; S.n_rules = (int)rule_args.size();
     S.kmax = attack_kmax; S.nt_eval = solo_nt_eval; S.max_rounds = 1 << 20;

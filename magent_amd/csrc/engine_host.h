@@ -209,6 +209,7 @@ private:
     RuleArgs *d_rule_args = nullptr; RuleProg *d_rule_progs = nullptr;
     void shuffle_buffers(int n_max);
     void push_rng();
+    ShuffleBufs shuffle_bufs() const;
     void attack_rounds_checked(const WorldView &W);
     void move_rounds_checked(const WorldView &W);
     void phase_tail(const WorldView &W, int from);

@@ -88,6 +88,36 @@ __global__ void k_step_reset(int *counters) {
     if (threadIdx.x == 0) counters[CTR_ATTACK] = 0;
     for (int k = CTR_TRIGGER + threadIdx.x; k < CTR_TRIGGER_END; k += blockDim.x) counters[k] = 0;
 }
+// The end-of-step report of the multi-launch step, straight into pinned host memory (the host spins on `seq`: a stream
+// synchronisation behind a device-to-host copy costs several times the PCIe write it waits for), and the per-step counters
+// back to zero -- unless a phase was left open: then the host continues from exactly this state and resets afterwards.
+__global__ void __launch_bounds__(64) k_step_report(int *counters, StepRecord *rec, int seq, int NG) {
+    const int tid = threadIdx.x;
+    const int oa = counters[CTR_OPEN_ATTACK], om = counters[CTR_OPEN_MOVE];
+    const bool open = (oa | om) != 0;
+    const bool trig = tid < CTR_TRIGGER_END - CTR_TRIGGER && counters[CTR_TRIGGER + tid] != 0;
+    const unsigned long long mask = __ballot(trig);
+    if (tid < NG) {
+        int d = 0;
+        for (int k = 0; k < DEAD_SLOTS; k++) d += counters[dead_slot(tid, k)];
+        rec->dead[tid] = d; rec->taken[tid] = counters[CTR_TAKEN + tid];
+    }
+    if (tid == 0) {
+        rec->triggers = mask;
+        rec->rng = (unsigned)counters[CTR_RNG];
+        rec->last_a = counters[CTR_ATTACK];
+        rec->unsupported = counters[CTR_UNSUPPORTED]; rec->pack_overflow = counters[CTR_PACK_OVERFLOW];
+        rec->bad_action = counters[CTR_BAD_ACTION]; rec->hit_overflow = counters[CTR_HIT_OVERFLOW];
+        rec->error = 0; rec->rounds_attack = 0; rec->rounds_move = 0; rec->n_marks = 0;
+        rec->open_attack = oa; rec->open_move = om;
+    }
+    if (!open) {
+        if (tid < CTR_TRIGGER_END - CTR_TRIGGER) counters[CTR_TRIGGER + tid] = 0;
+        if (tid == 0) counters[CTR_ATTACK] = 0;
+    }
+    __threadfence_system();
+    if (tid == 0) __hip_atomic_store((int *)&rec->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_set_rng(int *counters, unsigned x) { if (threadIdx.x == 0) counters[CTR_RNG] = (int)x; }
 
 // memset that respects the gate: the claim array still holds the attack phase's hit bits when the host has to continue
@@ -597,68 +627,18 @@ __global__ void __launch_bounds__(256) k_commit_action(GroupDev G, TypeDev T) {
     if (pend != PEND_NONE) G.last_action[i] = pend_action(pend, T);
 }
 
-// ------------------------------------------------------------------------------------------------ generic int scan
-// exclusive prefix sum of an int array, ISCAN_TILE items per block, 8 consecutive items per thread
-constexpr int ISCAN_ITEMS = 8, ISCAN_TILE = 256 * ISCAN_ITEMS;
-
-__global__ void __launch_bounds__(256) k_iscan_a(const int *in, int n, int *sums) {
-    __shared__ int s_w[4];
-    int base = blockIdx.x * ISCAN_TILE + threadIdx.x * ISCAN_ITEMS, t = 0;
-#pragma unroll
-    for (int k = 0; k < ISCAN_ITEMS; k++) if (base + k < n) t += in[base + k];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
-    if (lane_id() == 0) s_w[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
-__global__ void __launch_bounds__(256) k_iscan_c(const int *in, int n, const int *sums, int *out) {
-    __shared__ int s_w[4];
-    int base = blockIdx.x * ISCAN_TILE + threadIdx.x * ISCAN_ITEMS;
-    int v[ISCAN_ITEMS], t = 0;
-#pragma unroll
-    for (int k = 0; k < ISCAN_ITEMS; k++) { v[k] = base + k < n ? in[base + k] : 0; t += v[k]; }
-    int x = t;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d); if (lane_id() >= d) x += y; }
-    if (lane_id() == 63) s_w[threadIdx.x >> 6] = x;
-    __syncthreads();
-    int run = block_prefix(sums, blockIdx.x) + x - t;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += s_w[w];
-#pragma unroll
-    for (int k = 0; k < ISCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
-}
-
-__device__ __forceinline__ void iscan_solo_body(const int *in, int n, int *out) {
-    __shared__ int s_w[SOLO_THREADS / 64];
-    const int wave = threadIdx.x >> 6;
-    int run = 0;
-    for (int t0 = 0; t0 < n; t0 += SOLO_THREADS) {
-        const int i = t0 + threadIdx.x;
-        const int v = i < n ? in[i] : 0;
-        int x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d); if (lane_id() >= d) x += y; }
-        if (lane_id() == 63) s_w[wave] = x;
-        __syncthreads();
-        int before = 0, all = 0;
-        for (int w = 0; w < SOLO_THREADS / 64; w++) { int t = s_w[w]; all += t; if (w < wave) before += t; }
-        if (i < n) out[i] = run + before + x - v;
-        run += all;
-        __syncthreads();
-    }
-}
-__global__ void __launch_bounds__(SOLO_THREADS) k_iscan_solo(const int *in, int n, int *out) { iscan_solo_body(in, n, out); }
-
 // ------------------------------------------------------------------------------------------------ attack shuffle
 // The reference shuffles the attack list with `for i: j = (int)rng() % (i + 1); swap(buf[i], buf[j])`
-// (GridWorld.cc:464-468), rng = minstd_rand0.  Exact parallel replay:
-//   draw   j_i from the i-th engine output, by LCG skip-ahead: r_i = 16807^(i+1) * x0 mod (2^31 - 1)
-//   bucket for every position v the list of steps k with j_k == v (counting sort: int atomics + scan; buckets hold
-//          ln(A / v) entries on average, so they are scanned rather than sorted)
+// (GridWorld.cc:464-468), rng = minstd_rand0.  Exact parallel replay in two launches:
+//   draw   j_i from the i-th engine output, by LCG skip-ahead: r_i = 16807^(i+1) * x0 mod (2^31 - 1).  Every step threads
+//          itself onto the list of its slot (head[v] -> the steps k with j_k == v, in arrival order: one atomicExch) and offers
+//          itself as the first LATER step that hits the slot (first[v] = the smallest m != v with j_m == v: one atomicMax of
+//          0x7FFFFFFF - m, so that the rest state of head[] and first[] is zero).
 //   chase  element i sits at j_i after step i; it is moved again by the first later step k whose j_k equals its
-//          position, and then sits at k.  Following that chain (expected length O(log A)) gives its final position.
+//          position, and then sits at k.  The first hop walks the list of slot j_i for the smallest entry above i (lists hold
+//          ln(A / v) entries on average); from then on the element sits at the slot of the step that moved it and every
+//          further hop is one load of first[].  The chain (expected length O(1), longest O(log A)) ends at the final position.
+// (Round 1 built the lists with a counting sort -- count, scan, fill: three more launches -- and searched a bucket per hop.)
 __device__ __forceinline__ unsigned mulmod31(unsigned a, unsigned b) {
     unsigned long long p = (unsigned long long)a * b;
     unsigned long long r = (p & 0x7FFFFFFFull) + (p >> 31);
@@ -667,12 +647,13 @@ __device__ __forceinline__ unsigned mulmod31(unsigned a, unsigned b) {
 }
 
 // powtab: 16807^t mod (2^31 - 1) for t = 0..255, then 16807^(256 h) for h = 0, 1, ... (host-computed, engine.hip)
-__device__ __forceinline__ void shuffle_draw_body(unsigned x0, int i, int *j, int *count, const unsigned *powtab) {
+__device__ __forceinline__ void shuffle_draw_body(unsigned x0, int i, int *j, int *head, int *first, int *link, const unsigned *powtab) {
     const unsigned e = (unsigned)i + 1u;               // the i-th draw is x0 * 16807^(i+1): two table factors
     const unsigned acc = mulmod31(mulmod31(x0, powtab[256 + (e >> 8)]), powtab[e & 255u]);
     int ji = (int)(acc % (unsigned)(i + 1));   // (int)rng() % (i + 1): outputs are in [1, 2^31 - 2]
     j[i] = ji;
-    atomicAdd(&count[ji], 1);
+    link[i] = atomicExch(&head[ji], i + 1);    // entries are step + 1: 0 ends a list
+    if (ji != i) atomicMax(&first[ji], 0x7FFFFFFF - i);
 }
 // the engine state after the shuffle's A draws: x <- 16807^A x
 __device__ __forceinline__ unsigned rng_skip(unsigned x, unsigned n) {
@@ -680,48 +661,36 @@ __device__ __forceinline__ unsigned rng_skip(unsigned x, unsigned n) {
     while (n) { if (n & 1u) x = mulmod31(x, base); base = mulmod31(base, base); n >>= 1; }
     return x;
 }
-__device__ __forceinline__ void shuffle_fill_body(int k, const int *j, const int *offset, int *cursor, int *list) {
-    int v = j[k];
-    list[offset[v] + atomicAdd(&cursor[v], 1)] = k;
-}
-__device__ __forceinline__ void shuffle_chase_body(int i, const int *j, const int *offset, const int *count, const int *list, int *rank) {
-    int p = j[i], t = i;
-    while (true) {
-        const int *b = list + offset[p];
-        int n = count[p], nxt = 0x7FFFFFFF;
-        for (int c = 0; c < n; c++) { int k = b[c]; if (k > t && k < nxt) nxt = k; }   // buckets are short (unsorted)
-        if (nxt == 0x7FFFFFFF) break;
-        p = nxt; t = nxt;
+__device__ __forceinline__ void shuffle_chase_body(int i, const int *j, const int *head, const int *first, const int *link, int *rank) {
+    int p = j[i];
+    int nxt = 0x7FFFFFFF;
+    for (int e = head[p]; e != 0; e = link[e - 1]) { const int k = e - 1; if (k > i && k < nxt) nxt = k; }
+    if (nxt != 0x7FFFFFFF) {
+        p = nxt;
+        for (int f; (f = first[p]) != 0;) p = 0x7FFFFFFF - f;
     }
     rank[i] = p;
 }
 
-__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *count, unsigned *hitbits, size_t ncell,
+__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *head, int *first, int *link, unsigned *hitbits, size_t ncell,
                                                      const unsigned *powtab) {
     const int A = counters[CTR_ATTACK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     // the per-cell hit words of the coming attack phase start from zero (they share the move phase's claim array)
     if (A > 0) for (size_t c = i; c < ncell; c += (size_t)gridDim.x * blockDim.x) hitbits[c] = 0u;
     if (i >= A) return;
-    shuffle_draw_body((unsigned)counters[CTR_RNG], i, j, count, powtab);
+    shuffle_draw_body((unsigned)counters[CTR_RNG], i, j, head, first, link, powtab);
 }
 
-__global__ void __launch_bounds__(256) k_shuffle_fill(int *counters, const int *j, const int *offset, int *cursor, int *list) {
-    const int A = counters[CTR_ATTACK];
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) {   // (every draw has read the old state: k_shuffle_draw ran before)
-        counters[CTR_LAST_A] = A;
-        counters[CTR_RNG] = (int)rng_skip((unsigned)counters[CTR_RNG], (unsigned)A);   // the host mirror is refreshed at the end-of-step readback
-    }
-    if (k >= A) return;
-    shuffle_fill_body(k, j, offset, cursor, list);
-}
-
-__global__ void __launch_bounds__(256) k_shuffle_chase(const int *counters, const int *j, const int *offset, const int *count, const int *list, int *rank) {
+__global__ void __launch_bounds__(256) k_shuffle_chase(int *counters, const int *j, const int *head, const int *first, const int *link, int *rank) {
     const int A = counters[CTR_ATTACK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {   // (every draw has read the old state: k_shuffle_draw ran before)
+        counters[CTR_LAST_A] = A;
+        counters[CTR_RNG] = (int)rng_skip((unsigned)counters[CTR_RNG], (unsigned)A);   // the host mirror is refreshed by the end-of-step report
+    }
     if (i >= A) return;
-    shuffle_chase_body(i, j, offset, count, list, rank);
+    shuffle_chase_body(i, j, head, first, link, rank);
 }
 
 // ------------------------------------------------------------------------------------------------ attack phase
@@ -756,13 +725,13 @@ __device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int 
     }
     if (W.food_mode) { G.eat[i] = -1.0f; G.fcell[i] = -1; }
 }
-__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_count, int *shuf_cursor) {
+__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_head, int *shuf_first) {
     if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // attack rounds start
     const int A = W.counters[CTR_ATTACK];
     if (A == 0) return;
-    // the shuffle's bucket counters have been read for the last time (k_shuffle_chase): back to zero for the next step
+    // the shuffle's list heads and first-hit words have been read for the last time (k_shuffle_chase): back to zero for the next step
     for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < A; k += gridDim.x * gridDim.y * blockDim.x) {
-        shuf_count[k] = 0; shuf_cursor[k] = 0;
+        shuf_head[k] = 0; shuf_first[k] = 0;
     }
     const int g = blockIdx.y;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1962,7 +1931,7 @@ __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int 
 }
 
 // The minimap of the next observations in one workgroup: an LDS histogram of every group (s_hist: [NG][VHW] counts, then
-// [NG] agents left out), then count / total exactly as the reference divides (k_minimap, k_minimap_norm; GridWorld.cc:331-360)
+// [NG] agents left out), then count / total exactly as the reference divides (k_minimap; GridWorld.cc:331-360)
 __device__ __forceinline__ void minimap_one_workgroup(const GroupDev *grp, int NG, const MiniArgs &M, int *s_hist, int nthreads) {
     const int tid = threadIdx.x, VHW = M.vh * M.vw;
     for (int k = tid; k < NG * VHW + NG; k += nthreads) s_hist[k] = 0;
@@ -2027,26 +1996,21 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
 
     if (A > 0) {
         // ---- shuffle (exact replay of the reference's Fisher-Yates, see k_shuffle_*)
-        for (int i = tid; i < A; i += SOLO_STEP_THREADS) shuffle_draw_body(x0, i, S.sj, S.scount, S.powtab);
+        for (int i = tid; i < A; i += SOLO_STEP_THREADS) shuffle_draw_body(x0, i, S.sj, S.shead, S.sfirst, S.slink, S.powtab);
         __syncthreads();
         if (tid == 0) W.counters[CTR_RNG] = (int)rng_skip(x0, (unsigned)A);
         SOLO_MARK();   // 1: draw
-        iscan_solo_body(S.scount, A, S.soff);
-        SOLO_MARK();   // 2: scan
-        for (int k = tid; k < A; k += SOLO_STEP_THREADS) shuffle_fill_body(k, S.sj, S.soff, S.scur, S.slist);
+        for (int i = tid; i < A; i += SOLO_STEP_THREADS) shuffle_chase_body(i, S.sj, S.shead, S.sfirst, S.slink, S.rank);
         __syncthreads();
-        SOLO_MARK();   // 3: fill
-        for (int i = tid; i < A; i += SOLO_STEP_THREADS) shuffle_chase_body(i, S.sj, S.soff, S.scount, S.slist, S.rank);
-        __syncthreads();
-        SOLO_MARK();   // 4: chase
-        // ---- ranks, hit bits; the shuffle's bucket counters go back to zero
-        for (int k = tid; k < A; k += SOLO_STEP_THREADS) { S.scount[k] = 0; S.scur[k] = 0; }
-        // (one-cell bodies: the targets are listed as they are hit -- in the shuffle's list array, free by now)
+        SOLO_MARK();   // 2: chase
+        // ---- ranks, hit bits; the shuffle's list heads go back to zero
+        for (int k = tid; k < A; k += SOLO_STEP_THREADS) { S.shead[k] = 0; S.sfirst[k] = 0; }
+        // (one-cell bodies: the targets are listed as they are hit -- in the shuffle's link array, free by now)
         __shared__ int s_ntgt;
         const bool listed = !W.any_multicell;
         if (tid == 0) s_ntgt = 0;
         __syncthreads();
-        SOLO_EACH(g, i) attack_rank_body(W, g, i, S.rank, S.hit, listed ? S.slist : nullptr, &s_ntgt);
+        SOLO_EACH(g, i) attack_rank_body(W, g, i, S.rank, S.hit, listed ? S.slink : nullptr, &s_ntgt);
         __syncthreads();
         SOLO_MARK();   // 5: rank
         // ---- death ranks: in-place fixed point, one round per barrier pair
@@ -2061,7 +2025,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
             if (listed) {
                 if (tid < S.nt_eval)
                     for (int j = tid, n = s_ntgt; j < n; j += S.nt_eval) {
-                        const int o = S.slist[j];
+                        const int o = S.slink[j];
                         attack_eval_body(W, gtab, ttab, ref_group(o), ref_index(o), rounds_attack, S.hit, s_rank, s_ref, S.nt_eval, tid, flag, S.kmax);
                     }
             } else if (tid < S.nt_eval)
@@ -2269,7 +2233,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
         __syncthreads();
         if (tid < MAXG) { S.gtab_out[tid] = s_W.grp[tid]; S.ttab_out[tid] = s_W.type[tid]; }
         // ---- (cycle) the minimap of the next observations: LDS histogram of every group, then count / total exactly as the
-        // reference divides (k_minimap, k_minimap_norm)
+        // reference divides (k_minimap)
         if (S.mini.vh > 0) minimap_one_workgroup(W.grp, NG, S.mini, (int *)s_dyn, SOLO_STEP_THREADS);   // (the hit lists are done with)
     }
     SOLO_MARK();       // (cycle) rewards, clear_dead, minimap
@@ -2288,7 +2252,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
             S.rec->pack_overflow = __hip_atomic_load(&W.counters[CTR_PACK_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             S.rec->bad_action = __hip_atomic_load(&W.counters[CTR_BAD_ACTION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             S.rec->hit_overflow = __hip_atomic_load(&W.counters[CTR_HIT_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            S.rec->error = error;
+            S.rec->error = error; S.rec->open_attack = 0; S.rec->open_move = 0;
             S.rec->rounds_attack = rounds_attack; S.rec->rounds_move = rounds_move;
             S.rec->n_marks = n_marks < 40 ? n_marks : 40;
             for (int k = 0; k < S.rec->n_marks; k++) S.rec->marks[k] = s_marks[k];
@@ -2426,6 +2390,7 @@ void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int 
     for (int g = 0; g < W.G; g++) mx = W.grp[g].n > mx ? W.grp[g].n : mx;
     int bx = (mx + 255) / 256;
     if (bx > 128) bx = 128;      // every block ends with one global atomic per non-empty bin: few, fat blocks
+    // (folding the normalisation into the histogram's last block -- ticket counter -- was measured: +12 us, the tickets serialise)
     hipLaunchKernelGGL(k_minimap, dim3(bx, W.G), dim3(256), VHW * sizeof(int), s, W, R, counts, left_out, skip);
     hipLaunchKernelGGL(k_minimap_norm, dim3((W.G * VHW + 255) / 256), dim3(256), 0, s, R, W.G, counts, mini, left_out, skip);
 }
@@ -2482,20 +2447,14 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
 }
 
 // n_max = upper bound of the attack-list length (the number of agents); the actual length is read on the device
-void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank,
-                    unsigned *hitbits, size_t ncell, const unsigned *powtab) {
-    // count / cursor are zero here: zeroed when allocated, and again by k_attack_rank after every use
+void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell, const unsigned *powtab) {
+    // head / first are zero here: zeroed when allocated, and again by k_attack_rank after every use
     dim3 g((n_max + 255) / 256), b(256);
-    int nb = (n_max + ISCAN_TILE - 1) / ISCAN_TILE;
-    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, j, count, hitbits, ncell, powtab);
-    if (n_max <= SOLO_MAX) {
-        hipLaunchKernelGGL(k_iscan_solo, dim3(1), dim3(SOLO_THREADS), 0, s, count, n_max, offset);
-    } else {
-        hipLaunchKernelGGL(k_iscan_a, dim3(nb), b, 0, s, count, n_max, sums);
-        hipLaunchKernelGGL(k_iscan_c, dim3(nb), b, 0, s, count, n_max, sums, offset);
-    }
-    hipLaunchKernelGGL(k_shuffle_fill, g, b, 0, s, counters, j, offset, cursor, list);
-    hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, j, offset, count, list, rank);
+    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, B.j, B.head, B.first, B.link, hitbits, ncell, powtab);
+    hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, B.j, B.head, B.first, B.link, rank);
+}
+void launch_step_report(hipStream_t s, int *counters, StepRecord *rec, int seq, int NG) {
+    hipLaunchKernelGGL(k_step_report, dim3(1), dim3(64), 0, s, counters, rec, seq, NG);
 }
 void launch_step_reset(hipStream_t s, int *counters) { hipLaunchKernelGGL(k_step_reset, dim3(1), dim3(64), 0, s, counters); }
 void launch_set_rng(hipStream_t s, int *counters, unsigned x) { hipLaunchKernelGGL(k_set_rng, dim3(1), dim3(64), 0, s, counters, x); }
@@ -2504,9 +2463,9 @@ void launch_set_counter(hipStream_t s, int *counters, int index, int value, int 
 }
 
 // hit bits live in the (then unused) claim array of the move phase
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, int *shuf_count, int *shuf_cursor, bool clear_hitbits) {
+void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits) {
     if (clear_hitbits) (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);   // (else k_shuffle_draw did it)
-    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim, shuf_count, shuf_cursor);
+    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim, B.head, B.first);
 }
 static int att_threads(int kmax) {
     static const int forced = getenv("MAGENT_ATT_THREADS") ? atoi(getenv("MAGENT_ATT_THREADS")) : 0;

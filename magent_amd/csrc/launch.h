@@ -73,7 +73,7 @@ struct MiniArgs {
 
 // the one-launch step of small worlds (k_step_solo)
 struct SoloStep {
-    int *sj, *scount, *soff, *scur, *slist, *rank;   // shuffle scratch (count / cursor zero between steps)
+    int *sj, *shead, *sfirst, *slink, *rank;   // shuffle scratch (head / first zero between steps; link doubles as the target list)
     const unsigned *powtab;
     unsigned *hit;                 // per cell: attack hit bits, then the generic move's `wanted` counters; zero between phases
     const RuleArgs *rules;         // device copies of the compiled reward rules
@@ -100,6 +100,7 @@ struct BatchItem {
     SoloStep S;
     RenderMulti M;
 };
+void launch_step_report(hipStream_t s, int *counters, StepRecord *rec, int seq, int NG);
 void launch_commit_action(hipStream_t s, const GroupDev &G, const TypeDev &T);
 void launch_cycle_batch(hipStream_t s, const BatchItem *d_items, int n_env, int slots, int max_blocks, size_t render_lds, size_t step_lds);
 size_t render_strip_lds(const RenderPlan &P);
@@ -111,13 +112,14 @@ void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int 
 void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt);
 void launch_render_multi(hipStream_t s, const WorldView &W, const RenderMulti &M);
 void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4);
-void launch_shuffle(hipStream_t s, int n_max, int *counters, int *j, int *count, int *offset, int *cursor, int *list, int *sums, int *rank,
-                    unsigned *hitbits, size_t ncell, const unsigned *powtab);
+// scratch of the attack shuffle: four int arrays of (at least) n_max entries; head / first are zero between steps
+struct ShuffleBufs { int *head, *first, *j, *link; };
+void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell, const unsigned *powtab);
 void launch_set_rng(hipStream_t s, int *counters, unsigned x);
 void launch_step_reset(hipStream_t s, int *counters);
 void launch_set_counter(hipStream_t s, int *counters, int index, int value, int unless_index);
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, int *shuf_count, int *shuf_cursor, bool clear_hitbits);
+void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits);
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);
 void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag);

@@ -16,7 +16,7 @@ env.set_seed(1); env.reset()
 hs = env.get_handles()
 for h in hs:
     env.add_agents(h, "random", n=N)
-names = ["start", "draw", "scan", "fill", "chase", "rank", "eval", "apply", "unhit", "prep", "claim", "init", "jump", "commit", "rules", "finish"]
+names = ["start", "draw", "chase", "rank", "eval", "apply", "unhit", "prep", "claim", "init", "jump", "commit", "rules", "finish"]
 acc = None
 for s in range(30):
     for h in hs:

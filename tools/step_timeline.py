@@ -7,7 +7,7 @@ import sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 names = [r["Kernel_Name"].split("(")[0].replace("magent_amd::", "").replace("void ", "") for r in rows]
-marks = [i for i, n in enumerate(names) if n.startswith("k_step_reset")]
+marks = [i for i, n in enumerate(names) if n.startswith("k_step_report")]
 if not marks:      # the one-launch step has no reset kernel of its own: a cycle ends with clear_dead
     marks = [i for i, n in enumerate(names) if n.startswith("k_clear_solo_all")]
 a, b = marks[-back], marks[-back + 1]
