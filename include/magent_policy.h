@@ -1,0 +1,57 @@
+/*
+ * magent_policy.h -- C-ABI of the inference path of the reference's deep Q network on MI355X (libmagent.so).
+ *
+ * What it replaces: the forward pass of python/magent/builtin/tf_model/dqn.py:151-189 (2 x conv3x3(32, valid, relu) ->
+ * dense 256 || dense 256 -> dueling head) as DeepQNetwork.infer_action calls it (dqn.py:191-228) between
+ * GridWorld.get_observation and GridWorld.set_action -- BASELINE config 5's policy step.  Additive: the reference has no
+ * C entry point here (its model is a TensorFlow graph); the Python binding is magent_amd/builtin/torch_model/hip_policy.py.
+ *
+ * All pointers are DEVICE pointers; the call enqueues two kernels on `stream` and returns.  Inputs are the engine's own
+ * observation tensors (env_get_observation_device): view float[n][view_h][view_w][view_c], feature float[n][feat].
+ * Numerics: inputs, weights and inter-layer activations are rounded to bf16, products accumulate in f32 (MFMA).
+ */
+#ifndef MAGENT_AMD_POLICY_H
+#define MAGENT_AMD_POLICY_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int view_h, view_w, view_c;   /* view_c <= 8 */
+    int feat;                     /* <= 64 */
+    int n_action;                 /* <= 31 */
+} PolicyDqnShape;
+
+/* Weights in "fragment order" (bf16, 16-byte units of 8 values): for k-step s (16 values of the reduction dimension) and
+ * 32-wide output tile T, lane l (0..63) holds W[out = 32 T + (l & 31)][k = 16 s + 8 (l >> 5) + 0..7].
+ * The reduction index k of each layer:
+ *   conv1      : tap (ky * 3 + kx) * 8 + channel          (channels padded to 8, taps to 10: 5 k-steps)        [5][64][8]
+ *   conv2      : tap * 32 + slot                          (18 k-steps)                                         [18][64][8]
+ *   dense_view : position (y * (view_w - 4) + x) * 32 + slot                                                    [K/16][8][64][8]
+ *   dense_emb  : feature index (padded to a multiple of 16)                                                     [FK/16][8][64][8]
+ *   head       : hidden slot (tile T' of dense_view / 256 + tile T' of dense_emb: 32 T' + slot); outputs 0..n_action-1 =
+ *                advantage, output n_action = value, the rest zero                                              [32][64][8]
+ * A "slot" s of a 32-wide tile stands for its channel / output (s & 3) + 8 ((s & 15) >> 2) + 4 (s >> 4): the order in which
+ * a lane of the MFMA result holds them (magent_amd/csrc/policy.hip: ch_of).  Biases are float[tiles][32] in slot order. */
+typedef struct {
+    const void *conv1, *conv2, *dense_view, *dense_emb, *head;
+    const float *conv1_bias, *conv2_bias, *dense_view_bias, *dense_emb_bias;
+    float value_bias;
+} PolicyDqnWeights;
+
+/* 1 if the kernels take this shape */
+int policy_dqn_supported(const PolicyDqnShape *shape);
+/* size of the activation workspace (conv2's output, bf16) for n agents */
+int policy_dqn_act_bytes(const PolicyDqnShape *shape, int n, size_t *bytes);
+/* actions[i] = argmax_a Q(view[i], feature[i]); q (optional, may be NULL) = float[n][n_action].  Returns 0, or non-zero if the
+ * shape is not supported / a launch failed (nothing is written then). */
+int policy_dqn_infer(const PolicyDqnShape *shape, const PolicyDqnWeights *weights, const float *view, const float *feature, int n,
+                     void *act_workspace, int *actions, float *q, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGENT_AMD_POLICY_H */

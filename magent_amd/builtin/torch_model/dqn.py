@@ -88,6 +88,15 @@ class DeepQNetwork(BaseModel):
         self.target_net = _QNet(self.view_space, self.feature_space, self.num_actions, use_dueling, use_conv).to(self.device)
         self.target_net.load_state_dict(self.qnet.state_dict())
         self.optimizer = torch.optim.Adam(self.qnet.parameters(), lr=learning_rate)
+        # acting on device-resident observations goes through the hand-written MFMA kernels (bf16 inputs, f32 accumulation;
+        # magent_amd/csrc/policy.hip) when the network has the reference's default shape; MAGENT_HIP_POLICY=0 keeps PyTorch
+        self._hip = None
+        if self.device.type == "cuda" and os.environ.get("MAGENT_HIP_POLICY", "1") != "0":
+            try:
+                from .hip_policy import HipDqnPolicy
+                self._hip = HipDqnPolicy(self.qnet, self.view_space, self.feature_space, self.num_actions, self.device)
+            except (ValueError, OSError, AttributeError):
+                self._hip = None
         # replay memory; mask == 0 marks the padding transition that closes an unfinished episode (dqn.py:249-252)
         self.memory_size, self.replay_len = memory_size, 0
         d = self.device
@@ -110,6 +119,13 @@ class DeepQNetwork(BaseModel):
         view, feature = raw_obs[0], raw_obs[1]
         eps = 0 if policy == "greedy" else eps
         n = len(view)
+        if (self._hip is not None and n > 0 and isinstance(view, torch.Tensor) and isinstance(feature, torch.Tensor) and view.is_cuda
+                and view.dtype == torch.float32 and feature.dtype == torch.float32 and view.is_contiguous() and feature.is_contiguous()):
+            best = self._hip.infer(view, feature)
+            if eps > 0:
+                rnd = torch.randint(self.num_actions, best.shape, dtype=torch.int32, device=self.device)
+                best = torch.where(torch.rand(best.shape, device=self.device) < eps, rnd, best)
+            return best
         out = torch.empty(n, dtype=torch.int32, device=self.device)
         step = max(1, min(n, self.infer_batch_size))
         for beg in range(0, n, step):
@@ -194,6 +210,8 @@ class DeepQNetwork(BaseModel):
             loss.backward()
             torch.nn.utils.clip_grad_norm_(self.qnet.parameters(), 5.0)
             self.optimizer.step()
+            if self._hip is not None:
+                self._hip.dirty = True
             total_loss += float(loss.detach())
             if ct % self.target_update == 0:
                 self.target_net.load_state_dict(self.qnet.state_dict())
@@ -227,6 +245,8 @@ class DeepQNetwork(BaseModel):
     def load(self, dir_name, epoch=0, name=None):
         state = torch.load(self._path(dir_name, name or self.name, epoch), map_location=self.device)
         self.qnet.load_state_dict(state["qnet"])
+        if self._hip is not None:
+            self._hip.dirty = True
         self.target_net.load_state_dict(state["target"])
         self.optimizer.load_state_dict(state["optimizer"])
         self.train_ct = state.get("train_ct", 0)

@@ -52,6 +52,12 @@ DEVICE_ABI = [
     ("env_profile_enable", [_vp, _i]),
     ("env_profile_read", [_vp, _cp, _ip, _fp]),
 ]
+# include/magent_policy.h (struct arguments are passed by reference from magent_amd/builtin/torch_model/hip_policy.py)
+POLICY_ABI = [
+    ("policy_dqn_supported", [_vp]),
+    ("policy_dqn_act_bytes", [_vp, _i, _c.POINTER(_c.c_size_t)]),
+    ("policy_dqn_infer", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+]
 
 _cache = {}
 _lock = __import__("threading").Lock()
@@ -93,5 +99,9 @@ def _load(path=None):
             lib.has_device_api = False
             continue
         fn.restype, fn.argtypes = ctypes.c_int, argtypes
+    for name, argtypes in POLICY_ABI:
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = ctypes.c_int, argtypes
     _cache[path] = lib
     return lib

@@ -1,0 +1,340 @@
+// policy.hip -- the reference's deep Q network (python/magent/builtin/tf_model/dqn.py:151-189), inference only, as two
+// hand-written bf16 MFMA kernels for gfx950.  This is the caller on the far side of the hot path (SURVEY.md 8f rank 1:
+// BASELINE config 5 puts a policy between get_observation and set_action); with the PyTorch / MIOpen network a 2 x 400k
+// self-play step is 42 ms of which the engine is 1.7.
+//
+//   network:  view [n][H][W][C] f32 -> conv3x3(32, valid) relu -> conv3x3(32, valid) relu -> flatten (NHWC) -> dense 256 relu
+//             feature [n][F] f32 -> dense 256 relu;  concat 512 -> advantage (n_action, no bias) and value (1);
+//             Q = value + advantage - mean(advantage)
+//   numerics: inputs, weights and the activations between layers are rounded to bf16 (round to nearest even), every product
+//             is accumulated in f32 by v_mfma_f32_32x32x16_bf16, biases are added in f32.  tests/test_policy.py compares with
+//             a PyTorch f32 computation that rounds at the same points.
+//
+// k_dqn_conv : conv1 + conv2 fused.  A workgroup takes TA agents at a time: their views go to LDS as bf16 with the channels
+//   padded to 8 (one window cell = one 16-byte MFMA operand), conv1's output stays in LDS, conv2's goes to HBM as bf16.
+//   Convolutions are implicit GEMMs with M = output positions, N = 32 channels, K = taps x channels; the 32 x 32 weight
+//   tiles of both layers live in REGISTERS for the life of the wave (92 VGPRs), so an MFMA costs one 16-byte LDS read per
+//   lane.  The weights are the first MFMA operand: the result tile then has the output channels down the registers and the
+//   positions across the lanes, i.e. a lane owns 16 channels of ONE position and stores them as two 16-byte vectors.
+//   (Which 16: ch_of() below.  Activations are kept in that "slot" order; the next layer's weights are permuted to match when
+//   they are packed -- magent_amd/builtin/torch_model/hip_policy.py.)
+// k_dqn_head : dense 2592 -> 256 as a GEMM over 64 agents per workgroup (activations through LDS, packed weights straight from
+//   L2 in fragment order), the feature embedding, the dueling head and the argmax, fused.
+//
+// Weight layouts ("fragment order"): for every k-step s (16 values of K) and 32-wide output tile, 64 lanes x 8 bf16 --
+// lane l holds W[out = l & 31][k = 16 s + 8 (l >> 5) + 0..7], exactly the first operand of v_mfma_f32_32x32x16_bf16
+// (lane map verified on the hardware by tools/probe/mfma_layout.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/magent_policy.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// result register r of lane group g (= lane >> 5) is row (r & 3) + 8 (r >> 2) + 4 g of the 32 x 32 tile
+__device__ __forceinline__ int ch_of(int g, int r) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+constexpr int CONV_THREADS = 256;
+
+struct ConvArgs {
+    const float *view;     // [n][H][W][C]
+    __bf16 *act;           // [n][H2 * W2][32 slots]
+    const bf16x8 *w1, *w2; // fragment order: [5][64], [18][64]
+    const float *b1, *b2;  // [2][16]: bias of the channel in slot 16 g + r
+    int n, H, W, C, TA, n_tiles;
+};
+
+__global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int H1 = A.H - 2, W1 = A.W - 2, H2 = A.H - 4, W2 = A.W - 4;
+    const int cells = A.TA * A.H * A.W, P1 = A.TA * H1 * W1, P2 = A.TA * H2 * W2;
+    bf16x8 *s_view = (bf16x8 *)s_raw;                     // [cells]          one window cell = 8 channels
+    bf16x8 *s_c1 = s_view + cells;                        // [P1][4 chunks]   conv1 output, 32 slots per position, swizzled
+    unsigned short *s_lut1 = (unsigned short *)(s_c1 + (size_t)P1 * 4);   // output position -> its top-left cell
+    unsigned short *s_lut2 = s_lut1 + P1;                                 // conv2 position -> its top-left conv1 position
+    float *s_bias = (float *)(s_lut2 + P2 + ((P1 + P2) & 1));             // [2 layers][2][16]
+
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 5, r32 = l & 31;
+    bf16x8 wf1[5], wf2[18];
+#pragma unroll
+    for (int s = 0; s < 5; s++) wf1[s] = A.w1[s * 64 + l];
+#pragma unroll
+    for (int s = 0; s < 18; s++) wf2[s] = A.w2[s * 64 + l];
+    for (int k = tid; k < 64; k += CONV_THREADS) s_bias[k] = k < 32 ? A.b1[k] : A.b2[k - 32];
+    for (int P = tid; P < P1; P += CONV_THREADS) {
+        const int a = P / (H1 * W1), rem = P - a * H1 * W1, y = rem / W1, x = rem - y * W1;
+        s_lut1[P] = (unsigned short)(a * A.H * A.W + y * A.W + x);
+    }
+    for (int Q = tid; Q < P2; Q += CONV_THREADS) {
+        const int a = Q / (H2 * W2), rem = Q - a * H2 * W2, y = rem / W2, x = rem - y * W2;
+        s_lut2[Q] = (unsigned short)(a * H1 * W1 + y * W1 + x);
+    }
+    // conv1: k-step s covers taps 2 s and 2 s + 1 (lane group g takes tap 2 s + g; tap 9 is padding: zero weights)
+    int off1[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) { const int tap = 2 * s + g; off1[s] = tap < 9 ? (tap / 3) * A.W + tap % 3 : 0; }
+
+    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const int a0 = tile * A.TA, na = min(A.TA, A.n - a0);
+        __syncthreads();     // the previous tile's readers are done (first pass: the tables are written)
+        // ---- the views of this tile, f32 -> bf16, channels padded to 8
+        const float *src = A.view + (size_t)a0 * A.H * A.W * A.C;
+        const int live = na * A.H * A.W;
+        for (int c = tid; c < cells; c += CONV_THREADS) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (__bf16)((c < live && e < A.C) ? src[(size_t)c * A.C + e] : 0.0f);
+            s_view[c] = v;
+        }
+        __syncthreads();
+        // ---- conv1: [P1 positions] x [32 channels], K = 10 taps x 8 channels
+        for (int t = w; t * 32 < P1; t += CONV_THREADS / 64) {
+            const int P = t * 32 + r32, base = s_lut1[min(P, P1 - 1)];
+            f32x16 acc = {0};
+#pragma unroll
+            for (int s = 0; s < 5; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[s], s_view[base + off1[s]], acc, 0, 0, 0);
+            if (P < P1) {
+                bf16x8 o0, o1;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    o0[r] = (__bf16)fmaxf(acc[r] + s_bias[g * 16 + r], 0.0f);
+                    o1[r] = (__bf16)fmaxf(acc[8 + r] + s_bias[g * 16 + 8 + r], 0.0f);
+                }
+                const int sw = (P >> 1) & 3;      // consecutive positions land in different 16-byte columns of the LDS banks
+                s_c1[P * 4 + ((2 * g) ^ sw)] = o0;
+                s_c1[P * 4 + ((2 * g + 1) ^ sw)] = o1;
+            }
+        }
+        __syncthreads();
+        // ---- conv2: [P2 positions] x [32 channels], K = 9 taps x 32 slots; result straight to HBM
+        for (int t = w; t * 32 < P2; t += CONV_THREADS / 64) {
+            const int Q = t * 32 + r32, base = s_lut2[min(Q, P2 - 1)];
+            f32x16 acc = {0};
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const int P = base + (tap / 3) * W1 + tap % 3, sw = (P >> 1) & 3;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap], s_c1[P * 4 + (g ^ sw)], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap + 1], s_c1[P * 4 + ((2 + g) ^ sw)], acc, 0, 0, 0);
+            }
+            if (Q < na * H2 * W2) {
+                bf16x8 o0, o1;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    o0[r] = (__bf16)fmaxf(acc[r] + s_bias[32 + g * 16 + r], 0.0f);
+                    o1[r] = (__bf16)fmaxf(acc[8 + r] + s_bias[32 + g * 16 + 8 + r], 0.0f);
+                }
+                bf16x8 *dst = (bf16x8 *)(A.act + ((size_t)a0 * H2 * W2 + Q) * 32 + 16 * g);
+                dst[0] = o0; dst[1] = o1;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- dense + head
+constexpr int HEAD_THREADS = 256, HEAD_M = 64, HEAD_KC = 64;   // 64 agents per workgroup; K staged 64 at a time
+
+struct HeadArgs {
+    const __bf16 *act;        // [n][K] (K = H2 * W2 * 32, slot order)
+    const float *feat;        // [n][F]
+    const bf16x8 *wv;         // dense_view, fragment order [K / 16][8 tiles][64]
+    const bf16x8 *we;         // dense_emb,  fragment order [FK / 16][8 tiles][64]   (FK = F rounded up to 16)
+    const bf16x8 *wh;         // head, fragment order [32][64]: K = 512 hidden slots, outputs 0..n_action-1 advantage, n_action value
+    const float *bv, *be;     // [8 tiles][2][16]: bias of the output in slot 16 g + r of its tile
+    float value_bias;
+    int n, K, F, FK, n_action;
+    int *actions;             // [n] argmax_a Q
+    float *q;                 // [n][n_action] or null
+};
+
+// one half of the hidden layer (256 values: relu(dense_view), later relu(dense_emb)) of the 64 agents: [agent][32 chunks of
+// 8 bf16], chunk index xor-ed with the agent's low bits.  The head is accumulated half by half, so 32 KB do for both.
+__device__ __forceinline__ int hid_at(int agent, int chunk) { return agent * 32 + (chunk ^ (agent & 7)); }
+
+__global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
+    __shared__ __attribute__((aligned(16))) bf16x8 s_act[2][HEAD_M * (HEAD_KC / 8)];   // 2 x 8 KB: [agent][8 chunks], swizzled
+    __shared__ __attribute__((aligned(16))) bf16x8 s_hid[HEAD_M * 32];                  // 32 KB: relu(dense_view), then relu(dense_emb)
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 5, r32 = l & 31;
+    const int a0 = blockIdx.x * HEAD_M;
+    const int n_chunks = A.K / HEAD_KC;            // K is a multiple of 32; a last half chunk is handled by the tail below
+    const int k_tail = A.K - n_chunks * HEAD_KC;   // 0 or 32
+
+    // stage one K-chunk of the 64 agents' activations: 64 rows x 128 B, thread t -> row t / 4, 32 B piece t % 4
+    auto stage = [&](int buf, int kc, int width_chunks) {
+        const int row = tid >> 2, piece = tid & 3, agent = min(a0 + row, A.n - 1);
+        const bf16x8 *src = (const bf16x8 *)(A.act + (size_t)agent * A.K + (size_t)kc * HEAD_KC) + piece * 2;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int c = piece * 2 + i;
+            if (c < width_chunks) s_act[buf][row * 8 + (c ^ (row & 7))] = src[i];
+        }
+    };
+
+    f32x16 acc[2][2];     // [out tile of this wave][agent tile]
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = f32x16{0};
+
+    stage(0, 0, 8);
+    __syncthreads();
+    const int total = n_chunks + (k_tail ? 1 : 0);
+    for (int kc = 0; kc < total; kc++) {
+        const int buf = kc & 1, steps = (kc < n_chunks) ? 4 : k_tail / 16;
+        if (kc + 1 < total) stage(buf ^ 1, kc + 1, (kc + 1 < n_chunks) ? 8 : k_tail / 8);
+#pragma unroll 4
+        for (int ks = 0; ks < steps; ks++) {
+            const int s = kc * (HEAD_KC / 16) + ks;
+            const bf16x8 w0 = A.wv[((size_t)s * 8 + 2 * w) * 64 + l], w1 = A.wv[((size_t)s * 8 + 2 * w + 1) * 64 + l];
+            const int c = 2 * ks + g;
+            const bf16x8 x0 = s_act[buf][r32 * 8 + (c ^ (r32 & 7))], x1 = s_act[buf][(32 + r32) * 8 + (c ^ (r32 & 7))];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // relu(dense_view) -> hidden slots [0, 256): tile T = 2 w + i holds chunks 4 T + 2 g, 4 T + 2 g + 1 of every agent
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int T = 2 * w + i, agent = 32 * j + r32;
+            bf16x8 o0, o1;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                o0[r] = (__bf16)fmaxf(acc[i][j][r] + A.bv[T * 32 + g * 16 + r], 0.0f);
+                o1[r] = (__bf16)fmaxf(acc[i][j][8 + r] + A.bv[T * 32 + g * 16 + 8 + r], 0.0f);
+            }
+            s_hid[hid_at(agent, 4 * T + 2 * g)] = o0;
+            s_hid[hid_at(agent, 4 * T + 2 * g + 1)] = o1;
+        }
+    // ---- the dueling head: [32 outputs] x [64 agents], K = 512 hidden slots in two halves; waves 0 and 1 take 32 agents each
+    f32x16 h = {0};
+    const int hagent = 32 * (w & 1) + r32;
+    __syncthreads();
+    if (w < 2) {
+#pragma unroll 4
+        for (int s = 0; s < 16; s++) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.wh[s * 64 + l], s_hid[hid_at(hagent, 2 * s + g)], h, 0, 0, 0);
+    }
+    // ---- the feature embedding: K = FK (features as bf16 through the staging buffer, [agent][FK / 8 chunks] <= 8 chunks)
+    {
+        const int row = tid >> 2, piece = tid & 3, agent = min(a0 + row, A.n - 1);
+        for (int c = piece; c < A.FK / 8; c += 4) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const int k = c * 8 + e; v[e] = (__bf16)(k < A.F ? A.feat[(size_t)agent * A.F + k] : 0.0f); }
+            s_act[0][row * 8 + (c ^ (row & 7))] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = f32x16{0};
+    for (int s = 0; s < A.FK / 16; s++) {
+        const bf16x8 w0 = A.we[((size_t)s * 8 + 2 * w) * 64 + l], w1 = A.we[((size_t)s * 8 + 2 * w + 1) * 64 + l];
+        const int c = 2 * s + g;
+        const bf16x8 x0 = s_act[0][r32 * 8 + (c ^ (r32 & 7))], x1 = s_act[0][(32 + r32) * 8 + (c ^ (r32 & 7))];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();     // the first half of the head has read relu(dense_view)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int T = 2 * w + i, agent = 32 * j + r32;
+            bf16x8 o0, o1;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                o0[r] = (__bf16)fmaxf(acc[i][j][r] + A.be[T * 32 + g * 16 + r], 0.0f);
+                o1[r] = (__bf16)fmaxf(acc[i][j][8 + r] + A.be[T * 32 + g * 16 + 8 + r], 0.0f);
+            }
+            s_hid[hid_at(agent, 4 * T + 2 * g)] = o0;
+            s_hid[hid_at(agent, 4 * T + 2 * g + 1)] = o1;
+        }
+    __syncthreads();
+    if (w < 2) {
+#pragma unroll 4
+        for (int s = 16; s < 32; s++) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.wh[s * 64 + l], s_hid[hid_at(hagent, 2 * (s - 16) + g)], h, 0, 0, 0);
+        const int agent = hagent;
+        // lane (agent, g) holds outputs ch_of(g, r); its partner lane ^ 32 the other sixteen
+        float best = -INFINITY, sum = 0.0f, value = 0.0f;
+        int arg = 0x7FFFFFFF;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int o = ch_of(g, r);
+            if (o < A.n_action) { sum += h[r]; if (h[r] > best || (h[r] == best && o < arg)) { best = h[r]; arg = o; } }
+            if (o == A.n_action) value = h[r];
+        }
+        const float obest = __shfl_xor(best, 32);
+        const int oarg = __shfl_xor(arg, 32);
+        sum += __shfl_xor(sum, 32);
+        value += __shfl_xor(value, 32);
+        if (obest > best || (obest == best && oarg < arg)) { best = obest; arg = oarg; }
+        if (a0 + agent < A.n) {
+            if (g == 0) A.actions[a0 + agent] = arg;      // argmax Q = argmax advantage: value and mean are per-agent constants
+            if (A.q) {
+                const float shift = value + A.value_bias - sum / (float)A.n_action;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { const int o = ch_of(g, r); if (o < A.n_action) A.q[(size_t)(a0 + agent) * A.n_action + o] = h[r] + shift; }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int policy_dqn_act_bytes(const PolicyDqnShape *s, int n, size_t *bytes) {
+    *bytes = (size_t)n * (s->view_h - 4) * (s->view_w - 4) * 32 * 2;
+    return 0;
+}
+
+int policy_dqn_supported(const PolicyDqnShape *s) {
+    return s->view_c >= 1 && s->view_c <= 8 && s->view_h >= 5 && s->view_w >= 5 && s->view_h * s->view_w <= 1024 && s->feat >= 1 && s->feat <= 64 &&
+           s->n_action >= 1 && s->n_action <= 31;
+}
+
+int policy_dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const float *view, const float *feat, int n, void *act_workspace,
+                     int *actions, float *q, void *stream) {
+    if (!policy_dqn_supported(s)) return 1;
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int H = s->view_h, W = s->view_w, H1 = H - 2, W1 = W - 2, H2 = H - 4, W2 = W - 4;
+    // agents per workgroup pass: as many as leave two workgroups per CU their LDS (view 16 B / cell, conv1 64 B / position)
+    int TA = 8;
+    size_t lds = 0;
+    for (; TA >= 1; TA--) {
+        const size_t P1 = (size_t)TA * H1 * W1, P2 = (size_t)TA * H2 * W2;
+        lds = (size_t)TA * H * W * 16 + P1 * 64 + (P1 + P2 + ((P1 + P2) & 1)) * 2 + 64 * 4;
+        if (lds <= 72 * 1024 && P1 <= 65535 && (size_t)TA * H * W <= 65535) break;
+    }
+    if (TA < 1) return 1;
+    static bool lds_ok = false;
+    if (!lds_ok) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_conv), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return 2;
+        lds_ok = true;
+    }
+    ConvArgs C{};
+    C.view = view; C.act = (__bf16 *)act_workspace; C.w1 = (const bf16x8 *)w->conv1; C.w2 = (const bf16x8 *)w->conv2; C.b1 = w->conv1_bias; C.b2 = w->conv2_bias;
+    C.n = n; C.H = H; C.W = W; C.C = s->view_c; C.TA = TA; C.n_tiles = (n + TA - 1) / TA;
+    const int grid = C.n_tiles < 512 ? C.n_tiles : 512;     // persistent: weights are fetched once per wave
+    hipLaunchKernelGGL(k_dqn_conv, dim3(grid), dim3(CONV_THREADS), lds, st, C);
+    HeadArgs Hd{};
+    Hd.act = (const __bf16 *)act_workspace; Hd.feat = feat; Hd.wv = (const bf16x8 *)w->dense_view; Hd.we = (const bf16x8 *)w->dense_emb; Hd.wh = (const bf16x8 *)w->head;
+    Hd.bv = w->dense_view_bias; Hd.be = w->dense_emb_bias; Hd.value_bias = w->value_bias;
+    Hd.n = n; Hd.K = H2 * W2 * 32; Hd.F = s->feat; Hd.FK = (s->feat + 15) / 16 * 16; Hd.n_action = s->n_action; Hd.actions = actions; Hd.q = q;
+    hipLaunchKernelGGL(k_dqn_head, dim3((n + HEAD_M - 1) / HEAD_M), dim3(HEAD_THREADS), 0, st, Hd);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+}  // extern "C"

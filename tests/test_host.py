@@ -26,7 +26,7 @@ def hip_lib():
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "magent_runtime_api.h")).read()
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("magent_runtime_api.h", "magent_policy.h"))
     return sorted(set(re.findall(r"^int\s+(\w+)\s*\(", text, flags=re.M)))
 
 

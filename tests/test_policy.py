@@ -1,0 +1,89 @@
+"""The hand-written bf16 MFMA inference kernels of the reference's deep Q network (magent_amd/csrc/policy.hip) against a plain
+PyTorch f32 computation of the same network that rounds to bf16 at the same points (inputs, weights, activations between
+layers) -- so that what is left is the order of the f32 accumulation.
+
+Tolerance: |Q_hip - Q_ref| <= 2e-3 * max|Q_ref| + 2e-3 per entry.  A bf16 activation that sits on a rounding boundary may round
+the other way under a different summation order (one bf16 ulp = 2^-8 relative, on one of 2592 + 256 inputs of the next layer):
+that, not the f32 sums themselves (1e-6), is what the bound covers.  Greedy actions must agree wherever the reference's best and
+second-best Q are further apart than that bound."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(qnet, view, feat):
+    import torch
+    import torch.nn.functional as F
+    r = lambda t: t.to(torch.bfloat16).float()
+    x = r(view).permute(0, 3, 1, 2)
+    x = r(F.relu(F.conv2d(x, r(qnet.conv1.weight), qnet.conv1.bias.float())))
+    x = r(F.relu(F.conv2d(x, r(qnet.conv2.weight), qnet.conv2.bias.float())))
+    x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+    hv = r(F.relu(F.linear(x, r(qnet.dense_view.weight), qnet.dense_view.bias.float())))
+    he = r(F.relu(F.linear(r(feat), r(qnet.dense_emb.weight), qnet.dense_emb.bias.float())))
+    h = torch.cat([hv, he], dim=1)
+    adv = F.linear(h, r(qnet.advantage.weight))
+    val = F.linear(h, r(qnet.value.weight), qnet.value.bias.float())
+    return val + adv - adv.mean(dim=1, keepdim=True)
+
+
+@pytest.mark.parametrize("view_space,feat,n_action,n", [((13, 13, 7), 34, 21, 1000), ((13, 13, 7), 34, 21, 64 * 6 + 5),
+                                                         ((9, 9, 5), 18, 9, 777), ((13, 11, 8), 40, 31, 300), ((7, 7, 3), 5, 5, 131)])
+def test_hip_policy_matches_torch_reference(view_space, feat, n_action, n):
+    import torch
+    from magent_amd.builtin.torch_model.dqn import _QNet
+    from magent_amd.builtin.torch_model.hip_policy import HipDqnPolicy
+    torch.manual_seed(1234 + n)
+    dev = torch.device("cuda", 0)
+    torch.backends.cudnn.allow_tf32 = False
+    qnet = _QNet(view_space, (feat,), n_action, True, True).to(dev)
+    with torch.no_grad():
+        for p in qnet.parameters():          # larger weights than the default init: every layer's output matters in Q
+            p.mul_(3.0)
+    # observation-like inputs: sparse 0/1 channels, fractions, a few large values
+    view = (torch.rand((n,) + view_space, device=dev) < 0.3).float() * torch.rand((n,) + view_space, device=dev)
+    featv = torch.rand((n, feat), device=dev) * 2 - 0.5
+    pol = HipDqnPolicy(qnet, view_space, (feat,), n_action, dev, chunk=512)     # several chunks on the larger cases
+    actions, q = pol.infer(view, featv, want_q=True)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = _reference(qnet, view, featv)
+    scale = float(ref.abs().max())
+    err = (q - ref).abs().max().item()
+    assert err <= 2e-3 * scale + 2e-3, (err, scale)
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * (2e-3 * scale + 2e-3)
+    assert clear.float().mean().item() > 0.5          # the comparison below is not vacuous
+    assert torch.equal(actions[clear].long(), ref.argmax(dim=1)[clear])
+    assert torch.equal(actions.long(), q.argmax(dim=1))      # the kernel's own argmax (first index on ties)
+    # actions only (no Q output) give the same answer
+    assert torch.equal(pol.infer(view, featv), actions)
+
+
+def test_hip_policy_follows_parameter_updates():
+    """DeepQNetwork repacks the kernel's weights after training: infer_action through the HIP path tracks the torch network"""
+    import torch
+    import magent_amd
+    from magent_amd.builtin.torch_model import DeepQNetwork
+    env = magent_amd.GridWorld("battle", map_size=40, device_obs=True)
+    env.set_seed(3); env.reset()
+    hs = env.get_handles()
+    for h in hs:
+        env.add_agents(h, "random", n=200)
+    m = DeepQNetwork(env, hs[0], "m", memory_size=64)
+    assert m._hip is not None
+    obs = env.get_observation(hs[0]); env.sync()
+    a1 = m.infer_action(obs, None, policy="greedy")
+    with torch.no_grad():
+        ref1 = _reference(m.qnet, obs[0], obs[1]).argmax(dim=1)
+    with torch.no_grad():
+        for p in m.qnet.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    m._hip.dirty = True
+    a2 = m.infer_action(obs, None, policy="greedy")
+    with torch.no_grad():
+        ref2 = _reference(m.qnet, obs[0], obs[1]).argmax(dim=1)
+    assert (a1.long() == ref1).float().mean().item() > 0.97 and (a2.long() == ref2).float().mean().item() > 0.97
+    assert not torch.equal(a1, a2)
+    env.close()
