@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 typedef struct {
-    int view_h, view_w, view_c;   /* view_c <= 8 */
+    int view_h, view_w, view_c;   /* view_c <= 7 (the eighth channel of a window cell carries conv1's bias) */
     int feat;                     /* <= 64 */
     int n_action;                 /* <= 31 */
 } PolicyDqnShape;
@@ -29,6 +29,7 @@ typedef struct {
  * 32-wide output tile T, lane l (0..63) holds W[out = 32 T + (l & 31)][k = 16 s + 8 (l >> 5) + 0..7].
  * The reduction index k of each layer:
  *   conv1      : tap (ky * 3 + kx) * 8 + channel          (channels padded to 8, taps to 10: 5 k-steps)        [5][64][8]
+ *                its bias is the weight of (tap 0, channel 7): the kernel feeds a constant 1.0 there
  *   conv2      : tap * 32 + slot                          (18 k-steps)                                         [18][64][8]
  *   dense_view : position (y * (view_w - 4) + x) * 32 + slot                                                    [K/16][8][64][8]
  *   dense_emb  : feature index (padded to a multiple of 16)                                                     [FK/16][8][64][8]
@@ -38,7 +39,7 @@ typedef struct {
  * a lane of the MFMA result holds them (magent_amd/csrc/policy.hip: ch_of).  Biases are float[tiles][32] in slot order. */
 typedef struct {
     const void *conv1, *conv2, *dense_view, *dense_emb, *head;
-    const float *conv1_bias, *conv2_bias, *dense_view_bias, *dense_emb_bias;
+    const float *conv2_bias, *dense_view_bias, *dense_emb_bias;
     float value_bias;
 } PolicyDqnWeights;
 

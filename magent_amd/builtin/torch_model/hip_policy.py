@@ -17,7 +17,7 @@ class _Shape(ctypes.Structure):
 
 
 class _Weights(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_void_p) for k in ("conv1", "conv2", "dense_view", "dense_emb", "head", "conv1_bias", "conv2_bias",
+    _fields_ = [(k, ctypes.c_void_p) for k in ("conv1", "conv2", "dense_view", "dense_emb", "head", "conv2_bias",
                                                "dense_view_bias", "dense_emb_bias")] + [("value_bias", ctypes.c_float)]
 
 
@@ -59,7 +59,9 @@ class HipDqnPolicy(object):
         ch = slot_channels(dev)
         c = self.shape.view_c
         w1 = q.conv1.weight.detach().float()                              # [32][C][3][3] -> [32][ky][kx][8] -> K = tap * 8 + channel
-        w1 = torch.cat([w1, w1.new_zeros(32, 8 - c, 3, 3)], dim=1).permute(0, 2, 3, 1).reshape(32, 72)
+        w1 = torch.cat([w1, w1.new_zeros(32, 8 - c, 3, 3)], dim=1).permute(0, 2, 3, 1).contiguous()
+        w1[:, 0, 0, 7] = q.conv1.bias.detach().float()       # the kernel feeds a constant 1.0 in channel 7: the MFMA adds the bias
+        w1 = w1.reshape(32, 72)
         w2 = q.conv2.weight.detach().float()[:, ch].permute(0, 2, 3, 1).reshape(32, 288)            # K = tap * 32 + slot
         wv = q.dense_view.weight.detach().float().reshape(256, -1, 32)[:, :, ch].reshape(256, self.k_dense)   # K = position * 32 + slot
         fk = (self.shape.feat + 15) // 16 * 16
@@ -71,7 +73,7 @@ class HipDqnPolicy(object):
         t = {
             "conv1": fragment_order(_pad_k(w1, 80)), "conv2": fragment_order(w2), "dense_view": fragment_order(wv),
             "dense_emb": fragment_order(we), "head": fragment_order(head[:, hidden]),
-            "conv1_bias": q.conv1.bias.detach().float()[ch].contiguous(), "conv2_bias": q.conv2.bias.detach().float()[ch].contiguous(),
+            "conv2_bias": q.conv2.bias.detach().float()[ch].contiguous(),
             "dense_view_bias": q.dense_view.bias.detach().float()[hidden[:256]].contiguous(),
             "dense_emb_bias": q.dense_emb.bias.detach().float()[hidden[:256]].contiguous(),
         }

@@ -38,25 +38,35 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // result register r of lane group g (= lane >> 5) is row (r & 3) + 8 (r >> 2) + 4 g of the 32 x 32 tile
 __device__ __forceinline__ int ch_of(int g, int r) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-constexpr int CONV_THREADS = 256;
+constexpr int CONV_THREADS = 256, CONV_CELLS = 4, CONV_C2_ITERS = 4;   // CONV_C2_ITERS x 8 tiles of 32 conv2 positions per pass, at most   // CONV_CELLS: window cells of a tile per thread (register prefetch)
 
 struct ConvArgs {
     const float *view;     // [n][H][W][C]
     __bf16 *act;           // [n][H2 * W2][32 slots]
-    const bf16x8 *w1, *w2; // fragment order: [5][64], [18][64]
-    const float *b1, *b2;  // [2][16]: bias of the channel in slot 16 g + r
-    int n, H, W, C, TA, n_tiles;
+    const bf16x8 *w1, *w2; // fragment order: [5][64], [18][64]; conv1's bias sits in w1 at (tap 0, channel 7)
+    const float *b2;       // [2][16]: conv2's bias of the channel in slot 16 g + r
+    int n, H, W, C, TA, AP, n_tiles;
 };
 
+// LDS images (the layouts make every ds_read_b128 of an MFMA operand conflict-free: a 16-lane service group of the instruction
+// must hit 16 different 16-byte slots of the 256-byte LDS row -- checked offline by simulating the group lists of
+// MI355X_MICROARCH.md, LDS section):
+//   s_view [TA * H * W + 2] cells of 8 bf16: channels 0..C-1, zeros, and 1.0 in channel 7 -- conv1's bias is the weight of that
+//          constant, so the MFMA adds it.  conv1 is evaluated over FULL rows of W positions (the last two of a row are garbage
+//          that lands in the padding columns of s_c1): consecutive lanes then read consecutive cells.
+//   s_c1   [TA][AP = H1 * W + pad positions][4 chunks of 8 slots]: row pitch W (== W2 mod 4) and agent pitch AP (== H2 * W2
+//          mod 4) make a position's index congruent mod 4 to u = its rank in conv2's own enumeration; the chunk index is xor-ed
+//          with (u >> 2) & 3.  The 16 lanes of a group have 16 consecutive-modulo-16 ranks, for every tap: 16 distinct slots.
 __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int H1 = A.H - 2, W1 = A.W - 2, H2 = A.H - 4, W2 = A.W - 4;
-    const int cells = A.TA * A.H * A.W, P1 = A.TA * H1 * W1, P2 = A.TA * H2 * W2;
-    bf16x8 *s_view = (bf16x8 *)s_raw;                     // [cells]          one window cell = 8 channels
-    bf16x8 *s_c1 = s_view + cells;                        // [P1][4 chunks]   conv1 output, 32 slots per position, swizzled
-    unsigned short *s_lut1 = (unsigned short *)(s_c1 + (size_t)P1 * 4);   // output position -> its top-left cell
-    unsigned short *s_lut2 = s_lut1 + P1;                                 // conv2 position -> its top-left conv1 position
-    float *s_bias = (float *)(s_lut2 + P2 + ((P1 + P2) & 1));             // [2 layers][2][16]
+    const int cells = A.TA * A.H * A.W, E1 = A.TA * H1 * A.W, P2 = A.TA * H2 * W2;
+    bf16x8 *s_view = (bf16x8 *)s_raw;                                  // [cells + 2]
+    bf16x8 *s_c1 = s_view + cells + 2;                                 // [TA * AP][4]
+    unsigned *s_lut2 = (unsigned *)(s_c1 + (size_t)A.TA * A.AP * 4);   // conv2 position -> its top-left c1 position | 9 taps x 2 swizzle bits << 12
+    unsigned short *s_lut1 = (unsigned short *)(s_lut2 + P2);          // conv1 position (full rows) -> c1 position | swizzle << 14
+    unsigned short *s_lutc = s_lut1 + E1;                              // conv1 position -> its top-left window cell
+    float *s_bias = (float *)(s_lutc + E1);                            // [2][16] (4-byte aligned: 2 * E1 ushorts lie before it)
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 5, r32 = l & 31;
     bf16x8 wf1[5], wf2[18];
@@ -64,70 +74,142 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     for (int s = 0; s < 5; s++) wf1[s] = A.w1[s * 64 + l];
 #pragma unroll
     for (int s = 0; s < 18; s++) wf2[s] = A.w2[s * 64 + l];
-    for (int k = tid; k < 64; k += CONV_THREADS) s_bias[k] = k < 32 ? A.b1[k] : A.b2[k - 32];
-    for (int P = tid; P < P1; P += CONV_THREADS) {
-        const int a = P / (H1 * W1), rem = P - a * H1 * W1, y = rem / W1, x = rem - y * W1;
-        s_lut1[P] = (unsigned short)(a * A.H * A.W + y * A.W + x);
+    for (int k = tid; k < 32; k += CONV_THREADS) s_bias[k] = A.b2[k];
+    for (int E = tid; E < E1; E += CONV_THREADS) {
+        const int a = E / (H1 * A.W), rem = E - a * H1 * A.W, y = rem / A.W, x = rem - y * A.W;
+        const int u = (a * H2 * W2 + y * W2 + x) & 15;                 // (rank of c1 position (a, y, x) in conv2's enumeration, mod 16)
+        s_lut1[E] = (unsigned short)((a * A.AP + y * A.W + x) | (((u >> 2) & 3) << 14));
+        s_lutc[E] = (unsigned short)(a * A.H * A.W + y * A.W + x);
     }
     for (int Q = tid; Q < P2; Q += CONV_THREADS) {
         const int a = Q / (H2 * W2), rem = Q - a * H2 * W2, y = rem / W2, x = rem - y * W2;
-        s_lut2[Q] = (unsigned short)(a * H1 * W1 + y * W1 + x);
+        unsigned q = 0;
+        for (int tap = 0; tap < 9; tap++) q |= (unsigned)((((Q + (tap / 3) * W2 + tap % 3) & 15) >> 2) & 3) << (2 * tap);
+        s_lut2[Q] = (unsigned)(a * A.AP + y * A.W + x) | (q << 12);
     }
+    if (tid < 2) s_view[cells + tid] = bf16x8{0};
     // conv1: k-step s covers taps 2 s and 2 s + 1 (lane group g takes tap 2 s + g; tap 9 is padding: zero weights)
     int off1[5];
 #pragma unroll
     for (int s = 0; s < 5; s++) { const int tap = 2 * s + g; off1[s] = tap < 9 ? (tap / 3) * A.W + tap % 3 : 0; }
 
+    // A tile's window cells are fetched a whole tile AHEAD, into registers: the loads of tile t + 1 are issued before the
+    // convolutions of tile t and waited for after them, so their HBM latency hides behind ~2 us of MFMA work (the loop was bound
+    // by it).  A thread owns whole cells: C floats in, one 16-byte LDS store out.
+    float nv[CONV_CELLS][7];
+    // (the loads are unconditional, from clamped addresses: a select on a loaded value would make the wave wait for it at once)
+    auto fetch = [&](int tile) {
+        const float *src = A.view + (size_t)tile * cells * A.C;
+        const int live = min(A.TA, A.n - tile * A.TA) * A.H * A.W;
+#pragma unroll
+        for (int k = 0; k < CONV_CELLS; k++) {
+            const float *p = src + (size_t)min(k * CONV_THREADS + tid, live - 1) * A.C;
+#pragma unroll
+            for (int e = 0; e < 7; e++) nv[k][e] = p[min(e, A.C - 1)];
+        }
+    };
+    if ((int)blockIdx.x < A.n_tiles) fetch(blockIdx.x);
+
     for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
         const int a0 = tile * A.TA, na = min(A.TA, A.n - a0);
         __syncthreads();     // the previous tile's readers are done (first pass: the tables are written)
-        // ---- the views of this tile, f32 -> bf16, channels padded to 8
-        const float *src = A.view + (size_t)a0 * A.H * A.W * A.C;
-        const int live = na * A.H * A.W;
-        for (int c = tid; c < cells; c += CONV_THREADS) {
+#pragma unroll
+        for (int k = 0; k < CONV_CELLS; k++) {
+            const int c = k * CONV_THREADS + tid;
+            const bool have = c < na * A.H * A.W;
             bf16x8 v;
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (__bf16)((c < live && e < A.C) ? src[(size_t)c * A.C + e] : 0.0f);
-            s_view[c] = v;
+            for (int e = 0; e < 7; e++) v[e] = (__bf16)((have && e < A.C) ? nv[k][e] : 0.0f);
+            v[7] = (__bf16)1.0f;
+            if (c < cells) s_view[c] = v;
         }
+        if (tile + (int)gridDim.x < A.n_tiles) fetch(tile + gridDim.x);
         __syncthreads();
-        // ---- conv1: [P1 positions] x [32 channels], K = 10 taps x 8 channels
-        for (int t = w; t * 32 < P1; t += CONV_THREADS / 64) {
-            const int P = t * 32 + r32, base = s_lut1[min(P, P1 - 1)];
-            f32x16 acc = {0};
+        // ---- conv1: [E1 positions, full rows] x [32 channels], K = 10 taps x 8 channels (bias: the constant channel of tap 0).
+        // A wave runs TWO position tiles at a time (t and t + 4): two independent accumulator chains keep the matrix pipe busy
+        // while the other chain's operands are on their way from LDS.
+        const int T1 = (E1 + 31) / 32, T2 = (P2 + 31) / 32, NW = CONV_THREADS / 64;
+        for (int t = w; t < T1; t += 2 * NW) {
+            const bool two = t + NW < T1;
+            const int Ea = min(t * 32 + r32, E1 - 1), Eb = min((t + NW) * 32 + r32, E1 - 1);
+            const int ba = s_lutc[Ea], bb = s_lutc[Eb];
+            const unsigned ea = s_lut1[Ea], eb = s_lut1[Eb];
+            bf16x8 xa[5], xb[5];
 #pragma unroll
-            for (int s = 0; s < 5; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[s], s_view[base + off1[s]], acc, 0, 0, 0);
-            if (P < P1) {
-                bf16x8 o0, o1;
+            for (int s = 0; s < 5; s++) { xa[s] = s_view[ba + off1[s]]; xb[s] = s_view[bb + off1[s]]; }
+            f32x16 acca = {0}, accb = {0};
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    o0[r] = (__bf16)fmaxf(acc[r] + s_bias[g * 16 + r], 0.0f);
-                    o1[r] = (__bf16)fmaxf(acc[8 + r] + s_bias[g * 16 + 8 + r], 0.0f);
-                }
-                const int sw = (P >> 1) & 3;      // consecutive positions land in different 16-byte columns of the LDS banks
-                s_c1[P * 4 + ((2 * g) ^ sw)] = o0;
-                s_c1[P * 4 + ((2 * g + 1) ^ sw)] = o1;
+            for (int s = 0; s < 5; s++) {
+                acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[s], xa[s], acca, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[s], xb[s], accb, 0, 0, 0);
+            }
+            bf16x8 o0, o1;
+#pragma unroll
+            for (int r = 0; r < 8; r++) { o0[r] = (__bf16)fmaxf(acca[r], 0.0f); o1[r] = (__bf16)fmaxf(acca[8 + r], 0.0f); }
+            s_c1[(ea & 0x3FFF) * 4 + ((2 * g) ^ (ea >> 14))] = o0;       // (lanes past E1 repeat the last position: same values, harmless)
+            s_c1[(ea & 0x3FFF) * 4 + ((2 * g + 1) ^ (ea >> 14))] = o1;
+            if (two) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) { o0[r] = (__bf16)fmaxf(accb[r], 0.0f); o1[r] = (__bf16)fmaxf(accb[8 + r], 0.0f); }
+                s_c1[(eb & 0x3FFF) * 4 + ((2 * g) ^ (eb >> 14))] = o0;
+                s_c1[(eb & 0x3FFF) * 4 + ((2 * g + 1) ^ (eb >> 14))] = o1;
             }
         }
         __syncthreads();
-        // ---- conv2: [P2 positions] x [32 channels], K = 9 taps x 32 slots; result straight to HBM
-        for (int t = w; t * 32 < P2; t += CONV_THREADS / 64) {
-            const int Q = t * 32 + r32, base = s_lut2[min(Q, P2 - 1)];
-            f32x16 acc = {0};
+        // ---- conv2: [P2 positions] x [32 channels], K = 9 taps x 32 slots; starts from the bias, result straight to HBM.
+        // Two tiles per wave at a time here too; the operands of the next tap are read while the current one runs.
+        const unsigned char *c1b = (const unsigned char *)s_c1;
+        // (not a loop: with global stores inside a loop the compiler drains every outstanding load -- the prefetch of the next
+        // tile -- before entering it; unrolled under predicates it keeps them in flight)
+#pragma unroll
+        for (int it = 0; it < CONV_C2_ITERS; it++) {
+            const int t = w + it * 2 * NW;
+            if (t >= T2) break;
+            const int Qa = t * 32 + r32, Qb = (t + NW) * 32 + r32;
+            const unsigned ea = s_lut2[min(Qa, P2 - 1)], eb = s_lut2[min(Qb, P2 - 1)];
+            const unsigned basea = (ea & 0xFFFu) << 6, qa = ea >> 12, baseb = (eb & 0xFFFu) << 6, qb = eb >> 12;
+            f32x16 acca, accb;
+            {
+                const f32x4 *bp = (const f32x4 *)(s_bias + g * 16);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    const f32x4 bq = bp[q4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { acca[4 * q4 + i] = bq[i]; accb[4 * q4 + i] = bq[i]; }
+                }
+            }
+            unsigned ada = basea + (((qa & 3) ^ g) << 4), adb = baseb + (((qb & 3) ^ g) << 4);
+            bf16x8 xa0 = *(const bf16x8 *)(c1b + ada), xa1 = *(const bf16x8 *)(c1b + (ada ^ 32));
+            bf16x8 xb0 = *(const bf16x8 *)(c1b + adb), xb1 = *(const bf16x8 *)(c1b + (adb ^ 32));
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
-                const int P = base + (tap / 3) * W1 + tap % 3, sw = (P >> 1) & 3;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap], s_c1[P * 4 + (g ^ sw)], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap + 1], s_c1[P * 4 + ((2 + g) ^ sw)], acc, 0, 0, 0);
-            }
-            if (Q < na * H2 * W2) {
-                bf16x8 o0, o1;
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    o0[r] = (__bf16)fmaxf(acc[r] + s_bias[32 + g * 16 + r], 0.0f);
-                    o1[r] = (__bf16)fmaxf(acc[8 + r] + s_bias[32 + g * 16 + 8 + r], 0.0f);
+                bf16x8 nxa0 = xa0, nxa1 = xa1, nxb0 = xb0, nxb1 = xb1;
+                if (tap < 8) {
+                    const int nt = tap + 1;
+                    const unsigned toff = (unsigned)(((nt / 3) * A.W + nt % 3) * 64);
+                    ada = basea + toff + ((((qa >> (2 * nt)) & 3) ^ g) << 4);
+                    adb = baseb + toff + ((((qb >> (2 * nt)) & 3) ^ g) << 4);
+                    nxa0 = *(const bf16x8 *)(c1b + ada); nxa1 = *(const bf16x8 *)(c1b + (ada ^ 32));
+                    nxb0 = *(const bf16x8 *)(c1b + adb); nxb1 = *(const bf16x8 *)(c1b + (adb ^ 32));
                 }
-                bf16x8 *dst = (bf16x8 *)(A.act + ((size_t)a0 * H2 * W2 + Q) * 32 + 16 * g);
+                acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap], xa0, acca, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap], xb0, accb, 0, 0, 0);
+                acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap + 1], xa1, acca, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap + 1], xb1, accb, 0, 0, 0);
+                xa0 = nxa0; xa1 = nxa1; xb0 = nxb0; xb1 = nxb1;
+            }
+            const int lim = na * H2 * W2;
+            bf16x8 o0, o1;
+            if (Qa < lim) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) { o0[r] = (__bf16)fmaxf(acca[r], 0.0f); o1[r] = (__bf16)fmaxf(acca[8 + r], 0.0f); }
+                bf16x8 *dst = (bf16x8 *)(A.act + ((size_t)a0 * H2 * W2 + Qa) * 32 + 16 * g);
+                dst[0] = o0; dst[1] = o1;
+            }
+            if (Qb < lim) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) { o0[r] = (__bf16)fmaxf(accb[r], 0.0f); o1[r] = (__bf16)fmaxf(accb[8 + r], 0.0f); }
+                bf16x8 *dst = (bf16x8 *)(A.act + ((size_t)a0 * H2 * W2 + Qb) * 32 + 16 * g);
                 dst[0] = o0; dst[1] = o1;
             }
         }
@@ -151,8 +233,8 @@ struct HeadArgs {
 };
 
 // one half of the hidden layer (256 values: relu(dense_view), later relu(dense_emb)) of the 64 agents: [agent][32 chunks of
-// 8 bf16], chunk index xor-ed with the agent's low bits.  The head is accumulated half by half, so 32 KB do for both.
-__device__ __forceinline__ int hid_at(int agent, int chunk) { return agent * 32 + (chunk ^ (agent & 7)); }
+// 8 bf16], chunk index xor-ed with the agent's low bits (a 16-lane group of ds_read_b128 then covers all 16 slots of the LDS).  The head is accumulated half by half, so 32 KB do for both.
+__device__ __forceinline__ int hid_at(int agent, int chunk) { return agent * 32 + (chunk ^ (agent & 15)); }
 
 __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
     __shared__ __attribute__((aligned(16))) bf16x8 s_act[2][HEAD_M * (HEAD_KC / 8)];   // 2 x 8 KB: [agent][8 chunks], swizzled
@@ -169,7 +251,7 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int c = piece * 2 + i;
-            if (c < width_chunks) s_act[buf][row * 8 + (c ^ (row & 7))] = src[i];
+            if (c < width_chunks) s_act[buf][row * 8 + (c ^ ((row >> 1) & 7))] = src[i];
         }
     };
 
@@ -190,7 +272,7 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
             const int s = kc * (HEAD_KC / 16) + ks;
             const bf16x8 w0 = A.wv[((size_t)s * 8 + 2 * w) * 64 + l], w1 = A.wv[((size_t)s * 8 + 2 * w + 1) * 64 + l];
             const int c = 2 * ks + g;
-            const bf16x8 x0 = s_act[buf][r32 * 8 + (c ^ (r32 & 7))], x1 = s_act[buf][(32 + r32) * 8 + (c ^ (r32 & 7))];
+            const bf16x8 x0 = s_act[buf][r32 * 8 + (c ^ ((r32 >> 1) & 7))], x1 = s_act[buf][(32 + r32) * 8 + (c ^ ((r32 >> 1) & 7))];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, acc[1][0], 0, 0, 0);
@@ -228,7 +310,7 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
             bf16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; e++) { const int k = c * 8 + e; v[e] = (__bf16)(k < A.F ? A.feat[(size_t)agent * A.F + k] : 0.0f); }
-            s_act[0][row * 8 + (c ^ (row & 7))] = v;
+            s_act[0][row * 8 + (c ^ ((row >> 1) & 7))] = v;
         }
     }
     __syncthreads();
@@ -239,7 +321,7 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
     for (int s = 0; s < A.FK / 16; s++) {
         const bf16x8 w0 = A.we[((size_t)s * 8 + 2 * w) * 64 + l], w1 = A.we[((size_t)s * 8 + 2 * w + 1) * 64 + l];
         const int c = 2 * s + g;
-        const bf16x8 x0 = s_act[0][r32 * 8 + (c ^ (r32 & 7))], x1 = s_act[0][(32 + r32) * 8 + (c ^ (r32 & 7))];
+        const bf16x8 x0 = s_act[0][r32 * 8 + (c ^ ((r32 >> 1) & 7))], x1 = s_act[0][(32 + r32) * 8 + (c ^ ((r32 >> 1) & 7))];
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, acc[1][0], 0, 0, 0);
@@ -300,7 +382,7 @@ int policy_dqn_act_bytes(const PolicyDqnShape *s, int n, size_t *bytes) {
 }
 
 int policy_dqn_supported(const PolicyDqnShape *s) {
-    return s->view_c >= 1 && s->view_c <= 8 && s->view_h >= 5 && s->view_w >= 5 && s->view_h * s->view_w <= 1024 && s->feat >= 1 && s->feat <= 64 &&
+    return s->view_c >= 1 && s->view_c <= 7 && s->view_h >= 5 && s->view_w >= 5 && s->view_h * s->view_w <= 1024 && s->feat >= 1 && s->feat <= 64 &&
            s->n_action >= 1 && s->n_action <= 31;
 }
 
@@ -310,13 +392,14 @@ int policy_dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const f
     if (n <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int H = s->view_h, W = s->view_w, H1 = H - 2, W1 = W - 2, H2 = H - 4, W2 = W - 4;
-    // agents per workgroup pass: as many as leave two workgroups per CU their LDS (view 16 B / cell, conv1 64 B / position)
+    // agents per workgroup pass: as many as leave two workgroups per CU their LDS (views 16 B / cell, conv1 64 B / position)
+    const int AP = H1 * W + ((H2 * W2 - H1 * W) % 4 + 4) % 4;      // agent pitch of conv1's LDS image: == H2 * W2 (mod 4)
     int TA = 8;
     size_t lds = 0;
     for (; TA >= 1; TA--) {
-        const size_t P1 = (size_t)TA * H1 * W1, P2 = (size_t)TA * H2 * W2;
-        lds = (size_t)TA * H * W * 16 + P1 * 64 + (P1 + P2 + ((P1 + P2) & 1)) * 2 + 64 * 4;
-        if (lds <= 72 * 1024 && P1 <= 65535 && (size_t)TA * H * W <= 65535) break;
+        const size_t cells = (size_t)TA * H * W, E1 = (size_t)TA * H1 * W, P2 = (size_t)TA * H2 * W2;
+        lds = (cells + 2) * 16 + (size_t)TA * AP * 64 + P2 * 4 + E1 * 4 + 32 * 4;
+        if (lds <= 78 * 1024 && (size_t)TA * AP < 4096 && cells <= (size_t)CONV_CELLS * CONV_THREADS && P2 <= (size_t)CONV_C2_ITERS * 256) break;
     }
     if (TA < 1) return 1;
     static bool lds_ok = false;
@@ -325,9 +408,9 @@ int policy_dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const f
         lds_ok = true;
     }
     ConvArgs C{};
-    C.view = view; C.act = (__bf16 *)act_workspace; C.w1 = (const bf16x8 *)w->conv1; C.w2 = (const bf16x8 *)w->conv2; C.b1 = w->conv1_bias; C.b2 = w->conv2_bias;
-    C.n = n; C.H = H; C.W = W; C.C = s->view_c; C.TA = TA; C.n_tiles = (n + TA - 1) / TA;
-    const int grid = C.n_tiles < 512 ? C.n_tiles : 512;     // persistent: weights are fetched once per wave
+    C.view = view; C.act = (__bf16 *)act_workspace; C.w1 = (const bf16x8 *)w->conv1; C.w2 = (const bf16x8 *)w->conv2; C.b2 = w->conv2_bias;
+    C.n = n; C.H = H; C.W = W; C.C = s->view_c; C.TA = TA; C.AP = AP; C.n_tiles = (n + TA - 1) / TA;
+    const int grid = C.n_tiles < 512 ? C.n_tiles : 512;     // persistent (2 per CU): weights are fetched once per wave
     hipLaunchKernelGGL(k_dqn_conv, dim3(grid), dim3(CONV_THREADS), lds, st, C);
     HeadArgs Hd{};
     Hd.act = (const __bf16 *)act_workspace; Hd.feat = feat; Hd.wv = (const bf16x8 *)w->dense_view; Hd.we = (const bf16x8 *)w->dense_emb; Hd.wh = (const bf16x8 *)w->head;

