@@ -244,16 +244,14 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
     const int n_chunks = A.K / HEAD_KC;            // K is a multiple of 32; a last half chunk is handled by the tail below
     const int k_tail = A.K - n_chunks * HEAD_KC;   // 0 or 32
 
-    // stage one K-chunk of the 64 agents' activations: 64 rows x 128 B, thread t -> row t / 4, 32 B piece t % 4
-    auto stage = [&](int buf, int kc, int width_chunks) {
-        const int row = tid >> 2, piece = tid & 3, agent = min(a0 + row, A.n - 1);
-        const bf16x8 *src = (const bf16x8 *)(A.act + (size_t)agent * A.K + (size_t)kc * HEAD_KC) + piece * 2;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int c = piece * 2 + i;
-            if (c < width_chunks) s_act[buf][row * 8 + (c ^ ((row >> 1) & 7))] = src[i];
-        }
-    };
+    // One K-chunk = 64 values of K = 4 k-steps.  Both operand streams run a whole chunk AHEAD, in registers: the 64 agents'
+    // activations of chunk c + 1 (64 rows x 128 B; thread t -> row t / 4, 32-byte piece t % 4) and this wave's eight weight
+    // fragments of chunk c + 1 are requested before the MFMAs of chunk c and consumed after them -- the loop used to wait for an
+    // L2 round trip at every k-step (79 % of the wave cycles were waits).
+    const int srow = tid >> 2, spiece = tid & 3;
+    const bf16x8 *arow = (const bf16x8 *)(A.act + (size_t)min(a0 + srow, A.n - 1) * A.K) + spiece * 2;
+    const int sdst = srow * 8;
+    const bf16x8 *wbase = A.wv + (size_t)(2 * w) * 64 + l;      // fragment (s, tile 2 w + i) = wbase[(s * 8 + i) * 64]
 
     f32x16 acc[2][2];     // [out tile of this wave][agent tile]
 #pragma unroll
@@ -261,22 +259,45 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = f32x16{0};
 
-    stage(0, 0, 8);
+    bf16x8 an[2], wc[4][2], wn[4][2];
+    an[0] = arow[0]; an[1] = arow[1];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { wc[ks][0] = wbase[(size_t)(ks * 8) * 64]; wc[ks][1] = wbase[(size_t)(ks * 8 + 1) * 64]; }
+    s_act[0][sdst + ((spiece * 2) ^ ((srow >> 1) & 7))] = an[0];
+    s_act[0][sdst + ((spiece * 2 + 1) ^ ((srow >> 1) & 7))] = an[1];
     __syncthreads();
-    const int total = n_chunks + (k_tail ? 1 : 0);
+    const int n_steps = A.K / 16;                  // k-steps in all; the last chunk may be half (K is a multiple of 32)
+    const int total = (n_steps + 3) / 4;
     for (int kc = 0; kc < total; kc++) {
-        const int buf = kc & 1, steps = (kc < n_chunks) ? 4 : k_tail / 16;
-        if (kc + 1 < total) stage(buf ^ 1, kc + 1, (kc + 1 < n_chunks) ? 8 : k_tail / 8);
-#pragma unroll 4
-        for (int ks = 0; ks < steps; ks++) {
-            const int s = kc * (HEAD_KC / 16) + ks;
-            const bf16x8 w0 = A.wv[((size_t)s * 8 + 2 * w) * 64 + l], w1 = A.wv[((size_t)s * 8 + 2 * w + 1) * 64 + l];
-            const int c = 2 * ks + g;
-            const bf16x8 x0 = s_act[buf][r32 * 8 + (c ^ ((r32 >> 1) & 7))], x1 = s_act[buf][(32 + r32) * 8 + (c ^ ((r32 >> 1) & 7))];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc[1][1], 0, 0, 0);
+        const int buf = kc & 1;
+        const bool more = kc + 1 < total;
+        if (more) {       // requests of the next chunk (a half chunk reads the same addresses twice: clamped, never out of range)
+            const int s1 = (kc + 1) * 4;
+            an[0] = arow[(size_t)(kc + 1) * 8 + (spiece * 2 + 0 < (n_steps - s1) * 2 ? 0 : -spiece * 2)];
+            an[1] = arow[(size_t)(kc + 1) * 8 + (spiece * 2 + 1 < (n_steps - s1) * 2 ? 1 : -spiece * 2)];
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const int sq = min(s1 + ks, n_steps - 1);
+                wn[ks][0] = wbase[(size_t)(sq * 8) * 64]; wn[ks][1] = wbase[(size_t)(sq * 8 + 1) * 64];
+            }
+        }
+        const int steps = min(4, n_steps - kc * 4);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            if (ks < steps) {
+                const int c = 2 * ks + g;
+                const bf16x8 x0 = s_act[buf][r32 * 8 + (c ^ ((r32 >> 1) & 7))], x1 = s_act[buf][(32 + r32) * 8 + (c ^ ((r32 >> 1) & 7))];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][0], x0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][0], x1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][1], x0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][1], x1, acc[1][1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            s_act[buf ^ 1][sdst + ((spiece * 2) ^ ((srow >> 1) & 7))] = an[0];
+            s_act[buf ^ 1][sdst + ((spiece * 2 + 1) ^ ((srow >> 1) & 7))] = an[1];
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) { wc[ks][0] = wn[ks][0]; wc[ks][1] = wn[ks][1]; }
         }
         __syncthreads();
     }
