@@ -152,6 +152,38 @@ def small_world_extras(torch, magent_amd, dev, steps=200, warmup=20):
     return out
 
 
+def selfplay_extra(torch, magent_amd, n=400000, steps=4):
+    """BASELINE config 5's shape on one GPU: battle 1000x1000, both sides acting through the reference's DQN (inference only,
+    epsilon-greedy), observations and actions staying in HBM; the forward pass runs on the hand-written MFMA kernels
+    (magent_amd/csrc/policy.hip).  Whole-cycle time: observe, infer, set_action per group; step; rewards; clear_dead."""
+    from magent_amd.builtin.torch_model import DeepQNetwork
+    env = magent_amd.GridWorld("battle", map_size=MAP_SIZE, device_obs=True)
+    env.set_seed(12345); env.reset()
+    hs = env.get_handles()
+    for h in hs:
+        env.add_agents(h, "random", n=n)
+    models = [DeepQNetwork(env, h, "m%d" % i, memory_size=16, infer_batch_size=65536) for i, h in enumerate(hs)]
+    total, t0 = 0, 0.0
+    for s in range(steps + 2):
+        if s == 2:
+            torch.cuda.synchronize(); env.sync()
+            total, t0 = 0, time.perf_counter()
+        for h, m in zip(hs, models):
+            obs = env.get_observation(h)
+            env.set_action(h, m.infer_action(obs, None, policy="e_greedy", eps=0.1))
+            total += env.get_num(h)
+        env.step()
+        for h in hs:
+            env.get_reward(h)
+        env.clear_dead()
+    torch.cuda.synchronize(); env.sync()
+    dt = time.perf_counter() - t0
+    out = {"agent_steps_per_s": total / dt, "ms_per_step": dt / steps * 1e3, "agents": [n, n],
+           "policy": "DQN forward pass, bf16 MFMA kernels" if models[0]._hip is not None else "DQN forward pass, PyTorch"}
+    env.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -415,6 +447,7 @@ def main():
                 T = measure("test_1m", 0, 500000, 10, 3, False)
                 extra["test_1m_2x500k"] = {"agent_steps_per_s": T["agent_steps"] / T["elapsed"], "ms_per_step": T["elapsed"] / 10 * 1e3, "agents": T["n0"], "map": T["map_size"]}
                 extra["battle_200_2x2000"] = small_world_extras(torch, magent_amd, dev)
+                extra["battle_selfplay_2x400k"] = selfplay_extra(torch, magent_amd)
             except Exception as e:     # secondary lines never fail the bench
                 extra["error"] = repr(e)
             rec["extra"] = extra

@@ -244,14 +244,26 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
     const int n_chunks = A.K / HEAD_KC;            // K is a multiple of 32; a last half chunk is handled by the tail below
     const int k_tail = A.K - n_chunks * HEAD_KC;   // 0 or 32
 
-    // One K-chunk = 64 values of K = 4 k-steps.  Both operand streams run a whole chunk AHEAD, in registers: the 64 agents'
-    // activations of chunk c + 1 (64 rows x 128 B; thread t -> row t / 4, 32-byte piece t % 4) and this wave's eight weight
-    // fragments of chunk c + 1 are requested before the MFMAs of chunk c and consumed after them -- the loop used to wait for an
-    // L2 round trip at every k-step (79 % of the wave cycles were waits).
+    // One K-chunk = 64 values of K = 4 k-steps.  Both operand streams run AHEAD of the MFMAs, in registers: this wave's eight
+    // weight fragments (L2) one chunk, the 64 agents' activations (HBM: 64 rows x 128 B; thread t -> row t / 4, 32-byte piece
+    // t % 4) FOUR chunks, through a ring of four register pairs -- a chunk is 0.26 us of MFMA work, an HBM round trip 1.5-2 us.
+    // (History, per 131072 agents: operands loaded at the k-step that uses them 0.45 ms, 79 % of the wave cycles waiting; one
+    // chunk ahead 0.31 ms.)
     const int srow = tid >> 2, spiece = tid & 3;
-    const bf16x8 *arow = (const bf16x8 *)(A.act + (size_t)min(a0 + srow, A.n - 1) * A.K) + spiece * 2;
-    const int sdst = srow * 8;
+    const bf16x8 *arow = (const bf16x8 *)(A.act + (size_t)min(a0 + srow, A.n - 1) * A.K);
+    const int sdst = srow * 8, ssw = (srow >> 1) & 7;
     const bf16x8 *wbase = A.wv + (size_t)(2 * w) * 64 + l;      // fragment (s, tile 2 w + i) = wbase[(s * 8 + i) * 64]
+    const int n_steps = A.K / 16;                  // k-steps in all; the last chunk may be half (K is a multiple of 32)
+    const int total = (n_steps + 3) / 4;
+    auto aload = [&](int c, bf16x8 (&dst)[2]) {    // (a half chunk re-reads its first piece: clamped, never out of range)
+        const int valid = min(8, (n_steps - c * 4) * 2);
+#pragma unroll
+        for (int i = 0; i < 2; i++) { const int ch = spiece * 2 + i; dst[i] = arow[(size_t)c * 8 + (ch < valid ? ch : 0)]; }   // (non-temporal loads here: measured slower, 0.31 -> 0.35 ms)
+    };
+    auto astore = [&](int buf, const bf16x8 (&src)[2]) {
+        s_act[buf][sdst + ((spiece * 2) ^ ssw)] = src[0];
+        s_act[buf][sdst + ((spiece * 2 + 1) ^ ssw)] = src[1];
+    };
 
     f32x16 acc[2][2];     // [out tile of this wave][agent tile]
 #pragma unroll
@@ -259,47 +271,49 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = f32x16{0};
 
-    bf16x8 an[2], wc[4][2], wn[4][2];
-    an[0] = arow[0]; an[1] = arow[1];
+    bf16x8 ar[4][2], wc[4][2], wn[4][2];
+    aload(0, ar[0]);
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) { wc[ks][0] = wbase[(size_t)(ks * 8) * 64]; wc[ks][1] = wbase[(size_t)(ks * 8 + 1) * 64]; }
-    s_act[0][sdst + ((spiece * 2) ^ ((srow >> 1) & 7))] = an[0];
-    s_act[0][sdst + ((spiece * 2 + 1) ^ ((srow >> 1) & 7))] = an[1];
+    astore(0, ar[0]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) aload(min(1 + q, total - 1), ar[q]);
     __syncthreads();
-    const int n_steps = A.K / 16;                  // k-steps in all; the last chunk may be half (K is a multiple of 32)
-    const int total = (n_steps + 3) / 4;
-    for (int kc = 0; kc < total; kc++) {
-        const int buf = kc & 1;
-        const bool more = kc + 1 < total;
-        if (more) {       // requests of the next chunk (a half chunk reads the same addresses twice: clamped, never out of range)
-            const int s1 = (kc + 1) * 4;
-            an[0] = arow[(size_t)(kc + 1) * 8 + (spiece * 2 + 0 < (n_steps - s1) * 2 ? 0 : -spiece * 2)];
-            an[1] = arow[(size_t)(kc + 1) * 8 + (spiece * 2 + 1 < (n_steps - s1) * 2 ? 1 : -spiece * 2)];
+    for (int kc0 = 0; kc0 < total; kc0 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int kc = kc0 + q;
+            if (kc >= total) break;
+            const int buf = kc & 1;
+            const bool more = kc + 1 < total;
+            if (more) {
+                const int s1 = (kc + 1) * 4;
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const int sq = min(s1 + ks, n_steps - 1);
+                    wn[ks][0] = wbase[(size_t)(sq * 8) * 64]; wn[ks][1] = wbase[(size_t)(sq * 8 + 1) * 64];
+                }
+            }
+            const int steps = min(4, n_steps - kc * 4);
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
-                const int sq = min(s1 + ks, n_steps - 1);
-                wn[ks][0] = wbase[(size_t)(sq * 8) * 64]; wn[ks][1] = wbase[(size_t)(sq * 8 + 1) * 64];
+                if (ks < steps) {
+                    const int c = 2 * ks + g;
+                    const bf16x8 x0 = s_act[buf][r32 * 8 + (c ^ ((r32 >> 1) & 7))], x1 = s_act[buf][(32 + r32) * 8 + (c ^ ((r32 >> 1) & 7))];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][0], x0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][0], x1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][1], x0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][1], x1, acc[1][1], 0, 0, 0);
+                }
             }
-        }
-        const int steps = min(4, n_steps - kc * 4);
+            if (more) {
+                astore(buf ^ 1, ar[q]);                                   // chunk kc + 1, requested four chunks ago
+                aload(min(kc + 5, total - 1), ar[q]);
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            if (ks < steps) {
-                const int c = 2 * ks + g;
-                const bf16x8 x0 = s_act[buf][r32 * 8 + (c ^ ((r32 >> 1) & 7))], x1 = s_act[buf][(32 + r32) * 8 + (c ^ ((r32 >> 1) & 7))];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][0], x0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][0], x1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][1], x0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][1], x1, acc[1][1], 0, 0, 0);
+                for (int ks = 0; ks < 4; ks++) { wc[ks][0] = wn[ks][0]; wc[ks][1] = wn[ks][1]; }
             }
+            __syncthreads();
         }
-        if (more) {
-            s_act[buf ^ 1][sdst + ((spiece * 2) ^ ((srow >> 1) & 7))] = an[0];
-            s_act[buf ^ 1][sdst + ((spiece * 2 + 1) ^ ((srow >> 1) & 7))] = an[1];
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) { wc[ks][0] = wn[ks][0]; wc[ks][1] = wn[ks][1]; }
-        }
-        __syncthreads();
     }
     // relu(dense_view) -> hidden slots [0, 256): tile T = 2 w + i holds chunks 4 T + 2 g, 4 T + 2 g + 1 of every agent
 #pragma unroll
