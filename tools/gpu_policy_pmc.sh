@@ -1,4 +1,5 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2polpmc; mkdir -p $O
+# Development helper (GPU box, via gpurun): PMC passes over the policy kernels (SQ, TCC counters).
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/policypmc; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --list-avail 2>/dev/null | grep -o "TCC_[A-Z0-9_]*\|TCP_[A-Z0-9_]*\|TA_[A-Z0-9_]*\|SQ_WAIT[A-Z_]*\|SQ_INST_LEVEL[A-Z_]*" | sort -u | tr '\n' ' ' > $O/avail.txt
 wc -c $O/avail.txt

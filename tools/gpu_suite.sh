@@ -1,4 +1,5 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2suite; mkdir -p $O
+# Development helper (GPU box, via gpurun): the whole GPU suite, two bench lines and the launch timeline of one cycle.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/suite; mkdir -p $O
 cd $R; timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
 cd /tmp && export TMPDIR=/tmp
 for k in 1 2; do timeout 300 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>&1 | tail -1 | cut -c1-1700 > $O/bench.log; python - <<PY
