@@ -217,7 +217,8 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------- dense + head
-constexpr int HEAD_THREADS = 256, HEAD_M = 64, HEAD_KC = 64;   // 64 agents per workgroup; K staged 64 at a time
+constexpr int HEAD_THREADS = 512, HEAD_M = 128, HEAD_KC = 64;   // 128 agents per workgroup of 8 waves; K staged 64 at a time
+constexpr size_t HEAD_LDS = (2 * HEAD_M * (HEAD_KC / 8) + HEAD_M * 32 + 32 * 64) * 16;   // 2 x 16 KB activations + 64 KB hidden + 32 KB head weights = 128 KB
 
 struct HeadArgs {
     const __bf16 *act;        // [n][K] (K = H2 * W2 * 32, slot order)
@@ -232,49 +233,61 @@ struct HeadArgs {
     float *q;                 // [n][n_action] or null
 };
 
-// one half of the hidden layer (256 values: relu(dense_view), later relu(dense_emb)) of the 64 agents: [agent][32 chunks of
-// 8 bf16], chunk index xor-ed with the agent's low bits (a 16-lane group of ds_read_b128 then covers all 16 slots of the LDS).  The head is accumulated half by half, so 32 KB do for both.
+// one half of the hidden layer (256 values: relu(dense_view), later relu(dense_emb)) of the 128 agents: [agent][32 chunks of
+// 8 bf16], chunk index xor-ed with the agent's low bits (a 16-lane group of ds_read_b128 then covers all 16 slots of the LDS).
+// The head is accumulated half by half, so one buffer does for both.
 __device__ __forceinline__ int hid_at(int agent, int chunk) { return agent * 32 + (chunk ^ (agent & 15)); }
 
+// Wave w owns output tile w (32 of the 256 outputs) for all four agent tiles: per k-step ONE weight fragment from L2 and four
+// activation operands from LDS feed four MFMAs.  Both global streams run ahead of the MFMAs through rings of four register
+// sets: the wave's weight fragments (L2: ~0.5 us away) and the workgroup's activations (HBM: 1.5-2 us), each FOUR 64-wide
+// K-chunks ahead; a chunk is 0.26 us of MFMA work per wave.
+// (History per 131072 agents, 64 agents / 4 waves per workgroup: operands loaded at the k-step that uses them 0.45 ms, 79 % of
+// the wave cycles waiting; one chunk ahead 0.31 ms -- two weight fragments per k-step left room for one chunk of look-ahead only.)
 __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
-    __shared__ __attribute__((aligned(16))) bf16x8 s_act[2][HEAD_M * (HEAD_KC / 8)];   // 2 x 8 KB: [agent][8 chunks], swizzled
-    __shared__ __attribute__((aligned(16))) bf16x8 s_hid[HEAD_M * 32];                  // 32 KB: relu(dense_view), then relu(dense_emb)
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    bf16x8 (*s_act)[HEAD_M * (HEAD_KC / 8)] = (bf16x8 (*)[HEAD_M * (HEAD_KC / 8)])s_raw;      // [2][agent][8 chunks], swizzled
+    bf16x8 *s_hid = (bf16x8 *)s_raw + 2 * HEAD_M * (HEAD_KC / 8);                              // [agent][32 chunks], swizzled
+    bf16x8 *s_wh = s_hid + HEAD_M * 32;                                                        // the head's weights, fragment order [32][64]
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 5, r32 = l & 31;
     const int a0 = blockIdx.x * HEAD_M;
-    const int n_chunks = A.K / HEAD_KC;            // K is a multiple of 32; a last half chunk is handled by the tail below
-    const int k_tail = A.K - n_chunks * HEAD_KC;   // 0 or 32
 
-    // One K-chunk = 64 values of K = 4 k-steps.  Both operand streams run AHEAD of the MFMAs, in registers: this wave's eight
-    // weight fragments (L2) one chunk, the 64 agents' activations (HBM: 64 rows x 128 B; thread t -> row t / 4, 32-byte piece
-    // t % 4) FOUR chunks, through a ring of four register pairs -- a chunk is 0.26 us of MFMA work, an HBM round trip 1.5-2 us.
-    // (History, per 131072 agents: operands loaded at the k-step that uses them 0.45 ms, 79 % of the wave cycles waiting; one
-    // chunk ahead 0.31 ms.)
-    const int srow = tid >> 2, spiece = tid & 3;
+    const int srow = tid >> 2, spiece = tid & 3;       // staging: thread t -> row t / 4, 32-byte piece t % 4 of a 128-byte chunk row
     const bf16x8 *arow = (const bf16x8 *)(A.act + (size_t)min(a0 + srow, A.n - 1) * A.K);
-    const int sdst = srow * 8, ssw = (srow >> 1) & 7;
-    const bf16x8 *wbase = A.wv + (size_t)(2 * w) * 64 + l;      // fragment (s, tile 2 w + i) = wbase[(s * 8 + i) * 64]
-    const int n_steps = A.K / 16;                  // k-steps in all; the last chunk may be half (K is a multiple of 32)
+    const int sdst = srow * 8, ssw = (srow >> 1) & 7, rsw = (r32 >> 1) & 7;
+    const bf16x8 *wbase = A.wv + (size_t)w * 64 + l;   // fragment (k-step s, tile w) = wbase[s * 8 * 64]
+    const int n_steps = A.K / 16;                      // k-steps in all; the last chunk may be half (K is a multiple of 32)
     const int total = (n_steps + 3) / 4;
-    auto aload = [&](int c, bf16x8 (&dst)[2]) {    // (a half chunk re-reads its first piece: clamped, never out of range)
+    auto aload = [&](int c, bf16x8 (&dst)[2]) {        // (a half chunk re-reads its first piece: clamped, never out of range)
         const int valid = min(8, (n_steps - c * 4) * 2);
 #pragma unroll
-        for (int i = 0; i < 2; i++) { const int ch = spiece * 2 + i; dst[i] = arow[(size_t)c * 8 + (ch < valid ? ch : 0)]; }   // (non-temporal loads here: measured slower, 0.31 -> 0.35 ms)
+        for (int i = 0; i < 2; i++) { const int ch = spiece * 2 + i; dst[i] = arow[(size_t)c * 8 + (ch < valid ? ch : 0)]; }
     };
     auto astore = [&](int buf, const bf16x8 (&src)[2]) {
         s_act[buf][sdst + ((spiece * 2) ^ ssw)] = src[0];
         s_act[buf][sdst + ((spiece * 2 + 1) ^ ssw)] = src[1];
     };
-
-    f32x16 acc[2][2];     // [out tile of this wave][agent tile]
+    auto wload = [&](int c, bf16x8 (&dst)[4]) {
 #pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = f32x16{0};
+        for (int ks = 0; ks < 4; ks++) dst[ks] = wbase[(size_t)min(c * 4 + ks, n_steps - 1) * 8 * 64];
+    };
 
-    bf16x8 ar[4][2], wc[4][2], wn[4][2];
+    f32x16 acc[4];        // [agent tile]
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j] = f32x16{0};
+    // what the phases behind the main loop need from L2 is fetched now (measured: loaded at their point of use -- 32 dependent
+    // round trips for the head's weights alone -- those phases were 100 of the kernel's 280 us): the head's weights go to LDS,
+    // this lane's biases to registers
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_wh[k * HEAD_THREADS + tid] = A.wh[k * HEAD_THREADS + tid];
+    float bias_v[16], bias_e[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { bias_v[r] = A.bv[w * 32 + g * 16 + r]; bias_e[r] = A.be[w * 32 + g * 16 + r]; }
+
+    bf16x8 ar[4][2], wr[4][4];
     aload(0, ar[0]);
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) { wc[ks][0] = wbase[(size_t)(ks * 8) * 64]; wc[ks][1] = wbase[(size_t)(ks * 8 + 1) * 64]; }
+    for (int q = 0; q < 4; q++) wload(min(q, total - 1), wr[q]);
     astore(0, ar[0]);
 #pragma unroll
     for (int q = 0; q < 4; q++) aload(min(1 + q, total - 1), ar[q]);
@@ -285,102 +298,78 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
             const int kc = kc0 + q;
             if (kc >= total) break;
             const int buf = kc & 1;
-            const bool more = kc + 1 < total;
-            if (more) {
-                const int s1 = (kc + 1) * 4;
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    const int sq = min(s1 + ks, n_steps - 1);
-                    wn[ks][0] = wbase[(size_t)(sq * 8) * 64]; wn[ks][1] = wbase[(size_t)(sq * 8 + 1) * 64];
-                }
-            }
             const int steps = min(4, n_steps - kc * 4);
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 if (ks < steps) {
-                    const int c = 2 * ks + g;
-                    const bf16x8 x0 = s_act[buf][r32 * 8 + (c ^ ((r32 >> 1) & 7))], x1 = s_act[buf][(32 + r32) * 8 + (c ^ ((r32 >> 1) & 7))];
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][0], x0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][0], x1, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][1], x0, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ks][1], x1, acc[1][1], 0, 0, 0);
+                    const int c = (2 * ks + g) ^ rsw;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[q][ks], s_act[buf][(32 * j + r32) * 8 + c], acc[j], 0, 0, 0);
                 }
             }
-            if (more) {
+            if (kc + 1 < total) {
                 astore(buf ^ 1, ar[q]);                                   // chunk kc + 1, requested four chunks ago
                 aload(min(kc + 5, total - 1), ar[q]);
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) { wc[ks][0] = wn[ks][0]; wc[ks][1] = wn[ks][1]; }
             }
+            wload(min(kc + 4, total - 1), wr[q]);                         // this ring slot is chunk kc + 4's now
             __syncthreads();
         }
     }
-    // relu(dense_view) -> hidden slots [0, 256): tile T = 2 w + i holds chunks 4 T + 2 g, 4 T + 2 g + 1 of every agent
+    // relu(dense_view) -> hidden slots: output tile w holds chunks 4 w + 2 g, 4 w + 2 g + 1 of every agent
+    auto hidden_out = [&](const float (&bias)[16]) {
 #pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int T = 2 * w + i, agent = 32 * j + r32;
+        for (int j = 0; j < 4; j++) {
+            const int agent = 32 * j + r32;
             bf16x8 o0, o1;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                o0[r] = (__bf16)fmaxf(acc[i][j][r] + A.bv[T * 32 + g * 16 + r], 0.0f);
-                o1[r] = (__bf16)fmaxf(acc[i][j][8 + r] + A.bv[T * 32 + g * 16 + 8 + r], 0.0f);
+                o0[r] = (__bf16)fmaxf(acc[j][r] + bias[r], 0.0f);
+                o1[r] = (__bf16)fmaxf(acc[j][8 + r] + bias[8 + r], 0.0f);
             }
-            s_hid[hid_at(agent, 4 * T + 2 * g)] = o0;
-            s_hid[hid_at(agent, 4 * T + 2 * g + 1)] = o1;
+            s_hid[hid_at(agent, 4 * w + 2 * g)] = o0;
+            s_hid[hid_at(agent, 4 * w + 2 * g + 1)] = o1;
         }
-    // ---- the dueling head: [32 outputs] x [64 agents], K = 512 hidden slots in two halves; waves 0 and 1 take 32 agents each
+    };
+    hidden_out(bias_v);
+    // ---- the dueling head: [32 outputs] x [128 agents], K = 512 hidden slots in two halves; waves 0..3 take 32 agents each
     f32x16 h = {0};
-    const int hagent = 32 * (w & 1) + r32;
+    const int hagent = 32 * (w & 3) + r32;
     __syncthreads();
-    if (w < 2) {
+    if (w < 4) {
 #pragma unroll 4
-        for (int s = 0; s < 16; s++) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.wh[s * 64 + l], s_hid[hid_at(hagent, 2 * s + g)], h, 0, 0, 0);
+        for (int s = 0; s < 16; s++) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s_wh[s * 64 + l], s_hid[hid_at(hagent, 2 * s + g)], h, 0, 0, 0);
     }
     // ---- the feature embedding: K = FK (features as bf16 through the staging buffer, [agent][FK / 8 chunks] <= 8 chunks)
+    bf16x8 wemb[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) wemb[s] = A.we[((size_t)min(s, A.FK / 16 - 1) * 8 + w) * 64 + l];
     {
-        const int row = tid >> 2, piece = tid & 3, agent = min(a0 + row, A.n - 1);
-        for (int c = piece; c < A.FK / 8; c += 4) {
+        const int agent = min(a0 + srow, A.n - 1);
+        for (int c = spiece; c < A.FK / 8; c += 4) {
             bf16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; e++) { const int k = c * 8 + e; v[e] = (__bf16)(k < A.F ? A.feat[(size_t)agent * A.F + k] : 0.0f); }
-            s_act[0][row * 8 + (c ^ ((row >> 1) & 7))] = v;
+            s_act[0][sdst + (c ^ ssw)] = v;
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 4; j++) acc[j] = f32x16{0};
 #pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = f32x16{0};
-    for (int s = 0; s < A.FK / 16; s++) {
-        const bf16x8 w0 = A.we[((size_t)s * 8 + 2 * w) * 64 + l], w1 = A.we[((size_t)s * 8 + 2 * w + 1) * 64 + l];
-        const int c = 2 * s + g;
-        const bf16x8 x0 = s_act[0][r32 * 8 + (c ^ ((r32 >> 1) & 7))], x1 = s_act[0][(32 + r32) * 8 + (c ^ ((r32 >> 1) & 7))];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc[1][1], 0, 0, 0);
+    for (int s = 0; s < 4; s++) {
+        if (s < A.FK / 16) {
+            const int c = (2 * s + g) ^ rsw;
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wemb[s], s_act[0][(32 * j + r32) * 8 + c], acc[j], 0, 0, 0);
+        }
     }
     __syncthreads();     // the first half of the head has read relu(dense_view)
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int T = 2 * w + i, agent = 32 * j + r32;
-            bf16x8 o0, o1;
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                o0[r] = (__bf16)fmaxf(acc[i][j][r] + A.be[T * 32 + g * 16 + r], 0.0f);
-                o1[r] = (__bf16)fmaxf(acc[i][j][8 + r] + A.be[T * 32 + g * 16 + 8 + r], 0.0f);
-            }
-            s_hid[hid_at(agent, 4 * T + 2 * g)] = o0;
-            s_hid[hid_at(agent, 4 * T + 2 * g + 1)] = o1;
-        }
+    hidden_out(bias_e);
     __syncthreads();
-    if (w < 2) {
+    if (w < 4) {
 #pragma unroll 4
-        for (int s = 16; s < 32; s++) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.wh[s * 64 + l], s_hid[hid_at(hagent, 2 * (s - 16) + g)], h, 0, 0, 0);
+        for (int s = 16; s < 32; s++) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s_wh[s * 64 + l], s_hid[hid_at(hagent, 2 * (s - 16) + g)], h, 0, 0, 0);
         const int agent = hagent;
         // lane (agent, g) holds outputs ch_of(g, r); its partner lane ^ 32 the other sixteen
         float best = -INFINITY, sum = 0.0f, value = 0.0f;
@@ -440,6 +429,7 @@ int policy_dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const f
     static bool lds_ok = false;
     if (!lds_ok) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_conv), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return 2;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_head), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS) != hipSuccess) return 2;
         lds_ok = true;
     }
     ConvArgs C{};
@@ -451,7 +441,7 @@ int policy_dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const f
     Hd.act = (const __bf16 *)act_workspace; Hd.feat = feat; Hd.wv = (const bf16x8 *)w->dense_view; Hd.we = (const bf16x8 *)w->dense_emb; Hd.wh = (const bf16x8 *)w->head;
     Hd.bv = w->dense_view_bias; Hd.be = w->dense_emb_bias; Hd.value_bias = w->value_bias;
     Hd.n = n; Hd.K = H2 * W2 * 32; Hd.F = s->feat; Hd.FK = (s->feat + 15) / 16 * 16; Hd.n_action = s->n_action; Hd.actions = actions; Hd.q = q;
-    hipLaunchKernelGGL(k_dqn_head, dim3((n + HEAD_M - 1) / HEAD_M), dim3(HEAD_THREADS), 0, st, Hd);
+    hipLaunchKernelGGL(k_dqn_head, dim3((n + HEAD_M - 1) / HEAD_M), dim3(HEAD_THREADS), HEAD_LDS, st, Hd);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
