@@ -98,14 +98,25 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     // by it).  A thread owns whole cells: C floats in, one 16-byte LDS store out.
     float nv[CONV_CELLS][7];
     // (the loads are unconditional, from clamped addresses: a select on a loaded value would make the wave wait for it at once)
+    // (seven channels -- every reference game with a minimap and two groups -- are fetched as one 16-byte and one 12-byte load per
+    // cell: a wave's lanes are 28 bytes apart, so every load instruction walks 14 cache lines whatever its width, and seven
+    // 4-byte loads per cell kept the CU's one address pipeline busy for a quarter of the kernel)
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
     auto fetch = [&](int tile) {
         const float *src = A.view + (size_t)tile * cells * A.C;
         const int live = min(A.TA, A.n - tile * A.TA) * A.H * A.W;
 #pragma unroll
         for (int k = 0; k < CONV_CELLS; k++) {
             const float *p = src + (size_t)min(k * CONV_THREADS + tid, live - 1) * A.C;
+            if (A.C == 7) {
+                const f32x4u lo = *(const f32x4u *)p;
+                const f32x3u hi = *(const f32x3u *)(p + 4);
+                nv[k][0] = lo[0]; nv[k][1] = lo[1]; nv[k][2] = lo[2]; nv[k][3] = lo[3]; nv[k][4] = hi[0]; nv[k][5] = hi[1]; nv[k][6] = hi[2];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 7; e++) nv[k][e] = p[min(e, A.C - 1)];
+                for (int e = 0; e < 7; e++) nv[k][e] = p[min(e, A.C - 1)];
+            }
         }
     };
     if ((int)blockIdx.x < A.n_tiles) fetch(blockIdx.x);
