@@ -9,7 +9,6 @@ second-best Q are further apart than that bound."""
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
 
 
 def _reference(qnet, view, feat):
@@ -28,6 +27,7 @@ def _reference(qnet, view, feat):
     return val + adv - adv.mean(dim=1, keepdim=True)
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("view_space,feat,n_action,n", [((13, 13, 7), 34, 21, 1000), ((13, 13, 7), 34, 21, 64 * 6 + 5),
                                                          ((9, 9, 5), 18, 9, 777), ((13, 11, 6), 40, 31, 300), ((7, 7, 3), 5, 5, 131)])
 def test_hip_policy_matches_torch_reference(view_space, feat, n_action, n):
@@ -61,6 +61,7 @@ def test_hip_policy_matches_torch_reference(view_space, feat, n_action, n):
     assert torch.equal(pol.infer(view, featv), actions)
 
 
+@pytest.mark.gpu
 def test_hip_policy_follows_parameter_updates():
     """DeepQNetwork repacks the kernel's weights after training: infer_action through the HIP path tracks the torch network"""
     import torch
@@ -87,3 +88,47 @@ def test_hip_policy_follows_parameter_updates():
     assert (a1.long() == ref1).float().mean().item() > 0.97 and (a2.long() == ref2).float().mean().item() > 0.97
     assert not torch.equal(a1, a2)
     env.close()
+
+
+def test_weight_packing_is_the_documented_permutation():
+    """CPU-only: include/magent_policy.h's "fragment order" and "slot order", checked by undoing them -- lane l of k-step s and tile
+    T holds W[32 T + (l & 31)][16 s + 8 (l >> 5) + 0..7], and slot s of a 32-wide tile stands for channel
+    (s & 3) + 8 ((s & 15) >> 2) + 4 (s >> 4)"""
+    import torch
+    from magent_amd.builtin.torch_model.dqn import _QNet
+    from magent_amd.builtin.torch_model.hip_policy import HipDqnPolicy, fragment_order, slot_channels
+    torch.manual_seed(7)
+    ch = slot_channels("cpu")
+    assert sorted(ch.tolist()) == list(range(32))
+    assert ch[:8].tolist() == [0, 1, 2, 3, 8, 9, 10, 11] and ch[16:20].tolist() == [4, 5, 6, 7]      # lane group 0 / 1 of the MFMA result
+    w = torch.randn(64, 48)
+    f = fragment_order(w).float()
+    assert f.shape == (3, 2, 64, 8)
+    for (s, T, l, e) in [(0, 0, 0, 0), (2, 1, 63, 7), (1, 0, 37, 3), (2, 1, 5, 6)]:
+        assert f[s, T, l, e] == w[32 * T + (l & 31), 16 * s + 8 * (l >> 5) + e].to(torch.bfloat16).float()
+    view_space, feat, n_action = (13, 13, 7), 34, 21
+    qnet = _QNet(view_space, (feat,), n_action, True, True)
+    pol = HipDqnPolicy(qnet, view_space, (feat,), n_action, "cpu")
+    pol.pack()
+    t = pol._packed
+    assert t["conv1"].shape == (5, 1, 64, 8) and t["conv2"].shape == (18, 1, 64, 8) and t["dense_view"].shape == (162, 8, 64, 8)
+    assert t["dense_emb"].shape == (3, 8, 64, 8) and t["head"].shape == (32, 1, 64, 8)
+    bf = lambda x: x.detach().to(torch.bfloat16).float()
+    # conv1: k = tap * 8 + channel; (tap 0, channel 7) carries the bias; taps 9.. and channels >= C are zero
+    c1 = t["conv1"].float()
+    get1 = lambda co, k: c1[k // 16, 0, 32 * ((k % 16) // 8) + co, k % 8]
+    assert get1(5, 2 * 8 + 3) == bf(qnet.conv1.weight)[5, 3, 0, 2] and get1(9, 7) == bf(qnet.conv1.bias)[9] and get1(9, 9 * 8 + 1) == 0
+    # conv2: k = tap * 32 + slot, slot -> input channel ch[slot]
+    c2 = t["conv2"].float()
+    get2 = lambda co, k: c2[k // 16, 0, 32 * ((k % 16) // 8) + co, k % 8]
+    assert get2(11, 4 * 32 + 17) == bf(qnet.conv2.weight)[11, int(ch[17]), 1, 1]
+    # dense_view: k = position * 32 + slot; output tile T row i is output 32 T + i; its bias sits in slot order
+    dv = t["dense_view"].float()
+    getv = lambda o, k: dv[k // 16, o // 32, 32 * ((k % 16) // 8) + o % 32, k % 8]
+    assert getv(200, 40 * 32 + 9) == bf(qnet.dense_view.weight)[200, 40 * 32 + int(ch[9])]
+    assert t["dense_view_bias"][3 * 32 + 21] == qnet.dense_view.bias[3 * 32 + int(ch[21])]
+    # head: k = hidden slot 32 T' + slot (T' < 8: dense_view, then dense_emb); output n_action is the value
+    hd = t["head"].float()
+    geth = lambda o, k: hd[k // 16, 0, 32 * ((k % 16) // 8) + o, k % 8]
+    assert geth(4, 5 * 32 + 30) == bf(qnet.advantage.weight)[4, 5 * 32 + int(ch[30])]
+    assert geth(n_action, 256 + 2 * 32 + 1) == bf(qnet.value.weight)[0, 256 + 2 * 32 + int(ch[1])] and geth(n_action + 1, 77) == 0
