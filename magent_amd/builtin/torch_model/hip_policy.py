@@ -92,7 +92,7 @@ class HipDqnPolicy(object):
         n = view.shape[0]
         actions = torch.empty(n, dtype=torch.int32, device=view.device)
         q = torch.empty((n, self.shape.n_action), dtype=torch.float32, device=view.device) if want_q else None
-        need = min(n, self.chunk) * self.k_dense * 2
+        need = min(n, self.chunk) * self.k_dense * 2 + 2048          # (policy_dqn_act_bytes: activations + the conv kernel's dump line)
         if self._work is None or self._work.numel() < need:
             self._work = torch.empty(need, dtype=torch.uint8, device=view.device)
         stream = torch.cuda.current_stream(view.device).cuda_stream

@@ -46,6 +46,7 @@ struct ConvArgs {
     const bf16x8 *w1, *w2; // fragment order: [5][64], [18][64]; conv1's bias sits in w1 at (tap 0, channel 7)
     const float *b2;       // [2][16]: conv2's bias of the channel in slot 16 g + r
     int n, H, W, C, TA, AP, n_tiles;
+    bf16x8 *dump;          // 2 KB behind the workspace: where lanes without a conv2 position store
 };
 
 // LDS images (the layouts make every ds_read_b128 of an MFMA operand conflict-free: a 16-lane service group of the instruction
@@ -57,6 +58,7 @@ struct ConvArgs {
 //   s_c1   [TA][AP = H1 * W + pad positions][4 chunks of 8 slots]: row pitch W (== W2 mod 4) and agent pitch AP (== H2 * W2
 //          mod 4) make a position's index congruent mod 4 to u = its rank in conv2's own enumeration; the chunk index is xor-ed
 //          with (u >> 2) & 3.  The 16 lanes of a group have 16 consecutive-modulo-16 ranks, for every tap: 16 distinct slots.
+template <int C2I>      // passes of conv2 per tile: ceil(tiles of 32 positions / 8), a compile-time count (see the stores below)
 __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int H1 = A.H - 2, W1 = A.W - 2, H2 = A.H - 4, W2 = A.W - 4;
@@ -170,12 +172,13 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
         // ---- conv2: [P2 positions] x [32 channels], K = 9 taps x 32 slots; starts from the bias, result straight to HBM.
         // Two tiles per wave at a time here too; the operands of the next tap are read while the current one runs.
         const unsigned char *c1b = (const unsigned char *)s_c1;
-        // (not a loop: with global stores inside a loop the compiler drains every outstanding load -- the prefetch of the next
-        // tile -- before entering it; unrolled under predicates it keeps them in flight)
+        // (a fixed number of passes, every one issuing its four stores -- lanes without a position write to a dump line behind the
+        // workspace: the number of stores outstanding when the next tile's views are waited for is then known at compile time,
+        // and nothing sits in a run-time loop that would make the compiler drain the prefetch before entering it.  Measured:
+        // neutral -- the conv2 stores cost their 0.1 ms per 131072 agents either way, profiles/r02_policy.txt.)
 #pragma unroll
-        for (int it = 0; it < CONV_C2_ITERS; it++) {
+        for (int it = 0; it < C2I; it++) {
             const int t = w + it * 2 * NW;
-            if (t >= T2) break;
             const int Qa = t * 32 + r32, Qb = (t + NW) * 32 + r32;
             const unsigned ea = s_lut2[min(Qa, P2 - 1)], eb = s_lut2[min(Qb, P2 - 1)];
             const unsigned basea = (ea & 0xFFFu) << 6, qa = ea >> 12, baseb = (eb & 0xFFFu) << 6, qb = eb >> 12;
@@ -211,16 +214,16 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
             }
             const int lim = na * H2 * W2;
             bf16x8 o0, o1;
-            if (Qa < lim) {
+            {
 #pragma unroll
                 for (int r = 0; r < 8; r++) { o0[r] = (__bf16)fmaxf(acca[r], 0.0f); o1[r] = (__bf16)fmaxf(acca[8 + r], 0.0f); }
-                bf16x8 *dst = (bf16x8 *)(A.act + ((size_t)a0 * H2 * W2 + Qa) * 32 + 16 * g);
+                bf16x8 *dst = Qa < lim ? (bf16x8 *)(A.act + ((size_t)a0 * H2 * W2 + Qa) * 32 + 16 * g) : A.dump + 2 * l;
                 dst[0] = o0; dst[1] = o1;
             }
-            if (Qb < lim) {
+            {
 #pragma unroll
                 for (int r = 0; r < 8; r++) { o0[r] = (__bf16)fmaxf(accb[r], 0.0f); o1[r] = (__bf16)fmaxf(accb[8 + r], 0.0f); }
-                bf16x8 *dst = (bf16x8 *)(A.act + ((size_t)a0 * H2 * W2 + Qb) * 32 + 16 * g);
+                bf16x8 *dst = Qb < lim ? (bf16x8 *)(A.act + ((size_t)a0 * H2 * W2 + Qb) * 32 + 16 * g) : A.dump + 2 * l;
                 dst[0] = o0; dst[1] = o1;
             }
         }
@@ -411,8 +414,9 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
 
 extern "C" {
 
+static size_t act_bytes(const PolicyDqnShape *s, int n) { return (size_t)n * (s->view_h - 4) * (s->view_w - 4) * 32 * 2; }
 int policy_dqn_act_bytes(const PolicyDqnShape *s, int n, size_t *bytes) {
-    *bytes = (size_t)n * (s->view_h - 4) * (s->view_w - 4) * 32 * 2;
+    *bytes = act_bytes(s, n) + 2048;       // (+ the dump line of k_dqn_conv)
     return 0;
 }
 
@@ -437,17 +441,26 @@ int policy_dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const f
         if (lds <= 78 * 1024 && (size_t)TA * AP < 4096 && cells <= (size_t)CONV_CELLS * CONV_THREADS && P2 <= (size_t)CONV_C2_ITERS * 256) break;
     }
     if (TA < 1) return 1;
+    const int T2 = (TA * H2 * W2 + 31) / 32, c2i = (T2 + 7) / 8;
     static bool lds_ok = false;
     if (!lds_ok) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_conv), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return 2;
+        const void *convs[4] = {reinterpret_cast<const void *>(k_dqn_conv<1>), reinterpret_cast<const void *>(k_dqn_conv<2>),
+                                reinterpret_cast<const void *>(k_dqn_conv<3>), reinterpret_cast<const void *>(k_dqn_conv<4>)};
+        for (const void *f : convs)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return 2;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_head), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS) != hipSuccess) return 2;
         lds_ok = true;
     }
     ConvArgs C{};
     C.view = view; C.act = (__bf16 *)act_workspace; C.w1 = (const bf16x8 *)w->conv1; C.w2 = (const bf16x8 *)w->conv2; C.b2 = w->conv2_bias;
-    C.n = n; C.H = H; C.W = W; C.C = s->view_c; C.TA = TA; C.AP = AP; C.n_tiles = (n + TA - 1) / TA;
+    C.n = n; C.H = H; C.W = W; C.C = s->view_c; C.TA = TA; C.AP = AP; C.n_tiles = (n + TA - 1) / TA; C.dump = (bf16x8 *)((char *)act_workspace + act_bytes(s, n));
     const int grid = C.n_tiles < 512 ? C.n_tiles : 512;     // persistent (2 per CU): weights are fetched once per wave
-    hipLaunchKernelGGL(k_dqn_conv, dim3(grid), dim3(CONV_THREADS), lds, st, C);
+    switch (c2i) {
+        case 1: hipLaunchKernelGGL(k_dqn_conv<1>, dim3(grid), dim3(CONV_THREADS), lds, st, C); break;
+        case 2: hipLaunchKernelGGL(k_dqn_conv<2>, dim3(grid), dim3(CONV_THREADS), lds, st, C); break;
+        case 3: hipLaunchKernelGGL(k_dqn_conv<3>, dim3(grid), dim3(CONV_THREADS), lds, st, C); break;
+        default: hipLaunchKernelGGL(k_dqn_conv<4>, dim3(grid), dim3(CONV_THREADS), lds, st, C); break;
+    }
     HeadArgs Hd{};
     Hd.act = (const __bf16 *)act_workspace; Hd.feat = feat; Hd.wv = (const bf16x8 *)w->dense_view; Hd.we = (const bf16x8 *)w->dense_emb; Hd.wh = (const bf16x8 *)w->head;
     Hd.bv = w->dense_view_bias; Hd.be = w->dense_emb_bias; Hd.value_bias = w->value_bias;
