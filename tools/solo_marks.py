@@ -16,7 +16,7 @@ env.set_seed(1); env.reset()
 hs = env.get_handles()
 for h in hs:
     env.add_agents(h, "random", n=N)
-names = ["start", "draw", "chase", "rank", "eval", "apply", "unhit", "prep", "claim", "init", "jump", "commit", "rules", "finish"]
+names = ["start", "set_action", "draw", "chase", "rank", "eval", "apply", "hit reset", "starve+cand", "claim", "init", "jump", "commit", "rules", "finish", "cycle tail"]
 acc = None
 for s in range(30):
     for h in hs:
