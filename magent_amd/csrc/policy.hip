@@ -61,7 +61,7 @@ struct ConvArgs {
 template <int C2I>      // passes of conv2 per tile: ceil(tiles of 32 positions / 8), a compile-time count (see the stores below)
 __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    const int H1 = A.H - 2, W1 = A.W - 2, H2 = A.H - 4, W2 = A.W - 4;
+    const int H1 = A.H - 2, H2 = A.H - 4, W2 = A.W - 4;
     const int cells = A.TA * A.H * A.W, E1 = A.TA * H1 * A.W, P2 = A.TA * H2 * W2;
     bf16x8 *s_view = (bf16x8 *)s_raw;                                  // [cells + 2]
     bf16x8 *s_c1 = s_view + cells + 2;                                 // [TA * AP][4]
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
         // ---- conv1: [E1 positions, full rows] x [32 channels], K = 10 taps x 8 channels (bias: the constant channel of tap 0).
         // A wave runs TWO position tiles at a time (t and t + 4): two independent accumulator chains keep the matrix pipe busy
         // while the other chain's operands are on their way from LDS.
-        const int T1 = (E1 + 31) / 32, T2 = (P2 + 31) / 32, NW = CONV_THREADS / 64;
+        const int T1 = (E1 + 31) / 32, NW = CONV_THREADS / 64;
         for (int t = w; t < T1; t += 2 * NW) {
             const bool two = t + NW < T1;
             const int Ea = min(t * 32 + r32, E1 - 1), Eb = min((t + NW) * 32 + r32, E1 - 1);
@@ -430,7 +430,7 @@ int policy_dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const f
     if (!policy_dqn_supported(s)) return 1;
     if (n <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const int H = s->view_h, W = s->view_w, H1 = H - 2, W1 = W - 2, H2 = H - 4, W2 = W - 4;
+    const int H = s->view_h, W = s->view_w, H1 = H - 2, H2 = H - 4, W2 = W - 4;
     // agents per workgroup pass: as many as leave two workgroups per CU their LDS (views 16 B / cell, conv1 64 B / position)
     const int AP = H1 * W + ((H2 * W2 - H1 * W) % 4 + 4) % 4;      // agent pitch of conv1's LDS image: == H2 * W2 (mod 4)
     int TA = 8;
