@@ -52,6 +52,11 @@ int policy_dqn_act_bytes(const PolicyDqnShape *shape, int n, size_t *bytes);
 int policy_dqn_infer(const PolicyDqnShape *shape, const PolicyDqnWeights *weights, const float *view, const float *feature, int n,
                      void *act_workspace, int *actions, float *q, void *stream);
 
+/* the same with the views as the engine's bf16 cells (env_get_observation_device_bf16: [n][view_h][view_w][8], channel 7 = 1.0):
+ * they ARE conv1's operands -- nothing is converted, and the kernel reads 16 bytes per window cell instead of 4 * view_c */
+int policy_dqn_infer_bf16(const PolicyDqnShape *shape, const PolicyDqnWeights *weights, const void *view_cells, const float *feature, int n,
+                          void *act_workspace, int *actions, float *q, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,11 @@ int discrete_snake_add_object(EnvHandle game, int obj_id, int n, const char *met
 
 /* same layout as env_get_observation, written straight into caller-owned device memory */
 int env_get_observation_device(EnvHandle game, GroupHandle group, float **device_buffer);
+/* the same observation in the policy kernels' input format (include/magent_policy.h): device_buffer[0] = view as bf16
+ * [n][view_h][view_w][8] -- the n_channel (<= 7) channels of env_get_observation rounded to nearest even, zeros, and 1.0 in
+ * channel 7; 16-byte aligned -- device_buffer[1] = feature float[n][feature_size] as above.  2.7 KB per agent instead of 4.7:
+ * the render is HBM-write bound, and a policy that computes in bf16 reads these cells as its MFMA operands. */
+int env_get_observation_device_bf16(EnvHandle game, GroupHandle group, void **device_buffer);
 /* actions int32[n] in device memory */
 int env_set_action_device(EnvHandle game, GroupHandle group, const int *device_actions);
 /* rewards float[n] in device memory */

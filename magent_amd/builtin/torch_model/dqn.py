@@ -120,7 +120,8 @@ class DeepQNetwork(BaseModel):
         eps = 0 if policy == "greedy" else eps
         n = len(view)
         if (self._hip is not None and n > 0 and isinstance(view, torch.Tensor) and isinstance(feature, torch.Tensor) and view.is_cuda
-                and view.dtype == torch.float32 and feature.dtype == torch.float32 and view.is_contiguous() and feature.is_contiguous()):
+                and view.dtype in (torch.float32, torch.bfloat16) and feature.dtype == torch.float32 and view.is_contiguous()
+                and feature.is_contiguous()):
             best = self._hip.infer(view, feature)
             if eps > 0:
                 rnd = torch.randint(self.num_actions, best.shape, dtype=torch.int32, device=self.device)

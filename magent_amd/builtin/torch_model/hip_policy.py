@@ -85,8 +85,12 @@ class HipDqnPolicy(object):
 
     @torch.no_grad()
     def infer(self, view, feature, want_q=False):
-        """view float32 [n][H][W][C], feature float32 [n][F]: contiguous CUDA tensors.  Returns int32 actions [n] (and Q [n][A])"""
-        assert view.is_cuda and view.dtype == torch.float32 and view.is_contiguous() and feature.is_contiguous() and feature.dtype == torch.float32
+        """view float32 [n][H][W][C] -- or bfloat16 [n][H][W][8], the engine's cells (GridWorld.get_observation_device_bf16) --,
+        feature float32 [n][F]: contiguous CUDA tensors.  Returns int32 actions [n] (and Q [n][A])"""
+        cells16 = view.dtype == torch.bfloat16
+        assert view.is_cuda and view.is_contiguous() and feature.is_contiguous() and feature.dtype == torch.float32
+        assert (cells16 and view.shape[-1] == 8) or (view.dtype == torch.float32 and view.shape[-1] == self.shape.view_c)
+        call = self._lib.policy_dqn_infer_bf16 if cells16 else self._lib.policy_dqn_infer
         if self.dirty:
             self.pack()
         n = view.shape[0]
@@ -98,7 +102,7 @@ class HipDqnPolicy(object):
         stream = torch.cuda.current_stream(view.device).cuda_stream
         for beg in range(0, n, self.chunk):
             m = min(self.chunk, n - beg)
-            rc = self._lib.policy_dqn_infer(ctypes.byref(self.shape), ctypes.byref(self._w), view[beg:].data_ptr(), feature[beg:].data_ptr(), m,
+            rc = call(ctypes.byref(self.shape), ctypes.byref(self._w), view[beg:].data_ptr(), feature[beg:].data_ptr(), m,
                                             self._work.data_ptr(), actions[beg:].data_ptr(), q[beg:].data_ptr() if want_q else None, stream)
             if rc != 0:
                 raise RuntimeError("policy_dqn_infer failed (%d)" % rc)

@@ -40,6 +40,7 @@ REFERENCE_ABI = [
 ]
 DEVICE_ABI = [
     ("env_get_observation_device", [_vp, _i, _c.POINTER(_vp)]),
+    ("env_get_observation_device_bf16", [_vp, _i, _c.POINTER(_vp)]),
     ("env_set_action_device", [_vp, _i, _vp]),
     ("env_get_reward_device", [_vp, _i, _vp]),
     ("env_get_info_device", [_vp, _i, _cp, _vp]),
@@ -57,6 +58,7 @@ POLICY_ABI = [
     ("policy_dqn_supported", [_vp]),
     ("policy_dqn_act_bytes", [_vp, _i, _c.POINTER(_c.c_size_t)]),
     ("policy_dqn_infer", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    ("policy_dqn_infer_bf16", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
 ]
 
 _cache = {}

@@ -180,6 +180,7 @@ struct RenderArgs {
     int totals[MAXG];            // group sizes (minimap divisor)
     const float *mini;           // float[G][VH*VW]: count / total per group (k_minimap)
     float *view, *feat;
+    int cells16;                 // 1: `view` is bf16 [n][VH][VW][8] -- channels 0..C-1, zeros, and 1.0 in channel 7 (include/magent_policy.h)
 };
 
 }  // namespace magent_amd

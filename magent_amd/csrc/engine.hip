@@ -1269,8 +1269,10 @@ bool Env::prepare_render(int g, const WorldView &W, RenderArgs &R, RenderPlan &P
 }
 
 // GridWorld::get_observation (GridWorld.cc:292-401) into DEVICE buffers, asynchronous on the env stream
-void Env::observe_device(int g, float *view, float *feat) {
+void Env::observe_device(int g, float *view, float *feat, bool cells16) {
     if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in get_observation : %d", g);
+    if (cells16 && (n_channel() > 7 || (((uintptr_t)view) & 15)))
+        fatal("get_observation (bf16 cells): needs at most 7 channels (this game has %d) and a 16-byte aligned buffer", n_channel());
     use_device();
     if (groups[g].n == 0) return;   // the reference dereferences agents[0] here (UB); nothing to write for n = 0
     if (groups[g].acted) {          // set_action came first: the feature rows show the new last_action (GridWorld.cc:386-396)
@@ -1283,6 +1285,7 @@ void Env::observe_device(int g, float *view, float *feat) {
     RenderArgs R; RenderPlan P;
     const bool aligned = prepare_render(g, W, R, P, view, feat);
     const bool feat_aligned = (((uintptr_t)feat) & 15) == 0;
+    R.cells16 = cells16 ? 1 : 0;
     {
         ProfScope p(*this, "render", true);
         launch_render(stream, W, R, P, aligned, aligned && nt_stores);

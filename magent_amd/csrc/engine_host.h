@@ -119,7 +119,7 @@ public:
     void render();
 
     // device-resident extensions
-    void observe_device(int g, float *view, float *feat);
+    void observe_device(int g, float *view, float *feat, bool cells16 = false);   // cells16: `view` is bf16 [n][VH][VW][8] (RenderArgs::cells16)
     void set_action_device(int g, const int *d_act);
     void get_reward_device(int g, float *out);
     void info_device(int g, const char *name, void *out);

@@ -319,7 +319,11 @@ constexpr int RENDER_WAVES = 4;
 
 // (bx of nb workgroups of the launch work on this group: the render spans first, then the feature rows)
 // (TURN: turn_mode -- the window is laid out in the agent's frame; a template parameter so that the ordinary kernel carries none of it)
-template <bool VEC4, bool NT, int U, bool PACKED, bool TURN>
+// (CELLS16: the policy kernels' input format -- every window cell one 16-byte vector of 8 bf16: the C channels rounded to nearest
+// even, zeros, and 1.0 in channel 7 (conv1's bias rides on it, magent_amd/csrc/policy.hip).  2.7 KB per agent instead of 4.7, a
+// lane stores its own cell: no hand-over between lanes)
+typedef __attribute__((ext_vector_type(8))) __bf16 cell16_t;
+template <bool VEC4, bool NT, int U, bool PACKED, bool TURN, bool CELLS16 = false>
 __device__ __forceinline__ void render_block(const RenderWorld &W, const RenderArgs &R, const RenderPlan &P, int bx, int nb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int VHW = R.VH * R.VW, C = R.C, G = W.G;
@@ -416,6 +420,14 @@ __device__ __forceinline__ void render_block(const RenderWorld &W, const RenderA
                         j = (j + 1 == G) ? 0 : j + 1;
                     }
             }
+            if (CELLS16) {
+                cell16_t v;
+#pragma unroll
+                for (int e = 0; e < 7; e++) v[e] = (__bf16)(e < C ? dst[e] : 0.0f);      // (the lane's own strip entries, just written)
+                v[7] = (__bf16)1.0f;
+                if (valid[u]) __builtin_nontemporal_store(v, (cell16_t *)R.view + (k0 + lane));
+                continue;
+            }
             // wave-private LDS hand-over between lanes: LDS ops of one wave execute in order; the fences keep the
             // compiler from moving accesses across the hand-over
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -448,6 +460,10 @@ __device__ __forceinline__ void render_block(const RenderWorld &W, const RenderA
 template <bool VEC4, bool NT, int U, bool PACKED, bool TURN>
 __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render(WorldView W, RenderArgs R, RenderPlan P) {
     render_block<VEC4, NT, U, PACKED, TURN>(render_world(W, R.g), R, P, blockIdx.x, gridDim.x);
+}
+template <bool PACKED, bool TURN>
+__global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_cells16(WorldView W, RenderArgs R, RenderPlan P) {
+    render_block<true, true, 1, PACKED, TURN, true>(render_world(W, R.g), R, P, blockIdx.x, gridDim.x);
 }
 // several groups of a small world in one launch (blockIdx.y = slot): small worlds are bound by the number of launches
 template <bool PACKED>
@@ -2400,6 +2416,11 @@ void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const
     size_t lds = (size_t)RENDER_WAVES * P.strip_floats * sizeof(float);
     dim3 grid(P.spans + P.feat_blocks), block(64 * RENDER_WAVES);
     const bool packed = W.vc_packed != 0;   // must match launch_paint
+    if (R.cells16) {
+        if (R.turn) { if (packed) hipLaunchKernelGGL((k_render_cells16<true, true>), grid, block, lds, s, W, R, P); else hipLaunchKernelGGL((k_render_cells16<false, true>), grid, block, lds, s, W, R, P); }
+        else { if (packed) hipLaunchKernelGGL((k_render_cells16<true, false>), grid, block, lds, s, W, R, P); else hipLaunchKernelGGL((k_render_cells16<false, false>), grid, block, lds, s, W, R, P); }
+        return;
+    }
 #define RENDER_LAUNCH(V, N, UU, PK) hipLaunchKernelGGL((k_render<V, N, UU, PK, false>), grid, block, lds, s, W, R, P)
 #define RENDER_PK(V, N, UU) do { if (packed) RENDER_LAUNCH(V, N, UU, true); else RENDER_LAUNCH(V, N, UU, false); } while (0)
     if (R.turn) {      // turn_mode: one step per wave iteration, scalar or 16-byte stores

@@ -41,7 +41,7 @@ __device__ __forceinline__ int ch_of(int g, int r) { return (r & 3) + 8 * (r >> 
 constexpr int CONV_THREADS = 256, CONV_CELLS = 4, CONV_C2_ITERS = 4;   // CONV_C2_ITERS x 8 tiles of 32 conv2 positions per pass, at most   // CONV_CELLS: window cells of a tile per thread (register prefetch)
 
 struct ConvArgs {
-    const float *view;     // [n][H][W][C]
+    const float *view;     // [n][H][W][C] f32, or (CELLS16) [n][H][W][8] bf16 cells as env_get_observation_device_bf16 writes them
     __bf16 *act;           // [n][H2 * W2][32 slots]
     const bf16x8 *w1, *w2; // fragment order: [5][64], [18][64]; conv1's bias sits in w1 at (tap 0, channel 7)
     const float *b2;       // [2][16]: conv2's bias of the channel in slot 16 g + r
@@ -58,7 +58,8 @@ struct ConvArgs {
 //   s_c1   [TA][AP = H1 * W + pad positions][4 chunks of 8 slots]: row pitch W (== W2 mod 4) and agent pitch AP (== H2 * W2
 //          mod 4) make a position's index congruent mod 4 to u = its rank in conv2's own enumeration; the chunk index is xor-ed
 //          with (u >> 2) & 3.  The 16 lanes of a group have 16 consecutive-modulo-16 ranks, for every tap: 16 distinct slots.
-template <int C2I>      // passes of conv2 per tile: ceil(tiles of 32 positions / 8), a compile-time count (see the stores below)
+template <int C2I, bool CELLS16>   // C2I: passes of conv2 per tile = ceil(tiles of 32 positions / 8), a compile-time count (see the
+                                   // stores below).  CELLS16: the views arrive as bf16 cells -- conv1's operands as they are
 __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int H1 = A.H - 2, H2 = A.H - 4, W2 = A.W - 4;
@@ -105,9 +106,16 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     // 4-byte loads per cell kept the CU's one address pipeline busy for a quarter of the kernel)
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+    bf16x8 nc[CONV_CELLS];
     auto fetch = [&](int tile) {
-        const float *src = A.view + (size_t)tile * cells * A.C;
         const int live = min(A.TA, A.n - tile * A.TA) * A.H * A.W;
+        if (CELLS16) {
+            const bf16x8 *src16 = (const bf16x8 *)A.view + (size_t)tile * cells;
+#pragma unroll
+            for (int k = 0; k < CONV_CELLS; k++) nc[k] = src16[min(k * CONV_THREADS + tid, live - 1)];
+            return;
+        }
+        const float *src = A.view + (size_t)tile * cells * A.C;
 #pragma unroll
         for (int k = 0; k < CONV_CELLS; k++) {
             const float *p = src + (size_t)min(k * CONV_THREADS + tid, live - 1) * A.C;
@@ -131,9 +139,14 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
             const int c = k * CONV_THREADS + tid;
             const bool have = c < na * A.H * A.W;
             bf16x8 v;
+            if (CELLS16) {
+                v = nc[k];
+                if (!have) { v = bf16x8{0}; v[7] = (__bf16)1.0f; }
+            } else {
 #pragma unroll
-            for (int e = 0; e < 7; e++) v[e] = (__bf16)((have && e < A.C) ? nv[k][e] : 0.0f);
-            v[7] = (__bf16)1.0f;
+                for (int e = 0; e < 7; e++) v[e] = (__bf16)((have && e < A.C) ? nv[k][e] : 0.0f);
+                v[7] = (__bf16)1.0f;
+            }
             if (c < cells) s_view[c] = v;
         }
         if (tile + (int)gridDim.x < A.n_tiles) fetch(tile + gridDim.x);
@@ -425,8 +438,9 @@ int policy_dqn_supported(const PolicyDqnShape *s) {
            s->n_action >= 1 && s->n_action <= 31;
 }
 
-int policy_dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const float *view, const float *feat, int n, void *act_workspace,
-                     int *actions, float *q, void *stream) {
+static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const void *view_any, bool cells16, const float *feat, int n,
+                     void *act_workspace, int *actions, float *q, void *stream) {
+    const float *view = (const float *)view_any;
     if (!policy_dqn_supported(s)) return 1;
     if (n <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -444,8 +458,10 @@ int policy_dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const f
     const int T2 = (TA * H2 * W2 + 31) / 32, c2i = (T2 + 7) / 8;
     static bool lds_ok = false;
     if (!lds_ok) {
-        const void *convs[4] = {reinterpret_cast<const void *>(k_dqn_conv<1>), reinterpret_cast<const void *>(k_dqn_conv<2>),
-                                reinterpret_cast<const void *>(k_dqn_conv<3>), reinterpret_cast<const void *>(k_dqn_conv<4>)};
+        const void *convs[8] = {reinterpret_cast<const void *>(k_dqn_conv<1, false>), reinterpret_cast<const void *>(k_dqn_conv<2, false>),
+                                reinterpret_cast<const void *>(k_dqn_conv<3, false>), reinterpret_cast<const void *>(k_dqn_conv<4, false>),
+                                reinterpret_cast<const void *>(k_dqn_conv<1, true>), reinterpret_cast<const void *>(k_dqn_conv<2, true>),
+                                reinterpret_cast<const void *>(k_dqn_conv<3, true>), reinterpret_cast<const void *>(k_dqn_conv<4, true>)};
         for (const void *f : convs)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return 2;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_head), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS) != hipSuccess) return 2;
@@ -455,18 +471,33 @@ int policy_dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const f
     C.view = view; C.act = (__bf16 *)act_workspace; C.w1 = (const bf16x8 *)w->conv1; C.w2 = (const bf16x8 *)w->conv2; C.b2 = w->conv2_bias;
     C.n = n; C.H = H; C.W = W; C.C = s->view_c; C.TA = TA; C.AP = AP; C.n_tiles = (n + TA - 1) / TA; C.dump = (bf16x8 *)((char *)act_workspace + act_bytes(s, n));
     const int grid = C.n_tiles < 512 ? C.n_tiles : 512;     // persistent (2 per CU): weights are fetched once per wave
-    switch (c2i) {
-        case 1: hipLaunchKernelGGL(k_dqn_conv<1>, dim3(grid), dim3(CONV_THREADS), lds, st, C); break;
-        case 2: hipLaunchKernelGGL(k_dqn_conv<2>, dim3(grid), dim3(CONV_THREADS), lds, st, C); break;
-        case 3: hipLaunchKernelGGL(k_dqn_conv<3>, dim3(grid), dim3(CONV_THREADS), lds, st, C); break;
-        default: hipLaunchKernelGGL(k_dqn_conv<4>, dim3(grid), dim3(CONV_THREADS), lds, st, C); break;
+#define CONV_LAUNCH(I, B) hipLaunchKernelGGL((k_dqn_conv<I, B>), dim3(grid), dim3(CONV_THREADS), lds, st, C)
+    switch (c2i * 2 + (cells16 ? 1 : 0)) {
+        case 2: CONV_LAUNCH(1, false); break;
+        case 3: CONV_LAUNCH(1, true); break;
+        case 4: CONV_LAUNCH(2, false); break;
+        case 5: CONV_LAUNCH(2, true); break;
+        case 6: CONV_LAUNCH(3, false); break;
+        case 7: CONV_LAUNCH(3, true); break;
+        case 8: CONV_LAUNCH(4, false); break;
+        default: CONV_LAUNCH(4, true); break;
     }
+#undef CONV_LAUNCH
     HeadArgs Hd{};
     Hd.act = (const __bf16 *)act_workspace; Hd.feat = feat; Hd.wv = (const bf16x8 *)w->dense_view; Hd.we = (const bf16x8 *)w->dense_emb; Hd.wh = (const bf16x8 *)w->head;
     Hd.bv = w->dense_view_bias; Hd.be = w->dense_emb_bias; Hd.value_bias = w->value_bias;
     Hd.n = n; Hd.K = H2 * W2 * 32; Hd.F = s->feat; Hd.FK = (s->feat + 15) / 16 * 16; Hd.n_action = s->n_action; Hd.actions = actions; Hd.q = q;
     hipLaunchKernelGGL(k_dqn_head, dim3((n + HEAD_M - 1) / HEAD_M), dim3(HEAD_THREADS), HEAD_LDS, st, Hd);
     return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int policy_dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const float *view, const float *feat, int n, void *act_workspace,
+                     int *actions, float *q, void *stream) {
+    return dqn_infer(s, w, view, false, feat, n, act_workspace, actions, q, stream);
+}
+int policy_dqn_infer_bf16(const PolicyDqnShape *s, const PolicyDqnWeights *w, const void *view_cells, const float *feat, int n,
+                          void *act_workspace, int *actions, float *q, void *stream) {
+    return dqn_infer(s, w, view_cells, true, feat, n, act_workspace, actions, q, stream);
 }
 
 }  // extern "C"

@@ -111,6 +111,9 @@ int discrete_snake_add_object(EnvHandle, int, int, const char *, const int *) { 
 int env_get_observation_device(EnvHandle game, GroupHandle group, float **device_buffer) {
     E(game)->observe_device(group, device_buffer[0], device_buffer[1]); return 0;
 }
+int env_get_observation_device_bf16(EnvHandle game, GroupHandle group, void **device_buffer) {
+    E(game)->observe_device(group, (float *)device_buffer[0], (float *)device_buffer[1], true); return 0;
+}
 int env_set_action_device(EnvHandle game, GroupHandle group, const int *device_actions) { E(game)->set_action_device(group, device_actions); return 0; }
 int env_get_reward_device(EnvHandle game, GroupHandle group, float *device_buffer) { E(game)->get_reward_device(group, device_buffer); return 0; }
 int env_get_info_device(EnvHandle game, GroupHandle group, const char *name, void *device_buffer) { E(game)->info_device(group, name, device_buffer); return 0; }

@@ -65,12 +65,16 @@ class GridWorld(object):
         """config: name of a built-in game ("battle", "gather", "pursuit", kwargs -> its get_config) or a Config
         device_obs: get_observation() returns torch tensors living on the engine's GPU instead of numpy arrays (the
                     same reused buffers, no PCIe); default from the environment variable MAGENT_DEVICE_OBS=1.  Lets an
-                    unmodified training script keep observations, policy and replay memory on the device."""
+                    unmodified training script keep observations, policy and replay memory on the device.
+                    device_obs="bf16": the views come as torch.bfloat16 [n, H, W, 8] (get_observation_device_bf16) -- what
+                    DeepQNetwork.infer_action feeds to its MFMA kernels without a conversion; for acting, not for the
+                    float32 replay memory of training."""
         self._lib = c_lib.load(type(self)._engine_path)
         L = self._lib
         if device_obs is None:
-            device_obs = os.environ.get("MAGENT_DEVICE_OBS", "0") == "1"
+            device_obs = {"0": False, "1": True}.get(os.environ.get("MAGENT_DEVICE_OBS", "0"), os.environ.get("MAGENT_DEVICE_OBS"))
         self._device_obs = bool(device_obs) and getattr(L, "has_device_api", False)
+        self._obs_bf16 = device_obs == "bf16"      # views as bf16 cells of 8 channels, the policy kernels' input format
         self._dev_cache = ({}, {})
         if isinstance(config, str):
             config = _builtin_config(config, **kwargs)
@@ -190,19 +194,29 @@ class GridWorld(object):
     def _observe_device_cached(self, g, n):
         import torch
         out = []
-        for which, space in ((0, self.view_space[g]), (1, self.feature_space[g])):
+        spaces = ((0, self.view_space[g], torch.float32), (1, self.feature_space[g], torch.float32))
+        if self._obs_bf16:
+            spaces = ((0, self.view_space[g][:2] + (8,), torch.bfloat16), spaces[1])
+        for which, space, dtype in spaces:
             buf = self._dev_cache[which].get(g)
             if buf is None or buf.shape[0] < n:
-                buf = self._dev_cache[which][g] = torch.empty((n,) + space, dtype=torch.float32,
-                                                              device=torch.device("cuda", self._device_id))
+                buf = self._dev_cache[which][g] = torch.empty((n,) + space, dtype=dtype, device=torch.device("cuda", self._device_id))
             out.append(buf[:n])
         # The cached buffers are written on the engine's own stream.  Work still queued on torch's current stream may be
         # reading their previous contents (an episode buffer cloning rows, a policy forward): the render has to wait for
         # it, and torch's stream for the render -- stream-to-stream, the host does not block.
         self.order_after_torch()
-        self.get_observation_device(g, out[0], out[1])
+        if self._obs_bf16:
+            self.get_observation_device_bf16(g, out[0], out[1])
+        else:
+            self.get_observation_device(g, out[0], out[1])
         self.order_torch_after()
         return out[0], out[1]
+
+    def use_bf16_observations(self, on=True):
+        """device_obs mode: get_observation hands out the views as bf16 cells of 8 channels (get_observation_device_bf16)"""
+        if bool(on) != self._obs_bf16:
+            self._obs_bf16, self._dev_cache = bool(on), ({}, {})
 
     def set_action(self, handle, actions):
         if not isinstance(actions, np.ndarray):   # a torch int32 tensor on the engine's device
@@ -352,6 +366,26 @@ class GridWorld(object):
         assert view.numel() >= n * int(np.prod(self.view_space[g])) and feature.numel() >= n * self.feature_space[g][0]
         ptrs = (ctypes.c_void_p * 2)(view.data_ptr(), feature.data_ptr())
         self._lib.env_get_observation_device(self.game, g, ptrs)
+        return view, feature
+
+    def get_observation_device_bf16(self, handle, view=None, feature=None):
+        """The observation in the policy kernels' input format: view as torch.bfloat16 [n, H, W, 8] (the channels of
+        get_observation rounded to nearest even, zeros, 1.0 in channel 7), feature float32 [n, F].  Same asynchronous contract
+        as get_observation_device; needs a game with at most 7 observation channels."""
+        import torch
+        self._require_device_api()
+        g = _gid(handle)
+        n = self.get_num(g)
+        dev = torch.device("cuda", self.device_id)
+        h, w, _ = self.view_space[g]
+        if view is None:
+            view = torch.empty((n, h, w, 8), dtype=torch.bfloat16, device=dev)
+        if feature is None:
+            feature = torch.empty((n,) + self.feature_space[g], dtype=torch.float32, device=dev)
+        assert view.is_contiguous() and feature.is_contiguous() and view.dtype == torch.bfloat16
+        assert view.numel() >= n * h * w * 8 and feature.numel() >= n * self.feature_space[g][0]
+        ptrs = (ctypes.c_void_p * 2)(view.data_ptr(), feature.data_ptr())
+        self._lib.env_get_observation_device_bf16(self.game, g, ptrs)
         return view, feature
 
     def set_action_device(self, handle, actions):

@@ -133,3 +133,51 @@ def test_weight_packing_is_the_documented_permutation():
     geth = lambda o, k: hd[k // 16, 0, 32 * ((k % 16) // 8) + o, k % 8]
     assert geth(4, 5 * 32 + 30) == bf(qnet.advantage.weight)[4, 5 * 32 + int(ch[30])]
     assert geth(n_action, 256 + 2 * 32 + 1) == bf(qnet.value.weight)[0, 256 + 2 * 32 + int(ch[1])] and geth(n_action + 1, 77) == 0
+
+
+@pytest.mark.gpu
+def test_bf16_cell_observation_and_policy_on_it():
+    """env_get_observation_device_bf16: every window cell as 8 bf16 = the float32 observation's channels rounded to nearest even,
+    zeros, and 1.0 in channel 7 -- bit for bit; the policy kernels fed with those cells give the very Q values they give on the
+    float32 views (the same bf16 operands reach the same MFMAs)"""
+    import torch
+    import magent_amd
+    from magent_amd.builtin.torch_model.dqn import _QNet
+    from magent_amd.builtin.torch_model.hip_policy import HipDqnPolicy
+    for game, size, n in (("battle", 60, 700), ("gather", 60, 300)):
+        env = magent_amd.GridWorld(game, map_size=size)
+        env.set_seed(11); env.reset()
+        hs = env.get_handles()
+        if game == "battle":
+            for h in hs:
+                env.add_agents(h, "random", n=n)
+        else:
+            env.add_agents(hs[0], "random", n=400); env.add_agents(hs[1], "random", n=n)
+        h = hs[-1]
+        for step in range(3):
+            view32, feat = env.get_observation_device(h)
+            view16, feat16 = env.get_observation_device_bf16(h)
+            env.sync()
+            c = view32.shape[-1]
+            if c > 7:
+                break
+            assert torch.equal(view16[..., :c].view(torch.int16), view32.to(torch.bfloat16).view(torch.int16))
+            assert torch.equal(view16[..., c:7].float(), torch.zeros_like(view16[..., c:7].float())) and bool((view16[..., 7].float() == 1).all())
+            assert torch.equal(feat16, feat)
+            if step == 0:
+                torch.manual_seed(3)
+                vs, fs, na = env.get_view_space(h), env.get_feature_space(h), env.get_action_space(h)[0]
+                qnet = _QNet(vs, fs, na, True, True).to(view32.device)
+                try:
+                    pol = HipDqnPolicy(qnet, vs, fs, na, view32.device, chunk=256)
+                except ValueError:          # (gather: 33 actions, more than the head's 32-wide output tile holds: PyTorch takes it)
+                    assert game == "gather"
+                    continue
+                a32, q32 = pol.infer(view32, feat, want_q=True)
+                a16, q16 = pol.infer(view16, feat, want_q=True)
+                torch.cuda.synchronize()
+                assert torch.equal(q32, q16) and torch.equal(a32, a16)
+            for hh in hs[-1:] if game == "gather" else hs:
+                env.set_action(hh, np.random.RandomState(step).randint(env.get_action_space(hh)[0], size=env.get_num(hh)).astype(np.int32))
+            env.step(); env.clear_dead()
+        env.close()

@@ -17,6 +17,8 @@ hs = env.get_handles()
 for h in hs:
     env.add_agents(h, "random", n=n)
 models = [DeepQNetwork(env, h, "m%d" % i, memory_size=16, infer_batch_size=65536) for i, h in enumerate(hs)]
+cells = len(sys.argv) > 4 and sys.argv[4] == "cells" and all(m._hip is not None for m in models)
+env.use_bf16_observations(cells)       # views as bf16 cells: the MFMA kernels' operands, 2.7 KB per agent instead of 4.7
 t_env = t_pol = 0.0
 agent_steps = 0
 for s in range(steps + 2):
@@ -37,5 +39,5 @@ for s in range(steps + 2):
     t_env += time.perf_counter() - t0
 torch.cuda.synchronize()
 dt = time.perf_counter() - t_all
-print("self-play (%s policy): %.1f ms/step = engine %.2f ms + policy %.1f ms; %.2e agent-steps/s"
-      % (dtype, dt / steps * 1e3, t_env / steps * 1e3, t_pol / steps * 1e3, agent_steps / dt))
+print("self-play (%s policy%s): %.1f ms/step = engine %.2f ms + policy %.1f ms; %.2e agent-steps/s"
+      % (dtype, ", bf16-cell observations" if cells else "", dt / steps * 1e3, t_env / steps * 1e3, t_pol / steps * 1e3, agent_steps / dt))
