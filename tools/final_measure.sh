@@ -10,6 +10,6 @@ python $R/bench.py --no-cpu-baseline --no-extras --workload gather --map-size 50
 python $R/bench.py --map-size 200 --agents 2000 --steps 300 --warmup 20 --no-extras 2>&1 | tail -1 > $O/c2.log
 for a in "1 1" "8 8" "32 8" "128 8"; do python $R/tools/many_envs_batch.py $a 2>&1 | grep -v amdgpu.ids; done > $O/batch.log
 python $R/tools/host_abi_rate.py > $O/host_abi.log 2>&1
-python $R/tools/selfplay_rate.py 400000 6 bf16 > $O/selfplay_bf16.log 2>&1
-python $R/tools/policy_rate.py 131072 20 torch 2>&1 | grep "HIP policy\|torch bf16" > $O/policy_rate.log
-cat $O/gather.log; cut -c1-400 $O/c2.log; cat $O/batch.log; tail -1 $O/host_abi.log; tail -1 $O/selfplay_bf16.log; cat $O/policy_rate.log
+python $R/tools/selfplay_rate.py 400000 6 bf16 > $O/selfplay_bf16.log 2>&1; python $R/tools/selfplay_rate.py 400000 6 bf16 cells > $O/selfplay_cells.log 2>&1
+python $R/tools/policy_rate.py 131072 20 torch 2>&1 | grep "HIP policy\|torch bf16" > $O/policy_rate.log; python $R/tools/policy_rate.py 131072 20 cells 2>&1 | grep "HIP policy" >> $O/policy_rate.log
+cat $O/gather.log; cut -c1-400 $O/c2.log; cat $O/batch.log; tail -1 $O/host_abi.log; tail -1 $O/selfplay_bf16.log; tail -1 $O/selfplay_cells.log; cat $O/policy_rate.log

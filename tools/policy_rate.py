@@ -15,6 +15,10 @@ qnet = _QNet(vs, (F,), A, True, True).to(dev)
 view = (torch.rand((n,) + vs, device=dev) < 0.3).float()
 feat = torch.rand((n, F), device=dev)
 pol = HipDqnPolicy(qnet, vs, (F,), A, dev, chunk=n)
+if "cells" in sys.argv:      # the engine's bf16-cell observation format (env_get_observation_device_bf16)
+    cells = torch.zeros((n,) + vs[:2] + (8,), dtype=torch.bfloat16, device=dev)
+    cells[..., :vs[2]] = view.to(torch.bfloat16); cells[..., 7] = 1
+    view = cells
 for _ in range(3):
     pol.infer(view, feat)
 torch.cuda.synchronize()
@@ -25,7 +29,7 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 flop = n * (2 * 121 * 32 * 63 + 2 * 81 * 32 * 288 + 2 * 2592 * 256 + 2 * F * 256 + 2 * 512 * (A + 1))
 print("HIP policy: %.3f ms for %d agents = %.1f TFLOP/s (useful flops), %.2f us per 1000 agents" % (dt * 1e3, n, flop / dt / 1e12, dt * 1e9 / n))
-if len(sys.argv) > 3:
+if "torch" in sys.argv and "cells" not in sys.argv:
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         for _ in range(2):
             qnet(view[:65536], feat[:65536])
