@@ -78,7 +78,13 @@ def main():
             json.dump(rec, open(os.path.join(out_dir, "render_pmc.json"), "w"), indent=1)
             lines += ["", "k_render: algorithmic bytes per launch = n_g * 4 * VH*VW*C; measured write %.3f GB, fetch %.3f GB" %
                       (rec["write_bytes_per_launch"] / 1e9, rec["fetch_bytes_per_launch"] / 1e9)]
-    open(os.path.join(out_dir, tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
+    target = os.path.join(out_dir, tag + "_summary.md")
+    notes = ""          # hand-written notes behind the generated tables survive a refresh
+    if os.path.exists(target):
+        old = open(target).read()
+        k = old.find("\n## Round")
+        notes = old[k:] if k >= 0 else ""
+    open(target, "w").write("\n".join(lines) + "\n" + notes)
     print("\n".join(lines[:16]))
 
 
