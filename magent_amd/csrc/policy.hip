@@ -1,13 +1,14 @@
 // policy.hip -- the reference's deep Q network (python/magent/builtin/tf_model/dqn.py:151-189), inference only, as two
 // hand-written bf16 MFMA kernels for gfx950.  This is the caller on the far side of the hot path (SURVEY.md 8f rank 1:
 // BASELINE config 5 puts a policy between get_observation and set_action); with the PyTorch / MIOpen network a 2 x 400k
-// self-play step is 42 ms of which the engine is 1.7.
+// self-play step is 42-48 ms of which the engine is 1.5; with these kernels 5.2 (profiles/r02_policy.txt).
 //
-//   network:  view [n][H][W][C] f32 -> conv3x3(32, valid) relu -> conv3x3(32, valid) relu -> flatten (NHWC) -> dense 256 relu
+//   network:  view [n][H][W][C] f32 (or the engine's bf16 cells, env_get_observation_device_bf16) -> conv3x3(32, valid) relu -> conv3x3(32, valid) relu -> flatten (NHWC) -> dense 256 relu
 //             feature [n][F] f32 -> dense 256 relu;  concat 512 -> advantage (n_action, no bias) and value (1);
 //             Q = value + advantage - mean(advantage)
 //   numerics: inputs, weights and the activations between layers are rounded to bf16 (round to nearest even), every product
-//             is accumulated in f32 by v_mfma_f32_32x32x16_bf16, biases are added in f32.  tests/test_policy.py compares with
+//             is accumulated in f32 by v_mfma_f32_32x32x16_bf16, biases are added in f32 (conv1's rides in the MFMA as the
+//             weight of a constant-1 channel: bf16).  tests/test_policy.py compares with
 //             a PyTorch f32 computation that rounds at the same points.
 //
 // k_dqn_conv : conv1 + conv2 fused.  A workgroup takes TA agents at a time: their views go to LDS as bf16 with the channels
@@ -18,8 +19,9 @@
 //   positions across the lanes, i.e. a lane owns 16 channels of ONE position and stores them as two 16-byte vectors.
 //   (Which 16: ch_of() below.  Activations are kept in that "slot" order; the next layer's weights are permuted to match when
 //   they are packed -- magent_amd/builtin/torch_model/hip_policy.py.)
-// k_dqn_head : dense 2592 -> 256 as a GEMM over 64 agents per workgroup (activations through LDS, packed weights straight from
-//   L2 in fragment order), the feature embedding, the dueling head and the argmax, fused.
+// k_dqn_head : dense 2592 -> 256 as a GEMM over 128 agents per workgroup of 8 waves (activations through LDS, packed weights
+//   straight from L2 in fragment order, both streams four K-chunks ahead in registers), the feature embedding, the dueling head
+//   and the argmax, fused.
 //
 // Weight layouts ("fragment order"): for every k-step s (16 values of K) and 32-wide output tile, 64 lanes x 8 bf16 --
 // lane l holds W[out = l & 31][k = 16 s + 8 (l >> 5) + 0..7], exactly the first operand of v_mfma_f32_32x32x16_bf16
