@@ -2,6 +2,8 @@
 
   python tools/fuzz_parity.py ref oracle 0 300      # here: pins the CPU restatement against the compiled reference
   python tools/fuzz_parity.py oracle hip 0 300      # GPU box: the HIP engine against the oracle
+  FUZZ_CYCLE=1 python tools/fuzz_parity.py oracle hip 0 300   # the HIP leg through env_cycle_many (two launches per cycle), the
+                                                              # other leg through the reference call sequence
 """
 import os
 import sys
@@ -25,7 +27,11 @@ for seed in seeds:
     sc = H.fuzz_scenario(seed)
     print("seed", seed, flush=True, file=sys.stderr)
     try:
-        H.assert_same(H.run(sc, LIBS[a]), H.run(sc, LIBS[b]), sc.name)
+        if os.environ.get("FUZZ_CYCLE", "0") == "1":
+            sc.clear_every = 1
+            H.assert_same(H.run_cycle(sc, LIBS[a], fused=(a == "hip")), H.run_cycle(sc, LIBS[b], fused=(b == "hip")), sc.name + " (cycle)")
+        else:
+            H.assert_same(H.run(sc, LIBS[a]), H.run(sc, LIBS[b]), sc.name)
     except AssertionError as e:
         bad.append(seed)
         print("FAIL seed %d: %s" % (seed, str(e)[:300]), flush=True)
