@@ -417,6 +417,57 @@ def run_cycle(sc, lib, fused):
     return out
 
 
+def run_cycle_batch(scs, lib):
+    """run_cycle(fused=True) for SEVERAL environments of one configuration at once: a single magent_amd.EnvBatch, so that for
+    small worlds all of them share one pair of launches per cycle (k_render_batch + k_step_solo_batch).  Returns one trajectory
+    per scenario; an environment whose groups are all empty keeps cycling with the others (its trajectory stops there, as
+    run_cycle's does)."""
+    import torch
+    built = [sc.build(lib) for sc in scs]
+    envs, handles = [b[0] for b in built], [b[1] for b in built]
+    dev = torch.device("cuda", envs[0].device_id)
+    batch = magent_amd.EnvBatch(envs, n_threads=1)
+    rss = [np.random.RandomState(sc.action_seed) for sc in scs]
+    out, live = [[] for _ in scs], [True] * len(scs)
+    for step in range(max(sc.steps for sc in scs)):
+        recs, views, feats, d_acts, rews, observes = [], [], [], [], [], []
+        for k, (sc, env, hs) in enumerate(zip(scs, envs, handles)):
+            assert sc.clear_every == 1
+            acting = sc.acting if sc.acting is not None else list(range(len(hs)))
+            rec = {}
+            sc.apply_events(env, step)
+            nums = [env.get_num(h) for h in hs]
+            acts = [rss[k].randint(env.get_action_space(h)[0], size=nums[g]).astype(np.int32) if g in acting else None for g, h in enumerate(hs)]
+            observe = [step % sc.obs_every == 0 and nums[g] > 0 for g in range(len(hs))]
+            for g, h in enumerate(hs):
+                rec["id%d" % g] = env.get_agent_id(h)
+            views.append([torch.empty((nums[g],) + env.get_view_space(h), device=dev) if observe[g] else None for g, h in enumerate(hs)])
+            feats.append([torch.empty((nums[g],) + env.get_feature_space(h), device=dev) if observe[g] else None for g, h in enumerate(hs)])
+            d_acts.append([torch.from_numpy(a).to(dev) if a is not None else None for a in acts])
+            rews.append([torch.empty(nums[g], device=dev) for g in range(len(hs))])
+            recs.append(rec); observes.append(observe)
+        torch.cuda.synchronize()
+        dones = batch.cycle(views, feats, d_acts, rews)
+        for k, (sc, env, hs) in enumerate(zip(scs, envs, handles)):
+            env.sync()
+            rec = recs[k]
+            for g in range(len(hs)):
+                if observes[k][g]:
+                    rec["view%d" % g], rec["feat%d" % g] = views[k][g].cpu().numpy(), feats[k][g].cpu().numpy()
+                rec["reward%d" % g] = rews[k][g].cpu().numpy()
+            rec["done"] = np.array([dones[k]], dtype=np.int32)
+            for g, h in enumerate(hs):
+                rec["num%d" % g] = np.array([env.get_num(h)], dtype=np.int32)
+                rec["pos%d" % g] = env.get_pos(h)
+                rec["alive%d" % g] = env.get_alive(h).astype(np.uint8)
+                rec["ids_after%d" % g] = env.get_agent_id(h)
+            if live[k] and step < sc.steps:
+                out[k].append(rec)
+                if all(env.get_num(h) == 0 for h in hs) and not any(e > step for e in sc.events):
+                    live[k] = False
+    return out
+
+
 def run_hashed(sc, lib):
     """run(sc, lib) for sizes whose trajectories do not fit in memory: every array of every step is reduced to its
     xxh3-128 (10 GB/s on one core; SHA-256 would cost more than the engines) as soon as the step is over.

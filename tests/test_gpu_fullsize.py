@@ -92,3 +92,12 @@ def test_fuzz_fused_cycle():
     out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "150"], env=env,
                          capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0 and "150 seeds, 0 failures" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
+
+
+def test_fuzz_batched_cycle():
+    """three environments per random game in ONE magent_amd.EnvBatch -- k_render_batch + k_step_solo_batch: one pair of launches for
+    all of them -- each against the oracle driven alone through the reference call sequence"""
+    env = dict(os.environ, OMP_NUM_THREADS="1", FUZZ_BATCH="3", FUZZ_TURN="1")
+    out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "80"], env=env,
+                         capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and "80 seeds, 0 failures" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])

@@ -2,6 +2,7 @@
 
   python tools/fuzz_parity.py ref oracle 0 300      # here: pins the CPU restatement against the compiled reference
   python tools/fuzz_parity.py oracle hip 0 300      # GPU box: the HIP engine against the oracle
+  FUZZ_BATCH=3 python tools/fuzz_parity.py oracle hip 0 300   # three environments per game in one EnvBatch (one launch pair for all)
   FUZZ_CYCLE=1 python tools/fuzz_parity.py oracle hip 0 300   # the HIP leg through env_cycle_many (two launches per cycle), the
                                                               # other leg through the reference call sequence
 """
@@ -27,7 +28,18 @@ for seed in seeds:
     sc = H.fuzz_scenario(seed)
     print("seed", seed, flush=True, file=sys.stderr)
     try:
-        if os.environ.get("FUZZ_CYCLE", "0") == "1":
+        nb = int(os.environ.get("FUZZ_BATCH", "0"))
+        if nb > 1:      # nb environments of this configuration (different engine and action seeds) in ONE EnvBatch on the HIP side
+            import copy
+            scs = []
+            for k in range(nb):
+                c = copy.deepcopy(sc); c.seed, c.action_seed, c.clear_every = sc.seed + 1000 * k, sc.action_seed + k, 1
+                scs.append(c)
+            hip_side = H.run_cycle_batch(scs, H.HIP_LIB)
+            other = b if a == "hip" else a
+            for k, c in enumerate(scs):
+                H.assert_same(H.run_cycle(c, LIBS[other], fused=False), hip_side[k], "%s (batch of %d, env %d)" % (sc.name, nb, k))
+        elif os.environ.get("FUZZ_CYCLE", "0") == "1":
             sc.clear_every = 1
             H.assert_same(H.run_cycle(sc, LIBS[a], fused=(a == "hip")), H.run_cycle(sc, LIBS[b], fused=(b == "hip")), sc.name + " (cycle)")
         else:
