@@ -181,3 +181,35 @@ def test_bf16_cell_observation_and_policy_on_it():
                 env.set_action(hh, np.random.RandomState(step).randint(env.get_action_space(hh)[0], size=env.get_num(hh)).astype(np.int32))
             env.step(); env.clear_dead()
         env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["battle_turn", "arrange", "tri_rect", "battle_food", "sector_turn", "pursuit"])
+def test_bf16_cells_on_other_games(name):
+    """the bf16-cell render in its other instantiations -- turn_mode windows, unpacked view cells (goals), three groups, food
+    channel, multi-cell bodies: cells == the float32 observation rounded to nearest even, wherever the game has <= 7 channels"""
+    import torch
+    import helpers as H
+    sc = H.scenarios()[name]
+    env, hs = sc.build(H.HIP_LIB)
+    rs = np.random.RandomState(1)
+    checked = 0
+    channels = [env.get_view_space(h)[2] for h in hs]
+    for step in range(3):
+        for h in hs:
+            if env.get_num(h) == 0 or env.get_view_space(h)[2] > 7:
+                continue
+            view32, feat = env.get_observation_device(h)
+            view16, feat16 = env.get_observation_device_bf16(h)
+            env.sync()
+            c = view32.shape[-1]
+            assert torch.equal(view16[..., :c].view(torch.int16), view32.to(torch.bfloat16).view(torch.int16)), (name, step)
+            assert bool((view16[..., c:7].float() == 0).all()) and bool((view16[..., 7].float() == 1).all()) and torch.equal(feat16, feat)
+            checked += 1
+        acting = sc.acting if sc.acting is not None else list(range(len(hs)))
+        for g, h in enumerate(hs):
+            if g in acting:
+                env.set_action(h, rs.randint(env.get_action_space(h)[0], size=env.get_num(h)).astype(np.int32))
+        env.step(); env.clear_dead()
+    env.close()
+    assert checked > 0 or all(c > 7 for c in channels), name      # (battle_food: 8 channels, refused by the bf16-cell format)
