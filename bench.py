@@ -190,7 +190,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--map-size", type=int, default=MAP_SIZE)
     ap.add_argument("--agents", type=int, default=N_PER_GROUP, help="agents per group")
     ap.add_argument("--workload", choices=["battle", "battle_fill", "test_1m", "gather"], default="battle",
