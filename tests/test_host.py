@@ -197,3 +197,21 @@ def test_no_kernel_keeps_the_world_in_scratch(hip_lib):
         assert sc <= 16, (n, sc)
     render = [v for n, v in zip(names, vgprs) if "k_renderILb1ELb1ELi1ELb1ELb0" in n]
     assert render and max(render) <= 96, render      # 5 waves per SIMD (the measured sweet spot of the store-bound kernel)
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r02_bench_line.json is the line `python bench.py` printed at the end of the round: the driver's contract fields, the
+    roofline object of the dominant kernel and the CPU baseline timed beside it"""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_line.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "agent-steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2          # PMC bytes vs algorithmic bytes of the same launch
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"]
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / sum(d["config"]["agents_at_start"]) - 1) < 0.25    # value ~ agents / step time
