@@ -70,7 +70,7 @@ def cpu_baseline_worker(args):
     print(json.dumps({"agent_steps": agent_steps, "seconds": elapsed}))
 
 
-def run_cpu_baseline(map_size=MAP_SIZE, agents=N_PER_GROUP, steps=2):
+def run_cpu_baseline(map_size=MAP_SIZE, agents=N_PER_GROUP, steps=4):
     ref = os.path.join(ROOT, "oracle", "_ref", "libmagent_ref.so")
     port = os.path.join(ROOT, "oracle", "liboracle.so")
     if os.path.exists(ref):
@@ -81,7 +81,8 @@ def run_cpu_baseline(map_size=MAP_SIZE, agents=N_PER_GROUP, steps=2):
         return None
     ncpu = os.cpu_count() or 1
     best = None
-    threads = [1] if kind == "port" else sorted({1, max(1, ncpu // 2)})
+    # best of OMP_NUM_THREADS in {1, nproc//2 (the reference's default, c_lib.py:41), nproc}
+    threads = [1] if kind == "port" else sorted({1, max(1, ncpu // 2), ncpu})
     for th in threads:
         env = dict(os.environ, OMP_NUM_THREADS=str(th), MAGENT_AMD_NO_TORCH="1")
         try:
@@ -186,6 +187,57 @@ def selfplay_extra(torch, magent_amd, n=400000, steps=4):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: re-run this command line as N ranks, one per GPU, the way the driver's
+    own launcher would (torch.distributed.run, rendezvous on 127.0.0.1); rank 0's JSON line passes through on stdout"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def host_abi_extra(magent_amd, n=N_PER_GROUP, steps=3, warm=2):
+    """SURVEY.md 8d "report both kernel and API-level rates": the same cycle through the REFERENCE ABI -- env_get_observation
+    into caller-owned numpy buffers, host action arrays, host reward buffers (3.9 GB device -> host per step, PCIe included).
+    Never the headline value."""
+    import numpy as np
+    env = magent_amd.GridWorld("battle", map_size=MAP_SIZE)
+    env.set_seed(12345); env.reset()
+    hs = env.get_handles()
+    for h in hs:
+        env.add_agents(h, "random", n=n)
+    rs = np.random.RandomState(0)
+    tot = t_obs = 0.0
+    agent_steps = obs_bytes = 0
+    for step in range(steps + warm):
+        acts = [rs.randint(21, size=env.get_num(h)).astype(np.int32) for h in hs]
+        nn = sum(env.get_num(h) for h in hs)
+        t0 = time.perf_counter()
+        for h, a in zip(hs, acts):
+            t1 = time.perf_counter()
+            view, feat = env.get_observation(h)
+            if step >= warm:
+                t_obs += time.perf_counter() - t1
+                obs_bytes += view.nbytes + feat.nbytes
+            env.set_action(h, a)
+        env.step()
+        for h in hs:
+            env.get_reward(h)
+        env.clear_dead()
+        if step >= warm:
+            tot += time.perf_counter() - t0
+            agent_steps += nn
+    env.close()
+    return {"agent_steps_per_s": agent_steps / tot, "ms_per_step": tot / steps * 1e3, "get_observation_GBps_to_numpy": obs_bytes / t_obs / 1e9,
+            "agents": [n, n], "io": "host buffers (reference ABI: env_get_observation / env_set_action / env_get_reward), PCIe included"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,10 +261,15 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (capacity fill, test_1m, small worlds)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-lib", default="")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--check-gather", action="store_true",
+                    help="with --gather: after the timed region every rank digests its own rendered rows and the shards it received; "
+                         "rank 0 prints which shards were bit-identical to the peer's own tensor (config.gather_detail.verified)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -222,6 +279,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    assert args.gpus in (1, world), "--gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world)
     if args.backend == "gloo":
         local_rank %= torch.cuda.device_count()   # dry run: ranks may share a GPU
     torch.cuda.set_device(local_rank)
@@ -275,7 +333,10 @@ def main():
         feat_bytes = [4 * f[0] for f in fss]                 # per agent: the feature rows (they ride in the render launch)
 
         # caller-owned device buffers (the reference's ownership convention), sized once for the initial population
-        views = [torch.empty((n0[g],) + vss[g], dtype=torch.float32, device=dev) for g in range(G)]
+        # with the gather on, two view tensors per group used alternately: the render of step t+1 then only waits for the
+        # exchange of step t-1 (the one that read the tensor it overwrites), not for the exchange of step t
+        n_buf = 2 if (gather != "none" and world > 1) else 1
+        views = [[torch.empty((n0[g],) + vss[g], dtype=torch.float32, device=dev) for _ in range(n_buf)] for g in range(G)]
         feats = [torch.empty((n0[g],) + fss[g], dtype=torch.float32, device=dev) for g in range(G)]
         rewards = [torch.empty(n0[g], dtype=torch.float32, device=dev) for g in range(G)]
         total_steps = steps + warmup
@@ -288,6 +349,9 @@ def main():
             gdev = dev if args.backend == "nccl" else torch.device("cpu")
             gathers = [replicas.ObservationGather(vss[g], capacity=n0[g], device=gdev, mode="padded" if gather == "obs-padded" else "exact")
                        if g in acting else None for g in range(G)]
+        staged = [torch.empty((n0[g],) + vss[g], dtype=torch.float32).pin_memory() if gathers and args.backend != "nccl" and g in acting else None
+                  for g in range(G)]
+        last_sent = {}
         torch.cuda.synchronize()
         rendered = {"view": 0, "feat": 0, "launches": 0}
         step_ends = []
@@ -302,15 +366,19 @@ def main():
                 rendered["view"] += n * view_bytes[g]
                 rendered["feat"] += n * feat_bytes[g]
                 rendered["launches"] += 1
-                if gathers:                      # the previous exchange still reads the tensor the render is about to overwrite
-                    gathers[g].wait(env.stream if args.backend == "nccl" else None)
-                env.get_observation_device(h, views[g], feats[g])
+                view = views[g][s % n_buf]
+                if gathers and args.backend == "nccl":   # the exchange of step t-1 may still read the tensor this render overwrites
+                    gathers[g].release(view, env.stream)
+                env.get_observation_device(h, view, feats[g])
                 env.set_action_device(h, actions[s % n_sets][g])
                 if gathers:                      # counts now (behind the render, on the side stream); the rows follow below
-                    src = views[g] if args.backend == "nccl" else views[g][:n].cpu()
-                    if args.backend != "nccl":
+                    if args.backend == "nccl":
+                        gathers[g].launch(view, n, producer_stream=env.stream)
+                    else:                        # gloo dry run: the rows are staged through host memory
                         env.sync()
-                    gathers[g].launch(src, n, producer_stream=env.stream if args.backend == "nccl" else None)
+                        staged[g][:n].copy_(view[:n])
+                        gathers[g].launch(staged[g], n)
+                    last_sent[g] = (view, n)
             if gathers:                          # the rows travel on the side stream while the step kernels run on the engine's
                 for g in acting:
                     gathers[g].post()
@@ -354,7 +422,7 @@ def main():
         median_ms = per_step[len(per_step) // 2] * 1e3 if per_step else None
 
         res = {"elapsed": elapsed, "agent_steps": agent_steps, "median_ms": median_ms, "n0": n0, "agents_at_end": [env.get_num(h) for h in handles],
-               "host_finished_steps": env.engine_stats()[0], "roofline": None, "breakdown": {}, "map_size": map_size}
+               "host_finished_steps": env.engine_stats()[0], "cycles_run": total_steps, "roofline": None, "breakdown": {}, "map_size": map_size}
         if profile:
             n_launch, ms = env.profile_read("render")
             n_feat, ms_feat = env.profile_read("features")
@@ -375,7 +443,7 @@ def main():
                     except Exception:
                         traffic = None
                 res["roofline"] = {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                                   "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_scaled_from_profiles_not_this_run": traffic_note,
                                    "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
                                    "algorithmic_bytes_per_launch": int(obs_bytes / n_launch)}
             # phase breakdown: a few more steps of the same episode, OUTSIDE the timed region, with an event pair around every phase
@@ -394,7 +462,31 @@ def main():
                 res["breakdown"]["render_ms_per_step"] = round(ms / steps, 4)
             env.profile_enable(False)
         if gathers:
-            res["gather"] = {"mode": gathers[acting[0]].mode, "payload_bytes_sent_per_step": sum(gathers[g].bytes_sent for g in acting)}
+            res["gather"] = {"mode": gathers[acting[0]].mode, "payload_bytes_sent_per_step": sum(gathers[g].bytes_sent for g in acting),
+                             "view_buffers": n_buf}
+            if args.check_gather:
+                # every rank digests the rows it rendered in the last exchanged step and the shards it received; the lists meet on
+                # every rank: shard r as received anywhere must be the bytes rank r rendered (HIP engine output, bit for bit)
+                import hashlib
+
+                def dig(t):
+                    return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+                mine = {}
+                for g in acting:
+                    shards = gathers[g].wait()
+                    torch.cuda.synchronize()
+                    view, n = last_sent[g]
+                    mine[g] = {"own": dig(view[:n]), "n": n, "got": [dig(t) for t in shards], "got_n": [int(t.shape[0]) for t in shards]}
+                everyone = [None] * world
+                dist.all_gather_object(everyone, mine)
+                ok, pairs = True, 0
+                for g in acting:
+                    for r in range(world):
+                        for q in range(world):
+                            pairs += 1
+                            ok = ok and everyone[q][g]["got"][r] == everyone[r][g]["own"] and everyone[q][g]["got_n"][r] == everyone[r][g]["n"]
+                distinct = len({everyone[r][acting[0]]["own"] for r in range(world)})
+                res["gather"]["verified"] = {"all_shards_bit_identical": bool(ok), "pairs_checked": pairs, "distinct_replicas": distinct}
         del env
         return res
 
@@ -427,8 +519,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOAD if is_default else names[args.workload],
                        "envs": world, "parallelism": "replicas x%d" % world, "gather": args.gather,
+                       "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": (args.backend if world > 1 else None),
                        "agents_at_start": R["n0"], "agents_at_end": R["agents_at_end"],
-                       "io": "device-resident (env_*_device C-ABI)", "steps_finished_by_host_driver": R["host_finished_steps"]},
+                       "io": "device-resident (env_*_device C-ABI)", "steps_finished_by_host_driver": R["host_finished_steps"],
+                       "host_driver_rate": R["host_finished_steps"] / float(R["cycles_run"])},
             "roofline": R["roofline"],
             "breakdown": R["breakdown"],
         }
@@ -436,7 +530,7 @@ def main():
             rec["config"]["gather_detail"] = R["gather"]
         if world == 1 and not args.no_cpu_baseline:
             small = args.map_size * args.map_size <= 250000
-            rec["cpu_baseline"] = run_cpu_baseline(args.map_size, args.agents, steps=200 if small else 2) \
+            rec["cpu_baseline"] = run_cpu_baseline(args.map_size, args.agents, steps=200 if small else 4) \
                 if args.workload == "battle" else None
         else:
             rec["cpu_baseline"] = None
@@ -450,6 +544,7 @@ def main():
                 extra["test_1m_2x500k"] = {"agent_steps_per_s": T["agent_steps"] / T["elapsed"], "ms_per_step": T["elapsed"] / 10 * 1e3, "agents": T["n0"], "map": T["map_size"]}
                 extra["battle_200_2x2000"] = small_world_extras(torch, magent_amd, dev)
                 extra["battle_selfplay_2x400k"] = selfplay_extra(torch, magent_amd)
+                extra["host_abi_2x400k"] = host_abi_extra(magent_amd)
             except Exception as e:     # secondary lines never fail the bench
                 extra["error"] = repr(e)
             rec["extra"] = extra

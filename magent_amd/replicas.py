@@ -67,6 +67,7 @@ class ObservationGather(object):
         else:
             self.stream = None
         self._posted, self._view, self._n = True, None, 0
+        self._busy = {}            # send tensor (data_ptr) -> event recorded behind the last exchange that read it
 
     # -- step 1: the counts (and, for GPUs, the hand-over from the producer's stream)
     def launch(self, view, n, producer_stream=None):
@@ -122,9 +123,11 @@ class ObservationGather(object):
                 if n > 0:
                     ops.append(dist.P2POp(dist.isend, view[:n], peer, group=self.group))
             if ops:
+                # Work.wait() on a ProcessGroupNCCL work is a STREAM-side wait: it makes the current stream (the side stream
+                # here) depend on the communicator's internal stream and does not block the host.  Without it the event
+                # recorded below would not cover the transfers.  On gloo it blocks until the rows are in.
                 for req in dist.batch_isend_irecv(ops):
-                    if self.stream is None:
-                        req.wait()
+                    req.wait()
             self.bytes_sent = n * self.row_bytes * (self.world - 1)
             self.bytes_received = (sum(self.counts) - n) * self.row_bytes
 
@@ -132,8 +135,23 @@ class ObservationGather(object):
             with torch.cuda.stream(self.stream):
                 exchange()
                 self._done.record(self.stream)
+                ev = self._busy.get(view.data_ptr())
+                if ev is None:
+                    ev = self._busy[view.data_ptr()] = torch.cuda.Event()
+                ev.record(self.stream)
         else:
             exchange()
+
+    def release(self, view, producer_stream=None):
+        """orders `producer_stream` after the last exchange that READ `view`, so that it may be overwritten.  With two send
+        tensors used alternately the render of step t+1 does not wait for the exchange of step t, only for that of t-1."""
+        if self.stream is None or self.world == 1:
+            return
+        if not self._posted and self._view is not None and self._view.data_ptr() == view.data_ptr():
+            self.post()
+        ev = self._busy.get(view.data_ptr())
+        if ev is not None:
+            (producer_stream or torch.cuda.current_stream(self.device)).wait_event(ev)
 
     def wait(self, consumer_stream=None):
         """orders `consumer_stream` (default: the current CUDA stream) after the exchange; returns the shards"""

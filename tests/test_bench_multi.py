@@ -1,0 +1,65 @@
+"""`bench.py --gpus N` the way the driver starts it: no launcher around it, WORLD_SIZE unset.
+
+bench.py re-runs itself as N ranks under torch.distributed.run (spawn_ranks).  On the single-GPU test box the two ranks
+share the GPU, so the process group is gloo (RCCL refuses two ranks on one device) and the observation rows are staged
+through host memory; everything else is the N > 1 path of the real run: one HIP engine replica per rank (seed 12345 +
+rank), the counts-then-rows exchange of magent_amd.replicas.ObservationGather with two view tensors used alternately,
+max-over-ranks timing, whole-job aggregation.  --check-gather digests, on every rank, the rows it rendered and the
+shards it received: shard r anywhere must be the bytes rank r's engine rendered."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gpus_flag_spawns_ranks(monkeypatch):
+    """CPU: --gpus N without a launcher builds the driver's own command line (torch.distributed.run, 127.0.0.1)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.main() == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_gpu_and_exchange_their_observations():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--gather", "obs",
+                        "--check-gather", "--steps", "3", "--warmup", "1", "--map-size", "200", "--agents", "6000",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["rccl_ranks"] == 2 and rec["config"]["envs"] == 2
+    g = rec["config"]["gather_detail"]
+    assert g["payload_bytes_sent_per_step"] > 0 and g["view_buffers"] == 2
+    v = g["verified"]
+    assert v["all_shards_bit_identical"] is True and v["pairs_checked"] == 8 and v["distinct_replicas"] == 2
+    assert rec["value"] > 0 and rec["roofline"]["achieved"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_rccl_when_two_gpus():
+    """the same through RCCL (device tensors, side stream, stream-ordered waits) where the box has two GPUs"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: RCCL needs a device per rank")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gather", "obs", "--check-gather",
+                        "--steps", "5", "--warmup", "2", "--map-size", "400", "--agents", "50000", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["rccl_ranks"] == 2 and rec["config"]["backend"] == "nccl"
+    assert rec["config"]["gather_detail"]["verified"]["all_shards_bit_identical"] is True
