@@ -7,6 +7,7 @@ All are driven through the same magent_amd.GridWorld wrapper with the same seeds
 import hashlib
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -18,6 +19,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libmagent_ref.so")
 HIP_LIB = os.path.join(ROOT, "magent_amd", "lib", "libmagent.so")
+EMU_LIB = os.path.join(ROOT, "tests", "hipemu", "_build", "libmagent_emu.so")
+
+
+def ensure_emu():
+    """the engine's HIP sources compiled as plain C++ against tests/hipemu (kernels run lane by lane on the CPU): a checker of
+    the kernels' logic for the GPU-less build container, never the product"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    import build as emu_build
+    return emu_build.build()
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 

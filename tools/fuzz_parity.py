@@ -18,6 +18,9 @@ if "hip" in sys.argv[1:3]:
 import helpers as H  # noqa: E402
 
 LIBS = {"ref": H.REF_LIB, "oracle": H.ensure_oracle(), "hip": H.HIP_LIB}
+if "emu" in sys.argv[1:3]:     # the HIP sources run lane by lane on the CPU (tests/hipemu): takes the place of "hip" in a GPU-less container
+    LIBS["hip"] = H.HIP_LIB = H.ensure_emu()
+    sys.argv[1:3] = ["hip" if v == "emu" else v for v in sys.argv[1:3]]
 a, b = sys.argv[1], sys.argv[2]
 if "," in sys.argv[3]:       # an explicit list of seeds:  fuzz_parity.py hip oracle 21841,21943
     seeds = [int(x) for x in sys.argv[3].split(",") if x]
