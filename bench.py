@@ -124,6 +124,7 @@ def small_world_extras(torch, magent_amd, dev, steps=200, warmup=20):
         acts = [[[torch.randint(21, (N,), dtype=torch.int32, device=dev, generator=gen) for _ in range(2)] for _ in envs] for _ in range(4)]
         torch.cuda.synchronize()
         batch = magent_amd.EnvBatch(envs, n_threads=8)
+        batch.order_streams = False          # (this loop orders by env.sync(); no torch work touches the buffers in between)
         if batched:      # fixed buffers: the device-pointer arrays are built once, not 8 x K data_ptr() calls per cycle
             views_p, feats_p, rews_p = batch.pointers(views), batch.pointers(feats), batch.pointers(rews)
             acts_p = [batch.pointers(a) for a in acts]
@@ -236,6 +237,80 @@ def host_abi_extra(magent_amd, n=N_PER_GROUP, steps=3, warm=2):
     env.close()
     return {"agent_steps_per_s": agent_steps / tot, "ms_per_step": tot / steps * 1e3, "get_observation_GBps_to_numpy": obs_bytes / t_obs / 1e9,
             "agents": [n, n], "io": "host buffers (reference ABI: env_get_observation / env_set_action / env_get_reward), PCIe included"}
+
+
+def train_round_extra(torch, magent_amd, map_size=1000, steps=12, on_step=None, train=True):
+    """BASELINE config 5's loop on one GPU: examples/train_battle.py:61-140 (`play_a_round`) at --map_size 1000 -- its
+    generate_map puts (int(sqrt(0.04 M^2)))^2 = 40,000 agents on each side -- with the observations staying in HBM
+    (device_obs): observe -> infer_action (e-greedy, DQN) -> set_action per side; step; get_reward / get_alive -> sample_step;
+    clear_dead; after `steps` steps one train() per model (replay sampling, double-DQN targets, Adam).  Times the three parts
+    with the device synchronised around them.  on_step(step, env, handles, obs, acts, rewards, alives) lets a test check the
+    engine's outputs against its checker."""
+    import math
+    from magent_amd.builtin.torch_model import DeepQNetwork
+    from magent_amd.model import ProcessingModel
+    env = magent_amd.GridWorld("battle", map_size=map_size, device_obs=True)
+    env.set_seed(12345); env.reset()
+    handles = env.get_handles()
+    side = int(math.sqrt(map_size * map_size * 0.04)) * 2          # train_battle.py:18-40, gap 3, every other cell
+    for k, h in enumerate(handles):
+        x0 = map_size // 2 - 3 - side if k == 0 else map_size // 2 + 3
+        pos = [[x, y, 0] for x in range(x0, x0 + side, 2) for y in range((map_size - side) // 2, (map_size - side) // 2 + side, 2)]
+        env.add_agents(h, method="custom", pos=pos)
+    n0 = [env.get_num(h) for h in handles]
+    models = [ProcessingModel(env, h, "c5_%d" % i, 20000 + i, 1000, DeepQNetwork, batch_size=512, memory_size=2 ** 17,
+                              target_update=1000, train_freq=4) for i, h in enumerate(handles)]
+
+    def synced():
+        torch.cuda.synchronize(); env.sync()
+        return time.perf_counter()
+    t_env = t_infer = t_sample = 0.0
+    agent_steps = 0
+    for step in range(steps):
+        obs, acts = [None] * len(handles), [None] * len(handles)
+        for i, h in enumerate(handles):
+            t0 = synced()
+            obs[i] = env.get_observation(h)
+            ids = env.get_agent_id(h)
+            t1 = synced()
+            models[i].infer_action(obs[i], ids, "e_greedy", 0.5, block=False)
+            t2 = synced()
+            t_env += t1 - t0; t_infer += t2 - t1
+        t0 = synced()
+        for i, h in enumerate(handles):
+            acts[i] = models[i].fetch_action()
+            env.set_action(h, acts[i])
+            agent_steps += env.get_num(h)
+        env.step()
+        rewards = [env.get_reward(h) for h in handles]
+        alives = [env.get_alive(h) for h in handles]
+        t1 = synced()
+        if train:
+            for i in range(len(handles)):
+                models[i].sample_step(rewards[i], alives[i], block=False)
+        t2 = synced()
+        if on_step is not None:
+            on_step(step, env, handles, obs, acts, rewards, alives)
+        t3 = synced()
+        env.clear_dead()
+        t4 = synced()
+        t_env += (t1 - t0) + (t4 - t3); t_sample += t2 - t1
+    out = {"map_size": map_size, "agents": n0, "steps": steps, "env_ms_per_step": t_env / steps * 1e3, "infer_ms_per_step": t_infer / steps * 1e3,
+           "sample_ms_per_step": t_sample / steps * 1e3,
+           "agent_steps_per_s_sampling": agent_steps / (t_env + t_infer + t_sample),
+           "policy": "DQN (2 x conv3x3(32) -> dense 256 || dense 256 -> dueling head), MFMA inference kernels: %s" % all(m.model._hip is not None for m in models)}
+    if train:
+        t0 = synced()
+        res = []
+        for m in models:
+            m.train(print_every=10 ** 9, block=False)
+        for m in models:
+            res.append(m.fetch_train())
+        out["train_ms_per_round"] = (synced() - t0) * 1e3
+        out["loss"] = [float(r[0]) for r in res]
+        out["value"] = [float(r[1]) for r in res]
+    env.close()
+    return out
 
 
 def main():
@@ -545,6 +620,7 @@ def main():
                 extra["battle_200_2x2000"] = small_world_extras(torch, magent_amd, dev)
                 extra["battle_selfplay_2x400k"] = selfplay_extra(torch, magent_amd)
                 extra["host_abi_2x400k"] = host_abi_extra(magent_amd)
+                extra["c5_train_round_2x40k"] = train_round_extra(torch, magent_amd)
             except Exception as e:     # secondary lines never fail the bench
                 extra["error"] = repr(e)
             rec["extra"] = extra

@@ -127,6 +127,10 @@ class DeepQNetwork(BaseModel):
                 rnd = torch.randint(self.num_actions, best.shape, dtype=torch.int32, device=self.device)
                 best = torch.where(torch.rand(best.shape, device=self.device) < eps, rnd, best)
             return best
+        if isinstance(view, torch.Tensor) and view.dtype == torch.bfloat16:
+            # bf16 cells [n, H, W, 8] are the MFMA kernels' operand format (channels, zeros, a constant 1); without those kernels
+            # (MAGENT_HIP_POLICY=0, an unsupported shape) the PyTorch network takes the channels back as float32
+            view = view[..., :self.view_space[-1]].float()
         out = torch.empty(n, dtype=torch.int32, device=self.device)
         step = max(1, min(n, self.infer_batch_size))
         for beg in range(0, n, step):

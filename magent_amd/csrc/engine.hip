@@ -334,6 +334,7 @@ void Env::mark_state() {
     marked_epoch = state_epoch;
 }
 hipStream_t Env::side_stream() {
+    use_device();
     if (!side) {
         HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&ev_state, hipEventDisableTiming));
@@ -1712,9 +1713,10 @@ void Env::step_end(int *done) {
 //   cycle_prepare : eligibility, stale paint / minimap brought up to date, the launch descriptions of this environment
 //   (the launches : Env::cycle for one environment, launch_cycle_batch for many)
 //   cycle_finish  : the step record, the host mirror of what clear_dead did on the device
-bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, BatchItem &item) {
+// can this environment's cycle run as the two-launch form (k_render_multi + k_step_solo)?  No device work: the batch asks
+// before it decides whose stream an environment uses
+bool Env::cycle_eligible(int n_group, float *const *view, float *const *feat, int *first_obs_out) {
     if (!device_ready) fatal("cycle called before reset");
-    enter();
     const int NG = (int)groups.size();
     if (n_group != NG) fatal("env_cycle_many: n_group (%d) differs from the number of groups (%d)", n_group, NG);
     int total_n = 0;
@@ -1732,7 +1734,17 @@ bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, con
         n_obs++;
     }
     if (n_obs > RENDER_MULTI_MAX) fused = false;
-    if (!fused) return false;
+    if (first_obs_out) *first_obs_out = first_obs;
+    return fused;
+}
+
+bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, BatchItem &item) {
+    int first_obs = -1;
+    if (!cycle_eligible(n_group, view, feat, &first_obs)) return false;
+    enter();
+    const int NG = (int)groups.size();
+    int total_n = 0;
+    for (auto &g : groups) total_n += g.n;
     WorldView &W = item.W;
     W = this->view();
     // ---- launch 1: the observations of every observed group
@@ -1849,11 +1861,30 @@ void Env::cycle(int n_group, float *const *view, float *const *feat, const int *
 
 // many small environments, one pair of launches: every environment that can take the two-launch cycle is described in an
 // item of a device array (one workgroup of k_step_solo_batch each); the others go one by one
-void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **feat, const int **actions, float **rewards, int *done) {
-    Env &lead = *envs[0];
+// (others: called once the batch's launches are enqueued, with the list of environments that did NOT take the two-launch form --
+// too large for the one-launch step, food_mode, rules on the host; they keep their own streams and the caller runs their
+// ordinary cycles, on its host threads, while the batch is in flight)
+void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **feat, const int **actions, float **rewards, int *done,
+                     const std::function<void(const std::vector<int> &)> &others) {
+    // the batch shares the stream of its first eligible environment: launches need no cross-stream events.  Environments that
+    // cannot join are not touched (they used to adopt the stream too and then ran one after the other)
+    std::vector<char> eligible(n_env, 0);
+    int lead_e = -1;
+    for (int e = 0; e < n_env; e++) {
+        const int o = e * n_group;
+        eligible[e] = envs[e]->cycle_eligible(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, nullptr);
+        if (eligible[e] && lead_e < 0) lead_e = e;
+    }
+    std::vector<int> alone;
+    if (lead_e < 0) {
+        for (int e = 0; e < n_env; e++) alone.push_back(e);
+        others(alone);
+        return;
+    }
+    Env &lead = *envs[lead_e];
     lead.use_device();
     const auto t0 = std::chrono::steady_clock::now();
-    for (int e = 1; e < n_env; e++) envs[e]->adopt_stream(lead);   // one stream for the batch: launches need no cross-stream events
+    for (int e = 0; e < n_env; e++) if (eligible[e] && e != lead_e) envs[e]->adopt_stream(lead);
     if ((size_t)n_env > lead.batch_cap) {
         HIP_OK(hipStreamSynchronize(lead.stream));
         if (lead.batch_h) HIP_OK(hipHostFree(lead.batch_h));
@@ -1870,7 +1901,7 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         const int o = e * n_group;
         envs[e]->batch_width = n_env;
         BatchItem &it = lead.batch_h[e];
-        in_batch[e] = envs[e]->device_id == lead.device_id &&
+        in_batch[e] = eligible[e] && envs[e]->device_id == lead.device_id &&
                       envs[e]->cycle_prepare(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
                                              rewards ? rewards + o : nullptr, it);
         if (!in_batch[e]) { it.M.n = 0; it.S.rec = nullptr; }
@@ -1892,12 +1923,8 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         launch_cycle_batch(lead.stream, lead.batch_d, n_env, slots, max_blocks, render_lds, step_lds);
         HIP_OK(hipGetLastError());
     }
-    for (int e = 0; e < n_env; e++) {
-        if (in_batch[e]) continue;
-        const int o = e * n_group;
-        envs[e]->cycle(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
-                       rewards ? rewards + o : nullptr, &done[e]);
-    }
+    for (int e = 0; e < n_env; e++) if (!in_batch[e]) alone.push_back(e);
+    if (!alone.empty()) others(alone);
     const auto t2 = std::chrono::steady_clock::now();
     auto t3 = t2;
     bool first = true;

@@ -128,7 +128,8 @@ public:
     void cycle(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, int *done);
     // ... and for many small environments in ONE pair of launches (one workgroup of k_step_solo_batch per environment)
     int group_count(int g) const { return g >= 0 && g < (int)groups.size() ? groups[g].n : 0; }
-    static void cycle_many(Env **envs, int n_env, int n_group, float **view, float **feat, const int **actions, float **rewards, int *done);
+    static void cycle_many(Env **envs, int n_env, int n_group, float **view, float **feat, const int **actions, float **rewards, int *done,
+                           const std::function<void(const std::vector<int> &)> &others);
     void sync();
     void profile_read(const char *name, int *n, float *ms);
 
@@ -195,6 +196,7 @@ private:
     void enqueue_counters();
     bool step_pending = false, step_was_fast = false, step_was_solo = false, step_live_paint = false, live_paint_now = false;
     bool solo_ok(int total_n);
+    bool cycle_eligible(int n_group, float *const *view, float *const *feat, int *first_obs_out);
     bool cycle_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, BatchItem &item);
     void cycle_finish(int *done);
     void adopt_stream(Env &lead);

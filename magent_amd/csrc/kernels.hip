@@ -2254,7 +2254,11 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
     }
     SOLO_MARK();       // (cycle) rewards, clear_dead, minimap
 
-    // ---- the step's report, straight into pinned host memory; per-step counters back to zero
+    // ---- the step's report, straight into pinned host memory; per-step counters back to zero.
+    // Every wave's device-memory writes (rewards, compacted arrays, tables, minimap) are released and the workgroup has met
+    // before wave 0 publishes the sequence number: a host that has seen it may enqueue readers of those outputs
+    __threadfence();
+    __syncthreads();
     if (tid < 64) {
         const bool trig = tid < CTR_TRIGGER_END - CTR_TRIGGER && __hip_atomic_load(&W.counters[CTR_TRIGGER + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         const unsigned long long mask = __ballot(trig);

@@ -458,7 +458,13 @@ static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const v
     }
     if (TA < 1) return 1;
     const int T2 = (TA * H2 * W2 + 31) / 32, c2i = (T2 + 7) / 8;
-    static bool lds_ok = false;
+    // the stream's device is made current (launches and function attributes are per device), and the dynamic-LDS allowance is
+    // granted once per DEVICE, not once per process
+    int dev = 0;
+    if (st) { if (hipStreamGetDevice(st, &dev) != hipSuccess || hipSetDevice(dev) != hipSuccess) return 2; }
+    else if (hipGetDevice(&dev) != hipSuccess) return 2;
+    static bool lds_ok_dev[64] = {};
+    bool &lds_ok = lds_ok_dev[dev & 63];
     if (!lds_ok) {
         const void *convs[8] = {reinterpret_cast<const void *>(k_dqn_conv<1, false>), reinterpret_cast<const void *>(k_dqn_conv<2, false>),
                                 reinterpret_cast<const void *>(k_dqn_conv<3, false>), reinterpret_cast<const void *>(k_dqn_conv<4, false>),

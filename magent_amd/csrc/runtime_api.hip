@@ -140,7 +140,11 @@ int env_cycle_many(EnvHandle *games, int n_env, int n_group, float **view, float
     if (n_env >= 2 && batch) {
         std::vector<Env *> envs(n_env);
         for (int e = 0; e < n_env; e++) envs[e] = E(games[e]);
-        Env::cycle_many(envs.data(), n_env, n_group, view, feat, actions, rewards, done);
+        Env::cycle_many(envs.data(), n_env, n_group, view, feat, actions, rewards, done, [&](const std::vector<int> &alone) {
+            // environments outside the batch: ordinary cycles on their own streams, spread over the host threads
+            if (n_threads <= 1 || alone.size() <= 1) { for (int e : alone) one(e); return; }
+            cycle_pool().run(n_threads < (int)alone.size() ? n_threads : (int)alone.size(), (int)alone.size(), [&](int k) { one(alone[k]); });
+        });
         return 0;
     }
     if (n_threads <= 1 || n_env <= 1) { for (int e = 0; e < n_env; e++) one(e); return 0; }

@@ -215,6 +215,8 @@ class GridWorld(object):
 
     def use_bf16_observations(self, on=True):
         """device_obs mode: get_observation hands out the views as bf16 cells of 8 channels (get_observation_device_bf16)"""
+        if on and max(v[2] for v in self.view_space.values()) > 7:
+            raise ValueError("bf16-cell observations hold at most 7 channels; this game has %d" % max(v[2] for v in self.view_space.values()))
         if bool(on) != self._obs_bf16:
             self._obs_bf16, self._dev_cache = bool(on), ({}, {})
 
@@ -377,7 +379,9 @@ class GridWorld(object):
         g = _gid(handle)
         n = self.get_num(g)
         dev = torch.device("cuda", self.device_id)
-        h, w, _ = self.view_space[g]
+        h, w, c = self.view_space[g]
+        if c > 7:     # (the engine would abort the process: 8 bf16 per cell = 7 channels + the constant-1 bias channel)
+            raise ValueError("bf16-cell observations hold at most 7 channels; this game has %d (use get_observation_device)" % c)
         if view is None:
             view = torch.empty((n, h, w, 8), dtype=torch.bfloat16, device=dev)
         if feature is None:
@@ -635,6 +639,8 @@ class EnvBatch(object):
         self._handles = (ctypes.c_void_p * n)(*[e.game for e in self.envs])
         self._done = (ctypes.c_int32 * n)()
         self._adopted = False
+        self.order_streams = True
+        self._uniq = None
 
     def pointers(self, tensors):
         """the device-pointer array of a list (per env) of lists (per group) of CUDA tensors (None entries allowed).  cycle()
@@ -659,11 +665,38 @@ class EnvBatch(object):
 
     def cycle(self, views=None, feats=None, actions=None, rewards=None):
         """each argument: list (per env) of lists (per group) of CUDA tensors or None, or the result of pointers();
-        returns the done flags"""
+        returns the done flags.
+
+        Stream contract: the library enqueues on the environments' own HIP streams.  With `order_streams` (default on) every
+        environment's stream is first ordered after torch's current stream (the producers of `actions`, readers of the output
+        tensors) and torch's current stream after the cycle, stream to stream -- a torch consumer of `rewards` or the views
+        needs nothing else.  Callers that manage their own streams switch it off (EnvBatch.order_streams = False)."""
+        if self.order_streams:
+            for e in self._distinct():
+                e.order_after_torch()
+        self._cycle_raw(views, feats, actions, rewards)
+        if self.order_streams:
+            for e in self._distinct():
+                e.order_torch_after()
+        return [bool(d) for d in self._done]
+
+    def _distinct(self):
+        """one environment per distinct engine stream (batched environments share their leader's stream)"""
+        if self._uniq is None or not self._adopted:
+            seen, self._uniq = set(), []
+            for e in self.envs:
+                key = tuple(st.cuda_stream for st in e._streams())
+                if key not in seen:
+                    seen.add(key)
+                    self._uniq.append(e)
+        return self._uniq
+
+    def _cycle_raw(self, views, feats, actions, rewards):
         self._lib.env_cycle_many(self._handles, len(self.envs), self.n_group, self._ptrs(views), self._ptrs(feats),
                                  self._ptrs(actions), self._ptrs(rewards), self._done, self.n_threads)
         if not self._adopted:      # environments cycled together share the first one's stream from now on
             self._adopted = True
+            self._uniq = None
             for e in self.envs:
                 e._ext_stream = None
         return [bool(d) for d in self._done]

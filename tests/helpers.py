@@ -331,20 +331,43 @@ class Scenario(object):
                 self.populate(env, ev[1], 0)
 
 
-def run(sc, lib, record=None):
+def run(sc, lib, record=None, device_io=False):
     """Play scenario `sc` on library `lib`; returns list (one dict per step) of every observable output.
 
     Order of calls per step follows examples/train_battle.py:61-109: get_observation + set_action per group,
-    step, get_reward / get_alive / get_pos / get_num per group, clear_dead."""
+    step, get_reward / get_alive / get_pos / get_num per group, clear_dead.
+
+    device_io (HIP engine only): the call sequence bench.py times -- env_get_observation_device into caller-owned torch
+    tensors allocated ONCE for the initial population, env_set_action_device from a device tensor, env_get_reward_device --
+    instead of the host-buffer reference ABI; the arrays are brought to the host only to be recorded."""
     env, handles = sc.build(lib)
     rs = np.random.RandomState(sc.action_seed)
     acting = sc.acting if sc.acting is not None else list(range(len(handles)))
+    if device_io:
+        import torch
+        dev = torch.device("cuda", env.device_id)
+        cap = [env.get_num(h) for h in handles]
+        d_view = [torch.empty((cap[g],) + env.get_view_space(h), device=dev) for g, h in enumerate(handles)]
+        d_feat = [torch.empty((cap[g],) + env.get_feature_space(h), device=dev) for g, h in enumerate(handles)]
+        d_rew = [torch.empty(cap[g], device=dev) for g in range(len(handles))]
     out = []
     for step in range(sc.steps):
         rec = {}
         sc.apply_events(env, step)
         for g, h in enumerate(handles):
             n = env.get_num(h)
+            if device_io:
+                assert n <= cap[g], "device_io: the population grew beyond the caller's buffers"
+                if step % sc.obs_every == 0 and n > 0:
+                    env.get_observation_device(h, d_view[g], d_feat[g])
+                    env.sync()
+                    rec["view%d" % g], rec["feat%d" % g] = d_view[g][:n].cpu().numpy(), d_feat[g][:n].cpu().numpy()
+                rec["id%d" % g] = env.get_agent_id(h)
+                if g in acting:
+                    a = torch.from_numpy(rs.randint(env.get_action_space(h)[0], size=n).astype(np.int32)).to(dev)
+                    torch.cuda.synchronize()
+                    env.set_action_device(h, a)
+                continue
             if step % sc.obs_every == 0 and n > 0:
                 view, feat = env.get_observation(h)
                 rec["view%d" % g], rec["feat%d" % g] = view.copy(), feat.copy()
@@ -353,7 +376,12 @@ def run(sc, lib, record=None):
                 env.set_action(h, rs.randint(env.get_action_space(h)[0], size=n).astype(np.int32))
         rec["done"] = np.array([env.step()], dtype=np.int32)
         for g, h in enumerate(handles):
-            rec["reward%d" % g] = env.get_reward(h)
+            if device_io:
+                env.get_reward_device(h, d_rew[g])
+                env.sync()
+                rec["reward%d" % g] = d_rew[g][:env.get_num(h)].cpu().numpy()
+            else:
+                rec["reward%d" % g] = env.get_reward(h)
             rec["alive%d" % g] = env.get_alive(h).astype(np.uint8)
             rec["pos%d" % g] = env.get_pos(h)
             rec["num%d" % g] = np.array([env.get_num(h)], dtype=np.int32)
@@ -478,7 +506,7 @@ def run_cycle_batch(scs, lib):
     return out
 
 
-def run_hashed(sc, lib):
+def run_hashed(sc, lib, device_io=False):
     """run(sc, lib) for sizes whose trajectories do not fit in memory: every array of every step is reduced to its
     xxh3-128 (10 GB/s on one core; SHA-256 would cost more than the engines) as soon as the step is over.
     Returns [{key: hex digest} per step]."""
@@ -490,7 +518,7 @@ def run_hashed(sc, lib):
                       for k, v in rec.items()})
         rec.clear()
 
-    run(sc, lib, record=keep)
+    run(sc, lib, record=keep, device_io=device_io)
     return steps
 
 
@@ -513,6 +541,9 @@ def fullsize_scenarios():
         # ~300k attack-list entries compared bit for bit at 2 x 400k
         Scenario("c3_battle1000_deaths", "battle", 1000, place=[rnd(0, 400000), rnd(1, 400000)], steps=6,
                  over={"small": {"hp": 4, "damage": 3}}),
+        # C3(i) as bench.py plays it: default hp (10) / damage (2), 30 steps -- the first deaths come after a few steps, then
+        # compaction every step; the horizon of a bench run (25 cycles) and more
+        Scenario("c3_battle1000_long", "battle", 1000, place=[rnd(0, 400000), rnd(1, 400000)], steps=30),
         # C4: gather 500x500 (train_gather.py), 20k food + 100k agents, only the agents act
         Scenario("c4_gather500", "gather", 500, place=[rnd(0, 20000), rnd(1, 100000)], acting=[1], steps=8),
         # the reference's own 1M harness (scripts/test/test_1m.py:62-71): map sqrt(20 N), N/10 walls, N/2 2x2 predators, N/2 prey

@@ -39,6 +39,45 @@ def test_fullsize_matches_reference_digest_and_oracle(name):
             H.assert_same_hashed(H.run_hashed(FULL[name], H.REF_LIB), got, name + " vs compiled reference")
 
 
+@pytest.mark.parametrize("name", ["c3_battle1000_deaths", "c3_battle1000_long"])
+def test_fullsize_device_abi_matches_reference_digest(name):
+    """the call sequence bench.py TIMES (env_get_observation_device into caller-owned tensors sized once, env_set_action_device,
+    env_get_reward_device) at 2 x 400k agents, against the digests of the compiled reference: `c3_battle1000_long` is the bench
+    workload itself (default hp, 30 steps: longer than a bench run) -- every view, feature row, reward, position, alive flag of
+    every step"""
+    got = H.run_hashed(FULL[name], H.HIP_LIB, device_io=True)
+    H.assert_same_hashed(GOLD[name], got, name + " (device ABI) vs compiled-reference digest")
+
+
+def test_bf16_cell_observation_at_full_size():
+    """env_get_observation_device_bf16 at 2 x 400k: every window cell is the round-to-nearest-even bf16 of the float32 observation's
+    channels, zeros up to channel 6, 1.0 in channel 7 (include/magent_policy.h) -- compared on the device, all 2 x 67.6 M cells,
+    before and after five steps of play"""
+    import numpy as np
+    import torch
+    sc = FULL["c3_battle1000_long"]
+    env, handles = sc.build(H.HIP_LIB)
+    dev = torch.device("cuda", env.device_id)
+    rs = np.random.RandomState(3)
+    for step in range(6):
+        for h in handles:
+            n = env.get_num(h)
+            if step in (0, 5):
+                view, feat = env.get_observation_device(h)
+                env.sync()
+                cells, feat16 = env.get_observation_device_bf16(h)
+                env.sync()
+                C = view.shape[-1]
+                assert cells.dtype == torch.bfloat16 and tuple(cells.shape) == (n,) + tuple(view.shape[1:3]) + (8,)
+                assert torch.equal(cells[..., :C].view(torch.int16), view.to(torch.bfloat16).view(torch.int16)), "step %d" % step
+                assert bool((cells[..., C:7] == 0).all()) and bool((cells[..., 7] == 1).all())
+                assert torch.equal(feat16, feat)
+                del view, cells
+            env.set_action(h, rs.randint(21, size=n).astype(np.int32))
+        env.step()
+        env.clear_dead()
+
+
 # The step has two drivers over the same kernels (engine.hip: Env::step) and, in the single-sync driver, a continuation
 # path for the rare step whose optimistic fixed-point rounds run out.  Each variant is forced through the environment
 # (read once per process) and must reproduce the oracle on dense scenarios: long attack chains, conga lines of movers,
