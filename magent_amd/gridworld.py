@@ -419,12 +419,14 @@ class GridWorld(object):
     @property
     def stream(self):
         """the engine's HIP stream as a torch.cuda.ExternalStream (every *_device call is asynchronous on it)"""
+        # (asked for every time: an environment that joins an EnvBatch later gives up its own stream for the batch's, and a
+        # wrapper of the destroyed one must not be used again)
+        self._require_device_api()
+        ptr = ctypes.c_void_p()
+        self._lib.env_get_stream(self.game, ctypes.byref(ptr))
         st = getattr(self, "_ext_stream", None)
-        if st is None:
+        if st is None or st.cuda_stream != ptr.value:
             import torch
-            self._require_device_api()
-            ptr = ctypes.c_void_p()
-            self._lib.env_get_stream(self.game, ctypes.byref(ptr))
             st = self._ext_stream = torch.cuda.ExternalStream(ptr.value, device=torch.device("cuda", self.device_id))
         return st
 
@@ -681,15 +683,15 @@ class EnvBatch(object):
         return [bool(d) for d in self._done]
 
     def _distinct(self):
-        """one environment per distinct engine stream (batched environments share their leader's stream)"""
-        if self._uniq is None or not self._adopted:
-            seen, self._uniq = set(), []
-            for e in self.envs:
-                key = tuple(st.cuda_stream for st in e._streams())
-                if key not in seen:
-                    seen.add(key)
-                    self._uniq.append(e)
-        return self._uniq
+        """one environment per distinct engine stream (batched environments share their leader's stream; an environment may
+        join the batch in a later cycle, so the streams are asked for every time: a ctypes call each)"""
+        seen, uniq = set(), []
+        for e in self.envs:
+            key = tuple(st.cuda_stream for st in e._streams())
+            if key not in seen:
+                seen.add(key)
+                uniq.append(e)
+        return uniq
 
     def _cycle_raw(self, views, feats, actions, rewards):
         self._lib.env_cycle_many(self._handles, len(self.envs), self.n_group, self._ptrs(views), self._ptrs(feats),

@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libmagent_ref.so")
 HIP_LIB = os.path.join(ROOT, "magent_amd", "lib", "libmagent.so")
+PRODUCT_LIB = HIP_LIB          # (tools/fuzz_parity.py points HIP_LIB at the emulated build when asked for "emu")
 EMU_LIB = os.path.join(ROOT, "tests", "hipemu", "_build", "libmagent_emu.so")
 
 
@@ -46,10 +47,27 @@ def have_ref():
 _WORLDS = {}
 
 
+def is_emu(lib):
+    return lib is not None and os.path.abspath(lib) == os.path.abspath(EMU_LIB)
+
+
+def torch_device(env, lib):
+    """where the caller-owned "device" tensors of the *_device API live: the GPU -- or, for the emulated library, host memory
+    (its HBM is the host heap, a CPU tensor's data_ptr() is a valid device pointer there)"""
+    import torch
+    return torch.device("cpu") if is_emu(lib) else torch.device("cuda", env.device_id)
+
+
+def device_sync(lib):
+    import torch
+    if not is_emu(lib):
+        torch.cuda.synchronize()
+
+
 def world_on(lib):
     """the GridWorld wrapper bound to engine library `lib` (None / HIP_LIB: the product class itself).  The product has no
     switch for this: the test suite subclasses it and overrides the class attribute that names the library."""
-    if lib is None or os.path.abspath(lib) == os.path.abspath(HIP_LIB):
+    if lib is None or os.path.abspath(lib) == os.path.abspath(PRODUCT_LIB):
         return magent_amd.GridWorld
     key = os.path.abspath(lib)
     if key not in _WORLDS:
@@ -345,7 +363,7 @@ def run(sc, lib, record=None, device_io=False):
     acting = sc.acting if sc.acting is not None else list(range(len(handles)))
     if device_io:
         import torch
-        dev = torch.device("cuda", env.device_id)
+        dev = torch_device(env, lib)
         cap = [env.get_num(h) for h in handles]
         d_view = [torch.empty((cap[g],) + env.get_view_space(h), device=dev) for g, h in enumerate(handles)]
         d_feat = [torch.empty((cap[g],) + env.get_feature_space(h), device=dev) for g, h in enumerate(handles)]
@@ -365,7 +383,7 @@ def run(sc, lib, record=None, device_io=False):
                 rec["id%d" % g] = env.get_agent_id(h)
                 if g in acting:
                     a = torch.from_numpy(rs.randint(env.get_action_space(h)[0], size=n).astype(np.int32)).to(dev)
-                    torch.cuda.synchronize()
+                    device_sync(lib)
                     env.set_action_device(h, a)
                 continue
             if step % sc.obs_every == 0 and n > 0:
@@ -409,8 +427,9 @@ def run_cycle(sc, lib, fused):
     acting = sc.acting if sc.acting is not None else list(range(len(handles)))
     if fused:
         import torch
-        dev = torch.device("cuda", env.device_id)
+        dev = torch_device(env, lib)
         batch = magent_amd.EnvBatch([env], n_threads=1)
+        batch.order_streams = not is_emu(lib)
     out = []
     for step in range(sc.steps):
         rec = {}
@@ -425,7 +444,7 @@ def run_cycle(sc, lib, fused):
             feats = [torch.empty((nums[g],) + env.get_feature_space(h), device=dev) if observe[g] else None for g, h in enumerate(handles)]
             d_acts = [torch.from_numpy(a).to(dev) if a is not None else None for a in acts]
             rews = [torch.empty(nums[g], device=dev) for g in range(len(handles))]
-            torch.cuda.synchronize()
+            device_sync(lib)
             done = batch.cycle([views], [feats], [d_acts], [rews])[0]
             env.sync()
             for g in range(len(handles)):
@@ -463,8 +482,9 @@ def run_cycle_batch(scs, lib):
     import torch
     built = [sc.build(lib) for sc in scs]
     envs, handles = [b[0] for b in built], [b[1] for b in built]
-    dev = torch.device("cuda", envs[0].device_id)
+    dev = torch_device(envs[0], lib)
     batch = magent_amd.EnvBatch(envs, n_threads=1)
+    batch.order_streams = not is_emu(lib)
     rss = [np.random.RandomState(sc.action_seed) for sc in scs]
     out, live = [[] for _ in scs], [True] * len(scs)
     for step in range(max(sc.steps for sc in scs)):
@@ -484,7 +504,7 @@ def run_cycle_batch(scs, lib):
             d_acts.append([torch.from_numpy(a).to(dev) if a is not None else None for a in acts])
             rews.append([torch.empty(nums[g], device=dev) for g in range(len(hs))])
             recs.append(rec); observes.append(observe)
-        torch.cuda.synchronize()
+        device_sync(lib)
         dones = batch.cycle(views, feats, d_acts, rews)
         for k, (sc, env, hs) in enumerate(zip(scs, envs, handles)):
             env.sync()
