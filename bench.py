@@ -331,6 +331,9 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to dry-run the N > 1 "
                          "code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--obs", choices=["f32", "bf16"], default="f32",
+                    help="bf16: render the observations as the policy kernels' bf16 cells (env_get_observation_device_bf16, 8 x bf16 per window "
+                         "cell) -- a secondary reading; the headline stays on the reference's float32 tensors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (capacity fill, test_1m, small worlds)")
@@ -404,14 +407,16 @@ def main():
         vss = [env.get_view_space(h) for h in handles]
         fss = [env.get_feature_space(h) for h in handles]
         n_actions = [env.get_action_space(h)[0] for h in handles]
-        view_bytes = [4 * v[0] * v[1] * v[2] for v in vss]   # per agent: what k_render writes (the dominant kernel)
+        bf16 = args.obs == "bf16"
+        view_bytes = [(16 * v[0] * v[1]) if bf16 else (4 * v[0] * v[1] * v[2]) for v in vss]   # per agent: what k_render writes (the dominant kernel)
         feat_bytes = [4 * f[0] for f in fss]                 # per agent: the feature rows (they ride in the render launch)
 
         # caller-owned device buffers (the reference's ownership convention), sized once for the initial population
         # with the gather on, two view tensors per group used alternately: the render of step t+1 then only waits for the
         # exchange of step t-1 (the one that read the tensor it overwrites), not for the exchange of step t
         n_buf = 2 if (gather != "none" and world > 1) else 1
-        views = [[torch.empty((n0[g],) + vss[g], dtype=torch.float32, device=dev) for _ in range(n_buf)] for g in range(G)]
+        views = [[torch.empty((n0[g],) + (vss[g][:2] + (8,) if bf16 else vss[g]), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+                  for _ in range(n_buf)] for g in range(G)]
         feats = [torch.empty((n0[g],) + fss[g], dtype=torch.float32, device=dev) for g in range(G)]
         rewards = [torch.empty(n0[g], dtype=torch.float32, device=dev) for g in range(G)]
         total_steps = steps + warmup
@@ -444,7 +449,10 @@ def main():
                 view = views[g][s % n_buf]
                 if gathers and args.backend == "nccl":   # the exchange of step t-1 may still read the tensor this render overwrites
                     gathers[g].release(view, env.stream)
-                env.get_observation_device(h, view, feats[g])
+                if bf16:
+                    env.get_observation_device_bf16(h, view, feats[g])
+                else:
+                    env.get_observation_device(h, view, feats[g])
                 env.set_action_device(h, actions[s % n_sets][g])
                 if gathers:                      # counts now (behind the render, on the side stream); the rows follow below
                     if args.backend == "nccl":

@@ -45,3 +45,41 @@ def test_emulated_kernels_do_not_depend_on_lane_order(emu):
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPEMU_SCRAMBLE=seed, OMP_NUM_THREADS="1"),
                            capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-1000:] + p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("knobs", [{"MAGENT_RENDER_FAST": "1"}, {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "3"},
+                                   {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "2", "MAGENT_RENDER_SU": "3", "MAGENT_RENDER_DEPTH": "3"},
+                                   {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "7", "MAGENT_RENDER_SU": "1", "MAGENT_RENDER_DEPTH": "1"}],
+                         ids=["fast", "sweep", "sweep_3strips_depth3", "sweep_1strip_depth1"])
+def test_emulated_battle_render_kernels(emu, knobs):
+    """the battle-shaped render kernels (k_render_fast: LDS tables + one-step look-ahead; k_render_sweep2: persistent workgroups
+    sweeping the output, register ring of requests, several strips per wave) forced onto small worlds with few workgroups, so
+    that every workgroup plays many rounds: float32 observations against the oracle, and the bf16-cell form against the rounded
+    float32 one"""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, torch\n"
+            "import helpers as H\n"
+            "emu = H.ensure_emu()\n"
+            "for n in ('battle_small_dense', 'battle_walls', 'battle_largemap_odd', 'battle_tiny', 'battle_grow', 'gather'):\n"
+            "    sc = H.scenarios()[n]\n"
+            "    H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, emu), n)\n"
+            "env = H.gridworld('battle', lib=emu, map_size=45)\n"
+            "env.set_seed(5); env.reset()\n"
+            "hs = env.get_handles()\n"
+            "for h in hs: env.add_agents(h, 'random', n=500)\n"
+            "rs = np.random.RandomState(1)\n"
+            "for step in range(3):\n"
+            "    for h in hs:\n"
+            "        k = env.get_num(h)\n"
+            "        view, feat = torch.empty((k, 13, 13, 7)), torch.empty((k, 34))\n"
+            "        env.get_observation_device(h, view, feat)\n"
+            "        cells, f2 = torch.empty((k, 13, 13, 8), dtype=torch.bfloat16), torch.empty((k, 34))\n"
+            "        env.get_observation_device_bf16(h, cells, f2)\n"
+            "        assert view.numpy().tobytes() == env.get_observation(h)[0].tobytes()\n"
+            "        assert torch.equal(cells[..., :7].contiguous().view(torch.int16), view.to(torch.bfloat16).view(torch.int16))\n"
+            "        assert bool((cells[..., 7] == 1).all()) and torch.equal(f2, feat)\n"
+            "        env.set_action(h, rs.randint(21, size=k).astype(np.int32))\n"
+            "    env.step(); env.clear_dead()\n"
+            "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS="1", **knobs), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-1000:] + p.stderr[-3000:]

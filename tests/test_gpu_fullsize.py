@@ -91,6 +91,10 @@ VARIANTS = {
     "host_shuffle": {"MAGENT_HOST_SHUFFLE": "1"},
     "multi_launch_step": {"MAGENT_SOLO_STEP": "0"},
     "multi_launch_side_stream": {"MAGENT_SOLO_STEP": "0", "MAGENT_OVERLAP": "3"},   # set_action and the head of the step beside the renders
+    # the battle-shaped render kernels forced on small worlds (defaults: k_render_sweep2 only at scale, k_render_fast only for bf16 cells)
+    "render_fast": {"MAGENT_RENDER_FAST": "1"},
+    "render_sweep": {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "5"},
+    "render_sweep_3strips": {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "2", "MAGENT_RENDER_SU": "3", "MAGENT_RENDER_DEPTH": "3"},
 }
 
 
