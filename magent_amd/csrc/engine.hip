@@ -1220,6 +1220,20 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
 }
 
 // the minimap of a vh x vw window into d_minif (grown if needed)
+// The minimap the next observations will ask for, to be made by clear_dead's own launches (large worlds): the window they used last.
+// Not when the observing type skips absorbed agents (the histogram would need the `absorbed` flags: the ordinary path), nor before
+// the first observation (no window known).  vh == 0: not folded.
+MiniArgs Env::next_minimap() {
+    MiniArgs M{};
+    static const bool off = std::getenv("MAGENT_FOLD_MINIMAP") && std::atoi(std::getenv("MAGENT_FOLD_MINIMAP")) == 0;
+    if (off || !minimap_mode || mini_vh <= 0 || mini_skip) return M;
+    const size_t need = MAXG + groups.size() * (size_t)mini_vh * mini_vw * (1 + MINI_COPIES);
+    if (need > mini_cap) return M;       // (the histogram buffer of the first observation is not there yet)
+    return mini_args(mini_vh, mini_vw, false);
+}
+
+int *Env::fold_counts() { return d_mini ? d_mini + MAXG + groups.size() * (size_t)mini_vh * mini_vw : nullptr; }
+
 MiniArgs Env::mini_args(int vh, int vw, bool skip) {
     MiniArgs M{};
     M.vh = vh; M.vw = vw; M.skip = skip ? 1 : 0;
@@ -1248,7 +1262,7 @@ bool Env::prepare_render(int g, const WorldView &W, RenderArgs &R, RenderPlan &P
     plan_render(g, R, P, view, feat);
     if (minimap_mode) {
         size_t need = (size_t)W.G * R.VH * R.VW;
-        const size_t need_counts = need + MAXG;      // + the per-group count of agents left out (k_minimap, skip mode)
+        const size_t need_counts = MAXG + need * (1 + MINI_COPIES);   // left-out counters (k_minimap, skip mode) | histogram | clear_dead's copies
         if (need_counts > mini_cap) {   // the histogram buffer is kept zero between uses (k_minimap's last block zeroes what it reads)
             grow(arena, d_mini, mini_cap, need_counts, stream);
             HIP_OK(hipMemsetAsync(d_mini, 0, sizeof(int) * mini_cap, stream));
@@ -1407,12 +1421,13 @@ void Env::attack_rounds_checked(const WorldView &W) {
 
 // move rounds, host-checked: `move_jump_batch` rounds per convergence check (a resolved agent is a no-op later)
 void Env::move_rounds_checked(const WorldView &W) {
+    if (!any_multicell) { last_move_iters = 0; return; }   // one-cell bodies: the commit walks the dependency chains itself (move_resolve)
     int iters = 0;
     do {
         clear_changed();
         for (int k = 0; k < move_jump_batch; k++) {
             const int flag = k == move_jump_batch - 1 ? CTR_CHANGED : -1;
-            if (any_multicell) launch_movg_sweep(stream, W, d_gtab, flag); else launch_move_jump(stream, W, d_gtab, flag);
+            launch_movg_sweep(stream, W, d_gtab, flag);
         }
         iters += move_jump_batch;
         if (iters > 1000000) fatal("move resolution did not converge");
@@ -1540,10 +1555,11 @@ void Env::step_begin() {
         {
             ProfScope p(*this, "move");
             if (any_multicell) launch_movg_prep(stream, W, true); else launch_move_prep(stream, W, d_gtab);
+            // (one-cell bodies need no rounds: the commit walks the dependency chains itself; the generic sweeps iterate)
             const int batches = opt_fixed ? opt_move_batches : (boost_move > 0 ? 2 : 1);
-            for (int r = 0; r < batches * move_jump_batch; r++) {
+            for (int r = 0; any_multicell && r < batches * move_jump_batch; r++) {
                 const int flag = r == batches * move_jump_batch - 1 ? CTR_OPEN_MOVE : -1;   // the last round reports
-                if (any_multicell) launch_movg_sweep(stream, W, d_gtab, flag); else launch_move_jump(stream, W, d_gtab, flag);
+                launch_movg_sweep(stream, W, d_gtab, flag);
             }
             if (batches == 0) launch_set_counter(stream, d_counters, CTR_OPEN_MOVE, 1, CTR_OPEN_ATTACK);   // tests
             if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
@@ -2000,10 +2016,12 @@ void Env::clear_dead() {
         for (size_t g = 0; g < groups.size(); g++) if (A.mode[g] == 2) swap_buffers(groups[g]);
         tables_valid = true;
         solo_mini = next_mini;
-    } else if (!any) {                  // Agent::init_reward for everybody: one launch
+    } else if (!any) {                  // Agent::init_reward for everybody: one launch (+ the normalisation of the next minimap)
         ClearArgs A{};
         for (size_t g = 0; g < groups.size(); g++) A.mode[g] = groups[g].n > 0 ? 1 : 0;
-        launch_clear_compact(stream, W, A, d_sums);
+        const MiniArgs M = next_minimap();
+        launch_clear_compact(stream, W, A, d_sums, M, fold_counts());
+        if (M.vh > 0) { launch_mini_norm(stream, W, M, fold_counts()); solo_mini = true; }
     } else if (all_solo) {       // small worlds: one workgroup per group does everything for that group
         for (size_t g = 0; g < groups.size(); g++) {
             HostGroup &G = groups[g];
@@ -2029,10 +2047,12 @@ void Env::clear_dead() {
             A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed, G.alt.dir};
         }
         grow(arena, d_sums, sums_cap, nb_total, stream);
-        launch_clear_compact(stream, W, A, d_sums);
+        const MiniArgs M = next_minimap();
+        launch_clear_compact(stream, W, A, d_sums, M, fold_counts());
         for (size_t g = 0; g < groups.size(); g++) if (A.mode[g] == 2) swap_buffers(groups[g]);
-        launch_clear_finish(stream, view(), A, d_gtab, d_ttab);   // also refreshes the device tables
+        launch_clear_finish(stream, view(), A, d_gtab, d_ttab, M, fold_counts());   // also refreshes the device tables
         tables_valid = true;
+        if (M.vh > 0) solo_mini = true;
     }
     // (the death counters of the compacted groups were zeroed by the compaction kernels; the others were zero)
     if (any) { h_occ_valid = false; mini_valid = false; }

@@ -196,6 +196,8 @@ private:
     void enqueue_counters();
     bool step_pending = false, step_was_fast = false, step_was_solo = false, step_live_paint = false, live_paint_now = false;
     bool solo_ok(int total_n);
+    MiniArgs next_minimap();
+    int *fold_counts();
     bool cycle_eligible(int n_group, float *const *view, float *const *feat, int *first_obs_out);
     bool cycle_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, BatchItem &item);
     void cycle_finish(int *done);

@@ -758,7 +758,8 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_multi(WorldView W,
 // Exclusive prefix sum of a per-agent predicate over one group, SCAN_ITEMS elements per thread:
 //   pass A  per-block totals            pass B  one block scans the totals (+ base)      pass C  per-element ranks
 // In-wave ranks come from ballots (wave64), cross-wave from LDS.
-constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+constexpr int SCAN_THREADS = 256, SCAN_ITEMS = SCAN_ITEMS_HOST, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+static_assert(SCAN_TILE == SCAN_TILE_HOST, "scan tile");
 
 template <class Pred>
 __device__ __forceinline__ int block_count(Pred pred, int n) {
@@ -777,29 +778,49 @@ __device__ __forceinline__ int block_count(Pred pred, int n) {
     return tot;
 }
 
-// calls emit(i, exclusive_rank) for every i in this block's tile with pred(i)
+// calls emit(i, exclusive_rank) for every i in this block's tile with pred(i); returns the tile's total.
+// (all SCAN_ITEMS predicates are evaluated first -- their loads are in flight together -- and the waves meet once: the earlier
+// form, one item at a time with two barriers each, made every launch that used it a chain of 8 dependent round trips)
 template <class Pred, class Emit>
-__device__ __forceinline__ void block_rank(Pred pred, Emit emit, int n, int block_offset) {
-    __shared__ int s_w[SCAN_THREADS / 64];
-    int base = blockIdx.x * SCAN_TILE, run = block_offset;
+__device__ __forceinline__ int block_rank(Pred pred, Emit emit, int n, int block_offset) {
+    __shared__ int s_w[SCAN_ITEMS][SCAN_THREADS / 64];
+    const int base = blockIdx.x * SCAN_TILE;
     const int wave = threadIdx.x >> 6;
+    bool p[SCAN_ITEMS];
+    int r[SCAN_ITEMS];
+#pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
-        int i = base + k * SCAN_THREADS + threadIdx.x;
-        bool p = i < n && pred(i);
-        int wtot, r = wave_rank(p, wtot);
-        if (lane_id() == 0) s_w[wave] = wtot;
-        __syncthreads();
-        int before = 0, all = 0;
-        for (int v = 0; v < SCAN_THREADS / 64; v++) { int t = s_w[v]; all += t; if (v < wave) before += t; }
-        if (p) emit(i, run + before + r);
-        run += all;
-        __syncthreads();
+        const int i = base + k * SCAN_THREADS + threadIdx.x;
+        p[k] = i < n && pred(i);
     }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        int wtot;
+        r[k] = wave_rank(p[k], wtot);
+        if (lane_id() == 0) s_w[k][wave] = wtot;
+    }
+    __syncthreads();
+    int run = block_offset;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        int before = 0, all = 0;
+#pragma unroll
+        for (int v = 0; v < SCAN_THREADS / 64; v++) { const int t = s_w[k][v]; all += t; if (v < wave) before += t; }
+        if (p[k]) emit(base + k * SCAN_THREADS + threadIdx.x, run + before + r[k]);
+        run += all;
+    }
+    __syncthreads();       // (s_w may be written again by the caller's next use)
+    return run - block_offset;
 }
 
 // One-workgroup form for small groups (n <= SOLO_MAX): a single 1024-thread workgroup walks the group in tiles and
 // carries the running rank itself -- one launch instead of three when the whole job is launch-latency bound.
 constexpr int SOLO_THREADS = 1024, SOLO_MAX = 32768;
+// (MAGENT_SCAN_SOLO_MAX: tests lower it so that small worlds run the multi-block scans of the large ones)
+static int scan_solo_max() {
+    static const int v = std::getenv("MAGENT_SCAN_SOLO_MAX") ? std::max(0, std::min(SOLO_MAX, std::atoi(std::getenv("MAGENT_SCAN_SOLO_MAX")))) : SOLO_MAX;
+    return v;
+}
 
 template <class Pred, class Emit>
 __device__ __forceinline__ int solo_rank(Pred pred, Emit emit, int n, int base) {
@@ -851,25 +872,42 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int 
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
     const int tile0 = blockIdx.x * SCAN_TILE;
+    // (every load of the tile first -- SCAN_ITEMS independent requests per thread -- then the classification: one round trip
+    // per launch instead of eight)
+    int act[SCAN_ITEMS], xs[SCAN_ITEMS];
+#pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
-        int i = tile0 + k * SCAN_THREADS + threadIdx.x;
+        const int i = tile0 + k * SCAN_THREADS + threadIdx.x;
+        act[k] = i < G.n ? actions[i] : 0;
+        xs[k] = (i < G.n && W.large_map) ? G.x[i] : 0;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const int i = tile0 + k * SCAN_THREADS + threadIdx.x;
+        const bool attack = i < G.n && act[k] >= T.n_move + T.n_turn;
+        cnt += __popcll(__ballot(attack));
         if (i < G.n) {
-            int act = actions[i];
-            if (act < 0 || act >= T.n_move + T.n_turn + T.n_attack) {   // outside the action space: no action, reported at the end of the step
+            const int a = act[k];
+            if (a < 0 || a >= T.n_move + T.n_turn + T.n_attack) {   // outside the action space: no action, reported at the end of the step
                 W.counters[CTR_BAD_ACTION] = 1;
                 G.pend[i] = PEND_NONE;
-            } else if (act < T.n_move + T.n_turn) {   // moves and (turn_mode) turns: ordered by stripe class, then insertion
+            } else if (a < T.n_move + T.n_turn) {   // moves and (turn_mode) turns: ordered by stripe class, then insertion
                 unsigned bound = 0;
-                if (W.large_map) { int x_ = G.x[i] % W.bandwidth; bound = (x_ < 4 || x_ > W.bandwidth - 4) ? 1u : 0u; }
-                G.pend[i] = (act < T.n_move ? PEND_MOVE : PEND_TURN) | act;
+                if (W.large_map) { int x_ = xs[k] % W.bandwidth; bound = (x_ < 4 || x_ > W.bandwidth - 4) ? 1u : 0u; }
+                G.pend[i] = (a < T.n_move ? PEND_MOVE : PEND_TURN) | a;
                 G.key[i] = (bound << 31) | (unsigned)(call_base + i);
             } else {
-                G.pend[i] = PEND_ATTACK | (act - T.n_move - T.n_turn);
+                G.pend[i] = PEND_ATTACK | (a - T.n_move - T.n_turn);
             }
         }
     }
-    int tot = block_count([&](int i) { return actions[i] >= T.n_move + T.n_turn; }, G.n);
+    __shared__ int s_w[SCAN_THREADS / 64];
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < SCAN_THREADS / 64; k++) tot += s_w[k];
         sums[blockIdx.x] = tot;
         if (blockIdx.x == 0) W.counters[CTR_ATTACK_BASE] = W.counters[CTR_ATTACK];   // nothing writes CTR_ATTACK in this launch
     }
@@ -1478,18 +1516,14 @@ __global__ void __launch_bounds__(256) k_move_init(WorldView W) {
     if (i < W.grp[g].n) move_init_body(W, g, i);
 }
 
-__device__ __forceinline__ void move_jump_body(const WorldView &W, const GroupDev *gtab, int g, int i, int *flagp) {
-    const GroupDev &G = W.grp[g];
-    unsigned m = G.mv[i];
-    if (m >= MV_OK) return;
-    unsigned s = gtab[ref_group((int)m)].mv[ref_index((int)m)];
-    G.mv[i] = s;                                                   // OK / FAIL resolve me; otherwise jump
-    if (flagp && s < MV_OK) *flagp = 1;                            // (multi-launch driver: only the last round of a batch reports)
-}
-__global__ void __launch_bounds__(256) k_move_jump(WorldView W, const GroupDev *gtab, int flag) {
-    if (attack_open(W)) return;
-    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < W.grp[g].n) move_jump_body(W, gtab, g, i, flag >= 0 ? &W.counters[flag] : nullptr);
+// Whether a mover's chain of dependencies ends in success: its move succeeds iff the phase-start occupant of its target succeeds,
+// iff ... -- every link points to a LOWER key, so the walk terminates; links are read-only once k_move_init has run.  The chain
+// is walked by whoever needs the answer (round 2 resolved every agent by pointer jumping first: three to six more dependent
+// launches -- or workgroup barriers, in the one-launch step -- to shorten chains that are one or two links long on average;
+// a long "conga line" now costs its length in dependent loads to the agents at its tail, and nothing to anybody else).
+__device__ __forceinline__ unsigned move_resolve(const GroupDev *gtab, unsigned m) {
+    while (m < MV_OK) m = gtab[ref_group((int)m)].mv[ref_index((int)m)];
+    return m;
 }
 
 // End of the 1x1 move phase, one launch.
@@ -1502,7 +1536,7 @@ __device__ __forceinline__ void move_commit_body(const WorldView &W, const Group
     const GroupDev &G = W.grp[g];
     const int c = G.drank_a[i];
     if (c >= 0) {
-        if (G.mv[i] == MV_OK) {
+        if (move_resolve(gtab, G.mv[i]) == MV_OK) {
             const int old = G.y[i] * W.w + G.x[i];
             if (W.claim[old] == CLAIM_NONE) { W.occ[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }
             W.occ[c] = ref_pack(g, i);
@@ -1516,7 +1550,7 @@ __device__ __forceinline__ void move_commit_body(const WorldView &W, const Group
             else {
                 const GroupDev O = gtab[ref_group(o)];
                 int oi = ref_index(o);
-                bool left_before = O.mv[oi] == MV_OK && O.key[oi] < G.key[i];
+                bool left_before = move_resolve(gtab, O.mv[oi]) == MV_OK && O.key[oi] < G.key[i];
                 blocker = left_before ? (int)(unsigned)W.claim[c] : o;
             }
             G.last_op[i] = OP_COLLIDE;
@@ -2164,39 +2198,71 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_clear_count(WorldView W, Clear
 
 // ... then stable compaction into the alternate buffers + init_reward + re-index the map (groups with deaths), or
 // Agent::init_reward alone (groups without)
-__global__ void __launch_bounds__(SCAN_THREADS) k_clear_compact(WorldView W, ClearArgs A, const int *sums) {
+// (M.vh > 0: the minimap of the NEXT observations rides along -- every block adds the survivors it handles to an LDS histogram of
+// their minimap cells and flushes it with one global atomic per non-empty bin; k_clear_finish / k_mini_norm divide.  That is
+// k_minimap + k_minimap_norm, two launches per cycle, gone: the positions pass through this kernel anyway)
+__global__ void __launch_bounds__(SCAN_THREADS) k_clear_compact(WorldView W, ClearArgs A, const int *sums, MiniArgs M, int *counts) {
+    extern __shared__ int s_hist[];
     const int g = blockIdx.y;
     const GroupDev G = W.grp[g];
     if ((int)(blockIdx.x * SCAN_TILE) >= G.n) return;
     const float step_reward = W.type[g].step_reward;
+    const int VHW = M.vh * M.vw;
+    if (VHW > 0) {
+        for (int k = threadIdx.x; k < VHW; k += SCAN_THREADS) s_hist[k] = 0;
+        __syncthreads();
+    }
     if (A.mode[g] == 1) {
         for (int k = 0; k < SCAN_ITEMS; k++) {
             const int i = blockIdx.x * SCAN_TILE + k * SCAN_THREADS + threadIdx.x;
-            if (i < G.n) { G.last_reward[i] = G.next_reward[i]; G.next_reward[i] = step_reward; G.last_op[i] = OP_NULL; G.op_obj[i] = -1; }
+            if (i < G.n) {
+                G.last_reward[i] = G.next_reward[i]; G.next_reward[i] = step_reward; G.last_op[i] = OP_NULL; G.op_obj[i] = -1;
+                if (VHW > 0) atomicAdd(&s_hist[(G.y[i] / M.scale_h) * M.vw + G.x[i] / M.scale_w], 1);
+            }
         }
-        return;
+    } else if (A.mode[g] == 2) {
+        const ClearArgs::Alt D = A.dst[g];
+        const int bw = W.type[g].bw, bl = W.type[g].bl;
+        block_rank([&](int i) { return !G.dead[i]; },
+                   [&](int i, int r) {
+                       int x = G.x[i], y = G.y[i];
+                       D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
+                       D.absorbed[r] = G.absorbed[i];
+                       if (G.dir) D.dir[r] = G.dir[i];
+                       D.last_reward[r] = G.next_reward[i];
+                       D.next_reward[r] = step_reward;
+                       { const int2 fp = W.turn_mode ? dims_for_dir(W.type[g], G.dir[i]) : make_int2(bw, bl); body_fill(W, x, y, fp.x, fp.y, ref_pack(g, r)); }
+                       if (VHW > 0) atomicAdd(&s_hist[(y / M.scale_h) * M.vw + x / M.scale_w], 1);
+                   },
+                   G.n, block_prefix(sums + A.sums_off[g], blockIdx.x));
     }
-    if (A.mode[g] != 2) return;
-    const ClearArgs::Alt D = A.dst[g];
-    const int bw = W.type[g].bw, bl = W.type[g].bl;
-    block_rank([&](int i) { return !G.dead[i]; },
-               [&](int i, int r) {
-                   int x = G.x[i], y = G.y[i];
-                   D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
-                   D.absorbed[r] = G.absorbed[i];
-                   if (G.dir) D.dir[r] = G.dir[i];
-                   D.last_reward[r] = G.next_reward[i];
-                   D.next_reward[r] = step_reward;
-                   { const int2 fp = W.turn_mode ? dims_for_dir(W.type[g], G.dir[i]) : make_int2(bw, bl); body_fill(W, x, y, fp.x, fp.y, ref_pack(g, r)); }
-               },
-               G.n, block_prefix(sums + A.sums_off[g], blockIdx.x));
+    if (VHW > 0) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < VHW; k += SCAN_THREADS)
+            if (s_hist[k]) atomicAdd(&counts[((blockIdx.x % MINI_COPIES) * W.G + g) * VHW + k], s_hist[k]);   // MINI_COPIES histograms: same-address atomics serialise
+    }
+}
+
+// mini[j][cell] = float(count) / float(n_j) exactly as the reference divides (k_minimap_norm), from the histogram k_clear_compact
+// left; the histogram goes back to zero
+__device__ __forceinline__ void mini_norm_body(const WorldView &Wn, const MiniArgs &M, int *counts, int k) {
+    const int VHW = M.vh * M.vw;
+    if (k >= Wn.G * VHW) return;
+    const int tot = Wn.grp[k / VHW].n;
+    int cnt = 0;
+    for (int c = 0; c < MINI_COPIES; c++) { cnt += counts[c * Wn.G * VHW + k]; counts[c * Wn.G * VHW + k] = 0; }
+    M.out[k] = tot == 0 ? __int_as_float(0xFFC00000) : __fdiv_rn((float)min(cnt, 1 << 24), (float)(unsigned)tot);
+}
+__global__ void __launch_bounds__(256) k_mini_norm(WorldView Wn, MiniArgs M, int *counts) {
+    mini_norm_body(Wn, M, counts, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ... and, with the pointers swapped (Wn = the view after clear_dead): the single-buffered per-agent state of the
 // survivors, the death counters and the device copies of the group / type tables
-__global__ void __launch_bounds__(256) k_clear_finish(WorldView Wn, ClearArgs A, GroupDev *gtab, TypeDev *ttab) {
+__global__ void __launch_bounds__(256) k_clear_finish(WorldView Wn, ClearArgs A, GroupDev *gtab, TypeDev *ttab, MiniArgs M, int *counts) {
     const int g = blockIdx.y;
     if ((blockIdx.x | blockIdx.y) == 0 && threadIdx.x < MAXG) { gtab[threadIdx.x] = Wn.grp[threadIdx.x]; ttab[threadIdx.x] = Wn.type[threadIdx.x]; }
+    if (M.vh > 0 && g == 0) mini_norm_body(Wn, M, counts, blockIdx.x * blockDim.x + threadIdx.x);   // (the grid covers the largest group: >= G * VHW threads, checked by the launcher)
     if (A.mode[g] != 2) return;
     const GroupDev D = Wn.grp[g];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2370,19 +2436,9 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
         __syncthreads();
         SOLO_MARK();   // 10: claim
         SOLO_EACH(g, i) move_init_body(W, g, i);
-        if (tid < 3) s_flags[tid] = 0;
         __syncthreads();
         SOLO_MARK();   // 11: init
-        while (true) {
-            rounds_move++;
-            int *flag = &s_flags[rounds_move % 3];
-            if (tid == 0) s_flags[(rounds_move + 1) % 3] = 0;
-            SOLO_EACH(g, i) move_jump_body(W, gtab, g, i, flag);
-            __syncthreads();
-            const int open = *flag;
-            if (!open) break;
-            if (rounds_move > S.max_rounds) { error = 2; break; }
-        }
+        rounds_move = 1;                    // (chains are walked inside the commit: move_resolve)
         SOLO_MARK();   // 12: jump rounds
         SOLO_EACH(g, i) move_commit_body(W, gtab, g, i);
         __syncthreads();
@@ -2775,7 +2831,7 @@ void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, con
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums) {
     int n = W.grp[g].n;
     if (n <= 0) return;
-    if (n <= SOLO_MAX) { hipLaunchKernelGGL(k_set_action_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, actions, call_base); return; }
+    if (n <= scan_solo_max()) { hipLaunchKernelGGL(k_set_action_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, actions, call_base); return; }
     int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_set_action_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, call_base, sums);
     hipLaunchKernelGGL(k_set_action_c, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, sums);
@@ -2869,9 +2925,6 @@ void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) 
     hipLaunchKernelGGL(k_movg_vacate, g, dim3(256), 0, s, W);
     hipLaunchKernelGGL(k_movg_enter, g, dim3(256), 0, s, W);
 }
-void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag) {
-    hipLaunchKernelGGL(k_move_jump, grid_all(W, 256), dim3(256), 0, s, W, gtab, flag);
-}
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     dim3 g = grid_all(W, 256);
     hipLaunchKernelGGL(k_move_commit, g, dim3(256), 0, s, W, gtab);
@@ -2938,18 +2991,21 @@ void launch_init_reward(hipStream_t s, const WorldView &W, int g) {
     int n = W.grp[g].n;
     if (n > 0) hipLaunchKernelGGL(k_init_reward, dim3((n + 255) / 256), dim3(256), 0, s, W, g);
 }
-bool compact_is_solo(int n) { return n <= SOLO_MAX; }
+bool compact_is_solo(int n) { return n <= scan_solo_max(); }
 void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D, int new_n, int *sums) {   // small groups: one workgroup
     (void)new_n; (void)sums;
     if (W.grp[g].n > 0) hipLaunchKernelGGL(k_compact_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, D);
 }
-void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A, int *sums) {
+void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A, int *sums, const MiniArgs &M, int *counts) {
     int mx = 1;
     bool any = false;
     for (int g = 0; g < W.G; g++) { mx = std::max(mx, W.grp[g].n); any |= A.mode[g] == 2; }
     dim3 grid((mx + SCAN_TILE - 1) / SCAN_TILE, W.G);
     if (any) hipLaunchKernelGGL(k_clear_count, grid, dim3(SCAN_THREADS), 0, s, W, A, sums);
-    hipLaunchKernelGGL(k_clear_compact, grid, dim3(SCAN_THREADS), 0, s, W, A, sums);
+    hipLaunchKernelGGL(k_clear_compact, grid, dim3(SCAN_THREADS), sizeof(int) * (size_t)M.vh * M.vw, s, W, A, sums, M, counts);
+}
+void launch_mini_norm(hipStream_t s, const WorldView &Wn, const MiniArgs &M, int *counts) {
+    hipLaunchKernelGGL(k_mini_norm, dim3((Wn.G * M.vh * M.vw + 255) / 256), dim3(256), 0, s, Wn, M, counts);
 }
 void launch_step_solo(hipStream_t s, const WorldView &W, const SoloStep &S) {
     hipLaunchKernelGGL(k_step_solo, dim3(1), dim3(SOLO_STEP_THREADS), solo_step_lds(W, S), s, W, S);
@@ -2978,8 +3034,13 @@ bool solo_step_allow_lds(size_t bytes) {   // dynamic LDS above the default limi
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_solo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_solo_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
-void launch_clear_finish(hipStream_t s, const WorldView &Wn, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab) {
-    hipLaunchKernelGGL(k_clear_finish, grid_all(Wn, 256), dim3(256), 0, s, Wn, A, gtab, ttab);
+void launch_clear_finish(hipStream_t s, const WorldView &Wn, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab, const MiniArgs &M, int *counts) {
+    dim3 grid = grid_all(Wn, 256);
+    const bool fold = M.vh > 0 && (long long)grid.x * 256 >= (long long)Wn.G * M.vh * M.vw;   // the normalisation rides in the blocks of group 0
+    MiniArgs Mf = M;
+    if (!fold) Mf.vh = 0;
+    hipLaunchKernelGGL(k_clear_finish, grid, dim3(256), 0, s, Wn, A, gtab, ttab, Mf, counts);
+    if (M.vh > 0 && !fold) launch_mini_norm(s, Wn, M, counts);
 }
 
 }  // namespace magent_amd

@@ -131,7 +131,6 @@ void launch_turn_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, 
 void launch_turn_apply(hipStream_t s, const WorldView &W);
 void launch_movg_sweep(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag);
 void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
-void launch_move_jump(hipStream_t s, const WorldView &W, const GroupDev *gtab, int flag);
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab);
 void launch_rule(hipStream_t s, const WorldView &W, const RuleArgs &A);
 void launch_rules(hipStream_t s, const WorldView &W, const RuleArgs *rules, int n, const RuleProg *progs, const GroupDev *gtab);
@@ -146,8 +145,12 @@ struct ClearArgs {
     typedef AltArrays Alt;
     Alt dst[MAXG];
 };
-void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A, int *sums);
-void launch_clear_finish(hipStream_t s, const WorldView &Wnew, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab);
+void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A, int *sums, const MiniArgs &M, int *counts);
+void launch_clear_finish(hipStream_t s, const WorldView &Wnew, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab, const MiniArgs &M, int *counts);
+// clear_dead's own minimap histogram (large worlds): MINI_COPIES copies of [G][VHW] counts, behind the ordinary histogram's
+// [MAXG left-out counters][G][VHW] in the same buffer
+constexpr int MINI_COPIES = 16;
+void launch_mini_norm(hipStream_t s, const WorldView &Wnew, const MiniArgs &M, int *counts);
 void launch_clear_solo_all(hipStream_t s, const WorldView &W, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab, const MiniArgs &M);
 bool compact_is_solo(int n);
 bool attack_lds_ok(int kmax);
@@ -157,7 +160,13 @@ bool solo_step_allow_lds(size_t bytes);
 void launch_init_reward(hipStream_t s, const WorldView &W, int g);
 void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D, int new_n, int *sums);
 
-constexpr int SCAN_TILE_HOST = 256 * 8;  // must equal SCAN_TILE in kernels.hip
+// agents per workgroup of the scan-based passes (set_action, clear_dead).  2 per thread: at 400k agents that is 782 workgroups --
+// the earlier 8 per thread left 196, less than one per CU, and every such launch was bound by its own latency chain
+#ifndef MAGENT_SCAN_ITEMS
+#define MAGENT_SCAN_ITEMS 2
+#endif
+constexpr int SCAN_ITEMS_HOST = MAGENT_SCAN_ITEMS;
+constexpr int SCAN_TILE_HOST = 256 * SCAN_ITEMS_HOST;
 constexpr int ATTACK_KMAX_HOST = 32;     // attack offsets of all groups share one 32-bit word per cell
 
 }  // namespace magent_amd

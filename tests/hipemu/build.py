@@ -37,7 +37,10 @@ def build(force=False):
     obj = os.path.join(OUT, "emu_runtime.o")
     subprocess.check_call([CXX] + FLAGS + ["-c", os.path.join(HERE, "emu_runtime.cc"), "-o", obj])
     objs.append(obj)
-    subprocess.check_call([CXX, "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-Bsymbolic", "-lpthread"])
+    # (linked beside the target and renamed over it: a test process that has the old library mapped keeps its own copy)
+    tmp = LIB + ".%d.tmp" % os.getpid()
+    subprocess.check_call([CXX, "-shared", "-fPIC", "-o", tmp] + objs + ["-Wl,-Bsymbolic", "-lpthread"])
+    os.replace(tmp, LIB)
     return LIB
 
 
