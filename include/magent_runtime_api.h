@@ -49,10 +49,11 @@ int env_reset(EnvHandle game);
  * buffer[0] = view   float[n][view_h][view_w][n_channel], buffer[1] = feature float[n][feature_size] */
 int env_get_observation(EnvHandle game, GroupHandle group, float **buffer);
 /* runtime_api.h:28 -> GridWorld::set_action (GridWorld.cc:403-454); actions int32[n].
- * One deliberate strictness: a SECOND set_action for the same group before env_step is FATAL.  The reference appends
- * the second call's actions to the same lists and would execute both for every agent (two moves, two attacks); no
- * caller in the reference does that, and reproducing it would put a variable-length action list per agent on the hot
- * path.  An action outside [0, n_action) is FATAL too (checked on the device, reported at env_step). */
+ * A SECOND set_action for the same group before env_step appends, as in the reference: every agent of the group then acts once per
+ * call (two entries in the shuffled attack list, two moves in list order), and last_action is the latest call's.  No caller of the
+ * reference does that, so it is served off the hot path: the step runs the reference's sequential loops on one lane of the device
+ * (exact, about a microsecond per list entry) -- for one-cell bodies without turn_mode, food_mode and goals; other games still
+ * abort with a message.  An action outside [0, n_action) is reported at env_step (FATAL; the reference indexes out of range). */
 int env_set_action(EnvHandle game, GroupHandle group, const int *actions);
 /* runtime_api.h:29 -> GridWorld::step (GridWorld.cc:456-631) */
 int env_step(EnvHandle game, int *done);

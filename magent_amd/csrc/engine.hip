@@ -944,6 +944,12 @@ void Env::reset() {
     enter();
     HIP_OK(hipStreamSynchronize(stream));
     id_counter = 0;
+    for (auto &c : serial_calls) if (c.actions) { int *buf = const_cast<int *>(c.actions); dfree(arena, buf); }
+    serial_calls.clear(); step_calls.clear(); serial_calls_on = false;
+    // a fresh episode starts with two pairs of optimistic attack rounds: the first steps of a dense placement hold the deepest
+    // dependency chains (measured at 2 x 400k: one pair runs out once in the first few steps, two never did), and a step that runs
+    // out costs a host round trip; the budget falls back to one pair after 64 steps that did not need the second
+    boost_attack = 64;
     file_ct++; frame_ct = 0;   // RenderGenerator::next_file (GridWorld.cc:97)
     large_map_mode = width * height > 99 * 99;
     const int n_sep = large_map_mode ? (width * height > 1000 * 1000 ? 16 : 8) : 1;
@@ -1290,7 +1296,7 @@ void Env::observe_device(int g, float *view, float *feat, bool cells16) {
         fatal("get_observation (bf16 cells): needs at most 7 channels (this game has %d) and a 16-byte aligned buffer", n_channel());
     use_device();
     if (groups[g].n == 0) return;   // the reference dereferences agents[0] here (UB); nothing to write for n = 0
-    if (groups[g].acted) {          // set_action came first: the feature rows show the new last_action (GridWorld.cc:386-396)
+    if (groups[g].acted && !serial_calls_on) {   // set_action came first: the feature rows show the new last_action (GridWorld.cc:386-396)
         join_side();
         GroupDev G = groups[g].cur; G.n = groups[g].n;
         launch_commit_action(stream, G, groups[g].tdev);
@@ -1332,8 +1338,13 @@ void Env::set_action_device(int g, const int *d_act) {
     if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in set_action : %d", g);
     use_device();
     HostGroup &G = groups[g];
-    if (G.acted) fatal("set_action called twice for group %d before step: the reference would execute both action lists; unsupported", g);
+    if (G.acted || serial_calls_on) {   // a group is given actions again before the step: the reference appends (GridWorld.cc:403-454)
+        serial_add_call(g, d_act);
+        G.acted = true;
+        return;
+    }
     G.acted = true;
+    step_calls.push_back(g);
     if (G.n == 0) return;
     int nb = (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
     if ((size_t)nb > sums_cap) { enter(); grow(arena, d_sums, sums_cap, (size_t)nb, stream); }
@@ -1341,6 +1352,57 @@ void Env::set_action_device(int g, const int *d_act) {
     ProfScope p(*this, "set_action", false, s);
     launch_set_action(s, view(), g, d_act, move_seq_base, d_sums);
     move_seq_base += G.n;
+}
+
+// Repeated set_action inside one step.  From the first repetition on every call of the step is kept as a list of (group, saved copy
+// of the actions) in call order -- the earlier calls' actions are recovered from the pending actions they left -- and the step runs
+// the reference's sequential loops on the device (k_step_serial).
+void Env::serial_add_call(int g, const int *d_act) {
+    if (turn_mode || food_mode || any_absorb || any_multicell)
+        fatal("set_action called twice for group %d before step: the reference would execute both action lists; this engine does that for "
+              "one-cell bodies without turn_mode, food_mode and goals only", g);
+    enter();
+    auto keep = [&](int gg, const int *src, bool from_pend) {
+        HostGroup &G = groups[gg];
+        int *buf = nullptr;
+        if (G.n > 0) {
+            HIP_OK(dev_malloc(arena, &buf, sizeof(int) * (size_t)G.n));
+            GroupDev D = G.cur; D.n = G.n;
+            if (from_pend) launch_pend_to_actions(stream, D, G.tdev, buf);
+            else HIP_OK(hipMemcpyAsync(buf, src, sizeof(int) * (size_t)G.n, hipMemcpyDeviceToDevice, stream));
+            // Agent::set_action stores last_action at once (GridWorld.h:176-178): an observation asked for before the step shows the latest call
+            HIP_OK(hipMemcpyAsync(G.cur.last_action, buf, sizeof(int) * (size_t)G.n, hipMemcpyDeviceToDevice, stream));
+        }
+        serial_calls.push_back({gg, buf});
+    };
+    if (!serial_calls_on) {
+        serial_calls_on = true;
+        for (int gg : step_calls) keep(gg, nullptr, true);
+    }
+    keep(g, d_act, false);
+}
+
+void Env::serial_step() {
+    WorldView W = view();
+    size_t entries = 0;
+    for (auto &c : serial_calls) entries += (size_t)groups[c.g].n;
+    int2 *alist = nullptr; int4 *mlist = nullptr, *msorted = nullptr; SerialCall *d_calls = nullptr;
+    HIP_OK(dev_malloc(arena, &alist, sizeof(int2) * (entries + 1)));
+    HIP_OK(dev_malloc(arena, &mlist, sizeof(int4) * (entries + 1)));
+    HIP_OK(dev_malloc(arena, &msorted, sizeof(int4) * (entries + 1)));
+    HIP_OK(dev_malloc(arena, &d_calls, sizeof(SerialCall) * serial_calls.size()));
+    HIP_OK(hipMemcpyAsync(d_calls, serial_calls.data(), sizeof(SerialCall) * serial_calls.size(), hipMemcpyHostToDevice, stream));
+    const int n_sep = large_map_mode ? (width + bandwidth - 1) / bandwidth : 0;
+    if (n_sep >= 39) fatal("internal: too many move stripes for the serial step");
+    push_rng();
+    launch_step_serial(stream, W, d_calls, (int)serial_calls.size(), alist, mlist, msorted, n_sep);
+    if (!rules_on_host) launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
+    launch_step_report(stream, d_counters, h_rec, ++step_seq, (int)groups.size());
+    HIP_OK(hipStreamSynchronize(stream));    // (the slow path: the scratch goes back at once)
+    dfree(arena, alist); dfree(arena, mlist); dfree(arena, msorted); dfree(arena, d_calls);
+    for (auto &c : serial_calls) if (c.actions) { int *buf = const_cast<int *>(c.actions); dfree(arena, buf); }
+    serial_calls.clear();
+    serial_calls_on = false;
 }
 
 void Env::set_action_host(int g, const int *actions) {
@@ -1498,10 +1560,17 @@ void Env::step_begin() {
     step_was_fast = false;
     step_was_solo = false;
 
-    const bool beside = total_n > 0 && fast && side_wanted() && overlap_level >= 2;   // the read-only head of the step goes beside the renders
+    const bool beside = total_n > 0 && fast && side_wanted() && overlap_level >= 2 && !serial_calls_on;   // the read-only head of the step goes beside the renders
     if (!beside) join_side();
+    step_calls.clear();
     if (total_n == 0) {
         enqueue_counters();
+    } else if (serial_calls_on) {
+        // ---------------- some group was given actions more than once: the reference's sequential loops, on the device
+        claim_clean = false;
+        step_was_fast = true;                    // (reports through the pinned record like the single-sync driver)
+        step_live_paint = live_paint_now = false;   // the painted map is rebuilt by the next observation
+        serial_step();
     } else if (solo_ok(total_n)) {
         // ---------------- one launch for the whole step
         step_was_solo = true;
@@ -1687,6 +1756,7 @@ void Env::step_end(int *done) {
             WorldView W = view();
             const int phase = c[CTR_OPEN_ATTACK] ? 1 : 2;
             fallback_steps++;
+            if (phase == 1) fallback_attack++; else fallback_move++;
             if (phase == 1) boost_attack = 64; else boost_move = 64;   // deeper dependency chains around: one more batch
             HIP_OK(hipMemsetAsync(d_counters + CTR_OPEN_ATTACK, 0, 2 * sizeof(int), stream));   // both phase flags
             clear_changed();
@@ -1861,6 +1931,10 @@ void Env::cycle(int n_group, float *const *view, float *const *feat, const int *
         step(done);
         for (int g = 0; g < NG; g++) if (rewards && rewards[g]) get_reward_device(g, rewards[g]);
         clear_dead();
+        // env_cycle_many promises finished outputs at return (the two-launch form waits for its step record, published after
+        // everything else): here the rewards and the compaction are still queued -- wait for them (microseconds against a
+        // large world's cycle)
+        HIP_OK(hipStreamSynchronize(stream));
         return;
     }
     {
@@ -2082,6 +2156,7 @@ void Env::info_host(int g, const char *name, void *buf) {
     if (k == "num") { need_group(); ib[0] = groups[g].n; return; }
     if (k == "engine_stats") {   // additive: steps whose optimistic rounds ran out (host continued), rounds of the last checked phases
         ib[0] = fallback_steps; ib[1] = last_attack_iters; ib[2] = last_move_iters; ib[3] = attack_round;
+        ib[4] = fallback_attack; ib[5] = fallback_move;      // (which phase's optimistic rounds ran out)
         return;
     }
     if (k == "batch_host_us") {  // additive (tuning): host microseconds per env_cycle_many round since the last read:

@@ -157,7 +157,7 @@ public:
     int render_unroll = 1;
     bool host_shuffle = false;
     int move_jump_batch = 3;
-    int last_attack_iters = 0, last_move_iters = 0, fallback_steps = 0;
+    int last_attack_iters = 0, last_move_iters = 0, fallback_steps = 0, fallback_attack = 0, fallback_move = 0;
     bool checked_step = false;            // host-checked convergence instead of the single-sync driver
     // optimistic rounds of the single-sync driver: one pair / batch, two for 64 steps after a run-out (or fixed by env)
     int opt_attack_pairs = 1, opt_move_batches = 1, boost_attack = 0, boost_move = 0;
@@ -196,6 +196,11 @@ private:
     void enqueue_counters();
     bool step_pending = false, step_was_fast = false, step_was_solo = false, step_live_paint = false, live_paint_now = false;
     bool solo_ok(int total_n);
+    void serial_add_call(int g, const int *d_act);
+    void serial_step();
+    std::vector<SerialCall> serial_calls;   // the calls of a step in which a group was given actions twice (k_step_serial)
+    std::vector<int> step_calls;            // groups given actions in this step, in call order
+    bool serial_calls_on = false;
     MiniArgs next_minimap();
     int *fold_counts();
     bool cycle_eligible(int n_group, float *const *view, float *const *feat, int *first_obs_out);

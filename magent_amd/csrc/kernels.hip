@@ -2844,6 +2844,124 @@ void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &
     hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, B.j, B.head, B.first, B.link, hitbits, ncell, powtab);
     hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, B.j, B.head, B.first, B.link, rank);
 }
+// ================================================================================================ repeated set_action: the literal loop
+// GridWorld::set_action APPENDS to the step's action lists (GridWorld.cc:403-454): a group that is given actions twice before a step
+// has every agent act twice -- two entries in the shuffled attack list, two moves in list order, the second from wherever the first
+// one ended.  The parallel phases above rest on "one pending action per agent"; no caller of the reference does this, so the case
+// is served by the reference's own sequential loops on ONE lane of the device, exact by construction and slow (about a microsecond
+// per list entry).  One-cell bodies without turn_mode, food_mode and goals; everything else still refuses.
+//   attack loop GridWorld.cc:464-507 (Map::get_attack_obj Map.cc:209-252, Map::do_attack Map.cc:255-310, Agent::be_attack
+//   GridWorld.h:203-209), starve GridWorld.cc:519-542, moves GridWorld.cc:574-613 (Map::do_move Map.cc:313-358)
+__global__ void __launch_bounds__(64) k_step_serial(WorldView W, const SerialCall *calls, int n_calls, int2 *alist, int4 *mlist, int4 *msorted, int n_sep) {
+    if (threadIdx.x != 0) return;
+    const int bandwidth = W.bandwidth;
+    int A = 0, M = 0;
+    // ---- the lists, in call order (Agent::set_action stores last_action at once: the last call wins)
+    for (int c = 0; c < n_calls; c++) {
+        const int g = calls[c].g;
+        const GroupDev &G = W.grp[g];
+        const TypeDev &T = W.type[g];
+        const int *act = calls[c].actions;
+        for (int i = 0; i < G.n; i++) {
+            const int a = act[i];
+            if (a < 0 || a >= T.n_move + T.n_attack) { W.counters[CTR_BAD_ACTION] = 1; continue; }
+            G.last_action[i] = a;
+            if (a < T.n_move) {
+                int list = n_sep;                                            // the boundary list runs last
+                if (W.large_map) { const int x_ = G.x[i] % bandwidth; if (!(x_ < 4 || x_ > bandwidth - 4)) list = G.x[i] / bandwidth; }
+                mlist[M++] = make_int4(ref_pack(g, i), a, list, 0);
+            } else alist[A++] = make_int2(ref_pack(g, i), a - T.n_move);
+        }
+    }
+    // ---- shuffle (GridWorld.cc:464-468): minstd_rand0, (int)rng() % (i + 1)
+    unsigned long long x = (unsigned)W.counters[CTR_RNG];
+    for (int i = 0; i < A; i++) {
+        x = x * 16807ull % 2147483647ull;
+        const int j = (int)x % (i + 1);
+        const int2 t = alist[i]; alist[i] = alist[j]; alist[j] = t;
+    }
+    W.counters[CTR_RNG] = (int)x;
+    W.counters[CTR_LAST_A] = A;
+    // ---- attacks, in that order
+    for (int e = 0; e < A; e++) {
+        const int g = ref_group(alist[e].x), i = ref_index(alist[e].x), k = alist[e].y;
+        const GroupDev &G = W.grp[g];
+        const TypeDev &T = W.type[g];
+        if (G.dead[i]) continue;
+        const int2 d = W.delta[T.attack_off + k];
+        const int tx = G.x[i] + d.x, ty = G.y[i] + d.y;
+        int o = OCC_EMPTY;
+        if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) o = W.occ[ty * W.w + tx];
+        if (o < 0 || (!T.attack_in_group && ref_group(o) == g)) { G.next_reward[i] += T.attack_penalty; continue; }
+        const int tg = ref_group(o), ti = ref_index(o);
+        const GroupDev &V = W.grp[tg];
+        const TypeDev &TV = W.type[tg];
+        float reward = 0.0f;
+        V.hp[ti] -= T.damage;
+        if (V.hp[ti] < 0.0f) { V.dead[ti] = 1; V.next_reward[ti] = TV.dead_penalty; }
+        if (V.dead[ti]) {
+            G.last_op[i] = OP_KILL; G.op_obj[i] = o;
+            W.occ[V.y[ti] * W.w + V.x[ti]] = OCC_EMPTY;
+            W.counters[dead_slot(tg, 0)] += 1;
+            G.hp[i] = fminf(T.hp, G.hp[i] + TV.kill_supply);
+            reward = TV.kill_reward;
+        } else { G.last_op[i] = OP_ATTACK; G.op_obj[i] = o; }
+        G.next_reward[i] += reward + T.attack_penalty;
+    }
+    // ---- starve / recover
+    for (int g = 0; g < W.G; g++) {
+        const GroupDev &G = W.grp[g];
+        const TypeDev &T = W.type[g];
+        for (int i = 0; i < G.n; i++) {
+            if (G.dead[i]) continue;
+            if (T.step_recover > 0) G.hp[i] = fminf(T.hp, G.hp[i] + T.step_recover);
+            else {
+                G.hp[i] -= -T.step_recover;
+                if (G.hp[i] < 0.0f) {
+                    G.dead[i] = 1; G.next_reward[i] = T.dead_penalty;
+                    W.occ[G.y[i] * W.w + G.x[i]] = OCC_EMPTY;
+                    W.counters[dead_slot(g, 0)] += 1;
+                }
+            }
+        }
+    }
+    // ---- moves: stripe lists 0 .. n_sep - 1, then the boundary list, each in insertion order (a stable counting sort by list)
+    int start[40];
+    for (int l = 0; l <= n_sep; l++) start[l] = 0;
+    for (int e = 0; e < M; e++) start[mlist[e].z]++;
+    for (int l = 0, run = 0; l <= n_sep; l++) { const int c = start[l]; start[l] = run; run += c; }
+    for (int e = 0; e < M; e++) msorted[start[mlist[e].z]++] = mlist[e];
+    for (int e = 0; e < M; e++) {
+        const int g = ref_group(msorted[e].x), i = ref_index(msorted[e].x);
+        const GroupDev &G = W.grp[g];
+        const TypeDev &T = W.type[g];
+        if (G.dead[i]) continue;
+        const int2 d = W.delta[T.move_off + msorted[e].y];
+        const int nx = G.x[i] + d.x, ny = G.y[i] + d.y;
+        if (nx < 0 || ny < 0 || nx + 1 >= W.w || ny + 1 >= W.h) continue;     // Map::is_blank_area's bounds; no collide object out there
+        const int c = ny * W.w + nx;
+        const int o = W.occ[c];
+        if (o == OCC_EMPTY || o == ref_pack(g, i)) {
+            W.occ[G.y[i] * W.w + G.x[i]] = OCC_EMPTY;
+            W.occ[c] = ref_pack(g, i);
+            G.x[i] = nx; G.y[i] = ny;
+        } else if (o >= 0) { G.last_op[i] = OP_COLLIDE; G.op_obj[i] = o; }    // Map::get_collide: agents only (walls are no objects)
+    }
+    // ---- the step's pending actions are consumed
+    for (int g = 0; g < W.G; g++) for (int i = 0; i < W.grp[g].n; i++) W.grp[g].pend[i] = PEND_NONE;
+}
+// the actions a group's pending actions came from (the first call of a step, when a second one follows)
+__global__ void __launch_bounds__(256) k_pend_to_actions(GroupDev G, TypeDev T, int *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < G.n) out[i] = G.pend[i] == PEND_NONE ? T.n_move + T.n_turn + T.n_attack : pend_action(G.pend[i], T);   // (an action outside the space stays one)
+}
+void launch_step_serial(hipStream_t s, const WorldView &W, const SerialCall *calls, int n_calls, int2 *alist, int4 *mlist, int4 *msorted, int n_sep) {
+    hipLaunchKernelGGL(k_step_serial, dim3(1), dim3(64), 0, s, W, calls, n_calls, alist, mlist, msorted, n_sep);
+}
+void launch_pend_to_actions(hipStream_t s, const GroupDev &G, const TypeDev &T, int *out) {
+    if (G.n > 0) hipLaunchKernelGGL(k_pend_to_actions, dim3((G.n + 255) / 256), dim3(256), 0, s, G, T, out);
+}
+
 void launch_step_report(hipStream_t s, int *counters, StepRecord *rec, int seq, int NG) {
     hipLaunchKernelGGL(k_step_report, dim3(1), dim3(64), 0, s, counters, rec, seq, NG);
 }

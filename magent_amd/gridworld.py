@@ -462,8 +462,8 @@ class GridWorld(object):
 
     def engine_stats(self):
         """additive: (steps finished by the host-checked driver, attack rounds, move rounds of the last such step, attack
-        rounds launched in the last step)"""
-        buf = np.zeros(4, dtype=np.int32)
+        rounds launched in the last step, steps whose ATTACK rounds ran out, steps whose MOVE rounds ran out)"""
+        buf = np.zeros(6, dtype=np.int32)
         self._lib.env_get_info(self.game, 0, b"engine_stats", buf.ctypes.data)
         return tuple(int(v) for v in buf)
 
@@ -669,17 +669,16 @@ class EnvBatch(object):
         """each argument: list (per env) of lists (per group) of CUDA tensors or None, or the result of pointers();
         returns the done flags.
 
-        Stream contract: the library enqueues on the environments' own HIP streams.  With `order_streams` (default on) every
-        environment's stream is first ordered after torch's current stream (the producers of `actions`, readers of the output
-        tensors) and torch's current stream after the cycle, stream to stream -- a torch consumer of `rewards` or the views
-        needs nothing else.  Callers that manage their own streams switch it off (EnvBatch.order_streams = False)."""
+        Stream contract.  Outputs: the call returns after the host has seen every environment's step record, which the step
+        kernel publishes behind an agent-scope release and a workgroup barrier -- rewards, observations and the compacted state
+        are complete in device memory, and a kernel launched afterwards on ANY stream sees them (no stream ordering needed;
+        measured: an event pair per cycle costs a 4000-agent world 30 us of its 110).  Inputs: the library reads `actions` on
+        the environments' own streams; with `order_streams` (default on) those streams are first ordered after torch's current
+        stream, the producer of the actions, stream to stream.  Callers that synchronise themselves switch it off."""
         if self.order_streams:
             for e in self._distinct():
                 e.order_after_torch()
         self._cycle_raw(views, feats, actions, rewards)
-        if self.order_streams:
-            for e in self._distinct():
-                e.order_torch_after()
         return [bool(d) for d in self._done]
 
     def _distinct(self):

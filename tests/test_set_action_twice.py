@@ -1,0 +1,78 @@
+"""A group that is given actions more than once before a step.
+
+GridWorld::set_action appends to the step's action lists (/root/reference/src/gridworld/GridWorld.cc:403-454): every agent of
+such a group acts once per call -- two entries in the shuffled attack list, two moves in list order, the second from wherever
+the first one ended; `last_action` is the latest call's.  Rounds 1-2 refused this; the engine now serves it with the
+reference's own sequential loops on one lane of the device (k_step_serial: exact by construction, slow, taken only when it
+happens).  Pinned three ways: compiled reference == oracle (here, when oracle/_ref is present), oracle == the HIP sources on
+the emulator (here), oracle == the HIP engine (GPU)."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+PATTERNS = [[(0, 1, 0)], [(0, 0, 1, 1)], [(1, 0, 1, 0, 1)], [(0, 1), (0, 1, 1), (0, 0), (1,)]]   # groups given actions, per step (cycled)
+WORLDS = ((20, 60), (45, 400), (120, 1500))     # (map size, agents per group); 120 > 99: large_map_mode, moves run stripe by stripe
+
+
+def play(lib, map_size, n, steps, seed, pattern):
+    env = H.gridworld("battle", lib=lib, map_size=map_size)
+    env.set_seed(seed)
+    env.reset()
+    hs = env.get_handles()
+    for h in hs:
+        env.add_agents(h, "random", n=n)
+    rs = np.random.RandomState(seed)
+    out = []
+    for step in range(steps):
+        rec = {}
+        order = pattern[step % len(pattern)]
+        for k, g in enumerate(order):
+            env.set_action(hs[g], rs.randint(21, size=env.get_num(hs[g])).astype(np.int32))
+            if k == len(order) - 1:      # observed BEFORE the step: the feature rows show the latest call's action
+                for gg, hh in enumerate(hs):
+                    if env.get_num(hh):
+                        rec["view%d" % gg], rec["feat%d" % gg] = [a.copy() for a in env.get_observation(hh)]
+        rec["done"] = np.array([env.step()])
+        for gg, hh in enumerate(hs):
+            rec["reward%d" % gg] = env.get_reward(hh)
+            rec["alive%d" % gg] = env.get_alive(hh).astype(np.uint8)
+            rec["pos%d" % gg] = env.get_pos(hh)
+        env.clear_dead()
+        for gg, hh in enumerate(hs):
+            if env.get_num(hh):
+                rec["view_after%d" % gg] = env.get_observation(hh)[0].copy()
+        out.append(rec)
+    return out
+
+
+@pytest.mark.parametrize("world", WORLDS, ids=lambda w: "map%d" % w[0])
+def test_repeated_set_action_oracle_is_the_reference_and_the_kernels_are_the_oracle(world):
+    emu = H.ensure_emu()
+    for pi, pat in enumerate(PATTERNS):
+        want = play(H.ensure_oracle(), world[0], world[1], 6, 3 + pi, pat)
+        if H.have_ref():
+            H.assert_same(play(H.REF_LIB, world[0], world[1], 6, 3 + pi, pat), want, "reference vs oracle, pattern %d" % pi)
+        H.assert_same(want, play(emu, world[0], world[1], 6, 3 + pi, pat), "oracle vs emulated kernels, pattern %d" % pi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", WORLDS + ((300, 20000),), ids=lambda w: "map%d" % w[0])
+def test_repeated_set_action_on_the_gpu(world):
+    for pi, pat in enumerate(PATTERNS):
+        H.assert_same(play(H.ensure_oracle(), world[0], world[1], 5, 3 + pi, pat), play(H.HIP_LIB, world[0], world[1], 5, 3 + pi, pat),
+                      "oracle vs HIP engine, pattern %d" % pi)
+
+
+@pytest.mark.gpu
+def test_repeated_set_action_is_still_refused_where_the_serial_step_does_not_reach():
+    """bodies larger than one cell (pursuit's predators): a clear message and an abort, not an approximation"""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, helpers as H\n"
+            "env = H.gridworld('pursuit', lib=H.HIP_LIB, map_size=30); env.reset(); hs = env.get_handles()\n"
+            "for h in hs: env.add_agents(h, 'random', n=10)\n"
+            "a = np.zeros(10, dtype=np.int32)\n"
+            "env.set_action(hs[0], a); env.set_action(hs[0], a)\n") % (H.ROOT, H.ROOT + "/tests")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "one-cell bodies" in p.stderr

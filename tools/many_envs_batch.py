@@ -22,6 +22,7 @@ feats = [[torch.empty((N, 34), device=dev) for _ in range(2)] for _ in envs]
 rews = [[torch.empty(N, device=dev) for _ in range(2)] for _ in envs]
 acts = [[[torch.randint(21, (N,), dtype=torch.int32, device=dev) for _ in range(2)] for _ in envs] for _ in range(4)]
 batch = magent_amd.EnvBatch(envs, n_threads=T)
+batch.order_streams = os.environ.get("ORDER_STREAMS", "0") == "1"   # (this loop orders by env.sync(): no torch work touches the buffers in between)
 us = np.zeros(4, dtype=np.float32)
 view_p, feat_p, rew_p = batch.pointers(views), batch.pointers(feats), batch.pointers(rews)      # fixed buffers: pointer arrays built once (the tensors stay alive)
 act_ptrs = [batch.pointers(a) for a in acts]
