@@ -269,6 +269,9 @@ Env::Env() {
     if (const char *v = std::getenv("MAGENT_SOLO_STEP")) solo_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("MAGENT_OVERLAP")) { overlap_level = std::atoi(v); overlap_enabled = overlap_level != 0; }
     if (const char *v = std::getenv("MAGENT_SOLO_MAX")) solo_max_agents = std::max(0, std::atoi(v));
+    // the next step's shuffle draws a step ahead (Env::draw_ahead): 0 off (default: measured slower, profiles/r03_summary.md) | 1 beside the
+    // step's own phases, large worlds | 2 the same for every world (tests) | 3 beside the next observation render
+    if (const char *v = std::getenv("MAGENT_DRAW_AHEAD")) { const int m = std::atoi(v); ahead_enabled = m != 0; if (m == 2) ahead_min = 0; ahead_at_render = m == 3; }
 }
 
 template <class T>
@@ -280,6 +283,7 @@ Env::~Env() {
     if (!device_ready) return;
     use_device();
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_state); (void)hipEventDestroy(ev_side); }
+    if (pre_stream) { (void)hipStreamSynchronize(pre_stream); (void)hipStreamDestroy(pre_stream); (void)hipEventDestroy(ev_chased); (void)hipEventDestroy(ev_drawn); }
     (void)hipStreamSynchronize(stream);
     for (auto &g : groups) free_group(g);
     dfree(arena, d_occ); dfree(arena, d_viewcell); dfree(arena, d_claim); dfree(arena, d_food); dfree(arena, d_powtab); dfree(arena, d_counters); dfree(arena, d_gtab); dfree(arena, d_ttab);
@@ -1285,7 +1289,8 @@ bool Env::prepare_render(int g, const WorldView &W, RenderArgs &R, RenderPlan &P
     const bool aligned = (((uintptr_t)view) & 15) == 0, feat_aligned = (((uintptr_t)feat) & 15) == 0;
     // the feature rows ride in the render launch (its trailing workgroups) when both pointers have the same alignment
     const unsigned feat_q = (unsigned)R.n * (unsigned)R.F / 4;
-    P.feat_blocks = aligned == feat_aligned ? (int)std::min<unsigned>((feat_q + 255) / 256 + 1, 16384) : 0;
+    static const bool feat_separate = std::getenv("MAGENT_FEAT_SEPARATE") && std::atoi(std::getenv("MAGENT_FEAT_SEPARATE")) != 0;   // (tuning)
+    P.feat_blocks = (aligned == feat_aligned && !feat_separate) ? (int)std::min<unsigned>((feat_q + 255) / 256 + 1, 16384) : 0;
     return aligned;
 }
 
@@ -1302,6 +1307,7 @@ void Env::observe_device(int g, float *view, float *feat, bool cells16) {
         launch_commit_action(stream, G, groups[g].tdev);
     }
     mark_state();                   // (the side stream waits for the world as it is before this render, not for the render)
+    if (ahead_pending > 0) { draw_ahead(ahead_pending); ahead_pending = 0; }   // (MAGENT_DRAW_AHEAD=3: the next step's draws beside this render)
     WorldView W = this->view();
     RenderArgs R; RenderPlan P;
     const bool aligned = prepare_render(g, W, R, P, view, feat);
@@ -1433,11 +1439,14 @@ void Env::set_action_host(int g, const int *actions) {
 //     recording attack events, and with MAGENT_HOST_SHUFFLE / MAGENT_CHECKED_STEP for A/B runs).
 void Env::shuffle_buffers(int n_max) {
     grow(arena, d_rank, rank_cap, (size_t)n_max, stream);
-    if ((size_t)n_max * 4 > shuf_cap) {   // four arrays at fixed quarters of the buffer: head | first | j | link
-        grow(arena, d_shuf, shuf_cap, (size_t)n_max * 4, stream);
+    if ((size_t)n_max * 4 > shuf_cap) {   // two sets (this step's shuffle | the next step's, drawn ahead) of four arrays each: head | first | j | link
+        drop_ahead();
+        size_t total = shuf_cap * 2;
+        grow(arena, d_shuf, total, (size_t)n_max * 8, stream);
+        shuf_cap = total / 2;
         shuf_cap -= shuf_cap % 4;
         // head and first are kept zero between steps (k_attack_rank clears what a step used)
-        HIP_OK(hipMemsetAsync(d_shuf, 0, sizeof(int) * (shuf_cap / 4) * 2, stream));
+        HIP_OK(hipMemsetAsync(d_shuf, 0, sizeof(int) * shuf_cap * 2, stream));
     }
     int nb = (n_max + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
     grow(arena, d_sums, sums_cap, (size_t)nb, stream);
@@ -1456,15 +1465,48 @@ void Env::shuffle_buffers(int n_max) {
     }
 }
 
-ShuffleBufs Env::shuffle_bufs() const {
+ShuffleBufs Env::shuffle_bufs(int set) const {
+    if (set < 0) set = shuf_set;
     const size_t seg = shuf_cap / 4;
-    return ShuffleBufs{d_shuf, d_shuf + seg, d_shuf + 2 * seg, d_shuf + 3 * seg};
+    int *base = d_shuf + (size_t)set * shuf_cap;
+    return ShuffleBufs{base, base + seg, base + 2 * seg, base + 3 * seg};
 }
 
 void Env::push_rng() {
     if (rng_on_device) return;
+    drop_ahead();                        // (draws made ahead used the device's old state)
     launch_set_rng(stream, d_counters, (unsigned)rng.x);
     rng_on_device = true;
+}
+
+// ---- the next step's shuffle draws, made a step ahead (single-sync driver, large worlds).
+// The draws j_i depend on the engine's RNG state alone -- not on how many agents will attack, nor on the world -- and the state
+// after this step is known as soon as k_shuffle_chase has run.  So the ~27 us of list building (two device-scope atomics per list
+// entry) leave the critical path: right behind the chase, the draws for EVERY agent (an upper bound of the next attack list) go to
+// a stream of their own, into the other scratch set, beside this step's latency-bound attack and move phases; the next step waits
+// for an event and launches the chase alone (it skips the steps beyond its list's length).  Anything that changes the RNG state
+// or lets the list outgrow the draws (set_seed, reset, add_agents, a step of another driver) drops them.
+void Env::draw_ahead(int n_entries) {
+    if (!ahead_enabled || n_entries < ahead_min) return;
+    use_device();
+    if (!pre_stream) {
+        HIP_OK(hipStreamCreateWithFlags(&pre_stream, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&ev_chased, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&ev_drawn, hipEventDisableTiming));
+    }
+    HIP_OK(hipEventRecord(ev_chased, stream));
+    HIP_OK(hipStreamWaitEvent(pre_stream, ev_chased, 0));
+    launch_shuffle_ahead(pre_stream, n_entries, d_counters, shuffle_bufs(shuf_set ^ 1), d_powtab);
+    HIP_OK(hipEventRecord(ev_drawn, pre_stream));
+    ahead_valid = true; ahead_n = n_entries;
+}
+void Env::drop_ahead() {
+    if (!ahead_valid) return;
+    ahead_valid = false;
+    use_device();
+    HIP_OK(hipStreamWaitEvent(stream, ev_drawn, 0));           // the lists of the unused draws go back to zero
+    const ShuffleBufs B = shuffle_bufs(shuf_set ^ 1);
+    HIP_OK(hipMemsetAsync(B.head, 0, sizeof(int) * (shuf_cap / 4) * 2, stream));
 }
 
 // attack rounds, host-checked: pairs with ONE convergence check per pair (the flag of the second round)
@@ -1567,12 +1609,14 @@ void Env::step_begin() {
         enqueue_counters();
     } else if (serial_calls_on) {
         // ---------------- some group was given actions more than once: the reference's sequential loops, on the device
+        drop_ahead();
         claim_clean = false;
         step_was_fast = true;                    // (reports through the pinned record like the single-sync driver)
         step_live_paint = live_paint_now = false;   // the painted map is rebuilt by the next observation
         serial_step();
     } else if (solo_ok(total_n)) {
         // ---------------- one launch for the whole step
+        drop_ahead();
         step_was_solo = true;
         shuffle_buffers(total_n);
         push_rng();
@@ -1605,9 +1649,20 @@ void Env::step_begin() {
         hipStream_t a = beside ? side_stream() : stream;
         {
             ProfScope p(*this, "attack", false, a);
-            launch_shuffle(a, total_n, d_counters, B, d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
+            int n_drawn = -1;
+            if (ahead_valid && ahead_n >= total_n && a == stream) {     // the draws were made during the last step: the chase alone
+                HIP_OK(hipStreamWaitEvent(stream, ev_drawn, 0));
+                shuf_set ^= 1;
+                n_drawn = ahead_n;
+                ahead_valid = false;
+                launch_shuffle_chase(a, total_n, d_counters, shuffle_bufs(), d_rank, (unsigned *)d_claim, (size_t)width * height);
+            } else {
+                drop_ahead();
+                launch_shuffle(a, total_n, d_counters, shuffle_bufs(), d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
+            }
+            if (a == stream) { if (ahead_at_render) ahead_pending = total_n; else draw_ahead(total_n); }   // (the RNG state of the next step is on the device now)
             if (overlap_level == 2 && a != stream) { join_side(); a = stream; }
-            launch_attack_rank(a, W, d_rank, B, false);
+            launch_attack_rank(a, W, d_rank, shuffle_bufs(), false, n_drawn);
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
             // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
@@ -1641,6 +1696,7 @@ void Env::step_begin() {
         launch_step_report(stream, d_counters, h_rec, ++step_seq, (int)groups.size());
     } else {
         // ---------------- checked driver
+        drop_ahead();
         claim_clean = false;
         HIP_OK(hipMemsetAsync(d_counters + CTR_OPEN_ATTACK, 0, 2 * sizeof(int), stream));
         const int A = read_counters()[CTR_ATTACK];

@@ -218,7 +218,14 @@ private:
     RuleArgs *d_rule_args = nullptr; RuleProg *d_rule_progs = nullptr;
     void shuffle_buffers(int n_max);
     void push_rng();
-    ShuffleBufs shuffle_bufs() const;
+    ShuffleBufs shuffle_bufs(int set = -1) const;
+    void draw_ahead(int n_entries);
+    void drop_ahead();
+    hipStream_t pre_stream = nullptr;       // the next step's shuffle draws run here, beside the step
+    hipEvent_t ev_chased = nullptr, ev_drawn = nullptr;
+    int shuf_set = 0, ahead_n = 0, ahead_min = 65536;
+    bool ahead_valid = false, ahead_enabled = false, ahead_at_render = false;
+    int ahead_pending = 0;
     void attack_rounds_checked(const WorldView &W);
     void move_rounds_checked(const WorldView &W);
     void phase_tail(const WorldView &W, int from);

@@ -742,7 +742,7 @@ __host__ __device__ inline size_t render_fast_lds(int VHW) {
 static bool render_fast_ok(const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4) {
     const int VHW = R.VH * R.VW;
     return vec4 && W.G == 2 && R.minimap && !R.food && R.C == 7 && W.vc_packed && !R.turn && VHW >= 16 && VHW <= 1024 &&
-           P.feat_blocks > 0 && render_fast_lds(VHW) <= 48 * 1024;
+           render_fast_lds(VHW) <= 48 * 1024;
 }
 
 // several groups of a small world in one launch (blockIdx.y = slot): small worlds are bound by the number of launches
@@ -995,36 +995,44 @@ __device__ __forceinline__ unsigned rng_skip(unsigned x, unsigned n) {
     while (n) { if (n & 1u) x = mulmod31(x, base); base = mulmod31(base, base); n >>= 1; }
     return x;
 }
-__device__ __forceinline__ void shuffle_chase_body(int i, const int *j, const int *head, const int *first, const int *link, int *rank) {
+// (A: the length of this step's attack list.  The lists may have been built for MORE entries than that -- the draw of a step can
+// run a step ahead, for every agent, before anybody knows how many will attack (launch_shuffle_ahead): steps k >= A do not exist
+// in this step's shuffle and are skipped; `first` holds the SMALLEST later step per slot, so one that is >= A means there is none)
+__device__ __forceinline__ void shuffle_chase_body(int i, int A, const int *j, const int *head, const int *first, const int *link, int *rank) {
     int p = j[i];
     int nxt = 0x7FFFFFFF;
-    for (int e = head[p]; e != 0; e = link[e - 1]) { const int k = e - 1; if (k > i && k < nxt) nxt = k; }
+    for (int e = head[p]; e != 0; e = link[e - 1]) { const int k = e - 1; if (k > i && k < nxt && k < A) nxt = k; }
     if (nxt != 0x7FFFFFFF) {
         p = nxt;
-        for (int f; (f = first[p]) != 0;) p = 0x7FFFFFFF - f;
+        for (int f; (f = first[p]) != 0;) { const int m = 0x7FFFFFFF - f; if (m >= A) break; p = m; }
     }
     rank[i] = p;
 }
 
-__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *head, int *first, int *link, unsigned *hitbits, size_t ncell,
+// (n_fixed < 0: the draws of THIS step's list, length counters[CTR_ATTACK], and the hit words' zero-fill; n_fixed >= 0: the draws of
+// the NEXT step, for n_fixed entries, on the stream beside the rest of the step -- nothing but the shuffle scratch is touched)
+__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int n_fixed, int *j, int *head, int *first, int *link, unsigned *hitbits, size_t ncell,
                                                      const unsigned *powtab) {
-    const int A = counters[CTR_ATTACK];
+    const int A = n_fixed >= 0 ? n_fixed : counters[CTR_ATTACK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     // the per-cell hit words of the coming attack phase start from zero (they share the move phase's claim array)
-    if (A > 0) for (size_t c = i; c < ncell; c += (size_t)gridDim.x * blockDim.x) hitbits[c] = 0u;
+    if (hitbits && A > 0) for (size_t c = i; c < ncell; c += (size_t)gridDim.x * blockDim.x) hitbits[c] = 0u;
     if (i >= A) return;
     shuffle_draw_body((unsigned)counters[CTR_RNG], i, j, head, first, link, powtab);
 }
 
-__global__ void __launch_bounds__(256) k_shuffle_chase(int *counters, const int *j, const int *head, const int *first, const int *link, int *rank) {
+// (hitbits != null: the draws were made a step ahead -- the zero-fill of the hit words rides here instead)
+__global__ void __launch_bounds__(256) k_shuffle_chase(int *counters, const int *j, const int *head, const int *first, const int *link, int *rank,
+                                                      unsigned *hitbits, size_t ncell) {
     const int A = counters[CTR_ATTACK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (hitbits && A > 0) for (size_t c = i; c < ncell; c += (size_t)gridDim.x * blockDim.x) hitbits[c] = 0u;
     if (i == 0) {   // (every draw has read the old state: k_shuffle_draw ran before)
         counters[CTR_LAST_A] = A;
         counters[CTR_RNG] = (int)rng_skip((unsigned)counters[CTR_RNG], (unsigned)A);   // the host mirror is refreshed by the end-of-step report
     }
     if (i >= A) return;
-    shuffle_chase_body(i, j, head, first, link, rank);
+    shuffle_chase_body(i, A, j, head, first, link, rank);
 }
 
 // ------------------------------------------------------------------------------------------------ attack phase
@@ -1059,14 +1067,16 @@ __device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int 
     }
     if (W.food_mode) { G.eat[i] = -1.0f; G.fcell[i] = -1; }
 }
-__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_head, int *shuf_first) {
+__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_head, int *shuf_first, int n_drawn) {
     if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // attack rounds start
     const int A = W.counters[CTR_ATTACK];
-    if (A == 0) return;
-    // the shuffle's list heads and first-hit words have been read for the last time (k_shuffle_chase): back to zero for the next step
-    for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < A; k += gridDim.x * gridDim.y * blockDim.x) {
+    // the shuffle's list heads and first-hit words have been read for the last time (k_shuffle_chase): back to zero for their next use
+    // (n_drawn: the entries the draw was made for -- more than A when it ran a step ahead; < 0: A)
+    const int nz = n_drawn >= 0 ? n_drawn : A;
+    for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < nz; k += gridDim.x * gridDim.y * blockDim.x) {
         shuf_head[k] = 0; shuf_first[k] = 0;
     }
+    if (A == 0) return;
     const int g = blockIdx.y;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W.grp[g].n) return;
@@ -2362,7 +2372,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
         __syncthreads();
         if (tid == 0) W.counters[CTR_RNG] = (int)rng_skip(x0, (unsigned)A);
         SOLO_MARK();   // 1: draw
-        for (int i = tid; i < A; i += SOLO_STEP_THREADS) shuffle_chase_body(i, S.sj, S.shead, S.sfirst, S.slink, S.rank);
+        for (int i = tid; i < A; i += SOLO_STEP_THREADS) shuffle_chase_body(i, A, S.sj, S.shead, S.sfirst, S.slink, S.rank);
         __syncthreads();
         SOLO_MARK();   // 2: chase
         // ---- ranks, hit bits; the shuffle's list heads go back to zero
@@ -2770,7 +2780,13 @@ void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const
             const int SUv = su_env >= 3 ? 3 : su_env >= 2 ? 2 : 1;
             const int sweep = (int)std::min<long long>(sweep_fixed > 0 ? sweep_fixed : 256, (steps + RENDER_WAVES * SUv - 1) / (RENDER_WAVES * SUv));
             dim3 sgrid(sweep + P.feat_blocks);
-            const size_t sl = (size_t)RENDER_WAVES * SUv * 64 * 7 * sizeof(float) + (size_t)VHW * sizeof(RenderFastPos);
+            static const size_t pad = std::getenv("MAGENT_RENDER_PAD") ? (size_t)std::atoi(std::getenv("MAGENT_RENDER_PAD")) : 0;   // (tuning: extra LDS caps workgroups per CU)
+            static bool allowed = false;
+            if (pad && !allowed) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_sweep2<false, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                allowed = true;
+            }
+            const size_t sl = (size_t)RENDER_WAVES * SUv * 64 * 7 * sizeof(float) + (size_t)VHW * sizeof(RenderFastPos) + pad;
 #define SW2(C16, DVV, SUV) hipLaunchKernelGGL((k_render_sweep2<C16, DVV, SUV>), sgrid, block, sl, s, render_world(W, R.g), R, P, sweep)
 #define SW2D(C16, SUV) do { if (dv_env <= 1) SW2(C16, 1, SUV); else if (dv_env == 2) SW2(C16, 2, SUV); else SW2(C16, 3, SUV); } while (0)
             if (R.cells16) { if (SUv == 3) SW2D(true, 3); else if (SUv == 2) SW2D(true, 2); else SW2D(true, 1); }
@@ -2841,8 +2857,20 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
 void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell, const unsigned *powtab) {
     // head / first are zero here: zeroed when allocated, and again by k_attack_rank after every use
     dim3 g((n_max + 255) / 256), b(256);
-    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, B.j, B.head, B.first, B.link, hitbits, ncell, powtab);
-    hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, B.j, B.head, B.first, B.link, rank);
+    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, -1, B.j, B.head, B.first, B.link, hitbits, ncell, powtab);
+    hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, B.j, B.head, B.first, B.link, rank, (unsigned *)nullptr, (size_t)0);
+}
+// The draws of the NEXT step's shuffle, for `n_entries` list entries (an upper bound of its attack list: every agent), into a clean
+// scratch set.  They depend on the engine's RNG state alone, which k_shuffle_chase has just advanced: the launch goes on a stream
+// beside the step's latency-bound phases and takes 27 us out of the next step's critical path (engine.hip: Env::draw_ahead).
+void launch_shuffle_ahead(hipStream_t s, int n_entries, const int *counters, const ShuffleBufs &B, const unsigned *powtab) {
+    if (n_entries <= 0) return;
+    hipLaunchKernelGGL(k_shuffle_draw, dim3((n_entries + 255) / 256), dim3(256), 0, s, counters, n_entries, B.j, B.head, B.first, B.link,
+                       (unsigned *)nullptr, (size_t)0, powtab);
+}
+// ... and the rest of that shuffle when its step has come: the chase alone (with the hit words' zero-fill)
+void launch_shuffle_chase(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell) {
+    hipLaunchKernelGGL(k_shuffle_chase, dim3((n_max + 255) / 256), dim3(256), 0, s, counters, B.j, B.head, B.first, B.link, rank, hitbits, ncell);
 }
 // ================================================================================================ repeated set_action: the literal loop
 // GridWorld::set_action APPENDS to the step's action lists (GridWorld.cc:403-454): a group that is given actions twice before a step
@@ -2972,9 +3000,9 @@ void launch_set_counter(hipStream_t s, int *counters, int index, int value, int 
 }
 
 // hit bits live in the (then unused) claim array of the move phase
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits) {
-    if (clear_hitbits) (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);   // (else k_shuffle_draw did it)
-    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim, B.head, B.first);
+void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits, int n_drawn) {
+    if (clear_hitbits) (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);   // (else k_shuffle_draw / k_shuffle_chase did it)
+    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim, B.head, B.first, n_drawn);
 }
 static int att_threads(int kmax) {
     static const int forced = getenv("MAGENT_ATT_THREADS") ? atoi(getenv("MAGENT_ATT_THREADS")) : 0;

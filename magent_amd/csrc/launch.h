@@ -123,7 +123,9 @@ void launch_set_rng(hipStream_t s, int *counters, unsigned x);
 void launch_step_reset(hipStream_t s, int *counters);
 void launch_set_counter(hipStream_t s, int *counters, int index, int value, int unless_index);
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits);
+void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits, int n_drawn = -1);
+void launch_shuffle_ahead(hipStream_t s, int n_entries, const int *counters, const ShuffleBufs &B, const unsigned *powtab);
+void launch_shuffle_chase(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell);
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);
 void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag);

@@ -83,3 +83,20 @@ def test_emulated_battle_render_kernels(emu, knobs):
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS="1", **knobs), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-1000:] + p.stderr[-3000:]
+
+
+def test_emulated_large_world_drivers(emu):
+    """the multi-launch step of large worlds forced onto small ones (MAGENT_SOLO_STEP=0, block scans from 100 agents on): the
+    single-sync driver, its continuation when the optimistic attack rounds run out, the minimap made by clear_dead's own
+    launches, and the shuffle draws made a step ahead (MAGENT_DRAW_AHEAD=2; off by default -- measured slower on the MI355X)"""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import helpers as H\n"
+            "emu = H.ensure_emu()\n"
+            "for n in ('battle_brawl', 'battle_brawl_dense_big', 'battle_largemap_odd', 'gather_largemap', 'battle_grow', 'battle_events', 'tri_rect', 'bodies', 'forest'):\n"
+            "    sc = H.scenarios()[n]\n"
+            "    H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, emu), n)\n"
+            "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    base = {"MAGENT_SOLO_STEP": "0", "MAGENT_SCAN_SOLO_MAX": "100", "OMP_NUM_THREADS": "1"}
+    for extra in ({}, {"MAGENT_DRAW_AHEAD": "2"}, {"MAGENT_OPT_ATTACK_PAIRS": "0", "MAGENT_DRAW_AHEAD": "2"}, {"MAGENT_FOLD_MINIMAP": "0"}):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **base, **extra), capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])
