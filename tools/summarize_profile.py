@@ -54,7 +54,7 @@ def main():
             if not k.startswith("void magent_amd") and not k.startswith("magent_amd"):
                 continue
             lines.append("| `%s` | %d | %.2f | %.2f |" % (k.split("(")[0][:70], nf[k], fetch[k] * 1024 / 1e6, write.get(k, 0) * 1024 / 1e6))
-        rk = [k for k in fetch if "k_render" in k]
+        rk = sorted((k for k in fetch if "k_render" in k), key=lambda k: -write.get(k, 0))   # the render of the bench workload: the one that writes most
         if rk:
             k = rk[0]
             # agents per k_render launch of the PMC runs (the populations shrink as agents die): mean of start / end, from the runs' own bench lines
