@@ -525,7 +525,8 @@ def main():
                         traffic_note = "PMC FETCH_SIZE + WRITE_SIZE per rendered agent (%s) x %.0f agents per launch of this run" % (rec.get("source", "profiles/"), agents_per_launch)
                     except Exception:
                         traffic = None
-                res["roofline"] = {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                kname = {0: "k_render_cells16" if bf16 else "k_render", 1: "k_render_fast", 4: "k_render_sweep2"}.get(env.engine_stats()[6], "k_render")
+                res["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_scaled_from_profiles_not_this_run": traffic_note,
                                    "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
                                    "algorithmic_bytes_per_launch": int(obs_bytes / n_launch)}

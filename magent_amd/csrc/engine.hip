@@ -1315,7 +1315,7 @@ void Env::observe_device(int g, float *view, float *feat, bool cells16) {
     R.cells16 = cells16 ? 1 : 0;
     {
         ProfScope p(*this, "render", true);
-        launch_render(stream, W, R, P, aligned, aligned && nt_stores);
+        last_render_kernel = launch_render(stream, W, R, P, aligned, aligned && nt_stores);
     }
     if (P.feat_blocks == 0) {
         ProfScope p(*this, "features", true);
@@ -2213,6 +2213,7 @@ void Env::info_host(int g, const char *name, void *buf) {
     if (k == "engine_stats") {   // additive: steps whose optimistic rounds ran out (host continued), rounds of the last checked phases
         ib[0] = fallback_steps; ib[1] = last_attack_iters; ib[2] = last_move_iters; ib[3] = attack_round;
         ib[4] = fallback_attack; ib[5] = fallback_move;      // (which phase's optimistic rounds ran out)
+        ib[6] = last_render_kernel;                          // 0 k_render, 1 k_render_fast, 4 k_render_sweep2
         return;
     }
     if (k == "batch_host_us") {  // additive (tuning): host microseconds per env_cycle_many round since the last read:

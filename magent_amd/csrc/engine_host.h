@@ -157,7 +157,7 @@ public:
     int render_unroll = 1;
     bool host_shuffle = false;
     int move_jump_batch = 3;
-    int last_attack_iters = 0, last_move_iters = 0, fallback_steps = 0, fallback_attack = 0, fallback_move = 0;
+    int last_attack_iters = 0, last_move_iters = 0, fallback_steps = 0, fallback_attack = 0, fallback_move = 0, last_render_kernel = 0;
     bool checked_step = false;            // host-checked convergence instead of the single-sync driver
     // optimistic rounds of the single-sync driver: one pair / batch, two for 64 steps after a run-out (or fixed by env)
     int opt_attack_pairs = 1, opt_move_batches = 1, boost_attack = 0, boost_move = 0;

@@ -2761,8 +2761,9 @@ void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int 
     hipLaunchKernelGGL(k_minimap_norm, dim3((W.G * VHW + 255) / 256), dim3(256), 0, s, R, W.G, counts, mini, left_out, skip);
 }
 
-void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt) {
-    if (R.n <= 0) return;
+// returns the kernel taken: 0 k_render / k_render_cells16 (every game), 1 k_render_fast, 4 k_render_sweep2
+int launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt) {
+    if (R.n <= 0) return 0;
     size_t lds = (size_t)RENDER_WAVES * P.strip_floats * sizeof(float);
     dim3 grid(P.spans + P.feat_blocks), block(64 * RENDER_WAVES);
     const bool packed = W.vc_packed != 0;   // must match launch_paint
@@ -2793,19 +2794,19 @@ void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const
             else { if (SUv == 3) SW2D(false, 3); else if (SUv == 2) SW2D(false, 2); else SW2D(false, 1); }
 #undef SW2D
 #undef SW2
-            return;
+            return 4;
         }
         if (mode == 1) {
             const size_t fl = render_fast_lds(VHW);
             if (R.cells16) hipLaunchKernelGGL((k_render_fast<true>), grid, block, fl, s, render_world(W, R.g), R, P);
             else hipLaunchKernelGGL((k_render_fast<false>), grid, block, fl, s, render_world(W, R.g), R, P);
-            return;
+            return 1;
         }
     }
     if (R.cells16) {
         if (R.turn) { if (packed) hipLaunchKernelGGL((k_render_cells16<true, true>), grid, block, lds, s, W, R, P); else hipLaunchKernelGGL((k_render_cells16<false, true>), grid, block, lds, s, W, R, P); }
         else { if (packed) hipLaunchKernelGGL((k_render_cells16<true, false>), grid, block, lds, s, W, R, P); else hipLaunchKernelGGL((k_render_cells16<false, false>), grid, block, lds, s, W, R, P); }
-        return;
+        return 0;
     }
 #define RENDER_LAUNCH(V, N, UU, PK) hipLaunchKernelGGL((k_render<V, N, UU, PK, false>), grid, block, lds, s, W, R, P)
 #define RENDER_PK(V, N, UU) do { if (packed) RENDER_LAUNCH(V, N, UU, true); else RENDER_LAUNCH(V, N, UU, false); } while (0)
@@ -2820,6 +2821,7 @@ void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const
     else { if (nt) RENDER_PK(true, true, 1); else RENDER_PK(true, false, 1); }
 #undef RENDER_PK
 #undef RENDER_LAUNCH
+    return 0;
 }
 
 void launch_render_multi(hipStream_t s, const WorldView &W, const RenderMulti &M) {

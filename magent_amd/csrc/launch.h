@@ -113,7 +113,7 @@ size_t solo_step_lds(const WorldView &W, const SoloStep &S);
 void launch_set_tables(hipStream_t s, const WorldView &W, GroupDev *gtab, TypeDev *ttab);
 void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab);
 void launch_minimap(hipStream_t s, const WorldView &W, const RenderArgs &R, int *counts, float *mini);
-void launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt);
+int launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4, bool nt);   // -> which kernel ran (0 generic, 1 fast, 4 sweep)
 void launch_render_multi(hipStream_t s, const WorldView &W, const RenderMulti &M);
 void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4);
 // scratch of the attack shuffle: four int arrays of (at least) n_max entries; head / first are zero between steps

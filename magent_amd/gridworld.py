@@ -462,8 +462,9 @@ class GridWorld(object):
 
     def engine_stats(self):
         """additive: (steps finished by the host-checked driver, attack rounds, move rounds of the last such step, attack
-        rounds launched in the last step, steps whose ATTACK rounds ran out, steps whose MOVE rounds ran out)"""
-        buf = np.zeros(6, dtype=np.int32)
+        rounds launched in the last step, steps whose ATTACK rounds ran out, steps whose MOVE rounds ran out, the kernel of the last
+        observation render: 0 k_render, 1 k_render_fast, 4 k_render_sweep2)"""
+        buf = np.zeros(8, dtype=np.int32)
         self._lib.env_get_info(self.game, 0, b"engine_stats", buf.ctypes.data)
         return tuple(int(v) for v in buf)
 

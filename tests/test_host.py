@@ -204,10 +204,10 @@ def test_no_kernel_keeps_the_world_in_scratch(hip_lib):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r02_bench_line.json is the line `python bench.py` printed at the end of the round: the driver's contract fields, the
+    """profiles/r03_bench_line.json is the line `python bench.py` printed at the end of the round: the driver's contract fields, the
     roofline object of the dominant kernel and the CPU baseline timed beside it"""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_line.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_line.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
