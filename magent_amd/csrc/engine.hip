@@ -269,6 +269,8 @@ Env::Env() {
     if (const char *v = std::getenv("MAGENT_SOLO_STEP")) solo_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("MAGENT_OVERLAP")) { overlap_level = std::atoi(v); overlap_enabled = overlap_level != 0; }
     if (const char *v = std::getenv("MAGENT_SOLO_MAX")) solo_max_agents = std::max(0, std::atoi(v));
+    // the cell-major, LDS-tiled attack / move phases: 0 off | 1 worlds of >= 32768 agents | 2 every world the multi-launch step takes (tests)
+    if (const char *v = std::getenv("MAGENT_CELL_STEP")) { const int m = std::atoi(v); cm_enabled = m != 0; if (m == 2) cm_min = 0; }
     // the next step's shuffle draws a step ahead (Env::draw_ahead): 0 off (default: measured slower, profiles/r03_summary.md) | 1 beside the
     // step's own phases, large worlds | 2 the same for every world (tests) | 3 beside the next observation render
     if (const char *v = std::getenv("MAGENT_DRAW_AHEAD")) { const int m = std::atoi(v); ahead_enabled = m != 0; if (m == 2) ahead_min = 0; ahead_at_render = m == 3; }
@@ -290,6 +292,7 @@ Env::~Env() {
     dfree(arena, d_delta); dfree(arena, d_mask); dfree(arena, d_mini); dfree(arena, d_minif); dfree(arena, d_sums); dfree(arena, d_rank); dfree(arena, d_shuf); dfree(arena, d_events); dfree(arena, d_actions);
     dfree(arena, d_stage_view); dfree(arena, d_stage_feat); dfree(arena, d_stage_small);
     dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d);
+    dfree(arena, d_crec); dfree(arena, d_cout); dfree(arena, d_cmv); dfree(arena, d_occ2);
     if (batch_h) (void)hipHostFree(batch_h);
     if (h_rec) (void)hipHostFree(h_rec);
     if (pool) {
@@ -969,6 +972,7 @@ void Env::reset() {
         map_cells = ncell;
     }
     HIP_OK(hipMemset(d_hit, 0, sizeof(unsigned) * ncell));
+    if (ncell != cm_cells) { dfree(arena, d_crec); dfree(arena, d_cout); dfree(arena, d_cmv); dfree(arena, d_occ2); cm_cells = 0; }
     claim_clean = false;
     if (food_mode && !d_food) HIP_OK(dev_malloc(arena, &d_food, sizeof(float) * 2 * ncell));   // amounts, then the attack phase's scratch
     if (d_food) HIP_OK(hipMemset(d_food, 0, sizeof(float) * 2 * ncell));
@@ -1035,6 +1039,19 @@ void Env::reset() {
             map_reach = std::max(map_reach, std::max(far, M - 1) + M - 1);
         }
     }
+    // the cell-major, LDS-tiled attack / move phases (kernels.hip: k_cm_*): one-cell bodies, no turn_mode / food_mode / goals /
+    // kill_supply, ranges that fit a tile's halo
+    cm_total_attack = total_attack;
+    cm_ha = 0; cm_hm = 0;
+    for (auto &g : groups) {
+        const HostType &t = *g.type;
+        for (int k = 0; k < t.attack.count; k++)
+            cm_ha = std::max(cm_ha, std::max(std::abs(t.attack.dx[k] + t.att_x_offset), std::abs(t.attack.dy[k] + t.att_y_offset)));
+        for (int k = 0; k < t.move.count; k++) cm_hm = std::max(cm_hm, 2 * std::max(std::abs(t.move.dx[k]), std::abs(t.move.dy[k])));
+    }
+    cm_ha = std::max(cm_ha, 1); cm_hm = std::max(cm_hm, 2);
+    cm_possible = cm_enabled && !any_multicell && !turn_mode && !food_mode && !any_absorb && !any_kill_supply && cm_ha <= 3 && cm_hm <= 6 &&
+                  total_attack >= 0 && cm_allow_lds(cm_ha, cm_hm);
     if (attack_kmax > 256) fatal("attack ranges x body size too large for the LDS hit lists (%d > 256)", attack_kmax);
     if (!attack_lds_ok(attack_kmax)) fatal("attack ranges x body size (%d hits per target) need more LDS per workgroup than this device grants", attack_kmax);
     if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
@@ -1465,6 +1482,20 @@ void Env::shuffle_buffers(int n_max) {
     }
 }
 
+// the cell-major arrays of the tiled phases: allocated when a step first takes that path
+bool Env::ensure_cell_world() {
+    const size_t ncell = (size_t)width * height;
+    if (cm_cells != ncell) {
+        HIP_OK(dev_malloc(arena, &d_crec, sizeof(CellRec) * ncell));
+        HIP_OK(dev_malloc(arena, &d_cout, sizeof(CellOut) * ncell));
+        HIP_OK(dev_malloc(arena, &d_cmv, sizeof(unsigned) * ncell));
+        HIP_OK(dev_malloc(arena, &d_occ2, sizeof(int) * ncell));
+        cm_cells = ncell;
+    }
+    return true;
+}
+CellWorld Env::cell_world() const { return CellWorld{d_crec, d_cout, d_cmv}; }
+
 ShuffleBufs Env::shuffle_bufs(int set) const {
     if (set < 0) set = shuf_set;
     const size_t seg = shuf_cap / 4;
@@ -1514,6 +1545,15 @@ void Env::attack_rounds_checked(const WorldView &W) {
     int iters = 0;
     while (true) {
         clear_changed();
+        if (step_was_cm) {
+            launch_cm_attack(stream, W, cell_world(), d_ttab, cm_ha, cm_total_attack, -1);
+            launch_cm_attack(stream, W, cell_world(), d_ttab, cm_ha, cm_total_attack, CTR_CHANGED);
+            attack_round += 2;
+            iters += 2;
+            if (!read_changed()) break;
+            if (iters > 1000000) fatal("attack resolution did not converge");
+            continue;
+        }
         launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, -1);
         launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, CTR_CHANGED);
         iters += 2;
@@ -1525,6 +1565,16 @@ void Env::attack_rounds_checked(const WorldView &W) {
 
 // move rounds, host-checked: `move_jump_batch` rounds per convergence check (a resolved agent is a no-op later)
 void Env::move_rounds_checked(const WorldView &W) {
+    if (step_was_cm) {               // tiled move phase: rounds until one changes nothing
+        int iters = 0;
+        do {
+            clear_changed();
+            launch_cm_move(stream, W, cell_world(), d_ttab, cm_hm, CTR_CHANGED);
+            if (++iters > 1000000) fatal("move resolution did not converge");
+        } while (read_changed());
+        last_move_iters = iters;
+        return;
+    }
     if (!any_multicell) { last_move_iters = 0; return; }   // one-cell bodies: the commit walks the dependency chains itself (move_resolve)
     int iters = 0;
     do {
@@ -1540,6 +1590,12 @@ void Env::move_rounds_checked(const WorldView &W) {
 }
 
 void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 = after move rounds */) {
+    if (step_was_cm) {
+        if (from == 0) { launch_cm_apply(stream, W, cell_world(), d_ttab); move_rounds_checked(W); }
+        launch_cm_commit(stream, W, cell_world(), d_gtab, d_ttab, cm_hm, d_occ2);
+        if (!rules_on_host) launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
+        return;
+    }
     if (from == 0) {
         launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
         if (any_multicell) launch_movg_prep(stream, W, true); else launch_move_prep(stream, W, d_gtab);   // (starve / recover first)
@@ -1601,6 +1657,7 @@ void Env::step_begin() {
     step_pending = true;
     step_was_fast = false;
     step_was_solo = false;
+    step_was_cm = false;
 
     const bool beside = total_n > 0 && fast && side_wanted() && overlap_level >= 2 && !serial_calls_on;   // the read-only head of the step goes beside the renders
     if (!beside) join_side();
@@ -1636,6 +1693,9 @@ void Env::step_begin() {
     } else if (fast) {
         claim_clean = false;
         step_was_fast = true;
+        const bool cm = cm_possible && !beside && total_n >= cm_min && ensure_cell_world();
+        step_was_cm = cm;
+        if (cm) cm_steps++;
         // ---------------- single-sync driver
         {
             const size_t caps = rank_cap + shuf_cap + sums_cap + powtab_cap;
@@ -1662,16 +1722,39 @@ void Env::step_begin() {
             }
             if (a == stream) { if (ahead_at_render) ahead_pending = total_n; else draw_ahead(total_n); }   // (the RNG state of the next step is on the device now)
             if (overlap_level == 2 && a != stream) { join_side(); a = stream; }
-            launch_attack_rank(a, W, d_rank, shuffle_bufs(), false, n_drawn);
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
-            // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
-            // LAST one reports whether anything still moved (one gate for all of them)
-            for (int r = 0; r < 2 * pairs; r++)
-                launch_attack_iter(a, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
+            if (cm) {
+                // cell-major, LDS-tiled: the agents' records onto their cells, then rounds over the tiles; the LAST one reports
+                launch_cm_scatter(a, W, cell_world(), d_rank, shuffle_bufs(), n_drawn);
+                const int rounds = pairs == 0 ? 0 : pairs + 1;       // (a round settles everything a tile and its halo hold: 2 rounds where the per-agent form takes 2 pairs... measured)
+                for (int r = 0; r < rounds; r++)
+                    launch_cm_attack(a, W, cell_world(), d_ttab, cm_ha, cm_total_attack, r == rounds - 1 ? CTR_OPEN_ATTACK : -1);
+                attack_round = rounds;
+            } else {
+                launch_attack_rank(a, W, d_rank, shuffle_bufs(), false, n_drawn);
+                // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
+                // LAST one reports whether anything still moved (one gate for all of them)
+                for (int r = 0; r < 2 * pairs; r++)
+                    launch_attack_iter(a, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
+            }
             if (pairs == 0) launch_set_counter(a, d_counters, CTR_OPEN_ATTACK, 1, -1);   // tests: straight to the host
         }
         join_side();      // from here on the world changes: behind every render enqueued so far
+        if (cm) {
+            {
+                ProfScope p(*this, "attack");
+                launch_cm_apply(stream, W, cell_world(), d_ttab);
+            }
+            {
+                ProfScope p(*this, "move");
+                const int batches = opt_fixed ? opt_move_batches : (boost_move > 0 ? 2 : 1);
+                const int rounds = batches == 0 ? 0 : batches + 1;
+                for (int r = 0; r < rounds; r++) launch_cm_move(stream, W, cell_world(), d_ttab, cm_hm, r == rounds - 1 ? CTR_OPEN_MOVE : -1);
+                if (batches == 0) launch_set_counter(stream, d_counters, CTR_OPEN_MOVE, 1, CTR_OPEN_ATTACK);   // tests
+                launch_cm_commit(stream, W, cell_world(), d_gtab, d_ttab, cm_hm, d_occ2);
+            }
+        } else {
         {
             ProfScope p(*this, "attack");
             launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
@@ -1687,6 +1770,7 @@ void Env::step_begin() {
             }
             if (batches == 0) launch_set_counter(stream, d_counters, CTR_OPEN_MOVE, 1, CTR_OPEN_ATTACK);   // tests
             if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
+        }
         }
         {
             ProfScope p(*this, "rules");
@@ -1801,6 +1885,7 @@ void Env::step_end(int *done) {
             h_occ_valid = false;
             paint_valid = step_live_paint; mini_valid = false;
             live_paint_now = false;
+            if (step_was_cm) std::swap(d_occ, d_occ2);     // k_cm_commit left the occupancy after the step in the second map
             return;
         }
         read_counters();     // a phase ran out of optimistic rounds: the whole counter block, for the continuation below
@@ -1819,6 +1904,7 @@ void Env::step_end(int *done) {
             if (phase == 1) { attack_rounds_checked(W); phase_tail(W, 0); }
             else { move_rounds_checked(W); phase_tail(W, 1); }
             c = read_counters();
+            if (step_was_cm) std::swap(d_occ, d_occ2);     // (read_counters waited for the commit)
         }
         if (boost_attack > 0) boost_attack--;
         if (boost_move > 0) boost_move--;
@@ -2214,6 +2300,7 @@ void Env::info_host(int g, const char *name, void *buf) {
         ib[0] = fallback_steps; ib[1] = last_attack_iters; ib[2] = last_move_iters; ib[3] = attack_round;
         ib[4] = fallback_attack; ib[5] = fallback_move;      // (which phase's optimistic rounds ran out)
         ib[6] = last_render_kernel;                          // 0 k_render, 1 k_render_fast, 4 k_render_sweep2
+        ib[7] = cm_steps;                                    // steps that took the cell-major, LDS-tiled phases
         return;
     }
     if (k == "batch_host_us") {  // additive (tuning): host microseconds per env_cycle_many round since the last read:

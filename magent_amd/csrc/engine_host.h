@@ -201,6 +201,12 @@ private:
     std::vector<SerialCall> serial_calls;   // the calls of a step in which a group was given actions twice (k_step_serial)
     std::vector<int> step_calls;            // groups given actions in this step, in call order
     bool serial_calls_on = false;
+    bool ensure_cell_world();
+    CellWorld cell_world() const;
+    CellRec *d_crec = nullptr; CellOut *d_cout = nullptr; unsigned *d_cmv = nullptr; int *d_occ2 = nullptr;
+    size_t cm_cells = 0;
+    int cm_ha = 1, cm_hm = 2, cm_total_attack = 0, cm_min = 32768, cm_steps = 0;
+    bool cm_enabled = false, cm_possible = false, step_was_cm = false;
     MiniArgs next_minimap();
     int *fold_counts();
     bool cycle_eligible(int n_group, float *const *view, float *const *feat, int *first_obs_out);

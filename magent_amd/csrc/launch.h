@@ -100,6 +100,19 @@ struct BatchItem {
     SoloStep S;
     RenderMulti M;
 };
+// the cell-major arrays of the LDS-tiled attack / move phases (kernels.hip: k_cm_*): one record per map cell
+struct CellRec { unsigned act; unsigned key; float hp; int dr; };   // the occupant's pending action, rank (attack) or order key (move), hp at phase start, death rank
+struct CellOut { float hp; unsigned out; };                         // hp after the attack phase (then after the step), what the occupant's own attack came to
+struct CellWorld { CellRec *rec; CellOut *out; unsigned *mv; };
+size_t cm_attack_lds(int H);
+size_t cm_move_lds(int H);
+bool cm_allow_lds(int Ha, int Hm);
+struct ShuffleBufs;
+void launch_cm_scatter(hipStream_t s, const WorldView &W, const CellWorld &C, const int *rank, const ShuffleBufs &B, int n_drawn);
+void launch_cm_attack(hipStream_t s, const WorldView &W, const CellWorld &C, const TypeDev *ttab, int H, int n_off, int flag);
+void launch_cm_apply(hipStream_t s, const WorldView &W, const CellWorld &C, const TypeDev *ttab);
+void launch_cm_move(hipStream_t s, const WorldView &W, const CellWorld &C, const TypeDev *ttab, int H, int flag);
+void launch_cm_commit(hipStream_t s, const WorldView &W, const CellWorld &C, const GroupDev *gtab, const TypeDev *ttab, int H, int *occ_next);
 // one set_action call of a step in which some group was given actions more than once (k_step_serial)
 struct SerialCall { int g; const int *actions; };
 void launch_step_serial(hipStream_t s, const WorldView &W, const SerialCall *calls, int n_calls, int2 *alist, int4 *mlist, int4 *msorted, int n_sep);
