@@ -1727,7 +1727,7 @@ void Env::step_begin() {
             if (cm) {
                 // cell-major, LDS-tiled: the agents' records onto their cells, then rounds over the tiles; the LAST one reports
                 launch_cm_scatter(a, W, cell_world(), d_rank, shuffle_bufs(), n_drawn);
-                const int rounds = pairs == 0 ? 0 : pairs + 1;       // (a round settles everything a tile and its halo hold: 2 rounds where the per-agent form takes 2 pairs... measured)
+                const int rounds = pairs == 0 ? 0 : pairs + 1;       // (a round settles everything a tile and its halo hold)
                 for (int r = 0; r < rounds; r++)
                     launch_cm_attack(a, W, cell_world(), d_ttab, cm_ha, cm_total_attack, r == rounds - 1 ? CTR_OPEN_ATTACK : -1);
                 attack_round = rounds;

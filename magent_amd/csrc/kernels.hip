@@ -3049,9 +3049,6 @@ __global__ void __launch_bounds__(CM_THREADS) k_cm_attack(WorldView W, CellWorld
         oc.hp = cnt[q] ? hpres[q] : __uint_as_float(CM_NOT_HIT);
         oc.out = out;
         C.out[c] = oc;
-#ifdef HIPEMU_DEBUG_CM
-        if (getenv("CM_WATCH") && c == atoi(getenv("CM_WATCH"))) fprintf(stderr, "K_A tile %d,%d writes out[%d] hp %g out %x\n", blockIdx.x, blockIdx.y, c, oc.hp, oc.out);
-#endif
     }
     if (news && flag >= 0) W.counters[flag] = 1;
 }
@@ -3066,9 +3063,6 @@ __global__ void __launch_bounds__(256) k_cm_apply(WorldView W, CellWorld C, cons
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int A = W.counters[CTR_ATTACK];
     bool died = false;
-#ifdef HIPEMU_DEBUG_CM
-    if (getenv("CM_WATCH_AGENT") && ref_pack(g, i) == (int)strtol(getenv("CM_WATCH_AGENT"), 0, 16)) fprintf(stderr, "K_P sees agent %x: n %d dead %d pos %d,%d A %d\n", ref_pack(g, i), G.n, i < G.n ? (int)G.dead[i] : -1, i < G.n ? G.x[i] : -1, i < G.n ? G.y[i] : -1, A);
-#endif
     if (i < G.n) {
         const int pend = G.pend[i];
         if (pend != PEND_NONE) G.last_action[i] = pend_action(pend, T);
@@ -3111,15 +3105,9 @@ __global__ void __launch_bounds__(256) k_cm_apply(WorldView W, CellWorld C, cons
                     }
                 }
             }
-#ifdef HIPEMU_DEBUG_CM
-            if (!(hp <= T.hp) || (hp < 0 && !G.dead[i])) fprintf(stderr, "CM apply: g %d i %d cell %d hp %g (was %g) A %d out %x dr %d dead %d\n", g, i, c, hp, G.hp[i], A, A > 0 ? C.out[c].out : 0u, A > 0 ? C.rec[c].dr : 0, (int)G.dead[i]);
-#endif
             G.hp[i] = hp;
             G.next_reward[i] = nr;
             C.out[c].hp = hp;
-#ifdef HIPEMU_DEBUG_CM
-            if (getenv("CM_WATCH") && c == atoi(getenv("CM_WATCH"))) fprintf(stderr, "K_P g %d i %d writes out[%d].hp %g\n", g, i, c, hp);
-#endif
         }
     }
     int wtot; wave_rank(died, wtot);
@@ -3306,9 +3294,6 @@ __global__ void __launch_bounds__(CM_THREADS) k_cm_commit(WorldView W, CellWorld
         occ_next[c] = now;
         if (o == OCC_WALL) continue;
         if (W.live_paint) {
-#ifdef HIPEMU_DEBUG_CM
-            if (now >= 0 && (__float_as_uint(__fdiv_rn(hp, s_typehp[ref_group(now)])) >> 30)) fprintf(stderr, "CM commit: cell (%d,%d) now %x o %x hp %g win %llx leaves %d tile %d,%d\n", gx, gy, now, o, hp, (unsigned long long)wv, (int)leaves, blockIdx.x, blockIdx.y);
-#endif
             if (now >= 0) vc_store(W, c, ref_group(now), __float_as_uint(__fdiv_rn(hp, s_typehp[ref_group(now)])));
             else if (now != o) vc_store(W, c, OCC_EMPTY, 0u);
         }

@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libmagent_emu.so")
 SOURCES = ["kernels.hip", "engine.hip", "runtime_api.hip"]      # policy.hip (MFMA) is not emulated
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-FLAGS = (["-DHIPEMU_DEBUG_CM"] if os.environ.get("HIPEMU_DEBUG_CM") else []) + ["-x", "c++", "-std=c++17", "-O1", "-g1", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-w",
+FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-g1", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-w",
          "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include")]
 DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?((?:unsigned\s+)?\w+)\s+(\w+)\[\];")
 

@@ -88,15 +88,20 @@ def test_emulated_battle_render_kernels(emu, knobs):
 def test_emulated_large_world_drivers(emu):
     """the multi-launch step of large worlds forced onto small ones (MAGENT_SOLO_STEP=0, block scans from 100 agents on): the
     single-sync driver, its continuation when the optimistic attack rounds run out, the minimap made by clear_dead's own
-    launches, and the shuffle draws made a step ahead (MAGENT_DRAW_AHEAD=2; off by default -- measured slower on the MI355X)"""
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+    launches, the shuffle draws made a step ahead (MAGENT_DRAW_AHEAD=2) and the cell-major, LDS-tiled attack / move phases
+    (MAGENT_CELL_STEP=2, tiles in scrambled order) -- the last two are off by default: measured slower on the MI355X"""
+    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import helpers as H\n"
             "emu = H.ensure_emu()\n"
-            "for n in ('battle_brawl', 'battle_brawl_dense_big', 'battle_largemap_odd', 'gather_largemap', 'battle_grow', 'battle_events', 'tri_rect', 'bodies', 'forest'):\n"
+            "for n in os.environ['EMU_SCENARIOS'].split(','):\n"
             "    sc = H.scenarios()[n]\n"
             "    H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, emu), n)\n"
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
     base = {"MAGENT_SOLO_STEP": "0", "MAGENT_SCAN_SOLO_MAX": "100", "OMP_NUM_THREADS": "1"}
-    for extra in ({}, {"MAGENT_DRAW_AHEAD": "2"}, {"MAGENT_OPT_ATTACK_PAIRS": "0", "MAGENT_DRAW_AHEAD": "2"}, {"MAGENT_FOLD_MINIMAP": "0"}):
-        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **base, **extra), capture_output=True, text=True, timeout=900)
+    wide = "battle_brawl,battle_brawl_dense_big,battle_largemap_odd,gather_largemap,battle_grow,battle_events,tri_rect,bodies,forest"
+    tiled = "battle_brawl,battle_largemap_odd,gather_largemap,battle_grow"        # (games the tiled phases take, several tiles)
+    for extra, names in (({}, wide), ({"MAGENT_DRAW_AHEAD": "2", "MAGENT_OPT_ATTACK_PAIRS": "0"}, tiled), ({"MAGENT_FOLD_MINIMAP": "0"}, tiled),
+                         ({"MAGENT_CELL_STEP": "2", "HIPEMU_SCRAMBLE": "3"}, tiled + ",battle_brawl_dense_big"),
+                         ({"MAGENT_CELL_STEP": "2", "MAGENT_OPT_MOVE_BATCHES": "0", "MAGENT_OPT_ATTACK_PAIRS": "0", "HIPEMU_SCRAMBLE": "11"}, tiled)):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EMU_SCENARIOS=names, **base, **extra), capture_output=True, text=True, timeout=900)
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])
