@@ -131,15 +131,13 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
             }
         }
     };
-    if ((int)blockIdx.x < A.n_tiles) fetch(blockIdx.x);
-
-    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
-        const int a0 = tile * A.TA, na = min(A.TA, A.n - a0);
-        __syncthreads();     // the previous tile's readers are done (first pass: the tables are written)
+    // the window cells in registers (a tile's, fetched earlier) -> s_view as conv1's operands
+    auto stage = [&](int tile) {
+        const int na_t = min(A.TA, A.n - tile * A.TA);
 #pragma unroll
         for (int k = 0; k < CONV_CELLS; k++) {
             const int c = k * CONV_THREADS + tid;
-            const bool have = c < na * A.H * A.W;
+            const bool have = c < na_t * A.H * A.W;
             bf16x8 v;
             if (CELLS16) {
                 v = nc[k];
@@ -151,8 +149,19 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
             }
             if (c < cells) s_view[c] = v;
         }
-        if (tile + (int)gridDim.x < A.n_tiles) fetch(tile + gridDim.x);
-        __syncthreads();
+    };
+    // Order of a tile's memory traffic (round 3).  Loads and stores share one counter on this part and complete out of order with respect
+    // to each other, so WAITING FOR A LOAD ALSO WAITS FOR EVERY STORE IN FLIGHT (profiles/r03_render_experiments.md).  Round 2 staged the
+    // next tile's views at the top of the loop -- right behind the conv2 stores of the tile before, whose whole round trip the wave then sat
+    // out (the "stores 0.11 ms" of profiles/r02_policy.txt).  Now the views of tile t + 1 go to LDS in the MIDDLE of tile t: conv1 has
+    // finished with s_view, the loads were issued a conv2 + a conv1 ago, and the only stores in flight are the previous tile's, a conv1 old;
+    // the stores of tile t then have the whole conv1 of tile t + 1 to land before anybody waits again.
+    if ((int)blockIdx.x < A.n_tiles) { fetch(blockIdx.x); __syncthreads(); stage(blockIdx.x); }
+    if ((int)(blockIdx.x + gridDim.x) < A.n_tiles) fetch(blockIdx.x + gridDim.x);
+
+    for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const int a0 = tile * A.TA, na = min(A.TA, A.n - a0);
+        __syncthreads();     // s_view holds this tile (staged in the middle of the tile before); the previous conv2's readers of s_c1 are done
         // ---- conv1: [E1 positions, full rows] x [32 channels], K = 10 taps x 8 channels (bias: the constant channel of tap 0).
         // A wave runs TWO position tiles at a time (t and t + 4): two independent accumulator chains keep the matrix pipe busy
         // while the other chain's operands are on their way from LDS.
@@ -184,6 +193,11 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
             }
         }
         __syncthreads();
+        // ---- conv1 is done with s_view: the next tile's views move in, the one after is requested (see above)
+        if (tile + (int)gridDim.x < A.n_tiles) {
+            stage(tile + gridDim.x);
+            if (tile + 2 * (int)gridDim.x < A.n_tiles) fetch(tile + 2 * gridDim.x);
+        }
         // ---- conv2: [P2 positions] x [32 channels], K = 9 taps x 32 slots; starts from the bias, result straight to HBM.
         // Two tiles per wave at a time here too; the operands of the next tap are read while the current one runs.
         const unsigned char *c1b = (const unsigned char *)s_c1;

@@ -1,0 +1,14 @@
+# round-end differential fuzzing on the GPU box (HIP engine vs CPU oracle); ~4 GPU-minutes
+export OMP_NUM_THREADS=1
+run() { echo "== $*"; env "$@" 2>&1 | tail -1; }
+run python tools/fuzz_parity.py oracle hip 0 1200
+run MAGENT_SOLO_STEP=0 python tools/fuzz_parity.py oracle hip 1200 2000
+run MAGENT_SOLO_STEP=0 MAGENT_SCAN_SOLO_MAX=64 python tools/fuzz_parity.py oracle hip 2000 2600
+run FUZZ_TURN=2 python tools/fuzz_parity.py oracle hip 0 500
+run FUZZ_RULES=2 python tools/fuzz_parity.py oracle hip 0 400
+run FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 500
+run FUZZ_BATCH=3 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 200
+run MAGENT_CELL_STEP=2 MAGENT_SOLO_STEP=0 python tools/fuzz_parity.py oracle hip 2600 3200
+run MAGENT_DRAW_AHEAD=2 MAGENT_SOLO_STEP=0 python tools/fuzz_parity.py oracle hip 3200 3500
+run MAGENT_RENDER_FAST=4 MAGENT_RENDER_SWEEP=3 python tools/fuzz_parity.py oracle hip 3500 3900
+run MAGENT_RENDER_FAST=1 python tools/fuzz_parity.py oracle hip 3900 4200
