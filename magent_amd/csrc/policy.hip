@@ -463,7 +463,9 @@ static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const v
     const int H = s->view_h, W = s->view_w, H1 = H - 2, H2 = H - 4, W2 = W - 4;
     // agents per workgroup pass: as many as leave two workgroups per CU their LDS (views 16 B / cell, conv1 64 B / position)
     const int AP = H1 * W + ((H2 * W2 - H1 * W) % 4 + 4) % 4;      // agent pitch of conv1's LDS image: == H2 * W2 (mod 4)
-    int TA = 8;
+    static const int ta_cap = getenv("MAGENT_POLICY_TA") ? atoi(getenv("MAGENT_POLICY_TA")) : 8;       // (tuning: fewer agents per pass = more workgroups per CU)
+    static const int conv_wpc = getenv("MAGENT_POLICY_WPC") ? atoi(getenv("MAGENT_POLICY_WPC")) : 2;
+    int TA = ta_cap < 1 ? 1 : ta_cap > 8 ? 8 : ta_cap;
     size_t lds = 0;
     for (; TA >= 1; TA--) {
         const size_t cells = (size_t)TA * H * W, E1 = (size_t)TA * H1 * W, P2 = (size_t)TA * H2 * W2;
@@ -492,7 +494,7 @@ static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const v
     ConvArgs C{};
     C.view = view; C.act = (__bf16 *)act_workspace; C.w1 = (const bf16x8 *)w->conv1; C.w2 = (const bf16x8 *)w->conv2; C.b2 = w->conv2_bias;
     C.n = n; C.H = H; C.W = W; C.C = s->view_c; C.TA = TA; C.AP = AP; C.n_tiles = (n + TA - 1) / TA; C.dump = (bf16x8 *)((char *)act_workspace + act_bytes(s, n));
-    const int grid = C.n_tiles < 512 ? C.n_tiles : 512;     // persistent (2 per CU): weights are fetched once per wave
+    const int grid = C.n_tiles < 256 * conv_wpc ? C.n_tiles : 256 * conv_wpc;     // persistent (2 per CU): weights are fetched once per wave
 #define CONV_LAUNCH(I, B) hipLaunchKernelGGL((k_dqn_conv<I, B>), dim3(grid), dim3(CONV_THREADS), lds, st, C)
     switch (c2i * 2 + (cells16 ? 1 : 0)) {
         case 2: CONV_LAUNCH(1, false); break;
