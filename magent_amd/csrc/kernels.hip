@@ -631,7 +631,10 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_sweep2(RenderWorld
     // ring state per slot and step: agent, window cell, x, y (requested DV + 1 rounds ahead), view cell (DV rounds ahead)
     int ia[N][SU], ic[N][SU], x[N][SU], y[N][SU];
     unsigned v[N][SU], in[N][SU];
-    auto first_step = [&](unsigned round) { return ((round * (unsigned)sweep + blockIdx.x) * RENDER_WAVES + wave) * SU; };
+    // (P.xcd_chunk < 0, tuning: workgroup b -- which runs on XCD b % 8 -- takes slot (b % 8) * (sweep / 8) + b / 8 of the round, so that an XCD's
+    // workgroups write one contiguous eighth of the window)
+    const unsigned slot = (P.xcd_chunk < 0 && (sweep & 7) == 0) ? (blockIdx.x & 7u) * ((unsigned)sweep >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    auto first_step = [&](unsigned round) { return ((round * (unsigned)sweep + slot) * RENDER_WAVES + wave) * SU; };
     auto index = [&](unsigned round, int slot) {
 #pragma unroll
         for (int u = 0; u < SU; u++) {
@@ -2788,7 +2791,10 @@ int launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const 
                 allowed = true;
             }
             const size_t sl = (size_t)RENDER_WAVES * SUv * 64 * 7 * sizeof(float) + (size_t)VHW * sizeof(RenderFastPos) + pad;
-#define SW2(C16, DVV, SUV) hipLaunchKernelGGL((k_render_sweep2<C16, DVV, SUV>), sgrid, block, sl, s, render_world(W, R.g), R, P, sweep)
+            static const bool xcd_slots = std::getenv("MAGENT_RENDER_XCD") && std::atoi(std::getenv("MAGENT_RENDER_XCD")) != 0;   // (tuning)
+            RenderPlan Ps = P;
+            if (xcd_slots) Ps.xcd_chunk = -1;
+#define SW2(C16, DVV, SUV) hipLaunchKernelGGL((k_render_sweep2<C16, DVV, SUV>), sgrid, block, sl, s, render_world(W, R.g), R, Ps, sweep)
 #define SW2D(C16, SUV) do { if (dv_env <= 1) SW2(C16, 1, SUV); else if (dv_env == 2) SW2(C16, 2, SUV); else SW2(C16, 3, SUV); } while (0)
             if (R.cells16) { if (SUv == 3) SW2D(true, 3); else if (SUv == 2) SW2D(true, 2); else SW2D(true, 1); }
             else { if (SUv == 3) SW2D(false, 3); else if (SUv == 2) SW2D(false, 2); else SW2D(false, 1); }
