@@ -15,8 +15,8 @@ PATTERNS = [[(0, 1, 0)], [(0, 0, 1, 1)], [(1, 0, 1, 0, 1)], [(0, 1), (0, 1, 1), 
 WORLDS = ((20, 60), (45, 400), (120, 1500))     # (map size, agents per group); 120 > 99: large_map_mode, moves run stripe by stripe
 
 
-def play(lib, map_size, n, steps, seed, pattern):
-    env = H.gridworld("battle", lib=lib, map_size=map_size)
+def play(lib, map_size, n, steps, seed, pattern, game="battle"):
+    env = H.gridworld(game, lib=lib, map_size=map_size)
     env.set_seed(seed)
     env.reset()
     hs = env.get_handles()
@@ -28,7 +28,7 @@ def play(lib, map_size, n, steps, seed, pattern):
         rec = {}
         order = pattern[step % len(pattern)]
         for k, g in enumerate(order):
-            env.set_action(hs[g], rs.randint(21, size=env.get_num(hs[g])).astype(np.int32))
+            env.set_action(hs[g], rs.randint(env.get_action_space(hs[g])[0], size=env.get_num(hs[g])).astype(np.int32))
             if k == len(order) - 1:      # observed BEFORE the step: the feature rows show the latest call's action
                 for gg, hh in enumerate(hs):
                     if env.get_num(hh):
@@ -54,6 +54,16 @@ def test_repeated_set_action_oracle_is_the_reference_and_the_kernels_are_the_ora
         if H.have_ref():
             H.assert_same(play(H.REF_LIB, world[0], world[1], 6, 3 + pi, pat), want, "reference vs oracle, pattern %d" % pi)
         H.assert_same(want, play(emu, world[0], world[1], 6, 3 + pi, pat), "oracle vs emulated kernels, pattern %d" % pi)
+
+
+def test_repeated_set_action_with_starvation():
+    """gather: the agents lose hp every step (step_recover < 0) and starve; the food group never acts -- the serial step's starve loop"""
+    emu = H.ensure_emu()
+    for pat in ([(1, 1)], [(1,), (1, 1, 1)]):
+        want = play(H.ensure_oracle(), 40, 120, 12, 5, pat, game="gather")
+        if H.have_ref():
+            H.assert_same(play(H.REF_LIB, 40, 120, 12, 5, pat, game="gather"), want, "reference vs oracle (gather)")
+        H.assert_same(want, play(emu, 40, 120, 12, 5, pat, game="gather"), "oracle vs emulated kernels (gather)")
 
 
 @pytest.mark.gpu
