@@ -1704,7 +1704,6 @@ void Env::step_begin() {
             push_rng();
             if (rng_here || caps != rank_cap + shuf_cap + sums_cap + powtab_cap) state_epoch++;   // (something was enqueued on `stream`)
         }
-        const ShuffleBufs B = shuffle_bufs();
         // shuffle, hit gather and the death-rank fixed point only read the world (and write scratch no render looks at)
         hipStream_t a = beside ? side_stream() : stream;
         {
