@@ -28,6 +28,10 @@
 // (lane map verified on the hardware by tools/probe/mfma_layout.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
 
 #include "../../include/magent_policy.h"
 
@@ -49,6 +53,7 @@ struct ConvArgs {
     const float *b2;       // [2][16]: conv2's bias of the channel in slot 16 g + r
     int n, H, W, C, TA, AP, n_tiles;
     bf16x8 *dump;          // 2 KB behind the workspace: where lanes without a conv2 position store
+    long long *stamps;     // STAMPS instantiation (MAGENT_POLICY_STAMPS): per workgroup, cycles spent in each phase
 };
 
 // LDS images (the layouts make every ds_read_b128 of an MFMA operand conflict-free: a 16-lane service group of the instruction
@@ -60,7 +65,7 @@ struct ConvArgs {
 //   s_c1   [TA][AP = H1 * W + pad positions][4 chunks of 8 slots]: row pitch W (== W2 mod 4) and agent pitch AP (== H2 * W2
 //          mod 4) make a position's index congruent mod 4 to u = its rank in conv2's own enumeration; the chunk index is xor-ed
 //          with (u >> 2) & 3.  The 16 lanes of a group have 16 consecutive-modulo-16 ranks, for every tap: 16 distinct slots.
-template <int C2I, bool CELLS16>   // C2I: passes of conv2 per tile = ceil(tiles of 32 positions / 8), a compile-time count (see the
+template <int C2I, bool CELLS16, bool STAMPS = false>   // C2I: passes of conv2 per tile = ceil(tiles of 32 positions / 8), a compile-time count (see the
                                    // stores below).  CELLS16: the views arrive as bf16 cells -- conv1's operands as they are
 __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -156,15 +161,24 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     // out (the "stores 0.11 ms" of profiles/r02_policy.txt).  Now the views of tile t + 1 go to LDS in the MIDDLE of tile t: conv1 has
     // finished with s_view, the loads were issued a conv2 + a conv1 ago, and the only stores in flight are the previous tile's, a conv1 old;
     // the stores of tile t then have the whole conv1 of tile t + 1 to land before anybody waits again.
-    if ((int)blockIdx.x < A.n_tiles) { fetch(blockIdx.x); __syncthreads(); stage(blockIdx.x); }
+    // (The compiler's wait-count pass merges control-flow paths pessimistically.  Every wait for the weight loads above sat inside some
+    // branch, so there was a path on which they were still in flight at the head of the tile loop -- and the loop then waited for
+    // vmcnt(4) / vmcnt(0), i.e. for the view prefetch issued a moment earlier and for the previous tile's stores, in the middle of
+    // EVERY conv1 and conv2.  An explicit wait here retires the weights on every path; it costs one round trip per workgroup.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the weights are in their registers, on every path into the loop
+    fetch(blockIdx.x); __syncthreads(); stage(blockIdx.x);
     if ((int)(blockIdx.x + gridDim.x) < A.n_tiles) fetch(blockIdx.x + gridDim.x);
 
+    long long t_bar = 0, t_c1 = 0, t_stage = 0, t_c2 = 0, t_a = 0, t_b = 0;      // (STAMPS: wave 0's cycle counter around the phases)
+    const long long t_begin = STAMPS ? clock64() : 0;
     for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
         const int a0 = tile * A.TA, na = min(A.TA, A.n - a0);
+        if (STAMPS) t_a = clock64();
         __syncthreads();     // s_view holds this tile (staged in the middle of the tile before); the previous conv2's readers of s_c1 are done
         // ---- conv1: [E1 positions, full rows] x [32 channels], K = 10 taps x 8 channels (bias: the constant channel of tap 0).
         // A wave runs TWO position tiles at a time (t and t + 4): two independent accumulator chains keep the matrix pipe busy
         // while the other chain's operands are on their way from LDS.
+        if (STAMPS) { t_b = clock64(); t_bar += t_b - t_a; }
         const int T1 = (E1 + 31) / 32, NW = CONV_THREADS / 64;
         for (int t = w; t < T1; t += 2 * NW) {
             const bool two = t + NW < T1;
@@ -192,12 +206,15 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
                 s_c1[(eb & 0x3FFF) * 4 + ((2 * g + 1) ^ (eb >> 14))] = o1;
             }
         }
+        if (STAMPS) { t_a = clock64(); t_c1 += t_a - t_b; }
         __syncthreads();
+        if (STAMPS) { t_b = clock64(); t_bar += t_b - t_a; }
         // ---- conv1 is done with s_view: the next tile's views move in, the one after is requested (see above)
         if (tile + (int)gridDim.x < A.n_tiles) {
             stage(tile + gridDim.x);
             if (tile + 2 * (int)gridDim.x < A.n_tiles) fetch(tile + 2 * gridDim.x);
         }
+        if (STAMPS) { t_a = clock64(); t_stage += t_a - t_b; }
         // ---- conv2: [P2 positions] x [32 channels], K = 9 taps x 32 slots; starts from the bias, result straight to HBM.
         // Two tiles per wave at a time here too; the operands of the next tap are read while the current one runs.
         const unsigned char *c1b = (const unsigned char *)s_c1;
@@ -256,6 +273,11 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
                 dst[0] = o0; dst[1] = o1;
             }
         }
+        if (STAMPS) t_c2 += clock64() - t_a;
+    }
+    if (STAMPS && tid == 0) {
+        long long *o = A.stamps + (size_t)blockIdx.x * 8;
+        o[0] = t_bar; o[1] = t_c1; o[2] = t_stage; o[3] = t_c2; o[4] = clock64() - t_begin; o[5] = t_begin;
     }
 }
 
@@ -274,6 +296,7 @@ struct HeadArgs {
     int n, K, F, FK, n_action;
     int *actions;             // [n] argmax_a Q
     float *q;                 // [n][n_action] or null
+    long long *stamps;        // STAMPS instantiation: per workgroup, the cycle counter at the phase boundaries
 };
 
 // one half of the hidden layer (256 values: relu(dense_view), later relu(dense_emb)) of the 128 agents: [agent][32 chunks of
@@ -287,7 +310,9 @@ __device__ __forceinline__ int hid_at(int agent, int chunk) { return agent * 32 
 // K-chunks ahead; a chunk is 0.26 us of MFMA work per wave.
 // (History per 131072 agents, 64 agents / 4 waves per workgroup: operands loaded at the k-step that uses them 0.45 ms, 79 % of
 // the wave cycles waiting; one chunk ahead 0.31 ms -- two weight fragments per k-step left room for one chunk of look-ahead only.)
+template <bool STAMPS>
 __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
+    const long long t_begin = STAMPS ? clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     bf16x8 (*s_act)[HEAD_M * (HEAD_KC / 8)] = (bf16x8 (*)[HEAD_M * (HEAD_KC / 8)])s_raw;      // [2][agent][8 chunks], swizzled
     bf16x8 *s_hid = (bf16x8 *)s_raw + 2 * HEAD_M * (HEAD_KC / 8);                              // [agent][32 chunks], swizzled
@@ -335,30 +360,51 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
 #pragma unroll
     for (int q = 0; q < 4; q++) aload(min(1 + q, total - 1), ar[q]);
     __syncthreads();
-    for (int kc0 = 0; kc0 < total; kc0 += 4) {
+    const long long t_loop = STAMPS ? clock64() : 0;
+    // One 64-wide K-chunk: its MFMAs, then the ring slot q = kc & 3 moves on (chunk kc + 1 to LDS, chunk kc + 5's activations and
+    // chunk kc + 4's weights requested).  The loop over chunks is written WITHOUT a branch inside a group of four (round 3).  The
+    // compiler's wait-count pass merges control-flow paths pessimistically: with `if (kc >= total) break` after every chunk there is
+    // a path from the end of chunk q = 0 straight to the loop latch and back to the top, on which only three loads follow the one a
+    // k-step waits for -- so the top of every group waited for vmcnt(3), (2), (1), (0): the whole ring of 24 loads drained once per
+    // four chunks, and a k-step in its own basic block (`if (ks < steps)`) read its LDS operands right before the MFMAs that use them.
+    // Full groups are now straight-line code (the stores and requests of a chunk past the end are clamped and harmless: the buffer
+    // they land in was last read before the previous barrier); the chunks left over, one of which may be short, follow the loop.
+    auto chunk = [&](int kc, int q, bool full) __attribute__((always_inline)) {
+        const int buf = kc & 1;
+        const int steps = full ? 4 : min(4, n_steps - kc * 4);
+        // (the four activation operands of k-step ks + 1 are read while the MFMAs of k-step ks run; the scheduling barriers keep the
+        // compiler from sinking the reads to where their values are used, which is what it does to save registers)
+        bf16x8 b[2][4];
+        auto bread = [&](int ks, bf16x8 (&dst)[4]) {
+            const int c = (2 * ks + g) ^ rsw;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int kc = kc0 + q;
-            if (kc >= total) break;
-            const int buf = kc & 1;
-            const int steps = min(4, n_steps - kc * 4);
+            for (int j = 0; j < 4; j++) dst[j] = s_act[buf][(32 * j + r32) * 8 + c];
+        };
+        bread(0, b[0]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                if (ks < steps) {
-                    const int c = (2 * ks + g) ^ rsw;
+        for (int ks = 0; ks < 4; ks++) {
+            if (ks < 3 && (full || ks + 1 < steps)) bread(ks + 1, b[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (full || ks < steps) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[q][ks], s_act[buf][(32 * j + r32) * 8 + c], acc[j], 0, 0, 0);
-                }
+                for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[q][ks], b[ks & 1][j], acc[j], 0, 0, 0);
             }
-            if (kc + 1 < total) {
-                astore(buf ^ 1, ar[q]);                                   // chunk kc + 1, requested four chunks ago
-                aload(min(kc + 5, total - 1), ar[q]);
-            }
-            wload(min(kc + 4, total - 1), wr[q]);                         // this ring slot is chunk kc + 4's now
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
         }
+        astore(buf ^ 1, ar[q]);                                       // chunk kc + 1, requested four chunks ago
+        aload(min(kc + 5, total - 1), ar[q]);
+        wload(min(kc + 4, total - 1), wr[q]);                         // this ring slot is chunk kc + 4's now
+        __syncthreads();
+    };
+    int kc0 = 0;
+    for (; (kc0 + 4) * 4 <= n_steps; kc0 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) chunk(kc0 + q, q, true);
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (kc0 + q < total) chunk(kc0 + q, q, false);
+    const long long t_tail = STAMPS ? clock64() : 0;
     // relu(dense_view) -> hidden slots: output tile w holds chunks 4 w + 2 g, 4 w + 2 g + 1 of every agent
     auto hidden_out = [&](const float (&bias)[16]) {
 #pragma unroll
@@ -437,6 +483,10 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
             }
         }
     }
+    if (STAMPS && tid == 0) {
+        long long *o = A.stamps + (size_t)blockIdx.x * 8;
+        o[0] = t_loop - t_begin; o[1] = t_tail - t_loop; o[2] = clock64() - t_tail; o[3] = t_begin;
+    }
 }
 
 }  // namespace
@@ -488,15 +538,31 @@ static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const v
                                 reinterpret_cast<const void *>(k_dqn_conv<3, true>), reinterpret_cast<const void *>(k_dqn_conv<4, true>)};
         for (const void *f : convs)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return 2;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_head), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS) != hipSuccess) return 2;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_conv<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return 2;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_head<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS) != hipSuccess) return 2;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_head<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS) != hipSuccess) return 2;
         lds_ok = true;
     }
     ConvArgs C{};
     C.view = view; C.act = (__bf16 *)act_workspace; C.w1 = (const bf16x8 *)w->conv1; C.w2 = (const bf16x8 *)w->conv2; C.b2 = w->conv2_bias;
     C.n = n; C.H = H; C.W = W; C.C = s->view_c; C.TA = TA; C.AP = AP; C.n_tiles = (n + TA - 1) / TA; C.dump = (bf16x8 *)((char *)act_workspace + act_bytes(s, n));
-    const int grid = C.n_tiles < 256 * conv_wpc ? C.n_tiles : 256 * conv_wpc;     // persistent (2 per CU): weights are fetched once per wave
+    static const int grid_cap = getenv("MAGENT_POLICY_GRID") ? atoi(getenv("MAGENT_POLICY_GRID")) : 256 * conv_wpc;   // (tests: a few workgroups walk many tiles)
+    const int grid = C.n_tiles < grid_cap ? C.n_tiles : grid_cap < 1 ? 1 : grid_cap;     // persistent (2 per CU): weights are fetched once per wave
+    // development (MAGENT_POLICY_STAMPS=1, bf16-cell views of the battle shape only): wave 0 of every workgroup reads the cycle counter at
+    // its phase boundaries; the launch is waited for and the averages go to stderr.  A separate instantiation: the product kernels
+    // carry none of it.
+    static const bool stamps_on = getenv("MAGENT_POLICY_STAMPS") && atoi(getenv("MAGENT_POLICY_STAMPS")) != 0;
+    const int head_grid = (n + HEAD_M - 1) / HEAD_M;
+    long long *d_stamps = nullptr;
+    const bool stamp_conv = stamps_on && cells16 && c2i == 2;
+    if (stamps_on) {
+        if (hipMalloc((void **)&d_stamps, (size_t)(grid + head_grid) * 64) != hipSuccess) return 2;
+        (void)hipMemsetAsync(d_stamps, 0, (size_t)(grid + head_grid) * 64, st);
+        C.stamps = d_stamps;
+    }
 #define CONV_LAUNCH(I, B) hipLaunchKernelGGL((k_dqn_conv<I, B>), dim3(grid), dim3(CONV_THREADS), lds, st, C)
-    switch (c2i * 2 + (cells16 ? 1 : 0)) {
+    if (stamp_conv) hipLaunchKernelGGL((k_dqn_conv<2, true, true>), dim3(grid), dim3(CONV_THREADS), lds, st, C);
+    else switch (c2i * 2 + (cells16 ? 1 : 0)) {
         case 2: CONV_LAUNCH(1, false); break;
         case 3: CONV_LAUNCH(1, true); break;
         case 4: CONV_LAUNCH(2, false); break;
@@ -511,7 +577,27 @@ static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const v
     Hd.act = (const __bf16 *)act_workspace; Hd.feat = feat; Hd.wv = (const bf16x8 *)w->dense_view; Hd.we = (const bf16x8 *)w->dense_emb; Hd.wh = (const bf16x8 *)w->head;
     Hd.bv = w->dense_view_bias; Hd.be = w->dense_emb_bias; Hd.value_bias = w->value_bias;
     Hd.n = n; Hd.K = H2 * W2 * 32; Hd.F = s->feat; Hd.FK = (s->feat + 15) / 16 * 16; Hd.n_action = s->n_action; Hd.actions = actions; Hd.q = q;
-    hipLaunchKernelGGL(k_dqn_head, dim3((n + HEAD_M - 1) / HEAD_M), dim3(HEAD_THREADS), HEAD_LDS, st, Hd);
+    if (stamps_on) {
+        Hd.stamps = d_stamps + (size_t)grid * 8;
+        hipLaunchKernelGGL(k_dqn_head<true>, dim3(head_grid), dim3(HEAD_THREADS), HEAD_LDS, st, Hd);
+        std::vector<long long> h((size_t)(grid + head_grid) * 8);
+        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+        (void)hipFree(d_stamps);
+        auto mean = [&](int first, int count, int k) { double a = 0; for (int i = 0; i < count; i++) a += (double)h[(size_t)(first + i) * 8 + k]; return a / count; };
+        auto span = [&](int first, int count, int k_begin, int k_total) {      // first start .. last end, cycles
+            long long lo = h[(size_t)first * 8 + k_begin], hi = lo;
+            for (int i = 0; i < count; i++) { const long long b = h[(size_t)(first + i) * 8 + k_begin]; lo = b < lo ? b : lo; hi = b + k_total > hi ? b + k_total : hi; }
+            return (double)(hi - lo);
+        };
+        if (stamp_conv)
+            fprintf(stderr, "[policy stamps] conv: %d workgroups x %.1f tiles; cycles per tile: barriers %.0f conv1 %.0f stage %.0f conv2 %.0f; per workgroup %.0f\n", grid,
+                    (double)C.n_tiles / grid, mean(0, grid, 0) * grid / C.n_tiles, mean(0, grid, 1) * grid / C.n_tiles, mean(0, grid, 2) * grid / C.n_tiles,
+                    mean(0, grid, 3) * grid / C.n_tiles, mean(0, grid, 4));
+        fprintf(stderr, "[policy stamps] head: %d workgroups; cycles: prologue %.0f main loop %.0f tail %.0f\n", head_grid, mean(grid, head_grid, 0),
+                mean(grid, head_grid, 1), mean(grid, head_grid, 2));
+        (void)span;
+    } else
+        hipLaunchKernelGGL(k_dqn_head<false>, dim3(head_grid), dim3(HEAD_THREADS), HEAD_LDS, st, Hd);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

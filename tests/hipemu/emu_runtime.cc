@@ -240,13 +240,3 @@ hipError_t hipFuncGetAttributes(hipFuncAttributes *a, const void *) {
     a->maxThreadsPerBlock = 1024;
     return hipSuccess;
 }
-
-// the MFMA policy kernels (magent_amd/csrc/policy.hip) are not emulated: the entry points exist and refuse
-struct PolicyDqnShape;
-struct PolicyDqnWeights;
-extern "C" {
-int policy_dqn_supported(const PolicyDqnShape *) { return 0; }
-int policy_dqn_act_bytes(const PolicyDqnShape *, int, size_t *bytes) { *bytes = 0; return 1; }
-int policy_dqn_infer(const PolicyDqnShape *, const PolicyDqnWeights *, const float *, const float *, int, void *, void *, void *, void *) { return 1; }
-int policy_dqn_infer_bf16(const PolicyDqnShape *, const PolicyDqnWeights *, const void *, const float *, int, void *, void *, void *, void *) { return 1; }
-}

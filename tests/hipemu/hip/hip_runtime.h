@@ -101,6 +101,46 @@ template <typename T> static inline T shfl_at(const void *site, T v, int src) {
 }
 }  // namespace hipemu
 
+// ------------------------------------------------------------------------------------------------ matrix cores
+// v_mfma_f32_32x32x16_bf16 as a wave-wide meeting: every lane posts its 16 bytes of A and of B (four 8-byte posts), then computes
+// its own 16 results from the gathered operands.  Lane maps as measured on the MI355X (tools/probe/mfma_layout.hip): lane l holds
+// A[row = l & 31][k = 8 (l >> 5) + 0..7] and B[k = 8 (l >> 5) + 0..7][col = l & 31]; result register r of lane l is
+// D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31].  The sum is taken in double and rounded once (the hardware's own
+// internal order is not documented: tests compare with a tolerance, as they do on the GPU).
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu::mfma_32x32x16_bf16((a), (b), (c))
+namespace hipemu {
+static inline float bf16_bits_to_float(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+template <typename V8, typename V16> static inline V16 mfma_32x32x16_bf16(V8 a, V8 b, V16 c) {
+    static_assert(sizeof(V8) == 16 && sizeof(V16) == 64, "operand shapes of v_mfma_f32_32x32x16_bf16");
+    static const char site[4] = {0, 0, 0, 0};
+    unsigned long long mine[4], all[4][64];
+    memcpy(mine, &a, 16);
+    memcpy(mine + 2, &b, 16);
+    for (int p = 0; p < 4; p++) {
+        wave_meet(&site[p], mine[p]);
+        if (wave_mask() != ~0ull) { fprintf(stderr, "hipemu: MFMA with inactive lanes\n"); abort(); }
+        for (int l = 0; l < 64; l++) all[p][l] = wave_posted(l);
+    }
+    auto elem = [&](int operand, int lane, int e) {     // element e (0..7) of lane's A (operand 0) or B (operand 1)
+        unsigned short h;
+        memcpy(&h, (const unsigned char *)&all[2 * operand + (e >> 2)][lane] + 2 * (e & 3), 2);
+        return (double)bf16_bits_to_float(h);
+    };
+    const int col = lane_ & 31, g = lane_ >> 5;
+    V16 d;
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+        double acc = (double)c[r];
+        for (int k = 0; k < 16; k++) acc += elem(0, row + 32 * (k >> 3), k & 7) * elem(1, col + 32 * (k >> 3), k & 7);
+        d[r] = (float)acc;
+    }
+    return d;
+}
+}  // namespace hipemu
+
 // ------------------------------------------------------------------------------------------------ arithmetic intrinsics
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int __mulhi(int a, int b) { return (int)(((long long)a * b) >> 32); }
@@ -161,6 +201,8 @@ const char *hipGetErrorString(hipError_t e);
 hipError_t hipGetLastError();
 hipError_t hipGetDeviceCount(int *n);
 hipError_t hipSetDevice(int d);
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipStreamGetDevice(hipStream_t, int *d) { *d = 0; return hipSuccess; }
 hipError_t hipDeviceSynchronize();
 hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int dev);
 hipError_t hipMalloc(void **p, size_t n);

@@ -1,0 +1,66 @@
+"""The MFMA policy kernels (magent_amd/csrc/policy.hip) on the CPU emulator (tests/hipemu: every lane a fiber, v_mfma_f32_32x32x16_bf16
+as a wave-wide meeting with the lane maps measured on the MI355X) against the same PyTorch f32 computation tests/test_policy.py
+uses on the GPU.  What this checks in the GPU-less container: the LDS images and their swizzles, the look-up tables, the tile /
+chunk bookkeeping, the prefetch rings and every barrier (the emulator runs the lanes of a workgroup one after the other between
+meetings: a missing barrier shows as stale data).  TEST INFRASTRUCTURE: the product is the HIP build, checked by test_policy.py."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def _emu():
+    os.environ["MAGENT_POLICY_GRID"] = "3"      # (read once, at the emulated library's first call: three workgroups walk every tile of the conv kernel)
+    lib = ctypes.CDLL(H.ensure_emu())
+    lib.policy_dqn_infer.restype = ctypes.c_int
+    lib.policy_dqn_infer_bf16.restype = ctypes.c_int
+    return lib
+
+
+def _infer(lib, pol, view, feat, cells16=False):
+    import torch
+    if pol.dirty:
+        pol.pack()
+    n = view.shape[0]
+    actions = torch.empty(n, dtype=torch.int32)
+    q = torch.empty((n, pol.shape.n_action), dtype=torch.float32)
+    work = torch.zeros(n * pol.k_dense * 2 + 2048, dtype=torch.uint8)
+    call = lib.policy_dqn_infer_bf16 if cells16 else lib.policy_dqn_infer
+    rc = call(ctypes.byref(pol.shape), ctypes.byref(pol._w), ctypes.c_void_p(view.data_ptr()), ctypes.c_void_p(feat.data_ptr()), ctypes.c_int(n),
+              ctypes.c_void_p(work.data_ptr()), ctypes.c_void_p(actions.data_ptr()), ctypes.c_void_p(q.data_ptr()), None)
+    assert rc == 0
+    return actions, q
+
+
+@pytest.mark.parametrize("view_space,feat,n_action,n", [((13, 13, 7), 34, 21, 128 + 37), ((9, 9, 5), 18, 9, 77), ((13, 11, 6), 40, 31, 70),
+                                                         ((7, 7, 3), 5, 5, 131), ((13, 13, 7), 34, 21, 1), ((5, 5, 1), 1, 2, 40)])
+def test_emulated_policy_matches_torch_reference(view_space, feat, n_action, n):
+    import torch
+    from test_policy import _reference
+    from magent_amd.builtin.torch_model.dqn import _QNet
+    from magent_amd.builtin.torch_model.hip_policy import HipDqnPolicy
+    lib = _emu()
+    torch.manual_seed(4321 + n)
+    qnet = _QNet(view_space, (feat,), n_action, True, True)
+    with torch.no_grad():
+        for p in qnet.parameters():
+            p.mul_(3.0)
+    view = ((torch.rand((n,) + view_space) < 0.3).float() * torch.rand((n,) + view_space)).contiguous()
+    featv = (torch.rand((n, feat)) * 2 - 0.5).contiguous()
+    pol = HipDqnPolicy(qnet, view_space, (feat,), n_action, "cpu")
+    actions, q = _infer(lib, pol, view, featv)
+    with torch.no_grad():
+        ref = _reference(qnet, view, featv)
+    scale = float(ref.abs().max())
+    err = (q - ref).abs().max().item()
+    assert err <= 2e-3 * scale + 2e-3, (err, scale)
+    assert torch.equal(actions.long(), q.argmax(dim=1))
+    # the bf16-cell entry point on the same views: identical operands reach the same MFMAs
+    cells = torch.zeros((n,) + view_space[:2] + (8,), dtype=torch.bfloat16)
+    cells[..., :view_space[2]] = view.to(torch.bfloat16)
+    cells[..., 7] = 1.0
+    a16, q16 = _infer(lib, pol, cells.contiguous(), featv, cells16=True)
+    assert torch.equal(q16, q) and torch.equal(a16, actions)
