@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 typedef struct {
-    int view_h, view_w, view_c;   /* view_c <= 7 (the eighth channel of a window cell carries conv1's bias) */
+    int view_h, view_w, view_c;   /* view_c <= 7 (the eighth channel of a window cell carries conv1's bias); view_h * view_w <= 256 */
     int feat;                     /* <= 64 */
     int n_action;                 /* <= 31 */
 } PolicyDqnShape;
@@ -28,7 +28,8 @@ typedef struct {
 /* Weights in "fragment order" (bf16, 16-byte units of 8 values): for k-step s (16 values of the reduction dimension) and
  * 32-wide output tile T, lane l (0..63) holds W[out = 32 T + (l & 31)][k = 16 s + 8 (l >> 5) + 0..7].
  * The reduction index k of each layer:
- *   conv1      : tap (ky * 3 + kx) * 8 + channel          (channels padded to 8, taps to 10: 5 k-steps)        [5][64][8]
+ *   conv1      : j * 8 + channel, j = 0..9 standing for tap (ky * 3 + kx) 0, 3, 1, 4, 2, 5, 6, 7, 8, padding -- the two taps of
+ *                a k-step lie a constant number of window cells apart (channels padded to 8: 5 k-steps)       [5][64][8]
  *                its bias is the weight of (tap 0, channel 7): the kernel feeds a constant 1.0 there
  *   conv2      : tap * 32 + slot                          (18 k-steps)                                         [18][64][8]
  *   dense_view : position (y * (view_w - 4) + x) * 32 + slot                                                    [K/16][8][64][8]

@@ -35,6 +35,9 @@ def fragment_order(w):
     return w.reshape(n // 32, 32, k // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous().to(torch.bfloat16).reshape(k // 16, n // 32, 64, 8)
 
 
+CONV1_TAP_ORDER = [0, 3, 1, 4, 2, 5, 6, 7, 8, 9]       # tap (ky * 3 + kx; 9 = padding) in position 2 s + g of conv1's reduction index
+
+
 def _pad_k(w, k):
     return torch.cat([w, w.new_zeros(w.shape[0], k - w.shape[1])], dim=1) if w.shape[1] < k else w
 
@@ -61,7 +64,8 @@ class HipDqnPolicy(object):
         w1 = q.conv1.weight.detach().float()                              # [32][C][3][3] -> [32][ky][kx][8] -> K = tap * 8 + channel
         w1 = torch.cat([w1, w1.new_zeros(32, 8 - c, 3, 3)], dim=1).permute(0, 2, 3, 1).contiguous()
         w1[:, 0, 0, 7] = q.conv1.bias.detach().float()       # the kernel feeds a constant 1.0 in channel 7: the MFMA adds the bias
-        w1 = w1.reshape(32, 72)
+        # the kernel pairs the taps (0|3) (1|4) (2|5) (6|7) (8|pad) into its five k-steps (policy.hip: k_dqn_conv)
+        w1 = _pad_k(w1.reshape(32, 72), 80).reshape(32, 10, 8)[:, CONV1_TAP_ORDER].reshape(32, 80)
         w2 = q.conv2.weight.detach().float()[:, ch].permute(0, 2, 3, 1).reshape(32, 288)            # K = tap * 32 + slot
         wv = q.dense_view.weight.detach().float().reshape(256, -1, 32)[:, :, ch].reshape(256, self.k_dense)   # K = position * 32 + slot
         fk = (self.shape.feat + 15) // 16 * 16
@@ -71,7 +75,7 @@ class HipDqnPolicy(object):
         head[:self.shape.n_action] = q.advantage.weight.detach().float()
         head[self.shape.n_action] = q.value.weight.detach().float()[0]
         t = {
-            "conv1": fragment_order(_pad_k(w1, 80)), "conv2": fragment_order(w2), "dense_view": fragment_order(wv),
+            "conv1": fragment_order(w1), "conv2": fragment_order(w2), "dense_view": fragment_order(wv),
             "dense_emb": fragment_order(we), "head": fragment_order(head[:, hidden]),
             "conv2_bias": q.conv2.bias.detach().float()[ch].contiguous(),
             "dense_view_bias": q.dense_view.bias.detach().float()[hidden[:256]].contiguous(),
@@ -96,7 +100,9 @@ class HipDqnPolicy(object):
         n = view.shape[0]
         actions = torch.empty(n, dtype=torch.int32, device=view.device)
         q = torch.empty((n, self.shape.n_action), dtype=torch.float32, device=view.device) if want_q else None
-        need = min(n, self.chunk) * self.k_dense * 2 + 2048          # (policy_dqn_act_bytes: activations + the conv kernel's dump line)
+        nbytes = ctypes.c_size_t(0)
+        self._lib.policy_dqn_act_bytes(ctypes.byref(self.shape), min(n, self.chunk), ctypes.byref(nbytes))
+        need = nbytes.value          # (activations in the kernels' own layout + the conv kernel's dump line)
         if self._work is None or self._work.numel() < need:
             self._work = torch.empty(need, dtype=torch.uint8, device=view.device)
         stream = torch.cuda.current_stream(view.device).cuda_stream

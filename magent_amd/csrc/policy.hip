@@ -31,6 +31,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "../../include/magent_policy.h"
@@ -44,39 +45,75 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // result register r of lane group g (= lane >> 5) is row (r & 3) + 8 (r >> 2) + 4 g of the 32 x 32 tile
 __device__ __forceinline__ int ch_of(int g, int r) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-constexpr int CONV_THREADS = 256, CONV_CELLS = 4, CONV_C2_ITERS = 4;   // CONV_C2_ITERS x 8 tiles of 32 conv2 positions per pass, at most   // CONV_CELLS: window cells of a tile per thread (register prefetch)
+// conv2's output, dense_view's input: [group of ACT_GROUP agents][K-chunk of 64 values = two positions][agent][64 values].  A k_dqn_head
+// workgroup (ACT_GROUP agents) then reads one contiguous 16 KB block per K-chunk, and its blocks follow each other -- round 2 kept
+// [agent][K]: 128-byte pieces 5 KB apart, and the head waited for them (without its activation loads the head ran 0.064 ms faster of
+// 0.205 -- the pieces came at the rate HBM serves scattered lines, not at its streaming rate).
+constexpr int ACT_GROUP = 128;
+__device__ __forceinline__ size_t act_at(int agent, int pos, int n_pos) {       // index (in bf16 values) of slot 0 of `pos` of `agent`
+    const int chunks = (n_pos + 1) >> 1;
+    return ((size_t)(agent / ACT_GROUP) * chunks + (pos >> 1)) * (ACT_GROUP * 64) + (size_t)(agent % ACT_GROUP) * 64 + (pos & 1) * 32;
+}
+constexpr int CONV_THREADS = 256, CONV_TA = 4, CONV_CELLS = 4;   // CONV_TA agents per tile; CONV_CELLS: window cells of a tile per thread (register prefetch)
 
 struct ConvArgs {
     const float *view;     // [n][H][W][C] f32, or (CELLS16) [n][H][W][8] bf16 cells as env_get_observation_device_bf16 writes them
-    __bf16 *act;           // [n][H2 * W2][32 slots]
+    __bf16 *act;           // [n / 128][K / 64][128 agents][64 values] (ACT_GROUP): what one k_dqn_head workgroup reads per K-chunk is one 16 KB block
     const bf16x8 *w1, *w2; // fragment order: [5][64], [18][64]; conv1's bias sits in w1 at (tap 0, channel 7)
     const float *b2;       // [2][16]: conv2's bias of the channel in slot 16 g + r
-    int n, H, W, C, TA, AP, n_tiles;
+    int n, H, W, C, VP, AP, n_tiles;
     bf16x8 *dump;          // 2 KB behind the workspace: where lanes without a conv2 position store
     long long *stamps;     // STAMPS instantiation (MAGENT_POLICY_STAMPS): per workgroup, cycles spent in each phase
 };
 
-// LDS images (the layouts make every ds_read_b128 of an MFMA operand conflict-free: a 16-lane service group of the instruction
-// must hit 16 different 16-byte slots of the 256-byte LDS row -- checked offline by simulating the group lists of
-// MI355X_MICROARCH.md, LDS section):
-//   s_view [TA * H * W + 2] cells of 8 bf16: channels 0..C-1, zeros, and 1.0 in channel 7 -- conv1's bias is the weight of that
-//          constant, so the MFMA adds it.  conv1 is evaluated over FULL rows of W positions (the last two of a row are garbage
-//          that lands in the padding columns of s_c1): consecutive lanes then read consecutive cells.
-//   s_c1   [TA][AP = H1 * W + pad positions][4 chunks of 8 slots]: row pitch W (== W2 mod 4) and agent pitch AP (== H2 * W2
-//          mod 4) make a position's index congruent mod 4 to u = its rank in conv2's own enumeration; the chunk index is xor-ed
-//          with (u >> 2) & 3.  The 16 lanes of a group have 16 consecutive-modulo-16 ranks, for every tap: 16 distinct slots.
-template <int C2I, bool CELLS16, bool STAMPS = false>   // C2I: passes of conv2 per tile = ceil(tiles of 32 positions / 8), a compile-time count (see the
-                                   // stores below).  CELLS16: the views arrive as bf16 cells -- conv1's operands as they are
+// relu and round two f32 to a bf16 pair: v_cvt_pk_bf16_f32, then v_pk_max_i16 against 0 -- a negative bf16 is a negative int16, and
+// rounding never changes a sign (-0 becomes +0), so max(int16(round(x)), 0) == round(max(x, 0)) bit for bit.  Two instructions per
+// pair; `(__bf16)fmaxf(x, 0)` is five (two v_max_f32 each -- one quiets NaNs -- and the conversion).
+__device__ __forceinline__ unsigned relu_bf16x2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    const f32x2 v = {a, b};
+    s16x2 t = __builtin_bit_cast(s16x2, __builtin_convertvector(v, bf16x2));
+    t = __builtin_elementwise_max(t, (s16x2)(0));
+    return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ bf16x8 relu_bf16x8(const f32x16 &acc, int base) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 u;
+#pragma unroll
+    for (int r = 0; r < 4; r++) u[r] = relu_bf16x2(acc[base + 2 * r], acc[base + 2 * r + 1]);
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+// Round 3 layout.  The kernel was bound by instruction issue, not by the matrix pipe (per-phase cycle stamps: 1430 instructions per
+// wave and tile around 106 MFMAs -- 15 vector instructions per MFMA in conv1, 7 in conv2: look-up tables, swizzled addresses for every
+// tap, a five-instruction ReLU).  Now:
+//   * the 32 lanes of an MFMA tile are 8 CONSECUTIVE POSITIONS x 4 AGENTS (position-major, agent-minor: lane index E -> position
+//     E >> 2, agent E & 3).  With the agent pitches of both LDS images == 4 (mod 16) sixteen-byte slots, every 16-lane service group of a
+//     ds_read_b128 (MI355X_MICROARCH.md, LDS) lands on 16 different slots WITHOUT any swizzle -- agents contribute 0, 4, 8, 12, the
+//     group's four positions four different residues mod 4 (a row wrap of conv2's 9-wide rows in the 13-wide image adds W - W2 = 4) --
+//     so a tap is a constant offset from a per-lane base: an immediate of the ds_read when the view is the 13 x 13 one (F13).
+//   s_view [4][VP] cells of 8 bf16: channels 0..C-1, zeros, 1.0 in channel 7 (conv1's bias is the weight of that constant); VP >= H W + 3,
+//          the cells past H W are zero (the padding tap and the garbage columns below read them).  conv1 is evaluated over FULL rows
+//          of W positions (the last two of a row are garbage that lands in columns conv2 never reads): a position's index IS its
+//          top-left cell's index, and its index in conv1's output image.
+//   s_c1   [4 planes][4 agents][AP positions] x 8 bf16: plane c holds slots 8 c .. 8 c + 7 of every position (conv1's result lane
+//          (position, g) writes planes 2 g and 2 g + 1; conv2's operand for (tap, half h) of lane group g is plane 2 h + g).
+//   * conv1's ten taps (nine and a zero-weight one) are paired (0|3) (1|4) (2|5) (6|7) (8|pad): lane group 1 reads W cells (first three
+//     k-steps) or 1 cell (last two) after lane group 0 -- two bases per tile, the rest immediates.  The padding tap reads cell + 2W + 3:
+//     a real or a zeroed cell, never uninitialised LDS (NaN x 0).
+//   * no look-up tables: positions are shifts and one division by a constant.
+template <bool CELLS16, bool F13, bool STAMPS = false>     // CELLS16: the views arrive as bf16 cells -- conv1's operands as they are.  F13: 13 x 13 views
 __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    const int H1 = A.H - 2, H2 = A.H - 4, W2 = A.W - 4;
-    const int cells = A.TA * A.H * A.W, E1 = A.TA * H1 * A.W, P2 = A.TA * H2 * W2;
-    bf16x8 *s_view = (bf16x8 *)s_raw;                                  // [cells + 2]
-    bf16x8 *s_c1 = s_view + cells + 2;                                 // [TA * AP][4]
-    unsigned *s_lut2 = (unsigned *)(s_c1 + (size_t)A.TA * A.AP * 4);   // conv2 position -> its top-left c1 position | 9 taps x 2 swizzle bits << 12
-    unsigned short *s_lut1 = (unsigned short *)(s_lut2 + P2);          // conv1 position (full rows) -> c1 position | swizzle << 14
-    unsigned short *s_lutc = s_lut1 + E1;                              // conv1 position -> its top-left window cell
-    float *s_bias = (float *)(s_lutc + E1);                            // [2][16] (4-byte aligned: 2 * E1 ushorts lie before it)
+    constexpr int TA = CONV_TA, NW = CONV_THREADS / 64;
+    const int H = F13 ? 13 : A.H, W = F13 ? 13 : A.W, VP = F13 ? 180 : A.VP, AP = F13 ? 148 : A.AP;
+    const int H1 = H - 2, H2 = H - 4, W2 = W - 4, HW = H * W, NP2 = H2 * W2;
+    const int E1 = TA * H1 * W, P2 = TA * NP2, PL = TA * AP;
+    bf16x8 *s_view = (bf16x8 *)s_raw;                     // [TA][VP]
+    bf16x8 *s_c1 = s_view + TA * VP;                      // [4][TA][AP]
+    float *s_bias = (float *)(s_c1 + 4 * PL);             // [2][16]
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 5, r32 = l & 31;
     bf16x8 wf1[5], wf2[18];
@@ -85,27 +122,12 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
 #pragma unroll
     for (int s = 0; s < 18; s++) wf2[s] = A.w2[s * 64 + l];
     for (int k = tid; k < 32; k += CONV_THREADS) s_bias[k] = A.b2[k];
-    for (int E = tid; E < E1; E += CONV_THREADS) {
-        const int a = E / (H1 * A.W), rem = E - a * H1 * A.W, y = rem / A.W, x = rem - y * A.W;
-        const int u = (a * H2 * W2 + y * W2 + x) & 15;                 // (rank of c1 position (a, y, x) in conv2's enumeration, mod 16)
-        s_lut1[E] = (unsigned short)((a * A.AP + y * A.W + x) | (((u >> 2) & 3) << 14));
-        s_lutc[E] = (unsigned short)(a * A.H * A.W + y * A.W + x);
-    }
-    for (int Q = tid; Q < P2; Q += CONV_THREADS) {
-        const int a = Q / (H2 * W2), rem = Q - a * H2 * W2, y = rem / W2, x = rem - y * W2;
-        unsigned q = 0;
-        for (int tap = 0; tap < 9; tap++) q |= (unsigned)((((Q + (tap / 3) * W2 + tap % 3) & 15) >> 2) & 3) << (2 * tap);
-        s_lut2[Q] = (unsigned)(a * A.AP + y * A.W + x) | (q << 12);
-    }
-    if (tid < 2) s_view[cells + tid] = bf16x8{0};
-    // conv1: k-step s covers taps 2 s and 2 s + 1 (lane group g takes tap 2 s + g; tap 9 is padding: zero weights)
-    int off1[5];
-#pragma unroll
-    for (int s = 0; s < 5; s++) { const int tap = 2 * s + g; off1[s] = tap < 9 ? (tap / 3) * A.W + tap % 3 : 0; }
+    for (int c = tid; c < TA * VP; c += CONV_THREADS) s_view[c] = bf16x8{0};      // (the cells behind every agent's H W stay zero)
 
     // A tile's window cells are fetched a whole tile AHEAD, into registers: the loads of tile t + 1 are issued before the
-    // convolutions of tile t and waited for after them, so their HBM latency hides behind ~2 us of MFMA work (the loop was bound
-    // by it).  A thread owns whole cells: C floats in, one 16-byte LDS store out.
+    // convolutions of tile t and waited for after them, so their HBM latency hides behind the MFMA work.  A thread owns whole
+    // cells: C floats (or one bf16 cell) in, one 16-byte LDS store out.  Cell c of a tile (agent-major, as the views lie in memory)
+    // goes to s_view[(c / HW) * VP + c % HW].
     float nv[CONV_CELLS][7];
     // (the loads are unconditional, from clamped addresses: a select on a loaded value would make the wave wait for it at once)
     // (seven channels -- every reference game with a minimap and two groups -- are fetched as one 16-byte and one 12-byte load per
@@ -114,15 +136,18 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
     bf16x8 nc[CONV_CELLS];
+    int sdst[CONV_CELLS];
+#pragma unroll
+    for (int k = 0; k < CONV_CELLS; k++) { const int c = k * CONV_THREADS + tid, a = c / HW; sdst[k] = a < TA ? a * VP + (c - a * HW) : -1; }
     auto fetch = [&](int tile) {
-        const int live = min(A.TA, A.n - tile * A.TA) * A.H * A.W;
+        const int live = min(TA, A.n - tile * TA) * HW;
         if (CELLS16) {
-            const bf16x8 *src16 = (const bf16x8 *)A.view + (size_t)tile * cells;
+            const bf16x8 *src16 = (const bf16x8 *)A.view + (size_t)tile * TA * HW;
 #pragma unroll
             for (int k = 0; k < CONV_CELLS; k++) nc[k] = src16[min(k * CONV_THREADS + tid, live - 1)];
             return;
         }
-        const float *src = A.view + (size_t)tile * cells * A.C;
+        const float *src = A.view + (size_t)tile * TA * HW * A.C;
 #pragma unroll
         for (int k = 0; k < CONV_CELLS; k++) {
             const float *p = src + (size_t)min(k * CONV_THREADS + tid, live - 1) * A.C;
@@ -138,11 +163,10 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
     };
     // the window cells in registers (a tile's, fetched earlier) -> s_view as conv1's operands
     auto stage = [&](int tile) {
-        const int na_t = min(A.TA, A.n - tile * A.TA);
+        const int live = min(TA, A.n - tile * TA) * HW;
 #pragma unroll
         for (int k = 0; k < CONV_CELLS; k++) {
-            const int c = k * CONV_THREADS + tid;
-            const bool have = c < na_t * A.H * A.W;
+            const bool have = k * CONV_THREADS + tid < live;
             bf16x8 v;
             if (CELLS16) {
                 v = nc[k];
@@ -152,59 +176,60 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
                 for (int e = 0; e < 7; e++) v[e] = (__bf16)((have && e < A.C) ? nv[k][e] : 0.0f);
                 v[7] = (__bf16)1.0f;
             }
-            if (c < cells) s_view[c] = v;
+            if (sdst[k] >= 0) s_view[sdst[k]] = v;
         }
     };
-    // Order of a tile's memory traffic (round 3).  Loads and stores share one counter on this part and complete out of order with respect
-    // to each other, so WAITING FOR A LOAD ALSO WAITS FOR EVERY STORE IN FLIGHT (profiles/r03_render_experiments.md).  Round 2 staged the
-    // next tile's views at the top of the loop -- right behind the conv2 stores of the tile before, whose whole round trip the wave then sat
-    // out (the "stores 0.11 ms" of profiles/r02_policy.txt).  Now the views of tile t + 1 go to LDS in the MIDDLE of tile t: conv1 has
-    // finished with s_view, the loads were issued a conv2 + a conv1 ago, and the only stores in flight are the previous tile's, a conv1 old;
-    // the stores of tile t then have the whole conv1 of tile t + 1 to land before anybody waits again.
+    // Order of a tile's memory traffic.  Loads and stores share one counter on this part and complete out of order with respect
+    // to each other, so WAITING FOR A LOAD ALSO WAITS FOR EVERY STORE IN FLIGHT (profiles/r03_render_experiments.md).  The views of tile
+    // t + 1 go to LDS in the MIDDLE of tile t: conv1 has finished with s_view, the loads were issued a conv2 + a conv1 ago, and the only
+    // stores in flight are the previous tile's, a conv1 old; the stores of tile t then have the whole conv1 of tile t + 1 to land
+    // before anybody waits again.
     // (The compiler's wait-count pass merges control-flow paths pessimistically.  Every wait for the weight loads above sat inside some
     // branch, so there was a path on which they were still in flight at the head of the tile loop -- and the loop then waited for
     // vmcnt(4) / vmcnt(0), i.e. for the view prefetch issued a moment earlier and for the previous tile's stores, in the middle of
     // EVERY conv1 and conv2.  An explicit wait here retires the weights on every path; it costs one round trip per workgroup.)
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the weights are in their registers, on every path into the loop
-    fetch(blockIdx.x); __syncthreads(); stage(blockIdx.x);
+    __syncthreads();                         // (the zero fill of s_view is complete before the first cells land)
+    fetch(blockIdx.x); stage(blockIdx.x);
     if ((int)(blockIdx.x + gridDim.x) < A.n_tiles) fetch(blockIdx.x + gridDim.x);
 
+    const int T1 = (E1 + 31) / 32, T2 = (P2 + 31) / 32;
     long long t_bar = 0, t_c1 = 0, t_stage = 0, t_c2 = 0, t_a = 0, t_b = 0;      // (STAMPS: wave 0's cycle counter around the phases)
     const long long t_begin = STAMPS ? clock64() : 0;
     for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
-        const int a0 = tile * A.TA, na = min(A.TA, A.n - a0);
+        const int a0 = tile * TA;
         if (STAMPS) t_a = clock64();
         __syncthreads();     // s_view holds this tile (staged in the middle of the tile before); the previous conv2's readers of s_c1 are done
+        if (STAMPS) { t_b = clock64(); t_bar += t_b - t_a; }
         // ---- conv1: [E1 positions, full rows] x [32 channels], K = 10 taps x 8 channels (bias: the constant channel of tap 0).
         // A wave runs TWO position tiles at a time (t and t + 4): two independent accumulator chains keep the matrix pipe busy
         // while the other chain's operands are on their way from LDS.
-        if (STAMPS) { t_b = clock64(); t_bar += t_b - t_a; }
-        const int T1 = (E1 + 31) / 32, NW = CONV_THREADS / 64;
-        for (int t = w; t < T1; t += 2 * NW) {
-            const bool two = t + NW < T1;
+        auto conv1 = [&](int t, auto two_c) __attribute__((always_inline)) {
+            constexpr bool two = decltype(two_c)::value;
             const int Ea = min(t * 32 + r32, E1 - 1), Eb = min((t + NW) * 32 + r32, E1 - 1);
-            const int ba = s_lutc[Ea], bb = s_lutc[Eb];
-            const unsigned ea = s_lut1[Ea], eb = s_lut1[Eb];
+            const int pa = Ea >> 2, pb = Eb >> 2, aa = Ea & 3, ab = Eb & 3;         // position (= top-left cell = c1 position), agent
+            const bf16x8 *va = s_view + aa * VP + pa + g * W, *vb = s_view + ab * VP + pb + g * W;        // taps (0|3) (1|4) (2|5)
+            const bf16x8 *ua = s_view + aa * VP + pa + g + 2 * W, *ub = s_view + ab * VP + pb + g + 2 * W;  // taps (6|7) (8|pad)
             bf16x8 xa[5], xb[5];
-#pragma unroll
-            for (int s = 0; s < 5; s++) { xa[s] = s_view[ba + off1[s]]; xb[s] = s_view[bb + off1[s]]; }
+            xa[0] = va[0]; xa[1] = va[1]; xa[2] = va[2]; xa[3] = ua[0]; xa[4] = ua[2];
+            if (two) { xb[0] = vb[0]; xb[1] = vb[1]; xb[2] = vb[2]; xb[3] = ub[0]; xb[4] = ub[2]; }
             f32x16 acca = {0}, accb = {0};
 #pragma unroll
             for (int s = 0; s < 5; s++) {
                 acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[s], xa[s], acca, 0, 0, 0);
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[s], xb[s], accb, 0, 0, 0);
+                if (two) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[s], xb[s], accb, 0, 0, 0);
             }
-            bf16x8 o0, o1;
-#pragma unroll
-            for (int r = 0; r < 8; r++) { o0[r] = (__bf16)fmaxf(acca[r], 0.0f); o1[r] = (__bf16)fmaxf(acca[8 + r], 0.0f); }
-            s_c1[(ea & 0x3FFF) * 4 + ((2 * g) ^ (ea >> 14))] = o0;       // (lanes past E1 repeat the last position: same values, harmless)
-            s_c1[(ea & 0x3FFF) * 4 + ((2 * g + 1) ^ (ea >> 14))] = o1;
+            bf16x8 *da = s_c1 + (2 * g) * PL + aa * AP + pa;       // (lanes past E1 repeat the last position: same values, harmless)
+            da[0] = relu_bf16x8(acca, 0); da[PL] = relu_bf16x8(acca, 8);
             if (two) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) { o0[r] = (__bf16)fmaxf(accb[r], 0.0f); o1[r] = (__bf16)fmaxf(accb[8 + r], 0.0f); }
-                s_c1[(eb & 0x3FFF) * 4 + ((2 * g) ^ (eb >> 14))] = o0;
-                s_c1[(eb & 0x3FFF) * 4 + ((2 * g + 1) ^ (eb >> 14))] = o1;
+                bf16x8 *db = s_c1 + (2 * g) * PL + ab * AP + pb;
+                db[0] = relu_bf16x8(accb, 0); db[PL] = relu_bf16x8(accb, 8);
             }
+        };
+        {
+            int t = w;
+            for (; t + NW < T1; t += 2 * NW) conv1(t, std::true_type{});
+            if (t < T1) conv1(t, std::false_type{});
         }
         if (STAMPS) { t_a = clock64(); t_c1 += t_a - t_b; }
         __syncthreads();
@@ -216,18 +241,16 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
         }
         if (STAMPS) { t_a = clock64(); t_stage += t_a - t_b; }
         // ---- conv2: [P2 positions] x [32 channels], K = 9 taps x 32 slots; starts from the bias, result straight to HBM.
-        // Two tiles per wave at a time here too; the operands of the next tap are read while the current one runs.
-        const unsigned char *c1b = (const unsigned char *)s_c1;
-        // (a fixed number of passes, every one issuing its four stores -- lanes without a position write to a dump line behind the
-        // workspace: the number of stores outstanding when the next tile's views are waited for is then known at compile time,
-        // and nothing sits in a run-time loop that would make the compiler drain the prefetch before entering it.  Measured:
-        // neutral -- the conv2 stores cost their 0.1 ms per 131072 agents either way, profiles/r02_policy.txt.)
-#pragma unroll
-        for (int it = 0; it < C2I; it++) {
-            const int t = w + it * 2 * NW;
+        // Two tiles per wave at a time here too; the four operands of tap + 1 are read while the MFMAs of tap run (the scheduling
+        // barriers keep the compiler from sinking the reads to where their values are used).
+        auto conv2 = [&](int t, auto two_c) __attribute__((always_inline)) {
+            constexpr bool two = decltype(two_c)::value;
             const int Qa = t * 32 + r32, Qb = (t + NW) * 32 + r32;
-            const unsigned ea = s_lut2[min(Qa, P2 - 1)], eb = s_lut2[min(Qb, P2 - 1)];
-            const unsigned basea = (ea & 0xFFFu) << 6, qa = ea >> 12, baseb = (eb & 0xFFFu) << 6, qb = eb >> 12;
+            const int Qca = min(Qa, P2 - 1), Qcb = min(Qb, P2 - 1);
+            const int qa = Qca >> 2, qb = Qcb >> 2, aa = Qca & 3, ab = Qcb & 3;
+            const int ya = qa / W2, yb = qb / W2;
+            const bf16x8 *ca = s_c1 + g * PL + aa * AP + ya * W + (qa - ya * W2);      // plane g (and g + 2) of the top-left c1 position
+            const bf16x8 *cb = s_c1 + g * PL + ab * AP + yb * W + (qb - yb * W2);
             f32x16 acca, accb;
             {
                 const f32x4 *bp = (const f32x4 *)(s_bias + g * 16);
@@ -238,40 +261,36 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
                     for (int i = 0; i < 4; i++) { acca[4 * q4 + i] = bq[i]; accb[4 * q4 + i] = bq[i]; }
                 }
             }
-            unsigned ada = basea + (((qa & 3) ^ g) << 4), adb = baseb + (((qb & 3) ^ g) << 4);
-            bf16x8 xa0 = *(const bf16x8 *)(c1b + ada), xa1 = *(const bf16x8 *)(c1b + (ada ^ 32));
-            bf16x8 xb0 = *(const bf16x8 *)(c1b + adb), xb1 = *(const bf16x8 *)(c1b + (adb ^ 32));
+            bf16x8 x[2][4];
+            auto xread = [&](int tap, bf16x8 (&dst)[4]) {
+                const int off = (tap / 3) * W + tap % 3;
+                dst[0] = ca[off]; dst[1] = ca[off + 2 * PL];
+                if (two) { dst[2] = cb[off]; dst[3] = cb[off + 2 * PL]; }
+            };
+            xread(0, x[0]);
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
-                bf16x8 nxa0 = xa0, nxa1 = xa1, nxb0 = xb0, nxb1 = xb1;
-                if (tap < 8) {
-                    const int nt = tap + 1;
-                    const unsigned toff = (unsigned)(((nt / 3) * A.W + nt % 3) * 64);
-                    ada = basea + toff + ((((qa >> (2 * nt)) & 3) ^ g) << 4);
-                    adb = baseb + toff + ((((qb >> (2 * nt)) & 3) ^ g) << 4);
-                    nxa0 = *(const bf16x8 *)(c1b + ada); nxa1 = *(const bf16x8 *)(c1b + (ada ^ 32));
-                    nxb0 = *(const bf16x8 *)(c1b + adb); nxb1 = *(const bf16x8 *)(c1b + (adb ^ 32));
-                }
-                acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap], xa0, acca, 0, 0, 0);
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap], xb0, accb, 0, 0, 0);
-                acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap + 1], xa1, acca, 0, 0, 0);
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap + 1], xb1, accb, 0, 0, 0);
-                xa0 = nxa0; xa1 = nxa1; xb0 = nxb0; xb1 = nxb1;
-            }
-            const int lim = na * H2 * W2;
-            bf16x8 o0, o1;
-            {
-#pragma unroll
-                for (int r = 0; r < 8; r++) { o0[r] = (__bf16)fmaxf(acca[r], 0.0f); o1[r] = (__bf16)fmaxf(acca[8 + r], 0.0f); }
-                bf16x8 *dst = Qa < lim ? (bf16x8 *)(A.act + ((size_t)a0 * H2 * W2 + Qa) * 32 + 16 * g) : A.dump + 2 * l;
-                dst[0] = o0; dst[1] = o1;
+                if (tap < 8) xread(tap + 1, x[(tap + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap], x[tap & 1][0], acca, 0, 0, 0);
+                if (two) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap], x[tap & 1][2], accb, 0, 0, 0);
+                acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap + 1], x[tap & 1][1], acca, 0, 0, 0);
+                if (two) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2[2 * tap + 1], x[tap & 1][3], accb, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             {
-#pragma unroll
-                for (int r = 0; r < 8; r++) { o0[r] = (__bf16)fmaxf(accb[r], 0.0f); o1[r] = (__bf16)fmaxf(accb[8 + r], 0.0f); }
-                bf16x8 *dst = Qb < lim ? (bf16x8 *)(A.act + ((size_t)a0 * H2 * W2 + Qb) * 32 + 16 * g) : A.dump + 2 * l;
-                dst[0] = o0; dst[1] = o1;
+                bf16x8 *dst = (Qa < P2 && a0 + aa < A.n) ? (bf16x8 *)(A.act + act_at(a0 + aa, qa, NP2) + 16 * g) : A.dump + 2 * l;
+                dst[0] = relu_bf16x8(acca, 0); dst[1] = relu_bf16x8(acca, 8);
             }
+            if (two) {
+                bf16x8 *dst = (Qb < P2 && a0 + ab < A.n) ? (bf16x8 *)(A.act + act_at(a0 + ab, qb, NP2) + 16 * g) : A.dump + 2 * l;
+                dst[0] = relu_bf16x8(accb, 0); dst[1] = relu_bf16x8(accb, 8);
+            }
+        };
+        {
+            int t = w;
+            for (; t + NW < T2; t += 2 * NW) conv2(t, std::true_type{});
+            if (t < T2) conv2(t, std::false_type{});
         }
         if (STAMPS) t_c2 += clock64() - t_a;
     }
@@ -283,10 +302,11 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
 
 // ---------------------------------------------------------------------------------------------------- dense + head
 constexpr int HEAD_THREADS = 512, HEAD_M = 128, HEAD_KC = 64;   // 128 agents per workgroup of 8 waves; K staged 64 at a time
-constexpr size_t HEAD_LDS = (2 * HEAD_M * (HEAD_KC / 8) + HEAD_M * 32 + 32 * 64) * 16;   // 2 x 16 KB activations + 64 KB hidden + 32 KB head weights = 128 KB
+constexpr int HEAD_ABUF = HEAD_M * (HEAD_KC / 8);                  // 16-byte units of one activation buffer (128 agents x 64 K values)
+constexpr size_t HEAD_LDS = (3 * HEAD_ABUF + HEAD_M * 32 + 32 * 64) * 16;   // 3 x 16 KB activations + 64 KB hidden + 32 KB head weights = 144 KB
 
 struct HeadArgs {
-    const __bf16 *act;        // [n][K] (K = H2 * W2 * 32, slot order)
+    const __bf16 *act;        // [n / 128][K / 64][128][64] (act_at; K = H2 * W2 * 32, slot order)
     const float *feat;        // [n][F]
     const bf16x8 *wv;         // dense_view, fragment order [K / 16][8 tiles][64]
     const bf16x8 *we;         // dense_emb,  fragment order [FK / 16][8 tiles][64]   (FK = F rounded up to 16)
@@ -314,30 +334,32 @@ template <bool STAMPS>
 __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
     const long long t_begin = STAMPS ? clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    bf16x8 (*s_act)[HEAD_M * (HEAD_KC / 8)] = (bf16x8 (*)[HEAD_M * (HEAD_KC / 8)])s_raw;      // [2][agent][8 chunks], swizzled
-    bf16x8 *s_hid = (bf16x8 *)s_raw + 2 * HEAD_M * (HEAD_KC / 8);                              // [agent][32 chunks], swizzled
+    bf16x8 *s_act = (bf16x8 *)s_raw;                                                           // [3][agent][8 chunks], swizzled
+    bf16x8 *s_hid = s_act + 3 * HEAD_ABUF;                                                     // [agent][32 chunks], swizzled
     bf16x8 *s_wh = s_hid + HEAD_M * 32;                                                        // the head's weights, fragment order [32][64]
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 5, r32 = l & 31;
     const int a0 = blockIdx.x * HEAD_M;
 
     const int srow = tid >> 2, spiece = tid & 3;       // staging: thread t -> row t / 4, 32-byte piece t % 4 of a 128-byte chunk row
-    const bf16x8 *arow = (const bf16x8 *)(A.act + (size_t)min(a0 + srow, A.n - 1) * A.K);
     const int sdst = srow * 8, ssw = (srow >> 1) & 7, rsw = (r32 >> 1) & 7;
     const bf16x8 *wbase = A.wv + (size_t)w * 64 + l;   // fragment (k-step s, tile w) = wbase[s * 8 * 64]
     const int n_steps = A.K / 16;                      // k-steps in all; the last chunk may be half (K is a multiple of 32)
     const int total = (n_steps + 3) / 4;
+    static_assert(HEAD_M == ACT_GROUP && HEAD_KC == 64, "one workgroup reads one block of the activation layout per chunk");
+    const bf16x8 *arow = (const bf16x8 *)A.act + (size_t)blockIdx.x * total * HEAD_ABUF + srow * 8;       // (+ chunk * HEAD_ABUF: chunk-major)
     auto aload = [&](int c, bf16x8 (&dst)[2]) {        // (a half chunk re-reads its first piece: clamped, never out of range)
         const int valid = min(8, (n_steps - c * 4) * 2);
 #pragma unroll
-        for (int i = 0; i < 2; i++) { const int ch = spiece * 2 + i; dst[i] = arow[(size_t)c * 8 + (ch < valid ? ch : 0)]; }
+        for (int i = 0; i < 2; i++) { const int ch = spiece * 2 + i; dst[i] = arow[(size_t)c * HEAD_ABUF + (ch < valid ? ch : 0)]; }
     };
-    auto astore = [&](int buf, const bf16x8 (&src)[2]) {
-        s_act[buf][sdst + ((spiece * 2) ^ ssw)] = src[0];
-        s_act[buf][sdst + ((spiece * 2 + 1) ^ ssw)] = src[1];
+    auto astore = [&](int off, const bf16x8 (&src)[2]) {       // (off: the buffer's offset in s_act)
+        s_act[off + sdst + ((spiece * 2) ^ ssw)] = src[0];
+        s_act[off + sdst + ((spiece * 2 + 1) ^ ssw)] = src[1];
     };
+    auto wload1 = [&](int c, int ks) { return wbase[(size_t)min(c * 4 + ks, n_steps - 1) * 8 * 64]; };
     auto wload = [&](int c, bf16x8 (&dst)[4]) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) dst[ks] = wbase[(size_t)min(c * 4 + ks, n_steps - 1) * 8 * 64];
+        for (int ks = 0; ks < 4; ks++) dst[ks] = wload1(c, ks);
     };
 
     f32x16 acc[4];        // [agent tile]
@@ -352,49 +374,58 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
 #pragma unroll
     for (int r = 0; r < 16; r++) { bias_v[r] = A.bv[w * 32 + g * 16 + r]; bias_e[r] = A.be[w * 32 + g * 16 + r]; }
 
-    bf16x8 ar[4][2], wr[4][4];
+    // The main loop (round 3).  THREE activation buffers: chunk kc + 2 is written while chunk kc is multiplied, so the barrier that ends
+    // chunk kc publishes data nobody reads before chunk kc + 1 is over -- and the first operands of chunk kc + 1 (published a barrier
+    // earlier) are read BEFORE that barrier, during the last k-step of chunk kc.  The matrix pipe then runs straight through the
+    // barriers (with two buffers every chunk began with all eight waves waiting for their first LDS reads: 2100 cycles per chunk for
+    // 1024 of MFMAs, by the cycle stamps).  Within a chunk the four operands of k-step ks + 1 are read while the MFMAs of k-step ks
+    // run; the chunk's LDS stores and global requests sit behind its second k-step, their latencies behind the other two.  The
+    // scheduling barriers pin that order (left alone the compiler sinks every read to its use).
+    // The loop over chunks is written WITHOUT a branch inside a group of four: the compiler's wait-count pass merges control-flow
+    // paths pessimistically, and with `if (kc >= total) break` after every chunk there was a path from the end of chunk q = 0 straight
+    // to the loop latch and back to the top on which only three loads follow the one a k-step waits for -- the top of every group
+    // waited for vmcnt(3), (2), (1), (0): the whole ring of 24 loads drained once per four chunks.  Full groups are straight-line code
+    // (stores and requests past the end are clamped and harmless); the chunks left over, one of which may be short, follow the loop.
+    bf16x8 ar[4][2], wr[4][4];       // ring slot q = kc & 3: activations of chunk kc + 2 (on their way to LDS), weights of chunk kc
     aload(0, ar[0]);
+    aload(min(1, total - 1), ar[1]);
 #pragma unroll
     for (int q = 0; q < 4; q++) wload(min(q, total - 1), wr[q]);
     astore(0, ar[0]);
+    astore(HEAD_ABUF, ar[1]);
 #pragma unroll
-    for (int q = 0; q < 4; q++) aload(min(1 + q, total - 1), ar[q]);
+    for (int q = 0; q < 4; q++) aload(min(2 + q, total - 1), ar[q]);
+    int boff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) boff[ks] = r32 * 8 + ((2 * ks + g) ^ rsw);
+    bf16x8 b[2][4];
+    auto bread = [&](int off, int ks, bf16x8 (&dst)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) dst[j] = s_act[off + 32 * 8 * j + boff[ks]];
+    };
     __syncthreads();
+    int o_cur = 0, o_nxt = HEAD_ABUF, o_wr = 2 * HEAD_ABUF;      // buffers of chunk kc, kc + 1, kc + 2
+    bread(o_cur, 0, b[0]);
     const long long t_loop = STAMPS ? clock64() : 0;
-    // One 64-wide K-chunk: its MFMAs, then the ring slot q = kc & 3 moves on (chunk kc + 1 to LDS, chunk kc + 5's activations and
-    // chunk kc + 4's weights requested).  The loop over chunks is written WITHOUT a branch inside a group of four (round 3).  The
-    // compiler's wait-count pass merges control-flow paths pessimistically: with `if (kc >= total) break` after every chunk there is
-    // a path from the end of chunk q = 0 straight to the loop latch and back to the top, on which only three loads follow the one a
-    // k-step waits for -- so the top of every group waited for vmcnt(3), (2), (1), (0): the whole ring of 24 loads drained once per
-    // four chunks, and a k-step in its own basic block (`if (ks < steps)`) read its LDS operands right before the MFMAs that use them.
-    // Full groups are now straight-line code (the stores and requests of a chunk past the end are clamped and harmless: the buffer
-    // they land in was last read before the previous barrier); the chunks left over, one of which may be short, follow the loop.
     auto chunk = [&](int kc, int q, bool full) __attribute__((always_inline)) {
-        const int buf = kc & 1;
         const int steps = full ? 4 : min(4, n_steps - kc * 4);
-        // (the four activation operands of k-step ks + 1 are read while the MFMAs of k-step ks run; the scheduling barriers keep the
-        // compiler from sinking the reads to where their values are used, which is what it does to save registers)
-        bf16x8 b[2][4];
-        auto bread = [&](int ks, bf16x8 (&dst)[4]) {
-            const int c = (2 * ks + g) ^ rsw;
-#pragma unroll
-            for (int j = 0; j < 4; j++) dst[j] = s_act[buf][(32 * j + r32) * 8 + c];
-        };
-        bread(0, b[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-            if (ks < 3 && (full || ks + 1 < steps)) bread(ks + 1, b[(ks + 1) & 1]);
+            bread(ks < 3 ? o_cur : o_nxt, (ks + 1) & 3, b[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
             if (full || ks < steps) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[q][ks], b[ks & 1][j], acc[j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            wr[q][ks] = wload1(min(kc + 4, total - 1), ks);                   // this ring slot is chunk kc + 4's now
+            if (ks == 1) {
+                astore(o_wr, ar[q]);                                      // chunk kc + 2, requested four chunks ago
+                aload(min(kc + 6, total - 1), ar[q]);
+            }
         }
-        astore(buf ^ 1, ar[q]);                                       // chunk kc + 1, requested four chunks ago
-        aload(min(kc + 5, total - 1), ar[q]);
-        wload(min(kc + 4, total - 1), wr[q]);                         // this ring slot is chunk kc + 4's now
         __syncthreads();
+        const int o = o_cur; o_cur = o_nxt; o_nxt = o_wr; o_wr = o;
     };
     int kc0 = 0;
     for (; (kc0 + 4) * 4 <= n_steps; kc0 += 4) {
@@ -439,7 +470,7 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
             bf16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; e++) { const int k = c * 8 + e; v[e] = (__bf16)(k < A.F ? A.feat[(size_t)agent * A.F + k] : 0.0f); }
-            s_act[0][sdst + (c ^ ssw)] = v;
+            s_act[sdst + (c ^ ssw)] = v;
         }
     }
     __syncthreads();
@@ -450,7 +481,7 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
         if (s < A.FK / 16) {
             const int c = (2 * s + g) ^ rsw;
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wemb[s], s_act[0][(32 * j + r32) * 8 + c], acc[j], 0, 0, 0);
+            for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wemb[s], s_act[(32 * j + r32) * 8 + c], acc[j], 0, 0, 0);
         }
     }
     __syncthreads();     // the first half of the head has read relu(dense_view)
@@ -493,14 +524,17 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
 
 extern "C" {
 
-static size_t act_bytes(const PolicyDqnShape *s, int n) { return (size_t)n * (s->view_h - 4) * (s->view_w - 4) * 32 * 2; }
+static size_t act_bytes(const PolicyDqnShape *s, int n) {      // whole groups of ACT_GROUP agents, whole K-chunks of 64
+    const size_t n_pos = (size_t)(s->view_h - 4) * (s->view_w - 4);
+    return (size_t)((n + ACT_GROUP - 1) / ACT_GROUP) * ((n_pos + 1) / 2) * ACT_GROUP * 64 * 2;
+}
 int policy_dqn_act_bytes(const PolicyDqnShape *s, int n, size_t *bytes) {
     *bytes = act_bytes(s, n) + 2048;       // (+ the dump line of k_dqn_conv)
     return 0;
 }
 
 int policy_dqn_supported(const PolicyDqnShape *s) {
-    return s->view_c >= 1 && s->view_c <= 7 && s->view_h >= 5 && s->view_w >= 5 && s->view_h * s->view_w <= 1024 && s->feat >= 1 && s->feat <= 64 &&
+    return s->view_c >= 1 && s->view_c <= 7 && s->view_h >= 5 && s->view_w >= 5 && s->view_h * s->view_w * CONV_TA <= CONV_CELLS * CONV_THREADS && s->feat >= 1 && s->feat <= 64 &&
            s->n_action >= 1 && s->n_action <= 31;
 }
 
@@ -511,19 +545,13 @@ static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const v
     if (n <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int H = s->view_h, W = s->view_w, H1 = H - 2, H2 = H - 4, W2 = W - 4;
-    // agents per workgroup pass: as many as leave two workgroups per CU their LDS (views 16 B / cell, conv1 64 B / position)
-    const int AP = H1 * W + ((H2 * W2 - H1 * W) % 4 + 4) % 4;      // agent pitch of conv1's LDS image: == H2 * W2 (mod 4)
-    static const int ta_cap = getenv("MAGENT_POLICY_TA") ? atoi(getenv("MAGENT_POLICY_TA")) : 8;       // (tuning: fewer agents per pass = more workgroups per CU)
+    // LDS images of k_dqn_conv: agent pitches == 4 (mod 16) sixteen-byte slots (conflict-free operand reads without a swizzle)
+    auto pitch = [](int least) { return least + ((4 - least % 16) % 16 + 16) % 16; };
+    const int VP = pitch(H * W + 3), AP = pitch(H1 * W);
+    const size_t lds = ((size_t)CONV_TA * VP + (size_t)4 * CONV_TA * AP) * 16 + 32 * 4;
+    if (lds > 150 * 1024) return 1;
     static const int conv_wpc = getenv("MAGENT_POLICY_WPC") ? atoi(getenv("MAGENT_POLICY_WPC")) : 2;
-    int TA = ta_cap < 1 ? 1 : ta_cap > 8 ? 8 : ta_cap;
-    size_t lds = 0;
-    for (; TA >= 1; TA--) {
-        const size_t cells = (size_t)TA * H * W, E1 = (size_t)TA * H1 * W, P2 = (size_t)TA * H2 * W2;
-        lds = (cells + 2) * 16 + (size_t)TA * AP * 64 + P2 * 4 + E1 * 4 + 32 * 4;
-        if (lds <= 78 * 1024 && (size_t)TA * AP < 4096 && cells <= (size_t)CONV_CELLS * CONV_THREADS && P2 <= (size_t)CONV_C2_ITERS * 256) break;
-    }
-    if (TA < 1) return 1;
-    const int T2 = (TA * H2 * W2 + 31) / 32, c2i = (T2 + 7) / 8;
+    const bool f13 = H == 13 && W == 13;
     // the stream's device is made current (launches and function attributes are per device), and the dynamic-LDS allowance is
     // granted once per DEVICE, not once per process
     int dev = 0;
@@ -532,20 +560,18 @@ static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const v
     static bool lds_ok_dev[64] = {};
     bool &lds_ok = lds_ok_dev[dev & 63];
     if (!lds_ok) {
-        const void *convs[8] = {reinterpret_cast<const void *>(k_dqn_conv<1, false>), reinterpret_cast<const void *>(k_dqn_conv<2, false>),
-                                reinterpret_cast<const void *>(k_dqn_conv<3, false>), reinterpret_cast<const void *>(k_dqn_conv<4, false>),
-                                reinterpret_cast<const void *>(k_dqn_conv<1, true>), reinterpret_cast<const void *>(k_dqn_conv<2, true>),
-                                reinterpret_cast<const void *>(k_dqn_conv<3, true>), reinterpret_cast<const void *>(k_dqn_conv<4, true>)};
+        const void *convs[5] = {reinterpret_cast<const void *>(k_dqn_conv<false, false>), reinterpret_cast<const void *>(k_dqn_conv<true, false>),
+                                reinterpret_cast<const void *>(k_dqn_conv<false, true>), reinterpret_cast<const void *>(k_dqn_conv<true, true>),
+                                reinterpret_cast<const void *>(k_dqn_conv<true, true, true>)};
         for (const void *f : convs)
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return 2;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_conv<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return 2;
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return 2;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_head<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS) != hipSuccess) return 2;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dqn_head<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS) != hipSuccess) return 2;
         lds_ok = true;
     }
     ConvArgs C{};
     C.view = view; C.act = (__bf16 *)act_workspace; C.w1 = (const bf16x8 *)w->conv1; C.w2 = (const bf16x8 *)w->conv2; C.b2 = w->conv2_bias;
-    C.n = n; C.H = H; C.W = W; C.C = s->view_c; C.TA = TA; C.AP = AP; C.n_tiles = (n + TA - 1) / TA; C.dump = (bf16x8 *)((char *)act_workspace + act_bytes(s, n));
+    C.n = n; C.H = H; C.W = W; C.C = s->view_c; C.VP = VP; C.AP = AP; C.n_tiles = (n + CONV_TA - 1) / CONV_TA; C.dump = (bf16x8 *)((char *)act_workspace + act_bytes(s, n));
     static const int grid_cap = getenv("MAGENT_POLICY_GRID") ? atoi(getenv("MAGENT_POLICY_GRID")) : 256 * conv_wpc;   // (tests: a few workgroups walk many tiles)
     const int grid = C.n_tiles < grid_cap ? C.n_tiles : grid_cap < 1 ? 1 : grid_cap;     // persistent (2 per CU): weights are fetched once per wave
     // development (MAGENT_POLICY_STAMPS=1, bf16-cell views of the battle shape only): wave 0 of every workgroup reads the cycle counter at
@@ -554,24 +580,16 @@ static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const v
     static const bool stamps_on = getenv("MAGENT_POLICY_STAMPS") && atoi(getenv("MAGENT_POLICY_STAMPS")) != 0;
     const int head_grid = (n + HEAD_M - 1) / HEAD_M;
     long long *d_stamps = nullptr;
-    const bool stamp_conv = stamps_on && cells16 && c2i == 2;
+    const bool stamp_conv = stamps_on && cells16 && f13;
     if (stamps_on) {
         if (hipMalloc((void **)&d_stamps, (size_t)(grid + head_grid) * 64) != hipSuccess) return 2;
         (void)hipMemsetAsync(d_stamps, 0, (size_t)(grid + head_grid) * 64, st);
         C.stamps = d_stamps;
     }
-#define CONV_LAUNCH(I, B) hipLaunchKernelGGL((k_dqn_conv<I, B>), dim3(grid), dim3(CONV_THREADS), lds, st, C)
-    if (stamp_conv) hipLaunchKernelGGL((k_dqn_conv<2, true, true>), dim3(grid), dim3(CONV_THREADS), lds, st, C);
-    else switch (c2i * 2 + (cells16 ? 1 : 0)) {
-        case 2: CONV_LAUNCH(1, false); break;
-        case 3: CONV_LAUNCH(1, true); break;
-        case 4: CONV_LAUNCH(2, false); break;
-        case 5: CONV_LAUNCH(2, true); break;
-        case 6: CONV_LAUNCH(3, false); break;
-        case 7: CONV_LAUNCH(3, true); break;
-        case 8: CONV_LAUNCH(4, false); break;
-        default: CONV_LAUNCH(4, true); break;
-    }
+#define CONV_LAUNCH(...) hipLaunchKernelGGL((k_dqn_conv<__VA_ARGS__>), dim3(grid), dim3(CONV_THREADS), lds, st, C)
+    if (stamp_conv) CONV_LAUNCH(true, true, true);
+    else if (f13) { if (cells16) CONV_LAUNCH(true, true); else CONV_LAUNCH(false, true); }
+    else { if (cells16) CONV_LAUNCH(true, false); else CONV_LAUNCH(false, false); }
 #undef CONV_LAUNCH
     HeadArgs Hd{};
     Hd.act = (const __bf16 *)act_workspace; Hd.feat = feat; Hd.wv = (const bf16x8 *)w->dense_view; Hd.we = (const bf16x8 *)w->dense_emb; Hd.wh = (const bf16x8 *)w->head;

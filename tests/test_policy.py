@@ -115,10 +115,13 @@ def test_weight_packing_is_the_documented_permutation():
     assert t["conv1"].shape == (5, 1, 64, 8) and t["conv2"].shape == (18, 1, 64, 8) and t["dense_view"].shape == (162, 8, 64, 8)
     assert t["dense_emb"].shape == (3, 8, 64, 8) and t["head"].shape == (32, 1, 64, 8)
     bf = lambda x: x.detach().to(torch.bfloat16).float()
-    # conv1: k = tap * 8 + channel; (tap 0, channel 7) carries the bias; taps 9.. and channels >= C are zero
+    # conv1: k = j * 8 + channel, j the tap's place in the order 0 3 1 4 2 5 6 7 8 pad; (tap 0, channel 7) carries the bias; the padding
+    # tap and channels >= C are zero
+    from magent_amd.builtin.torch_model.hip_policy import CONV1_TAP_ORDER
     c1 = t["conv1"].float()
-    get1 = lambda co, k: c1[k // 16, 0, 32 * ((k % 16) // 8) + co, k % 8]
-    assert get1(5, 2 * 8 + 3) == bf(qnet.conv1.weight)[5, 3, 0, 2] and get1(9, 7) == bf(qnet.conv1.bias)[9] and get1(9, 9 * 8 + 1) == 0
+    get1 = lambda co, tap, c: c1[(CONV1_TAP_ORDER.index(tap) * 8 + c) // 16, 0, 32 * (((CONV1_TAP_ORDER.index(tap) * 8 + c) % 16) // 8) + co, c]
+    assert get1(5, 2, 3) == bf(qnet.conv1.weight)[5, 3, 0, 2] and get1(5, 7, 1) == bf(qnet.conv1.weight)[5, 1, 2, 1]
+    assert get1(9, 0, 7) == bf(qnet.conv1.bias)[9] and get1(9, 9, 1) == 0 and get1(9, 4, 7) == 0
     # conv2: k = tap * 32 + slot, slot -> input channel ch[slot]
     c2 = t["conv2"].float()
     get2 = lambda co, k: c2[k // 16, 0, 32 * ((k % 16) // 8) + co, k % 8]

@@ -27,7 +27,9 @@ def _infer(lib, pol, view, feat, cells16=False):
     n = view.shape[0]
     actions = torch.empty(n, dtype=torch.int32)
     q = torch.empty((n, pol.shape.n_action), dtype=torch.float32)
-    work = torch.zeros(n * pol.k_dense * 2 + 2048, dtype=torch.uint8)
+    nbytes = ctypes.c_size_t(0)
+    lib.policy_dqn_act_bytes(ctypes.byref(pol.shape), ctypes.c_int(n), ctypes.byref(nbytes))
+    work = torch.zeros(nbytes.value, dtype=torch.uint8)
     call = lib.policy_dqn_infer_bf16 if cells16 else lib.policy_dqn_infer
     rc = call(ctypes.byref(pol.shape), ctypes.byref(pol._w), ctypes.c_void_p(view.data_ptr()), ctypes.c_void_p(feat.data_ptr()), ctypes.c_int(n),
               ctypes.c_void_p(work.data_ptr()), ctypes.c_void_p(actions.data_ptr()), ctypes.c_void_p(q.data_ptr()), None)
