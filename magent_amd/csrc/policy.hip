@@ -302,8 +302,11 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv(ConvArgs A) {
 
 // ---------------------------------------------------------------------------------------------------- dense + head
 constexpr int HEAD_THREADS = 512, HEAD_M = 128, HEAD_KC = 64;   // 128 agents per workgroup of 8 waves; K staged 64 at a time
+#ifndef HEAD_RING
+#define HEAD_RING 4
+#endif
 constexpr int HEAD_ABUF = HEAD_M * (HEAD_KC / 8);                  // 16-byte units of one activation buffer (128 agents x 64 K values)
-constexpr size_t HEAD_LDS = (3 * HEAD_ABUF + HEAD_M * 32 + 32 * 64) * 16;   // 3 x 16 KB activations + 64 KB hidden + 32 KB head weights = 144 KB
+constexpr size_t HEAD_LDS = (3 * HEAD_ABUF + HEAD_M * 32 + 32 * 64) * 16 + 512 * 4;   // 3 x 16 KB activations + 64 KB hidden + 32 KB head weights + 2 KB biases = 146 KB
 
 struct HeadArgs {
     const __bf16 *act;        // [n / 128][K / 64][128][64] (act_at; K = H2 * W2 * 32, slot order)
@@ -345,16 +348,22 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
     const bf16x8 *wbase = A.wv + (size_t)w * 64 + l;   // fragment (k-step s, tile w) = wbase[s * 8 * 64]
     const int n_steps = A.K / 16;                      // k-steps in all; the last chunk may be half (K is a multiple of 32)
     const int total = (n_steps + 3) / 4;
-    static_assert(HEAD_M == ACT_GROUP && HEAD_KC == 64, "one workgroup reads one block of the activation layout per chunk");
-    const bf16x8 *arow = (const bf16x8 *)A.act + (size_t)blockIdx.x * total * HEAD_ABUF + srow * 8;       // (+ chunk * HEAD_ABUF: chunk-major)
+    static_assert(HEAD_M == ACT_GROUP && HEAD_KC == 64 && HEAD_THREADS == 512, "one workgroup reads one block of the activation layout per chunk");
+    // activation block of a chunk: 1024 sixteen-byte units (unit u: agent row u >> 3, piece u & 7).  Thread t moves units t and 512 + t:
+    // every load instruction of a wave covers 1 KB of consecutive memory (eight whole cache lines), every LDS store a whole swizzled row
+    // per eight lanes.
+    const int arow0 = tid >> 3, apiece = tid & 7;
+    const bf16x8 *ablock = (const bf16x8 *)A.act + (size_t)blockIdx.x * total * HEAD_ABUF;
     auto aload = [&](int c, bf16x8 (&dst)[2]) {        // (a half chunk re-reads its first piece: clamped, never out of range)
         const int valid = min(8, (n_steps - c * 4) * 2);
-#pragma unroll
-        for (int i = 0; i < 2; i++) { const int ch = spiece * 2 + i; dst[i] = arow[(size_t)c * HEAD_ABUF + (ch < valid ? ch : 0)]; }
+        const int u = arow0 * 8 + (apiece < valid ? apiece : 0);
+        dst[0] = ablock[(size_t)c * HEAD_ABUF + u];
+        dst[1] = ablock[(size_t)c * HEAD_ABUF + 512 + u];
     };
     auto astore = [&](int off, const bf16x8 (&src)[2]) {       // (off: the buffer's offset in s_act)
-        s_act[off + sdst + ((spiece * 2) ^ ssw)] = src[0];
-        s_act[off + sdst + ((spiece * 2 + 1) ^ ssw)] = src[1];
+        const int slot = arow0 * 8 + (apiece ^ ((arow0 >> 1) & 7));       // (rows r and 64 + r share (r >> 1) & 7)
+        s_act[off + slot] = src[0];
+        s_act[off + 512 + slot] = src[1];
     };
     auto wload1 = [&](int c, int ks) { return wbase[(size_t)min(c * 4 + ks, n_steps - 1) * 8 * 64]; };
     auto wload = [&](int c, bf16x8 (&dst)[4]) {
@@ -366,13 +375,12 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[j] = f32x16{0};
     // what the phases behind the main loop need from L2 is fetched now (measured: loaded at their point of use -- 32 dependent
-    // round trips for the head's weights alone -- those phases were 100 of the kernel's 280 us): the head's weights go to LDS,
-    // this lane's biases to registers
+    // round trips for the head's weights alone -- those phases were 100 of the kernel's 280 us): the head's weights and the biases of
+    // both hidden halves go to LDS (the biases sat in 32 registers through the main loop in round 2; the activation ring has them now)
 #pragma unroll
     for (int k = 0; k < 4; k++) s_wh[k * HEAD_THREADS + tid] = A.wh[k * HEAD_THREADS + tid];
-    float bias_v[16], bias_e[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) { bias_v[r] = A.bv[w * 32 + g * 16 + r]; bias_e[r] = A.be[w * 32 + g * 16 + r]; }
+    float *s_bias = (float *)(s_wh + 32 * 64);            // [2][8 tiles][2][16]
+    s_bias[tid] = tid < 256 ? A.bv[tid] : A.be[tid - 256];
 
     // The main loop (round 3).  THREE activation buffers: chunk kc + 2 is written while chunk kc is multiplied, so the barrier that ends
     // chunk kc publishes data nobody reads before chunk kc + 1 is over -- and the first operands of chunk kc + 1 (published a barrier
@@ -386,15 +394,19 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
     // to the loop latch and back to the top on which only three loads follow the one a k-step waits for -- the top of every group
     // waited for vmcnt(3), (2), (1), (0): the whole ring of 24 loads drained once per four chunks.  Full groups are straight-line code
     // (stores and requests past the end are clamped and harmless); the chunks left over, one of which may be short, follow the loop.
-    bf16x8 ar[4][2], wr[4][4];       // ring slot q = kc & 3: activations of chunk kc + 2 (on their way to LDS), weights of chunk kc
+    // (Four chunks ahead for both streams: loads return in order on one counter, so the shallower ring sets the distance of both, and
+    // eight slots of each do not fit the register file.  The waves still wait for activations a quarter of the loop -- storing data
+    // nobody waits for instead ran 0.053 ms faster of 0.23, profiles/r03_policy.txt.)
+    constexpr int RING = HEAD_RING;
+    bf16x8 ar[RING][2], wr[RING][4];       // ring slot q = kc % RING: activations of chunk kc + 2 (on their way to LDS), weights of chunk kc
     aload(0, ar[0]);
     aload(min(1, total - 1), ar[1]);
 #pragma unroll
-    for (int q = 0; q < 4; q++) wload(min(q, total - 1), wr[q]);
+    for (int q = 0; q < RING; q++) wload(min(q, total - 1), wr[q]);
     astore(0, ar[0]);
     astore(HEAD_ABUF, ar[1]);
 #pragma unroll
-    for (int q = 0; q < 4; q++) aload(min(2 + q, total - 1), ar[q]);
+    for (int q = 0; q < RING; q++) aload(min(2 + q, total - 1), ar[q]);
     int boff[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) boff[ks] = r32 * 8 + ((2 * ks + g) ^ rsw);
@@ -418,40 +430,41 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
                 for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[q][ks], b[ks & 1][j], acc[j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            wr[q][ks] = wload1(min(kc + 4, total - 1), ks);                   // this ring slot is chunk kc + 4's now
+            wr[q][ks] = wload1(min(kc + RING, total - 1), ks);                // this ring slot is chunk kc + RING's now
             if (ks == 1) {
                 astore(o_wr, ar[q]);                                      // chunk kc + 2, requested four chunks ago
-                aload(min(kc + 6, total - 1), ar[q]);
+                aload(min(kc + 2 + RING, total - 1), ar[q]);
             }
         }
         __syncthreads();
         const int o = o_cur; o_cur = o_nxt; o_nxt = o_wr; o_wr = o;
     };
     int kc0 = 0;
-    for (; (kc0 + 4) * 4 <= n_steps; kc0 += 4) {
+    for (; (kc0 + RING) * 4 <= n_steps; kc0 += RING) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) chunk(kc0 + q, q, true);
+        for (int q = 0; q < RING; q++) chunk(kc0 + q, q, true);
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+    for (int q = 0; q < RING; q++)
         if (kc0 + q < total) chunk(kc0 + q, q, false);
     const long long t_tail = STAMPS ? clock64() : 0;
     // relu(dense_view) -> hidden slots: output tile w holds chunks 4 w + 2 g, 4 w + 2 g + 1 of every agent
-    auto hidden_out = [&](const float (&bias)[16]) {
+    auto hidden_out = [&](int half) {
+        float bias[16];
+        const f32x4 *bp = (const f32x4 *)(s_bias + half * 256 + w * 32 + g * 16);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) { const f32x4 bq = bp[q4]; bias[4 * q4] = bq[0]; bias[4 * q4 + 1] = bq[1]; bias[4 * q4 + 2] = bq[2]; bias[4 * q4 + 3] = bq[3]; }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int agent = 32 * j + r32;
-            bf16x8 o0, o1;
+            f32x16 v;
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                o0[r] = (__bf16)fmaxf(acc[j][r] + bias[r], 0.0f);
-                o1[r] = (__bf16)fmaxf(acc[j][8 + r] + bias[8 + r], 0.0f);
-            }
-            s_hid[hid_at(agent, 4 * w + 2 * g)] = o0;
-            s_hid[hid_at(agent, 4 * w + 2 * g + 1)] = o1;
+            for (int r = 0; r < 16; r++) v[r] = acc[j][r] + bias[r];
+            s_hid[hid_at(agent, 4 * w + 2 * g)] = relu_bf16x8(v, 0);
+            s_hid[hid_at(agent, 4 * w + 2 * g + 1)] = relu_bf16x8(v, 8);
         }
     };
-    hidden_out(bias_v);
+    hidden_out(0);
     // ---- the dueling head: [32 outputs] x [128 agents], K = 512 hidden slots in two halves; waves 0..3 take 32 agents each
     f32x16 h = {0};
     const int hagent = 32 * (w & 3) + r32;
@@ -485,7 +498,7 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
         }
     }
     __syncthreads();     // the first half of the head has read relu(dense_view)
-    hidden_out(bias_e);
+    hidden_out(1);
     __syncthreads();
     if (w < 4) {
 #pragma unroll 4
