@@ -464,27 +464,37 @@ __global__ void __launch_bounds__(HEAD_THREADS) k_dqn_head(HeadArgs A) {
             s_hid[hid_at(agent, 4 * w + 2 * g + 1)] = relu_bf16x8(v, 8);
         }
     };
+    // what the embedding needs from memory is requested before the hidden layer is written out: the features of this thread's agent
+    // (two chunks of 8 at most: FK <= 64) and the wave's embedding weights fly while hidden_out and the first half of the head run
+    // (they were requested behind the head's first half and waited for on the spot: 2 of the tail's 14 thousand cycles)
+    bf16x8 wemb[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) wemb[s] = A.we[((size_t)min(s, A.FK / 16 - 1) * 8 + w) * 64 + l];
+    float fv[2][8];
+    {
+        const float *frow = A.feat + (size_t)min(a0 + srow, A.n - 1) * A.F;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) fv[i][e] = frow[min((spiece + 4 * i) * 8 + e, A.F - 1)];       // (clamped: selected below)
+    }
     hidden_out(0);
     // ---- the dueling head: [32 outputs] x [128 agents], K = 512 hidden slots in two halves; waves 0..3 take 32 agents each
     f32x16 h = {0};
     const int hagent = 32 * (w & 3) + r32;
     __syncthreads();
+    // ---- the feature embedding: K = FK (features as bf16 through the staging buffer, [agent][FK / 8 chunks] <= 8 chunks)
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int c = spiece + 4 * i;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (__bf16)(c * 8 + e < A.F ? fv[i][e] : 0.0f);
+        if (c < A.FK / 8) s_act[sdst + (c ^ ssw)] = v;
+    }
     if (w < 4) {
 #pragma unroll 4
         for (int s = 0; s < 16; s++) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s_wh[s * 64 + l], s_hid[hid_at(hagent, 2 * s + g)], h, 0, 0, 0);
-    }
-    // ---- the feature embedding: K = FK (features as bf16 through the staging buffer, [agent][FK / 8 chunks] <= 8 chunks)
-    bf16x8 wemb[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) wemb[s] = A.we[((size_t)min(s, A.FK / 16 - 1) * 8 + w) * 64 + l];
-    {
-        const int agent = min(a0 + srow, A.n - 1);
-        for (int c = spiece; c < A.FK / 8; c += 4) {
-            bf16x8 v;
-#pragma unroll
-            for (int e = 0; e < 8; e++) { const int k = c * 8 + e; v[e] = (__bf16)(k < A.F ? A.feat[(size_t)agent * A.F + k] : 0.0f); }
-            s_act[sdst + (c ^ ssw)] = v;
-        }
     }
     __syncthreads();
 #pragma unroll
