@@ -9,7 +9,8 @@
 //
 // Execution model: one launch = its workgroups one after another (optionally in a scrambled order); the threads of a
 // workgroup are fibers on ONE host thread.  A fiber runs until it reaches __syncthreads(), a wave-level operation (__ballot,
-// __shfl_down, wave barrier) or the end of the kernel; barriers and wave operations complete when every lane that can still
+// __shfl_down, wave barrier, an MFMA -- the matrix instruction is a wave-wide meeting that gathers every lane's operands, see
+// "matrix cores" below) or the end of the kernel; barriers and wave operations complete when every lane that can still
 // reach them has arrived.  HIPEMU_SCRAMBLE=<seed> runs the lanes of a workgroup (and the workgroups of a launch) in a
 // pseudo-random order that changes at every scheduling pass, which makes results that depend on an unsynchronised order show.
 #pragma once
