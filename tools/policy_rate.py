@@ -14,7 +14,7 @@ vs, F, A = (13, 13, 7), 34, 21
 qnet = _QNet(vs, (F,), A, True, True).to(dev)
 view = (torch.rand((n,) + vs, device=dev) < 0.3).float()
 feat = torch.rand((n, F), device=dev)
-pol = HipDqnPolicy(qnet, vs, (F,), A, dev, chunk=n)
+pol = HipDqnPolicy(qnet, vs, (F,), A, dev, chunk=int(os.environ.get("CHUNK", n)))
 if "cells" in sys.argv:      # the engine's bf16-cell observation format (env_get_observation_device_bf16)
     cells = torch.zeros((n,) + vs[:2] + (8,), dtype=torch.bfloat16, device=dev)
     cells[..., :vs[2]] = view.to(torch.bfloat16); cells[..., 7] = 1
