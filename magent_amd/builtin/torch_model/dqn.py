@@ -159,6 +159,20 @@ class DeepQNetwork(BaseModel):
 
     # ------------------------------------------------------------------ learning
     def _add_to_replay_buffer(self, sample_buffer):
+        if hasattr(sample_buffer, "packed"):      # every transition of the round in episode order, one put per array (utility.EpisodesBuffer)
+            packed = sample_buffer.packed()
+            if packed is None:
+                return 0
+            views, features, actions, rewards, terminal, mask = packed
+            n = len(rewards)
+            self.mem_view.put(views.to(self.device) if isinstance(views, torch.Tensor) else self._tensor(views))
+            self.mem_feature.put(features.to(self.device) if isinstance(features, torch.Tensor) else self._tensor(features))
+            self.mem_action.put(actions.to(self.device, torch.int64) if isinstance(actions, torch.Tensor) else self._tensor(actions, torch.int64))
+            self.mem_reward.put(self._tensor(rewards))
+            self.mem_terminal.put(self._tensor(terminal, torch.bool))
+            self.mem_mask.put(self._tensor(mask))
+            self.replay_len = min(self.memory_size, self.replay_len + n)
+            return n
         n = 0
         for ep in sample_buffer.episodes():
             m = len(ep.rewards)

@@ -42,6 +42,50 @@ def test_episodes_buffer_tracks_a_capped_random_subset():
     assert len(buf.buffer) == 5
 
 
+def test_episodes_buffer_packed_is_the_loop_over_episodes():
+    """packed() -- what DeepQNetwork puts into its replay memory in one go -- is exactly what the reference's loop over episodes()
+    appends episode by episode (views, features, actions, rewards; terminal on the last transition of an agent that died, mask 0 on
+    the last transition of one that did not), with agents dying, leaving and new ones showing up, numpy and torch observations"""
+    import torch
+    from magent_amd.utility import EpisodesBuffer
+    for as_torch in (False, True):
+        rs = np.random.RandomState(5)
+        np.random.seed(11)
+        buf = EpisodesBuffer(capacity=13)
+        alive_ids = list(range(50, 70))
+        next_id = 70
+        for t in range(9):
+            ids = np.array(alive_ids, dtype=np.int32)
+            n = len(ids)
+            views, feats = rs.rand(n, 3, 3, 2).astype(np.float32), rs.rand(n, 4).astype(np.float32)
+            acts, rewards = rs.randint(5, size=n).astype(np.int32), rs.rand(n).astype(np.float32)
+            alives = rs.rand(n) > 0.15
+            obs = (torch.from_numpy(views), torch.from_numpy(feats)) if as_torch else (views, feats)
+            buf.record_step(ids, obs, torch.from_numpy(acts) if as_torch else acts, rewards, alives)
+            alive_ids = [i for i, a in zip(alive_ids, alives) if a] + [next_id, next_id + 1]      # the dead are cleared, two are born
+            next_id += 2
+        assert buf.is_full and len(buf.buffer) == 13
+        want = {k: [] for k in ("views", "features", "actions", "rewards", "terminal", "mask")}
+        for ep in buf.episodes():                      # the loop of tf_model/dqn.py:233-262 / torch_model/dqn.py
+            m = len(ep.rewards)
+            assert m > 0
+            mask, terminal = np.ones(m, np.float32), np.zeros(m, bool)
+            if ep.terminal:
+                terminal[-1] = True
+            else:
+                mask[-1] = 0
+            want["views"] += [np.asarray(v) for v in ep.views]; want["features"] += [np.asarray(f) for f in ep.features]
+            want["actions"] += ep.actions; want["rewards"] += ep.rewards
+            want["terminal"] += list(terminal); want["mask"] += list(mask)
+        views, feats, acts, rewards, terminal, mask = buf.packed()
+        assert isinstance(views, torch.Tensor) == as_torch
+        assert np.array_equal(np.asarray(views), np.stack(want["views"])) and np.array_equal(np.asarray(feats), np.stack(want["features"]))
+        assert np.array_equal(np.asarray(acts), np.array(want["actions"])) and np.array_equal(rewards, np.array(want["rewards"], np.float32))
+        assert np.array_equal(terminal, np.array(want["terminal"])) and np.array_equal(mask, np.array(want["mask"], np.float32))
+        assert terminal.any() and (mask == 0).any()
+    assert EpisodesBuffer(3).packed() is None
+
+
 def _np_qnet(params, view, feature, use_dueling=True):
     """NumPy fp32 restatement of the reference network (tf_model/dqn.py:151-189): conv3x3(32) -> conv3x3(32), both VALID, NHWC,
     relu -> flatten (h, w, c order) -> dense 256 relu || dense 256 relu on the features -> concat -> dueling head
