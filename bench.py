@@ -172,10 +172,13 @@ def selfplay_extra(torch, magent_amd, n=400000, steps=4):
         if s == 2:
             torch.cuda.synchronize(); env.sync()
             total, t0 = 0, time.perf_counter()
-        for h, m in zip(hs, models):
-            obs = env.get_observation(h)
-            env.set_action(h, m.infer_action(obs, None, policy="e_greedy", eps=0.1))
+        acts = []
+        for h, m in zip(hs, models):        # (examples/train_battle.py:63-71: observe + infer for every side, then the actions are set;
+            obs = env.get_observation(h)    #  the second side's observation is rendered while the first side's policy runs)
+            acts.append(m.infer_action(obs, None, policy="e_greedy", eps=0.1))
             total += env.get_num(h)
+        for h, a in zip(hs, acts):
+            env.set_action(h, a)
         env.step()
         for h in hs:
             env.get_reward(h)
