@@ -30,7 +30,8 @@ def _reference(qnet, view, feat):
 @pytest.mark.gpu
 @pytest.mark.parametrize("view_space,feat,n_action,n", [((13, 13, 7), 34, 21, 1000), ((13, 13, 7), 34, 21, 64 * 6 + 5),
                                                          ((9, 9, 5), 18, 9, 777), ((13, 11, 6), 40, 31, 300), ((7, 7, 3), 5, 5, 131),
-                                                         ((13, 13, 7), 34, 21, 1), ((13, 13, 7), 34, 21, 7), ((5, 5, 1), 1, 2, 40)])
+                                                         ((13, 13, 7), 34, 21, 1), ((13, 13, 7), 34, 21, 7), ((5, 5, 1), 1, 2, 40),
+                                                         ((16, 16, 4), 36, 13, 300), ((15, 15, 7), 64, 31, 200)])
 def test_hip_policy_matches_torch_reference(view_space, feat, n_action, n):
     import torch
     from magent_amd.builtin.torch_model.dqn import _QNet

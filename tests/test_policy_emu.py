@@ -38,7 +38,7 @@ def _infer(lib, pol, view, feat, cells16=False):
 
 
 @pytest.mark.parametrize("view_space,feat,n_action,n", [((13, 13, 7), 34, 21, 128 + 37), ((9, 9, 5), 18, 9, 77), ((13, 11, 6), 40, 31, 70),
-                                                         ((7, 7, 3), 5, 5, 131), ((13, 13, 7), 34, 21, 1), ((5, 5, 1), 1, 2, 40)])
+                                                         ((7, 7, 3), 5, 5, 131), ((13, 13, 7), 34, 21, 1), ((5, 5, 1), 1, 2, 40), ((16, 16, 4), 36, 13, 9), ((15, 15, 7), 64, 31, 6)])
 def test_emulated_policy_matches_torch_reference(view_space, feat, n_action, n):
     import torch
     from test_policy import _reference
