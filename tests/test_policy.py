@@ -64,6 +64,35 @@ def test_hip_policy_matches_torch_reference(view_space, feat, n_action, n):
 
 
 @pytest.mark.gpu
+def test_hip_policy_many_tiles_per_workgroup():
+    """more agents per launch than the persistent conv grid has workgroups x 4: every workgroup walks several tiles (the register
+    prefetch a tile ahead, the staging in the middle of a tile), the head runs several rounds of workgroups; float32 and bf16-cell views"""
+    import torch
+    from magent_amd.builtin.torch_model.dqn import _QNet
+    from magent_amd.builtin.torch_model.hip_policy import HipDqnPolicy
+    torch.manual_seed(77)
+    dev = torch.device("cuda", 0)
+    view_space, feat, n_action, n = (13, 13, 7), 34, 21, 4 * 512 * 5 + 77 * 4 + 3
+    qnet = _QNet(view_space, (feat,), n_action, True, True).to(dev)
+    with torch.no_grad():
+        for p in qnet.parameters():
+            p.mul_(3.0)
+    view = (torch.rand((n,) + view_space, device=dev) < 0.3).float() * torch.rand((n,) + view_space, device=dev)
+    featv = torch.rand((n, feat), device=dev) * 2 - 0.5
+    pol = HipDqnPolicy(qnet, view_space, (feat,), n_action, dev, chunk=1 << 20)
+    actions, q = pol.infer(view, featv, want_q=True)
+    with torch.no_grad():
+        ref = _reference(qnet, view, featv)
+    scale = float(ref.abs().max())
+    assert (q - ref).abs().max().item() <= 2e-3 * scale + 2e-3
+    assert torch.equal(actions.long(), q.argmax(dim=1))
+    cells = torch.zeros((n,) + view_space[:2] + (8,), dtype=torch.bfloat16, device=dev)
+    cells[..., :7] = view.to(torch.bfloat16); cells[..., 7] = 1
+    a16, q16 = pol.infer(cells, featv, want_q=True)
+    assert torch.equal(q16, q) and torch.equal(a16, actions)
+
+
+@pytest.mark.gpu
 def test_hip_policy_follows_parameter_updates():
     """DeepQNetwork repacks the kernel's weights after training: infer_action through the HIP path tracks the torch network"""
     import torch
