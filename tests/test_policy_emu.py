@@ -66,3 +66,17 @@ def test_emulated_policy_matches_torch_reference(view_space, feat, n_action, n):
     cells[..., 7] = 1.0
     a16, q16 = _infer(lib, pol, cells.contiguous(), featv, cells16=True)
     assert torch.equal(q16, q) and torch.equal(a16, actions)
+
+
+@pytest.mark.parametrize("seed", ["5", "19"])
+def test_emulated_policy_in_scrambled_order(seed):
+    """HIPEMU_SCRAMBLE: the waves of a workgroup (and the workgroups of a launch) run in a pseudo-random order that changes at every
+    scheduling pass -- a wave may run a whole chunk ahead of its neighbours between two barriers.  The three-buffer ring of the head
+    and the staging of the conv kernel must not care: the same cases, in a process of their own (the variable is read at the first launch)"""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import test_policy_emu as T\n"
+            "for case in (((13, 13, 7), 34, 21, 128 + 37), ((9, 9, 5), 18, 9, 77), ((7, 7, 3), 5, 5, 131)):\n"
+            "    T.test_emulated_policy_matches_torch_reference(*case)\n"
+            "print('scrambled ok')\n") % os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPEMU_SCRAMBLE=seed, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "scrambled ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
