@@ -157,7 +157,7 @@ def small_world_extras(torch, magent_amd, dev, steps=200, warmup=20):
 def selfplay_extra(torch, magent_amd, n=400000, steps=4):
     """BASELINE config 5's shape on one GPU: battle 1000x1000, both sides acting through the reference's DQN (inference only,
     epsilon-greedy), observations and actions staying in HBM; the forward pass runs on the hand-written MFMA kernels
-    (magent_amd/csrc/policy.hip).  Whole-cycle time: observe, infer, set_action per group; step; rewards; clear_dead."""
+    (magent_amd/csrc/policy.hip).  Whole-cycle time: observe, infer, set_action per group; step; rewards (device-resident); clear_dead."""
     from magent_amd.builtin.torch_model import DeepQNetwork
     env = magent_amd.GridWorld("battle", map_size=MAP_SIZE, device_obs=True)
     env.set_seed(12345); env.reset()
@@ -167,7 +167,7 @@ def selfplay_extra(torch, magent_amd, n=400000, steps=4):
     models = [DeepQNetwork(env, h, "m%d" % i, memory_size=16, infer_batch_size=65536) for i, h in enumerate(hs)]
     cells = all(m._hip is not None for m in models)
     env.use_bf16_observations(cells)       # the MFMA kernels take the views as bf16 cells (2.7 KB per agent instead of 4.7)
-    total, t0 = 0, 0.0
+    total, t0, rew = 0, 0.0, [None] * len(hs)
     for s in range(steps + 2):
         if s == 2:
             torch.cuda.synchronize(); env.sync()
@@ -180,8 +180,11 @@ def selfplay_extra(torch, magent_amd, n=400000, steps=4):
         for h, a in zip(hs, acts):
             env.set_action(h, a)
         env.step()
-        for h in hs:
-            env.get_reward(h)
+        for i, h in enumerate(hs):          # (the rewards stay in HBM like everything else of this loop: env_get_reward_device)
+            k = env.get_num(h)
+            if rew[i] is None or rew[i].shape[0] < k:
+                rew[i] = torch.empty(k, dtype=torch.float32, device=torch.device("cuda", env.device_id))
+            env.get_reward_device(h, out=rew[i][:k])
         env.clear_dead()
     torch.cuda.synchronize(); env.sync()
     dt = time.perf_counter() - t0
