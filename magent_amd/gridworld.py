@@ -75,7 +75,7 @@ class GridWorld(object):
             device_obs = {"0": False, "1": True}.get(os.environ.get("MAGENT_DEVICE_OBS", "0"), os.environ.get("MAGENT_DEVICE_OBS"))
         self._device_obs = bool(device_obs) and getattr(L, "has_device_api", False)
         self._obs_bf16 = device_obs == "bf16"      # views as bf16 cells of 8 channels, the policy kernels' input format
-        self._dev_cache = ({}, {})
+        self._dev_cache, self._dev_slot, self._dev_guard = ({}, {}), {}, {}
         if isinstance(config, str):
             config = _builtin_config(config, **kwargs)
 
@@ -197,20 +197,33 @@ class GridWorld(object):
         spaces = ((0, self.view_space[g], torch.float32), (1, self.feature_space[g], torch.float32))
         if self._obs_bf16:
             spaces = ((0, self.view_space[g][:2] + (8,), torch.bfloat16), spaces[1])
+        # Two sets of buffers per group, handed out in turn.  The set written now was handed out two calls ago, and (like the
+        # reference's reused buffers) stopped being valid at the previous call for this group: whatever torch work reads it was
+        # queued before that call, where an event was recorded on torch's stream.  The render waits for THAT event -- not for
+        # torch's whole queue: a policy that is still running on the other group's observation does not hold this render back --
+        # and torch's stream for the render; stream-to-stream, the host does not block.
+        slot = self._dev_slot.get(g, 0) ^ 1
+        self._dev_slot[g] = slot
+        dev = torch.device("cuda", self._device_id)
         for which, space, dtype in spaces:
-            buf = self._dev_cache[which].get(g)
+            buf = self._dev_cache[which].get((g, slot))
             if buf is None or buf.shape[0] < n:
-                buf = self._dev_cache[which][g] = torch.empty((n,) + space, dtype=dtype, device=torch.device("cuda", self._device_id))
+                buf = self._dev_cache[which][(g, slot)] = torch.empty((n,) + space, dtype=dtype, device=dev)
             out.append(buf[:n])
-        # The cached buffers are written on the engine's own stream.  Work still queued on torch's current stream may be
-        # reading their previous contents (an episode buffer cloning rows, a policy forward): the render has to wait for
-        # it, and torch's stream for the render -- stream-to-stream, the host does not block.
-        self.order_after_torch()
+        guard = self._dev_guard.get((g, slot))
+        if guard is None:
+            self.order_after_torch()
+        else:
+            for st in self._streams():
+                st.wait_event(guard)
         if self._obs_bf16:
             self.get_observation_device_bf16(g, out[0], out[1])
         else:
             self.get_observation_device(g, out[0], out[1])
         self.order_torch_after()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))       # everything queued so far may still read the OTHER set: its next render waits for this
+        self._dev_guard[(g, slot ^ 1)] = ev
         return out[0], out[1]
 
     def use_bf16_observations(self, on=True):
@@ -218,7 +231,7 @@ class GridWorld(object):
         if on and max(v[2] for v in self.view_space.values()) > 7:
             raise ValueError("bf16-cell observations hold at most 7 channels; this game has %d" % max(v[2] for v in self.view_space.values()))
         if bool(on) != self._obs_bf16:
-            self._obs_bf16, self._dev_cache = bool(on), ({}, {})
+            self._obs_bf16, self._dev_cache, self._dev_slot, self._dev_guard = bool(on), ({}, {}), {}, {}
 
     def set_action(self, handle, actions):
         if not isinstance(actions, np.ndarray):   # a torch int32 tensor on the engine's device
@@ -332,7 +345,7 @@ class GridWorld(object):
         """gives the engine's resources back (device memory, stream); the object is unusable afterwards"""
         game, self.game = getattr(self, "game", None), None
         self._ext_stream = self._ext_side = None
-        self._dev_cache = ({}, {})
+        self._dev_cache, self._dev_slot, self._dev_guard = ({}, {}), {}, {}
         if game:
             try:
                 self._lib.env_delete_game(game)
