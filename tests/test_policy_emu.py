@@ -80,3 +80,18 @@ def test_emulated_policy_in_scrambled_order(seed):
             "print('scrambled ok')\n") % os.path.dirname(os.path.abspath(__file__))
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPEMU_SCRAMBLE=seed, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "scrambled ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_emulated_policy_random_shapes():
+    """seeded random shapes inside policy_dqn_supported: views 5..16 on a side with H x W <= 256, 1..7 channels, 1..64 features, 1..31 actions,
+    agent counts that leave partial conv tiles and partial head groups"""
+    rs = np.random.RandomState(2024)
+    done = 0
+    while done < 6:
+        h, w = int(rs.randint(5, 17)), int(rs.randint(5, 17))
+        if h * w > 256:
+            continue
+        c, feat, n_action = int(rs.randint(1, 8)), int(rs.randint(1, 65)), int(rs.randint(1, 32))
+        n = int(rs.randint(1, 60)) if h * w > 100 else int(rs.randint(1, 200))
+        test_emulated_policy_matches_torch_reference((h, w, c), feat, n_action, n)
+        done += 1
