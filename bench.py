@@ -87,7 +87,7 @@ def run_cpu_baseline(map_size=MAP_SIZE, agents=N_PER_GROUP, steps=4):
         env = dict(os.environ, OMP_NUM_THREADS=str(th), MAGENT_AMD_NO_TORCH="1")
         try:
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--cpu-lib", lib,
-                                  "--cpu-steps", str(steps), "--map-size", str(map_size), "--agents", str(agents)],
+                                  "--cpu-steps", str(steps if th > 1 or steps > 50 else min(steps, 3)), "--map-size", str(map_size), "--agents", str(agents)],
                                  env=env, capture_output=True, text=True, timeout=600)
             rec = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # the baseline is a reported extra; never fail the bench for it
@@ -96,7 +96,7 @@ def run_cpu_baseline(map_size=MAP_SIZE, agents=N_PER_GROUP, steps=4):
         rate = rec["agent_steps"] / rec["seconds"]
         if best is None or rate > best["value"]:
             best = {"value": rate, "unit": "agent-steps/s", "cores": th, "kind": kind,
-                    "sample": "%d timed steps (+1 warm-up) of the same workload, %d OpenMP thread(s), host buffers "
+                    "sample": "%d timed steps (+1 warm-up; the 1-thread leg: 3) of the same workload, %d OpenMP thread(s), host buffers "
                               "(reference ABI); best of threads %s" % (steps, th, threads)}
     return best
 
@@ -154,7 +154,7 @@ def small_world_extras(torch, magent_amd, dev, steps=200, warmup=20):
     return out
 
 
-def selfplay_extra(torch, magent_amd, n=400000, steps=4):
+def selfplay_extra(torch, magent_amd, n=400000, steps=4, infer_dtype="bf16"):
     """BASELINE config 5's shape on one GPU: battle 1000x1000, both sides acting through the reference's DQN (inference only,
     epsilon-greedy), observations and actions staying in HBM; the forward pass runs on the hand-written MFMA kernels
     (magent_amd/csrc/policy.hip).  Whole-cycle time: observe, infer, set_action per group; step; rewards (device-resident); clear_dead."""
@@ -164,7 +164,7 @@ def selfplay_extra(torch, magent_amd, n=400000, steps=4):
     hs = env.get_handles()
     for h in hs:
         env.add_agents(h, "random", n=n)
-    models = [DeepQNetwork(env, h, "m%d" % i, memory_size=16, infer_batch_size=65536) for i, h in enumerate(hs)]
+    models = [DeepQNetwork(env, h, "m%d" % i, memory_size=16, infer_batch_size=65536, infer_dtype=infer_dtype) for i, h in enumerate(hs)]
     cells = all(m._hip is not None for m in models)
     env.use_bf16_observations(cells)       # the MFMA kernels take the views as bf16 cells (2.7 KB per agent instead of 4.7)
     total, t0, rew = 0, 0.0, [None] * len(hs)
@@ -189,7 +189,8 @@ def selfplay_extra(torch, magent_amd, n=400000, steps=4):
     torch.cuda.synchronize(); env.sync()
     dt = time.perf_counter() - t0
     out = {"agent_steps_per_s": total / dt, "ms_per_step": dt / steps * 1e3, "agents": [n, n],
-           "policy": "DQN forward pass, bf16 MFMA kernels on bf16-cell observations" if cells else "DQN forward pass, PyTorch"}
+           "policy_dtype": "bf16 (inputs, weights, activations; f32 accumulation)" if cells else "f32",
+           "policy": "DQN forward pass, bf16 MFMA kernels on bf16-cell observations" if cells else "DQN forward pass, PyTorch float32 (the reference's arithmetic)"}
     env.close()
     return out
 
@@ -245,27 +246,41 @@ def host_abi_extra(magent_amd, n=N_PER_GROUP, steps=3, warm=2):
             "agents": [n, n], "io": "host buffers (reference ABI: env_get_observation / env_set_action / env_get_reward), PCIe included"}
 
 
-def train_round_extra(torch, magent_amd, map_size=1000, steps=12, on_step=None, train=True):
+def train_battle_formation(map_size, gap=3):
+    """examples/train_battle.py:15-40 (`generate_map`): two squares of agents on every other cell, side = 2 * int(sqrt(0.04 M^2)) cells,
+    `gap` cells either side of the middle column; the script swaps leftID / rightID before it places, so the first round of a process puts
+    handles[1] on the left and adds it first.  -> [(group, int32[n, 3] positions)] in placement order.  M = 1000: 2 x 40,000; M = 3536:
+    2 x 499,849 (BASELINE config 5's "1M agents")."""
+    import math
+    import numpy as np
+    side = int(math.sqrt(map_size * map_size * 0.04)) * 2
+    ys = np.arange((map_size - side) // 2, (map_size - side) // 2 + side, 2)
+    out = []
+    for g, x0 in ((1, map_size // 2 - gap - side), (0, map_size // 2 + gap)):
+        xs = np.arange(x0, x0 + side, 2)
+        pos = np.zeros((len(xs) * len(ys), 3), dtype=np.int32)
+        pos[:, 0], pos[:, 1] = np.repeat(xs, len(ys)), np.tile(ys, len(xs))      # x outer, y inner: the script's loop order
+        out.append((g, pos))
+    return out
+
+
+def train_round_extra(torch, magent_amd, map_size=1000, steps=12, on_step=None, train=True, infer_dtype="bf16"):
     """BASELINE config 5's loop on one GPU: examples/train_battle.py:61-140 (`play_a_round`) at --map_size 1000 -- its
     generate_map puts (int(sqrt(0.04 M^2)))^2 = 40,000 agents on each side -- with the observations staying in HBM
     (device_obs): observe -> infer_action (e-greedy, DQN) -> set_action per side; step; get_reward / get_alive -> sample_step;
     clear_dead; after `steps` steps one train() per model (replay sampling, double-DQN targets, Adam).  Times the three parts
     with the device synchronised around them.  on_step(step, env, handles, obs, acts, rewards, alives) lets a test check the
     engine's outputs against its checker."""
-    import math
     from magent_amd.builtin.torch_model import DeepQNetwork
     from magent_amd.model import ProcessingModel
     env = magent_amd.GridWorld("battle", map_size=map_size, device_obs=True)
     env.set_seed(12345); env.reset()
     handles = env.get_handles()
-    side = int(math.sqrt(map_size * map_size * 0.04)) * 2          # train_battle.py:18-40, gap 3, every other cell
-    for k, h in enumerate(handles):
-        x0 = map_size // 2 - 3 - side if k == 0 else map_size // 2 + 3
-        pos = [[x, y, 0] for x in range(x0, x0 + side, 2) for y in range((map_size - side) // 2, (map_size - side) // 2 + side, 2)]
-        env.add_agents(h, method="custom", pos=pos)
+    for g, pos in train_battle_formation(map_size):
+        env.add_agents(handles[g], method="custom", pos=pos)
     n0 = [env.get_num(h) for h in handles]
     models = [ProcessingModel(env, h, "c5_%d" % i, 20000 + i, 1000, DeepQNetwork, batch_size=512, memory_size=2 ** 17,
-                              target_update=1000, train_freq=4) for i, h in enumerate(handles)]
+                              target_update=1000, train_freq=4, infer_dtype=infer_dtype) for i, h in enumerate(handles)]
 
     def synced():
         torch.cuda.synchronize(); env.sync()
@@ -316,7 +331,9 @@ def train_round_extra(torch, magent_amd, map_size=1000, steps=12, on_step=None, 
     out = {"map_size": map_size, "agents": n0, "steps": steps, "env_ms_per_step": t_env / steps * 1e3, "infer_ms_per_step": t_infer / steps * 1e3,
            "sample_ms_per_step": t_sample / steps * 1e3,
            "agent_steps_per_s_sampling": agent_steps / (t_env + t_infer + t_sample),
-           "policy": "DQN (2 x conv3x3(32) -> dense 256 || dense 256 -> dueling head), MFMA inference kernels: %s" % all(m.model._hip is not None for m in models)}
+           "policy_dtype": "bf16 inference (MFMA kernels: inputs, weights, activations bf16, f32 accumulation), f32 training" if all(m.model._hip is not None for m in models)
+                           else "f32 inference (PyTorch), f32 training",
+           "policy": "DQN (2 x conv3x3(32) -> dense 256 || dense 256 -> dueling head)"}
     if train:
         # the first train() of a process also pays for MIOpen's choice of convolution kernels (seconds); a second round -- the
         # same number of steps played again -- is what a training run pays per round
@@ -327,6 +344,10 @@ def train_round_extra(torch, magent_amd, map_size=1000, steps=12, on_step=None, 
         out["value"] = [float(r[1]) for r in res]
     env.close()
     return out
+
+
+def is_default_workload(args):
+    return (args.workload, args.map_size, args.agents) == ("battle", MAP_SIZE, N_PER_GROUP)
 
 
 def main():
@@ -350,6 +371,7 @@ def main():
     ap.add_argument("--obs", choices=["f32", "bf16"], default="f32",
                     help="bf16: render the observations as the policy kernels' bf16 cells (env_get_observation_device_bf16, 8 x bf16 per window "
                          "cell) -- a secondary reading; the headline stays on the reference's float32 tensors")
+    ap.add_argument("--repeats", type=int, default=5, help="identical timed regions of --steps steps; the median one is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (capacity fill, test_1m, small worlds)")
@@ -387,7 +409,7 @@ def main():
             dist.init_process_group("gloo")
     from magent_amd import replicas
 
-    def measure(workload, map_size, agents, steps, warmup, profile, gather="none", seed=12345 + rank):
+    def measure(workload, map_size, agents, steps, warmup, profile, gather="none", seed=12345 + rank, check_gather=False):
         """K timed steps of `workload`; returns the fields of the bench line that depend on the run"""
         from magent_amd.builtin.config import _games
         if workload == "test_1m":
@@ -438,7 +460,7 @@ def main():
         total_steps = steps + warmup
         gen = torch.Generator(device=dev)
         gen.manual_seed(rank)
-        n_sets = min(total_steps + (5 if profile else 0), 32)   # action sets are recycled: 32 x 3.2 MB is enough entropy
+        n_sets = min(total_steps + 8, 32)   # action sets are recycled: 32 x 3.2 MB is enough entropy
         actions = [[torch.randint(n_actions[g], (n0[g],), dtype=torch.int32, device=dev, generator=gen) for g in range(G)] for _ in range(n_sets)]
         gathers = None
         if gather != "none" and world > 1:   # the north star's batched-observation gather: every replica's view tensor to every rank
@@ -533,7 +555,7 @@ def main():
                 achieved = obs_bytes / (ms * 1e-3) / 1e9
                 traffic, traffic_note = None, None
                 pmc = os.path.join(ROOT, "profiles", "render_pmc.json")
-                if os.path.exists(pmc):
+                if os.path.exists(pmc) and workload == "battle" and not bf16 and map_size == MAP_SIZE:   # (the PMC passes ran this workload)
                     try:     # PMC bytes per rendered AGENT (separate rocprofv3 --pmc passes, profiles/), scaled to this run's launches
                         rec = json.load(open(pmc))
                         agents_per_launch = (rendered["view"] / view_bytes[acting[0]]) / n_launch
@@ -564,7 +586,19 @@ def main():
         if gathers:
             res["gather"] = {"mode": gathers[acting[0]].mode, "payload_bytes_sent_per_step": sum(gathers[g].bytes_sent for g in acting),
                              "view_buffers": n_buf}
-            if args.check_gather:
+            # the payload exchange alone (events on the side stream; gloo: host time), on three more steps of the episode
+            ex = []
+            base = total_steps + (5 if profile else 0)
+            for s in range(base, base + 3):
+                one_step(s)
+                for g in acting:
+                    gathers[g].wait()
+                ex.append(sum(gathers[g].exchange_ms() for g in acting))
+            env.sync()
+            res["gather"]["exchange_ms"] = sorted(ex)[1]
+            res["gather"]["rows_sent_to_each_peer"] = sum(gathers[g]._n for g in acting)
+            res["gather"]["bytes_to_each_peer"] = sum(gathers[g]._n * gathers[g].row_bytes for g in acting)
+            if check_gather:
                 # every rank digests the rows it rendered in the last exchanged step and the shards it received; the lists meet on
                 # every rank: shard r as received anywhere must be the bytes rank r rendered (HIP engine output, bit for bit)
                 import hashlib
@@ -590,14 +624,27 @@ def main():
         del env
         return res
 
-    R = measure(args.workload, args.map_size, args.agents, args.steps, args.warmup, not args.no_profile, gather=args.gather)
-    elapsed, agent_steps = R["elapsed"], R["agent_steps"]
-    if world > 1:   # whole-job aggregate over the slowest replica's time
-        elapsed = replicas.max_over_replicas(elapsed, device=red_dev)
-        agent_steps = replicas.sum_over_replicas(agent_steps, device=red_dev)
+    # The headline: W untimed warm-up steps, then EXACTLY K timed steps between barriers + synchronisations -- done `--repeats` times
+    # on identically built worlds (same seed, same actions: the K-step window is the same work every time), and the repeat with
+    # the MEDIAN time is the one reported (a 20-step region is ~17 ms: one region moves +-2 % on nothing).  Every repeat's
+    # ms/step is in the line (`repeats_ms_per_step`).
+    runs = []
+    for rep in range(max(1, args.repeats)):
+        R = measure(args.workload, args.map_size, args.agents, args.steps, args.warmup, not args.no_profile, gather=args.gather,
+                    check_gather=args.check_gather and rep == 0)
+        e, a = R["elapsed"], R["agent_steps"]
+        if world > 1:   # whole-job aggregate over the slowest replica's time
+            e = replicas.max_over_replicas(e, device=red_dev)
+            a = replicas.sum_over_replicas(a, device=red_dev)
+        runs.append((e, a, R))
+    order = sorted(range(len(runs)), key=lambda k: runs[k][0])
+    elapsed, agent_steps, R = runs[order[len(order) // 2]]
+    if args.check_gather and "gather" in runs[0][2] and "verified" in runs[0][2]["gather"]:
+        R.setdefault("gather", {})["verified"] = runs[0][2]["gather"]["verified"]
+    repeats_ms = [round(r[0] / args.steps * 1e3, 4) for r in runs]
 
     if rank == 0:
-        is_default = (args.workload, args.map_size, args.agents) == ("battle", MAP_SIZE, N_PER_GROUP)
+        is_default = is_default_workload(args)
         names = {"test_1m": "reference test_1m.py harness: pursuit-like %dx%d, %d walls, %d prey + %d 2x2 predators" % (
                      R["map_size"], R["map_size"], 2 * args.agents // 10, args.agents, args.agents),
                  "gather": "gather %dx%d (train_gather.py), %d agents + %d food, only the agents act" % (args.map_size, args.map_size, args.agents, args.agents // 5),
@@ -612,6 +659,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_median": R["median_ms"],
+            "repeats": len(runs), "repeats_ms_per_step": repeats_ms,
+            "value_is": "the repeat with the median time of %d identical %d-step regions" % (len(runs), args.steps),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -630,7 +679,7 @@ def main():
             rec["config"]["gather_detail"] = R["gather"]
         if world == 1 and not args.no_cpu_baseline:
             small = args.map_size * args.map_size <= 250000
-            rec["cpu_baseline"] = run_cpu_baseline(args.map_size, args.agents, steps=200 if small else 4) \
+            rec["cpu_baseline"] = run_cpu_baseline(args.map_size, args.agents, steps=200 if small else 8) \
                 if args.workload == "battle" else None
         else:
             rec["cpu_baseline"] = None
@@ -640,15 +689,52 @@ def main():
             try:
                 F = measure("battle_fill", MAP_SIZE, 0, 10, 3, False)
                 extra["battle_fill_2x498002"] = {"agent_steps_per_s": F["agent_steps"] / F["elapsed"], "ms_per_step": F["elapsed"] / 10 * 1e3, "agents": F["n0"]}
-                T = measure("test_1m", 0, 500000, 10, 3, False)
-                extra["test_1m_2x500k"] = {"agent_steps_per_s": T["agent_steps"] / T["elapsed"], "ms_per_step": T["elapsed"] / 10 * 1e3, "agents": T["n0"], "map": T["map_size"]}
+                # every other BASELINE configuration with the roofline of ITS render kernel (algorithmic bytes 4 * (VH*VW*C + F) per
+                # rendered agent: test_1m 5 channels without minimap, gather 15 x 15 x 7 = 6444 B, C2 the battle shape at 2 x 2000)
+                T = measure("test_1m", 0, 500000, 10, 3, True)
+                extra["test_1m_2x500k"] = {"agent_steps_per_s": T["agent_steps"] / T["elapsed"], "ms_per_step": T["elapsed"] / 10 * 1e3, "agents": T["n0"], "map": T["map_size"],
+                                           "roofline": T["roofline"]}
+                C4 = measure("gather", 500, 100000, 20, 5, True)
+                extra["gather_500_100k"] = {"agent_steps_per_s": C4["agent_steps"] / C4["elapsed"], "ms_per_step": C4["elapsed"] / 20 * 1e3, "agents": C4["n0"],
+                                            "workload": "BASELINE config 4, one replica: gather 500x500 (train_gather.py), 100k agents + 20k food, only the agents act",
+                                            "roofline": C4["roofline"], "breakdown": C4["breakdown"]}
+                C2 = measure("battle", 200, 2000, 200, 20, True)
                 extra["battle_200_2x2000"] = small_world_extras(torch, magent_amd, dev)
+                extra["battle_200_2x2000"]["calls_with_events"] = {"ms_per_step": C2["elapsed"] / 200 * 1e3, "roofline": C2["roofline"], "breakdown": C2["breakdown"]}
                 extra["battle_selfplay_2x400k"] = selfplay_extra(torch, magent_amd)
+                extra["battle_selfplay_2x400k_f32_policy"] = selfplay_extra(torch, magent_amd, steps=2, infer_dtype="f32")
                 extra["host_abi_2x400k"] = host_abi_extra(magent_amd)
                 extra["c5_train_round_2x40k"] = train_round_extra(torch, magent_amd)
+                # BASELINE config 5 at the size it names: train_battle.py --map_size 3536, 2 x 499,849 agents in its own formation
+                extra["c5_train_round_1m"] = {"bf16_policy": train_round_extra(torch, magent_amd, map_size=3536, steps=6),
+                                              "f32_policy": train_round_extra(torch, magent_amd, map_size=3536, steps=3, infer_dtype="f32")}
             except Exception as e:     # secondary lines never fail the bench
                 extra["error"] = repr(e)
             rec["extra"] = extra
+    if world > 1 and is_default_workload(args) and not args.no_extras:
+        # north-star configuration 4 on the ranks of this job: gather 500 x 500, 100k agents + 20k food per replica, every replica's
+        # observation tensor to every rank each step (counts first, rows sized by count, on a side stream under the step) -- timed
+        # without and with the exchange, every gathered shard checked bit for bit against the rows its owner rendered
+        XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md: one xGMI link, per direction
+        A = measure("gather", 500, 100000, args.steps, args.warmup, False, gather="none")
+        B = measure("gather", 500, 100000, args.steps, args.warmup, False, gather="obs", check_gather=True)
+        ea = replicas.max_over_replicas(A["elapsed"], device=red_dev)
+        eb = replicas.max_over_replicas(B["elapsed"], device=red_dev)
+        na = replicas.sum_over_replicas(A["agent_steps"], device=red_dev)
+        nb = replicas.sum_over_replicas(B["agent_steps"], device=red_dev)
+        ex = replicas.max_over_replicas(B["gather"]["exchange_ms"], device=red_dev)
+        if rank == 0:
+            gb = B["gather"]
+            link = gb["bytes_to_each_peer"] / (ex * 1e-3) / 1e9 if ex > 0 else None
+            rec.setdefault("extra", {})["c4_gather_rccl"] = {
+                "workload": "gather 500x500 (train_gather.py), 100k agents + 20k food per replica, %d replicas, only the agents act" % world,
+                "backend": args.backend + (" (RCCL over xGMI)" if args.backend == "nccl" else " (dry run: rows staged through host memory)"),
+                "ms_per_step_without_gather": ea / args.steps * 1e3, "agent_steps_per_s_without_gather": na / ea,
+                "ms_per_step_with_gather": eb / args.steps * 1e3, "agent_steps_per_s_with_gather": nb / eb,
+                "exchange_ms": ex, "payload_bytes_to_each_peer": gb["bytes_to_each_peer"], "payload_bytes_sent_per_step": gb["payload_bytes_sent_per_step"],
+                "GBps_per_link": link, "xgmi_link_peak_GBps": XGMI_LINK_GBS, "link_frac": (link / XGMI_LINK_GBS if link else None),
+                "view_buffers": gb["view_buffers"], "verified": gb.get("verified")}
+    if rank == 0:
         print(json.dumps(rec))
     if world > 1:
         dist.destroy_process_group()

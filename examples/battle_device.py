@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--n", type=int, default=2000, help="agents per side")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--policy", choices=["random", "dqn"], default="random")
+    ap.add_argument("--infer-dtype", choices=["f32", "bf16"], default="f32", help="bf16: the MFMA inference kernels (magent_amd/csrc/policy.hip)")
     args = ap.parse_args()
 
     env = magent_amd.GridWorld("battle", map_size=args.map_size, device_obs=True)
@@ -33,8 +34,8 @@ def main():
     for h in handles:
         env.add_agents(h, "random", n=args.n)
     if args.policy == "dqn":
-        models = [DeepQNetwork(env, h, "side%d" % i, memory_size=16) for i, h in enumerate(handles)]
-        # the forward pass runs on the hand-written MFMA kernels (magent_amd/csrc/policy.hip); they take the views as bf16 cells of
+        models = [DeepQNetwork(env, h, "side%d" % i, memory_size=16, infer_dtype=args.infer_dtype) for i, h in enumerate(handles)]
+        # --infer-dtype bf16: the forward pass runs on the hand-written MFMA kernels (magent_amd/csrc/policy.hip); they take the views as bf16 cells of
         # 8 channels, which the engine can render directly (2.7 KB per agent instead of 4.7, nothing to convert)
         env.use_bf16_observations(all(m._hip is not None for m in models))
     else:

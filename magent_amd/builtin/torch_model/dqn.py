@@ -72,7 +72,7 @@ class DeepQNetwork(BaseModel):
     def __init__(self, env, handle, name, batch_size=64, learning_rate=1e-4, reward_decay=0.99, train_freq=1,
                  target_update=2000, memory_size=2 ** 20, eval_obs=None, use_dueling=True, use_double=True, use_conv=True,
                  custom_view_space=None, custom_feature_space=None, num_gpu=1, infer_batch_size=8192, network_type=0,
-                 device=None):
+                 device=None, infer_dtype=None):
         BaseModel.__init__(self, env, handle)
         self.env, self.handle, self.name, self.subclass_name = env, handle, name, "torchdqn"
         self.view_space = tuple(custom_view_space or env.get_view_space(handle))
@@ -88,10 +88,18 @@ class DeepQNetwork(BaseModel):
         self.target_net = _QNet(self.view_space, self.feature_space, self.num_actions, use_dueling, use_conv).to(self.device)
         self.target_net.load_state_dict(self.qnet.state_dict())
         self.optimizer = torch.optim.Adam(self.qnet.parameters(), lr=learning_rate)
-        # acting on device-resident observations goes through the hand-written MFMA kernels (bf16 inputs, f32 accumulation;
-        # magent_amd/csrc/policy.hip) when the network has the reference's default shape; MAGENT_HIP_POLICY=0 keeps PyTorch
+        # The arithmetic of infer_action.  "f32" (the default) is the reference's own: its TensorFlow graph computes in float32
+        # (tf_model/dqn.py:151-189), and so does the PyTorch network here.  "bf16" is an opt-in -- the constructor argument, or
+        # MAGENT_POLICY_DTYPE=bf16 for scripts that are run unmodified: acting on device-resident observations then goes through the
+        # hand-written MFMA kernels (bf16 inputs, weights and inter-layer activations, f32 accumulation; magent_amd/csrc/policy.hip)
+        # when the network has the reference's default shape.  How far that is from the f32 network on real observations is pinned
+        # in tests/test_policy.py::test_bf16_policy_against_the_f32_network (|dQ| <= 2 % of max |Q|, >= 97 % equal greedy actions).
+        # Training is float32 either way.
+        self.infer_dtype = (infer_dtype or os.environ.get("MAGENT_POLICY_DTYPE", "f32")).lower()
+        if self.infer_dtype not in ("f32", "bf16"):
+            raise ValueError("infer_dtype must be 'f32' or 'bf16', not %r" % (self.infer_dtype,))
         self._hip = None
-        if self.device.type == "cuda" and os.environ.get("MAGENT_HIP_POLICY", "1") != "0":
+        if self.device.type == "cuda" and self.infer_dtype == "bf16":
             try:
                 from .hip_policy import HipDqnPolicy
                 self._hip = HipDqnPolicy(self.qnet, self.view_space, self.feature_space, self.num_actions, self.device)
@@ -129,7 +137,7 @@ class DeepQNetwork(BaseModel):
             return best
         if isinstance(view, torch.Tensor) and view.dtype == torch.bfloat16:
             # bf16 cells [n, H, W, 8] are the MFMA kernels' operand format (channels, zeros, a constant 1); without those kernels
-            # (MAGENT_HIP_POLICY=0, an unsupported shape) the PyTorch network takes the channels back as float32
+            # (infer_dtype "f32", an unsupported shape) the PyTorch network takes the channels back as float32
             view = view[..., :self.view_space[-1]].float()
         out = torch.empty(n, dtype=torch.int32, device=self.device)
         step = max(1, min(n, self.infer_batch_size))

@@ -37,21 +37,61 @@ def replica_seed(base_seed, rank):
     return base_seed + rank
 
 
+class _TorchBackend(object):
+    """what ObservationGather needs from torch.distributed and torch.cuda, behind one small object so that the ORDER in which
+    the exchange uses streams, events and works can be unit-tested with a recording stand-in (tests/test_replicas.py) --
+    the RCCL path itself needs two GPUs, which the build container and the 1-GPU test box do not have"""
+
+    def __init__(self, device, group=None):
+        self.device, self.group = torch.device(device), group
+        self.streams = self.device.type == "cuda"
+
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def rank(self):
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    # -- streams and events (GPU only)
+    def new_stream(self):
+        return torch.cuda.Stream(device=self.device)
+
+    def new_event(self, timing=False):
+        return torch.cuda.Event(enable_timing=timing)
+
+    def current_stream(self):
+        return torch.cuda.current_stream(self.device)
+
+    def on(self, stream):
+        return torch.cuda.stream(stream)
+
+    # -- collectives and point-to-point
+    def all_gather_into_tensor(self, out, inp):
+        dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def exchange(self, sends, recvs):
+        """one group of point-to-point transfers: sends = [(tensor, peer)], recvs = [(tensor, peer)] -> the works"""
+        ops = [dist.P2POp(dist.irecv, t, peer, group=self.group) for t, peer in recvs]
+        ops += [dist.P2POp(dist.isend, t, peer, group=self.group) for t, peer in sends]
+        return dist.batch_isend_irecv(ops) if ops else []
+
+
 class ObservationGather(object):
     """All-gather of a per-replica observation tensor whose row count differs between replicas.
 
     row_shape : shape of one agent's observation, e.g. (13, 13, 7)
     capacity  : rows reserved per replica in the receive area (>= the largest population any replica will hold)
     device    : where the tensors live ("cpu" for gloo); mode: "exact" (counts, then sized sends / receives) | "padded"
+    backend   : test seam (see _TorchBackend); the default talks to torch.distributed / torch.cuda
     """
 
-    def __init__(self, row_shape, capacity, dtype=torch.float32, device="cpu", mode="exact", group=None):
+    def __init__(self, row_shape, capacity, dtype=torch.float32, device="cpu", mode="exact", group=None, backend=None):
         assert mode in ("exact", "padded")
         self.mode, self.group = mode, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.capacity, self.row_shape = int(capacity), tuple(row_shape)
         self.device = torch.device(device)
+        self._b = backend if backend is not None else _TorchBackend(self.device, group)
+        self.world, self.rank = self._b.world_size(), self._b.rank()
+        self.capacity, self.row_shape = int(capacity), tuple(row_shape)
         self.recv = torch.empty((self.world, self.capacity) + self.row_shape, dtype=dtype, device=self.device)
         self._count_send = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._count_recv = torch.zeros(self.world, dtype=torch.int64, device=self.device)
@@ -59,15 +99,15 @@ class ObservationGather(object):
         self.counts = [0] * self.world
         self.row_bytes = self.recv[0, 0].numel() * self.recv.element_size()
         self.bytes_sent = self.bytes_received = 0          # of the last exchange, payload only
-        if self.device.type == "cuda":
-            self.stream = torch.cuda.Stream(device=self.device)
-            self._ready = torch.cuda.Event()
-            self._counted = torch.cuda.Event()
-            self._done = torch.cuda.Event()
+        if self._b.streams:
+            self.stream = self._b.new_stream()
+            self._ready, self._counted = self._b.new_event(), self._b.new_event()
+            self._began, self._done = self._b.new_event(True), self._b.new_event(True)     # around the payload: exchange_ms()
         else:
             self.stream = None
         self._posted, self._view, self._n = True, None, 0
         self._busy = {}            # send tensor (data_ptr) -> event recorded behind the last exchange that read it
+        self._host_ms = None       # gloo: the payload's wall time (it blocks the host)
 
     # -- step 1: the counts (and, for GPUs, the hand-over from the producer's stream)
     def launch(self, view, n, producer_stream=None):
@@ -80,16 +120,36 @@ class ObservationGather(object):
             self.counts = [self._n]
             return
         if self.stream is not None:
-            (producer_stream or torch.cuda.current_stream(self.device)).record_event(self._ready)
+            (producer_stream or self._b.current_stream()).record_event(self._ready)
             self.stream.wait_event(self._ready)
-            with torch.cuda.stream(self.stream):
+            with self._b.on(self.stream):
                 self._count_send.fill_(self._n)
-                dist.all_gather_into_tensor(self._count_recv, self._count_send, group=self.group)
-                self._count_host.copy_(self._count_recv, non_blocking=True)
+                self._b.all_gather_into_tensor(self._count_recv, self._count_send)
+                (self._count_host if self._count_host is not None else self._count_recv).copy_(self._count_recv, non_blocking=True)
                 self._counted.record(self.stream)
         else:
             self._count_send.fill_(self._n)
-            dist.all_gather_into_tensor(self._count_recv, self._count_send, group=self.group)
+            self._b.all_gather_into_tensor(self._count_recv, self._count_send)
+
+    def _exchange_rows(self, view, n):
+        """the payload, on whatever stream is current: one collective (padded) or one group of sends / receives sized by count.
+        Every work is waited for HERE, on the issuing stream: Work.wait() on a ProcessGroupNCCL work is a STREAM-side wait -- it
+        makes the current stream (the side stream) depend on the communicator's internal stream and does not block the host.
+        Without it an event recorded behind the exchange would not cover the transfers.  On gloo it blocks
+        until the rows are in."""
+        if self.mode == "padded":
+            assert view.shape[0] >= self.capacity, "padded mode sends `capacity` rows: the send tensor must hold them"
+            self._b.all_gather_into_tensor(self.recv.view(self.world * self.capacity, *self.row_shape), view[:self.capacity])
+            self.bytes_sent = self.capacity * self.row_bytes * (self.world - 1)
+            self.bytes_received = self.bytes_sent
+            return
+        peers = [p for p in range(self.world) if p != self.rank]   # sized by count, no padding; every pair has its own link on the full mesh
+        recvs = [(self.recv[p, :self.counts[p]], p) for p in peers if self.counts[p] > 0]
+        sends = [(view[:n], p) for p in peers] if n > 0 else []
+        for work in self._b.exchange(sends, recvs):
+            work.wait()
+        self.bytes_sent = n * self.row_bytes * (self.world - 1)
+        self.bytes_received = (sum(self.counts) - n) * self.row_bytes
 
     # -- step 2: the rows
     def post(self):
@@ -101,46 +161,27 @@ class ObservationGather(object):
             return
         if self.stream is not None:
             self._counted.synchronize()                    # 8 * world bytes: the only host wait of the exchange
-            self.counts = self._count_host.tolist()
+            self.counts = (self._count_host if self._count_host is not None else self._count_recv).tolist()
         else:
             self.counts = self._count_recv.tolist()
         assert max(self.counts) <= self.capacity, "capacity smaller than a replica's agent count"
         view, n = self._view, self._n
-
-        def exchange():
-            if self.mode == "padded":
-                assert view.shape[0] >= self.capacity, "padded mode sends `capacity` rows: the send tensor must hold them"
-                dist.all_gather_into_tensor(self.recv.view(self.world * self.capacity, *self.row_shape), view[:self.capacity], group=self.group)
-                self.bytes_sent = self.capacity * self.row_bytes * (self.world - 1)
-                self.bytes_received = self.bytes_sent
-                return
-            ops = []
-            for peer in range(self.world):          # sized by count, no padding; every pair has its own link on the full mesh
-                if peer == self.rank:
-                    continue
-                if self.counts[peer] > 0:
-                    ops.append(dist.P2POp(dist.irecv, self.recv[peer, :self.counts[peer]], peer, group=self.group))
-                if n > 0:
-                    ops.append(dist.P2POp(dist.isend, view[:n], peer, group=self.group))
-            if ops:
-                # Work.wait() on a ProcessGroupNCCL work is a STREAM-side wait: it makes the current stream (the side stream
-                # here) depend on the communicator's internal stream and does not block the host.  Without it the event
-                # recorded below would not cover the transfers.  On gloo it blocks until the rows are in.
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-            self.bytes_sent = n * self.row_bytes * (self.world - 1)
-            self.bytes_received = (sum(self.counts) - n) * self.row_bytes
-
-        if self.stream is not None:
-            with torch.cuda.stream(self.stream):
-                exchange()
-                self._done.record(self.stream)
-                ev = self._busy.get(view.data_ptr())
-                if ev is None:
-                    ev = self._busy[view.data_ptr()] = torch.cuda.Event()
-                ev.record(self.stream)
-        else:
-            exchange()
+        if self.stream is None:
+            import time
+            t0 = time.perf_counter()
+            self._exchange_rows(view, n)
+            self._host_ms = (time.perf_counter() - t0) * 1e3
+            return
+        with self._b.on(self.stream):
+            self._began.record(self.stream)
+            self._exchange_rows(view, n)
+            # both events sit BEHIND the works' stream-side waits: `_done` is what consumers wait for, `_busy[view]` what the
+            # producer waits for before it overwrites the send tensor
+            self._done.record(self.stream)
+            ev = self._busy.get(view.data_ptr())
+            if ev is None:
+                ev = self._busy[view.data_ptr()] = self._b.new_event()
+            ev.record(self.stream)
 
     def release(self, view, producer_stream=None):
         """orders `producer_stream` after the last exchange that READ `view`, so that it may be overwritten.  With two send
@@ -151,14 +192,25 @@ class ObservationGather(object):
             self.post()
         ev = self._busy.get(view.data_ptr())
         if ev is not None:
-            (producer_stream or torch.cuda.current_stream(self.device)).wait_event(ev)
+            (producer_stream or self._b.current_stream()).wait_event(ev)
 
     def wait(self, consumer_stream=None):
         """orders `consumer_stream` (default: the current CUDA stream) after the exchange; returns the shards"""
         self.post()
         if self.stream is not None and self.world > 1:
-            (consumer_stream or torch.cuda.current_stream(self.device)).wait_event(self._done)
+            (consumer_stream or self._b.current_stream()).wait_event(self._done)
         return self.shards()
+
+    def exchange_ms(self):
+        """duration of the last payload exchange (rows only, counts excluded): on GPUs between two events on the side stream --
+        blocks the host until the exchange is over; on gloo the host time the blocking exchange took"""
+        if self.world == 1 or self._view is None:
+            return 0.0
+        if self.stream is None:
+            return self._host_ms
+        self.post()
+        self._done.synchronize()
+        return self._began.elapsed_time(self._done)
 
     def shards(self):
         """per-replica views of the gathered rows, trimmed to each replica's count (own rows: the send tensor itself)"""

@@ -550,6 +550,36 @@ def assert_same_hashed(want, got, what=""):
             assert a[k] == b[k], "%s step %d: %s differs" % (what, s, k)
 
 
+def battle_formation(map_size, gap=3, first_left=1):
+    """the placement of examples/train_battle.py:15-40 (`generate_map`) as Scenario.place entries: two squares of agents on
+    every other cell, `side` = 2 * int(sqrt(0.04 * map_size^2)) cells wide, `gap` cells either side of the middle column; the
+    script swaps leftID / rightID before it places (train_battle.py:21-22), so the FIRST round of a process puts handles[1] on
+    the left and adds it first.  map_size 3536 -> 2 x 707^2 = 2 x 499,849 agents (BASELINE config 5's "1M agents")."""
+    import math
+    side = int(math.sqrt(map_size * map_size * 0.04)) * 2
+    ys = np.arange((map_size - side) // 2, (map_size - side) // 2 + side, 2)
+
+    def square(x0):
+        xs = np.arange(x0, x0 + side, 2)
+        pos = np.zeros((len(xs) * len(ys), 3), dtype=np.int32)
+        pos[:, 0], pos[:, 1] = np.repeat(xs, len(ys)), np.tile(ys, len(xs))      # x outer, y inner: the script's loop order
+        return pos
+
+    left, right = square(map_size // 2 - gap - side), square(map_size // 2 + gap)
+    return [(first_left, "custom", {"pos": left}), (1 - first_left, "custom", {"pos": right})]
+
+
+def battle_melee(map_size):
+    """the two lattices of battle_formation pushed INTO each other (the state a self-play episode reaches once the fronts have met,
+    set up directly): one side on the even columns, the other on the odd columns of the same square -- every agent has hostile
+    neighbours at distance 1, half of all cells of the square are occupied"""
+    place = battle_formation(map_size)
+    (g_l, _, kw_l), (g_r, _, kw_r) = place
+    shifted = kw_r["pos"].copy()
+    shifted[:, 0] += kw_l["pos"][0, 0] + 1 - shifted[0, 0]
+    return [(g_l, "custom", {"pos": kw_l["pos"]}), (g_r, "custom", {"pos": shifted})]
+
+
 def fullsize_scenarios():
     """BASELINE.json's configurations at their stated sizes.  Too large for full trajectories in memory:
     compared through per-step hashes (run_hashed); goldens from the compiled reference in tests/golden/digests_fullsize.json"""
@@ -568,6 +598,13 @@ def fullsize_scenarios():
         Scenario("c4_gather500", "gather", 500, place=[rnd(0, 20000), rnd(1, 100000)], acting=[1], steps=8),
         # the reference's own 1M harness (scripts/test/test_1m.py:62-71): map sqrt(20 N), N/10 walls, N/2 2x2 predators, N/2 prey
         Scenario("test_1m", "pursuit", 4472, walls=100000, place=[rnd(0, 500000), rnd(1, 500000)], steps=2),
+        # C5 at the size BASELINE.json names: examples/train_battle.py --map_size 3536, its own formation (2 x 499,849 on every
+        # other cell of two squares 6 columns apart; 12.5 M cells, large_map_mode), 8 steps of random actions
+        Scenario("c5_battle3536_formation", "battle", 3536, place=battle_formation(3536), steps=8, action_seed=31),
+        # ... and the same two lattices interleaved, hp 4 / damage 3: a million agents with hostile neighbours on both sides --
+        # ~380k attacks per step nearly all of which land, thousands of kills per step, dense move contention
+        Scenario("c5_battle3536_melee", "battle", 3536, place=battle_melee(3536), steps=5, action_seed=32,
+                 over={"small": {"hp": 4, "damage": 3}}),
     ]
     return {s.name: s for s in S}
 

@@ -25,7 +25,9 @@ with open(os.path.join(H.GOLDEN_DIR, "digests_fullsize.json")) as f:
 @pytest.mark.parametrize("name", sorted(FULL))
 def test_fullsize_matches_reference_digest_and_oracle(name):
     """c2_battle200 (40 steps), c3_battle1000_deaths (2x400k, hp 4 / damage 3, 6 steps: kills, dead_penalty, compaction,
-    the ~300k-entry attack shuffle), c4_gather500 (100k agents + 20k food, 8 steps), test_1m (2x500k, 2x2 predators)"""
+    the ~300k-entry attack shuffle), c4_gather500 (100k agents + 20k food, 8 steps), test_1m (2x500k, 2x2 predators),
+    c5_battle3536_formation / _melee (train_battle.py --map_size 3536: 2 x 499,849 agents; host-buffer reference ABI here, the
+    device ABI below)"""
     got = H.run_hashed(FULL[name], H.HIP_LIB)
     try:
         H.assert_same_hashed(GOLD[name], got, name + " vs compiled-reference digest")
@@ -39,12 +41,13 @@ def test_fullsize_matches_reference_digest_and_oracle(name):
             H.assert_same_hashed(H.run_hashed(FULL[name], H.REF_LIB), got, name + " vs compiled reference")
 
 
-@pytest.mark.parametrize("name", ["c3_battle1000_deaths", "c3_battle1000_long"])
+@pytest.mark.parametrize("name", ["c3_battle1000_deaths", "c3_battle1000_long", "c5_battle3536_formation", "c5_battle3536_melee"])
 def test_fullsize_device_abi_matches_reference_digest(name):
     """the call sequence bench.py TIMES (env_get_observation_device into caller-owned tensors sized once, env_set_action_device,
     env_get_reward_device) at 2 x 400k agents, against the digests of the compiled reference: `c3_battle1000_long` is the bench
     workload itself (default hp, 30 steps: longer than a bench run) -- every view, feature row, reward, position, alive flag of
-    every step"""
+    every step.  `c5_battle3536_*`: BASELINE config 5's world (examples/train_battle.py --map_size 3536: 2 x 499,849 agents in the
+    script's own formation, 12.5 M cells) and the same two lattices interleaved (a million agents with hostile neighbours)"""
     got = H.run_hashed(FULL[name], H.HIP_LIB, device_io=True)
     H.assert_same_hashed(GOLD[name], got, name + " (device ABI) vs compiled-reference digest")
 

@@ -93,6 +93,53 @@ def test_hip_policy_many_tiles_per_workgroup():
 
 
 @pytest.mark.gpu
+def test_bf16_policy_against_the_f32_network():
+    """the bf16 MFMA kernels against the reference's OWN arithmetic -- the float32 network of tf_model/dqn.py:151-189 (here the
+    PyTorch _QNet, pinned to a NumPy restatement of the TensorFlow graph in tests/test_training.py) -- on real observations: battle
+    1000 x 1000, 2 x 400k agents, several steps into an episode (attacks, deaths, hp fractions and minimaps in the views).
+    Stated bound: max |Q_bf16 - Q_f32| <= 2 % of max |Q_f32|, and the greedy actions agree for >= 97 % of the agents (every
+    disagreement sits where the f32 network's best two Q values are closer than twice the measured error).  The numbers are
+    printed; DeepQNetwork only takes this path when the caller opts in (infer_dtype="bf16")."""
+    import torch
+    import magent_amd
+    from magent_amd.builtin.torch_model import DeepQNetwork
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    env = magent_amd.GridWorld("battle", map_size=1000, device_obs=True)
+    env.set_seed(12345); env.reset()
+    hs = env.get_handles()
+    for h in hs:
+        env.add_agents(h, "random", n=400000)
+    torch.manual_seed(7)
+    m = DeepQNetwork(env, hs[0], "pin", memory_size=16, infer_dtype="bf16")
+    assert m._hip is not None and m.infer_dtype == "bf16"
+    assert DeepQNetwork(env, hs[1], "dflt", memory_size=16)._hip is None           # float32 unless asked otherwise
+    rs = np.random.RandomState(5)
+    for step in range(6):
+        for h in hs:
+            env.set_action(h, torch.from_numpy(rs.randint(21, size=env.get_num(h)).astype(np.int32)).cuda())
+        env.step(); env.clear_dead()
+    worst, agree, total, unexplained = 0.0, 0, 0, 0
+    for h in hs:
+        view, feat = env.get_observation(h); env.sync()
+        a16, q16 = m._hip.infer(view, feat, want_q=True)
+        q32 = torch.cat([m.qnet(view[b:b + 65536], feat[b:b + 65536]) for b in range(0, len(view), 65536)]).detach()
+        torch.cuda.synchronize()
+        scale = float(q32.abs().max())
+        err = float((q16 - q32).abs().max())
+        worst = max(worst, err / scale)
+        same = a16.long() == q32.argmax(dim=1)
+        top2 = q32.topk(2, dim=1).values
+        unexplained += int((~same & ((top2[:, 0] - top2[:, 1]) > 2 * err)).sum())
+        agree += int(same.sum()); total += len(same)
+    print("bf16 policy vs f32 network on %d real observations: max |dQ| / max |Q| = %.4f, greedy actions equal for %.2f %%" % (total, worst, 100.0 * agree / total))
+    assert worst <= 0.02, worst
+    assert agree >= 0.97 * total, (agree, total)
+    assert unexplained == 0
+    env.close()
+
+
+@pytest.mark.gpu
 def test_hip_policy_follows_parameter_updates():
     """DeepQNetwork repacks the kernel's weights after training: infer_action through the HIP path tracks the torch network"""
     import torch
@@ -103,7 +150,7 @@ def test_hip_policy_follows_parameter_updates():
     hs = env.get_handles()
     for h in hs:
         env.add_agents(h, "random", n=200)
-    m = DeepQNetwork(env, hs[0], "m", memory_size=64)
+    m = DeepQNetwork(env, hs[0], "m", memory_size=64, infer_dtype="bf16")
     assert m._hip is not None
     obs = env.get_observation(hs[0]); env.sync()
     a1 = m.infer_action(obs, None, policy="greedy")

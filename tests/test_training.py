@@ -328,12 +328,13 @@ def test_device_resident_training_round_on_gpu():
 
 
 @pytest.mark.gpu
-def test_c5_train_round_at_map_size_1000():
-    """BASELINE config 5's loop at examples/train_battle.py's `--map_size 1000` (2 x 40,000 agents from its generate_map), device-
-    resident observations, both sides acting through the DQN (bench.py: train_round_extra -- the same function the bench line's
-    `extra.c5_train_round_2x40k` comes from): finite loss after one train() per model, and for the first three steps every
-    engine output (views, features, rewards, alive flags, and the positions after clear_dead) equals the oracle's, which is fed
-    the very actions the policy chose."""
+@pytest.mark.parametrize("map_size,per_side", [(1000, 40000), (3536, 499849)])
+def test_c5_train_round(map_size, per_side):
+    """BASELINE config 5's loop (examples/train_battle.py:45-140, `play_a_round`) at `--map_size 1000` (2 x 40,000 agents from its
+    generate_map) and at the size BASELINE.json names, `--map_size 3536` (2 x 499,849: "1M agents"): device-resident observations, both
+    sides acting through the DQN (bench.py: train_round_extra -- the function the bench line's `extra.c5_train_round_*` come from):
+    finite loss after one train() per model, and for the first three steps every engine output (views, features, rewards, alive
+    flags, and the positions after clear_dead) equals the oracle's, which is fed the very actions the policy chose."""
     import torch
     import bench
     import magent_amd
@@ -343,10 +344,10 @@ def test_c5_train_round_at_map_size_1000():
         if step >= 3:
             return
         if not twin:
-            o = H.gridworld("battle", lib=H.ensure_oracle(), map_size=1000)
+            o = H.gridworld("battle", lib=H.ensure_oracle(), map_size=map_size)
             o.set_seed(12345); o.reset()
-            for h in o.get_handles():
-                o.add_agents(h, method="custom", pos=twin_pos[h.value])
+            for g, pos in bench.train_battle_formation(map_size):      # the start positions as train_round_extra lays them out
+                o.add_agents(o.get_handles()[g], method="custom", pos=pos)
             twin["env"] = o
         o = twin["env"]
         for i, h in enumerate(o.get_handles()):
@@ -359,17 +360,11 @@ def test_c5_train_round_at_map_size_1000():
             r = rewards[i].cpu().numpy() if isinstance(rewards[i], torch.Tensor) else rewards[i]
             assert np.asarray(r).tobytes() == o.get_reward(h).tobytes(), "step %d reward %d" % (step, i)
             assert np.array_equal(np.asarray(alives[i].cpu() if isinstance(alives[i], torch.Tensor) else alives[i]).astype(bool), o.get_alive(h)), "step %d alive %d" % (step, i)
+            assert np.array_equal(env.get_pos(h), o.get_pos(h)), "step %d pos %d" % (step, i)
         o.clear_dead()
 
-    # the twin needs the start positions: train_battle.py's generate_map pattern, as train_round_extra lays it out
-    import math
-    side = int(math.sqrt(1000 * 1000 * 0.04)) * 2
-    twin_pos = {}
-    for k in (0, 1):
-        x0 = 1000 // 2 - 3 - side if k == 0 else 1000 // 2 + 3
-        twin_pos[k] = [[x, y, 0] for x in range(x0, x0 + side, 2) for y in range((1000 - side) // 2, (1000 - side) // 2 + side, 2)]
-    out = bench.train_round_extra(torch, magent_amd, map_size=1000, steps=8, on_step=check)
-    assert out["agents"] == [40000, 40000]
+    out = bench.train_round_extra(torch, magent_amd, map_size=map_size, steps=8 if map_size <= 1000 else 4, on_step=check)
+    assert out["agents"] == [per_side, per_side]
     assert all(np.isfinite(x) and x > 0 for x in out["loss"]) and all(np.isfinite(x) for x in out["value"])
     assert out["env_ms_per_step"] > 0 and out["infer_ms_per_step"] > 0 and out["train_ms_per_round"] > 0
     print("c5 train round:", out)

@@ -16,7 +16,8 @@ env.set_seed(12345); env.reset()
 hs = env.get_handles()
 for h in hs:
     env.add_agents(h, "random", n=n)
-models = [DeepQNetwork(env, h, "m%d" % i, memory_size=16, infer_batch_size=65536) for i, h in enumerate(hs)]
+models = [DeepQNetwork(env, h, "m%d" % i, memory_size=16, infer_batch_size=65536, infer_dtype="bf16" if "cells" in sys.argv[4:5] or dtype == "bf16" else "f32")
+          for i, h in enumerate(hs)]
 cells = len(sys.argv) > 4 and sys.argv[4] == "cells" and all(m._hip is not None for m in models)
 env.use_bf16_observations(cells)       # views as bf16 cells: the MFMA kernels' operands, 2.7 KB per agent instead of 4.7
 t_env = t_pol = 0.0
