@@ -269,11 +269,6 @@ Env::Env() {
     if (const char *v = std::getenv("MAGENT_SOLO_STEP")) solo_enabled = std::atoi(v) != 0;
     if (const char *v = std::getenv("MAGENT_OVERLAP")) { overlap_level = std::atoi(v); overlap_enabled = overlap_level != 0; }
     if (const char *v = std::getenv("MAGENT_SOLO_MAX")) solo_max_agents = std::max(0, std::atoi(v));
-    // the cell-major, LDS-tiled attack / move phases: 0 off | 1 worlds of >= 32768 agents | 2 every world the multi-launch step takes (tests)
-    if (const char *v = std::getenv("MAGENT_CELL_STEP")) { const int m = std::atoi(v); cm_enabled = m != 0; if (m == 2) cm_min = 0; }
-    // the next step's shuffle draws a step ahead (Env::draw_ahead): 0 off (default: measured slower, profiles/r03_summary.md) | 1 beside the
-    // step's own phases, large worlds | 2 the same for every world (tests) | 3 beside the next observation render
-    if (const char *v = std::getenv("MAGENT_DRAW_AHEAD")) { const int m = std::atoi(v); ahead_enabled = m != 0; if (m == 2) ahead_min = 0; ahead_at_render = m == 3; }
 }
 
 template <class T>
@@ -285,14 +280,12 @@ Env::~Env() {
     if (!device_ready) return;
     use_device();
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_state); (void)hipEventDestroy(ev_side); }
-    if (pre_stream) { (void)hipStreamSynchronize(pre_stream); (void)hipStreamDestroy(pre_stream); (void)hipEventDestroy(ev_chased); (void)hipEventDestroy(ev_drawn); }
     (void)hipStreamSynchronize(stream);
     for (auto &g : groups) free_group(g);
     dfree(arena, d_occ); dfree(arena, d_viewcell); dfree(arena, d_claim); dfree(arena, d_food); dfree(arena, d_powtab); dfree(arena, d_counters); dfree(arena, d_gtab); dfree(arena, d_ttab);
     dfree(arena, d_delta); dfree(arena, d_mask); dfree(arena, d_mini); dfree(arena, d_minif); dfree(arena, d_sums); dfree(arena, d_rank); dfree(arena, d_shuf); dfree(arena, d_events); dfree(arena, d_actions);
     dfree(arena, d_stage_view); dfree(arena, d_stage_feat); dfree(arena, d_stage_small);
     dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d);
-    dfree(arena, d_crec); dfree(arena, d_cout); dfree(arena, d_cmv); dfree(arena, d_occ2);
     if (batch_h) (void)hipHostFree(batch_h);
     if (h_rec) (void)hipHostFree(h_rec);
     if (pool) {
@@ -972,7 +965,6 @@ void Env::reset() {
         map_cells = ncell;
     }
     HIP_OK(hipMemset(d_hit, 0, sizeof(unsigned) * ncell));
-    if (ncell != cm_cells) { dfree(arena, d_crec); dfree(arena, d_cout); dfree(arena, d_cmv); dfree(arena, d_occ2); cm_cells = 0; }
     claim_clean = false;
     if (food_mode && !d_food) HIP_OK(dev_malloc(arena, &d_food, sizeof(float) * 2 * ncell));   // amounts, then the attack phase's scratch
     if (d_food) HIP_OK(hipMemset(d_food, 0, sizeof(float) * 2 * ncell));
@@ -1039,19 +1031,6 @@ void Env::reset() {
             map_reach = std::max(map_reach, std::max(far, M - 1) + M - 1);
         }
     }
-    // the cell-major, LDS-tiled attack / move phases (kernels.hip: k_cm_*): one-cell bodies, no turn_mode / food_mode / goals /
-    // kill_supply, ranges that fit a tile's halo
-    cm_total_attack = total_attack;
-    cm_ha = 0; cm_hm = 0;
-    for (auto &g : groups) {
-        const HostType &t = *g.type;
-        for (int k = 0; k < t.attack.count; k++)
-            cm_ha = std::max(cm_ha, std::max(std::abs(t.attack.dx[k] + t.att_x_offset), std::abs(t.attack.dy[k] + t.att_y_offset)));
-        for (int k = 0; k < t.move.count; k++) cm_hm = std::max(cm_hm, 2 * std::max(std::abs(t.move.dx[k]), std::abs(t.move.dy[k])));
-    }
-    cm_ha = std::max(cm_ha, 1); cm_hm = std::max(cm_hm, 2);
-    cm_possible = cm_enabled && !any_multicell && !turn_mode && !food_mode && !any_absorb && !any_kill_supply && cm_ha <= 3 && cm_hm <= 6 &&
-                  total_attack >= 0 && cm_allow_lds(cm_ha, cm_hm);
     if (attack_kmax > 256) fatal("attack ranges x body size too large for the LDS hit lists (%d > 256)", attack_kmax);
     if (!attack_lds_ok(attack_kmax)) fatal("attack ranges x body size (%d hits per target) need more LDS per workgroup than this device grants", attack_kmax);
     if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
@@ -1324,7 +1303,6 @@ void Env::observe_device(int g, float *view, float *feat, bool cells16) {
         launch_commit_action(stream, G, groups[g].tdev);
     }
     mark_state();                   // (the side stream waits for the world as it is before this render, not for the render)
-    if (ahead_pending > 0) { draw_ahead(ahead_pending); ahead_pending = 0; }   // (MAGENT_DRAW_AHEAD=3: the next step's draws beside this render)
     WorldView W = this->view();
     RenderArgs R; RenderPlan P;
     const bool aligned = prepare_render(g, W, R, P, view, feat);
@@ -1456,14 +1434,11 @@ void Env::set_action_host(int g, const int *actions) {
 //     recording attack events, and with MAGENT_HOST_SHUFFLE / MAGENT_CHECKED_STEP for A/B runs).
 void Env::shuffle_buffers(int n_max) {
     grow(arena, d_rank, rank_cap, (size_t)n_max, stream);
-    if ((size_t)n_max * 4 > shuf_cap) {   // two sets (this step's shuffle | the next step's, drawn ahead) of four arrays each: head | first | j | link
-        drop_ahead();
-        size_t total = shuf_cap * 2;
-        grow(arena, d_shuf, total, (size_t)n_max * 8, stream);
-        shuf_cap = total / 2;
+    if ((size_t)n_max * 4 > shuf_cap) {   // four arrays: head | first | j | link
+        grow(arena, d_shuf, shuf_cap, (size_t)n_max * 4, stream);
         shuf_cap -= shuf_cap % 4;
         // head and first are kept zero between steps (k_attack_rank clears what a step used)
-        HIP_OK(hipMemsetAsync(d_shuf, 0, sizeof(int) * shuf_cap * 2, stream));
+        HIP_OK(hipMemsetAsync(d_shuf, 0, sizeof(int) * shuf_cap, stream));
     }
     int nb = (n_max + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
     grow(arena, d_sums, sums_cap, (size_t)nb, stream);
@@ -1482,62 +1457,15 @@ void Env::shuffle_buffers(int n_max) {
     }
 }
 
-// the cell-major arrays of the tiled phases: allocated when a step first takes that path
-bool Env::ensure_cell_world() {
-    const size_t ncell = (size_t)width * height;
-    if (cm_cells != ncell) {
-        HIP_OK(dev_malloc(arena, &d_crec, sizeof(CellRec) * ncell));
-        HIP_OK(dev_malloc(arena, &d_cout, sizeof(CellOut) * ncell));
-        HIP_OK(dev_malloc(arena, &d_cmv, sizeof(unsigned) * ncell));
-        HIP_OK(dev_malloc(arena, &d_occ2, sizeof(int) * ncell));
-        cm_cells = ncell;
-    }
-    return true;
-}
-CellWorld Env::cell_world() const { return CellWorld{d_crec, d_cout, d_cmv}; }
-
-ShuffleBufs Env::shuffle_bufs(int set) const {
-    if (set < 0) set = shuf_set;
+ShuffleBufs Env::shuffle_bufs() const {
     const size_t seg = shuf_cap / 4;
-    int *base = d_shuf + (size_t)set * shuf_cap;
-    return ShuffleBufs{base, base + seg, base + 2 * seg, base + 3 * seg};
+    return ShuffleBufs{d_shuf, d_shuf + seg, d_shuf + 2 * seg, d_shuf + 3 * seg};
 }
 
 void Env::push_rng() {
     if (rng_on_device) return;
-    drop_ahead();                        // (draws made ahead used the device's old state)
     launch_set_rng(stream, d_counters, (unsigned)rng.x);
     rng_on_device = true;
-}
-
-// ---- the next step's shuffle draws, made a step ahead (single-sync driver, large worlds).
-// The draws j_i depend on the engine's RNG state alone -- not on how many agents will attack, nor on the world -- and the state
-// after this step is known as soon as k_shuffle_chase has run.  So the ~27 us of list building (two device-scope atomics per list
-// entry) leave the critical path: right behind the chase, the draws for EVERY agent (an upper bound of the next attack list) go to
-// a stream of their own, into the other scratch set, beside this step's latency-bound attack and move phases; the next step waits
-// for an event and launches the chase alone (it skips the steps beyond its list's length).  Anything that changes the RNG state
-// or lets the list outgrow the draws (set_seed, reset, add_agents, a step of another driver) drops them.
-void Env::draw_ahead(int n_entries) {
-    if (!ahead_enabled || n_entries < ahead_min) return;
-    use_device();
-    if (!pre_stream) {
-        HIP_OK(hipStreamCreateWithFlags(&pre_stream, hipStreamNonBlocking));
-        HIP_OK(hipEventCreateWithFlags(&ev_chased, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&ev_drawn, hipEventDisableTiming));
-    }
-    HIP_OK(hipEventRecord(ev_chased, stream));
-    HIP_OK(hipStreamWaitEvent(pre_stream, ev_chased, 0));
-    launch_shuffle_ahead(pre_stream, n_entries, d_counters, shuffle_bufs(shuf_set ^ 1), d_powtab);
-    HIP_OK(hipEventRecord(ev_drawn, pre_stream));
-    ahead_valid = true; ahead_n = n_entries;
-}
-void Env::drop_ahead() {
-    if (!ahead_valid) return;
-    ahead_valid = false;
-    use_device();
-    HIP_OK(hipStreamWaitEvent(stream, ev_drawn, 0));           // the lists of the unused draws go back to zero
-    const ShuffleBufs B = shuffle_bufs(shuf_set ^ 1);
-    HIP_OK(hipMemsetAsync(B.head, 0, sizeof(int) * (shuf_cap / 4) * 2, stream));
 }
 
 // attack rounds, host-checked: pairs with ONE convergence check per pair (the flag of the second round)
@@ -1545,15 +1473,6 @@ void Env::attack_rounds_checked(const WorldView &W) {
     int iters = 0;
     while (true) {
         clear_changed();
-        if (step_was_cm) {
-            launch_cm_attack(stream, W, cell_world(), d_ttab, cm_ha, cm_total_attack, -1);
-            launch_cm_attack(stream, W, cell_world(), d_ttab, cm_ha, cm_total_attack, CTR_CHANGED);
-            attack_round += 2;
-            iters += 2;
-            if (!read_changed()) break;
-            if (iters > 1000000) fatal("attack resolution did not converge");
-            continue;
-        }
         launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, -1);
         launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, CTR_CHANGED);
         iters += 2;
@@ -1565,16 +1484,6 @@ void Env::attack_rounds_checked(const WorldView &W) {
 
 // move rounds, host-checked: `move_jump_batch` rounds per convergence check (a resolved agent is a no-op later)
 void Env::move_rounds_checked(const WorldView &W) {
-    if (step_was_cm) {               // tiled move phase: rounds until one changes nothing
-        int iters = 0;
-        do {
-            clear_changed();
-            launch_cm_move(stream, W, cell_world(), d_ttab, cm_hm, CTR_CHANGED);
-            if (++iters > 1000000) fatal("move resolution did not converge");
-        } while (read_changed());
-        last_move_iters = iters;
-        return;
-    }
     if (!any_multicell) { last_move_iters = 0; return; }   // one-cell bodies: the commit walks the dependency chains itself (move_resolve)
     int iters = 0;
     do {
@@ -1590,12 +1499,6 @@ void Env::move_rounds_checked(const WorldView &W) {
 }
 
 void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 = after move rounds */) {
-    if (step_was_cm) {
-        if (from == 0) { launch_cm_apply(stream, W, cell_world(), d_ttab); move_rounds_checked(W); }
-        launch_cm_commit(stream, W, cell_world(), d_gtab, d_ttab, cm_hm, d_occ2);
-        if (!rules_on_host) launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
-        return;
-    }
     if (from == 0) {
         launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
         if (any_multicell) launch_movg_prep(stream, W, true); else launch_move_prep(stream, W, d_gtab);   // (starve / recover first)
@@ -1657,7 +1560,6 @@ void Env::step_begin() {
     step_pending = true;
     step_was_fast = false;
     step_was_solo = false;
-    step_was_cm = false;
 
     const bool beside = total_n > 0 && fast && side_wanted() && overlap_level >= 2 && !serial_calls_on;   // the read-only head of the step goes beside the renders
     if (!beside) join_side();
@@ -1666,14 +1568,12 @@ void Env::step_begin() {
         enqueue_counters();
     } else if (serial_calls_on) {
         // ---------------- some group was given actions more than once: the reference's sequential loops, on the device
-        drop_ahead();
         claim_clean = false;
         step_was_fast = true;                    // (reports through the pinned record like the single-sync driver)
         step_live_paint = live_paint_now = false;   // the painted map is rebuilt by the next observation
         serial_step();
     } else if (solo_ok(total_n)) {
         // ---------------- one launch for the whole step
-        drop_ahead();
         step_was_solo = true;
         shuffle_buffers(total_n);
         push_rng();
@@ -1693,9 +1593,6 @@ void Env::step_begin() {
     } else if (fast) {
         claim_clean = false;
         step_was_fast = true;
-        const bool cm = cm_possible && !beside && total_n >= cm_min && ensure_cell_world();
-        step_was_cm = cm;
-        if (cm) cm_steps++;
         // ---------------- single-sync driver
         {
             const size_t caps = rank_cap + shuf_cap + sums_cap + powtab_cap;
@@ -1708,52 +1605,18 @@ void Env::step_begin() {
         hipStream_t a = beside ? side_stream() : stream;
         {
             ProfScope p(*this, "attack", false, a);
-            int n_drawn = -1;
-            if (ahead_valid && ahead_n >= total_n && a == stream) {     // the draws were made during the last step: the chase alone
-                HIP_OK(hipStreamWaitEvent(stream, ev_drawn, 0));
-                shuf_set ^= 1;
-                n_drawn = ahead_n;
-                ahead_valid = false;
-                launch_shuffle_chase(a, total_n, d_counters, shuffle_bufs(), d_rank, (unsigned *)d_claim, (size_t)width * height);
-            } else {
-                drop_ahead();
-                launch_shuffle(a, total_n, d_counters, shuffle_bufs(), d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
-            }
-            if (a == stream) { if (ahead_at_render) ahead_pending = total_n; else draw_ahead(total_n); }   // (the RNG state of the next step is on the device now)
+            launch_shuffle(a, total_n, d_counters, shuffle_bufs(), d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
             if (overlap_level == 2 && a != stream) { join_side(); a = stream; }
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
-            if (cm) {
-                // cell-major, LDS-tiled: the agents' records onto their cells, then rounds over the tiles; the LAST one reports
-                launch_cm_scatter(a, W, cell_world(), d_rank, shuffle_bufs(), n_drawn);
-                const int rounds = pairs == 0 ? 0 : pairs + 1;       // (a round settles everything a tile and its halo hold)
-                for (int r = 0; r < rounds; r++)
-                    launch_cm_attack(a, W, cell_world(), d_ttab, cm_ha, cm_total_attack, r == rounds - 1 ? CTR_OPEN_ATTACK : -1);
-                attack_round = rounds;
-            } else {
-                launch_attack_rank(a, W, d_rank, shuffle_bufs(), false, n_drawn);
-                // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
-                // LAST one reports whether anything still moved (one gate for all of them)
-                for (int r = 0; r < 2 * pairs; r++)
-                    launch_attack_iter(a, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
-            }
+            launch_attack_rank(a, W, d_rank, shuffle_bufs(), false);
+            // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
+            // LAST one reports whether anything still moved (one gate for all of them)
+            for (int r = 0; r < 2 * pairs; r++)
+                launch_attack_iter(a, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
             if (pairs == 0) launch_set_counter(a, d_counters, CTR_OPEN_ATTACK, 1, -1);   // tests: straight to the host
         }
         join_side();      // from here on the world changes: behind every render enqueued so far
-        if (cm) {
-            {
-                ProfScope p(*this, "attack");
-                launch_cm_apply(stream, W, cell_world(), d_ttab);
-            }
-            {
-                ProfScope p(*this, "move");
-                const int batches = opt_fixed ? opt_move_batches : (boost_move > 0 ? 2 : 1);
-                const int rounds = batches == 0 ? 0 : batches + 1;
-                for (int r = 0; r < rounds; r++) launch_cm_move(stream, W, cell_world(), d_ttab, cm_hm, r == rounds - 1 ? CTR_OPEN_MOVE : -1);
-                if (batches == 0) launch_set_counter(stream, d_counters, CTR_OPEN_MOVE, 1, CTR_OPEN_ATTACK);   // tests
-                launch_cm_commit(stream, W, cell_world(), d_gtab, d_ttab, cm_hm, d_occ2);
-            }
-        } else {
         {
             ProfScope p(*this, "attack");
             launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
@@ -1770,7 +1633,6 @@ void Env::step_begin() {
             if (batches == 0) launch_set_counter(stream, d_counters, CTR_OPEN_MOVE, 1, CTR_OPEN_ATTACK);   // tests
             if (any_multicell) launch_movg_apply(stream, W, d_gtab); else launch_move_apply(stream, W, d_gtab);
         }
-        }
         {
             ProfScope p(*this, "rules");
             if (!rules_on_host) launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
@@ -1779,7 +1641,6 @@ void Env::step_begin() {
         launch_step_report(stream, d_counters, h_rec, ++step_seq, (int)groups.size());
     } else {
         // ---------------- checked driver
-        drop_ahead();
         claim_clean = false;
         HIP_OK(hipMemsetAsync(d_counters + CTR_OPEN_ATTACK, 0, 2 * sizeof(int), stream));
         const int A = read_counters()[CTR_ATTACK];
@@ -1884,7 +1745,6 @@ void Env::step_end(int *done) {
             h_occ_valid = false;
             paint_valid = step_live_paint; mini_valid = false;
             live_paint_now = false;
-            if (step_was_cm) std::swap(d_occ, d_occ2);     // k_cm_commit left the occupancy after the step in the second map
             return;
         }
         read_counters();     // a phase ran out of optimistic rounds: the whole counter block, for the continuation below
@@ -1903,7 +1763,6 @@ void Env::step_end(int *done) {
             if (phase == 1) { attack_rounds_checked(W); phase_tail(W, 0); }
             else { move_rounds_checked(W); phase_tail(W, 1); }
             c = read_counters();
-            if (step_was_cm) std::swap(d_occ, d_occ2);     // (read_counters waited for the commit)
         }
         if (boost_attack > 0) boost_attack--;
         if (boost_move > 0) boost_move--;
@@ -2299,7 +2158,7 @@ void Env::info_host(int g, const char *name, void *buf) {
         ib[0] = fallback_steps; ib[1] = last_attack_iters; ib[2] = last_move_iters; ib[3] = attack_round;
         ib[4] = fallback_attack; ib[5] = fallback_move;      // (which phase's optimistic rounds ran out)
         ib[6] = last_render_kernel;                          // 0 k_render, 1 k_render_fast, 4 k_render_sweep2
-        ib[7] = cm_steps;                                    // steps that took the cell-major, LDS-tiled phases
+        ib[7] = 0;                                           // (was: steps through the cell-major phases, removed in round 4)
         return;
     }
     if (k == "batch_host_us") {  // additive (tuning): host microseconds per env_cycle_many round since the last read:

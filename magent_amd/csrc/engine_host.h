@@ -201,12 +201,6 @@ private:
     std::vector<SerialCall> serial_calls;   // the calls of a step in which a group was given actions twice (k_step_serial)
     std::vector<int> step_calls;            // groups given actions in this step, in call order
     bool serial_calls_on = false;
-    bool ensure_cell_world();
-    CellWorld cell_world() const;
-    CellRec *d_crec = nullptr; CellOut *d_cout = nullptr; unsigned *d_cmv = nullptr; int *d_occ2 = nullptr;
-    size_t cm_cells = 0;
-    int cm_ha = 1, cm_hm = 2, cm_total_attack = 0, cm_min = 32768, cm_steps = 0;
-    bool cm_enabled = false, cm_possible = false, step_was_cm = false;
     MiniArgs next_minimap();
     int *fold_counts();
     bool cycle_eligible(int n_group, float *const *view, float *const *feat, int *first_obs_out);
@@ -224,14 +218,7 @@ private:
     RuleArgs *d_rule_args = nullptr; RuleProg *d_rule_progs = nullptr;
     void shuffle_buffers(int n_max);
     void push_rng();
-    ShuffleBufs shuffle_bufs(int set = -1) const;
-    void draw_ahead(int n_entries);
-    void drop_ahead();
-    hipStream_t pre_stream = nullptr;       // the next step's shuffle draws run here, beside the step
-    hipEvent_t ev_chased = nullptr, ev_drawn = nullptr;
-    int shuf_set = 0, ahead_n = 0, ahead_min = 65536;
-    bool ahead_valid = false, ahead_enabled = false, ahead_at_render = false;
-    int ahead_pending = 0;
+    ShuffleBufs shuffle_bufs() const;
     void attack_rounds_checked(const WorldView &W);
     void move_rounds_checked(const WorldView &W);
     void phase_tail(const WorldView &W, int from);

@@ -998,9 +998,7 @@ __device__ __forceinline__ unsigned rng_skip(unsigned x, unsigned n) {
     while (n) { if (n & 1u) x = mulmod31(x, base); base = mulmod31(base, base); n >>= 1; }
     return x;
 }
-// (A: the length of this step's attack list.  The lists may have been built for MORE entries than that -- the draw of a step can
-// run a step ahead, for every agent, before anybody knows how many will attack (launch_shuffle_ahead): steps k >= A do not exist
-// in this step's shuffle and are skipped; `first` holds the SMALLEST later step per slot, so one that is >= A means there is none)
+// (A: the length of this step's attack list)
 __device__ __forceinline__ void shuffle_chase_body(int i, int A, const int *j, const int *head, const int *first, const int *link, int *rank) {
     int p = j[i];
     int nxt = 0x7FFFFFFF;
@@ -1012,11 +1010,10 @@ __device__ __forceinline__ void shuffle_chase_body(int i, int A, const int *j, c
     rank[i] = p;
 }
 
-// (n_fixed < 0: the draws of THIS step's list, length counters[CTR_ATTACK], and the hit words' zero-fill; n_fixed >= 0: the draws of
-// the NEXT step, for n_fixed entries, on the stream beside the rest of the step -- nothing but the shuffle scratch is touched)
-__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int n_fixed, int *j, int *head, int *first, int *link, unsigned *hitbits, size_t ncell,
+// (the draws of this step's list, length counters[CTR_ATTACK], and the hit words' zero-fill)
+__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *head, int *first, int *link, unsigned *hitbits, size_t ncell,
                                                      const unsigned *powtab) {
-    const int A = n_fixed >= 0 ? n_fixed : counters[CTR_ATTACK];
+    const int A = counters[CTR_ATTACK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     // the per-cell hit words of the coming attack phase start from zero (they share the move phase's claim array)
     if (hitbits && A > 0) for (size_t c = i; c < ncell; c += (size_t)gridDim.x * blockDim.x) hitbits[c] = 0u;
@@ -1024,12 +1021,9 @@ __global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int n
     shuffle_draw_body((unsigned)counters[CTR_RNG], i, j, head, first, link, powtab);
 }
 
-// (hitbits != null: the draws were made a step ahead -- the zero-fill of the hit words rides here instead)
-__global__ void __launch_bounds__(256) k_shuffle_chase(int *counters, const int *j, const int *head, const int *first, const int *link, int *rank,
-                                                      unsigned *hitbits, size_t ncell) {
+__global__ void __launch_bounds__(256) k_shuffle_chase(int *counters, const int *j, const int *head, const int *first, const int *link, int *rank) {
     const int A = counters[CTR_ATTACK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (hitbits && A > 0) for (size_t c = i; c < ncell; c += (size_t)gridDim.x * blockDim.x) hitbits[c] = 0u;
     if (i == 0) {   // (every draw has read the old state: k_shuffle_draw ran before)
         counters[CTR_LAST_A] = A;
         counters[CTR_RNG] = (int)rng_skip((unsigned)counters[CTR_RNG], (unsigned)A);   // the host mirror is refreshed by the end-of-step report
@@ -1070,13 +1064,11 @@ __device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int 
     }
     if (W.food_mode) { G.eat[i] = -1.0f; G.fcell[i] = -1; }
 }
-__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_head, int *shuf_first, int n_drawn) {
+__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_head, int *shuf_first) {
     if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // attack rounds start
     const int A = W.counters[CTR_ATTACK];
     // the shuffle's list heads and first-hit words have been read for the last time (k_shuffle_chase): back to zero for their next use
-    // (n_drawn: the entries the draw was made for -- more than A when it ran a step ahead; < 0: A)
-    const int nz = n_drawn >= 0 ? n_drawn : A;
-    for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < nz; k += gridDim.x * gridDim.y * blockDim.x) {
+    for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < A; k += gridDim.x * gridDim.y * blockDim.x) {
         shuf_head[k] = 0; shuf_first[k] = 0;
     }
     if (A == 0) return;
@@ -2865,471 +2857,9 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
 void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell, const unsigned *powtab) {
     // head / first are zero here: zeroed when allocated, and again by k_attack_rank after every use
     dim3 g((n_max + 255) / 256), b(256);
-    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, -1, B.j, B.head, B.first, B.link, hitbits, ncell, powtab);
-    hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, B.j, B.head, B.first, B.link, rank, (unsigned *)nullptr, (size_t)0);
+    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, B.j, B.head, B.first, B.link, hitbits, ncell, powtab);
+    hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, B.j, B.head, B.first, B.link, rank);
 }
-// The draws of the NEXT step's shuffle, for `n_entries` list entries (an upper bound of its attack list: every agent), into a clean
-// scratch set.  They depend on the engine's RNG state alone, which k_shuffle_chase has just advanced: the launch goes on a stream
-// beside the step's latency-bound phases and takes 27 us out of the next step's critical path (engine.hip: Env::draw_ahead).
-void launch_shuffle_ahead(hipStream_t s, int n_entries, const int *counters, const ShuffleBufs &B, const unsigned *powtab) {
-    if (n_entries <= 0) return;
-    hipLaunchKernelGGL(k_shuffle_draw, dim3((n_entries + 255) / 256), dim3(256), 0, s, counters, n_entries, B.j, B.head, B.first, B.link,
-                       (unsigned *)nullptr, (size_t)0, powtab);
-}
-// ... and the rest of that shuffle when its step has come: the chase alone (with the hit words' zero-fill)
-void launch_shuffle_chase(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell) {
-    hipLaunchKernelGGL(k_shuffle_chase, dim3((n_max + 255) / 256), dim3(256), 0, s, counters, B.j, B.head, B.first, B.link, rank, hitbits, ncell);
-}
-// ================================================================================================ cell-major, LDS-tiled attack and move phases (round 3)
-// One-cell bodies without turn_mode / food_mode / goals / kill_supply (battle, gather, ...).  The per-agent passes above are chains
-// of dependent gathers: agent -> its cell -> the neighbour's cell -> that neighbour's arrays.  Here the agents write what their
-// neighbours need ONCE per step into a 16-byte record on their own cell (k_cm_scatter: pending action, rank or move key, hp, death
-// rank); from then on both order-dependent phases are passes over 32 x 32 TILES of the map with a halo, in LDS: neighbour probes, hit
-// sorting, the replay in rank order and the walk along a chain of movers are LDS reads; global memory is read once per tile, coalesced,
-// and supplies the halo's values of the previous round.  Dependencies that leave a tile are settled by running the pass again (every
-// round recomputes its interior from scratch, so any number of rounds converges to the one fixed point; a round that changes nothing
-// ends the phase -- the same optimistic-rounds protocol as the per-agent kernels).  Semantics restated from the kernels above, which
-// are pinned to the reference: attack_rank_body / attack_eval_body / attack_apply_body (GridWorld.cc:464-507, Map.cc:209-310),
-// starve_body (GridWorld.cc:519-542), move_prep / claim / init / commit bodies (GridWorld.cc:574-613, Map.cc:313-358).
-constexpr int CM_TILE = 32, CM_THREADS = 256, CM_CELLS_PER_THREAD = CM_TILE * CM_TILE / CM_THREADS;
-constexpr unsigned CM_OUT_NONE = 0u, CM_OUT_PEN = 1u, CM_OUT_ATTACK = 2u, CM_OUT_KILL = 3u;    // CellOut::out >> 30; the low 30 bits: the target's ref
-constexpr unsigned CM_NOT_HIT = 0xFFFFFFFFu;        // CellOut::hp bits while nobody has hit the agent standing on the cell
-constexpr unsigned CM_MV_UNKNOWN = 0xFFFFFFFCu;     // move status not decided yet (depends on a mover of another tile)
-
-// ---- once per step, per agent: the record on its own cell; the shuffle's scratch goes back to zero (as in k_attack_rank)
-__global__ void __launch_bounds__(256) k_cm_scatter(WorldView W, CellWorld C, const int *rank, int *shuf_head, int *shuf_first, int n_drawn) {
-    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;
-    const int A = W.counters[CTR_ATTACK];
-    const int nz = n_drawn >= 0 ? n_drawn : A;
-    for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < nz; k += gridDim.x * gridDim.y * blockDim.x) {
-        shuf_head[k] = 0; shuf_first[k] = 0;
-    }
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.n || G.dead[i]) return;                 // (agents dead before the step are not on the map)
-    const int pend = G.pend[i];
-    unsigned key = G.key[i];
-    if ((pend & ~PEND_ARG) == PEND_ATTACK) { key = (unsigned)rank[key]; G.key[i] = key; }
-    const int c = G.y[i] * W.w + G.x[i];
-    CellRec r;
-    r.act = (unsigned)pend; r.key = key; r.hp = G.hp[i]; r.dr = RANK_INF;
-    C.rec[c] = r;
-    C.mv[c] = CM_MV_UNKNOWN;
-}
-
-// the attack offsets of every group as one table: entry b = (group, payload, dx, dy) for hit bit b (TypeDev::attack_bit)
-struct CmOffset { int g, k, dx, dy; };
-
-// ---- one round of the attack phase over one tile.  LDS: the region's occ / act / key / dr / hp, a pool of hits (at most one per attacker
-// in the region), per interior cell its slice of the pool.
-__global__ void __launch_bounds__(CM_THREADS) k_cm_attack(WorldView W, CellWorld C, const TypeDev *ttab, int H, int n_off, int flag) {
-    if (W.counters[CTR_ATTACK] == 0) return;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int S = CM_TILE + 2 * H, RC = S * S;
-    int *s_occ = (int *)smem;
-    unsigned *s_act = (unsigned *)(s_occ + RC);
-    unsigned *s_key = s_act + RC;
-    int *s_dr = (int *)(s_key + RC);
-    float *s_hp = (float *)(s_dr + RC);
-    unsigned *s_prank = (unsigned *)(s_hp + RC);        // pool: rank of a hit
-    unsigned short *s_pidx = (unsigned short *)(s_prank + RC);   // pool: region index of its attacker
-    __shared__ CmOffset s_off[ATTACK_KMAX_HOST];
-    __shared__ float s_damage[MAXG];
-    __shared__ int s_aig[MAXG];
-    __shared__ int s_pool_n, s_chg;
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * CM_TILE - H, y0 = blockIdx.y * CM_TILE - H;
-    if (tid < n_off) {
-        int g = 0;
-        for (int q = 0; q < W.G; q++) if (ttab[q].n_attack > 0 && tid >= ttab[q].attack_bit && tid < ttab[q].attack_bit + ttab[q].n_attack) g = q;
-        const int k = tid - ttab[g].attack_bit;
-        const int2 d = W.delta[ttab[g].attack_off + k];
-        s_off[tid].g = g; s_off[tid].k = k; s_off[tid].dx = d.x; s_off[tid].dy = d.y;
-    }
-    if (tid < MAXG) { s_damage[tid] = tid < W.G ? ttab[tid].damage : 0.0f; s_aig[tid] = tid < W.G ? ttab[tid].attack_in_group : 0; }
-    if (tid == 0) s_pool_n = 0;
-    for (int r = tid; r < RC; r += CM_THREADS) {
-        const int ly = r / S, lx = r - ly * S;
-        const int gx = x0 + lx, gy = y0 + ly;
-        int o = OCC_WALL;
-        CellRec rec;
-        rec.act = 0u; rec.key = 0u; rec.hp = 0.0f; rec.dr = RANK_INF;
-        if (gx >= 0 && gx < W.w && gy >= 0 && gy < W.h) {
-            const int c = gy * W.w + gx;
-            o = W.occ[c];
-            if (o >= 0) rec = C.rec[c];
-        }
-        s_occ[r] = o; s_act[r] = rec.act; s_key[r] = rec.key; s_dr[r] = rec.dr; s_hp[r] = rec.hp;
-    }
-    __syncthreads();
-    // ---- the hits on my interior cells: probe every attack offset's source cell, sort my slice of the pool by rank
-    int ri[CM_CELLS_PER_THREAD], seg0[CM_CELLS_PER_THREAD], cnt[CM_CELLS_PER_THREAD], dr0[CM_CELLS_PER_THREAD];
-    float hpres[CM_CELLS_PER_THREAD];
-#pragma unroll
-    for (int q = 0; q < CM_CELLS_PER_THREAD; q++) {
-        const int ci = q * CM_THREADS + tid;
-        const int ly = ci / CM_TILE, lx = ci - ly * CM_TILE;
-        ri[q] = (ly + H) * S + lx + H;
-        cnt[q] = 0; seg0[q] = 0; dr0[q] = s_dr[ri[q]]; hpres[q] = 0.0f;
-        const int o = s_occ[ri[q]];
-        if (o < 0) continue;
-        const int mg = ref_group(o);
-        int n = 0;
-        for (int b = 0; b < n_off; b++) {
-            const CmOffset f = s_off[b];
-            const int a = ri[q] - f.dy * S - f.dx;                       // the cell an attacker with this offset would stand on (inside the region: |d| <= H)
-            const int ao = s_occ[a];
-            if (ao >= 0 && ref_group(ao) == f.g && s_act[a] == (unsigned)(PEND_ATTACK | f.k) && (s_aig[f.g] || f.g != mg)) n++;
-        }
-        if (n == 0) continue;
-        const int base = atomicAdd(&s_pool_n, n);
-        int m = 0;
-        for (int b = 0; b < n_off; b++) {
-            const CmOffset f = s_off[b];
-            const int a = ri[q] - f.dy * S - f.dx;
-            const int ao = s_occ[a];
-            if (ao >= 0 && ref_group(ao) == f.g && s_act[a] == (unsigned)(PEND_ATTACK | f.k) && (s_aig[f.g] || f.g != mg)) {
-                const unsigned rk = s_key[a];
-                int z = m - 1;                                            // insertion by rank (ranks are unique)
-                while (z >= 0 && s_prank[base + z] > rk) { s_prank[base + z + 1] = s_prank[base + z]; s_pidx[base + z + 1] = s_pidx[base + z]; z--; }
-                s_prank[base + z + 1] = rk; s_pidx[base + z + 1] = (unsigned short)a;
-                m++;
-            }
-        }
-        seg0[q] = base; cnt[q] = n;
-    }
-    // ---- the death ranks of the interior, iterated in place to the tile's fixed point (the halo keeps the previous round's values)
-    for (int it = 0; it < 4096; it++) {
-        __syncthreads();
-        if (tid == 0) s_chg = 0;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < CM_CELLS_PER_THREAD; q++) {
-            if (cnt[q] == 0) continue;
-            float hp = s_hp[ri[q]];
-            int dr = RANK_INF;
-            for (int k = 0; k < cnt[q]; k++) {
-                const unsigned rk = s_prank[seg0[q] + k];
-                const int a = s_pidx[seg0[q] + k];
-                if ((unsigned)s_dr[a] >= rk) {                            // the attacker is alive when its turn comes
-                    hp -= s_damage[ref_group(s_occ[a])];
-                    if (hp < 0.0f) { dr = (int)rk; break; }              // death iff hp < 0 strictly (GridWorld.h:205)
-                }
-            }
-            hpres[q] = hp;
-            if (dr != s_dr[ri[q]]) { s_dr[ri[q]] = dr; s_chg = 1; }
-        }
-        __syncthreads();
-        if (!s_chg) break;
-    }
-    // ---- out: death rank, hp after the phase, and what my own attack came to (read by k_cm_apply); was anything new?
-    bool news = false;
-#pragma unroll
-    for (int q = 0; q < CM_CELLS_PER_THREAD; q++) {
-        const int o = s_occ[ri[q]];
-        if (o < 0) continue;
-        const int ly = ri[q] / S, lx = ri[q] - ly * S;
-        const int c = (y0 + ly) * W.w + x0 + lx;
-        const int dr = s_dr[ri[q]];
-        if (dr != dr0[q]) { news = true; C.rec[c].dr = dr; }
-        unsigned out = CM_OUT_NONE << 30;
-        const unsigned act = s_act[ri[q]];
-        if ((act & ~(unsigned)PEND_ARG) == (unsigned)PEND_ATTACK) {
-            const unsigned my_rank = s_key[ri[q]];
-            if ((unsigned)dr >= my_rank) {                                // alive at my turn (GridWorld.cc:479-480)
-                const int mg = ref_group(o);
-                const int2 d = W.delta[ttab[mg].attack_off + (int)(act & PEND_ARG)];
-                const int gx = x0 + lx + d.x, gy = y0 + ly + d.y;
-                int tgt = -1, tdr = RANK_INF;
-                if (gx >= 0 && gx < W.w && gy >= 0 && gy < W.h) {
-                    const int t = ri[q] + d.y * S + d.x;
-                    const int to = s_occ[t];
-                    if (to >= 0 && (s_aig[mg] || ref_group(to) != mg)) { tgt = to; tdr = s_dr[t]; }
-                }
-                if (tgt < 0 || (unsigned)tdr < my_rank) out = CM_OUT_PEN << 30;          // blank, or the target died before my turn (Map.cc:229-231)
-                else out = (((unsigned)tdr == my_rank ? CM_OUT_KILL : CM_OUT_ATTACK) << 30) | (unsigned)tgt;
-            }
-        }
-        CellOut oc;
-        oc.hp = cnt[q] ? hpres[q] : __uint_as_float(CM_NOT_HIT);
-        oc.out = out;
-        C.out[c] = oc;
-    }
-    if (news && flag >= 0) W.counters[flag] = 1;
-}
-
-// ---- per agent: the attack phase applied (attack_apply_body), Agent::set_action's last_action, the dead off the map, starvation
-// (starve_body); the agent's hp after all that goes back onto its cell for the painted map.  Every lane of a wave comes here (ballot).
-__global__ void __launch_bounds__(256) k_cm_apply(WorldView W, CellWorld C, const TypeDev *ttab) {
-    if (attack_open(W)) return;
-    const int g = blockIdx.y;
-    const GroupDev G = W.grp[g];
-    const TypeDev T = W.type[g];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int A = W.counters[CTR_ATTACK];
-    bool died = false;
-    if (i < G.n) {
-        const int pend = G.pend[i];
-        if (pend != PEND_NONE) G.last_action[i] = pend_action(pend, T);
-        G.pend[i] = PEND_NONE;                         // (the move phase reads the action from the cell record)
-        if (!G.dead[i]) {
-            const int c = G.y[i] * W.w + G.x[i];
-            float hp = G.hp[i];
-            float nr = G.next_reward[i];
-            bool alive = true;
-            if (A > 0) {
-                const CellOut oc = C.out[c];
-                const int dr = C.rec[c].dr;
-                if (__float_as_uint(oc.hp) != CM_NOT_HIT) hp = oc.hp;
-                const unsigned code = oc.out >> 30;
-                float own = 0.0f;
-                if (code == CM_OUT_PEN) own = T.attack_penalty;
-                else if (code == CM_OUT_ATTACK || code == CM_OUT_KILL) {
-                    const int tgt = (int)(oc.out & 0x3FFFFFFFu);
-                    float reward = 0.0f;
-                    if (code == CM_OUT_KILL) { G.last_op[i] = OP_KILL; reward = ttab[ref_group(tgt)].kill_reward; }
-                    else G.last_op[i] = OP_ATTACK;
-                    G.op_obj[i] = tgt;
-                    own = reward + T.attack_penalty;                      // add_reward(reward + attack_penalty) (GridWorld.cc:505)
-                }
-                if (dr != RANK_INF) {                                     // killed: dead_penalty overwrites what was accumulated (GridWorld.h:207)
-                    alive = false; died = true;
-                    G.dead[i] = 1; nr = T.dead_penalty;
-                    W.occ[c] = OCC_EMPTY;
-                    if (W.live_paint) vc_store(W, c, OCC_EMPTY, 0u);
-                } else if (code != CM_OUT_NONE) nr += own;
-            }
-            if (alive) {
-                if (T.step_recover > 0) hp = fminf(T.hp, hp + T.step_recover);
-                else {
-                    hp -= -T.step_recover;
-                    if (hp < 0.0f) {
-                        died = true; G.dead[i] = 1; nr = T.dead_penalty;
-                        W.occ[c] = OCC_EMPTY;
-                        if (W.live_paint) vc_store(W, c, OCC_EMPTY, 0u);
-                    }
-                }
-            }
-            G.hp[i] = hp;
-            G.next_reward[i] = nr;
-            C.out[c].hp = hp;
-        }
-    }
-    int wtot; wave_rank(died, wtot);
-    if (wtot && lane_id() == 0) atomicAdd(&W.counters[dead_slot(g, blockIdx.x % DEAD_SLOTS)], wtot);
-}
-
-// ---- the move phase over one tile: who may move where (move_prep_body), the lowest-key contender of every target cell that may be
-// entered (move_claim_body), the status of every mover (move_init_body), chains walked in LDS.  The region reaches 2 * R cells past
-// the tile (R = the longest move): a mover of the tile aims at most R cells out, and that cell's contenders stand at most R further.
-struct CmMove {
-    int S, RC, H;
-    int *occ; unsigned *act, *key, *mv; int *tgt; unsigned long long *win; float *hp;
-};
-__device__ __forceinline__ CmMove cm_move_layout(char *smem, int H) {
-    CmMove L;
-    L.H = H; L.S = CM_TILE + 2 * H; L.RC = L.S * L.S;
-    L.win = (unsigned long long *)smem;
-    L.occ = (int *)(L.win + L.RC);
-    L.act = (unsigned *)(L.occ + L.RC);
-    L.key = L.act + L.RC;
-    L.mv = L.key + L.RC;
-    L.tgt = (int *)(L.mv + L.RC);
-    L.hp = (float *)(L.tgt + L.RC);
-    return L;
-}
-// loads the region and leaves: tgt[r] = region index of r's move target (-1: not a candidate), win[t] = (key << 32 | r) of the static
-// winner of cell t (~0: nobody), mv[r] = the status the previous round published for r (halo) / this round's first reading (interior)
-__device__ __forceinline__ void cm_move_region(const WorldView &W, const CellWorld &C, const TypeDev *ttab, const CmMove &L, int x0, int y0, bool want_hp) {
-    const int tid = threadIdx.x, S = L.S, RC = L.RC;
-    for (int r = tid; r < RC; r += CM_THREADS) {
-        const int ly = r / S, lx = r - ly * S;
-        const int gx = x0 + lx, gy = y0 + ly;
-        int o = OCC_WALL;
-        unsigned act = 0u, key = 0u, mv = MV_FAIL;
-        float hp = 0.0f;
-        if (gx >= 0 && gx < W.w && gy >= 0 && gy < W.h) {
-            const int c = gy * W.w + gx;
-            o = W.occ[c];
-            if (o >= 0) { const CellRec rec = C.rec[c]; act = rec.act; key = rec.key; mv = C.mv[c]; if (want_hp) hp = C.out[c].hp; }
-        }
-        L.occ[r] = o; L.act[r] = act; L.key[r] = key; L.mv[r] = mv; L.win[r] = ~0ull; L.hp[r] = hp;
-    }
-    __syncthreads();
-    for (int r = tid; r < RC; r += CM_THREADS) {
-        int t = -1;
-        const int o = L.occ[r];
-        if (o >= 0 && (L.act[r] & ~(unsigned)PEND_ARG) == (unsigned)PEND_MOVE) {
-            const int ly = r / S, lx = r - ly * S;
-            const int2 d = W.delta[ttab[ref_group(o)].move_off + (int)(L.act[r] & PEND_ARG)];
-            const int nx = x0 + lx + d.x, ny = y0 + ly + d.y;
-            const int tlx = lx + d.x, tly = ly + d.y;
-            // is_blank_area's bounds (Map.cc:455); a zero move "succeeds" in place and never vacates; targets outside the region belong to movers
-            // too far out to matter to this tile
-            if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + 1 < W.w && ny + 1 < W.h && tlx >= 0 && tlx < S && tly >= 0 && tly < S &&
-                L.occ[tly * S + tlx] != OCC_WALL) t = tly * S + tlx;
-        }
-        L.tgt[r] = t;
-    }
-    __syncthreads();
-    for (int r = tid; r < RC; r += CM_THREADS) {
-        const int t = L.tgt[r];
-        if (t < 0) continue;
-        const int o = L.occ[t];
-        bool ok = o == OCC_EMPTY;
-        if (o >= 0) ok = L.tgt[t] >= 0 && L.key[t] < L.key[r];           // the occupant may leave, and before my turn
-        if (ok) atomicMin(&L.win[t], ((unsigned long long)L.key[r] << 32) | (unsigned)r);
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ bool cm_interior(const CmMove &L, int r) {
-    const int ly = r / L.S, lx = r - ly * L.S;
-    return lx >= L.H && lx < L.H + CM_TILE && ly >= L.H && ly < L.H + CM_TILE;
-}
-
-__global__ void __launch_bounds__(CM_THREADS) k_cm_move(WorldView W, CellWorld C, const TypeDev *ttab, int H, int flag) {
-    if (attack_open(W)) return;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const CmMove L = cm_move_layout(smem, H);
-    __shared__ int s_chg;
-    const int tid = threadIdx.x, S = L.S;
-    const int x0 = blockIdx.x * CM_TILE - H, y0 = blockIdx.y * CM_TILE - H;
-    cm_move_region(W, C, ttab, L, x0, y0, false);
-    // ---- first reading of my interior movers: not the winner -> FAIL; an empty target -> OK; else whatever the occupant does (its region index)
-    int ri[CM_CELLS_PER_THREAD];
-    unsigned mv0[CM_CELLS_PER_THREAD];
-#pragma unroll
-    for (int q = 0; q < CM_CELLS_PER_THREAD; q++) {
-        const int ci = q * CM_THREADS + tid;
-        const int ly = ci / CM_TILE, lx = ci - ly * CM_TILE;
-        ri[q] = (ly + H) * S + lx + H;
-        mv0[q] = L.mv[ri[q]];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < CM_CELLS_PER_THREAD; q++) {
-        const int r = ri[q], t = L.tgt[r];
-        if (L.occ[r] < 0) continue;
-        unsigned st = MV_FAIL;
-        if (t >= 0 && (unsigned)L.win[t] == (unsigned)r) st = L.occ[t] == OCC_EMPTY ? MV_OK : (unsigned)t;
-        L.mv[r] = st;
-    }
-    // ---- chains: a status that is a region index < RC means "as that mover"; interior links are followed here, a link into the halo reads
-    // what its own tile published last round (final, or still unknown)
-    for (int it = 0; it < 4096; it++) {
-        __syncthreads();
-        if (tid == 0) s_chg = 0;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < CM_CELLS_PER_THREAD; q++) {
-            const unsigned m = L.mv[ri[q]];
-            if (m >= (unsigned)L.RC) continue;
-            const unsigned v = L.mv[m];
-            if (v == MV_OK || v == MV_FAIL) { L.mv[ri[q]] = v; s_chg = 1; }
-            else if (v < (unsigned)L.RC && cm_interior(L, (int)m)) { L.mv[ri[q]] = v; s_chg = 1; }     // jump along an interior link
-        }
-        __syncthreads();
-        if (!s_chg) break;
-    }
-    bool news = false;
-#pragma unroll
-    for (int q = 0; q < CM_CELLS_PER_THREAD; q++) {
-        const int r = ri[q];
-        if (L.occ[r] < 0) continue;
-        unsigned st = L.mv[r];
-        if (st < (unsigned)L.RC) st = CM_MV_UNKNOWN;                     // ends at a mover of another tile that is not decided yet
-        if (st != mv0[q]) {
-            news = true;
-            const int ly = r / S, lx = r - ly * S;
-            C.mv[(y0 + ly) * W.w + x0 + lx] = st;
-        }
-    }
-    if (news && flag >= 0) W.counters[flag] = 1;
-}
-
-// ---- the move phase committed over one tile (move_commit_body + repaint_body): every interior cell learns its occupant after the phase,
-// every interior mover its new position or what it bumped into
-// (the occupancy after the phase goes to a SECOND map, occ_next -- neighbouring tiles are still reading this one; the host swaps the two)
-__global__ void __launch_bounds__(CM_THREADS) k_cm_commit(WorldView W, CellWorld C, const GroupDev *gtab, const TypeDev *ttab, int H, int *occ_next) {
-    if (step_open(W)) return;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const CmMove L = cm_move_layout(smem, H);
-    __shared__ float s_typehp[MAXG];
-    const int tid = threadIdx.x, S = L.S;
-    const int x0 = blockIdx.x * CM_TILE - H, y0 = blockIdx.y * CM_TILE - H;
-    if (tid < MAXG) s_typehp[tid] = tid < W.G ? ttab[tid].hp : 1.0f;
-    cm_move_region(W, C, ttab, L, x0, y0, true);
-#pragma unroll
-    for (int q = 0; q < CM_CELLS_PER_THREAD; q++) {
-        const int ci = q * CM_THREADS + tid;
-        const int ly = ci / CM_TILE, lx = ci - ly * CM_TILE;
-        const int r = (ly + H) * S + lx + H;
-        const int gx = x0 + lx + H, gy = y0 + ly + H;
-        if (gx >= W.w || gy >= W.h) continue;
-        const int c = gy * W.w + gx;
-        const int o = L.occ[r];
-        // ---- the mover standing here: its new position, or the collide bookkeeping of a failed move (Map.cc:334-353)
-        bool leaves = false;
-        if (o >= 0 && L.tgt[r] >= 0) {
-            const int t = L.tgt[r];
-            const GroupDev &G = gtab[ref_group(o)];
-            const int i = ref_index(o);
-            if (L.mv[r] == MV_OK) {
-                leaves = true;
-                const int tly = t / S, tlx = t - tly * S;
-                G.x[i] = x0 + tlx; G.y[i] = y0 + tly;
-            } else {
-                const int to = L.occ[t];
-                int blocker;
-                if (to == OCC_EMPTY) blocker = L.occ[(int)(unsigned)L.win[t]];     // lost an empty cell to the lowest key
-                else {
-                    const bool left_before = L.mv[t] == MV_OK && L.key[t] < L.key[r];
-                    blocker = left_before ? L.occ[(int)(unsigned)L.win[t]] : to;
-                }
-                G.last_op[i] = OP_COLLIDE;
-                G.op_obj[i] = blocker;
-            }
-        }
-        // ---- the cell after the phase: its static winner if that one succeeds, else whoever stood here and stays, else nothing
-        int now = o;
-        float hp = L.hp[r];
-        const unsigned long long wv = L.win[r];
-        if (wv != ~0ull && L.mv[(int)(unsigned)wv] == MV_OK) { now = L.occ[(int)(unsigned)wv]; hp = L.hp[(int)(unsigned)wv]; }
-        else if (leaves) now = OCC_EMPTY;
-        occ_next[c] = now;
-        if (o == OCC_WALL) continue;
-        if (W.live_paint) {
-            if (now >= 0) vc_store(W, c, ref_group(now), __float_as_uint(__fdiv_rn(hp, s_typehp[ref_group(now)])));
-            else if (now != o) vc_store(W, c, OCC_EMPTY, 0u);
-        }
-    }
-}
-
-size_t cm_attack_lds(int H) { const size_t RC = (size_t)(CM_TILE + 2 * H) * (CM_TILE + 2 * H); return RC * (4 * 5 + 4 + 2) + 16; }
-size_t cm_move_lds(int H) { const size_t RC = (size_t)(CM_TILE + 2 * H) * (CM_TILE + 2 * H); return RC * (8 + 4 * 6) + 16; }
-static dim3 cm_grid(const WorldView &W) { return dim3((W.w + CM_TILE - 1) / CM_TILE, (W.h + CM_TILE - 1) / CM_TILE); }
-void launch_cm_scatter(hipStream_t s, const WorldView &W, const CellWorld &C, const int *rank, const ShuffleBufs &B, int n_drawn) {
-    hipLaunchKernelGGL(k_cm_scatter, grid_all(W, 256), dim3(256), 0, s, W, C, rank, B.head, B.first, n_drawn);
-}
-void launch_cm_attack(hipStream_t s, const WorldView &W, const CellWorld &C, const TypeDev *ttab, int H, int n_off, int flag) {
-    hipLaunchKernelGGL(k_cm_attack, cm_grid(W), dim3(CM_THREADS), cm_attack_lds(H), s, W, C, ttab, H, n_off, flag);
-}
-void launch_cm_apply(hipStream_t s, const WorldView &W, const CellWorld &C, const TypeDev *ttab) {
-    hipLaunchKernelGGL(k_cm_apply, grid_all(W, 256), dim3(256), 0, s, W, C, ttab);
-}
-void launch_cm_move(hipStream_t s, const WorldView &W, const CellWorld &C, const TypeDev *ttab, int H, int flag) {
-    hipLaunchKernelGGL(k_cm_move, cm_grid(W), dim3(CM_THREADS), cm_move_lds(H), s, W, C, ttab, H, flag);
-}
-void launch_cm_commit(hipStream_t s, const WorldView &W, const CellWorld &C, const GroupDev *gtab, const TypeDev *ttab, int H, int *occ_next) {
-    hipLaunchKernelGGL(k_cm_commit, cm_grid(W), dim3(CM_THREADS), cm_move_lds(H), s, W, C, gtab, ttab, H, occ_next);
-}
-bool cm_allow_lds(int Ha, int Hm) {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_attack), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cm_attack_lds(Ha)) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_move), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cm_move_lds(Hm)) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm_commit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cm_move_lds(Hm)) == hipSuccess;
-}
-
 // ================================================================================================ repeated set_action: the literal loop
 // GridWorld::set_action APPENDS to the step's action lists (GridWorld.cc:403-454): a group that is given actions twice before a step
 // has every agent act twice -- two entries in the shuffled attack list, two moves in list order, the second from wherever the first
@@ -3458,9 +2988,9 @@ void launch_set_counter(hipStream_t s, int *counters, int index, int value, int 
 }
 
 // hit bits live in the (then unused) claim array of the move phase
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits, int n_drawn) {
-    if (clear_hitbits) (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);   // (else k_shuffle_draw / k_shuffle_chase did it)
-    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim, B.head, B.first, n_drawn);
+void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits) {
+    if (clear_hitbits) (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);   // (else k_shuffle_draw did it)
+    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim, B.head, B.first);
 }
 static int att_threads(int kmax) {
     static const int forced = getenv("MAGENT_ATT_THREADS") ? atoi(getenv("MAGENT_ATT_THREADS")) : 0;

@@ -100,19 +100,6 @@ struct BatchItem {
     SoloStep S;
     RenderMulti M;
 };
-// the cell-major arrays of the LDS-tiled attack / move phases (kernels.hip: k_cm_*): one record per map cell
-struct CellRec { unsigned act; unsigned key; float hp; int dr; };   // the occupant's pending action, rank (attack) or order key (move), hp at phase start, death rank
-struct CellOut { float hp; unsigned out; };                         // hp after the attack phase (then after the step), what the occupant's own attack came to
-struct CellWorld { CellRec *rec; CellOut *out; unsigned *mv; };
-size_t cm_attack_lds(int H);
-size_t cm_move_lds(int H);
-bool cm_allow_lds(int Ha, int Hm);
-struct ShuffleBufs;
-void launch_cm_scatter(hipStream_t s, const WorldView &W, const CellWorld &C, const int *rank, const ShuffleBufs &B, int n_drawn);
-void launch_cm_attack(hipStream_t s, const WorldView &W, const CellWorld &C, const TypeDev *ttab, int H, int n_off, int flag);
-void launch_cm_apply(hipStream_t s, const WorldView &W, const CellWorld &C, const TypeDev *ttab);
-void launch_cm_move(hipStream_t s, const WorldView &W, const CellWorld &C, const TypeDev *ttab, int H, int flag);
-void launch_cm_commit(hipStream_t s, const WorldView &W, const CellWorld &C, const GroupDev *gtab, const TypeDev *ttab, int H, int *occ_next);
 // one set_action call of a step in which some group was given actions more than once (k_step_serial)
 struct SerialCall { int g; const int *actions; };
 void launch_step_serial(hipStream_t s, const WorldView &W, const SerialCall *calls, int n_calls, int2 *alist, int4 *mlist, int4 *msorted, int n_sep);
@@ -136,9 +123,7 @@ void launch_set_rng(hipStream_t s, int *counters, unsigned x);
 void launch_step_reset(hipStream_t s, int *counters);
 void launch_set_counter(hipStream_t s, int *counters, int index, int value, int unless_index);
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits, int n_drawn = -1);
-void launch_shuffle_ahead(hipStream_t s, int n_entries, const int *counters, const ShuffleBufs &B, const unsigned *powtab);
-void launch_shuffle_chase(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell);
+void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits);
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);
 void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag);

@@ -87,9 +87,8 @@ def test_emulated_battle_render_kernels(emu, knobs):
 
 def test_emulated_large_world_drivers(emu):
     """the multi-launch step of large worlds forced onto small ones (MAGENT_SOLO_STEP=0, block scans from 100 agents on): the
-    single-sync driver, its continuation when the optimistic attack rounds run out, the minimap made by clear_dead's own
-    launches, the shuffle draws made a step ahead (MAGENT_DRAW_AHEAD=2) and the cell-major, LDS-tiled attack / move phases
-    (MAGENT_CELL_STEP=2, tiles in scrambled order) -- the last two are off by default: measured slower on the MI355X"""
+    single-sync driver, its continuation when the optimistic attack / move rounds run out, the minimap made by k_minimap instead of
+    clear_dead's own launches; workgroups in scrambled order"""
     code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import helpers as H\n"
             "emu = H.ensure_emu()\n"
@@ -99,9 +98,9 @@ def test_emulated_large_world_drivers(emu):
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
     base = {"MAGENT_SOLO_STEP": "0", "MAGENT_SCAN_SOLO_MAX": "100", "OMP_NUM_THREADS": "1"}
     wide = "battle_brawl,battle_brawl_dense_big,battle_largemap_odd,gather_largemap,battle_grow,battle_events,tri_rect,bodies,forest"
-    tiled = "battle_brawl,battle_largemap_odd,gather_largemap,battle_grow"        # (games the tiled phases take, several tiles)
-    for extra, names in (({}, wide), ({"MAGENT_DRAW_AHEAD": "2", "MAGENT_OPT_ATTACK_PAIRS": "0"}, tiled), ({"MAGENT_FOLD_MINIMAP": "0"}, tiled),
-                         ({"MAGENT_CELL_STEP": "2", "HIPEMU_SCRAMBLE": "3"}, tiled + ",battle_brawl_dense_big"),
-                         ({"MAGENT_CELL_STEP": "2", "MAGENT_OPT_MOVE_BATCHES": "0", "MAGENT_OPT_ATTACK_PAIRS": "0", "HIPEMU_SCRAMBLE": "11"}, tiled)):
+    plain = "battle_brawl,battle_largemap_odd,gather_largemap,battle_grow"        # (one-cell bodies, large_map_mode among them)
+    for extra, names in (({}, wide), ({"MAGENT_OPT_ATTACK_PAIRS": "0"}, plain), ({"MAGENT_FOLD_MINIMAP": "0"}, plain),
+                         ({"HIPEMU_SCRAMBLE": "3"}, plain + ",battle_brawl_dense_big"),
+                         ({"MAGENT_OPT_MOVE_BATCHES": "0", "MAGENT_OPT_ATTACK_PAIRS": "0", "HIPEMU_SCRAMBLE": "11"}, plain)):
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EMU_SCENARIOS=names, **base, **extra), capture_output=True, text=True, timeout=900)
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])

@@ -98,10 +98,6 @@ VARIANTS = {
     "render_fast": {"MAGENT_RENDER_FAST": "1"},
     "render_sweep": {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "5"},
     "render_sweep_3strips": {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "2", "MAGENT_RENDER_SU": "3", "MAGENT_RENDER_DEPTH": "3"},
-    # the cell-major, LDS-tiled attack / move phases (off by default: measured slower) and the shuffle draws a step ahead (ditto)
-    "cell_step": {"MAGENT_CELL_STEP": "2", "MAGENT_SOLO_STEP": "0"},
-    "cell_step_runs_out": {"MAGENT_CELL_STEP": "2", "MAGENT_SOLO_STEP": "0", "MAGENT_OPT_ATTACK_PAIRS": "0"},
-    "draw_ahead": {"MAGENT_DRAW_AHEAD": "2", "MAGENT_SOLO_STEP": "0"},
 }
 
 

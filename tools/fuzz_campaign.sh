@@ -8,7 +8,6 @@ run FUZZ_TURN=2 python tools/fuzz_parity.py oracle hip 0 500
 run FUZZ_RULES=2 python tools/fuzz_parity.py oracle hip 0 400
 run FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 500
 run FUZZ_BATCH=3 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 200
-run MAGENT_CELL_STEP=2 MAGENT_SOLO_STEP=0 python tools/fuzz_parity.py oracle hip 2600 3200
-run MAGENT_DRAW_AHEAD=2 MAGENT_SOLO_STEP=0 python tools/fuzz_parity.py oracle hip 3200 3500
+run MAGENT_SOLO_STEP=0 MAGENT_OPT_ATTACK_PAIRS=0 python tools/fuzz_parity.py oracle hip 2600 3200
 run MAGENT_RENDER_FAST=4 MAGENT_RENDER_SWEEP=3 python tools/fuzz_parity.py oracle hip 3500 3900
 run MAGENT_RENDER_FAST=1 python tools/fuzz_parity.py oracle hip 3900 4200
