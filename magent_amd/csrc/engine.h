@@ -103,7 +103,11 @@ struct GroupDev {
     int *dir;                    // turn_mode: the way the agent faces (null when turn_mode is off: everybody faces north)
     unsigned *key;               // attack: sequence number -> rank after the shuffle; move: order key
     int *drank_a, *drank_b;      // attack fixed point: rank at which the agent dies (ping-pong)
-    unsigned *mv;                // move resolution status / dependency
+    unsigned *mv;                // move resolution status / dependency (generic step); hp after the attack phase, as float bits (every step)
+    // the fused step of plain games (kernels.hip: k_strike and friends): the cell a move is aimed at (-1: none; computed beside the
+    // first attack round, kept until the next step cleans the claim word it left there) and the move's status / dependency
+    int *tm;
+    unsigned *ms;
     int *hits;                   // reward rules: number of rule hits received as the object of an event
     // food_mode scratch of the attack phase: what my attack eats (-1 = it eats nothing), written by the owner of the
     // food; the cell on which I was killed and what is left of the food there (-1 = none)
@@ -116,6 +120,7 @@ struct WorldView {
     int *occ;
     int2 *viewcell;
     unsigned long long *claim;
+    unsigned *hitbits;           // per cell: one bit per (attacker group, attack offset) that hits it in this step's attack phase
     const int2 *delta;
     const unsigned char *mask;
     int *counters;               // CTR_* below: changed flag, attack count, dead_ct per group, gates, rule triggers
@@ -131,6 +136,7 @@ struct WorldView {
     int reach;                   // turn_mode: how far (in cells, per axis) the top-left cell of a body can be from a cell its move or turn enters
     int vc_packed;               // viewcell holds one 32-bit word per cell (<= 3 groups, no goals), else an int2
     int live_paint;              // the step keeps `viewcell` current itself (vacated cells, then every live agent's body)
+    int plain;                   // one-cell bodies, no turn_mode / food_mode / goals / kill_supply: the games the fused step takes
 };
 
 // What a step reports to the host.  The one-launch step (k_step_solo) writes it straight into pinned host memory and

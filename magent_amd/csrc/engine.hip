@@ -859,7 +859,7 @@ void Env::free_group(HostGroup &g) {
     dfree(arena, c.x); dfree(arena, c.y); dfree(arena, c.id); dfree(arena, c.last_action); dfree(arena, c.op_obj); dfree(arena, c.pend); dfree(arena, c.hp);
     dfree(arena, c.next_reward); dfree(arena, c.last_reward); dfree(arena, c.dead); dfree(arena, c.last_op); dfree(arena, c.key); dfree(arena, c.drank_a);
     dfree(arena, c.drank_b); dfree(arena, c.mv); dfree(arena, c.hits); dfree(arena, c.absorbed); dfree(arena, a.absorbed); dfree(arena, c.dir); dfree(arena, a.dir);
-    dfree(arena, c.eat); dfree(arena, c.fleft); dfree(arena, c.fcell);
+    dfree(arena, c.eat); dfree(arena, c.fleft); dfree(arena, c.fcell); dfree(arena, c.tm); dfree(arena, c.ms);
     dfree(arena, a.x); dfree(arena, a.y); dfree(arena, a.id); dfree(arena, a.last_action); dfree(arena, a.hp); dfree(arena, a.next_reward); dfree(arena, a.last_reward);
     g.cap = 0; g.n = 0;
 }
@@ -887,6 +887,9 @@ void Env::ensure_capacity(HostGroup &g, int need) {
     regrow(arena, c.absorbed, n, ncap); regrow(arena, a.absorbed, 0, ncap);
     if (turn_mode) { regrow(arena, c.dir, n, ncap); regrow(arena, a.dir, 0, ncap); }
     regrow(arena, c.eat, 0, ncap); regrow(arena, c.fleft, 0, ncap); regrow(arena, c.fcell, 0, ncap);   // attack-phase scratch (food_mode)
+    // the fused step's move targets: -1 wherever no step has written (k_attack_eval cleans the claim word of every target it finds)
+    regrow(arena, c.tm, n, ncap); regrow(arena, c.ms, 0, ncap);
+    HIP_OK(hipMemset(c.tm + n, 0xFF, sizeof(int) * (ncap - n)));
     regrow(arena, a.x, 0, ncap); regrow(arena, a.y, 0, ncap); regrow(arena, a.id, 0, ncap); regrow(arena, a.last_action, 0, ncap);
     regrow(arena, a.hp, 0, ncap); regrow(arena, a.next_reward, 0, ncap); regrow(arena, a.last_reward, 0, ncap);
     g.cap = (int)ncap;
@@ -896,7 +899,7 @@ void Env::ensure_capacity(HostGroup &g, int need) {
 WorldView Env::view() const {
     WorldView W{};
     W.w = width; W.h = height; W.G = (int)groups.size();
-    W.occ = d_occ; W.viewcell = d_viewcell; W.claim = d_claim; W.delta = d_delta; W.mask = d_mask; W.counters = d_counters;
+    W.occ = d_occ; W.viewcell = d_viewcell; W.claim = d_claim; W.hitbits = d_hit; W.delta = d_delta; W.mask = d_mask; W.counters = d_counters;
     W.any_kill_supply = any_kill_supply;
     W.any_multicell = any_multicell;
     W.any_absorb = any_absorb;
@@ -907,6 +910,7 @@ WorldView Env::view() const {
     W.reach = map_reach;
     W.vc_packed = (groups.size() <= 3 && !any_absorb) ? 1 : 0;
     W.live_paint = live_paint_now ? 1 : 0;   // (set for the length of a step whose painted map was current at its start)
+    W.plain = (!any_multicell && !turn_mode && !food_mode && !any_absorb && !any_kill_supply) ? 1 : 0;
     for (int g = 0; g < W.G; g++) {
         W.type[g] = groups[g].tdev;
         W.grp[g] = groups[g].cur;
@@ -965,7 +969,7 @@ void Env::reset() {
         map_cells = ncell;
     }
     HIP_OK(hipMemset(d_hit, 0, sizeof(unsigned) * ncell));
-    claim_clean = false;
+    claim_clean = claim_tm_only = false; hit_clean = true;
     if (food_mode && !d_food) HIP_OK(dev_malloc(arena, &d_food, sizeof(float) * 2 * ncell));   // amounts, then the attack phase's scratch
     if (d_food) HIP_OK(hipMemset(d_food, 0, sizeof(float) * 2 * ncell));
     h_occ.assign(ncell, OCC_EMPTY);
@@ -1004,6 +1008,8 @@ void Env::reset() {
         if (t.kill_supply != 0) any_kill_supply = 1;
         total_attack += t.attack.count;
         g.n = 0; g.group_reward = 0; g.acted = false; g.h_dead = 0; g.h_taken = 0; g.indexed = 0;
+        if (g.cur.tm) HIP_OK(hipMemset(g.cur.tm, 0xFF, sizeof(int) * g.cap));   // (the map may have changed its size: no stale move targets)
+        g.tm_high = 0;
     }
     // most hits one target can receive: attack offsets of every group allowed to attack it
     attack_kmax = 1;
@@ -1509,6 +1515,23 @@ void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 
     if (any_multicell) launch_finish(stream, W);   // (the 1x1 move commit already consumed the pending actions)
 }
 
+// The per-cell scratch words (claim, hitbits) as the three step paths want them and leave them:
+//   one-launch step / cycle (0): wants every claim word CLAIM_NONE and every hit word zero; keeps them so
+//   fused step of plain games (1): wants the hit words zero and the claim words either clean or dirty only where some `tm` entry below
+//       its group's tm_high points (those it cleans itself, beside its first attack round); leaves them exactly like that
+//   everything else (2): wants nothing (fills what it needs) and leaves both arrays dirty
+void Env::scratch_for(int path) {
+    const size_t ncell = (size_t)width * height;
+    if (path == 2) { claim_clean = claim_tm_only = hit_clean = false; return; }
+    if (!hit_clean) { HIP_OK(hipMemsetAsync(d_hit, 0, sizeof(unsigned) * ncell, stream)); hit_clean = true; }
+    if (!claim_clean && !(path == 1 && claim_tm_only)) {
+        HIP_OK(hipMemsetAsync(d_claim, 0xFF, sizeof(unsigned long long) * ncell, stream));
+        claim_clean = true;
+    }
+    if (path == 0) claim_tm_only = true;               // (clean is a special case of "dirty only at tm entries")
+    else { claim_clean = false; claim_tm_only = true; }
+}
+
 void Env::step(int *done) {
     step_begin();
     step_end(done);
@@ -1568,7 +1591,7 @@ void Env::step_begin() {
         enqueue_counters();
     } else if (serial_calls_on) {
         // ---------------- some group was given actions more than once: the reference's sequential loops, on the device
-        claim_clean = false;
+        scratch_for(2);
         step_was_fast = true;                    // (reports through the pinned record like the single-sync driver)
         step_live_paint = live_paint_now = false;   // the painted map is rebuilt by the next observation
         serial_step();
@@ -1577,10 +1600,7 @@ void Env::step_begin() {
         step_was_solo = true;
         shuffle_buffers(total_n);
         push_rng();
-        if (!claim_clean) {    // (after a multi-launch step or a reset: once)
-            HIP_OK(hipMemsetAsync(d_claim, 0xFF, sizeof(unsigned long long) * (size_t)width * height, stream));
-            claim_clean = true;
-        }
+        scratch_for(0);        // (fills after a multi-launch step or a reset: once)
         const ShuffleBufs B = shuffle_bufs();
         SoloStep S{};
         S.shead = B.head; S.sfirst = B.first; S.sj = B.j; S.slink = B.link;
@@ -1591,9 +1611,11 @@ void Env::step_begin() {
         ProfScope p(*this, "step");
         launch_step_solo(stream, W, S);
     } else if (fast) {
-        claim_clean = false;
         step_was_fast = true;
         // ---------------- single-sync driver
+        const bool plain = W.plain != 0;       // the fused step (kernels.hip: k_strike ...): four per-agent passes behind the death-rank rounds
+        if (plain) plain_steps++;
+        scratch_for(plain ? 1 : 2);
         {
             const size_t caps = rank_cap + shuf_cap + sums_cap + powtab_cap;
             const bool rng_here = !rng_on_device;
@@ -1605,18 +1627,33 @@ void Env::step_begin() {
         hipStream_t a = beside ? side_stream() : stream;
         {
             ProfScope p(*this, "attack", false, a);
-            launch_shuffle(a, total_n, d_counters, shuffle_bufs(), d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
+            // (the fused step keeps the hit words zero itself -- its attackers wipe the bits they set; otherwise the draw zero-fills them)
+            launch_shuffle(a, total_n, d_counters, shuffle_bufs(), d_rank, plain ? nullptr : d_hit, (size_t)width * height, d_powtab);
             if (overlap_level == 2 && a != stream) { join_side(); a = stream; }
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
             launch_attack_rank(a, W, d_rank, shuffle_bufs(), false);
+            TmHigh H{};
+            for (size_t g = 0; g < groups.size(); g++) H.hi[g] = groups[g].tm_high;
             // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
             // LAST one reports whether anything still moved (one gate for all of them)
             for (int r = 0; r < 2 * pairs; r++)
-                launch_attack_iter(a, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
+                launch_attack_iter(a, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1, plain ? &H : nullptr);
             if (pairs == 0) launch_set_counter(a, d_counters, CTR_OPEN_ATTACK, 1, -1);   // tests: straight to the host
         }
         join_side();      // from here on the world changes: behind every render enqueued so far
+        if (plain) {
+            const bool fuse = !rules_on_host && !stale_events && fused_rules(rule_args.data(), (int)rule_args.size());
+            {
+                ProfScope p(*this, "move");
+                launch_plain_tail(stream, W, d_gtab, d_ttab, fuse ? rule_args.data() : nullptr, (int)rule_args.size());
+            }
+            if (!fuse && !rules_on_host) {
+                ProfScope p(*this, "rules");
+                launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
+            }
+            for (auto &g : groups) g.tm_high = std::max(g.tm_high, g.n);   // (entries below are cleaned by the next fused step)
+        } else {
         {
             ProfScope p(*this, "attack");
             launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
@@ -1638,10 +1675,11 @@ void Env::step_begin() {
             if (!rules_on_host) launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
             if (any_multicell) launch_finish(stream, W);
         }
+        }
         launch_step_report(stream, d_counters, h_rec, ++step_seq, (int)groups.size());
     } else {
         // ---------------- checked driver
-        claim_clean = false;
+        scratch_for(2);
         HIP_OK(hipMemsetAsync(d_counters + CTR_OPEN_ATTACK, 0, 2 * sizeof(int), stream));
         const int A = read_counters()[CTR_ATTACK];
         if (A > 0) {
@@ -1665,7 +1703,7 @@ void Env::step_begin() {
                 rng_on_device = false;
             } else {              // exact parallel replay on the device
                 push_rng();
-                launch_shuffle(stream, total_n, d_counters, shuffle_bufs(), d_rank, (unsigned *)d_claim, (size_t)width * height, d_powtab);
+                launch_shuffle(stream, total_n, d_counters, shuffle_bufs(), d_rank, d_hit, (size_t)width * height, d_powtab);
             }
             launch_attack_rank(stream, W, d_rank, shuffle_bufs(), host_shuffle);
             attack_round = 0;
@@ -1705,6 +1743,7 @@ void Env::step_begin() {
         }
         enqueue_counters();
     }
+    stale_events = true;      // (last_op / op_obj hold this step's events until clear_dead resets them)
     state_epoch++;
 }
 
@@ -1755,6 +1794,7 @@ void Env::step_end(int *done) {
         if (c[CTR_OPEN_ATTACK] | c[CTR_OPEN_MOVE]) {   // continue from exactly the device state the open phase froze, host-checked
             WorldView W = view();
             const int phase = c[CTR_OPEN_ATTACK] ? 1 : 2;
+            scratch_for(2);              // (the continuation runs the unfused kernels, whatever the head of the step was)
             fallback_steps++;
             if (phase == 1) fallback_attack++; else fallback_move++;
             if (phase == 1) boost_attack = 64; else boost_move = 64;   // deeper dependency chains around: one more batch
@@ -1845,10 +1885,7 @@ bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, con
     // ---- launch 2: set_action, step, get_reward, clear_dead, the next minimap
     shuffle_buffers(total_n);
     push_rng();
-    if (!claim_clean) {
-        HIP_OK(hipMemsetAsync(d_claim, 0xFF, sizeof(unsigned long long) * (size_t)width * height, stream));
-        claim_clean = true;
-    }
+    scratch_for(0);
     step_live_paint = live_paint_now = paint_valid;
     W.live_paint = step_live_paint ? 1 : 0;
     const ShuffleBufs B = shuffle_bufs();
@@ -1911,6 +1948,7 @@ void Env::cycle_finish(int *done) {
     }
     *done = live < NG;   // GridWorld.cc:619-624
     for (size_t k = 0; k < rules.size(); k++) if (((r.triggers >> k) & 1ull) && rules[k].terminal) *done = 1;
+    stale_events = false;      // (the cycle's own clear_dead has reset every last_op)
     move_seq_base = 0;
     h_occ_valid = false;
     tables_valid = true;
@@ -2131,6 +2169,7 @@ void Env::clear_dead() {
     // (the death counters of the compacted groups were zeroed by the compaction kernels; the others were zero)
     if (any) { h_occ_valid = false; mini_valid = false; }
     for (auto &G : groups) G.indexed = G.n;   // Agent::set_index (GridWorld.cc:655)
+    stale_events = false;
     if (solo_mini) { mini_valid = true; mini_pop = mini_population(mini_skip); solo_mini = false; }
 }
 
@@ -2158,7 +2197,7 @@ void Env::info_host(int g, const char *name, void *buf) {
         ib[0] = fallback_steps; ib[1] = last_attack_iters; ib[2] = last_move_iters; ib[3] = attack_round;
         ib[4] = fallback_attack; ib[5] = fallback_move;      // (which phase's optimistic rounds ran out)
         ib[6] = last_render_kernel;                          // 0 k_render, 1 k_render_fast, 4 k_render_sweep2
-        ib[7] = 0;                                           // (was: steps through the cell-major phases, removed in round 4)
+        ib[7] = plain_steps;                                 // steps that took the fused passes of plain games (k_strike ...)
         return;
     }
     if (k == "batch_host_us") {  // additive (tuning): host microseconds per env_cycle_many round since the last read:

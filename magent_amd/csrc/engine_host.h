@@ -70,6 +70,7 @@ struct HostGroup {
     int h_dead = 0;              // dead_ct as of the last step (GridWorld.h Group::dead_ct)
     int h_taken = 0;             // movers taken in by goals: dead, but never counted in dead_ct (Map.cc:345)
     int indexed = 0;             // agents [0, indexed) have been through a clear_dead: Agent::index == position, else 0
+    int tm_high = 0;             // leading entries of cur.tm that may point at a claim word a fused step left behind (launch.h: TmHigh)
 };
 
 struct HostSymbol { int group = 0, index = 0; int ent_g = -1, ent_i = -1; };   // ent_*: the agent the host rule search last bound it to
@@ -215,6 +216,11 @@ private:
     int solo_nt_eval = 0;
     unsigned *d_hit = nullptr;            // per cell: hit bits / wanted counters of the one-launch step, zero between phases
     bool claim_clean = false;             // every claim word is CLAIM_NONE (the one-launch step keeps it so)
+    bool claim_tm_only = false;           // ... or dirty only where a `tm` entry below its group's tm_high points (the fused step of plain games)
+    bool hit_clean = false;               // every hit word is zero (both of those steps keep it so)
+    void scratch_for(int path);
+    int plain_steps = 0;
+    bool stale_events = false;            // a step has run since the last clear_dead: last_op / op_obj are not all OP_NULL / -1
     RuleArgs *d_rule_args = nullptr; RuleProg *d_rule_progs = nullptr;
     void shuffle_buffers(int n_max);
     void push_rng();

@@ -1264,15 +1264,43 @@ __device__ __forceinline__ void attack_eval_body(const WorldView &W, const Group
         if (flagp) *flagp = 1;                        // (multi-launch driver: only the last round of a batch reports)
     }
 }
+// (the head of the fused step of plain games rides in round 1: see "the fused step of plain games" below)
+constexpr unsigned MV_DIED = 0xFFFFFFFCu;   // `ms` between k_strike and k_plain_init: killed or starved in this step, still on the map
+
+__device__ __forceinline__ void plain_head_body(const WorldView &W, int g, int i) {
+    const GroupDev &G = W.grp[g];
+    const TypeDev &T = W.type[g];
+    const int told = G.tm[i];
+    if (told >= 0) W.claim[told] = CLAIM_NONE;           // (idempotent: a stale entry cleans a clean word)
+    int t = -1;
+    const int pend = G.pend[i];
+    if (!G.dead[i] && (pend & ~PEND_ARG) == PEND_MOVE) {
+        const int2 d = W.delta[T.move_off + (pend & PEND_ARG)];
+        const int nx = G.x[i] + d.x, ny = G.y[i] + d.y;
+        // is_blank_area bounds (Map.cc:455) for a 1x1 body; a zero move "succeeds" in place and never vacates
+        if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + 1 < W.w && ny + 1 < W.h && W.occ[ny * W.w + nx] != OCC_WALL) t = ny * W.w + nx;
+    }
+    G.tm[i] = t;
+    G.mv[i] = __float_as_uint(G.hp[i]);                  // (attack_eval_body overwrites it for the agents that are hit)
+}
+
 // workgroup size: as large as the hit lists (kmax x threads x 8 B of LDS) allow, see att_threads()
 __global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab, int round,
-                                                     const unsigned *hitbits, int kmax, int flag) {
-    if (W.counters[CTR_ATTACK] == 0) return;
+                                                     const unsigned *hitbits, int kmax, int flag, TmHigh H) {
     extern __shared__ unsigned s_hit[];               // [kmax][ATT_THREADS] ranks, then [kmax][ATT_THREADS] refs
     const int ATT_THREADS = blockDim.x;
     const int g = blockIdx.y, tid = threadIdx.x;
     const int i = blockIdx.x * blockDim.x + tid;
-    if (i >= W.grp[g].n) return;
+    if (i >= W.grp[g].n) {
+        // entries of agents that clear_dead has compacted away since their last fused step: their claim words are cleaned here
+        if (W.plain && round == 1 && i < H.hi[g]) {
+            const int told = W.grp[g].tm[i];
+            if (told >= 0) { W.claim[told] = CLAIM_NONE; W.grp[g].tm[i] = -1; }
+        }
+        return;
+    }
+    if (W.plain && round == 1) plain_head_body(W, g, i);   // (rides here: this launch visits every agent of every step, attacks or not)
+    if (W.counters[CTR_ATTACK] == 0) return;
     attack_eval_body(W, gtab, ttab, g, i, round, hitbits, s_hit, (int *)(s_hit + kmax * ATT_THREADS), ATT_THREADS, tid,
                      flag >= 0 ? &W.counters[flag] : nullptr, kmax);
 }
@@ -1573,6 +1601,182 @@ __global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev
     if (i >= W.grp[g].n) return;
     move_commit_body(W, gtab, g, i);
     if (W.live_paint) repaint_body(W, W.grp[g], W.type[g], g, i);
+}
+
+// ------------------------------------------------------------------------------------------------ the fused step of plain games
+// Plain games -- one-cell bodies, no turn_mode / food_mode / goals / kill_supply: battle, gather, every BASELINE configuration but the
+// reference's own 1M harness -- step through FOUR per-agent passes behind the death-rank rounds instead of eight:
+//   (beside round 1 of k_attack_eval)  plain_head_body: the cell my move is aimed at (`tm`), my hp as the attack phase will leave it
+//                                      unless somebody hits me (`mv`), and the claim word my LAST step's move left behind cleaned
+//   k_strike     what k_attack_apply, starve_body, k_rule (rules that pay the subject), k_move_prep and k_move_claim did in five
+//                launches: every agent finishes its own attack phase from the converged death ranks, starves / recovers, is paid by
+//                the rules, and claims its target cell.  Nobody writes the map in this pass, so everybody still finds targets and
+//                occupants through the phase-start map; whether an occupant is still there when the moves begin -- it may have been
+//                killed, or starve -- is decided by the claimant from the occupant's death rank and `mv` (what starve_body would do
+//                with it).  Attackers wipe the hit bit they set: the hit words are zero again when the pass ends.
+//   k_plain_init who won its cell, and on whom its move depends (k_move_init, without the map lookup: k_strike saved what it saw);
+//                the agents that died in this step leave the map here, after its last reader
+//   k_plain_commit  k_move_commit on `tm` / `ms`
+// The claim words are cleaned by their owners (plain_head_body, k_clear_compact) and the hit words by the attackers: no per-cell pass
+// is left in the step -- at BASELINE config 5's 3536 x 3536 cells the two fills were 150 MB per step.  The host keeps track of who
+// left the words in which state (engine.hip: claim_clean / claim_tm_only / hit_clean).
+// rules of the shape Event(a, attack | kill, b) that pay receivers bound to `a` only: evaluated by the agent itself, in rule order,
+// as soon as its own attack is known -- provided every last_op was OP_NULL when the step began (clear_dead has run since the last step:
+// otherwise an event of the LAST step is paid again unless a collision overwrites it, which only the move phase knows; the host then
+// runs k_rule behind the commit as before)
+struct StrikeRules {
+    int n;
+    struct One { int ga, gb, op, rule_no, n_subj; float v[4]; } r[4];
+};
+
+__global__ void __launch_bounds__(256) k_strike(WorldView W, const GroupDev *gtab, const TypeDev *ttab, StrikeRules R) {
+    if (attack_open(W)) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const GroupDev &G = W.grp[g];
+    const TypeDev &T = W.type[g];
+    const bool attacked = W.counters[CTR_ATTACK] != 0;
+    bool died = false;
+    unsigned trig = 0;
+    if (i < G.n) {
+        const int pend = G.pend[i];
+        if (pend != PEND_NONE) G.last_action[i] = pend_action(pend, T);     // Agent::set_action's `last_action = act` (see k_set_action_a)
+        bool dead = G.dead[i];
+        const int x = G.x[i], y = G.y[i];
+        float hp = __uint_as_float(G.mv[i]);             // hp after the attack phase (plain_head_body / the last evaluation)
+        float nr = G.next_reward[i];
+        int last_op = OP_NULL, op_obj = -1;              // (what clear_dead left: with rules fused, the host has seen it run since the last step)
+        // ---- the attack phase applied from the converged death ranks (attack_apply_body, one-cell bodies, no supply)
+        if (attacked && !dead) {
+            const int dr = G.drank_a[i];
+            if ((pend & ~PEND_ARG) == PEND_ATTACK) {
+                const unsigned my_rank = G.key[i];
+                const int2 tc = attack_target(W, G, T, i, pend & PEND_ARG);
+                int tgt = -1, tgt_dr = RANK_INF;
+                if (tc.x >= 0 && tc.x < W.w && tc.y >= 0 && tc.y < W.h) {
+                    const int o = W.occ[tc.y * W.w + tc.x];
+                    if (o >= 0 && (T.attack_in_group || ref_group(o) != g)) {
+                        tgt = o;
+                        tgt_dr = gtab[ref_group(o)].drank_a[ref_index(o)];
+                        W.hitbits[tc.y * W.w + tc.x] = 0u;                   // my bit, and the word's other setters do the same
+                    }
+                }
+                if ((unsigned)dr >= my_rank) {               // alive at my turn (GridWorld.cc:479-480)
+                    float own;
+                    if (tgt < 0 || (unsigned)tgt_dr < my_rank) own = T.attack_penalty;   // blank, or the target died before my turn (Map.cc:229-231)
+                    else {
+                        float reward = 0.0f;
+                        if ((unsigned)tgt_dr == my_rank) { last_op = OP_KILL; reward = ttab[ref_group(tgt)].kill_reward; }
+                        else last_op = OP_ATTACK;
+                        op_obj = tgt;
+                        G.last_op[i] = (unsigned char)last_op; G.op_obj[i] = tgt;
+                        own = reward + T.attack_penalty;     // add_reward(reward + attack_penalty) (GridWorld.cc:505)
+                    }
+                    nr += own;
+                }
+            }
+            if (dr != RANK_INF) { dead = died = true; nr = T.dead_penalty; }   // dead_penalty overwrites what was accumulated (GridWorld.h:207)
+        }
+        // ---- starve / recover (GridWorld.cc:519-542)
+        if (!dead) {
+            if (T.step_recover > 0) hp = fminf(T.hp, hp + T.step_recover);
+            else {
+                hp -= -T.step_recover;
+                if (hp < 0.0f) { dead = died = true; nr = T.dead_penalty; }
+            }
+        }
+        G.hp[i] = hp;
+        if (died) G.dead[i] = 1;
+        // ---- calc_reward for the rules that pay their subject (rule_body; the reference visits the dead too, GridWorld.cc:681-692)
+        for (int k = 0; k < R.n; k++) {
+            if (R.r[k].ga != g) continue;
+            if (op_obj >= 0 && ref_group(op_obj) == R.r[k].gb && last_op == R.r[k].op) {
+                trig |= 1u << k;
+                for (int q = 0; q < R.r[k].n_subj; q++) nr += R.r[k].v[q];
+            }
+        }
+        G.next_reward[i] = nr;
+        // ---- my move: the claim on its target cell (move_prep_body + move_claim_body)
+        unsigned ms = died ? MV_DIED : MV_FAIL;
+        if (!dead && (pend & ~PEND_ARG) == PEND_MOVE) {
+            const int c = G.tm[i];
+            if (c >= 0) {
+                const unsigned key = G.key[i];
+                int o = W.occ[c];
+                bool ok = o == OCC_EMPTY;
+                if (o >= 0) {
+                    const GroupDev O = gtab[ref_group(o)];
+                    const int oi = ref_index(o);
+                    const float orec = ttab[ref_group(o)].step_recover;
+                    bool gone = attacked && O.drank_a[oi] != RANK_INF;                          // killed in this step's attack phase
+                    if (!gone && !(orec > 0)) gone = __uint_as_float(O.mv[oi]) - (-orec) < 0.0f;   // ... or about to starve
+                    if (gone) { ok = true; o = OCC_EMPTY; }                                      // the cell is empty when the moves begin
+                    else ok = O.tm[oi] >= 0 && O.key[oi] < key;                                  // the occupant may leave, and before my turn
+                }
+                G.drank_b[i] = o;            // what my target cell holds when the moves begin, for k_plain_init / k_plain_commit
+                if (ok) atomicMin(&W.claim[c], ((unsigned long long)key << 32) | (unsigned)ref_pack(g, i));
+            }
+        }
+        G.ms[i] = ms;
+    }
+    int wtot;
+    wave_rank(died, wtot);
+    if (wtot && lane_id() == 0) atomicAdd(&W.counters[dead_slot(g, blockIdx.x % DEAD_SLOTS)], wtot);
+    for (int k = 0; k < R.n; k++)
+        if (__ballot((trig >> k) & 1u) && lane_id() == 0) W.counters[CTR_TRIGGER + R.r[k].rule_no] = 1;
+}
+
+__global__ void __launch_bounds__(256) k_plain_init(WorldView W) {
+    if (attack_open(W)) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const GroupDev &G = W.grp[g];
+    if (i >= G.n) return;
+    const unsigned ms = G.ms[i];
+    if (ms == MV_DIED) {                         // Map::remove_agent (Map.cc:272, GridWorld.cc:536): nobody reads the map in this launch
+        cells_clear(W, G.x[i], G.y[i], 1, 1);
+        G.ms[i] = MV_FAIL;
+        return;
+    }
+    const int c = G.tm[i];
+    if (c < 0 || G.dead[i]) return;
+    if ((unsigned)W.claim[c] != (unsigned)ref_pack(g, i)) return;   // not the static winner (or no claim of mine): stays MV_FAIL
+    const int o = G.drank_b[i];
+    G.ms[i] = o == OCC_EMPTY ? MV_OK : (unsigned)o;                 // succeeds iff the occupant o succeeds
+}
+
+__device__ __forceinline__ unsigned plain_resolve(const GroupDev *gtab, unsigned m) {
+    while (m < MV_DIED) m = gtab[ref_group((int)m)].ms[ref_index((int)m)];
+    return m;
+}
+// (move_commit_body on `tm` / `ms`: see there)
+__global__ void __launch_bounds__(256) k_plain_commit(WorldView W, const GroupDev *gtab) {
+    if (attack_open(W)) return;
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const GroupDev &G = W.grp[g];
+    if (i >= G.n) return;
+    const int c = G.tm[i];
+    if (c >= 0 && !G.dead[i]) {
+        if (plain_resolve(gtab, G.ms[i]) == MV_OK) {
+            const int old = G.y[i] * W.w + G.x[i];
+            if (W.claim[old] == CLAIM_NONE) { W.occ[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }
+            W.occ[c] = ref_pack(g, i);
+            const int ny = c / W.w;
+            G.x[i] = c - ny * W.w; G.y[i] = ny;
+        } else {
+            const int o = G.drank_b[i];
+            int blocker;
+            if (o == OCC_EMPTY) blocker = (int)(unsigned)W.claim[c];       // lost an empty cell to the lowest key
+            else {
+                const GroupDev O = gtab[ref_group(o)];
+                const int oi = ref_index(o);
+                const bool left_before = plain_resolve(gtab, O.ms[oi]) == MV_OK && O.key[oi] < G.key[i];
+                blocker = left_before ? (int)(unsigned)W.claim[c] : o;
+            }
+            G.last_op[i] = OP_COLLIDE;
+            G.op_obj[i] = blocker;
+        }
+    }
+    G.pend[i] = PEND_NONE;   // end of step: pending actions are consumed
+    if (W.live_paint) repaint_body(W, G, W.type[g], g, i);
 }
 
 // ------------------------------------------------------------------------------------------------ move, generic bodies
@@ -2987,10 +3191,10 @@ void launch_set_counter(hipStream_t s, int *counters, int index, int value, int 
     hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(64), 0, s, counters, index, value, unless_index);
 }
 
-// hit bits live in the (then unused) claim array of the move phase
+// (the hit bits have an array of their own, WorldView::hitbits -- until round 4 they shared the move phase's claim words)
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits) {
-    if (clear_hitbits) (void)hipMemsetAsync(W.claim, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);   // (else k_shuffle_draw did it)
-    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, (unsigned *)W.claim, B.head, B.first);
+    if (clear_hitbits) (void)hipMemsetAsync(W.hitbits, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);   // (else k_shuffle_draw did it, or the fused step keeps them zero)
+    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, W.hitbits, B.head, B.first);
 }
 static int att_threads(int kmax) {
     static const int forced = getenv("MAGENT_ATT_THREADS") ? atoi(getenv("MAGENT_ATT_THREADS")) : 0;
@@ -3004,24 +3208,30 @@ bool attack_lds_ok(int kmax) {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_attack_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void *>(k_food_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
 }
-void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag) {
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag, const TmHigh *tm_high) {
     const int ATT_THREADS = att_threads(kmax);
     size_t lds = (size_t)kmax * ATT_THREADS * 8;
-    hipLaunchKernelGGL(k_attack_eval, grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, round, (const unsigned *)W.claim, kmax, flag);
+    TmHigh H{};
+    dim3 grid = grid_all(W, ATT_THREADS);
+    if (tm_high && round == 1) {
+        H = *tm_high;
+        for (int g = 0; g < W.G; g++) grid.x = std::max<unsigned>(grid.x, (unsigned)((H.hi[g] + ATT_THREADS - 1) / ATT_THREADS));
+    }
+    hipLaunchKernelGGL(k_attack_eval, grid, dim3(ATT_THREADS), lds, s, W, gtab, ttab, round, (const unsigned *)W.hitbits, kmax, flag, H);
     if (W.food_mode) launch_food_iter(s, W, gtab, ttab, round, kmax, flag);   // the food cells are part of the same fixed point
 }
 void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag) {
     const int NT = att_threads(kmax);
     hipLaunchKernelGGL(k_food_eval, dim3((W.w * W.h + NT - 1) / NT), dim3(NT), (size_t)kmax * NT * 8, s, W, gtab, ttab, round,
-                       (const unsigned *)W.claim, kmax, flag);
+                       (const unsigned *)W.hitbits, kmax, flag);
 }
 void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev) {
     hipLaunchKernelGGL(k_attack_events, grid_all(W, 256), dim3(256), 0, s, W, ev);
 }
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax) {
     (void)kmax;
-    hipLaunchKernelGGL(k_attack_apply, grid_all(W, 256), dim3(256), 0, s, W, gtab, ttab, (const unsigned *)W.claim);
-    if (W.food_mode) hipLaunchKernelGGL(k_food_apply, dim3((W.w * W.h + 255) / 256), dim3(256), 0, s, W, (const unsigned *)W.claim);
+    hipLaunchKernelGGL(k_attack_apply, grid_all(W, 256), dim3(256), 0, s, W, gtab, ttab, (const unsigned *)W.hitbits);
+    if (W.food_mode) hipLaunchKernelGGL(k_food_apply, dim3((W.w * W.h + 255) / 256), dim3(256), 0, s, W, (const unsigned *)W.hitbits);
 }
 
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
@@ -3059,6 +3269,29 @@ void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) 
     hipLaunchKernelGGL(k_movg_vacate, g, dim3(256), 0, s, W);
     hipLaunchKernelGGL(k_movg_enter, g, dim3(256), 0, s, W);
 }
+// the fused step of plain games behind the death-rank rounds: k_strike, k_plain_init, k_plain_commit.  `rules`: the compiled rules, if
+// every one of them pays the subject of one event only (fused_rules); else null, and launch_rules runs behind the commit as usual
+bool fused_rules(const RuleArgs *rules, int n) {
+    if (n > 4) return false;
+    // (attack-phase events only: `collide` is decided by the move phase, behind k_strike)
+    for (int k = 0; k < n; k++) if (rules[k].pair || rules[k].prog >= 0 || rules[k].n_obj || (rules[k].op != OP_ATTACK && rules[k].op != OP_KILL)) return false;
+    return true;
+}
+void launch_plain_tail(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, const RuleArgs *rules, int n_rules) {
+    StrikeRules R{};
+    if (rules) {
+        R.n = n_rules;
+        for (int k = 0; k < n_rules; k++) {
+            R.r[k].ga = rules[k].ga; R.r[k].gb = rules[k].gb; R.r[k].op = rules[k].op; R.r[k].rule_no = rules[k].rule_no; R.r[k].n_subj = rules[k].n_subj;
+            for (int q = 0; q < 4; q++) R.r[k].v[q] = rules[k].v_subj[q];
+        }
+    }
+    dim3 g = grid_all(W, 256);
+    hipLaunchKernelGGL(k_strike, g, dim3(256), 0, s, W, gtab, ttab, R);
+    hipLaunchKernelGGL(k_plain_init, g, dim3(256), 0, s, W);
+    hipLaunchKernelGGL(k_plain_commit, g, dim3(256), 0, s, W, gtab);
+}
+
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
     dim3 g = grid_all(W, 256);
     hipLaunchKernelGGL(k_move_commit, g, dim3(256), 0, s, W, gtab);

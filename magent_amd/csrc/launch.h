@@ -124,8 +124,14 @@ void launch_step_reset(hipStream_t s, int *counters);
 void launch_set_counter(hipStream_t s, int *counters, int index, int value, int unless_index);
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits);
-void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */);
+// per group: how many leading entries of `tm` may still point at a claim word their move left behind (the fused step of plain games
+// cleans them beside its first attack round; entries beyond the group's current size belong to agents clear_dead has compacted away)
+struct TmHigh { int hi[MAXG]; };
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */,
+                        const TmHigh *tm_high = nullptr);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);
+bool fused_rules(const RuleArgs *rules, int n);
+void launch_plain_tail(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, const RuleArgs *rules /* null: not fused */, int n_rules);
 void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag);
 void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev);
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);   // starve / recover, then the move candidates

@@ -349,7 +349,7 @@ class Scenario(object):
                 self.populate(env, ev[1], 0)
 
 
-def run(sc, lib, record=None, device_io=False):
+def run(sc, lib, record=None, device_io=False, env_out=None):
     """Play scenario `sc` on library `lib`; returns list (one dict per step) of every observable output.
 
     Order of calls per step follows examples/train_battle.py:61-109: get_observation + set_action per group,
@@ -359,6 +359,8 @@ def run(sc, lib, record=None, device_io=False):
     tensors allocated ONCE for the initial population, env_set_action_device from a device tensor, env_get_reward_device --
     instead of the host-buffer reference ABI; the arrays are brought to the host only to be recorded."""
     env, handles = sc.build(lib)
+    if env_out is not None:
+        env_out.append(env)        # (the caller wants to look at the engine afterwards: engine_stats)
     rs = np.random.RandomState(sc.action_seed)
     acting = sc.acting if sc.acting is not None else list(range(len(handles)))
     if device_io:

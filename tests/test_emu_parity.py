@@ -104,3 +104,30 @@ def test_emulated_large_world_drivers(emu):
                          ({"MAGENT_OPT_MOVE_BATCHES": "0", "MAGENT_OPT_ATTACK_PAIRS": "0", "HIPEMU_SCRAMBLE": "11"}, plain)):
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EMU_SCENARIOS=names, **base, **extra), capture_output=True, text=True, timeout=900)
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])
+
+
+def test_emulated_fused_step_of_plain_games(emu):
+    """the fused step of plain games (k_strike, k_plain_init, k_plain_commit behind the death-rank rounds; kernels.hip) forced onto
+    small worlds (MAGENT_SOLO_STEP=0), workgroups and lanes in scrambled order: every scenario whose game it takes -- starving occupants
+    whose cell is claimed in the same step (battle_lowhp), skipped clear_dead (stale events are paid again, battle_no_clear),
+    agents and walls added mid-episode and a second episode (battle_events, battle_grow: the claim words are cleaned through `tm`
+    entries that compaction has moved away from), four groups, a group that never acts, rules that pay the object (chase: not fused)
+    or run on the host (rules_search), the run-out continuation from a fused head -- and that the fused passes really ran"""
+    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import helpers as H\n"
+            "emu = H.ensure_emu()\n"
+            "for n in os.environ['EMU_SCENARIOS'].split(','):\n"
+            "    sc = H.scenarios()[n]\n"
+            "    seen = []\n"
+            "    H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, emu, env_out=seen), n)\n"
+            "    assert seen[0].engine_stats()[7] > 0, (n, seen[0].engine_stats())\n"
+            "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    base = {"MAGENT_SOLO_STEP": "0", "MAGENT_SCAN_SOLO_MAX": "100", "OMP_NUM_THREADS": "1"}
+    plain = ("battle_small_dense,battle_brawl,battle_brawl_big,battle60,battle_walls,battle_largemap,battle_largemap_odd,battle_fill_full,"
+             "battle_no_clear,battle_tiny,gather,gather_largemap,battle_lowhp,quad,trans,chase,battle_events,battle_grow,rules_search,battle_second")
+    names = [n for n in plain.split(",") if n in H.scenarios()]
+    assert len(names) >= 19
+    for extra in ({"HIPEMU_SCRAMBLE": "5"}, {"MAGENT_OPT_ATTACK_PAIRS": "0", "HIPEMU_SCRAMBLE": "8"}):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EMU_SCENARIOS=",".join(names), **base, **extra), capture_output=True, text=True,
+                           timeout=1500)
+        assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])
