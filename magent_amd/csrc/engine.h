@@ -170,7 +170,9 @@ constexpr int CTR_OPEN_ATTACK = 10; // the optimistic attack rounds ran out
 constexpr int CTR_OPEN_MOVE = 11;   // the optimistic move rounds ran out
 constexpr int CTR_RNG = 13;         // engine RNG state (minstd_rand0), advanced on the device by the attack shuffle
 constexpr int CTR_LAST_A = 14;      // attack-list length of the last step (host information)
-constexpr int CTR_ATTACK_BASE = 15; // CTR_ATTACK as it was when the current set_action launch began
+// plain games: slot (round & 31) is raised by every agent whose death rank changes in that round of the attack fixed point; a round
+// whose predecessor raised nothing has nothing to do and returns at once (k_attack_eval).  Zero between steps.
+constexpr int CTR_ROUND_CHANGED = 80, ROUND_SLOTS = 32;
 
 // observation render parameters for one get_observation(group) call
 struct RenderArgs {

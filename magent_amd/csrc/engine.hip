@@ -285,7 +285,7 @@ Env::~Env() {
     dfree(arena, d_occ); dfree(arena, d_viewcell); dfree(arena, d_claim); dfree(arena, d_food); dfree(arena, d_powtab); dfree(arena, d_counters); dfree(arena, d_gtab); dfree(arena, d_ttab);
     dfree(arena, d_delta); dfree(arena, d_mask); dfree(arena, d_mini); dfree(arena, d_minif); dfree(arena, d_sums); dfree(arena, d_rank); dfree(arena, d_shuf); dfree(arena, d_events); dfree(arena, d_actions);
     dfree(arena, d_stage_view); dfree(arena, d_stage_feat); dfree(arena, d_stage_small);
-    dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d);
+    dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d); dfree(arena, d_asums); dfree(arena, d_wpre);
     if (batch_h) (void)hipHostFree(batch_h);
     if (h_rec) (void)hipHostFree(h_rec);
     if (pool) {
@@ -1007,7 +1007,7 @@ void Env::reset() {
         g.tdev = d;
         if (t.kill_supply != 0) any_kill_supply = 1;
         total_attack += t.attack.count;
-        g.n = 0; g.group_reward = 0; g.acted = false; g.h_dead = 0; g.h_taken = 0; g.indexed = 0;
+        g.n = 0; g.group_reward = 0; g.acted = false; g.h_dead = 0; g.h_taken = 0; g.indexed = 0; g.sa_off = -1;
         if (g.cur.tm) HIP_OK(hipMemset(g.cur.tm, 0xFF, sizeof(int) * g.cap));   // (the map may have changed its size: no stale move targets)
         g.tm_high = 0;
     }
@@ -1351,13 +1351,29 @@ void Env::set_action_device(int g, const int *d_act) {
         return;
     }
     G.acted = true;
+    if (step_calls.empty()) {           // the first call of a step fixes the form of all of them: worlds that step in one launch take the
+        int total_n = 0;                // one-workgroup form (sequence numbers assigned at once), the others leave tile counts (SeqPlan)
+        for (auto &q : groups) total_n += q.n;
+        step_sa_tiled = !solo_ok(total_n);
+        sa_tiles = 0;
+    }
     step_calls.push_back(g);
     if (G.n == 0) return;
-    int nb = (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
-    if ((size_t)nb > sums_cap) { enter(); grow(arena, d_sums, sums_cap, (size_t)nb, stream); }
+    int off = -1;
+    if (step_sa_tiled) {
+        const int nb = (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
+        off = sa_tiles;
+        sa_tiles += nb;
+        if ((size_t)sa_tiles > asums_cap) {      // (the counts of the step's earlier calls are kept)
+            enter();
+            grow(arena, d_asums, asums_cap, (size_t)sa_tiles, stream, true, (size_t)off);
+            grow(arena, d_wpre, wpre_cap, asums_cap * (SCAN_TILE_HOST / 64), stream, true, (size_t)off * (SCAN_TILE_HOST / 64));
+        }
+    }
+    G.sa_off = off;
     hipStream_t s = action_stream();    // large worlds: beside the observation renders (see side_stream)
     ProfScope p(*this, "set_action", false, s);
-    launch_set_action(s, view(), g, d_act, move_seq_base, d_sums);
+    launch_set_action(s, view(), g, d_act, move_seq_base, d_asums, d_wpre, off);
     move_seq_base += G.n;
 }
 
@@ -1601,6 +1617,8 @@ void Env::step_begin() {
         shuffle_buffers(total_n);
         push_rng();
         scratch_for(0);        // (fills after a multi-launch step or a reset: once)
+        for (size_t g = 0; g < groups.size(); g++)     // (given its actions in tiles, when the world was larger: the numbers written out)
+            if (groups[g].sa_off >= 0) launch_seq_assign(stream, W, (int)g, d_asums, d_wpre, groups[g].sa_off);
         const ShuffleBufs B = shuffle_bufs();
         SoloStep S{};
         S.shead = B.head; S.sfirst = B.first; S.sj = B.j; S.slink = B.link;
@@ -1632,7 +1650,7 @@ void Env::step_begin() {
             if (overlap_level == 2 && a != stream) { join_side(); a = stream; }
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
-            launch_attack_rank(a, W, d_rank, shuffle_bufs(), false);
+            launch_attack_rank(a, W, d_rank, shuffle_bufs(), false, d_asums, d_wpre, seq_plan());
             TmHigh H{};
             for (size_t g = 0; g < groups.size(); g++) H.hi[g] = groups[g].tm_high;
             // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
@@ -1705,7 +1723,7 @@ void Env::step_begin() {
                 push_rng();
                 launch_shuffle(stream, total_n, d_counters, shuffle_bufs(), d_rank, d_hit, (size_t)width * height, d_powtab);
             }
-            launch_attack_rank(stream, W, d_rank, shuffle_bufs(), host_shuffle);
+            launch_attack_rank(stream, W, d_rank, shuffle_bufs(), host_shuffle, d_asums, d_wpre, seq_plan());
             attack_round = 0;
             attack_rounds_checked(W);
             if (!first_render) {   // attack events are recorded once rendering has started (GridWorld.cc:484,508)
@@ -1744,7 +1762,14 @@ void Env::step_begin() {
         enqueue_counters();
     }
     stale_events = true;      // (last_op / op_obj hold this step's events until clear_dead resets them)
+    for (auto &g : groups) g.sa_off = -1;
     state_epoch++;
+}
+
+SeqPlan Env::seq_plan() const {
+    SeqPlan P{};
+    for (int g = 0; g < MAXG; g++) P.off[g] = g < (int)groups.size() ? groups[g].sa_off : -1;
+    return P;
 }
 
 // the one host synchronisation of the step: `done`, death counts, RNG state, and the (rare) continuation when a

@@ -70,6 +70,7 @@ struct HostGroup {
     int h_dead = 0;              // dead_ct as of the last step (GridWorld.h Group::dead_ct)
     int h_taken = 0;             // movers taken in by goals: dead, but never counted in dead_ct (Map.cc:345)
     int indexed = 0;             // agents [0, indexed) have been through a clear_dead: Agent::index == position, else 0
+    int sa_off = -1;             // this step's set_action call left its tile counts at d_asums[sa_off ...] (SeqPlan); -1: none / one-workgroup form
     int tm_high = 0;             // leading entries of cur.tm that may point at a claim word a fused step left behind (launch.h: TmHigh)
 };
 
@@ -284,6 +285,10 @@ private:
     int *d_mini = nullptr; size_t mini_cap = 0;
     float *d_minif = nullptr; size_t minif_cap = 0;
     int *d_sums = nullptr; size_t sums_cap = 0;
+    // attack counts per tile / per wave of the step's tiled set_action calls, in call order (k_set_action_a -> attack_seq)
+    int *d_asums = nullptr, *d_wpre = nullptr; size_t asums_cap = 0, wpre_cap = 0;
+    int sa_tiles = 0; bool step_sa_tiled = false;
+    SeqPlan seq_plan() const;
     int *d_rank = nullptr, *h_rank = nullptr; size_t rank_cap = 0, hrank_cap = 0;
     int *d_shuf = nullptr; size_t shuf_cap = 0;
     unsigned *d_powtab = nullptr; size_t powtab_cap = 0;   // powers of 16807 for the shuffle draws

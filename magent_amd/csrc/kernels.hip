@@ -87,6 +87,7 @@ __global__ void k_set_counter(int *counters, int index, int value, int unless_in
 __global__ void k_step_reset(int *counters) {
     if (threadIdx.x == 0) counters[CTR_ATTACK] = 0;
     for (int k = CTR_TRIGGER + threadIdx.x; k < CTR_TRIGGER_END; k += blockDim.x) counters[k] = 0;
+    for (int k = threadIdx.x; k < ROUND_SLOTS; k += blockDim.x) counters[CTR_ROUND_CHANGED + k] = 0;
 }
 // The end-of-step report of the multi-launch step, straight into pinned host memory (the host spins on `seq`: a stream
 // synchronisation behind a device-to-host copy costs several times the PCIe write it waits for), and the per-step counters
@@ -113,6 +114,7 @@ __global__ void __launch_bounds__(64) k_step_report(int *counters, StepRecord *r
     }
     if (!open) {
         if (tid < CTR_TRIGGER_END - CTR_TRIGGER) counters[CTR_TRIGGER + tid] = 0;
+        if (tid < ROUND_SLOTS) counters[CTR_ROUND_CHANGED + tid] = 0;
         if (tid == 0) counters[CTR_ATTACK] = 0;
     }
     __threadfence_system();
@@ -870,8 +872,13 @@ __device__ __forceinline__ int block_prefix(const int *sums, int b) {
 //   move  : key = (boundary << 31) | insertion index.  Reference: moves run stripe lists 0..S-1 then the boundary
 //           list, each in insertion order (GridWorld.cc:605-613); interior moves of different stripes cannot
 //           interact (margin 4 > max speed 3), so only "boundary after interior" + insertion order is observable.
-//   attack: key = running sequence number in the attack list (the shuffle permutes these; pass C below).
-__global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int g, const int *actions, int call_base, int *sums) {
+//   attack: key = running sequence number in the attack list (the shuffle permutes these).  It is NOT assigned here: this launch
+//           leaves, per tile of SCAN_TILE agents, the tile's attack count (`sums`, one array for all set_action calls of the step,
+//           in call order) and the exclusive prefix of every wave's count inside the tile (`wpre`); whoever needs the number
+//           computes it from those and one ballot (attack_seq, called by the step's first per-agent pass k_attack_rank).  Round 3
+//           ran a second launch per call for it (k_set_action_c).  The list's length grows by one atomic per tile.
+constexpr int SCAN_WAVES = SCAN_TILE / 64;
+__global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int g, const int *actions, int call_base, int *sums, int *wpre, int tile_off) {
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
     const int tile0 = blockIdx.x * SCAN_TILE;
@@ -884,12 +891,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int 
         act[k] = i < G.n ? actions[i] : 0;
         xs[k] = (i < G.n && W.large_map) ? G.x[i] : 0;
     }
-    int cnt = 0;
+    __shared__ int s_w[SCAN_WAVES];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const int i = tile0 + k * SCAN_THREADS + threadIdx.x;
-        const bool attack = i < G.n && act[k] >= T.n_move + T.n_turn;
-        cnt += __popcll(__ballot(attack));
+        const bool attack = i < G.n && act[k] >= T.n_move + T.n_turn && act[k] < T.n_move + T.n_turn + T.n_attack;
+        const int cnt = __popcll(__ballot(attack));
+        if (lane_id() == 0) s_w[k * (SCAN_THREADS / 64) + (threadIdx.x >> 6)] = cnt;     // wave (k, w) holds agents tile0 + 64 (4 k + w) ...
         if (i < G.n) {
             const int a = act[k];
             if (a < 0 || a >= T.n_move + T.n_turn + T.n_attack) {   // outside the action space: no action, reported at the end of the step
@@ -905,23 +913,38 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int 
             }
         }
     }
-    __shared__ int s_w[SCAN_THREADS / 64];
-    if (lane_id() == 0) s_w[threadIdx.x >> 6] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int k = 0; k < SCAN_THREADS / 64; k++) tot += s_w[k];
-        sums[blockIdx.x] = tot;
-        if (blockIdx.x == 0) W.counters[CTR_ATTACK_BASE] = W.counters[CTR_ATTACK];   // nothing writes CTR_ATTACK in this launch
+    if (threadIdx.x < SCAN_WAVES) {
+        int before = 0;
+        for (int v = 0; v < (int)threadIdx.x; v++) before += s_w[v];
+        wpre[(size_t)(tile_off + blockIdx.x) * SCAN_WAVES + threadIdx.x] = before;
+        if (threadIdx.x == SCAN_WAVES - 1) {
+            const int tot = before + s_w[SCAN_WAVES - 1];
+            sums[tile_off + blockIdx.x] = tot;
+            if (tot) atomicAdd(&W.counters[CTR_ATTACK], tot);
+        }
     }
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) k_set_action_c(WorldView W, int g, const int *actions, const int *sums) {
+// (launch.h: SeqPlan -- where a group's set_action call of this step left its tile counts in `sums` / `wpre`; -1: its sequence numbers
+// are in `key` already -- the one-workgroup form k_set_action_solo assigns them itself -- or the group was given no actions)
+// the sequence number of agent i's attack in the step's attack list (GridWorld.cc:435-445: list order = call order, then agent order).
+// Called by EVERY thread of a 256-thread workgroup whose agents lie in one tile (a barrier and a ballot inside); `att`: i attacks
+__device__ __forceinline__ int attack_seq(const int *sums, const int *wpre, int tile_off, int i, bool att) {
+    const int tile = tile_off + i / SCAN_TILE;
+    const int before = block_prefix(sums, tile);
+    int wtot;
+    const int r = wave_rank(att, wtot);
+    return before + wpre[(size_t)tile * SCAN_WAVES + (i % SCAN_TILE) / 64] + r;
+}
+// the sequence numbers written out (a step that was given its actions in tiles but runs as ONE launch after all: k_step_solo reads them
+// from `key`; happens when the world shrank below the one-launch limit between set_action and step)
+__global__ void __launch_bounds__(256) k_seq_assign(WorldView W, int g, const int *sums, const int *wpre, int tile_off) {
     const GroupDev G = W.grp[g];
-    const int n_move = W.type[g].n_move + W.type[g].n_turn;   // (the first attack action)
-    const int before = W.counters[CTR_ATTACK_BASE] + block_prefix(sums, blockIdx.x);
-    block_rank([&](int i) { return actions[i] >= n_move; }, [&](int i, int r) { G.key[i] = (unsigned)r; }, G.n, before);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) W.counters[CTR_ATTACK] = before + sums[blockIdx.x];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool att = i < G.n && (G.pend[i] & ~PEND_ARG) == PEND_ATTACK;
+    const int seq = attack_seq(sums, wpre, tile_off, i, att);
+    if (att) G.key[i] = (unsigned)seq;
 }
 
 // (takes the group and the type, not the world: indexing the by-value kernel argument with a run-time group number would make
@@ -1037,13 +1060,13 @@ __global__ void __launch_bounds__(256) k_shuffle_chase(int *counters, const int 
 // (tlist / n_tlist, one-launch step with one-cell bodies: the attacker that sets the FIRST bit of a cell appends the agent standing
 // there -- every target exactly once -- and the evaluation rounds visit the targets instead of scanning every agent)
 __device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int i, const int *rank, unsigned *hitbits, int *tlist = nullptr,
-                                                 int *n_tlist = nullptr) {
+                                                 int *n_tlist = nullptr, int seq = -1 /* >= 0: the attack's sequence number (else it is in `key`) */) {
     const GroupDev &G = W.grp[g];
     const TypeDev &T = W.type[g];
     const int pend = G.pend[i];
     const bool att = (pend & ~PEND_ARG) == PEND_ATTACK;
     const bool dead = G.dead[i];
-    if (att) G.key[i] = (unsigned)rank[G.key[i]];
+    if (att) G.key[i] = (unsigned)rank[seq >= 0 ? (unsigned)seq : G.key[i]];
     G.drank_a[i] = dead ? -1 : RANK_INF;   // agents dead before the phase never act and are not on the map
     G.drank_b[i] = 0;                      // "inputs changed in round 0": everybody is evaluated in round 1
     // push one bit per (attacker group, attack offset) onto the target's cell: targets then enumerate only the
@@ -1064,7 +1087,8 @@ __device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int 
     }
     if (W.food_mode) { G.eat[i] = -1.0f; G.fcell[i] = -1; }
 }
-__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_head, int *shuf_first) {
+__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_head, int *shuf_first,
+                                                     const int *sums, const int *wpre, SeqPlan P) {
     if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // attack rounds start
     const int A = W.counters[CTR_ATTACK];
     // the shuffle's list heads and first-hit words have been read for the last time (k_shuffle_chase): back to zero for their next use
@@ -1073,9 +1097,13 @@ __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *ran
     }
     if (A == 0) return;
     const int g = blockIdx.y;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W.grp[g].n) return;
-    attack_rank_body(W, g, i, rank, hitbits);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = W.grp[g].n;
+    if ((int)(blockIdx.x * blockDim.x) >= n) return;
+    int seq = -1;
+    if (P.off[g] >= 0) seq = attack_seq(sums, wpre, P.off[g], i, i < n && (W.grp[g].pend[i] & ~PEND_ARG) == PEND_ATTACK);   // (every thread of the workgroup)
+    if (i >= n) return;
+    attack_rank_body(W, g, i, rank, hitbits, nullptr, nullptr, seq);
 }
 
 // The hits that land on cell (cx, cy), appended to a thread-private LDS list (stride NT): bit (attack_bit[ga] + k) of
@@ -1159,7 +1187,7 @@ __device__ __forceinline__ bool set_eat(const WorldView &W, const GroupDev *gtab
 // (s_rank / s_ref: the thread's hit list, stride ATT_THREADS, slot tid; flagp: where to report a change, or null)
 __device__ __forceinline__ void attack_eval_body(const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int g, int i,
                                                  int round /* 1, 2, ... within this step */, const unsigned *hitbits,
-                                                 unsigned *s_rank, int *s_ref, int ATT_THREADS, int tid, int *flagp, int kmax) {
+                                                 unsigned *s_rank, int *s_ref, int ATT_THREADS, int tid, int *flagp, int kmax, int *round_flags = nullptr) {
     const GroupDev &G = W.grp[g];
     const TypeDev &T = W.type[g];
     const int dr_me_cur = G.drank_a[i];
@@ -1262,6 +1290,7 @@ __device__ __forceinline__ void attack_eval_body(const WorldView &W, const Group
         if (W.any_kill_supply)
             for (int k = 0; k < nh; k++) { const int a = s_ref[k * ATT_THREADS + tid]; gtab[ref_group(a)].drank_b[ref_index(a)] = round; }
         if (flagp) *flagp = 1;                        // (multi-launch driver: only the last round of a batch reports)
+        if (round_flags) round_flags[round & (ROUND_SLOTS - 1)] = 1;
     }
 }
 // (the head of the fused step of plain games rides in round 1: see "the fused step of plain games" below)
@@ -1301,8 +1330,10 @@ __global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev
     }
     if (W.plain && round == 1) plain_head_body(W, g, i);   // (rides here: this launch visits every agent of every step, attacks or not)
     if (W.counters[CTR_ATTACK] == 0) return;
+    // nobody's death rank changed in the round before: nobody is stamped for this one (plain games: food cells stamp eaters elsewhere)
+    if (W.plain && round > 1 && W.counters[CTR_ROUND_CHANGED + ((round - 1) & (ROUND_SLOTS - 1))] == 0) return;
     attack_eval_body(W, gtab, ttab, g, i, round, hitbits, s_hit, (int *)(s_hit + kmax * ATT_THREADS), ATT_THREADS, tid,
-                     flag >= 0 ? &W.counters[flag] : nullptr, kmax);
+                     flag >= 0 ? &W.counters[flag] : nullptr, kmax, W.plain ? &W.counters[CTR_ROUND_CHANGED] : nullptr);
 }
 
 // food_mode: the food that lay on the map before this step.  One thread per cell: the hits on a food cell eat from it
@@ -3048,13 +3079,18 @@ void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, con
     else hipLaunchKernelGGL((k_features<false>), dim3(fb), dim3(256), 0, s, W, R, P);
 }
 
-void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums) {
+// tile_off < 0: the one-workgroup form (worlds that step in one launch: it assigns the sequence numbers itself); else the tiled form,
+// whose counts go to sums[tile_off ...] / wpre (launch.h: SeqPlan)
+void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums, int *wpre, int tile_off) {
     int n = W.grp[g].n;
     if (n <= 0) return;
-    if (n <= scan_solo_max()) { hipLaunchKernelGGL(k_set_action_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, actions, call_base); return; }
+    if (tile_off < 0) { hipLaunchKernelGGL(k_set_action_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, actions, call_base); return; }
     int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_set_action_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, call_base, sums);
-    hipLaunchKernelGGL(k_set_action_c, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, sums);
+    hipLaunchKernelGGL(k_set_action_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, call_base, sums, wpre, tile_off);
+}
+void launch_seq_assign(hipStream_t s, const WorldView &W, int g, const int *sums, const int *wpre, int tile_off) {
+    int n = W.grp[g].n;
+    if (n > 0) hipLaunchKernelGGL(k_seq_assign, dim3((n + 255) / 256), dim3(256), 0, s, W, g, sums, wpre, tile_off);
 }
 
 // n_max = upper bound of the attack-list length (the number of agents); the actual length is read on the device
@@ -3192,9 +3228,10 @@ void launch_set_counter(hipStream_t s, int *counters, int index, int value, int 
 }
 
 // (the hit bits have an array of their own, WorldView::hitbits -- until round 4 they shared the move phase's claim words)
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits) {
+void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits, const int *sums, const int *wpre,
+                        const SeqPlan &P) {
     if (clear_hitbits) (void)hipMemsetAsync(W.hitbits, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);   // (else k_shuffle_draw did it, or the fused step keeps them zero)
-    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, W.hitbits, B.head, B.first);
+    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, W.hitbits, B.head, B.first, sums, wpre, P);
 }
 static int att_threads(int kmax) {
     static const int forced = getenv("MAGENT_ATT_THREADS") ? atoi(getenv("MAGENT_ATT_THREADS")) : 0;

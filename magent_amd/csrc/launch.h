@@ -122,8 +122,12 @@ void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &
 void launch_set_rng(hipStream_t s, int *counters, unsigned x);
 void launch_step_reset(hipStream_t s, int *counters);
 void launch_set_counter(hipStream_t s, int *counters, int index, int value, int unless_index);
-void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums);
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits);
+// where a group's set_action call of this step left its tile counts (kernels.hip: k_set_action_a, attack_seq); -1: none / numbers in `key`
+struct SeqPlan { int off[MAXG]; };
+void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums, int *wpre, int tile_off /* < 0: one-workgroup form */);
+void launch_seq_assign(hipStream_t s, const WorldView &W, int g, const int *sums, const int *wpre, int tile_off);
+void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits, const int *sums, const int *wpre,
+                        const SeqPlan &P);
 // per group: how many leading entries of `tm` may still point at a claim word their move left behind (the fused step of plain games
 // cleans them beside its first attack round; entries beyond the group's current size belong to agents clear_dead has compacted away)
 struct TmHigh { int hi[MAXG]; };
