@@ -104,10 +104,6 @@ struct GroupDev {
     unsigned *key;               // attack: sequence number -> rank after the shuffle; move: order key
     int *drank_a, *drank_b;      // attack fixed point: rank at which the agent dies (ping-pong)
     unsigned *mv;                // move resolution status / dependency (generic step); hp after the attack phase, as float bits (every step)
-    // the fused step of plain games (kernels.hip: k_strike and friends): the cell a move is aimed at (-1: none; computed beside the
-    // first attack round, kept until the next step cleans the claim word it left there) and the move's status / dependency
-    int *tm;
-    unsigned *ms;
     int *hits;                   // reward rules: number of rule hits received as the object of an event
     // food_mode scratch of the attack phase: what my attack eats (-1 = it eats nothing), written by the owner of the
     // food; the cell on which I was killed and what is left of the food there (-1 = none)
@@ -161,8 +157,12 @@ constexpr int CTR_BAD_ACTION = 73;   // set_action met an action outside [0, n_a
 // Deaths are counted in DEAD_SLOTS counters per group, each on its own cache line: device-scope atomics on ONE address
 // serialise at ~15 ns apiece on this part (measured: 4.8k of them cost a 800k-agent step 70 us).  dead_ct of group g =
 // sum over slots of counters[dead_slot(g, slot)]; the host adds them up after its one readback per step.
-constexpr int DEAD_SLOTS = 16, CTR_DEAD_SPREAD = 128, CTR_TOTAL = CTR_DEAD_SPREAD + MAXG * DEAD_SLOTS * 16;
+constexpr int DEAD_SLOTS = 16, CTR_DEAD_SPREAD = 128, CTR_ATT_SPREAD = CTR_DEAD_SPREAD + MAXG * DEAD_SLOTS * 16;
 __host__ __device__ inline int dead_slot(int g, int slot) { return CTR_DEAD_SPREAD + (g * DEAD_SLOTS + slot) * 16; }
+// the attack-list length as the tiled set_action leaves it: ATT_SLOTS partial counts, each on its own cache line (k_set_action_a adds one
+// atomic per tile; k_shuffle_draw -- or the host, in the checked driver -- adds them up into CTR_ATTACK); zero between steps
+constexpr int ATT_SLOTS = 64, CTR_TOTAL = CTR_ATT_SPREAD + ATT_SLOTS * 16;
+__host__ __device__ inline int att_slot(int slot) { return CTR_ATT_SPREAD + slot * 16; }
 // single-sync step: the fixed-point rounds are launched optimistically; the LAST round of a phase reports whether
 // anything still changed.  A phase left open makes every later kernel of the step return at once, and the host
 // continues from exactly that state (adjacent: cleared together)

@@ -285,7 +285,7 @@ Env::~Env() {
     dfree(arena, d_occ); dfree(arena, d_viewcell); dfree(arena, d_claim); dfree(arena, d_food); dfree(arena, d_powtab); dfree(arena, d_counters); dfree(arena, d_gtab); dfree(arena, d_ttab);
     dfree(arena, d_delta); dfree(arena, d_mask); dfree(arena, d_mini); dfree(arena, d_minif); dfree(arena, d_sums); dfree(arena, d_rank); dfree(arena, d_shuf); dfree(arena, d_events); dfree(arena, d_actions);
     dfree(arena, d_stage_view); dfree(arena, d_stage_feat); dfree(arena, d_stage_small);
-    dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d); dfree(arena, d_asums); dfree(arena, d_wpre);
+    dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d); dfree(arena, d_asums); dfree(arena, d_wpre); dfree(arena, d_ptab);
     if (batch_h) (void)hipHostFree(batch_h);
     if (h_rec) (void)hipHostFree(h_rec);
     if (pool) {
@@ -859,7 +859,9 @@ void Env::free_group(HostGroup &g) {
     dfree(arena, c.x); dfree(arena, c.y); dfree(arena, c.id); dfree(arena, c.last_action); dfree(arena, c.op_obj); dfree(arena, c.pend); dfree(arena, c.hp);
     dfree(arena, c.next_reward); dfree(arena, c.last_reward); dfree(arena, c.dead); dfree(arena, c.last_op); dfree(arena, c.key); dfree(arena, c.drank_a);
     dfree(arena, c.drank_b); dfree(arena, c.mv); dfree(arena, c.hits); dfree(arena, c.absorbed); dfree(arena, a.absorbed); dfree(arena, c.dir); dfree(arena, a.dir);
-    dfree(arena, c.eat); dfree(arena, c.fleft); dfree(arena, c.fcell); dfree(arena, c.tm); dfree(arena, c.ms);
+    dfree(arena, c.eat); dfree(arena, c.fleft); dfree(arena, c.fcell);
+    dfree(arena, g.pl.rec); dfree(arena, g.pl.atk); dfree(arena, g.pl.hmask); dfree(arena, g.pl.hlist);
+    ptab_valid = false;
     dfree(arena, a.x); dfree(arena, a.y); dfree(arena, a.id); dfree(arena, a.last_action); dfree(arena, a.hp); dfree(arena, a.next_reward); dfree(arena, a.last_reward);
     g.cap = 0; g.n = 0;
 }
@@ -873,8 +875,22 @@ static void regrow(DevArena &arena, T *&p, size_t old_n, size_t ncap) {
     p = q;
 }
 
+// the scratch of the step of plain games (launch.h: PlainGroup), for a group of capacity `cap` whose first n records are kept
+void Env::plain_arrays(HostGroup &g, size_t n, size_t cap) {
+    regrow(arena, g.pl.rec, n, cap);
+    HIP_OK(hipMemset(g.pl.rec + n, 0xFF, sizeof(int4) * (cap - n)));     // (no move target beyond: k_plain_rank cleans the claim word of every target it finds)
+    regrow(arena, g.pl.atk, 0, cap);
+    regrow(arena, g.pl.hmask, 0, cap);
+    HIP_OK(hipMemset(g.pl.hmask, 0, sizeof(unsigned) * cap));            // (every mask is zero between steps: k_strike leaves them so)
+    regrow(arena, g.pl.hlist, 0, cap * (size_t)std::max(1, plain_slots));
+    ptab_valid = false;
+}
+
 void Env::ensure_capacity(HostGroup &g, int need) {
-    if (need <= g.cap) return;
+    if (need <= g.cap) {
+        if (plain_world && !g.pl.rec && g.cap > 0) { HIP_OK(hipStreamSynchronize(stream)); plain_arrays(g, 0, (size_t)g.cap); }
+        return;
+    }
     HIP_OK(hipStreamSynchronize(stream));
     size_t ncap = std::max<size_t>(std::max<size_t>(need, (size_t)g.cap * 2), 1024);
     size_t n = g.n;
@@ -887,9 +903,7 @@ void Env::ensure_capacity(HostGroup &g, int need) {
     regrow(arena, c.absorbed, n, ncap); regrow(arena, a.absorbed, 0, ncap);
     if (turn_mode) { regrow(arena, c.dir, n, ncap); regrow(arena, a.dir, 0, ncap); }
     regrow(arena, c.eat, 0, ncap); regrow(arena, c.fleft, 0, ncap); regrow(arena, c.fcell, 0, ncap);   // attack-phase scratch (food_mode)
-    // the fused step's move targets: -1 wherever no step has written (k_attack_eval cleans the claim word of every target it finds)
-    regrow(arena, c.tm, n, ncap); regrow(arena, c.ms, 0, ncap);
-    HIP_OK(hipMemset(c.tm + n, 0xFF, sizeof(int) * (ncap - n)));
+    if (plain_world) plain_arrays(g, g.pl.rec ? n : 0, ncap);
     regrow(arena, a.x, 0, ncap); regrow(arena, a.y, 0, ncap); regrow(arena, a.id, 0, ncap); regrow(arena, a.last_action, 0, ncap);
     regrow(arena, a.hp, 0, ncap); regrow(arena, a.next_reward, 0, ncap); regrow(arena, a.last_reward, 0, ncap);
     g.cap = (int)ncap;
@@ -910,7 +924,7 @@ WorldView Env::view() const {
     W.reach = map_reach;
     W.vc_packed = (groups.size() <= 3 && !any_absorb) ? 1 : 0;
     W.live_paint = live_paint_now ? 1 : 0;   // (set for the length of a step whose painted map was current at its start)
-    W.plain = (!any_multicell && !turn_mode && !food_mode && !any_absorb && !any_kill_supply) ? 1 : 0;
+    W.plain = plain_world ? 1 : 0;
     for (int g = 0; g < W.G; g++) {
         W.type[g] = groups[g].tdev;
         W.grp[g] = groups[g].cur;
@@ -1008,7 +1022,6 @@ void Env::reset() {
         if (t.kill_supply != 0) any_kill_supply = 1;
         total_attack += t.attack.count;
         g.n = 0; g.group_reward = 0; g.acted = false; g.h_dead = 0; g.h_taken = 0; g.indexed = 0; g.sa_off = -1;
-        if (g.cur.tm) HIP_OK(hipMemset(g.cur.tm, 0xFF, sizeof(int) * g.cap));   // (the map may have changed its size: no stale move targets)
         g.tm_high = 0;
     }
     // most hits one target can receive: attack offsets of every group allowed to attack it
@@ -1041,6 +1054,22 @@ void Env::reset() {
     if (!attack_lds_ok(attack_kmax)) fatal("attack ranges x body size (%d hits per target) need more LDS per workgroup than this device grants", attack_kmax);
     if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
     if (n_channel() > 32) fatal("too many observation channels");
+    // the step of plain games (kernels.hip) keeps scratch of its own per agent, sized by the attack offsets of all groups
+    {
+        const bool plain = !any_multicell && !turn_mode && !food_mode && !any_absorb && !any_kill_supply && plain_eval_lds_ok(attack_kmax);
+        const int slots = std::max(1, total_attack);
+        for (auto &g : groups) {
+            if (g.pl.rec && (!plain || slots != plain_slots)) {      // (the configuration changed between two resets: built anew when agents are added)
+                dfree(arena, g.pl.rec); dfree(arena, g.pl.atk); dfree(arena, g.pl.hmask); dfree(arena, g.pl.hlist);
+            }
+            if (g.pl.rec) {
+                HIP_OK(hipMemset(g.pl.rec, 0xFF, sizeof(int4) * g.cap));   // (the map may have changed its size: no stale move targets)
+                HIP_OK(hipMemset(g.pl.hmask, 0, sizeof(unsigned) * g.cap));
+            }
+        }
+        plain_world = plain; plain_slots = slots;
+        ptab_valid = false;
+    }
     dfree(arena, d_delta); dfree(arena, d_mask);
     HIP_OK(dev_malloc(arena, &d_delta, sizeof(int2) * std::max<size_t>(delta.size(), 1)));
     HIP_OK(dev_malloc(arena, &d_mask, std::max<size_t>(mask.size(), 1)));
@@ -1495,6 +1524,15 @@ void Env::attack_rounds_checked(const WorldView &W) {
     int iters = 0;
     while (true) {
         clear_changed();
+        if (step_was_plain) {          // (the continuation of a step of the plain pipeline: its own rounds)
+            const PlainWorld PW = plain_view();
+            launch_plain_eval(stream, W, PW, d_ptab, d_gtab, d_ttab, ++attack_round, -1);
+            launch_plain_eval(stream, W, PW, d_ptab, d_gtab, d_ttab, ++attack_round, CTR_CHANGED);
+            iters += 2;
+            if (!read_changed()) break;
+            if (iters > 1000000) fatal("attack resolution did not converge");
+            continue;
+        }
         launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, -1);
         launch_attack_iter(stream, W, d_gtab, d_ttab, ++attack_round, attack_kmax, CTR_CHANGED);
         iters += 2;
@@ -1521,6 +1559,11 @@ void Env::move_rounds_checked(const WorldView &W) {
 }
 
 void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 = after move rounds */) {
+    if (step_was_plain) {              // (only its attack rounds can run out: from == 0)
+        launch_plain_tail(stream, W, plain_view(), d_ptab, d_gtab, d_ttab, step_fused_rules ? rule_args.data() : nullptr, (int)rule_args.size());
+        if (!step_fused_rules && !rules_on_host) launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
+        return;
+    }
     if (from == 0) {
         launch_attack_apply(stream, W, d_gtab, d_ttab, attack_kmax);
         if (any_multicell) launch_movg_prep(stream, W, true); else launch_move_prep(stream, W, d_gtab);   // (starve / recover first)
@@ -1533,18 +1576,19 @@ void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 
 
 // The per-cell scratch words (claim, hitbits) as the three step paths want them and leave them:
 //   one-launch step / cycle (0): wants every claim word CLAIM_NONE and every hit word zero; keeps them so
-//   fused step of plain games (1): wants the hit words zero and the claim words either clean or dirty only where some `tm` entry below
-//       its group's tm_high points (those it cleans itself, beside its first attack round); leaves them exactly like that
+//   step of plain games (1): does not use the hit words (its hits live in per-agent masks); wants the claim words either clean or dirty
+//       only where the move target of some record below its group's tm_high points (those it cleans itself, in k_plain_rank); leaves
+//       them exactly like that
 //   everything else (2): wants nothing (fills what it needs) and leaves both arrays dirty
 void Env::scratch_for(int path) {
     const size_t ncell = (size_t)width * height;
     if (path == 2) { claim_clean = claim_tm_only = hit_clean = false; return; }
-    if (!hit_clean) { HIP_OK(hipMemsetAsync(d_hit, 0, sizeof(unsigned) * ncell, stream)); hit_clean = true; }
+    if (path == 0 && !hit_clean) { HIP_OK(hipMemsetAsync(d_hit, 0, sizeof(unsigned) * ncell, stream)); hit_clean = true; }
     if (!claim_clean && !(path == 1 && claim_tm_only)) {
         HIP_OK(hipMemsetAsync(d_claim, 0xFF, sizeof(unsigned long long) * ncell, stream));
         claim_clean = true;
     }
-    if (path == 0) claim_tm_only = true;               // (clean is a special case of "dirty only at tm entries")
+    if (path == 0) claim_tm_only = true;               // (clean is a special case of "dirty only at move targets")
     else { claim_clean = false; claim_tm_only = true; }
 }
 
@@ -1599,6 +1643,7 @@ void Env::step_begin() {
     step_pending = true;
     step_was_fast = false;
     step_was_solo = false;
+    step_was_plain = false;
 
     const bool beside = total_n > 0 && fast && side_wanted() && overlap_level >= 2 && !serial_calls_on;   // the read-only head of the step goes beside the renders
     if (!beside) join_side();
@@ -1617,8 +1662,11 @@ void Env::step_begin() {
         shuffle_buffers(total_n);
         push_rng();
         scratch_for(0);        // (fills after a multi-launch step or a reset: once)
-        for (size_t g = 0; g < groups.size(); g++)     // (given its actions in tiles, when the world was larger: the numbers written out)
-            if (groups[g].sa_off >= 0) launch_seq_assign(stream, W, (int)g, d_asums, d_wpre, groups[g].sa_off);
+        {                      // (given its actions in tiles, when the world was larger: the numbers, and the list's length, written out)
+            bool first = true;
+            for (size_t g = 0; g < groups.size(); g++)
+                if (groups[g].sa_off >= 0) { launch_seq_assign(stream, W, (int)g, d_asums, d_wpre, groups[g].sa_off, first); first = false; }
+        }
         const ShuffleBufs B = shuffle_bufs();
         SoloStep S{};
         S.shead = B.head; S.sfirst = B.first; S.sj = B.j; S.slink = B.link;
@@ -1631,9 +1679,12 @@ void Env::step_begin() {
     } else if (fast) {
         step_was_fast = true;
         // ---------------- single-sync driver
-        const bool plain = W.plain != 0;       // the fused step (kernels.hip: k_strike ...): four per-agent passes behind the death-rank rounds
+        const bool plain = W.plain != 0;       // plain games have a pipeline of their own behind the shuffle (kernels.hip: k_plain_rank ...)
+        step_was_plain = plain;
         if (plain) plain_steps++;
         scratch_for(plain ? 1 : 2);
+        PlainWorld PW{};
+        if (plain) PW = plain_view();
         {
             const size_t caps = rank_cap + shuf_cap + sums_cap + powtab_cap;
             const bool rng_here = !rng_on_device;
@@ -1645,26 +1696,30 @@ void Env::step_begin() {
         hipStream_t a = beside ? side_stream() : stream;
         {
             ProfScope p(*this, "attack", false, a);
-            // (the fused step keeps the hit words zero itself -- its attackers wipe the bits they set; otherwise the draw zero-fills them)
-            launch_shuffle(a, total_n, d_counters, shuffle_bufs(), d_rank, plain ? nullptr : d_hit, (size_t)width * height, d_powtab);
+            // (plain games keep their hits in per-agent masks; otherwise the draw zero-fills the per-cell hit words)
+            launch_shuffle(a, total_n, d_counters, shuffle_bufs(), d_rank, plain ? nullptr : d_hit, (size_t)width * height, d_powtab, step_sa_tiled);
             if (overlap_level == 2 && a != stream) { join_side(); a = stream; }
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
-            launch_attack_rank(a, W, d_rank, shuffle_bufs(), false, d_asums, d_wpre, seq_plan());
-            TmHigh H{};
-            for (size_t g = 0; g < groups.size(); g++) H.hi[g] = groups[g].tm_high;
             // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
             // LAST one reports whether anything still moved (one gate for all of them)
-            for (int r = 0; r < 2 * pairs; r++)
-                launch_attack_iter(a, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1, plain ? &H : nullptr);
+            if (plain) {
+                launch_plain_rank(a, W, PW, d_ptab, d_rank, shuffle_bufs(), d_asums, d_wpre, seq_plan());
+                for (int r = 0; r < 2 * pairs; r++)
+                    launch_plain_eval(a, W, PW, d_ptab, d_gtab, d_ttab, ++attack_round, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
+            } else {
+                launch_attack_rank(a, W, d_rank, shuffle_bufs(), false, d_asums, d_wpre, seq_plan());
+                for (int r = 0; r < 2 * pairs; r++)
+                    launch_attack_iter(a, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
+            }
             if (pairs == 0) launch_set_counter(a, d_counters, CTR_OPEN_ATTACK, 1, -1);   // tests: straight to the host
         }
         join_side();      // from here on the world changes: behind every render enqueued so far
         if (plain) {
-            const bool fuse = !rules_on_host && !stale_events && fused_rules(rule_args.data(), (int)rule_args.size());
+            const bool fuse = step_fused_rules = !rules_on_host && !stale_events && fused_rules(rule_args.data(), (int)rule_args.size());
             {
                 ProfScope p(*this, "move");
-                launch_plain_tail(stream, W, d_gtab, d_ttab, fuse ? rule_args.data() : nullptr, (int)rule_args.size());
+                launch_plain_tail(stream, W, PW, d_ptab, d_gtab, d_ttab, fuse ? rule_args.data() : nullptr, (int)rule_args.size());
             }
             if (!fuse && !rules_on_host) {
                 ProfScope p(*this, "rules");
@@ -1699,7 +1754,8 @@ void Env::step_begin() {
         // ---------------- checked driver
         scratch_for(2);
         HIP_OK(hipMemsetAsync(d_counters + CTR_OPEN_ATTACK, 0, 2 * sizeof(int), stream));
-        const int A = read_counters()[CTR_ATTACK];
+        int A = read_counters()[CTR_ATTACK];
+        if (step_sa_tiled) for (int k = 0; k < ATT_SLOTS; k++) A += h_counters[att_slot(k)];   // (the tiled set_action's spread counters: k_shuffle_draw adds them up too)
         if (A > 0) {
             ProfScope p(*this, "attack");
             shuffle_buffers(std::max(A, total_n));
@@ -1718,10 +1774,11 @@ void Env::step_begin() {
                 }
                 for (int pos = 0; pos < A; pos++) h_rank[shuffle_perm[pos]] = pos;
                 HIP_OK(hipMemcpyAsync(d_rank, h_rank, sizeof(int) * A, hipMemcpyHostToDevice, stream));
+                if (step_sa_tiled) launch_set_counter(stream, d_counters, CTR_ATTACK, A, -1);   // (k_shuffle_draw would have left the list's length there)
                 rng_on_device = false;
             } else {              // exact parallel replay on the device
                 push_rng();
-                launch_shuffle(stream, total_n, d_counters, shuffle_bufs(), d_rank, d_hit, (size_t)width * height, d_powtab);
+                launch_shuffle(stream, total_n, d_counters, shuffle_bufs(), d_rank, d_hit, (size_t)width * height, d_powtab, step_sa_tiled);
             }
             launch_attack_rank(stream, W, d_rank, shuffle_bufs(), host_shuffle, d_asums, d_wpre, seq_plan());
             attack_round = 0;
@@ -1764,6 +1821,19 @@ void Env::step_begin() {
     stale_events = true;      // (last_op / op_obj hold this step's events until clear_dead resets them)
     for (auto &g : groups) g.sa_off = -1;
     state_epoch++;
+}
+
+PlainWorld Env::plain_view() {
+    PlainWorld PW{};
+    for (size_t g = 0; g < groups.size(); g++) { PW.g[g] = groups[g].pl; PW.hi[g] = groups[g].tm_high; }
+    PW.S = plain_slots; PW.kmax = attack_kmax;
+    if (!ptab_valid) {
+        if (!d_ptab) HIP_OK(dev_malloc(arena, &d_ptab, sizeof(PlainGroup) * MAXG));
+        HIP_OK(hipMemcpyAsync(d_ptab, PW.g, sizeof(PlainGroup) * MAXG, hipMemcpyHostToDevice, stream));   // (pageable source: the copy is done when the call returns)
+        ptab_valid = true;
+        state_epoch++;
+    }
+    return PW;
 }
 
 SeqPlan Env::seq_plan() const {
@@ -1819,7 +1889,6 @@ void Env::step_end(int *done) {
         if (c[CTR_OPEN_ATTACK] | c[CTR_OPEN_MOVE]) {   // continue from exactly the device state the open phase froze, host-checked
             WorldView W = view();
             const int phase = c[CTR_OPEN_ATTACK] ? 1 : 2;
-            scratch_for(2);              // (the continuation runs the unfused kernels, whatever the head of the step was)
             fallback_steps++;
             if (phase == 1) fallback_attack++; else fallback_move++;
             if (phase == 1) boost_attack = 64; else boost_move = 64;   // deeper dependency chains around: one more batch

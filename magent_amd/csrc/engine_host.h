@@ -71,7 +71,8 @@ struct HostGroup {
     int h_taken = 0;             // movers taken in by goals: dead, but never counted in dead_ct (Map.cc:345)
     int indexed = 0;             // agents [0, indexed) have been through a clear_dead: Agent::index == position, else 0
     int sa_off = -1;             // this step's set_action call left its tile counts at d_asums[sa_off ...] (SeqPlan); -1: none / one-workgroup form
-    int tm_high = 0;             // leading entries of cur.tm that may point at a claim word a fused step left behind (launch.h: TmHigh)
+    PlainGroup pl{};             // scratch of the step of plain games (launch.h)
+    int tm_high = 0;             // leading records of pl.rec whose move target may point at a claim word a step left behind (PlainWorld::hi)
 };
 
 struct HostSymbol { int group = 0, index = 0; int ent_g = -1, ent_i = -1; };   // ent_*: the agent the host rule search last bound it to
@@ -220,7 +221,11 @@ private:
     bool claim_tm_only = false;           // ... or dirty only where a `tm` entry below its group's tm_high points (the fused step of plain games)
     bool hit_clean = false;               // every hit word is zero (both of those steps keep it so)
     void scratch_for(int path);
-    int plain_steps = 0;
+    int plain_steps = 0, plain_slots = 0;
+    bool plain_world = false, step_was_plain = false, step_fused_rules = false, ptab_valid = false;
+    PlainGroup *d_ptab = nullptr;
+    PlainWorld plain_view();
+    void plain_arrays(HostGroup &g, size_t n, size_t cap);
     bool stale_events = false;            // a step has run since the last clear_dead: last_op / op_obj are not all OP_NULL / -1
     RuleArgs *d_rule_args = nullptr; RuleProg *d_rule_progs = nullptr;
     void shuffle_buffers(int n_max);

@@ -88,6 +88,7 @@ __global__ void k_step_reset(int *counters) {
     if (threadIdx.x == 0) counters[CTR_ATTACK] = 0;
     for (int k = CTR_TRIGGER + threadIdx.x; k < CTR_TRIGGER_END; k += blockDim.x) counters[k] = 0;
     for (int k = threadIdx.x; k < ROUND_SLOTS; k += blockDim.x) counters[CTR_ROUND_CHANGED + k] = 0;
+    for (int k = threadIdx.x; k < ATT_SLOTS; k += blockDim.x) counters[att_slot(k)] = 0;
 }
 // The end-of-step report of the multi-launch step, straight into pinned host memory (the host spins on `seq`: a stream
 // synchronisation behind a device-to-host copy costs several times the PCIe write it waits for), and the per-step counters
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(64) k_step_report(int *counters, StepRecord *r
     if (!open) {
         if (tid < CTR_TRIGGER_END - CTR_TRIGGER) counters[CTR_TRIGGER + tid] = 0;
         if (tid < ROUND_SLOTS) counters[CTR_ROUND_CHANGED + tid] = 0;
+        if (tid < ATT_SLOTS) counters[att_slot(tid)] = 0;
         if (tid == 0) counters[CTR_ATTACK] = 0;
     }
     __threadfence_system();
@@ -876,7 +878,7 @@ __device__ __forceinline__ int block_prefix(const int *sums, int b) {
 //           leaves, per tile of SCAN_TILE agents, the tile's attack count (`sums`, one array for all set_action calls of the step,
 //           in call order) and the exclusive prefix of every wave's count inside the tile (`wpre`); whoever needs the number
 //           computes it from those and one ballot (attack_seq, called by the step's first per-agent pass k_attack_rank).  Round 3
-//           ran a second launch per call for it (k_set_action_c).  The list's length grows by one atomic per tile.
+//           ran a second launch per call for it (k_set_action_c).  The list's length is the sum of ATT_SLOTS spread counters.
 constexpr int SCAN_WAVES = SCAN_TILE / 64;
 __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int g, const int *actions, int call_base, int *sums, int *wpre, int tile_off) {
     const GroupDev G = W.grp[g];
@@ -921,7 +923,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int 
         if (threadIdx.x == SCAN_WAVES - 1) {
             const int tot = before + s_w[SCAN_WAVES - 1];
             sums[tile_off + blockIdx.x] = tot;
-            if (tot) atomicAdd(&W.counters[CTR_ATTACK], tot);
+            // (one atomic per tile, on ATT_SLOTS different cache lines: 782 of them on ONE word serialise at ~15 ns apiece -- measured:
+            // the launch went from 4.6 to 11.9 us; k_shuffle_draw adds the slots up into CTR_ATTACK)
+            if (tot) atomicAdd(&W.counters[att_slot((tile_off + blockIdx.x) % ATT_SLOTS)], tot);
         }
     }
 }
@@ -939,7 +943,14 @@ __device__ __forceinline__ int attack_seq(const int *sums, const int *wpre, int 
 }
 // the sequence numbers written out (a step that was given its actions in tiles but runs as ONE launch after all: k_step_solo reads them
 // from `key`; happens when the world shrank below the one-launch limit between set_action and step)
-__global__ void __launch_bounds__(256) k_seq_assign(WorldView W, int g, const int *sums, const int *wpre, int tile_off) {
+__global__ void __launch_bounds__(256) k_seq_assign(WorldView W, int g, const int *sums, const int *wpre, int tile_off, int write_total) {
+    if (write_total && blockIdx.x == 0 && threadIdx.x < 64) {     // (the list's length where the one-launch step looks for it; the spread counters back to zero)
+        int v = threadIdx.x < ATT_SLOTS ? W.counters[att_slot(threadIdx.x)] : 0;
+        if (threadIdx.x < ATT_SLOTS) W.counters[att_slot(threadIdx.x)] = 0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+        if (threadIdx.x == 0) W.counters[CTR_ATTACK] = v;
+    }
     const GroupDev G = W.grp[g];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool att = i < G.n && (G.pend[i] & ~PEND_ARG) == PEND_ATTACK;
@@ -1033,10 +1044,24 @@ __device__ __forceinline__ void shuffle_chase_body(int i, int A, const int *j, c
     rank[i] = p;
 }
 
-// (the draws of this step's list, length counters[CTR_ATTACK], and the hit words' zero-fill)
-__global__ void __launch_bounds__(256) k_shuffle_draw(const int *counters, int *j, int *head, int *first, int *link, unsigned *hitbits, size_t ncell,
-                                                     const unsigned *powtab) {
-    const int A = counters[CTR_ATTACK];
+// (the draws of this step's list and the hit words' zero-fill.  The list's length: counters[CTR_ATTACK] when the one-workgroup
+// set_action left it there, else -- `tiled` -- the sum of the spread counters of k_set_action_a, which workgroup 0 then leaves in
+// CTR_ATTACK for every later launch of the step)
+__global__ void __launch_bounds__(256) k_shuffle_draw(int *counters, int *j, int *head, int *first, int *link, unsigned *hitbits, size_t ncell,
+                                                     const unsigned *powtab, int tiled) {
+    int A;
+    if (tiled) {
+        __shared__ int s_a;
+        if (threadIdx.x < 64) {
+            int v = threadIdx.x < ATT_SLOTS ? counters[att_slot(threadIdx.x)] : 0;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+            if (threadIdx.x == 0) s_a = v;
+        }
+        __syncthreads();
+        A = s_a;
+        if (blockIdx.x == 0 && threadIdx.x == 0) counters[CTR_ATTACK] = A;
+    } else A = counters[CTR_ATTACK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     // the per-cell hit words of the coming attack phase start from zero (they share the move phase's claim array)
     if (hitbits && A > 0) for (size_t c = i; c < ncell; c += (size_t)gridDim.x * blockDim.x) hitbits[c] = 0u;
@@ -1187,7 +1212,7 @@ __device__ __forceinline__ bool set_eat(const WorldView &W, const GroupDev *gtab
 // (s_rank / s_ref: the thread's hit list, stride ATT_THREADS, slot tid; flagp: where to report a change, or null)
 __device__ __forceinline__ void attack_eval_body(const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int g, int i,
                                                  int round /* 1, 2, ... within this step */, const unsigned *hitbits,
-                                                 unsigned *s_rank, int *s_ref, int ATT_THREADS, int tid, int *flagp, int kmax, int *round_flags = nullptr) {
+                                                 unsigned *s_rank, int *s_ref, int ATT_THREADS, int tid, int *flagp, int kmax) {
     const GroupDev &G = W.grp[g];
     const TypeDev &T = W.type[g];
     const int dr_me_cur = G.drank_a[i];
@@ -1290,50 +1315,19 @@ __device__ __forceinline__ void attack_eval_body(const WorldView &W, const Group
         if (W.any_kill_supply)
             for (int k = 0; k < nh; k++) { const int a = s_ref[k * ATT_THREADS + tid]; gtab[ref_group(a)].drank_b[ref_index(a)] = round; }
         if (flagp) *flagp = 1;                        // (multi-launch driver: only the last round of a batch reports)
-        if (round_flags) round_flags[round & (ROUND_SLOTS - 1)] = 1;
     }
 }
-// (the head of the fused step of plain games rides in round 1: see "the fused step of plain games" below)
-constexpr unsigned MV_DIED = 0xFFFFFFFCu;   // `ms` between k_strike and k_plain_init: killed or starved in this step, still on the map
-
-__device__ __forceinline__ void plain_head_body(const WorldView &W, int g, int i) {
-    const GroupDev &G = W.grp[g];
-    const TypeDev &T = W.type[g];
-    const int told = G.tm[i];
-    if (told >= 0) W.claim[told] = CLAIM_NONE;           // (idempotent: a stale entry cleans a clean word)
-    int t = -1;
-    const int pend = G.pend[i];
-    if (!G.dead[i] && (pend & ~PEND_ARG) == PEND_MOVE) {
-        const int2 d = W.delta[T.move_off + (pend & PEND_ARG)];
-        const int nx = G.x[i] + d.x, ny = G.y[i] + d.y;
-        // is_blank_area bounds (Map.cc:455) for a 1x1 body; a zero move "succeeds" in place and never vacates
-        if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + 1 < W.w && ny + 1 < W.h && W.occ[ny * W.w + nx] != OCC_WALL) t = ny * W.w + nx;
-    }
-    G.tm[i] = t;
-    G.mv[i] = __float_as_uint(G.hp[i]);                  // (attack_eval_body overwrites it for the agents that are hit)
-}
-
 // workgroup size: as large as the hit lists (kmax x threads x 8 B of LDS) allow, see att_threads()
 __global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab, int round,
-                                                     const unsigned *hitbits, int kmax, int flag, TmHigh H) {
+                                                     const unsigned *hitbits, int kmax, int flag) {
+    if (W.counters[CTR_ATTACK] == 0) return;
     extern __shared__ unsigned s_hit[];               // [kmax][ATT_THREADS] ranks, then [kmax][ATT_THREADS] refs
     const int ATT_THREADS = blockDim.x;
     const int g = blockIdx.y, tid = threadIdx.x;
     const int i = blockIdx.x * blockDim.x + tid;
-    if (i >= W.grp[g].n) {
-        // entries of agents that clear_dead has compacted away since their last fused step: their claim words are cleaned here
-        if (W.plain && round == 1 && i < H.hi[g]) {
-            const int told = W.grp[g].tm[i];
-            if (told >= 0) { W.claim[told] = CLAIM_NONE; W.grp[g].tm[i] = -1; }
-        }
-        return;
-    }
-    if (W.plain && round == 1) plain_head_body(W, g, i);   // (rides here: this launch visits every agent of every step, attacks or not)
-    if (W.counters[CTR_ATTACK] == 0) return;
-    // nobody's death rank changed in the round before: nobody is stamped for this one (plain games: food cells stamp eaters elsewhere)
-    if (W.plain && round > 1 && W.counters[CTR_ROUND_CHANGED + ((round - 1) & (ROUND_SLOTS - 1))] == 0) return;
+    if (i >= W.grp[g].n) return;
     attack_eval_body(W, gtab, ttab, g, i, round, hitbits, s_hit, (int *)(s_hit + kmax * ATT_THREADS), ATT_THREADS, tid,
-                     flag >= 0 ? &W.counters[flag] : nullptr, kmax, W.plain ? &W.counters[CTR_ROUND_CHANGED] : nullptr);
+                     flag >= 0 ? &W.counters[flag] : nullptr, kmax);
 }
 
 // food_mode: the food that lay on the map before this step.  One thread per cell: the hits on a food cell eat from it
@@ -1634,23 +1628,148 @@ __global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev
     if (W.live_paint) repaint_body(W, W.grp[g], W.type[g], g, i);
 }
 
-// ------------------------------------------------------------------------------------------------ the fused step of plain games
+// ------------------------------------------------------------------------------------------------ the step of plain games
 // Plain games -- one-cell bodies, no turn_mode / food_mode / goals / kill_supply: battle, gather, every BASELINE configuration but the
-// reference's own 1M harness -- step through FOUR per-agent passes behind the death-rank rounds instead of eight:
-//   (beside round 1 of k_attack_eval)  plain_head_body: the cell my move is aimed at (`tm`), my hp as the attack phase will leave it
-//                                      unless somebody hits me (`mv`), and the claim word my LAST step's move left behind cleaned
-//   k_strike     what k_attack_apply, starve_body, k_rule (rules that pay the subject), k_move_prep and k_move_claim did in five
-//                launches: every agent finishes its own attack phase from the converged death ranks, starves / recovers, is paid by
-//                the rules, and claims its target cell.  Nobody writes the map in this pass, so everybody still finds targets and
-//                occupants through the phase-start map; whether an occupant is still there when the moves begin -- it may have been
-//                killed, or starve -- is decided by the claimant from the occupant's death rank and `mv` (what starve_body would do
-//                with it).  Attackers wipe the hit bit they set: the hit words are zero again when the pass ends.
-//   k_plain_init who won its cell, and on whom its move depends (k_move_init, without the map lookup: k_strike saved what it saw);
-//                the agents that died in this step leave the map here, after its last reader
-//   k_plain_commit  k_move_commit on `tm` / `ms`
-// The claim words are cleaned by their owners (plain_head_body, k_clear_compact) and the hit words by the attackers: no per-cell pass
-// is left in the step -- at BASELINE config 5's 3536 x 3536 cells the two fills were 150 MB per step.  The host keeps track of who
-// left the words in which state (engine.hip: claim_clean / claim_tm_only / hit_clean).
+// reference's own 1M harness -- have a pipeline of their own behind the shuffle (round 4).  Five kinds of per-agent launches where the
+// generic step has nine, and half the dependent gathers per launch:
+//   k_plain_rank   every agent: its record {order key | rank in the shuffled attack list, death rank = "never"}, the cell its move is aimed
+//                  at (`tm`), its hp as the attack phase will leave it unless somebody hits it (`mv`), and the claim word its LAST step's
+//                  move left behind cleaned.  An attacker looks its target up ONCE, here: it keeps the target's reference (`atk`) and
+//                  hands the target its hit -- {rank, attacker} into the target's own slot for (attacker group, attack offset), one bit
+//                  into the target's hit mask.  Nobody looks an attacker up through the map afterwards.
+//   k_plain_eval   the death-rank fixed point (attack_eval_body for this case): an agent reads its mask (coalesced), its own slots, and
+//                  the death rank of each attacker -- one gather per hit where the generic form has three (map, key, death rank) plus two
+//                  for its own target.  A round whose predecessor changed nothing returns at once.
+//   k_strike       what k_attack_apply, starve_body, k_rule (rules that pay the attacker), k_move_prep and k_move_claim do in five
+//                  launches: every agent finishes its own attack phase from the converged death ranks, starves / recovers, is paid by the
+//                  rules, and claims its target cell.  Nobody writes the map in this pass, so occupants are still found through the
+//                  phase-start map; whether an occupant is still there when the moves begin -- it may have been killed, or starve -- is
+//                  decided by the claimant from the occupant's record and `mv` (what starve_body would do with it).
+//   k_plain_init   who won its cell, and on whom its move depends (k_move_init without the map lookup: k_strike saved what it saw);
+//                  the agents that died in this step leave the map here, after its last reader
+//   k_plain_commit k_move_commit on the records
+// Per-agent state that other agents read lives in ONE 16-byte record per agent (`rec`: a claimant reads its occupant's key, death rank
+// and target with one request).  The claim words are cleaned by their owners (k_plain_rank) and the hit masks by theirs (k_strike): no
+// per-cell pass is left in the step -- at BASELINE config 5's 3536 x 3536 cells the two fills were 150 MB per step.  The host keeps
+// track of who left the words in which state (engine.hip: scratch_for).
+constexpr unsigned MV_DIED = 0xFFFFFFFCu;   // move status between k_strike and k_plain_init: killed or starved in this step, still on the map
+
+__global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, const PlainGroup *ptab, const int *rank, int *shuf_head, int *shuf_first,
+                                                   const int *sums, const int *wpre, SeqPlan P) {
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // attack rounds start
+    const int A = W.counters[CTR_ATTACK];
+    // the shuffle's list heads and first-hit words have been read for the last time (k_shuffle_chase): back to zero for their next use
+    for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < A; k += gridDim.x * gridDim.y * blockDim.x) {
+        shuf_head[k] = 0; shuf_first[k] = 0;
+    }
+    const int g = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const GroupDev &G = W.grp[g];
+    const TypeDev &T = W.type[g];
+    const int n = G.n;
+    if ((int)(blockIdx.x * blockDim.x) >= n) {
+        // entries of agents that clear_dead has compacted away since their last step: the claim words their moves left are cleaned here
+        if (i < PW.hi[g]) {
+            const int told = PW.g[g].rec[i].z;
+            if (told >= 0) { W.claim[told] = CLAIM_NONE; PW.g[g].rec[i].z = -1; }
+        }
+        return;
+    }
+    const int pend = i < n ? G.pend[i] : PEND_NONE;
+    const bool att = (pend & ~PEND_ARG) == PEND_ATTACK;
+    int seq = -1;
+    if (A != 0 && P.off[g] >= 0) seq = attack_seq(sums, wpre, P.off[g], i, att);   // (every thread of the workgroup)
+    if (i >= n) {
+        if (i < PW.hi[g]) {
+            const int told = PW.g[g].rec[i].z;
+            if (told >= 0) { W.claim[told] = CLAIM_NONE; PW.g[g].rec[i].z = -1; }
+        }
+        return;
+    }
+    const bool dead = G.dead[i];
+    const int x = G.x[i], y = G.y[i];
+    unsigned key = G.key[i];          // a move's order key -- or, from the one-workgroup set_action, the attack's sequence number
+    const int told = PW.g[g].rec[i].z;
+    if (told >= 0) W.claim[told] = CLAIM_NONE;           // (idempotent: a stale entry cleans a clean word)
+    int tgt = -1, t = -1;
+    if (!dead && att) {
+        key = (unsigned)rank[seq >= 0 ? seq : (int)key];
+        const int k = pend & PEND_ARG;
+        const int2 d = W.delta[T.attack_off + k];
+        const int tx = x + d.x, ty = y + d.y;
+        if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
+            const int o = W.occ[ty * W.w + tx];
+            if (o >= 0 && (T.attack_in_group || ref_group(o) != g)) {       // Map::get_attack_obj (Map.cc:229-247)
+                tgt = o;
+                const PlainGroup TG = ptab[ref_group(o)];
+                const int slot = T.attack_bit + k;
+                TG.hlist[(size_t)ref_index(o) * PW.S + slot] = make_uint2(key, (unsigned)ref_pack(g, i));
+                atomicOr(&TG.hmask[ref_index(o)], 1u << slot);
+            }
+        }
+    } else if (att) {
+        key = (unsigned)rank[seq >= 0 ? seq : (int)key];   // (dead before the step: its list entry exists, and does nothing)
+    } else if (!dead && (pend & ~PEND_ARG) == PEND_MOVE) {
+        const int2 d = W.delta[T.move_off + (pend & PEND_ARG)];
+        const int nx = x + d.x, ny = y + d.y;
+        // is_blank_area bounds (Map.cc:455) for a 1x1 body; a zero move "succeeds" in place and never vacates
+        if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + 1 < W.w && ny + 1 < W.h && W.occ[ny * W.w + nx] != OCC_WALL) t = ny * W.w + nx;
+    }
+    PW.g[g].rec[i] = make_int4((int)key, dead ? -1 : RANK_INF, t, (int)MV_FAIL);
+    PW.g[g].atk[i] = tgt;
+    G.drank_b[i] = 0;                                    // "inputs changed in round 0": everybody who is hit is evaluated in round 1
+    G.mv[i] = __float_as_uint(G.hp[i]);                  // (k_plain_eval overwrites it for the agents that are hit)
+}
+
+// (s_rank / s_ref: the thread's hit list, stride NT, slot tid -- sort_hits)
+__global__ void __launch_bounds__(256) k_plain_eval(WorldView W, PlainWorld PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, int round, int flag) {
+    if (W.counters[CTR_ATTACK] == 0) return;
+    // nobody's death rank changed in the round before: nobody is stamped for this one
+    if (round > 1 && W.counters[CTR_ROUND_CHANGED + ((round - 1) & (ROUND_SLOTS - 1))] == 0) return;
+    extern __shared__ unsigned s_hit[];
+    const int NT = blockDim.x, tid = threadIdx.x;
+    unsigned *s_rank = s_hit;
+    int *s_ref = (int *)(s_hit + PW.kmax * NT);
+    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + tid;
+    const GroupDev &G = W.grp[g];
+    if (i >= G.n) return;
+    if (G.drank_b[i] < round - 1) return;                // no input has changed since my last evaluation
+    unsigned mask = PW.g[g].hmask[i];
+    if (!mask) return;                                   // nobody hits me: I stay alive (RANK_INF, the initial value)
+    const int dr_cur = PW.g[g].rec[i].y;
+    if (dr_cur == -1) return;                            // dead before the phase (never a target: it is off the map)
+    int nh = 0;
+    const uint2 *mine = PW.g[g].hlist + (size_t)i * PW.S;
+    while (mask) {
+        const int slot = __ffs(mask) - 1;
+        mask &= mask - 1;
+        const uint2 e = mine[slot];
+        s_rank[nh * NT + tid] = e.x; s_ref[nh * NT + tid] = (int)e.y;
+        nh++;
+    }
+    sort_hits(s_rank, s_ref, NT, tid, nh);
+    // replay in rank order: a hit counts iff its attacker did not die at an EARLIER rank
+    float hp = G.hp[i];
+    int dr = RANK_INF;
+    for (int k = 0; k < nh; k++) {
+        const unsigned r = s_rank[k * NT + tid];
+        const int a = s_ref[k * NT + tid];
+        const int adr = ptab[ref_group(a)].rec[ref_index(a)].y;
+        if ((unsigned)adr >= r) {
+            hp -= ttab[ref_group(a)].damage;
+            if (hp < 0.0f) { dr = (int)r; break; }       // death iff hp < 0 strictly (GridWorld.h:205)
+        }
+    }
+    G.mv[i] = __float_as_uint(hp);                       // final once the death ranks are: k_strike takes it from here
+    if (dr != dr_cur) {
+        PW.g[g].rec[i].y = dr;
+        const int reader = PW.g[g].atk[i];               // who reads my death rank: my target (is its attacker alive at that rank?)
+        if (reader >= 0) gtab[ref_group(reader)].drank_b[ref_index(reader)] = round;
+        if (flag >= 0) W.counters[flag] = 1;             // (only the last round of a batch reports)
+        W.counters[CTR_ROUND_CHANGED + (round & (ROUND_SLOTS - 1))] = 1;
+    }
+}
+
 // rules of the shape Event(a, attack | kill, b) that pay receivers bound to `a` only: evaluated by the agent itself, in rule order,
 // as soon as its own attack is known -- provided every last_op was OP_NULL when the step began (clear_dead has run since the last step:
 // otherwise an event of the LAST step is paid again unless a collision overwrites it, which only the move phase knows; the host then
@@ -1660,7 +1779,7 @@ struct StrikeRules {
     struct One { int ga, gb, op, rule_no, n_subj; float v[4]; } r[4];
 };
 
-__global__ void __launch_bounds__(256) k_strike(WorldView W, const GroupDev *gtab, const TypeDev *ttab, StrikeRules R) {
+__global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, StrikeRules R) {
     if (attack_open(W)) return;
     const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     const GroupDev &G = W.grp[g];
@@ -1672,26 +1791,19 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, const GroupDev *gta
         const int pend = G.pend[i];
         if (pend != PEND_NONE) G.last_action[i] = pend_action(pend, T);     // Agent::set_action's `last_action = act` (see k_set_action_a)
         bool dead = G.dead[i];
-        const int x = G.x[i], y = G.y[i];
-        float hp = __uint_as_float(G.mv[i]);             // hp after the attack phase (plain_head_body / the last evaluation)
+        const int4 me = PW.g[g].rec[i];                  // {key | rank, death rank, move target, -}
+        float hp = __uint_as_float(G.mv[i]);             // hp after the attack phase (k_plain_rank / the last evaluation)
         float nr = G.next_reward[i];
         int last_op = OP_NULL, op_obj = -1;              // (what clear_dead left: with rules fused, the host has seen it run since the last step)
         // ---- the attack phase applied from the converged death ranks (attack_apply_body, one-cell bodies, no supply)
         if (attacked && !dead) {
-            const int dr = G.drank_a[i];
+            if (PW.g[g].hmask[i]) PW.g[g].hmask[i] = 0u; // my hit mask: read for the last time by the rounds
             if ((pend & ~PEND_ARG) == PEND_ATTACK) {
-                const unsigned my_rank = G.key[i];
-                const int2 tc = attack_target(W, G, T, i, pend & PEND_ARG);
-                int tgt = -1, tgt_dr = RANK_INF;
-                if (tc.x >= 0 && tc.x < W.w && tc.y >= 0 && tc.y < W.h) {
-                    const int o = W.occ[tc.y * W.w + tc.x];
-                    if (o >= 0 && (T.attack_in_group || ref_group(o) != g)) {
-                        tgt = o;
-                        tgt_dr = gtab[ref_group(o)].drank_a[ref_index(o)];
-                        W.hitbits[tc.y * W.w + tc.x] = 0u;                   // my bit, and the word's other setters do the same
-                    }
-                }
-                if ((unsigned)dr >= my_rank) {               // alive at my turn (GridWorld.cc:479-480)
+                const unsigned my_rank = (unsigned)me.x;
+                const int tgt = PW.g[g].atk[i];
+                int tgt_dr = RANK_INF;
+                if (tgt >= 0) tgt_dr = ptab[ref_group(tgt)].rec[ref_index(tgt)].y;
+                if ((unsigned)me.y >= my_rank) {             // alive at my turn (GridWorld.cc:479-480)
                     float own;
                     if (tgt < 0 || (unsigned)tgt_dr < my_rank) own = T.attack_penalty;   // blank, or the target died before my turn (Map.cc:229-231)
                     else {
@@ -1705,7 +1817,7 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, const GroupDev *gta
                     nr += own;
                 }
             }
-            if (dr != RANK_INF) { dead = died = true; nr = T.dead_penalty; }   // dead_penalty overwrites what was accumulated (GridWorld.h:207)
+            if (me.y != RANK_INF) { dead = died = true; nr = T.dead_penalty; }   // dead_penalty overwrites what was accumulated (GridWorld.h:207)
         }
         // ---- starve / recover (GridWorld.cc:519-542)
         if (!dead) {
@@ -1727,27 +1839,23 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, const GroupDev *gta
         }
         G.next_reward[i] = nr;
         // ---- my move: the claim on its target cell (move_prep_body + move_claim_body)
-        unsigned ms = died ? MV_DIED : MV_FAIL;
-        if (!dead && (pend & ~PEND_ARG) == PEND_MOVE) {
-            const int c = G.tm[i];
-            if (c >= 0) {
-                const unsigned key = G.key[i];
-                int o = W.occ[c];
-                bool ok = o == OCC_EMPTY;
-                if (o >= 0) {
-                    const GroupDev O = gtab[ref_group(o)];
-                    const int oi = ref_index(o);
-                    const float orec = ttab[ref_group(o)].step_recover;
-                    bool gone = attacked && O.drank_a[oi] != RANK_INF;                          // killed in this step's attack phase
-                    if (!gone && !(orec > 0)) gone = __uint_as_float(O.mv[oi]) - (-orec) < 0.0f;   // ... or about to starve
-                    if (gone) { ok = true; o = OCC_EMPTY; }                                      // the cell is empty when the moves begin
-                    else ok = O.tm[oi] >= 0 && O.key[oi] < key;                                  // the occupant may leave, and before my turn
-                }
-                G.drank_b[i] = o;            // what my target cell holds when the moves begin, for k_plain_init / k_plain_commit
-                if (ok) atomicMin(&W.claim[c], ((unsigned long long)key << 32) | (unsigned)ref_pack(g, i));
+        if (!dead && me.z >= 0) {
+            const int c = me.z;
+            const unsigned key = (unsigned)me.x;
+            int o = W.occ[c];
+            bool ok = o == OCC_EMPTY;
+            if (o >= 0) {
+                const int4 oc = ptab[ref_group(o)].rec[ref_index(o)];
+                const float orec = ttab[ref_group(o)].step_recover;
+                bool gone = attacked && oc.y != RANK_INF;                                       // killed in this step's attack phase
+                if (!gone && !(orec > 0)) gone = __uint_as_float(gtab[ref_group(o)].mv[ref_index(o)]) - (-orec) < 0.0f;   // ... or about to starve
+                if (gone) { ok = true; o = OCC_EMPTY; }                                          // the cell is empty when the moves begin
+                else ok = oc.z >= 0 && (unsigned)oc.x < key;                                     // the occupant may leave, and before my turn
             }
+            G.drank_b[i] = o;                // what my target cell holds when the moves begin, for k_plain_init / k_plain_commit
+            if (ok) atomicMin(&W.claim[c], ((unsigned long long)key << 32) | (unsigned)ref_pack(g, i));
         }
-        G.ms[i] = ms;
+        if (died) PW.g[g].rec[i].w = (int)MV_DIED;
     }
     int wtot;
     wave_rank(died, wtot);
@@ -1756,37 +1864,38 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, const GroupDev *gta
         if (__ballot((trig >> k) & 1u) && lane_id() == 0) W.counters[CTR_TRIGGER + R.r[k].rule_no] = 1;
 }
 
-__global__ void __launch_bounds__(256) k_plain_init(WorldView W) {
+__global__ void __launch_bounds__(256) k_plain_init(WorldView W, PlainWorld PW) {
     if (attack_open(W)) return;
     const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     const GroupDev &G = W.grp[g];
     if (i >= G.n) return;
-    const unsigned ms = G.ms[i];
-    if (ms == MV_DIED) {                         // Map::remove_agent (Map.cc:272, GridWorld.cc:536): nobody reads the map in this launch
+    const int4 me = PW.g[g].rec[i];
+    if ((unsigned)me.w == MV_DIED) {             // Map::remove_agent (Map.cc:272, GridWorld.cc:536): nobody reads the map in this launch
         cells_clear(W, G.x[i], G.y[i], 1, 1);
-        G.ms[i] = MV_FAIL;
+        PW.g[g].rec[i].w = (int)MV_FAIL;
         return;
     }
-    const int c = G.tm[i];
+    const int c = me.z;
     if (c < 0 || G.dead[i]) return;
     if ((unsigned)W.claim[c] != (unsigned)ref_pack(g, i)) return;   // not the static winner (or no claim of mine): stays MV_FAIL
     const int o = G.drank_b[i];
-    G.ms[i] = o == OCC_EMPTY ? MV_OK : (unsigned)o;                 // succeeds iff the occupant o succeeds
+    PW.g[g].rec[i].w = o == OCC_EMPTY ? (int)MV_OK : o;             // succeeds iff the occupant o succeeds
 }
 
-__device__ __forceinline__ unsigned plain_resolve(const GroupDev *gtab, unsigned m) {
-    while (m < MV_DIED) m = gtab[ref_group((int)m)].ms[ref_index((int)m)];
+__device__ __forceinline__ unsigned plain_resolve(const PlainGroup *ptab, unsigned m) {
+    while (m < MV_DIED) m = (unsigned)ptab[ref_group((int)m)].rec[ref_index((int)m)].w;
     return m;
 }
-// (move_commit_body on `tm` / `ms`: see there)
-__global__ void __launch_bounds__(256) k_plain_commit(WorldView W, const GroupDev *gtab) {
+// (move_commit_body on the records: see there)
+__global__ void __launch_bounds__(256) k_plain_commit(WorldView W, PlainWorld PW, const PlainGroup *ptab) {
     if (attack_open(W)) return;
     const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     const GroupDev &G = W.grp[g];
     if (i >= G.n) return;
-    const int c = G.tm[i];
+    const int4 me = PW.g[g].rec[i];
+    const int c = me.z;
     if (c >= 0 && !G.dead[i]) {
-        if (plain_resolve(gtab, G.ms[i]) == MV_OK) {
+        if (plain_resolve(ptab, (unsigned)me.w) == MV_OK) {
             const int old = G.y[i] * W.w + G.x[i];
             if (W.claim[old] == CLAIM_NONE) { W.occ[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }
             W.occ[c] = ref_pack(g, i);
@@ -1797,9 +1906,8 @@ __global__ void __launch_bounds__(256) k_plain_commit(WorldView W, const GroupDe
             int blocker;
             if (o == OCC_EMPTY) blocker = (int)(unsigned)W.claim[c];       // lost an empty cell to the lowest key
             else {
-                const GroupDev O = gtab[ref_group(o)];
-                const int oi = ref_index(o);
-                const bool left_before = plain_resolve(gtab, O.ms[oi]) == MV_OK && O.key[oi] < G.key[i];
+                const int4 oc = ptab[ref_group(o)].rec[ref_index(o)];
+                const bool left_before = plain_resolve(ptab, (unsigned)oc.w) == MV_OK && (unsigned)oc.x < (unsigned)me.x;
                 blocker = left_before ? (int)(unsigned)W.claim[c] : o;
             }
             G.last_op[i] = OP_COLLIDE;
@@ -3088,16 +3196,16 @@ void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *acti
     int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_set_action_a, dim3(nb), dim3(SCAN_THREADS), 0, s, W, g, actions, call_base, sums, wpre, tile_off);
 }
-void launch_seq_assign(hipStream_t s, const WorldView &W, int g, const int *sums, const int *wpre, int tile_off) {
+void launch_seq_assign(hipStream_t s, const WorldView &W, int g, const int *sums, const int *wpre, int tile_off, bool write_total) {
     int n = W.grp[g].n;
-    if (n > 0) hipLaunchKernelGGL(k_seq_assign, dim3((n + 255) / 256), dim3(256), 0, s, W, g, sums, wpre, tile_off);
+    if (n > 0) hipLaunchKernelGGL(k_seq_assign, dim3((n + 255) / 256), dim3(256), 0, s, W, g, sums, wpre, tile_off, write_total ? 1 : 0);
 }
 
 // n_max = upper bound of the attack-list length (the number of agents); the actual length is read on the device
-void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell, const unsigned *powtab) {
+void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell, const unsigned *powtab, bool tiled) {
     // head / first are zero here: zeroed when allocated, and again by k_attack_rank after every use
     dim3 g((n_max + 255) / 256), b(256);
-    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, B.j, B.head, B.first, B.link, hitbits, ncell, powtab);
+    hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, B.j, B.head, B.first, B.link, hitbits, ncell, powtab, tiled ? 1 : 0);
     hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, B.j, B.head, B.first, B.link, rank);
 }
 // ================================================================================================ repeated set_action: the literal loop
@@ -3245,16 +3353,10 @@ bool attack_lds_ok(int kmax) {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_attack_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
            hipFuncSetAttribute(reinterpret_cast<const void *>(k_food_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
 }
-void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag, const TmHigh *tm_high) {
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag) {
     const int ATT_THREADS = att_threads(kmax);
     size_t lds = (size_t)kmax * ATT_THREADS * 8;
-    TmHigh H{};
-    dim3 grid = grid_all(W, ATT_THREADS);
-    if (tm_high && round == 1) {
-        H = *tm_high;
-        for (int g = 0; g < W.G; g++) grid.x = std::max<unsigned>(grid.x, (unsigned)((H.hi[g] + ATT_THREADS - 1) / ATT_THREADS));
-    }
-    hipLaunchKernelGGL(k_attack_eval, grid, dim3(ATT_THREADS), lds, s, W, gtab, ttab, round, (const unsigned *)W.hitbits, kmax, flag, H);
+    hipLaunchKernelGGL(k_attack_eval, grid_all(W, ATT_THREADS), dim3(ATT_THREADS), lds, s, W, gtab, ttab, round, (const unsigned *)W.hitbits, kmax, flag);
     if (W.food_mode) launch_food_iter(s, W, gtab, ttab, round, kmax, flag);   // the food cells are part of the same fixed point
 }
 void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag) {
@@ -3306,15 +3408,34 @@ void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) 
     hipLaunchKernelGGL(k_movg_vacate, g, dim3(256), 0, s, W);
     hipLaunchKernelGGL(k_movg_enter, g, dim3(256), 0, s, W);
 }
-// the fused step of plain games behind the death-rank rounds: k_strike, k_plain_init, k_plain_commit.  `rules`: the compiled rules, if
-// every one of them pays the subject of one event only (fused_rules); else null, and launch_rules runs behind the commit as usual
+// the step of plain games behind the shuffle: k_plain_rank, rounds of k_plain_eval, then k_strike, k_plain_init, k_plain_commit
+// (launch_plain_tail).  `rules`: the compiled rules, if every one of them pays the attacker of one event only (fused_rules); else
+// null, and launch_rules runs behind the commit as usual
 bool fused_rules(const RuleArgs *rules, int n) {
     if (n > 4) return false;
     // (attack-phase events only: `collide` is decided by the move phase, behind k_strike)
     for (int k = 0; k < n; k++) if (rules[k].pair || rules[k].prog >= 0 || rules[k].n_obj || (rules[k].op != OP_ATTACK && rules[k].op != OP_KILL)) return false;
     return true;
 }
-void launch_plain_tail(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, const RuleArgs *rules, int n_rules) {
+static dim3 plain_grid(const WorldView &W, const PlainWorld &PW, bool cover_hi) {
+    dim3 g = grid_all(W, 256);
+    if (cover_hi) for (int q = 0; q < W.G; q++) g.x = std::max<unsigned>(g.x, (unsigned)((PW.hi[q] + 255) / 256));
+    return g;
+}
+void launch_plain_rank(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const int *rank, const ShuffleBufs &B, const int *sums,
+                       const int *wpre, const SeqPlan &P) {
+    hipLaunchKernelGGL(k_plain_rank, plain_grid(W, PW, true), dim3(256), 0, s, W, PW, ptab, rank, B.head, B.first, sums, wpre, P);
+}
+size_t plain_eval_lds(int kmax) { return (size_t)kmax * 256 * 8; }
+bool plain_eval_lds_ok(int kmax) {
+    if (plain_eval_lds(kmax) <= (48u << 10)) return true;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_plain_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plain_eval_lds(kmax)) == hipSuccess;
+}
+void launch_plain_eval(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, int round, int flag) {
+    hipLaunchKernelGGL(k_plain_eval, grid_all(W, 256), dim3(256), plain_eval_lds(PW.kmax), s, W, PW, ptab, gtab, ttab, round, flag);
+}
+void launch_plain_tail(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab,
+                       const RuleArgs *rules, int n_rules) {
     StrikeRules R{};
     if (rules) {
         R.n = n_rules;
@@ -3324,9 +3445,9 @@ void launch_plain_tail(hipStream_t s, const WorldView &W, const GroupDev *gtab, 
         }
     }
     dim3 g = grid_all(W, 256);
-    hipLaunchKernelGGL(k_strike, g, dim3(256), 0, s, W, gtab, ttab, R);
-    hipLaunchKernelGGL(k_plain_init, g, dim3(256), 0, s, W);
-    hipLaunchKernelGGL(k_plain_commit, g, dim3(256), 0, s, W, gtab);
+    hipLaunchKernelGGL(k_strike, g, dim3(256), 0, s, W, PW, ptab, gtab, ttab, R);
+    hipLaunchKernelGGL(k_plain_init, g, dim3(256), 0, s, W, PW);
+    hipLaunchKernelGGL(k_plain_commit, g, dim3(256), 0, s, W, PW, ptab);
 }
 
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {

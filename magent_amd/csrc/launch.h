@@ -118,24 +118,36 @@ void launch_render_multi(hipStream_t s, const WorldView &W, const RenderMulti &M
 void launch_features(hipStream_t s, const WorldView &W, const RenderArgs &R, const RenderPlan &P, bool vec4);
 // scratch of the attack shuffle: four int arrays of (at least) n_max entries; head / first are zero between steps
 struct ShuffleBufs { int *head, *first, *j, *link; };
-void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell, const unsigned *powtab);
+void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, int *rank, unsigned *hitbits, size_t ncell, const unsigned *powtab, bool tiled);
 void launch_set_rng(hipStream_t s, int *counters, unsigned x);
 void launch_step_reset(hipStream_t s, int *counters);
 void launch_set_counter(hipStream_t s, int *counters, int index, int value, int unless_index);
 // where a group's set_action call of this step left its tile counts (kernels.hip: k_set_action_a, attack_seq); -1: none / numbers in `key`
 struct SeqPlan { int off[MAXG]; };
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums, int *wpre, int tile_off /* < 0: one-workgroup form */);
-void launch_seq_assign(hipStream_t s, const WorldView &W, int g, const int *sums, const int *wpre, int tile_off);
+void launch_seq_assign(hipStream_t s, const WorldView &W, int g, const int *sums, const int *wpre, int tile_off, bool write_total);
 void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits, const int *sums, const int *wpre,
                         const SeqPlan &P);
-// per group: how many leading entries of `tm` may still point at a claim word their move left behind (the fused step of plain games
-// cleans them beside its first attack round; entries beyond the group's current size belong to agents clear_dead has compacted away)
-struct TmHigh { int hi[MAXG]; };
-void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */,
-                        const TmHigh *tm_high = nullptr);
+void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);
+// ---- the step of plain games (kernels.hip: "the step of plain games"): per-agent scratch of its own
+//   rec   {x: order key (move) | rank in the shuffled attack list (attack), y: death rank, z: the cell the move is aimed at (-1: none; kept
+//          until the next step cleans the claim word it left there), w: move status / dependency}: what OTHER agents read of an agent
+//   atk   the agent my attack lands on (-1: nobody)
+//   hmask bit (attacker group's attack_bit + offset) set: that attacker hits me in this step; hlist[agent][slot] = {rank, attacker}
+struct PlainGroup { int4 *rec; int *atk; unsigned *hmask; uint2 *hlist; };
+struct PlainWorld {
+    PlainGroup g[MAXG];
+    int S, kmax;          // slots per agent (attack offsets of all groups); most hits one agent can receive
+    int hi[MAXG];         // leading entries of rec whose z may still point at a claim word (beyond the group's size: agents compacted away)
+};
 bool fused_rules(const RuleArgs *rules, int n);
-void launch_plain_tail(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, const RuleArgs *rules /* null: not fused */, int n_rules);
+bool plain_eval_lds_ok(int kmax);
+void launch_plain_rank(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const int *rank, const ShuffleBufs &B, const int *sums,
+                       const int *wpre, const SeqPlan &P);
+void launch_plain_eval(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, int round, int flag);
+void launch_plain_tail(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab,
+                       const RuleArgs *rules /* null: not fused */, int n_rules);
 void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag);
 void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev);
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);   // starve / recover, then the move candidates
