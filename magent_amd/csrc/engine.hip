@@ -877,8 +877,8 @@ static void regrow(DevArena &arena, T *&p, size_t old_n, size_t ncap) {
 
 // the scratch of the step of plain games (launch.h: PlainGroup), for a group of capacity `cap` whose first n records are kept
 void Env::plain_arrays(HostGroup &g, size_t n, size_t cap) {
-    regrow(arena, g.pl.rec, n, cap);
-    HIP_OK(hipMemset(g.pl.rec + n, 0xFF, sizeof(int4) * (cap - n)));     // (no move target beyond: k_plain_rank cleans the claim word of every target it finds)
+    (void)n;
+    regrow(arena, g.pl.rec, 0, cap);                                     // (every record is written by k_plain_rank before anybody reads it)
     regrow(arena, g.pl.atk, 0, cap);
     regrow(arena, g.pl.hmask, 0, cap);
     HIP_OK(hipMemset(g.pl.hmask, 0, sizeof(unsigned) * cap));            // (every mask is zero between steps: k_strike leaves them so)
@@ -983,7 +983,7 @@ void Env::reset() {
         map_cells = ncell;
     }
     HIP_OK(hipMemset(d_hit, 0, sizeof(unsigned) * ncell));
-    claim_clean = claim_tm_only = false; hit_clean = true;
+    claim_clean = claim_epochs = false; hit_clean = true;
     if (food_mode && !d_food) HIP_OK(dev_malloc(arena, &d_food, sizeof(float) * 2 * ncell));   // amounts, then the attack phase's scratch
     if (d_food) HIP_OK(hipMemset(d_food, 0, sizeof(float) * 2 * ncell));
     h_occ.assign(ncell, OCC_EMPTY);
@@ -1022,7 +1022,6 @@ void Env::reset() {
         if (t.kill_supply != 0) any_kill_supply = 1;
         total_attack += t.attack.count;
         g.n = 0; g.group_reward = 0; g.acted = false; g.h_dead = 0; g.h_taken = 0; g.indexed = 0; g.sa_off = -1;
-        g.tm_high = 0;
     }
     // most hits one target can receive: attack offsets of every group allowed to attack it
     attack_kmax = 1;
@@ -1062,10 +1061,7 @@ void Env::reset() {
             if (g.pl.rec && (!plain || slots != plain_slots)) {      // (the configuration changed between two resets: built anew when agents are added)
                 dfree(arena, g.pl.rec); dfree(arena, g.pl.atk); dfree(arena, g.pl.hmask); dfree(arena, g.pl.hlist);
             }
-            if (g.pl.rec) {
-                HIP_OK(hipMemset(g.pl.rec, 0xFF, sizeof(int4) * g.cap));   // (the map may have changed its size: no stale move targets)
-                HIP_OK(hipMemset(g.pl.hmask, 0, sizeof(unsigned) * g.cap));
-            }
+            if (g.pl.rec) HIP_OK(hipMemset(g.pl.hmask, 0, sizeof(unsigned) * g.cap));
         }
         plain_world = plain; plain_slots = slots;
         ptab_valid = false;
@@ -1400,6 +1396,7 @@ void Env::set_action_device(int g, const int *d_act) {
         }
     }
     G.sa_off = off;
+    if ((long long)move_seq_base + G.n >= (1ll << 27)) fatal("more than 2^27 agents given actions in one step");   // (order keys: 27-bit insertion index, kernels.hip claim_word)
     hipStream_t s = action_stream();    // large worlds: beside the observation renders (see side_stream)
     ProfScope p(*this, "set_action", false, s);
     launch_set_action(s, view(), g, d_act, move_seq_base, d_asums, d_wpre, off);
@@ -1576,20 +1573,24 @@ void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 
 
 // The per-cell scratch words (claim, hitbits) as the three step paths want them and leave them:
 //   one-launch step / cycle (0): wants every claim word CLAIM_NONE and every hit word zero; keeps them so
-//   step of plain games (1): does not use the hit words (its hits live in per-agent masks); wants the claim words either clean or dirty
-//       only where the move target of some record below its group's tm_high points (those it cleans itself, in k_plain_rank); leaves
-//       them exactly like that
+//   step of plain games (1): does not use the hit words (its hits live in per-agent masks); its claim words carry the epoch of the step
+//       that wrote them (kernels.hip: claim_word) and are never cleaned -- it wants every word either filled (all ones) or written by a
+//       plain step of the current window of 63 epochs, so the array is refilled when a window begins and after any other path wrote it
 //   everything else (2): wants nothing (fills what it needs) and leaves both arrays dirty
 void Env::scratch_for(int path) {
     const size_t ncell = (size_t)width * height;
-    if (path == 2) { claim_clean = claim_tm_only = hit_clean = false; return; }
+    if (path == 2) { claim_clean = claim_epochs = hit_clean = false; return; }
     if (path == 0 && !hit_clean) { HIP_OK(hipMemsetAsync(d_hit, 0, sizeof(unsigned) * ncell, stream)); hit_clean = true; }
-    if (!claim_clean && !(path == 1 && claim_tm_only)) {
+    if (path == 1) {
+        plain_epoch++;
+        if (plain_epoch % 63u == 0) claim_epochs = false;      // a new window: the oldest words would look like this step's
+    }
+    if (!claim_clean && !(path == 1 && claim_epochs)) {
         HIP_OK(hipMemsetAsync(d_claim, 0xFF, sizeof(unsigned long long) * ncell, stream));
         claim_clean = true;
     }
-    if (path == 0) claim_tm_only = true;               // (clean is a special case of "dirty only at move targets")
-    else { claim_clean = false; claim_tm_only = true; }
+    if (path == 0) claim_epochs = true;                // (filled is a special case of "filled or written in this window")
+    else { claim_clean = false; claim_epochs = true; }
 }
 
 void Env::step(int *done) {
@@ -1725,7 +1726,6 @@ void Env::step_begin() {
                 ProfScope p(*this, "rules");
                 launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
             }
-            for (auto &g : groups) g.tm_high = std::max(g.tm_high, g.n);   // (entries below are cleaned by the next fused step)
         } else {
         {
             ProfScope p(*this, "attack");
@@ -1825,8 +1825,10 @@ void Env::step_begin() {
 
 PlainWorld Env::plain_view() {
     PlainWorld PW{};
-    for (size_t g = 0; g < groups.size(); g++) { PW.g[g] = groups[g].pl; PW.hi[g] = groups[g].tm_high; }
+    for (size_t g = 0; g < groups.size(); g++) PW.g[g] = groups[g].pl;
     PW.S = plain_slots; PW.kmax = attack_kmax;
+    PW.epoch = 62 - (int)(plain_epoch % 63u);
+    PW.round_base = (int)(plain_epoch * 64u);            // (wraps after 2^26 steps: the stamps are compared modulo 2^32)
     if (!ptab_valid) {
         if (!d_ptab) HIP_OK(dev_malloc(arena, &d_ptab, sizeof(PlainGroup) * MAXG));
         HIP_OK(hipMemcpyAsync(d_ptab, PW.g, sizeof(PlainGroup) * MAXG, hipMemcpyHostToDevice, stream));   // (pageable source: the copy is done when the call returns)

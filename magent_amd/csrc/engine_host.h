@@ -72,7 +72,6 @@ struct HostGroup {
     int indexed = 0;             // agents [0, indexed) have been through a clear_dead: Agent::index == position, else 0
     int sa_off = -1;             // this step's set_action call left its tile counts at d_asums[sa_off ...] (SeqPlan); -1: none / one-workgroup form
     PlainGroup pl{};             // scratch of the step of plain games (launch.h)
-    int tm_high = 0;             // leading records of pl.rec whose move target may point at a claim word a step left behind (PlainWorld::hi)
 };
 
 struct HostSymbol { int group = 0, index = 0; int ent_g = -1, ent_i = -1; };   // ent_*: the agent the host rule search last bound it to
@@ -218,7 +217,8 @@ private:
     int solo_nt_eval = 0;
     unsigned *d_hit = nullptr;            // per cell: hit bits / wanted counters of the one-launch step, zero between phases
     bool claim_clean = false;             // every claim word is CLAIM_NONE (the one-launch step keeps it so)
-    bool claim_tm_only = false;           // ... or dirty only where a `tm` entry below its group's tm_high points (the fused step of plain games)
+    bool claim_epochs = false;            // ... or written only by steps of the plain pipeline in the current window of epochs (scratch_for)
+    unsigned plain_epoch = 0;             // steps of the plain pipeline so far: claim-word epochs and round stamps derive from it
     bool hit_clean = false;               // every hit word is zero (both of those steps keep it so)
     void scratch_for(int path);
     int plain_steps = 0, plain_slots = 0;

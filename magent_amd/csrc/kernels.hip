@@ -1632,9 +1632,8 @@ __global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev
 // Plain games -- one-cell bodies, no turn_mode / food_mode / goals / kill_supply: battle, gather, every BASELINE configuration but the
 // reference's own 1M harness -- have a pipeline of their own behind the shuffle (round 4).  Five kinds of per-agent launches where the
 // generic step has nine, and half the dependent gathers per launch:
-//   k_plain_rank   every agent: its record {order key | rank in the shuffled attack list, death rank = "never"}, the cell its move is aimed
-//                  at (`tm`), its hp as the attack phase will leave it unless somebody hits it (`mv`), and the claim word its LAST step's
-//                  move left behind cleaned.  An attacker looks its target up ONCE, here: it keeps the target's reference (`atk`) and
+//   k_plain_rank   every agent: its record {order key | rank in the shuffled attack list, death rank = "never", the cell its move is aimed
+//                  at}.  An attacker looks its target up ONCE, here: it keeps the target's reference (`atk`) and
 //                  hands the target its hit -- {rank, attacker} into the target's own slot for (attacker group, attack offset), one bit
 //                  into the target's hit mask.  Nobody looks an attacker up through the map afterwards.
 //   k_plain_eval   the death-rank fixed point (attack_eval_body for this case): an agent reads its mask (coalesced), its own slots, and
@@ -1649,10 +1648,20 @@ __global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev
 //                  the agents that died in this step leave the map here, after its last reader
 //   k_plain_commit k_move_commit on the records
 // Per-agent state that other agents read lives in ONE 16-byte record per agent (`rec`: a claimant reads its occupant's key, death rank
-// and target with one request).  The claim words are cleaned by their owners (k_plain_rank) and the hit masks by theirs (k_strike): no
-// per-cell pass is left in the step -- at BASELINE config 5's 3536 x 3536 cells the two fills were 150 MB per step.  The host keeps
-// track of who left the words in which state (engine.hip: scratch_for).
+// and target with one request).  No per-cell pass is left in the step -- at BASELINE config 5's 3536 x 3536 cells the two fills of the
+// generic step are 150 MB per step: the hit masks are per agent and cleaned by their owners (k_strike), and a claim word carries the
+// EPOCH of the step that wrote it in its top bits (claim_word below), counting DOWN from step to step: a word of an earlier step loses
+// every atomicMin against this step's claims and reads as "nobody" -- nothing is cleaned; every 63rd step the host refills the array
+// (engine.hip: scratch_for).  The "inputs changed" stamps of the rounds count on across steps in the same way (PlainWorld::round_base).
 constexpr unsigned MV_DIED = 0xFFFFFFFCu;   // move status between k_strike and k_plain_init: killed or starved in this step, still on the map
+// claim word of the plain pipeline: [63:58] epoch (0..62; 63 = the fill pattern: nobody) | [57:30] order key (boundary bit, 27-bit insertion
+// index) | [29:0] agent reference.  Smaller = earlier: a later step's epoch is smaller, so stale words never win
+__device__ __forceinline__ unsigned long long claim_word(int epoch, unsigned key, int ref) {
+    const unsigned long long k28 = ((unsigned long long)(key >> 31) << 27) | (key & 0x7FFFFFFu);
+    return ((unsigned long long)epoch << 58) | (k28 << 30) | (unsigned)ref;
+}
+__device__ __forceinline__ bool claim_live(unsigned long long w, int epoch) { return (int)(w >> 58) == epoch; }
+__device__ __forceinline__ int claim_ref(unsigned long long w) { return (int)(w & 0x3FFFFFFFu); }
 
 __global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, const PlainGroup *ptab, const int *rank, int *shuf_head, int *shuf_first,
                                                    const int *sums, const int *wpre, SeqPlan P) {
@@ -1667,30 +1676,15 @@ __global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, 
     const GroupDev &G = W.grp[g];
     const TypeDev &T = W.type[g];
     const int n = G.n;
-    if ((int)(blockIdx.x * blockDim.x) >= n) {
-        // entries of agents that clear_dead has compacted away since their last step: the claim words their moves left are cleaned here
-        if (i < PW.hi[g]) {
-            const int told = PW.g[g].rec[i].z;
-            if (told >= 0) { W.claim[told] = CLAIM_NONE; PW.g[g].rec[i].z = -1; }
-        }
-        return;
-    }
+    if ((int)(blockIdx.x * blockDim.x) >= n) return;
     const int pend = i < n ? G.pend[i] : PEND_NONE;
     const bool att = (pend & ~PEND_ARG) == PEND_ATTACK;
     int seq = -1;
     if (A != 0 && P.off[g] >= 0) seq = attack_seq(sums, wpre, P.off[g], i, att);   // (every thread of the workgroup)
-    if (i >= n) {
-        if (i < PW.hi[g]) {
-            const int told = PW.g[g].rec[i].z;
-            if (told >= 0) { W.claim[told] = CLAIM_NONE; PW.g[g].rec[i].z = -1; }
-        }
-        return;
-    }
+    if (i >= n) return;
     const bool dead = G.dead[i];
     const int x = G.x[i], y = G.y[i];
     unsigned key = G.key[i];          // a move's order key -- or, from the one-workgroup set_action, the attack's sequence number
-    const int told = PW.g[g].rec[i].z;
-    if (told >= 0) W.claim[told] = CLAIM_NONE;           // (idempotent: a stale entry cleans a clean word)
     int tgt = -1, t = -1;
     if (!dead && att) {
         key = (unsigned)rank[seq >= 0 ? seq : (int)key];
@@ -1717,8 +1711,9 @@ __global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, 
     }
     PW.g[g].rec[i] = make_int4((int)key, dead ? -1 : RANK_INF, t, (int)MV_FAIL);
     PW.g[g].atk[i] = tgt;
-    G.drank_b[i] = 0;                                    // "inputs changed in round 0": everybody who is hit is evaluated in round 1
-    G.mv[i] = __float_as_uint(G.hp[i]);                  // (k_plain_eval overwrites it for the agents that are hit)
+    // hp as the attack phase leaves it unless somebody hits me (k_plain_eval overwrites it then): only claimants that must know whether
+    // their occupant is about to starve read it of an agent that was not hit -- types that recover never starve
+    if (!(T.step_recover > 0)) G.mv[i] = __float_as_uint(G.hp[i]);
 }
 
 // (s_rank / s_ref: the thread's hit list, stride NT, slot tid -- sort_hits)
@@ -1733,7 +1728,9 @@ __global__ void __launch_bounds__(256) k_plain_eval(WorldView W, PlainWorld PW, 
     const int g = blockIdx.y, i = blockIdx.x * blockDim.x + tid;
     const GroupDev &G = W.grp[g];
     if (i >= G.n) return;
-    if (G.drank_b[i] < round - 1) return;                // no input has changed since my last evaluation
+    // no input of mine has changed since my last evaluation (stamps are PW.round_base + round: they count on from step to step, nothing
+    // resets them; in round 1 everybody who is hit is evaluated)
+    if (round > 1 && (int)((unsigned)G.drank_b[i] - (unsigned)(PW.round_base + round - 1)) < 0) return;
     unsigned mask = PW.g[g].hmask[i];
     if (!mask) return;                                   // nobody hits me: I stay alive (RANK_INF, the initial value)
     const int dr_cur = PW.g[g].rec[i].y;
@@ -1764,7 +1761,7 @@ __global__ void __launch_bounds__(256) k_plain_eval(WorldView W, PlainWorld PW, 
     if (dr != dr_cur) {
         PW.g[g].rec[i].y = dr;
         const int reader = PW.g[g].atk[i];               // who reads my death rank: my target (is its attacker alive at that rank?)
-        if (reader >= 0) gtab[ref_group(reader)].drank_b[ref_index(reader)] = round;
+        if (reader >= 0) gtab[ref_group(reader)].drank_b[ref_index(reader)] = PW.round_base + round;
         if (flag >= 0) W.counters[flag] = 1;             // (only the last round of a batch reports)
         W.counters[CTR_ROUND_CHANGED + (round & (ROUND_SLOTS - 1))] = 1;
     }
@@ -1792,12 +1789,15 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
         if (pend != PEND_NONE) G.last_action[i] = pend_action(pend, T);     // Agent::set_action's `last_action = act` (see k_set_action_a)
         bool dead = G.dead[i];
         const int4 me = PW.g[g].rec[i];                  // {key | rank, death rank, move target, -}
-        float hp = __uint_as_float(G.mv[i]);             // hp after the attack phase (k_plain_rank / the last evaluation)
+        float hp = G.hp[i];
         float nr = G.next_reward[i];
         int last_op = OP_NULL, op_obj = -1;              // (what clear_dead left: with rules fused, the host has seen it run since the last step)
         // ---- the attack phase applied from the converged death ranks (attack_apply_body, one-cell bodies, no supply)
         if (attacked && !dead) {
-            if (PW.g[g].hmask[i]) PW.g[g].hmask[i] = 0u; // my hit mask: read for the last time by the rounds
+            if (PW.g[g].hmask[i]) {                       // somebody hit me: my last evaluation left my hp; the mask was read for the last time
+                PW.g[g].hmask[i] = 0u;
+                hp = __uint_as_float(G.mv[i]);
+            }
             if ((pend & ~PEND_ARG) == PEND_ATTACK) {
                 const unsigned my_rank = (unsigned)me.x;
                 const int tgt = PW.g[g].atk[i];
@@ -1852,8 +1852,8 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
                 if (gone) { ok = true; o = OCC_EMPTY; }                                          // the cell is empty when the moves begin
                 else ok = oc.z >= 0 && (unsigned)oc.x < key;                                     // the occupant may leave, and before my turn
             }
-            G.drank_b[i] = o;                // what my target cell holds when the moves begin, for k_plain_init / k_plain_commit
-            if (ok) atomicMin(&W.claim[c], ((unsigned long long)key << 32) | (unsigned)ref_pack(g, i));
+            PW.g[g].atk[i] = o;              // what my target cell holds when the moves begin, for k_plain_init / k_plain_commit (a mover has no attack target)
+            if (ok) atomicMin(&W.claim[c], claim_word(PW.epoch, key, ref_pack(g, i)));
         }
         if (died) PW.g[g].rec[i].w = (int)MV_DIED;
     }
@@ -1877,8 +1877,9 @@ __global__ void __launch_bounds__(256) k_plain_init(WorldView W, PlainWorld PW) 
     }
     const int c = me.z;
     if (c < 0 || G.dead[i]) return;
-    if ((unsigned)W.claim[c] != (unsigned)ref_pack(g, i)) return;   // not the static winner (or no claim of mine): stays MV_FAIL
-    const int o = G.drank_b[i];
+    const unsigned long long cl = W.claim[c];
+    if (!claim_live(cl, PW.epoch) || claim_ref(cl) != ref_pack(g, i)) return;   // not the static winner (or no claim of mine): stays MV_FAIL
+    const int o = PW.g[g].atk[i];
     PW.g[g].rec[i].w = o == OCC_EMPTY ? (int)MV_OK : o;             // succeeds iff the occupant o succeeds
 }
 
@@ -1897,18 +1898,18 @@ __global__ void __launch_bounds__(256) k_plain_commit(WorldView W, PlainWorld PW
     if (c >= 0 && !G.dead[i]) {
         if (plain_resolve(ptab, (unsigned)me.w) == MV_OK) {
             const int old = G.y[i] * W.w + G.x[i];
-            if (W.claim[old] == CLAIM_NONE) { W.occ[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }
+            if (!claim_live(W.claim[old], PW.epoch)) { W.occ[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }   // nobody claimed my cell
             W.occ[c] = ref_pack(g, i);
             const int ny = c / W.w;
             G.x[i] = c - ny * W.w; G.y[i] = ny;
         } else {
-            const int o = G.drank_b[i];
+            const int o = PW.g[g].atk[i];
             int blocker;
-            if (o == OCC_EMPTY) blocker = (int)(unsigned)W.claim[c];       // lost an empty cell to the lowest key
+            if (o == OCC_EMPTY) blocker = claim_ref(W.claim[c]);           // lost an empty cell to the lowest key
             else {
                 const int4 oc = ptab[ref_group(o)].rec[ref_index(o)];
                 const bool left_before = plain_resolve(ptab, (unsigned)oc.w) == MV_OK && (unsigned)oc.x < (unsigned)me.x;
-                blocker = left_before ? (int)(unsigned)W.claim[c] : o;
+                blocker = left_before ? claim_ref(W.claim[c]) : o;
             }
             G.last_op[i] = OP_COLLIDE;
             G.op_obj[i] = blocker;
@@ -3417,14 +3418,9 @@ bool fused_rules(const RuleArgs *rules, int n) {
     for (int k = 0; k < n; k++) if (rules[k].pair || rules[k].prog >= 0 || rules[k].n_obj || (rules[k].op != OP_ATTACK && rules[k].op != OP_KILL)) return false;
     return true;
 }
-static dim3 plain_grid(const WorldView &W, const PlainWorld &PW, bool cover_hi) {
-    dim3 g = grid_all(W, 256);
-    if (cover_hi) for (int q = 0; q < W.G; q++) g.x = std::max<unsigned>(g.x, (unsigned)((PW.hi[q] + 255) / 256));
-    return g;
-}
 void launch_plain_rank(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const int *rank, const ShuffleBufs &B, const int *sums,
                        const int *wpre, const SeqPlan &P) {
-    hipLaunchKernelGGL(k_plain_rank, plain_grid(W, PW, true), dim3(256), 0, s, W, PW, ptab, rank, B.head, B.first, sums, wpre, P);
+    hipLaunchKernelGGL(k_plain_rank, grid_all(W, 256), dim3(256), 0, s, W, PW, ptab, rank, B.head, B.first, sums, wpre, P);
 }
 size_t plain_eval_lds(int kmax) { return (size_t)kmax * 256 * 8; }
 bool plain_eval_lds_ok(int kmax) {

@@ -131,15 +131,16 @@ void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, cons
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);
 // ---- the step of plain games (kernels.hip: "the step of plain games"): per-agent scratch of its own
-//   rec   {x: order key (move) | rank in the shuffled attack list (attack), y: death rank, z: the cell the move is aimed at (-1: none; kept
-//          until the next step cleans the claim word it left there), w: move status / dependency}: what OTHER agents read of an agent
-//   atk   the agent my attack lands on (-1: nobody)
+//   rec   {x: order key (move) | rank in the shuffled attack list (attack), y: death rank, z: the cell the move is aimed at (-1: none),
+//          w: move status / dependency}: what OTHER agents read of an agent
+//   atk   the agent my attack lands on (-1: nobody); from k_strike on, for a mover: what its target cell holds when the moves begin
 //   hmask bit (attacker group's attack_bit + offset) set: that attacker hits me in this step; hlist[agent][slot] = {rank, attacker}
 struct PlainGroup { int4 *rec; int *atk; unsigned *hmask; uint2 *hlist; };
 struct PlainWorld {
     PlainGroup g[MAXG];
     int S, kmax;          // slots per agent (attack offsets of all groups); most hits one agent can receive
-    int hi[MAXG];         // leading entries of rec whose z may still point at a claim word (beyond the group's size: agents compacted away)
+    int epoch;            // of this step's claim words (kernels.hip: claim_word): 62 - (plain step number mod 63)
+    int round_base;       // + round = the "inputs changed" stamp of a round of this step (they count on from step to step)
 };
 bool fused_rules(const RuleArgs *rules, int n);
 bool plain_eval_lds_ok(int kmax);

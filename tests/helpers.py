@@ -922,6 +922,10 @@ def scenarios():
         Scenario("battle_brawl_big", "battle", 110, place=[rnd(0, 4500), rnd(1, 4500)], steps=14, action_seed=2,
                  over={"small": {"hp": 5, "damage": 3, "step_recover": 0.3}}),
         Scenario("battle60", "battle", 60, place=[rnd(0, 1200), rnd(1, 1200)], steps=40),
+        # a long episode: the plain pipeline's claim words carry an epoch that wraps every 63 steps (kernels.hip: claim_word)
+        Scenario("battle_epochs", "battle", 26, place=[rnd(0, 90), rnd(1, 90)], steps=140, action_seed=61, over={"small": {"hp": 6}},
+                 events={40: [("add", 0, "random", {"n": 50}), ("add", 1, "random", {"n": 50})],
+                         85: [("add", 0, "random", {"n": 60}), ("add", 1, "random", {"n": 60})], 120: [("add", 1, "random", {"n": 40})]}),
         Scenario("battle_walls", "battle", 50, walls=200, place=[rnd(0, 400), rnd(1, 400)], steps=20, action_seed=3),
         Scenario("battle_largemap", "battle", 120, place=[rnd(0, 3000), rnd(1, 3000)], steps=12, action_seed=5),
         Scenario("battle_largemap_odd", "battle", 101, place=[rnd(0, 2500), rnd(1, 2500)], steps=10, action_seed=6),

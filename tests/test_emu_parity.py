@@ -107,12 +107,12 @@ def test_emulated_large_world_drivers(emu):
 
 
 def test_emulated_fused_step_of_plain_games(emu):
-    """the fused step of plain games (k_strike, k_plain_init, k_plain_commit behind the death-rank rounds; kernels.hip) forced onto
-    small worlds (MAGENT_SOLO_STEP=0), workgroups and lanes in scrambled order: every scenario whose game it takes -- starving occupants
-    whose cell is claimed in the same step (battle_lowhp), skipped clear_dead (stale events are paid again, battle_no_clear),
-    agents and walls added mid-episode and a second episode (battle_events, battle_grow: the claim words are cleaned through `tm`
-    entries that compaction has moved away from), four groups, a group that never acts, rules that pay the object (chase: not fused)
-    or run on the host (rules_search), the run-out continuation from a fused head -- and that the fused passes really ran"""
+    """the pipeline of plain games (k_plain_rank, k_plain_eval, k_strike, k_plain_init, k_plain_commit; kernels.hip) forced onto small
+    worlds (MAGENT_SOLO_STEP=0), workgroups and lanes in scrambled order: every scenario whose game it takes -- starving occupants
+    whose cell is claimed in the same step (battle_lowhp), skipped clear_dead (stale events are paid again: rules not fused,
+    battle_no_clear), agents and walls added mid-episode and a second episode (battle_events, battle_grow), 140 steps (the claim
+    words' epoch wraps twice, battle_epochs), four groups, a group that never acts, rules that pay the object (chase: not fused) or
+    run on the host (rules_search), the run-out continuation of its own rounds -- and that the pipeline really ran"""
     code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import helpers as H\n"
             "emu = H.ensure_emu()\n"
@@ -124,9 +124,9 @@ def test_emulated_fused_step_of_plain_games(emu):
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
     base = {"MAGENT_SOLO_STEP": "0", "MAGENT_SCAN_SOLO_MAX": "100", "OMP_NUM_THREADS": "1"}
     plain = ("battle_small_dense,battle_brawl,battle_brawl_big,battle60,battle_walls,battle_largemap,battle_largemap_odd,battle_fill_full,"
-             "battle_no_clear,battle_tiny,gather,gather_largemap,battle_lowhp,quad,trans,chase,battle_events,battle_grow,rules_search,battle_second")
+             "battle_no_clear,battle_tiny,gather,gather_largemap,battle_lowhp,quad,trans,chase,battle_events,battle_grow,rules_search,battle_epochs")
     names = [n for n in plain.split(",") if n in H.scenarios()]
-    assert len(names) >= 19
+    assert len(names) == 20
     for extra in ({"HIPEMU_SCRAMBLE": "5"}, {"MAGENT_OPT_ATTACK_PAIRS": "0", "HIPEMU_SCRAMBLE": "8"}):
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EMU_SCENARIOS=",".join(names), **base, **extra), capture_output=True, text=True,
                            timeout=1500)
