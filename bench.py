@@ -324,8 +324,13 @@ def train_round_extra(torch, magent_amd, map_size=1000, steps=12, on_step=None, 
             m.train(print_every=10 ** 9, block=False)
         res = [m.fetch_train() for m in models]
         return (synced() - t0) * 1e3, res
-    for i, h in enumerate(handles):      # (untimed: the first inference of a process loads kernels and sizes workspaces)
+    # untimed: the first inference of a process loads kernels and sizes workspaces, and the first two steps allocate both sets of cached
+    # observation tensors and the episode buffer's blocks (gigabytes of hipMalloc at 2 x 500k agents: 20 ms per step if it is timed)
+    for i, h in enumerate(handles):
         models[i].infer_action(env.get_observation(h), env.get_agent_id(h), "e_greedy", 0.5, block=False)
+    play(-2, 2)
+    for k in T:
+        T[k] = 0 if k == "agent_steps" else 0.0
     play(0, steps)
     t_env, t_infer, t_sample, agent_steps = T["env"], T["infer"], T["sample"], T["agent_steps"]
     out = {"map_size": map_size, "agents": n0, "steps": steps, "env_ms_per_step": t_env / steps * 1e3, "infer_ms_per_step": t_infer / steps * 1e3,

@@ -1653,7 +1653,8 @@ __global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev
 // EPOCH of the step that wrote it in its top bits (claim_word below), counting DOWN from step to step: a word of an earlier step loses
 // every atomicMin against this step's claims and reads as "nobody" -- nothing is cleaned; every 63rd step the host refills the array
 // (engine.hip: scratch_for).  The "inputs changed" stamps of the rounds count on across steps in the same way (PlainWorld::round_base).
-constexpr unsigned MV_DIED = 0xFFFFFFFCu;   // move status between k_strike and k_plain_init: killed or starved in this step, still on the map
+constexpr unsigned MV_DIED = 0xFFFFFFFBu;   // move status between k_strike and k_plain_init: killed or starved in this step, still on the map
+constexpr unsigned MV_FAIL_SAME = 0xFFFFFFFCu;   // MV_FAIL of an agent whose hp this step left as it was: its painted cell is current (k_plain_commit)
 // claim word of the plain pipeline: [63:58] epoch (0..62; 63 = the fill pattern: nobody) | [57:30] order key (boundary bit, 27-bit insertion
 // index) | [29:0] agent reference.  Smaller = earlier: a later step's epoch is smaller, so stale words never win
 __device__ __forceinline__ unsigned long long claim_word(int epoch, unsigned key, int ref) {
@@ -1790,6 +1791,7 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
         bool dead = G.dead[i];
         const int4 me = PW.g[g].rec[i];                  // {key | rank, death rank, move target, -}
         float hp = G.hp[i];
+        const unsigned hp_before = __float_as_uint(hp);
         float nr = G.next_reward[i];
         int last_op = OP_NULL, op_obj = -1;              // (what clear_dead left: with rules fused, the host has seen it run since the last step)
         // ---- the attack phase applied from the converged death ranks (attack_apply_body, one-cell bodies, no supply)
@@ -1855,7 +1857,8 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
             PW.g[g].atk[i] = o;              // what my target cell holds when the moves begin, for k_plain_init / k_plain_commit (a mover has no attack target)
             if (ok) atomicMin(&W.claim[c], claim_word(PW.epoch, key, ref_pack(g, i)));
         }
-        if (died) PW.g[g].rec[i].w = (int)MV_DIED;
+        // (every agent's move status starts here; k_plain_init raises the winners')
+        PW.g[g].rec[i].w = died ? (int)MV_DIED : __float_as_uint(hp) == hp_before ? (int)MV_FAIL_SAME : (int)MV_FAIL;
     }
     int wtot;
     wave_rank(died, wtot);
@@ -1916,7 +1919,8 @@ __global__ void __launch_bounds__(256) k_plain_commit(WorldView W, PlainWorld PW
         }
     }
     G.pend[i] = PEND_NONE;   // end of step: pending actions are consumed
-    if (W.live_paint) repaint_body(W, G, W.type[g], g, i);
+    // live paint: every agent that moved or whose hp changed paints its cell (most agents of a battle stand at full hp: 4 of 5 stores saved)
+    if (W.live_paint && (unsigned)me.w != MV_FAIL_SAME) repaint_body(W, G, W.type[g], g, i);
 }
 
 // ------------------------------------------------------------------------------------------------ move, generic bodies
@@ -2572,7 +2576,14 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_clear_compact(WorldView W, Cle
     } else if (A.mode[g] == 2) {
         const ClearArgs::Alt D = A.dst[g];
         const int bw = W.type[g].bw, bl = W.type[g].bl;
-        block_rank([&](int i) { return !G.dead[i]; },
+        // (the single-buffered state goes back to its rest values at every agent's OWN index -- all that matters are the positions below
+        // the new size, and each is some thread's own; `dead` is read by that thread alone in this launch: no second pass for it)
+        block_rank([&](int i) {
+                       const bool d = G.dead[i];
+                       if (d) G.dead[i] = 0;
+                       G.last_op[i] = OP_NULL; G.op_obj[i] = -1; G.pend[i] = PEND_NONE;
+                       return !d;
+                   },
                    [&](int i, int r) {
                        int x = G.x[i], y = G.y[i];
                        D.x[r] = x; D.y[r] = y; D.id[r] = G.id[i]; D.hp[r] = G.hp[i]; D.last_action[r] = G.last_action[i];
@@ -2606,18 +2617,18 @@ __global__ void __launch_bounds__(256) k_mini_norm(WorldView Wn, MiniArgs M, int
     mini_norm_body(Wn, M, counts, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// ... and, with the pointers swapped (Wn = the view after clear_dead): the single-buffered per-agent state of the
-// survivors, the death counters and the device copies of the group / type tables
+// ... and, with the pointers swapped (Wn = the view after clear_dead): the death counters, the device copies of the group / type
+// tables and the division of the next minimap -- a handful of workgroups (the per-agent resets ride in k_clear_compact since round 4)
 __global__ void __launch_bounds__(256) k_clear_finish(WorldView Wn, ClearArgs A, GroupDev *gtab, TypeDev *ttab, MiniArgs M, int *counts) {
-    const int g = blockIdx.y;
-    if ((blockIdx.x | blockIdx.y) == 0 && threadIdx.x < MAXG) { gtab[threadIdx.x] = Wn.grp[threadIdx.x]; ttab[threadIdx.x] = Wn.type[threadIdx.x]; }
-    if (M.vh > 0 && g == 0) mini_norm_body(Wn, M, counts, blockIdx.x * blockDim.x + threadIdx.x);   // (the grid covers the largest group: >= G * VHW threads, checked by the launcher)
-    if (A.mode[g] != 2) return;
-    const GroupDev D = Wn.grp[g];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < DEAD_SLOTS) Wn.counters[dead_slot(g, i)] = 0;
-    if (i == 0) Wn.counters[CTR_TAKEN + g] = 0;
-    if (i < D.n) { D.dead[i] = 0; D.last_op[i] = OP_NULL; D.op_obj[i] = -1; D.pend[i] = PEND_NONE; }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < MAXG) { gtab[threadIdx.x] = Wn.grp[threadIdx.x]; ttab[threadIdx.x] = Wn.type[threadIdx.x]; }
+        for (int g = 0; g < Wn.G; g++) {
+            if (A.mode[g] != 2) continue;
+            if (threadIdx.x < DEAD_SLOTS) Wn.counters[dead_slot(g, threadIdx.x)] = 0;
+            if (threadIdx.x == 0) Wn.counters[CTR_TAKEN + g] = 0;
+        }
+    }
+    if (M.vh > 0) mini_norm_body(Wn, M, counts, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 __global__ void __launch_bounds__(SOLO_THREADS) k_compact_solo(WorldView W, int g, GroupDev D) {
@@ -3556,12 +3567,8 @@ bool solo_step_allow_lds(size_t bytes) {   // dynamic LDS above the default limi
            hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_solo_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 void launch_clear_finish(hipStream_t s, const WorldView &Wn, const ClearArgs &A, GroupDev *gtab, TypeDev *ttab, const MiniArgs &M, int *counts) {
-    dim3 grid = grid_all(Wn, 256);
-    const bool fold = M.vh > 0 && (long long)grid.x * 256 >= (long long)Wn.G * M.vh * M.vw;   // the normalisation rides in the blocks of group 0
-    MiniArgs Mf = M;
-    if (!fold) Mf.vh = 0;
-    hipLaunchKernelGGL(k_clear_finish, grid, dim3(256), 0, s, Wn, A, gtab, ttab, Mf, counts);
-    if (M.vh > 0 && !fold) launch_mini_norm(s, Wn, M, counts);
+    const int blocks = std::max(1, (Wn.G * M.vh * M.vw + 255) / 256);
+    hipLaunchKernelGGL(k_clear_finish, dim3(blocks), dim3(256), 0, s, Wn, A, gtab, ttab, M, counts);
 }
 
 }  // namespace magent_amd

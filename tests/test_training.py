@@ -341,9 +341,10 @@ def test_c5_train_round(map_size, per_side):
     twin = {}
 
     def check(step, env, handles, obs, acts, rewards, alives):
-        if step >= 3:
+        if step >= 1:          # (train_round_extra plays two untimed steps first, numbered -2 and -1: the first three steps of the episode)
             return
         if not twin:
+            assert step == -2
             o = H.gridworld("battle", lib=H.ensure_oracle(), map_size=map_size)
             o.set_seed(12345); o.reset()
             for g, pos in bench.train_battle_formation(map_size):      # the start positions as train_round_extra lays them out
