@@ -63,3 +63,22 @@ def test_two_ranks_rccl_when_two_gpus():
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["config"]["rccl_ranks"] == 2 and rec["config"]["backend"] == "nccl"
     assert rec["config"]["gather_detail"]["verified"]["all_shards_bit_identical"] is True
+
+
+@pytest.mark.gpu
+def test_default_multi_rank_line_carries_the_c4_gather_extra():
+    """`bench.py --gpus 2` with nothing else but the dry-run backend -- what the driver's N > 1 command produces: the replicas
+    headline on the default workload (no gather), and behind it `extra.c4_gather_rccl`: BASELINE config 4 on the job's ranks
+    (gather 500 x 500, 100k agents + 20k food per replica), timed without and with the exchange of every replica's observation
+    tensor, the exchange's own duration, bytes per peer and GB/s per link against the xGMI link peak, every gathered shard verified
+    bit for bit against the rows its owner rendered"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--repeats", "1"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["gather"] == "none" and rec["config"]["agents_at_start"] == [400000, 400000]
+    x = rec["extra"]["c4_gather_rccl"]
+    assert x["verified"]["all_shards_bit_identical"] is True and x["verified"]["distinct_replicas"] == 2
+    assert x["payload_bytes_to_each_peer"] > 100000 * 6300 * 0.9 and x["exchange_ms"] > 0 and x["GBps_per_link"] > 0
+    assert x["ms_per_step_with_gather"] > 0 and x["ms_per_step_without_gather"] > 0 and x["xgmi_link_peak_GBps"] == 153.0
