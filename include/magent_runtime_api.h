@@ -141,7 +141,7 @@ int env_get_stream(EnvHandle game, void **stream);
  * run set_action and the read-only head of env_step (attack shuffle, hit gather, death-rank fixed point) on a second
  * stream, beside the observation renders on env_get_stream's stream; a caller that produces actions
  * asynchronously on a stream of its own orders THIS stream behind it.  Equal to env_get_stream's for small worlds or
- * with MAGENT_OVERLAP=0.  All outputs (observations, rewards, infos) are ordered on env_get_stream's stream as before. */
+ * with MAGENT_TUNE overlap=0 (the default).  All outputs (observations, rewards, infos) are ordered on env_get_stream's stream as before. */
 int env_get_action_stream(EnvHandle game, void **stream);
 
 /* Kernel timing with HIP events recorded on the environment's stream.

@@ -258,17 +258,14 @@ Env::Env() {
     if (!d) d = std::getenv("LOCAL_RANK");
     device_id = d ? std::atoi(d) : 0;
     rng.seed(0);  // GridWorld.cc:29
-    // tuning knobs for experiments (defaults are the measured best)
-    if (const char *v = std::getenv("MAGENT_RENDER_SPAN")) render_steps_per_span = std::atoi(v);
-    if (const char *v = std::getenv("MAGENT_RENDER_UNROLL")) render_unroll = std::atoi(v);
-    if (const char *v = std::getenv("MAGENT_HOST_SHUFFLE")) host_shuffle = std::atoi(v) != 0;
-    if (const char *v = std::getenv("MAGENT_CHECKED_STEP")) checked_step = std::atoi(v) != 0;
-    if (const char *v = std::getenv("MAGENT_OPT_ATTACK_PAIRS")) { opt_attack_pairs = std::max(0, std::atoi(v)); opt_fixed = true; }
-    if (const char *v = std::getenv("MAGENT_OPT_MOVE_BATCHES")) { opt_move_batches = std::max(0, std::atoi(v)); opt_fixed = true; }
-    if (const char *v = std::getenv("MAGENT_RENDER_NT")) nt_stores = std::atoi(v) != 0;
-    if (const char *v = std::getenv("MAGENT_SOLO_STEP")) solo_enabled = std::atoi(v) != 0;
-    if (const char *v = std::getenv("MAGENT_OVERLAP")) { overlap_level = std::atoi(v); overlap_enabled = overlap_level != 0; }
-    if (const char *v = std::getenv("MAGENT_SOLO_MAX")) solo_max_agents = std::max(0, std::atoi(v));
+    // what tests and tuning runs force through MAGENT_TUNE (tune.h); the defaults are the measured best
+    host_shuffle = tune("host_shuffle", 0) != 0;
+    checked_step = tune("checked_step", 0) != 0;
+    if (tune_set("attack_pairs")) { opt_attack_pairs = std::max(0, tune("attack_pairs", 1)); opt_fixed = true; }
+    if (tune_set("move_batches")) { opt_move_batches = std::max(0, tune("move_batches", 1)); opt_fixed = true; }
+    solo_enabled = tune("solo_step", 1) != 0;
+    if (tune_set("overlap")) { overlap_level = tune("overlap", 0); overlap_enabled = overlap_level != 0; }
+    solo_max_agents = std::max(0, tune("solo_max", solo_max_agents));
 }
 
 template <class T>
@@ -313,7 +310,7 @@ void Env::use_device() { HIP_OK(hipSetDevice(device_id)); }
 //   side   :   (waits for the state)   set_action g0, g1, shuffle, rank, eval rounds |
 // MEASURED (MI355X, bench workload, profiles/r02_overlap.txt): 0.952 -> 0.896 ms per step (+6 %), but the renders stretch from
 // 0.303 to 0.347 ms each -- the side work is random 4-byte traffic that costs whole HBM transactions, so it takes back more
-// than half of what it hides.  OFF by default (MAGENT_OVERLAP=3 turns all of it on, 2 the shuffle only, 1 set_action only):
+// than half of what it hides.  OFF by default (MAGENT_TUNE overlap=3 turns all of it on, 2 the shuffle only, 1 set_action only):
 // the render stays at its roofline fraction and the step's head stays the thing to make cheaper.  The GPU suite runs the
 // dense scenarios both ways (tests/test_gpu_fullsize.py: multi_launch_step / multi_launch_one_stream).
 // Rules that keep this exact whatever the caller does:
@@ -1246,12 +1243,12 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
     // 32 steps per workgroup at scale; a small observation is cut finer so that it still spreads over the chip (a wave's
     // steps run one after the other: a step is ~1 us of latency)
     // (`batch_width` environments share the launch under env_cycle_many)
-    int per = render_steps_per_span > 0 ? render_steps_per_span : (int)std::min<long long>(32, std::max<long long>(4, steps * batch_width / 2048));
+    int per = (int)std::min<long long>(32, std::max<long long>(4, steps * batch_width / 2048));
     P.steps_per_span = per;
     P.spans = (int)((steps + per - 1) / per);
     P.xcd_chunk = P.spans >= 64 ? P.spans / 8 : 0;
     P.strip_floats = 64 * R.C;
-    P.unroll = render_unroll;
+    P.unroll = 1;
     P.div_vhw = make_fastdiv(R.VH * R.VW); P.div_vw = make_fastdiv(R.VW); P.div_f = make_fastdiv(R.F);
     P.div_scale_w = make_fastdiv(R.scale_w); P.div_scale_h = make_fastdiv(R.scale_h);
 }
@@ -1262,7 +1259,7 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
 // the first observation (no window known).  vh == 0: not folded.
 MiniArgs Env::next_minimap() {
     MiniArgs M{};
-    static const bool off = std::getenv("MAGENT_FOLD_MINIMAP") && std::atoi(std::getenv("MAGENT_FOLD_MINIMAP")) == 0;
+    static const bool off = tune("fold_minimap", 1) == 0;
     if (off || !minimap_mode || mini_vh <= 0 || mini_skip) return M;
     const size_t need = MAXG + groups.size() * (size_t)mini_vh * mini_vw * (1 + MINI_COPIES);
     if (need > mini_cap) return M;       // (the histogram buffer of the first observation is not there yet)
@@ -1316,8 +1313,7 @@ bool Env::prepare_render(int g, const WorldView &W, RenderArgs &R, RenderPlan &P
     const bool aligned = (((uintptr_t)view) & 15) == 0, feat_aligned = (((uintptr_t)feat) & 15) == 0;
     // the feature rows ride in the render launch (its trailing workgroups) when both pointers have the same alignment
     const unsigned feat_q = (unsigned)R.n * (unsigned)R.F / 4;
-    static const bool feat_separate = std::getenv("MAGENT_FEAT_SEPARATE") && std::atoi(std::getenv("MAGENT_FEAT_SEPARATE")) != 0;   // (tuning)
-    P.feat_blocks = (aligned == feat_aligned && !feat_separate) ? (int)std::min<unsigned>((feat_q + 255) / 256 + 1, 16384) : 0;
+    P.feat_blocks = aligned == feat_aligned ? (int)std::min<unsigned>((feat_q + 255) / 256 + 1, 16384) : 0;
     return aligned;
 }
 
@@ -1341,7 +1337,7 @@ void Env::observe_device(int g, float *view, float *feat, bool cells16) {
     R.cells16 = cells16 ? 1 : 0;
     {
         ProfScope p(*this, "render", true);
-        last_render_kernel = launch_render(stream, W, R, P, aligned, aligned && nt_stores);
+        last_render_kernel = launch_render(stream, W, R, P, aligned, aligned);
     }
     if (P.feat_blocks == 0) {
         ProfScope p(*this, "features", true);
@@ -1479,7 +1475,7 @@ void Env::set_action_host(int g, const int *actions) {
 //     RNG state and whether a phase ran out of rounds; in that (rare) case everything after that phase has been
 //     skipped on the device and the host continues from exactly that state with the checked driver.
 //   * checked: the host reads the convergence flag after every pair / batch (also used while the text render is
-//     recording attack events, and with MAGENT_HOST_SHUFFLE / MAGENT_CHECKED_STEP for A/B runs).
+//     recording attack events, and with MAGENT_TUNE host_shuffle=1 / checked_step=1 for A/B runs).
 void Env::shuffle_buffers(int n_max) {
     grow(arena, d_rank, rank_cap, (size_t)n_max, stream);
     if ((size_t)n_max * 4 > shuf_cap) {   // four arrays: head | first | j | link
@@ -1759,7 +1755,7 @@ void Env::step_begin() {
         if (A > 0) {
             ProfScope p(*this, "attack");
             shuffle_buffers(std::max(A, total_n));
-            if (host_shuffle) {   // the reference's literal loop on the host (MAGENT_HOST_SHUFFLE=1, for A/B checks)
+            if (host_shuffle) {   // the reference's literal loop on the host (MAGENT_TUNE host_shuffle=1, for A/B checks)
                 if (rng_on_device) { rng.x = (unsigned)read_counters()[CTR_RNG]; }
                 if ((size_t)A > hrank_cap) {
                     if (h_rank) HIP_OK(hipHostFree(h_rank));

@@ -12,6 +12,7 @@
 
 #include "engine.h"
 #include "launch.h"
+#include "tune.h"
 
 namespace magent_amd {
 
@@ -142,7 +143,7 @@ public:
     // gather and the death-rank fixed point -- run here, beside the observation renders on `stream` (engine.hip: side_stream)
     hipStream_t side{};
     hipEvent_t ev_state{}, ev_side{};
-    bool overlap_enabled = false;         // MAGENT_OVERLAP=1..3 turns it on (default: everything on `stream`, see engine.hip)
+    bool overlap_enabled = false;         // MAGENT_TUNE overlap=1..3 turns it on (default: everything on `stream`, see engine.hip)
     int overlap_level = 3;                // (tuning) 1: set_action beside the renders, 2: + the attack shuffle, 3: + hit gather and death ranks
     bool side_dirty = false;              // work on `side` that `stream` has not waited for yet
     unsigned state_epoch = 1, marked_epoch = 0, side_epoch = 0;   // state-changing calls | ... covered by ev_state | ... waited for by `side`
@@ -154,9 +155,6 @@ public:
     hipStream_t action_stream();          // where the next set_action will read its actions
     int attack_round = 0;        // rounds of the attack fixed point launched in the current step (k_attack_eval)
     int prof_level = 0;          // 0 off, 1 every named phase, 2 only the observation render launches
-    bool nt_stores = true;   // nontemporal stores keep the write-once output out of L2 (measured +15-20 %)
-    int render_steps_per_span = 0;  // 0 = default
-    int render_unroll = 1;
     bool host_shuffle = false;
     int move_jump_batch = 3;
     int last_attack_iters = 0, last_move_iters = 0, fallback_steps = 0, fallback_attack = 0, fallback_move = 0, last_render_kernel = 0;
@@ -164,7 +162,7 @@ public:
     // optimistic rounds of the single-sync driver: one pair / batch, two for 64 steps after a run-out (or fixed by env)
     int opt_attack_pairs = 1, opt_move_batches = 1, boost_attack = 0, boost_move = 0;
     bool opt_fixed = false;
-    // one-launch step of small worlds (k_step_solo): on by default, MAGENT_SOLO_STEP=0 keeps the multi-launch drivers
+    // one-launch step of small worlds (k_step_solo): on by default, MAGENT_TUNE solo_step=0 keeps the multi-launch drivers
     bool solo_enabled = true;
     int solo_max_agents = 16384;
     double batch_us[4] = {0, 0, 0, 0};   // host time of env_cycle_many rounds led by this environment (info "batch_host_us")

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/magent_policy.h"
+#include "tune.h"
 
 namespace {
 
@@ -63,7 +64,7 @@ struct ConvArgs {
     const float *b2;       // [2][16]: conv2's bias of the channel in slot 16 g + r
     int n, H, W, C, VP, AP, n_tiles;
     bf16x8 *dump;          // 2 KB behind the workspace: where lanes without a conv2 position store
-    long long *stamps;     // STAMPS instantiation (MAGENT_POLICY_STAMPS): per workgroup, cycles spent in each phase
+    long long *stamps;     // STAMPS instantiation (MAGENT_TUNE policy_stamps=1): per workgroup, cycles spent in each phase
 };
 
 // relu and round two f32 to a bf16 pair: v_cvt_pk_bf16_f32, then v_pk_max_i16 against 0 -- a negative bf16 is a negative int16, and
@@ -575,7 +576,7 @@ static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const v
     const int VP = pitch(H * W + 3), AP = pitch(H1 * W);
     const size_t lds = ((size_t)CONV_TA * VP + (size_t)4 * CONV_TA * AP) * 16 + 32 * 4;
     if (lds > 150 * 1024) return 1;
-    static const int conv_wpc = getenv("MAGENT_POLICY_WPC") ? atoi(getenv("MAGENT_POLICY_WPC")) : 2;
+    constexpr int conv_wpc = 2;      // workgroups of k_dqn_conv per CU (1 and 3 measured slower: profiles/r03_policy.txt)
     const bool f13 = H == 13 && W == 13;
     // the stream's device is made current (launches and function attributes are per device), and the dynamic-LDS allowance is
     // granted once per DEVICE, not once per process
@@ -597,12 +598,12 @@ static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const v
     ConvArgs C{};
     C.view = view; C.act = (__bf16 *)act_workspace; C.w1 = (const bf16x8 *)w->conv1; C.w2 = (const bf16x8 *)w->conv2; C.b2 = w->conv2_bias;
     C.n = n; C.H = H; C.W = W; C.C = s->view_c; C.VP = VP; C.AP = AP; C.n_tiles = (n + CONV_TA - 1) / CONV_TA; C.dump = (bf16x8 *)((char *)act_workspace + act_bytes(s, n));
-    static const int grid_cap = getenv("MAGENT_POLICY_GRID") ? atoi(getenv("MAGENT_POLICY_GRID")) : 256 * conv_wpc;   // (tests: a few workgroups walk many tiles)
+    static const int grid_cap = magent_amd::tune("policy_grid", 256 * conv_wpc);   // (tests: a few workgroups walk many tiles)
     const int grid = C.n_tiles < grid_cap ? C.n_tiles : grid_cap < 1 ? 1 : grid_cap;     // persistent (2 per CU): weights are fetched once per wave
-    // development (MAGENT_POLICY_STAMPS=1, bf16-cell views of the battle shape only): wave 0 of every workgroup reads the cycle counter at
+    // development (MAGENT_TUNE policy_stamps=1, bf16-cell views of the battle shape only): wave 0 of every workgroup reads the cycle counter at
     // its phase boundaries; the launch is waited for and the averages go to stderr.  A separate instantiation: the product kernels
     // carry none of it.
-    static const bool stamps_on = getenv("MAGENT_POLICY_STAMPS") && atoi(getenv("MAGENT_POLICY_STAMPS")) != 0;
+    static const bool stamps_on = magent_amd::tune("policy_stamps", 0) != 0;
     const int head_grid = (n + HEAD_M - 1) / HEAD_M;
     long long *d_stamps = nullptr;
     const bool stamp_conv = stamps_on && cells16 && f13;

@@ -135,8 +135,8 @@ int env_cycle_many(EnvHandle *games, int n_env, int n_group, float **view, float
         E(games[e])->cycle(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
                            rewards ? rewards + o : nullptr, &done[e]);
     };
-    // several environments: one pair of launches for all that are small enough (MAGENT_BATCH_CYCLE=0: one by one, by threads)
-    static const bool batch = !(std::getenv("MAGENT_BATCH_CYCLE") && std::atoi(std::getenv("MAGENT_BATCH_CYCLE")) == 0);
+    // several environments: one pair of launches for all that are small enough (MAGENT_TUNE batch_cycle=0: one by one, by threads)
+    static const bool batch = magent_amd::tune("batch_cycle", 1) != 0;
     if (n_env >= 2 && batch) {
         std::vector<Env *> envs(n_env);
         for (int e = 0; e < n_env; e++) envs[e] = E(games[e]);

@@ -1,0 +1,59 @@
+// tune.h -- ONE environment variable for everything that only tests and tuning runs ever set:
+//     MAGENT_TUNE="key=value,key=value"
+// The product reads its settings from the game configuration; these keys force a driver or a kernel that the defaults would not take,
+// so that the test suites can run every path on every scenario (tests/test_gpu_fullsize.py: VARIANTS, tests/test_emu_parity.py).
+// Unknown keys abort (a typo must not silently test the default path).
+//   checked_step=1      the host-checked step driver (one convergence read per pair of rounds) instead of the single-sync driver
+//   host_shuffle=1      the reference's literal Fisher-Yates loop on the host instead of the device replay (A/B of the shuffle)
+//   attack_pairs=N      optimistic pairs of attack rounds (0: none -- every step continues on the host)      default 1, 2 after a run-out
+//   move_batches=N      optimistic batches of generic move sweeps (0: none)                                   default 1, 2 after a run-out
+//   solo_step=0         worlds that would step in ONE launch (k_step_solo) take the multi-launch drivers
+//   solo_max=N          most agents a world may have to step in one launch                                   default 16384
+//   scan_solo_max=N     groups up to N agents compact in one workgroup (clear_dead)                          default 32768
+//   overlap=1..3        set_action / the shuffle / the attack rounds on a second stream beside the renders   default 0 (measured: DESIGN 3.5)
+//   fold_minimap=0      the next minimap by k_minimap instead of clear_dead's own launches
+//   render=0|1|4        force k_render | k_render_fast | k_render_sweep2;  render_sweep=N workgroups, render_su=1..3 strips, render_depth=1..3
+//   att_threads=64|128|256   workgroup size of k_attack_eval
+//   policy_grid=N       workgroups of k_dqn_conv (tests: a few workgroups walk many tiles);  policy_stamps=1: per-phase cycle stamps
+//   batch_cycle=0       env_cycle_many runs its environments one after another instead of in one pair of launches
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace magent_amd {
+
+inline int tune(const char *key, int dflt) {
+    static const char *const known[] = {"checked_step", "host_shuffle", "attack_pairs", "move_batches", "solo_step", "solo_max", "scan_solo_max", "overlap",
+                                        "fold_minimap", "render", "render_sweep", "render_su", "render_depth", "att_threads", "policy_grid", "policy_stamps",
+                                        "batch_cycle"};
+    const char *s = std::getenv("MAGENT_TUNE");
+    if (!s || !*s) return dflt;
+    static bool checked = false;
+    if (!checked) {
+        checked = true;
+        for (const char *p = s; *p;) {
+            const char *e = std::strchr(p, ',');
+            const size_t len = e ? (size_t)(e - p) : std::strlen(p);
+            const char *eq = (const char *)std::memchr(p, '=', len);
+            bool ok = false;
+            if (eq)
+                for (const char *k : known) ok |= std::strlen(k) == (size_t)(eq - p) && !std::strncmp(k, p, (size_t)(eq - p));
+            if (!ok && len) { std::fprintf(stderr, "magent-amd FATAL: MAGENT_TUNE: unknown entry \"%.*s\" (see magent_amd/csrc/tune.h)\n", (int)len, p); std::abort(); }
+            if (!e) break;
+            p = e + 1;
+        }
+    }
+    const size_t n = std::strlen(key);
+    for (const char *p = s; *p;) {
+        const char *e = std::strchr(p, ',');
+        const size_t len = e ? (size_t)(e - p) : std::strlen(p);
+        if (len > n && !std::strncmp(p, key, n) && p[n] == '=') return std::atoi(p + n + 1);
+        if (!e) break;
+        p = e + 1;
+    }
+    return dflt;
+}
+inline bool tune_set(const char *key) { return tune(key, -0x7FFFFFFF) != -0x7FFFFFFF; }
+
+}  // namespace magent_amd

@@ -32,6 +32,15 @@ def ensure_emu():
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
+def merge_env(*dicts):
+    """environment dicts merged; MAGENT_TUNE entries (magent_amd/csrc/tune.h: "key=value,key=value") are joined, not overwritten"""
+    out = {}
+    for d in dicts:
+        for k, v in d.items():
+            out[k] = out[k] + "," + v if k == "MAGENT_TUNE" and out.get(k) else v
+    return out
+
+
 def ensure_oracle():
     """build oracle/liboracle.so from its own source if needed (gcc only; no GPU involved)"""
     src = os.path.join(ROOT, "oracle", "gridworld_oracle.cc")

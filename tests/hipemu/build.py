@@ -1,7 +1,7 @@
 """Builds tests/hipemu/_build/libmagent_emu.so: the engine's HIP sources compiled as plain C++ against the hipemu shim.
 
 TEST INFRASTRUCTURE ONLY -- see tests/hipemu/hip/hip_runtime.h.  The sources are used as they are, except for one textual
-change made on a copy: `extern __shared__ T name[];` (dynamic LDS) becomes a pointer to the emulator's LDS block."""
+change made on copies (sources and headers): `extern __shared__ T name[];` (dynamic LDS) becomes a pointer to the emulator's LDS block."""
 import os
 import re
 import subprocess
@@ -12,10 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "magent_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libmagent_emu.so")
-SOURCES = ["kernels.hip", "engine.hip", "runtime_api.hip", "policy.hip"]     # (MFMAs: hipemu::mfma_32x32x16_bf16)
+SOURCES = ["render.hip", "step.hip", "cycle.hip", "engine.hip", "runtime_api.hip", "policy.hip"]     # (MFMAs: hipemu::mfma_32x32x16_bf16)
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-g1", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-w",
-         "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include")]
+         "-I", HERE, "-I", OUT, "-I", CSRC, "-I", os.path.join(ROOT, "include")]
 DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?((?:unsigned\s+)?\w+)\s+(\w+)\[\];")
 
 
@@ -26,9 +26,13 @@ def build(force=False):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     objs = []
+    sub = lambda text: DYN.sub(lambda m: "%s *%s = (%s *)hipemu::dynamic_lds();" % (m.group(1), m.group(2), m.group(1)), text)
+    for h in sorted(os.listdir(CSRC)):          # (the headers get the same textual change, on copies that are found first)
+        if h.endswith(".h"):
+            open(os.path.join(OUT, h), "w").write('#line 1 "%s"\n' % os.path.join(CSRC, h) + sub(open(os.path.join(CSRC, h)).read()))
     for src in SOURCES:
         text = open(os.path.join(CSRC, src)).read()
-        text = DYN.sub(lambda m: "%s *%s = (%s *)hipemu::dynamic_lds();" % (m.group(1), m.group(2), m.group(1)), text)
+        text = sub(text)
         cc = os.path.join(OUT, src.replace(".hip", "_emu.cc"))
         open(cc, "w").write('#line 1 "%s"\n' % os.path.join(CSRC, src) + text)
         obj = cc.replace(".cc", ".o")

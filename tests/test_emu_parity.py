@@ -47,9 +47,9 @@ def test_emulated_kernels_do_not_depend_on_lane_order(emu):
         assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-1000:] + p.stderr[-3000:]
 
 
-@pytest.mark.parametrize("knobs", [{"MAGENT_RENDER_FAST": "1"}, {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "3"},
-                                   {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "2", "MAGENT_RENDER_SU": "3", "MAGENT_RENDER_DEPTH": "3"},
-                                   {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "7", "MAGENT_RENDER_SU": "1", "MAGENT_RENDER_DEPTH": "1"}],
+@pytest.mark.parametrize("knobs", [{"MAGENT_TUNE": "render=1"}, {"MAGENT_TUNE": "render=4,render_sweep=3"},
+                                   {"MAGENT_TUNE": "render=4,render_sweep=2,render_su=3,render_depth=3"},
+                                   {"MAGENT_TUNE": "render=4,render_sweep=7,render_su=1,render_depth=1"}],
                          ids=["fast", "sweep", "sweep_3strips_depth3", "sweep_1strip_depth1"])
 def test_emulated_battle_render_kernels(emu, knobs):
     """the battle-shaped render kernels (k_render_fast: LDS tables + one-step look-ahead; k_render_sweep2: persistent workgroups
@@ -86,7 +86,7 @@ def test_emulated_battle_render_kernels(emu, knobs):
 
 
 def test_emulated_large_world_drivers(emu):
-    """the multi-launch step of large worlds forced onto small ones (MAGENT_SOLO_STEP=0, block scans from 100 agents on): the
+    """the multi-launch step of large worlds forced onto small ones (MAGENT_TUNE=solo_step=0, block scans from 100 agents on): the
     single-sync driver, its continuation when the optimistic attack / move rounds run out, the minimap made by k_minimap instead of
     clear_dead's own launches; workgroups in scrambled order"""
     code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
@@ -96,19 +96,19 @@ def test_emulated_large_world_drivers(emu):
             "    sc = H.scenarios()[n]\n"
             "    H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, emu), n)\n"
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
-    base = {"MAGENT_SOLO_STEP": "0", "MAGENT_SCAN_SOLO_MAX": "100", "OMP_NUM_THREADS": "1"}
+    base = {"MAGENT_TUNE": "solo_step=0,scan_solo_max=100", "OMP_NUM_THREADS": "1"}
     wide = "battle_brawl,battle_brawl_dense_big,battle_largemap_odd,gather_largemap,battle_grow,battle_events,tri_rect,bodies,forest"
     plain = "battle_brawl,battle_largemap_odd,gather_largemap,battle_grow"        # (one-cell bodies, large_map_mode among them)
-    for extra, names in (({}, wide), ({"MAGENT_OPT_ATTACK_PAIRS": "0"}, plain), ({"MAGENT_FOLD_MINIMAP": "0"}, plain),
+    for extra, names in (({}, wide), ({"MAGENT_TUNE": "attack_pairs=0"}, plain), ({"MAGENT_TUNE": "fold_minimap=0"}, plain),
                          ({"HIPEMU_SCRAMBLE": "3"}, plain + ",battle_brawl_dense_big"),
-                         ({"MAGENT_OPT_MOVE_BATCHES": "0", "MAGENT_OPT_ATTACK_PAIRS": "0", "HIPEMU_SCRAMBLE": "11"}, plain)):
-        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EMU_SCENARIOS=names, **base, **extra), capture_output=True, text=True, timeout=900)
+                         ({"MAGENT_TUNE": "move_batches=0,attack_pairs=0", "HIPEMU_SCRAMBLE": "11"}, plain)):
+        p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"EMU_SCENARIOS": names}, base, extra), capture_output=True, text=True, timeout=900)
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])
 
 
 def test_emulated_fused_step_of_plain_games(emu):
     """the pipeline of plain games (k_plain_rank, k_plain_eval, k_strike, k_plain_init, k_plain_commit; kernels.hip) forced onto small
-    worlds (MAGENT_SOLO_STEP=0), workgroups and lanes in scrambled order: every scenario whose game it takes -- starving occupants
+    worlds (MAGENT_TUNE=solo_step=0), workgroups and lanes in scrambled order: every scenario whose game it takes -- starving occupants
     whose cell is claimed in the same step (battle_lowhp), skipped clear_dead (stale events are paid again: rules not fused,
     battle_no_clear), agents and walls added mid-episode and a second episode (battle_events, battle_grow), 140 steps (the claim
     words' epoch wraps twice, battle_epochs), four groups, a group that never acts, rules that pay the object (chase: not fused) or
@@ -122,12 +122,12 @@ def test_emulated_fused_step_of_plain_games(emu):
             "    H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, emu, env_out=seen), n)\n"
             "    assert seen[0].engine_stats()[7] > 0, (n, seen[0].engine_stats())\n"
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
-    base = {"MAGENT_SOLO_STEP": "0", "MAGENT_SCAN_SOLO_MAX": "100", "OMP_NUM_THREADS": "1"}
+    base = {"MAGENT_TUNE": "solo_step=0,scan_solo_max=100", "OMP_NUM_THREADS": "1"}
     plain = ("battle_small_dense,battle_brawl,battle_brawl_big,battle60,battle_walls,battle_largemap,battle_largemap_odd,battle_fill_full,"
              "battle_no_clear,battle_tiny,gather,gather_largemap,battle_lowhp,quad,trans,chase,battle_events,battle_grow,rules_search,battle_epochs")
     names = [n for n in plain.split(",") if n in H.scenarios()]
     assert len(names) == 20
-    for extra in ({"HIPEMU_SCRAMBLE": "5"}, {"MAGENT_OPT_ATTACK_PAIRS": "0", "HIPEMU_SCRAMBLE": "8"}):
-        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EMU_SCENARIOS=",".join(names), **base, **extra), capture_output=True, text=True,
+    for extra in ({"HIPEMU_SCRAMBLE": "5"}, {"MAGENT_TUNE": "attack_pairs=0", "HIPEMU_SCRAMBLE": "8"}):
+        p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"EMU_SCENARIOS": ",".join(names)}, base, extra), capture_output=True, text=True,
                            timeout=1500)
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])

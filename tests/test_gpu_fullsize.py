@@ -88,22 +88,22 @@ def test_bf16_cell_observation_at_full_size():
 DENSE = ["battle_brawl", "battle_brawl_big", "battle_brawl_dense_big", "battle_fill_full", "bodies_large", "tri_rect_large",
          "arrange_live", "battle_food", "battle_turn_large", "bodies_turn", "bodies_turn_large", "arrange_turn"]
 VARIANTS = {
-    "checked_step": {"MAGENT_CHECKED_STEP": "1"},
-    "attack_runs_out": {"MAGENT_OPT_ATTACK_PAIRS": "0"},
-    "move_runs_out": {"MAGENT_OPT_MOVE_BATCHES": "0"},
-    "host_shuffle": {"MAGENT_HOST_SHUFFLE": "1"},
-    "multi_launch_step": {"MAGENT_SOLO_STEP": "0"},
-    "multi_launch_side_stream": {"MAGENT_SOLO_STEP": "0", "MAGENT_OVERLAP": "3"},   # set_action and the head of the step beside the renders
+    "checked_step": {"MAGENT_TUNE": "checked_step=1"},
+    "attack_runs_out": {"MAGENT_TUNE": "attack_pairs=0"},
+    "move_runs_out": {"MAGENT_TUNE": "move_batches=0"},
+    "host_shuffle": {"MAGENT_TUNE": "host_shuffle=1"},
+    "multi_launch_step": {"MAGENT_TUNE": "solo_step=0"},
+    "multi_launch_side_stream": {"MAGENT_TUNE": "solo_step=0,overlap=3"},   # set_action and the head of the step beside the renders
     # the battle-shaped render kernels forced on small worlds (defaults: k_render_sweep2 only at scale, k_render_fast only for bf16 cells)
-    "render_fast": {"MAGENT_RENDER_FAST": "1"},
-    "render_sweep": {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "5"},
-    "render_sweep_3strips": {"MAGENT_RENDER_FAST": "4", "MAGENT_RENDER_SWEEP": "2", "MAGENT_RENDER_SU": "3", "MAGENT_RENDER_DEPTH": "3"},
+    "render_fast": {"MAGENT_TUNE": "render=1"},
+    "render_sweep": {"MAGENT_TUNE": "render=4,render_sweep=5"},
+    "render_sweep_3strips": {"MAGENT_TUNE": "render=4,render_sweep=2,render_su=3,render_depth=3"},
 }
 
 
 @pytest.mark.parametrize("variant", sorted(VARIANTS))
 def test_step_driver_variants(variant):
-    env = dict(os.environ, OMP_NUM_THREADS="1", **VARIANTS[variant])
+    env = H.merge_env(os.environ, {"OMP_NUM_THREADS": "1"}, VARIANTS[variant])
     out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "gpu_check.py")] + DENSE, env=env, capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0 and "failures: 0" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
@@ -123,8 +123,8 @@ def test_fuzz_turn_mode():
     """turn_mode (agents face a direction; moves, attack offsets and the observation window live in the agent's frame; bodies larger
     than one cell re-lay their footprint when they turn -- an order-dependent fixed point of its own): random games, 60 % of them with
     turn_mode on (FUZZ_TURN=2), on both step drivers, HIP == oracle"""
-    for extra in ({}, {"MAGENT_SOLO_STEP": "0"}):
-        env = dict(os.environ, OMP_NUM_THREADS="1", FUZZ_TURN="2", **extra)
+    for extra in ({}, {"MAGENT_TUNE": "solo_step=0"}):
+        env = H.merge_env(os.environ, {"OMP_NUM_THREADS": "1", "FUZZ_TURN": "2"}, extra)
         out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "150"], env=env,
                              capture_output=True, text=True, timeout=1200)
         assert out.returncode == 0 and "150 seeds, 0 failures" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])

@@ -316,14 +316,14 @@ def _play_actions_first(lib, map_size, n, steps, device_api):
 
 @pytest.mark.parametrize("map_size,n", [(40, 300), (160, 9000)])
 def test_observation_between_set_action_and_step(map_size, n):
-    """the engine stores last_action lazily (with MAGENT_OVERLAP set_action runs on a side stream under the renders of large
+    """the engine stores last_action lazily (with MAGENT_TUNE=overlap=3 set_action runs on a side stream under the renders of large
     worlds): an observation asked for after set_action must still show it.  Small world (one-launch step) and large world, host and
     device API; the large world once more in a process with the side stream on."""
     want = _play_actions_first(H.ensure_oracle(), map_size, n, 5, False)
     H.assert_same(want, _play_actions_first(H.HIP_LIB, map_size, n, 5, False), "actions first, host API")
     H.assert_same(want, _play_actions_first(H.HIP_LIB, map_size, n, 5, True), "actions first, device API")
-    if n > 8192 and os.environ.get("MAGENT_OVERLAP") is None:
-        env = dict(os.environ, MAGENT_OVERLAP="3")
+    if n > 8192 and "overlap" not in os.environ.get("MAGENT_TUNE", ""):
+        env = H.merge_env(os.environ, {"MAGENT_TUNE": "overlap=3"})
         out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k", "test_observation_between_set_action_and_step"],
                              env=env, capture_output=True, text=True, timeout=900, cwd=H.ROOT)
         assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-2000:])

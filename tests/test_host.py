@@ -182,13 +182,15 @@ def test_font_provider_and_random_actor(tmp_path):
 
 
 def test_no_kernel_keeps_the_world_in_scratch(hip_lib):
-    """the compiler's resource report of the build (magent_amd/lib/kernel_resources.txt): indexing the by-value world description
+    """the compiler's resource report of the build (magent_amd/lib/kernel_resources_<translation unit>.txt): indexing the by-value world description
     with a per-lane value makes it keep a private copy in scratch memory, 2 KB per lane -- a 15x slowdown that no parity test
     sees.  Every kernel stays within a few bytes of scratch, and the render kernel within its register budget."""
     import re
-    path = os.path.join(os.path.dirname(hip_lib), "kernel_resources.txt")
-    assert os.path.exists(path), "run __graft_entry__.build()"
-    text = open(path).read()
+    text = ""
+    for tu in ("render", "step", "cycle"):
+        path = os.path.join(os.path.dirname(hip_lib), "kernel_resources_%s.txt" % tu)
+        assert os.path.exists(path), "run __graft_entry__.build()"
+        text += open(path).read()
     names = re.findall(r"Function Name: (\S+)", text)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]
     vgprs = [int(x) for x in re.findall(r"remark:\s+VGPRs: (\d+)", text)]

@@ -13,7 +13,7 @@ import helpers as H
 
 
 def _emu():
-    os.environ["MAGENT_POLICY_GRID"] = "3"      # (read once, at the emulated library's first call: three workgroups walk every tile of the conv kernel)
+    os.environ["MAGENT_TUNE"] = "policy_grid=3"      # (read once, at the emulated library's first call: three workgroups walk every tile of the conv kernel)
     lib = ctypes.CDLL(H.ensure_emu())
     lib.policy_dqn_infer.restype = ctypes.c_int
     lib.policy_dqn_infer_bf16.restype = ctypes.c_int

@@ -2,12 +2,12 @@
 export OMP_NUM_THREADS=1
 run() { echo "== $*"; env "$@" 2>&1 | tail -1; }
 run python tools/fuzz_parity.py oracle hip 0 1200
-run MAGENT_SOLO_STEP=0 python tools/fuzz_parity.py oracle hip 1200 2000
-run MAGENT_SOLO_STEP=0 MAGENT_SCAN_SOLO_MAX=64 python tools/fuzz_parity.py oracle hip 2000 2600
+run MAGENT_TUNE=solo_step=0 python tools/fuzz_parity.py oracle hip 1200 2000
+run MAGENT_TUNE=solo_step=0,scan_solo_max=64 python tools/fuzz_parity.py oracle hip 2000 2600
 run FUZZ_TURN=2 python tools/fuzz_parity.py oracle hip 0 500
 run FUZZ_RULES=2 python tools/fuzz_parity.py oracle hip 0 400
 run FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 500
 run FUZZ_BATCH=3 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 200
-run MAGENT_SOLO_STEP=0 MAGENT_OPT_ATTACK_PAIRS=0 python tools/fuzz_parity.py oracle hip 2600 3200
-run MAGENT_RENDER_FAST=4 MAGENT_RENDER_SWEEP=3 python tools/fuzz_parity.py oracle hip 3500 3900
-run MAGENT_RENDER_FAST=1 python tools/fuzz_parity.py oracle hip 3900 4200
+run MAGENT_TUNE=solo_step=0,attack_pairs=0 python tools/fuzz_parity.py oracle hip 2600 3200
+run MAGENT_TUNE=render=4,render_sweep=3 python tools/fuzz_parity.py oracle hip 3500 3900
+run MAGENT_TUNE=render=1 python tools/fuzz_parity.py oracle hip 3900 4200

@@ -41,7 +41,7 @@ if "--one" in sys.argv:
 else:
     configs = []
     for rep in range(2):
-        configs.append(({"MAGENT_RENDER_FAST": "0", "PROBE_BF16": "0"}, "generic"))
+        configs.append(({"MAGENT_TUNE": "render=0", "PROBE_BF16": "0"}, "generic"))
         for pad in ("0", "24000", "44000", "70000", "150000"):
             for span in ("16", "32", "128"):
                 e = {"MAGENT_RENDER_FAST": "1", "PROBE_BF16": "0", "MAGENT_RENDER_SPAN": span, "MAGENT_RENDER_PAD": pad}
