@@ -116,7 +116,10 @@ def small_world_extras(torch, magent_amd, dev, steps=200, warmup=20):
         return env
 
     gen = torch.Generator(device=dev); gen.manual_seed(99)
-    for label, K, batched in (("calls", 1, False), ("cycle_1env", 1, True), ("cycle_8env", 8, True), ("cycle_32env", 32, True)):
+    # (`ordered`: EnvBatch's DEFAULT input ordering -- the environments' streams wait for torch's current stream every cycle; the other
+    # lines switch it off because this loop orders by env.sync())
+    for label, K, batched, ordered in (("calls", 1, False, False), ("cycle_1env", 1, True, False), ("cycle_8env", 8, True, False),
+                                       ("cycle_32env", 32, True, False), ("cycle_32env_default_ordering", 32, True, True)):
         envs = [make(5000 + k) for k in range(K)]
         views = [[torch.empty((N, 13, 13, 7), device=dev) for _ in range(2)] for _ in envs]
         feats = [[torch.empty((N, 34), device=dev) for _ in range(2)] for _ in envs]
@@ -124,7 +127,7 @@ def small_world_extras(torch, magent_amd, dev, steps=200, warmup=20):
         acts = [[[torch.randint(21, (N,), dtype=torch.int32, device=dev, generator=gen) for _ in range(2)] for _ in envs] for _ in range(4)]
         torch.cuda.synchronize()
         batch = magent_amd.EnvBatch(envs, n_threads=8)
-        batch.order_streams = False          # (this loop orders by env.sync(); no torch work touches the buffers in between)
+        batch.order_streams = ordered
         if batched:      # fixed buffers: the device-pointer arrays are built once, not 8 x K data_ptr() calls per cycle
             views_p, feats_p, rews_p = batch.pointers(views), batch.pointers(feats), batch.pointers(rews)
             acts_p = [batch.pointers(a) for a in acts]

@@ -53,7 +53,8 @@ int env_get_observation(EnvHandle game, GroupHandle group, float **buffer);
  * call (two entries in the shuffled attack list, two moves in list order), and last_action is the latest call's.  No caller of the
  * reference does that, so it is served off the hot path: the step runs the reference's sequential loops on one lane of the device
  * (exact, about a microsecond per list entry) -- for one-cell bodies without turn_mode, food_mode and goals; other games still
- * abort with a message.  An action outside [0, n_action) is reported at env_step (FATAL; the reference indexes out of range). */
+ * abort with a message (the reference's own error path is an abort too: LOG(FATAL), utility.h:77-103).  A step of this kind records
+ * no attack events for env_render.  An action outside [0, n_action) is reported at env_step (FATAL; the reference indexes out of range). */
 int env_set_action(EnvHandle game, GroupHandle group, const int *actions);
 /* runtime_api.h:29 -> GridWorld::step (GridWorld.cc:456-631) */
 int env_step(EnvHandle game, int *done);
@@ -143,6 +144,9 @@ int env_get_stream(EnvHandle game, void **stream);
  * asynchronously on a stream of its own orders THIS stream behind it.  Equal to env_get_stream's for small worlds or
  * with MAGENT_TUNE overlap=0 (the default).  All outputs (observations, rewards, infos) are ordered on env_get_stream's stream as before. */
 int env_get_action_stream(EnvHandle game, void **stream);
+/* both streams of n_env environments in one call (out: 2 * n_env pointers, [2 e] = env_get_stream, [2 e + 1] = env_get_action_stream):
+ * what a batch of environments needs to order its inputs once per DISTINCT stream -- environments cycled together share one */
+int env_streams_many(EnvHandle *games, int n_env, void **out);
 
 /* Kernel timing with HIP events recorded on the environment's stream.
  * env_profile_enable(game, 1) starts recording one event pair per launch of each named kernel; (game, 2) records

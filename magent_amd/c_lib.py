@@ -49,6 +49,7 @@ DEVICE_ABI = [
     ("env_num_many", [_c.POINTER(_vp), _i, _i, _ip]),
     ("env_sync", [_vp]),
     ("env_get_stream", [_vp, _c.POINTER(_vp)]),
+    ("env_streams_many", [_c.POINTER(_vp), _i, _c.POINTER(_vp)]),
     ("env_get_action_stream", [_vp, _c.POINTER(_vp)]),
     ("env_profile_enable", [_vp, _i]),
     ("env_profile_read", [_vp, _cp, _ip, _fp]),

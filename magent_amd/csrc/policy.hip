@@ -580,11 +580,16 @@ static int dqn_infer(const PolicyDqnShape *s, const PolicyDqnWeights *w, const v
     const bool f13 = H == 13 && W == 13;
     // the stream's device is made current (launches and function attributes are per device), and the dynamic-LDS allowance is
     // granted once per DEVICE, not once per process
-    int dev = 0;
+    // (the caller's current device is put back when the call returns: a C-ABI call must not leave a side effect in a multi-GPU process)
+    int dev = 0, caller_dev = -1;
+    if (hipGetDevice(&caller_dev) != hipSuccess) return 2;
     if (st) { if (hipStreamGetDevice(st, &dev) != hipSuccess || hipSetDevice(dev) != hipSuccess) return 2; }
-    else if (hipGetDevice(&dev) != hipSuccess) return 2;
-    static bool lds_ok_dev[64] = {};
-    bool &lds_ok = lds_ok_dev[dev & 63];
+    else dev = caller_dev;
+    struct Restore { int d, cur; ~Restore() { if (d != cur) (void)hipSetDevice(d); } } restore{caller_dev, dev};
+    constexpr int MAX_DEV = 64;
+    if (dev < 0 || dev >= MAX_DEV) return 2;
+    static bool lds_ok_dev[MAX_DEV] = {};
+    bool &lds_ok = lds_ok_dev[dev];
     if (!lds_ok) {
         const void *convs[5] = {reinterpret_cast<const void *>(k_dqn_conv<false, false>), reinterpret_cast<const void *>(k_dqn_conv<true, false>),
                                 reinterpret_cast<const void *>(k_dqn_conv<false, true>), reinterpret_cast<const void *>(k_dqn_conv<true, true>),

@@ -159,6 +159,11 @@ int env_num_many(EnvHandle *games, int n_env, int n_group, int *out) {
     }
     return 0;
 }
+// the streams of n_env environments in one call: out[2 e] = env_get_stream's, out[2 e + 1] = env_get_action_stream's
+int env_streams_many(EnvHandle *games, int n_env, void **out) {
+    for (int e = 0; e < n_env; e++) { out[2 * e] = (void *)E(games[e])->stream; out[2 * e + 1] = (void *)E(games[e])->action_stream(); }
+    return 0;
+}
 int env_sync(EnvHandle game) { E(game)->sync(); return 0; }
 int env_get_stream(EnvHandle game, void **stream) { *stream = (void *)E(game)->stream; return 0; }
 int env_get_action_stream(EnvHandle game, void **stream) { *stream = (void *)E(game)->action_stream(); return 0; }

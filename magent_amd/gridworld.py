@@ -197,6 +197,9 @@ class GridWorld(object):
         spaces = ((0, self.view_space[g], torch.float32), (1, self.feature_space[g], torch.float32))
         if self._obs_bf16:
             spaces = ((0, self.view_space[g][:2] + (8,), torch.bfloat16), spaces[1])
+        # Validity contract: the tensors returned for a group stay valid until the NEXT get_observation call for that group (the reference
+        # reuses its numpy buffers the same way); the cache holds two sets per group -- twice the observation memory, 7.8 GB at
+        # 2 x 400k float32 agents.
         # Two sets of buffers per group, handed out in turn.  The set written now was handed out two calls ago, and (like the
         # reference's reused buffers) stopped being valid at the previous call for this group: whatever torch work reads it was
         # queued before that call, where an event was recorded on torch's stream.  The render waits for THAT event -- not for
@@ -210,20 +213,23 @@ class GridWorld(object):
             if buf is None or buf.shape[0] < n:
                 buf = self._dev_cache[which][(g, slot)] = torch.empty((n,) + space, dtype=dtype, device=dev)
             out.append(buf[:n])
+        # (the event only covers work queued on the torch stream it was recorded on: a caller that has switched streams since -- a
+        # worker stream, another thread -- gets the full ordering against its CURRENT stream instead)
         guard = self._dev_guard.get((g, slot))
-        if guard is None:
+        cur = torch.cuda.current_stream(dev)
+        if guard is None or guard[1] != cur.cuda_stream:
             self.order_after_torch()
         else:
             for st in self._streams():
-                st.wait_event(guard)
+                st.wait_event(guard[0])
         if self._obs_bf16:
             self.get_observation_device_bf16(g, out[0], out[1])
         else:
             self.get_observation_device(g, out[0], out[1])
         self.order_torch_after()
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))       # everything queued so far may still read the OTHER set: its next render waits for this
-        self._dev_guard[(g, slot ^ 1)] = ev
+        ev.record(cur)                                  # everything queued so far may still read the OTHER set: its next render waits for this
+        self._dev_guard[(g, slot ^ 1)] = (ev, cur.cuda_stream)
         return out[0], out[1]
 
     def use_bf16_observations(self, on=True):
@@ -656,7 +662,8 @@ class EnvBatch(object):
         self._done = (ctypes.c_int32 * n)()
         self._adopted = False
         self.order_streams = True
-        self._uniq = None
+        self._stream_ptrs = (ctypes.c_void_p * (2 * n))()
+        self._uniq, self._uniq_key = None, None
 
     def pointers(self, tensors):
         """the device-pointer array of a list (per env) of lists (per group) of CUDA tensors (None entries allowed).  cycle()
@@ -696,22 +703,28 @@ class EnvBatch(object):
         return [bool(d) for d in self._done]
 
     def _distinct(self):
-        """one environment per distinct engine stream (batched environments share their leader's stream; an environment may
-        join the batch in a later cycle, so the streams are asked for every time: a ctypes call each)"""
-        seen, uniq = set(), []
-        for e in self.envs:
-            key = tuple(st.cuda_stream for st in e._streams())
-            if key not in seen:
-                seen.add(key)
-                uniq.append(e)
-        return uniq
+        """one environment per distinct engine stream.  Batched environments share their leader's stream, and an environment may join
+        the batch in a later cycle: the streams are asked for every cycle -- ONE library call for all of them (env_streams_many) -- and
+        the list is rebuilt only when a pointer has changed (two ctypes calls per environment and cycle cost a 64-
+        environment batch as much as the cycle itself)"""
+        self._lib.env_streams_many(self._handles, len(self.envs), self._stream_ptrs)
+        key = bytes(self._stream_ptrs)
+        if key != self._uniq_key:
+            seen, uniq = set(), []
+            for k, e in enumerate(self.envs):
+                pair = (self._stream_ptrs[2 * k], self._stream_ptrs[2 * k + 1])
+                if pair not in seen:
+                    seen.add(pair)
+                    uniq.append(e)
+            self._uniq, self._uniq_key = uniq, key
+        return self._uniq
 
     def _cycle_raw(self, views, feats, actions, rewards):
         self._lib.env_cycle_many(self._handles, len(self.envs), self.n_group, self._ptrs(views), self._ptrs(feats),
                                  self._ptrs(actions), self._ptrs(rewards), self._done, self.n_threads)
         if not self._adopted:      # environments cycled together share the first one's stream from now on
             self._adopted = True
-            self._uniq = None
+            self._uniq_key = None
             for e in self.envs:
                 e._ext_stream = None
         return [bool(d) for d in self._done]
