@@ -80,5 +80,5 @@ def test_default_multi_rank_line_carries_the_c4_gather_extra():
     assert rec["n_gpus"] == 2 and rec["config"]["gather"] == "none" and rec["config"]["agents_at_start"] == [400000, 400000]
     x = rec["extra"]["c4_gather_rccl"]
     assert x["verified"]["all_shards_bit_identical"] is True and x["verified"]["distinct_replicas"] == 2
-    assert x["payload_bytes_to_each_peer"] > 100000 * 6300 * 0.9 and x["exchange_ms"] > 0 and x["GBps_per_link"] > 0
+    assert x["payload_bytes_to_each_peer"] > 50000 * 6300 and x["exchange_ms"] > 0 and x["GBps_per_link"] > 0
     assert x["ms_per_step_with_gather"] > 0 and x["ms_per_step_without_gather"] > 0 and x["xgmi_link_peak_GBps"] == 153.0
