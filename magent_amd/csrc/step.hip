@@ -349,10 +349,12 @@ __global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, 
     } else if (!dead && (pend & ~PEND_ARG) == PEND_MOVE) {
         const int2 d = W.delta[T.move_off + (pend & PEND_ARG)];
         const int nx = x + d.x, ny = y + d.y;
-        // is_blank_area bounds (Map.cc:455) for a 1x1 body; a zero move "succeeds" in place and never vacates
-        if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + 1 < W.w && ny + 1 < W.h && W.occ[ny * W.w + nx] != OCC_WALL) t = ny * W.w + nx;
+        // is_blank_area bounds (Map.cc:455) for a 1x1 body; a zero move "succeeds" in place and never vacates.  Whether the cell is a wall
+        // is looked up by k_strike, which reads the cell anyway: until then a mover into a wall counts as one that "may leave" -- whoever
+        // claims its cell on that ground depends on its move, which fails: the same outcome as "occupied by somebody who stays"
+        if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + 1 < W.w && ny + 1 < W.h) t = ny * W.w + nx;
     }
-    PW.g[g].rec[i] = make_int4((int)key, dead ? -1 : RANK_INF, t, (int)MV_FAIL);
+    PW.g[g].rec[i] = make_int4((int)key, dead ? -1 : RANK_INF, t, (int)MV_FAIL_SAME);    // (status: "no move, hp as it was" until k_strike knows better)
     PW.g[g].atk[i] = tgt;
     // hp as the attack phase leaves it unless somebody hits me (k_plain_eval overwrites it then): only claimants that must know whether
     // their occupant is about to starve read it of an agent that was not hit -- types that recover never starve
@@ -426,6 +428,7 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
         float hp = G.hp[i];
         const unsigned hp_before = __float_as_uint(hp);
         float nr = G.next_reward[i];
+        const unsigned nr_before = __float_as_uint(nr);
         int last_op = OP_NULL, op_obj = -1;              // (what clear_dead left: with rules fused, the host has seen it run since the last step)
         // ---- the attack phase applied from the converged death ranks (attack_apply_body, one-cell bodies, no supply)
         if (attacked && !dead) {
@@ -462,7 +465,7 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
                 if (hp < 0.0f) { dead = died = true; nr = T.dead_penalty; }
             }
         }
-        G.hp[i] = hp;
+        if (__float_as_uint(hp) != hp_before) G.hp[i] = hp;      // (most agents of a battle stand at full hp: stores only where something changed)
         if (died) G.dead[i] = 1;
         // ---- calc_reward for the rules that pay their subject (rule_body; the reference visits the dead too, GridWorld.cc:681-692)
         for (int k = 0; k < R.n; k++) {
@@ -472,13 +475,14 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
                 for (int q = 0; q < R.r[k].n_subj; q++) nr += R.r[k].v[q];
             }
         }
-        G.next_reward[i] = nr;
+        if (__float_as_uint(nr) != nr_before) G.next_reward[i] = nr;
         // ---- my move: the claim on its target cell (move_prep_body + move_claim_body)
         if (!dead && me.z >= 0) {
             const int c = me.z;
             const unsigned key = (unsigned)me.x;
             int o = W.occ[c];
             bool ok = o == OCC_EMPTY;
+            if (o == OCC_WALL) PW.g[g].rec[i].z = -1;    // no move at all (Map::is_blank_area): k_plain_init / k_plain_commit see a non-mover
             if (o >= 0) {
                 const int4 oc = ptab[ref_group(o)].rec[ref_index(o)];
                 const float orec = ttab[ref_group(o)].step_recover;
@@ -490,8 +494,9 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
             PW.g[g].atk[i] = o;              // what my target cell holds when the moves begin, for k_plain_init / k_plain_commit (a mover has no attack target)
             if (ok) atomicMin(&W.claim[c], claim_word(PW.epoch, key, ref_pack(g, i)));
         }
-        // (every agent's move status starts here; k_plain_init raises the winners')
-        PW.g[g].rec[i].w = died ? (int)MV_DIED : __float_as_uint(hp) == hp_before ? (int)MV_FAIL_SAME : (int)MV_FAIL;
+        // (the move status k_plain_rank left says "hp as it was": corrected here where it is not; k_plain_init raises the winners')
+        if (died) PW.g[g].rec[i].w = (int)MV_DIED;
+        else if (__float_as_uint(hp) != hp_before) PW.g[g].rec[i].w = (int)MV_FAIL;
     }
     int wtot;
     wave_rank(died, wtot);
@@ -505,7 +510,8 @@ __global__ void __launch_bounds__(256) k_plain_init(WorldView W, PlainWorld PW) 
     const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     const GroupDev &G = W.grp[g];
     if (i >= G.n) return;
-    const int4 me = PW.g[g].rec[i];
+    const int2 me_zw = ((const int2 *)&PW.g[g].rec[i])[1];       // {move target, status}
+    struct { int z, w; } me{me_zw.x, me_zw.y};
     if ((unsigned)me.w == MV_DIED) {             // Map::remove_agent (Map.cc:272, GridWorld.cc:536): nobody reads the map in this launch
         cells_clear(W, G.x[i], G.y[i], 1, 1);
         PW.g[g].rec[i].w = (int)MV_FAIL;
