@@ -282,7 +282,7 @@ Env::~Env() {
     dfree(arena, d_occ); dfree(arena, d_viewcell); dfree(arena, d_claim); dfree(arena, d_food); dfree(arena, d_powtab); dfree(arena, d_counters); dfree(arena, d_gtab); dfree(arena, d_ttab);
     dfree(arena, d_delta); dfree(arena, d_mask); dfree(arena, d_mini); dfree(arena, d_minif); dfree(arena, d_sums); dfree(arena, d_rank); dfree(arena, d_shuf); dfree(arena, d_events); dfree(arena, d_actions);
     dfree(arena, d_stage_view); dfree(arena, d_stage_feat); dfree(arena, d_stage_small);
-    dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d); dfree(arena, d_asums); dfree(arena, d_wpre); dfree(arena, d_ptab);
+    dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d); dfree(arena, d_asums); dfree(arena, d_wpre); dfree(arena, d_ptab); dfree(arena, d_alive);
     if (batch_h) (void)hipHostFree(batch_h);
     if (h_rec) (void)hipHostFree(h_rec);
     if (pool) {
@@ -1519,8 +1519,8 @@ void Env::attack_rounds_checked(const WorldView &W) {
         clear_changed();
         if (step_was_plain) {          // (the continuation of a step of the plain pipeline: its own rounds)
             const PlainWorld PW = plain_view();
-            launch_plain_eval(stream, W, PW, d_ptab, d_gtab, d_ttab, ++attack_round, -1);
-            launch_plain_eval(stream, W, PW, d_ptab, d_gtab, d_ttab, ++attack_round, CTR_CHANGED);
+            launch_plain_eval(stream, W, PW, d_ptab, d_gtab, d_ttab, ++attack_round, -1, shuffle_bufs());
+            launch_plain_eval(stream, W, PW, d_ptab, d_gtab, d_ttab, ++attack_round, CTR_CHANGED, shuffle_bufs());
             iters += 2;
             if (!read_changed()) break;
             if (iters > 1000000) fatal("attack resolution did not converge");
@@ -1638,6 +1638,7 @@ void Env::step_begin() {
     const bool generic_turns = turn_mode && any_multicell;
     const bool fast = !checked_step && !host_shuffle && first_render && !generic_turns;
     step_pending = true;
+    alive_valid = false;
     step_was_fast = false;
     step_was_solo = false;
     step_was_plain = false;
@@ -1694,16 +1695,17 @@ void Env::step_begin() {
         {
             ProfScope p(*this, "attack", false, a);
             // (plain games keep their hits in per-agent masks; otherwise the draw zero-fills the per-cell hit words)
-            launch_shuffle(a, total_n, d_counters, shuffle_bufs(), d_rank, plain ? nullptr : d_hit, (size_t)width * height, d_powtab, step_sa_tiled);
+            if (plain) launch_shuffle_draw(a, total_n, d_counters, shuffle_bufs(), d_powtab, step_sa_tiled);
+            else launch_shuffle(a, total_n, d_counters, shuffle_bufs(), d_rank, d_hit, (size_t)width * height, d_powtab, step_sa_tiled);
             if (overlap_level == 2 && a != stream) { join_side(); a = stream; }
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
             // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
             // LAST one reports whether anything still moved (one gate for all of them)
             if (plain) {
-                launch_plain_rank(a, W, PW, d_ptab, d_rank, shuffle_bufs(), d_asums, d_wpre, seq_plan());
+                launch_plain_rank(a, W, PW, d_ptab, shuffle_bufs(), d_asums, d_wpre, seq_plan());
                 for (int r = 0; r < 2 * pairs; r++)
-                    launch_plain_eval(a, W, PW, d_ptab, d_gtab, d_ttab, ++attack_round, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
+                    launch_plain_eval(a, W, PW, d_ptab, d_gtab, d_ttab, ++attack_round, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1, shuffle_bufs());
             } else {
                 launch_attack_rank(a, W, d_rank, shuffle_bufs(), false, d_asums, d_wpre, seq_plan());
                 for (int r = 0; r < 2 * pairs; r++)
@@ -1722,6 +1724,7 @@ void Env::step_begin() {
                 ProfScope p(*this, "rules");
                 launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
             }
+            alive_valid = true;
         } else {
         {
             ProfScope p(*this, "attack");
@@ -1823,6 +1826,13 @@ PlainWorld Env::plain_view() {
     PlainWorld PW{};
     for (size_t g = 0; g < groups.size(); g++) PW.g[g] = groups[g].pl;
     PW.S = plain_slots; PW.kmax = attack_kmax;
+    {   // where k_strike leaves its survivor counts (one per 256 agents, group after group)
+        size_t total = 0;
+        for (size_t g = 0; g < groups.size(); g++) { alive_off[g] = (int)total; alive_n[g] = groups[g].n; total += (size_t)(groups[g].n + 255) / 256; }
+        grow(arena, d_alive, alive_cap, std::max<size_t>(total, 1), stream);
+        PW.alive = d_alive;
+        for (int g = 0; g < MAXG; g++) PW.alive_off[g] = g < (int)groups.size() ? alive_off[g] : 0;
+    }
     PW.epoch = 62 - (int)(plain_epoch % 63u);
     PW.round_base = (int)(plain_epoch * 64u);            // (wraps after 2^26 steps: the stamps are compared modulo 2^32)
     if (!ptab_valid) {
@@ -2252,7 +2262,14 @@ void Env::clear_dead() {
         }
         grow(arena, d_sums, sums_cap, nb_total, stream);
         const MiniArgs M = next_minimap();
-        launch_clear_compact(stream, W, A, d_sums, M, fold_counts());
+        // (the last step was one of the plain pipeline and nothing was added since: k_strike has left the survivors of every 256 agents)
+        bool counted = alive_valid;
+        for (size_t g = 0; g < groups.size(); g++) counted &= groups[g].n == alive_n[g];
+        if (counted) {
+            for (size_t g = 0; g < groups.size(); g++) A.sums_off[g] = alive_off[g];
+            A.sums_per_tile = SCAN_TILE_HOST / 256;
+        }
+        launch_clear_compact(stream, W, A, counted ? d_alive : d_sums, M, fold_counts());
         for (size_t g = 0; g < groups.size(); g++) if (A.mode[g] == 2) swap_buffers(groups[g]);
         launch_clear_finish(stream, view(), A, d_gtab, d_ttab, M, fold_counts());   // also refreshes the device tables
         tables_valid = true;

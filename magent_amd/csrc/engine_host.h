@@ -222,6 +222,9 @@ private:
     int plain_steps = 0, plain_slots = 0;
     bool plain_world = false, step_was_plain = false, step_fused_rules = false, ptab_valid = false;
     PlainGroup *d_ptab = nullptr;
+    int *d_alive = nullptr; size_t alive_cap = 0;      // survivors per 256 agents, left by k_strike for clear_dead (PlainWorld::alive)
+    int alive_off[MAXG] = {}, alive_n[MAXG] = {};
+    bool alive_valid = false;
     PlainWorld plain_view();
     void plain_arrays(HostGroup &g, size_t n, size_t cap);
     bool stale_events = false;            // a step has run since the last clear_dead: last_op / op_obj are not all OP_NULL / -1

@@ -550,7 +550,7 @@ __device__ __forceinline__ unsigned rng_skip(unsigned x, unsigned n) {
     return x;
 }
 // (A: the length of this step's attack list)
-__device__ __forceinline__ void shuffle_chase_body(int i, int A, const int *j, const int *head, const int *first, const int *link, int *rank) {
+__device__ __forceinline__ int shuffle_chase_pos(int i, int A, const int *j, const int *head, const int *first, const int *link) {
     int p = j[i];
     int nxt = 0x7FFFFFFF;
     for (int e = head[p]; e != 0; e = link[e - 1]) { const int k = e - 1; if (k > i && k < nxt && k < A) nxt = k; }
@@ -558,7 +558,10 @@ __device__ __forceinline__ void shuffle_chase_body(int i, int A, const int *j, c
         p = nxt;
         for (int f; (f = first[p]) != 0;) { const int m = 0x7FFFFFFF - f; if (m >= A) break; p = m; }
     }
-    rank[i] = p;
+    return p;
+}
+__device__ __forceinline__ void shuffle_chase_body(int i, int A, const int *j, const int *head, const int *first, const int *link, int *rank) {
+    rank[i] = shuffle_chase_pos(i, A, j, head, first, link);
 }
 
 // ------------------------------------------------------------------------------------------------ attack phase

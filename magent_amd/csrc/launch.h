@@ -139,14 +139,18 @@ struct PlainGroup { int4 *rec; int *atk; unsigned *hmask; uint2 *hlist; };
 struct PlainWorld {
     PlainGroup g[MAXG];
     int S, kmax;          // slots per agent (attack offsets of all groups); most hits one agent can receive
+    int *alive;           // k_strike leaves the survivors of every 256 agents here (alive_off[g] + block): clear_dead's compaction needs no count pass
+    int alive_off[MAXG];
     int epoch;            // of this step's claim words (kernels.hip: claim_word): 62 - (plain step number mod 63)
     int round_base;       // + round = the "inputs changed" stamp of a round of this step (they count on from step to step)
 };
 bool fused_rules(const RuleArgs *rules, int n);
 bool plain_eval_lds_ok(int kmax);
-void launch_plain_rank(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const int *rank, const ShuffleBufs &B, const int *sums,
+void launch_shuffle_draw(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, const unsigned *powtab, bool tiled);
+void launch_plain_rank(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const ShuffleBufs &B, const int *sums,
                        const int *wpre, const SeqPlan &P);
-void launch_plain_eval(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, int round, int flag);
+void launch_plain_eval(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, int round, int flag,
+                       const ShuffleBufs &B);
 void launch_plain_tail(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab,
                        const RuleArgs *rules /* null: not fused */, int n_rules);
 void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag);
@@ -169,6 +173,7 @@ void launch_get_alive(hipStream_t s, const GroupDev &G, unsigned char *out);
 struct ClearArgs {
     int mode[MAXG];        // 0 nothing (empty group), 1 Agent::init_reward only, 2 compaction of the survivors
     int sums_off[MAXG];    // where the group's block totals start in `sums`
+    int sums_per_tile;     // entries of `sums` per compaction tile: 1 (k_clear_count), or SCAN_ITEMS when k_strike left one per 256 agents
     typedef AltArrays Alt;
     Alt dst[MAXG];
 };

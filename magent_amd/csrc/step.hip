@@ -306,13 +306,13 @@ __global__ void __launch_bounds__(256) k_move_commit(WorldView W, const GroupDev
     if (W.live_paint) repaint_body(W, W.grp[g], W.type[g], g, i);
 }
 
-__global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, const PlainGroup *ptab, const int *rank, int *shuf_head, int *shuf_first,
-                                                   const int *sums, const int *wpre, SeqPlan P) {
-    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // attack rounds start
+__global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, const PlainGroup *ptab, ShuffleBufs B, const int *sums, const int *wpre, SeqPlan P) {
     const int A = W.counters[CTR_ATTACK];
-    // the shuffle's list heads and first-hit words have been read for the last time (k_shuffle_chase): back to zero for their next use
-    for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < A; k += gridDim.x * gridDim.y * blockDim.x) {
-        shuf_head[k] = 0; shuf_first[k] = 0;
+    if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) {
+        W.counters[CTR_CHANGED] = 0;   // attack rounds start
+        // (every draw has read the old engine state: k_shuffle_draw ran before; nobody reads it in this launch)
+        W.counters[CTR_LAST_A] = A;
+        W.counters[CTR_RNG] = (int)rng_skip((unsigned)W.counters[CTR_RNG], (unsigned)A);
     }
     const int g = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -330,7 +330,9 @@ __global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, 
     unsigned key = G.key[i];          // a move's order key -- or, from the one-workgroup set_action, the attack's sequence number
     int tgt = -1, t = -1;
     if (!dead && att) {
-        key = (unsigned)rank[seq >= 0 ? seq : (int)key];
+        // the attack's rank in the shuffled list: the chase of its own list entry (k_shuffle_chase's walk, by the agent itself -- no rank
+        // array, one launch less); the lists are read-only in this launch and go back to zero in round 1 of k_plain_eval
+        key = (unsigned)shuffle_chase_pos(seq >= 0 ? seq : (int)key, A, B.j, B.head, B.first, B.link);
         const int k = pend & PEND_ARG;
         const int2 d = W.delta[T.attack_off + k];
         const int tx = x + d.x, ty = y + d.y;
@@ -344,9 +346,7 @@ __global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, 
                 atomicOr(&TG.hmask[ref_index(o)], 1u << slot);
             }
         }
-    } else if (att) {
-        key = (unsigned)rank[seq >= 0 ? seq : (int)key];   // (dead before the step: its list entry exists, and does nothing)
-    } else if (!dead && (pend & ~PEND_ARG) == PEND_MOVE) {
+    } else if (!dead && (pend & ~PEND_ARG) == PEND_MOVE) {      // (an attacker that was dead before the step: its list entry exists, and does nothing)
         const int2 d = W.delta[T.move_off + (pend & PEND_ARG)];
         const int nx = x + d.x, ny = y + d.y;
         // is_blank_area bounds (Map.cc:455) for a 1x1 body; a zero move "succeeds" in place and never vacates.  Whether the cell is a wall
@@ -362,8 +362,15 @@ __global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, 
 }
 
 // (s_rank / s_ref: the thread's hit list, stride NT, slot tid -- sort_hits)
-__global__ void __launch_bounds__(256) k_plain_eval(WorldView W, PlainWorld PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, int round, int flag) {
-    if (W.counters[CTR_ATTACK] == 0) return;
+__global__ void __launch_bounds__(256) k_plain_eval(WorldView W, PlainWorld PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, int round, int flag,
+                                                   int *shuf_head, int *shuf_first) {
+    const int A = W.counters[CTR_ATTACK];
+    if (A == 0) return;
+    // the shuffle's list heads and first-hit words have been read for the last time (k_plain_rank): back to zero for their next use
+    if (round == 1)
+        for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < A; k += gridDim.x * gridDim.y * blockDim.x) {
+            shuf_head[k] = 0; shuf_first[k] = 0;
+        }
     // nobody's death rank changed in the round before: nobody is stamped for this one
     if (round > 1 && W.counters[CTR_ROUND_CHANGED + ((round - 1) & (ROUND_SLOTS - 1))] == 0) return;
     extern __shared__ unsigned s_hit[];
@@ -418,7 +425,7 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
     const GroupDev &G = W.grp[g];
     const TypeDev &T = W.type[g];
     const bool attacked = W.counters[CTR_ATTACK] != 0;
-    bool died = false;
+    bool died = false, alive = false;
     unsigned trig = 0;
     if (i < G.n) {
         const int pend = G.pend[i];
@@ -467,6 +474,7 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
         }
         if (__float_as_uint(hp) != hp_before) G.hp[i] = hp;      // (most agents of a battle stand at full hp: stores only where something changed)
         if (died) G.dead[i] = 1;
+        alive = !dead;
         // ---- calc_reward for the rules that pay their subject (rule_body; the reference visits the dead too, GridWorld.cc:681-692)
         for (int k = 0; k < R.n; k++) {
             if (R.r[k].ga != g) continue;
@@ -503,6 +511,12 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
     if (wtot && lane_id() == 0) atomicAdd(&W.counters[dead_slot(g, blockIdx.x % DEAD_SLOTS)], wtot);
     for (int k = 0; k < R.n; k++)
         if (__ballot((trig >> k) & 1u) && lane_id() == 0) W.counters[CTR_TRIGGER + R.r[k].rule_no] = 1;
+    // the survivors of this workgroup's 256 agents, for clear_dead's compaction (k_clear_count's pass: nobody dies after this launch)
+    __shared__ int s_alive[4];
+    const int alive_w = __popcll(__ballot(alive));
+    if (lane_id() == 0) s_alive[threadIdx.x >> 6] = alive_w;
+    __syncthreads();
+    if (threadIdx.x == 0 && (int)(blockIdx.x * blockDim.x) < G.n) PW.alive[PW.alive_off[g] + blockIdx.x] = s_alive[0] + s_alive[1] + s_alive[2] + s_alive[3];
 }
 
 __global__ void __launch_bounds__(256) k_plain_init(WorldView W, PlainWorld PW) {
@@ -716,7 +730,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_clear_compact(WorldView W, Cle
                        { const int2 fp = W.turn_mode ? dims_for_dir(W.type[g], G.dir[i]) : make_int2(bw, bl); body_fill(W, x, y, fp.x, fp.y, ref_pack(g, r)); }
                        if (VHW > 0) atomicAdd(&s_hist[(y / M.scale_h) * M.vw + x / M.scale_w], 1);
                    },
-                   G.n, block_prefix(sums + A.sums_off[g], blockIdx.x));
+                   G.n, block_prefix(sums + A.sums_off[g], blockIdx.x * A.sums_per_tile));
     }
     if (VHW > 0) {
         __syncthreads();
@@ -1001,17 +1015,22 @@ bool fused_rules(const RuleArgs *rules, int n) {
     for (int k = 0; k < n; k++) if (rules[k].pair || rules[k].prog >= 0 || rules[k].n_obj || (rules[k].op != OP_ATTACK && rules[k].op != OP_KILL)) return false;
     return true;
 }
-void launch_plain_rank(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const int *rank, const ShuffleBufs &B, const int *sums,
+void launch_plain_rank(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const ShuffleBufs &B, const int *sums,
                        const int *wpre, const SeqPlan &P) {
-    hipLaunchKernelGGL(k_plain_rank, grid_all(W, 256), dim3(256), 0, s, W, PW, ptab, rank, B.head, B.first, sums, wpre, P);
+    hipLaunchKernelGGL(k_plain_rank, grid_all(W, 256), dim3(256), 0, s, W, PW, ptab, B, sums, wpre, P);
 }
 size_t plain_eval_lds(int kmax) { return (size_t)kmax * 256 * 8; }
 bool plain_eval_lds_ok(int kmax) {
     if (plain_eval_lds(kmax) <= (48u << 10)) return true;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_plain_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plain_eval_lds(kmax)) == hipSuccess;
 }
-void launch_plain_eval(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, int round, int flag) {
-    hipLaunchKernelGGL(k_plain_eval, grid_all(W, 256), dim3(256), plain_eval_lds(PW.kmax), s, W, PW, ptab, gtab, ttab, round, flag);
+void launch_plain_eval(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, int round, int flag,
+                       const ShuffleBufs &B) {
+    hipLaunchKernelGGL(k_plain_eval, grid_all(W, 256), dim3(256), plain_eval_lds(PW.kmax), s, W, PW, ptab, gtab, ttab, round, flag, B.head, B.first);
+}
+// the draws of the attack shuffle alone (the plain pipeline: every attacker chases its own list entry in k_plain_rank)
+void launch_shuffle_draw(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, const unsigned *powtab, bool tiled) {
+    hipLaunchKernelGGL(k_shuffle_draw, dim3((n_max + 255) / 256), dim3(256), 0, s, counters, B.j, B.head, B.first, B.link, (unsigned *)nullptr, (size_t)0, powtab, tiled ? 1 : 0);
 }
 void launch_plain_tail(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab,
                        const RuleArgs *rules, int n_rules) {
@@ -1100,12 +1119,14 @@ void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D,
     (void)new_n; (void)sums;
     if (W.grp[g].n > 0) hipLaunchKernelGGL(k_compact_solo, dim3(1), dim3(SOLO_THREADS), 0, s, W, g, D);
 }
-void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A, int *sums, const MiniArgs &M, int *counts) {
+void launch_clear_compact(hipStream_t s, const WorldView &W, const ClearArgs &A_in, int *sums, const MiniArgs &M, int *counts) {
+    ClearArgs A = A_in;
+    if (A.sums_per_tile <= 0) A.sums_per_tile = 1;
     int mx = 1;
     bool any = false;
     for (int g = 0; g < W.G; g++) { mx = std::max(mx, W.grp[g].n); any |= A.mode[g] == 2; }
     dim3 grid((mx + SCAN_TILE - 1) / SCAN_TILE, W.G);
-    if (any) hipLaunchKernelGGL(k_clear_count, grid, dim3(SCAN_THREADS), 0, s, W, A, sums);
+    if (any && A.sums_per_tile == 1) hipLaunchKernelGGL(k_clear_count, grid, dim3(SCAN_THREADS), 0, s, W, A, sums);    // (else: k_strike counted)
     hipLaunchKernelGGL(k_clear_compact, grid, dim3(SCAN_THREADS), sizeof(int) * (size_t)M.vh * M.vw, s, W, A, sums, M, counts);
 }
 void launch_mini_norm(hipStream_t s, const WorldView &Wn, const MiniArgs &M, int *counts) {
