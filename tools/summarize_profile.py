@@ -31,7 +31,7 @@ def main():
     shutil.copy(os.path.join(stats_dir, "bench_kernel_stats.csv"), os.path.join(out_dir, tag + "_kernel_stats.csv"))
     rows = list(csv.DictReader(open(os.path.join(stats_dir, "bench_kernel_stats.csv"))))
     lines = ["# rocprofv3 summary %s" % tag, "",
-             "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline`",
+             "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras`",
              "", "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
     for r in rows[:24]:
         lines.append("| `%s` | %s | %.1f | %.3f | %s |" % (r["Name"].split("(")[0][:70], r["Calls"], float(r["AverageNs"]) / 1e3,
