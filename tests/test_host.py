@@ -206,10 +206,11 @@ def test_no_kernel_keeps_the_world_in_scratch(hip_lib):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r03_bench_line.json is the line `python bench.py` printed at the end of the round: the driver's contract fields, the
-    roofline object of the dominant kernel and the CPU baseline timed beside it"""
+    """profiles/r04_bench_line.json is the line `python bench.py` printed at the end of the round: the driver's contract fields, the
+    roofline object of the dominant kernel, the CPU baseline timed beside it, the repeats behind the median, and the extras the
+    round-3 verdict asked for (per-configuration rooflines, config 5 at 2 x 499,849 agents with the policy's dtype named)"""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_line.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -221,3 +222,12 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"]
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 / sum(d["config"]["agents_at_start"]) - 1) < 0.25    # value ~ agents / step time
+    assert d["repeats"] == 5 and len(d["repeats_ms_per_step"]) == 5 and sorted(d["repeats_ms_per_step"])[2] == round(d["ms_per_step"], 4)
+    x = d["extra"]
+    assert "error" not in x
+    for k in ("gather_500_100k", "test_1m_2x500k"):
+        assert 0 < x[k]["roofline"]["frac"] < 1
+    assert 0 < x["battle_200_2x2000"]["calls_with_events"]["roofline"]["frac"] < 1
+    c5 = x["c5_train_round_1m"]
+    assert c5["bf16_policy"]["agents"] == [499849, 499849] and "bf16" in c5["bf16_policy"]["policy_dtype"] and c5["f32_policy"]["policy_dtype"].startswith("f32")
+    assert x["battle_selfplay_2x400k_f32_policy"]["policy_dtype"] == "f32"
