@@ -379,6 +379,7 @@ def main():
     ap.add_argument("--obs", choices=["f32", "bf16"], default="f32",
                     help="bf16: render the observations as the policy kernels' bf16 cells (env_get_observation_device_bf16, 8 x bf16 per window "
                          "cell) -- a secondary reading; the headline stays on the reference's float32 tensors")
+    ap.add_argument("--extra-timeout", type=int, default=300, help="N > 1: seconds the config-4 gather extra may take before the line is printed without it")
     ap.add_argument("--repeats", type=int, default=5, help="identical timed regions of --steps steps; the median one is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
@@ -722,26 +723,52 @@ def main():
     if world > 1 and is_default_workload(args) and not args.no_extras:
         # north-star configuration 4 on the ranks of this job: gather 500 x 500, 100k agents + 20k food per replica, every replica's
         # observation tensor to every rank each step (counts first, rows sized by count, on a side stream under the step) -- timed
-        # without and with the exchange, every gathered shard checked bit for bit against the rows its owner rendered
+        # without and with the exchange, every gathered shard checked bit for bit against the rows its owner rendered.
+        # The headline above is already measured: whatever happens in here -- an exception on some rank, a collective that never
+        # returns (this leg has never run on xGMI) -- rank 0 still prints its ONE line: a watchdog on every rank ends the process
+        # after --extra-timeout seconds, rank 0 printing the headline with the failure noted first.
+        import threading
         XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md: one xGMI link, per direction
-        A = measure("gather", 500, 100000, args.steps, args.warmup, False, gather="none")
-        B = measure("gather", 500, 100000, args.steps, args.warmup, False, gather="obs", check_gather=True)
-        ea = replicas.max_over_replicas(A["elapsed"], device=red_dev)
-        eb = replicas.max_over_replicas(B["elapsed"], device=red_dev)
-        na = replicas.sum_over_replicas(A["agent_steps"], device=red_dev)
-        nb = replicas.sum_over_replicas(B["agent_steps"], device=red_dev)
-        ex = replicas.max_over_replicas(B["gather"]["exchange_ms"], device=red_dev)
-        if rank == 0:
-            gb = B["gather"]
-            link = gb["bytes_to_each_peer"] / (ex * 1e-3) / 1e9 if ex > 0 else None
-            rec.setdefault("extra", {})["c4_gather_rccl"] = {
-                "workload": "gather 500x500 (train_gather.py), 100k agents + 20k food per replica, %d replicas, only the agents act" % world,
-                "backend": args.backend + (" (RCCL over xGMI)" if args.backend == "nccl" else " (dry run: rows staged through host memory)"),
-                "ms_per_step_without_gather": ea / args.steps * 1e3, "agent_steps_per_s_without_gather": na / ea,
-                "ms_per_step_with_gather": eb / args.steps * 1e3, "agent_steps_per_s_with_gather": nb / eb,
-                "exchange_ms": ex, "payload_bytes_to_each_peer": gb["bytes_to_each_peer"], "payload_bytes_sent_per_step": gb["payload_bytes_sent_per_step"],
-                "GBps_per_link": link, "xgmi_link_peak_GBps": XGMI_LINK_GBS, "link_frac": (link / XGMI_LINK_GBS if link else None),
-                "view_buffers": gb["view_buffers"], "verified": gb.get("verified")}
+        done_flag = threading.Event()
+
+        def bail():
+            if done_flag.is_set():
+                return
+            if rank == 0:
+                rec.setdefault("extra", {})["c4_gather_rccl"] = {"error": "did not finish within %d s (a rank failed, or a collective did not return)" % args.extra_timeout}
+                print(json.dumps(rec), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.extra_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            A = measure("gather", 500, 100000, args.steps, args.warmup, False, gather="none")
+            B = measure("gather", 500, 100000, args.steps, args.warmup, False, gather="obs", check_gather=True)
+            ea = replicas.max_over_replicas(A["elapsed"], device=red_dev)
+            eb = replicas.max_over_replicas(B["elapsed"], device=red_dev)
+            na = replicas.sum_over_replicas(A["agent_steps"], device=red_dev)
+            nb = replicas.sum_over_replicas(B["agent_steps"], device=red_dev)
+            ex = replicas.max_over_replicas(B["gather"]["exchange_ms"], device=red_dev)
+            if rank == 0:
+                gb = B["gather"]
+                link = gb["bytes_to_each_peer"] / (ex * 1e-3) / 1e9 if ex > 0 else None
+                rec.setdefault("extra", {})["c4_gather_rccl"] = {
+                    "workload": "gather 500x500 (train_gather.py), 100k agents + 20k food per replica, %d replicas, only the agents act" % world,
+                    "backend": args.backend + (" (RCCL over xGMI)" if args.backend == "nccl" else " (dry run: rows staged through host memory)"),
+                    "ms_per_step_without_gather": ea / args.steps * 1e3, "agent_steps_per_s_without_gather": na / ea,
+                    "ms_per_step_with_gather": eb / args.steps * 1e3, "agent_steps_per_s_with_gather": nb / eb,
+                    "exchange_ms": ex, "payload_bytes_to_each_peer": gb["bytes_to_each_peer"], "payload_bytes_sent_per_step": gb["payload_bytes_sent_per_step"],
+                    "GBps_per_link": link, "xgmi_link_peak_GBps": XGMI_LINK_GBS, "link_frac": (link / XGMI_LINK_GBS if link else None),
+                    "view_buffers": gb["view_buffers"], "verified": gb.get("verified")}
+            done_flag.set()
+            watchdog.cancel()
+        except Exception as e:             # (the other ranks are now waiting in a collective: everybody leaves through the watchdog)
+            sys.stderr.write("rank %d: extra.c4_gather_rccl failed: %r\n" % (rank, e))
+            if rank == 0:
+                rec.setdefault("extra", {})["c4_gather_rccl"] = {"error": repr(e)}
+                print(json.dumps(rec), flush=True)
+            done_flag.set()
+            os._exit(0)
     if rank == 0:
         print(json.dumps(rec))
     if world > 1:
