@@ -1,4 +1,4 @@
-// engine.h -- data model shared by the HIP kernels (kernels.hip) and the host engine (engine.hip).
+// engine.h -- data model shared by the HIP kernels (render.hip, step.hip, cycle.hip over kernels_dev.h) and the host engine (engine.hip).
 //
 // MI355X-first layout (not the reference's AoS heap objects, GridWorld.h:131-253 / Map.h:23-29):
 //   * every group is a set of struct-of-arrays device buffers indexed by the agent's position in the group

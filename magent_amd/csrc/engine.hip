@@ -1,5 +1,5 @@
 // engine.hip -- host side of the MI355X grid-world engine: configuration, agent types, placement, per-call
-// orchestration of the kernels in kernels.hip on one HIP stream per environment.
+// orchestration of the kernels in render.hip / step.hip / cycle.hip on one HIP stream per environment.
 //
 // Mirrors the behaviour of the reference's GridWorld class (src/gridworld/GridWorld.{h,cc}) for the hot-path scope
 // of SURVEY.md section 8.  The product never falls back to a CPU engine: every state-changing operation after
@@ -1035,7 +1035,7 @@ void Env::reset() {
         // an attack bit may stand for one attacker per direction.  The lists hold at most 256 hits: beyond that the worst case is not
         // covered by construction any more, and an overflow is reported at the end of the step (CTR_HIT_OVERFLOW) instead
         attack_kmax = std::min(attack_kmax * DIR_NUM, 256);
-        // how far the top-left cell of a body can be from a cell its move or its turn enters (neighbourhood scans, kernels.hip)
+        // how far the top-left cell of a body can be from a cell its move or its turn enters (neighbourhood scans, kernels_dev.h)
         for (auto &g : groups) {
             const HostType &t = *g.type;
             int far = 0;
@@ -1050,7 +1050,7 @@ void Env::reset() {
     if (!attack_lds_ok(attack_kmax)) fatal("attack ranges x body size (%d hits per target) need more LDS per workgroup than this device grants", attack_kmax);
     if (total_attack > ATTACK_KMAX_HOST) fatal("sum of attack-range sizes (%d) exceeds the engine limit %d", total_attack, ATTACK_KMAX_HOST);
     if (n_channel() > 32) fatal("too many observation channels");
-    // the step of plain games (kernels.hip) keeps scratch of its own per agent, sized by the attack offsets of all groups
+    // the step of plain games (step.hip) keeps scratch of its own per agent, sized by the attack offsets of all groups
     {
         const bool plain = !any_multicell && !turn_mode && !food_mode && !any_absorb && !any_kill_supply && plain_eval_lds_ok(attack_kmax);
         const int slots = std::max(1, total_attack);
@@ -1392,7 +1392,7 @@ void Env::set_action_device(int g, const int *d_act) {
         }
     }
     G.sa_off = off;
-    if ((long long)move_seq_base + G.n >= (1ll << 27)) fatal("more than 2^27 agents given actions in one step");   // (order keys: 27-bit insertion index, kernels.hip claim_word)
+    if ((long long)move_seq_base + G.n >= (1ll << 27)) fatal("more than 2^27 agents given actions in one step");   // (order keys: 27-bit insertion index, step.hip claim_word)
     hipStream_t s = action_stream();    // large worlds: beside the observation renders (see side_stream)
     ProfScope p(*this, "set_action", false, s);
     launch_set_action(s, view(), g, d_act, move_seq_base, d_asums, d_wpre, off);
@@ -1570,7 +1570,7 @@ void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 
 // The per-cell scratch words (claim, hitbits) as the three step paths want them and leave them:
 //   one-launch step / cycle (0): wants every claim word CLAIM_NONE and every hit word zero; keeps them so
 //   step of plain games (1): does not use the hit words (its hits live in per-agent masks); its claim words carry the epoch of the step
-//       that wrote them (kernels.hip: claim_word) and are never cleaned -- it wants every word either filled (all ones) or written by a
+//       that wrote them (step.hip: claim_word) and are never cleaned -- it wants every word either filled (all ones) or written by a
 //       plain step of the current window of 63 epochs, so the array is refilled when a window begins and after any other path wrote it
 //   everything else (2): wants nothing (fills what it needs) and leaves both arrays dirty
 void Env::scratch_for(int path) {
@@ -1677,7 +1677,7 @@ void Env::step_begin() {
     } else if (fast) {
         step_was_fast = true;
         // ---------------- single-sync driver
-        const bool plain = W.plain != 0;       // plain games have a pipeline of their own behind the shuffle (kernels.hip: k_plain_rank ...)
+        const bool plain = W.plain != 0;       // plain games have a pipeline of their own behind the shuffle (step.hip: k_plain_rank ...)
         step_was_plain = plain;
         if (plain) plain_steps++;
         scratch_for(plain ? 1 : 2);

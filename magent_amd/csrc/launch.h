@@ -1,4 +1,4 @@
-// launch.h -- host-visible launch wrappers of kernels.hip and the small plan structs they take.
+// launch.h -- host-visible launch wrappers of render.hip / step.hip / cycle.hip and the small plan structs they take.
 #pragma once
 #include "engine.h"
 
@@ -122,7 +122,7 @@ void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &
 void launch_set_rng(hipStream_t s, int *counters, unsigned x);
 void launch_step_reset(hipStream_t s, int *counters);
 void launch_set_counter(hipStream_t s, int *counters, int index, int value, int unless_index);
-// where a group's set_action call of this step left its tile counts (kernels.hip: k_set_action_a, attack_seq); -1: none / numbers in `key`
+// where a group's set_action call of this step left its tile counts (step.hip: k_set_action_a; kernels_dev.h: attack_seq); -1: none / numbers in `key`
 struct SeqPlan { int off[MAXG]; };
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums, int *wpre, int tile_off /* < 0: one-workgroup form */);
 void launch_seq_assign(hipStream_t s, const WorldView &W, int g, const int *sums, const int *wpre, int tile_off, bool write_total);
@@ -130,7 +130,7 @@ void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, cons
                         const SeqPlan &P);
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);
-// ---- the step of plain games (kernels.hip: "the step of plain games"): per-agent scratch of its own
+// ---- the step of plain games (step.hip: "the step of plain games"): per-agent scratch of its own
 //   rec   {x: order key (move) | rank in the shuffled attack list (attack), y: death rank, z: the cell the move is aimed at (-1: none),
 //          w: move status / dependency}: what OTHER agents read of an agent
 //   atk   the agent my attack lands on (-1: nobody); from k_strike on, for a mover: what its target cell holds when the moves begin
@@ -141,7 +141,7 @@ struct PlainWorld {
     int S, kmax;          // slots per agent (attack offsets of all groups); most hits one agent can receive
     int *alive;           // k_strike leaves the survivors of every 256 agents here (alive_off[g] + block): clear_dead's compaction needs no count pass
     int alive_off[MAXG];
-    int epoch;            // of this step's claim words (kernels.hip: claim_word): 62 - (plain step number mod 63)
+    int epoch;            // of this step's claim words (step.hip: claim_word): 62 - (plain step number mod 63)
     int round_base;       // + round = the "inputs changed" stamp of a round of this step (they count on from step to step)
 };
 bool fused_rules(const RuleArgs *rules, int n);

@@ -931,7 +931,7 @@ def scenarios():
         Scenario("battle_brawl_big", "battle", 110, place=[rnd(0, 4500), rnd(1, 4500)], steps=14, action_seed=2,
                  over={"small": {"hp": 5, "damage": 3, "step_recover": 0.3}}),
         Scenario("battle60", "battle", 60, place=[rnd(0, 1200), rnd(1, 1200)], steps=40),
-        # a long episode: the plain pipeline's claim words carry an epoch that wraps every 63 steps (kernels.hip: claim_word)
+        # a long episode: the plain pipeline's claim words carry an epoch that wraps every 63 steps (step.hip: claim_word)
         Scenario("battle_epochs", "battle", 26, place=[rnd(0, 90), rnd(1, 90)], steps=140, action_seed=61, over={"small": {"hp": 6}},
                  events={40: [("add", 0, "random", {"n": 50}), ("add", 1, "random", {"n": 50})],
                          85: [("add", 0, "random", {"n": 60}), ("add", 1, "random", {"n": 60})], 120: [("add", 1, "random", {"n": 40})]}),
