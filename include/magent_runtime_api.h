@@ -38,8 +38,8 @@ int env_new_game(EnvHandle *game, const char *name);
 int env_delete_game(EnvHandle game);
 /* runtime_api.h:23 -> GridWorld::set_config (GridWorld.cc:120-149).  keys: map_width,map_height (int*),
  * food_mode,turn_mode,minimap_mode,goal_mode (bool*), embedding_size (int*), render_dir (char*), seed (int*).
- * (turn_mode and food_mode are implemented; goal_mode = true -- "deprecated" at GridWorld.cc:137, set by no shipped
- * game -- is FATAL.)
+ * (turn_mode and food_mode are implemented; so is goal_mode, "deprecated" at GridWorld.cc:137 and set by no shipped game: what it
+ * does in the reference is add two feature slots that nothing ever writes, GridWorld.cc:926-934.)
  * Additive key: device_id (int*) selects the HIP device (before env_reset). */
 int env_config_game(EnvHandle game, const char *name, void *p_value);
 
@@ -82,8 +82,10 @@ int gridworld_add_agents(EnvHandle game, GroupHandle group, int n, const char *m
 
 /* runtime_api.h:49 -> GridWorld::clear_dead (GridWorld.cc:633-665) */
 int gridworld_clear_dead(EnvHandle game);
-/* runtime_api.h:50 -> GridWorld::set_goal (deprecated in the reference; accepted and ignored unless
- * goal_mode, which is FATAL unsupported) */
+/* runtime_api.h:50 -> GridWorld::set_goal (GridWorld.cc:667-679; deprecated in the reference).  method "random" draws a goal position
+ * for every agent of the group from the engine's generator (two draws each, the uncleared dead included); nothing in the reference
+ * reads a goal back, so the call's whole effect is on the generator -- on every shuffle and random placement after it -- with or
+ * without goal_mode.  Any other method is FATAL, as there.  linear_buffer is unused, as there. */
 int gridworld_set_goal(EnvHandle game, GroupHandle group, const char *method, const int *linear_buffer);
 
 /* runtime_api.h:53-56 -> RewardEngine.cc:28-69 */

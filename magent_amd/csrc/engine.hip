@@ -393,9 +393,8 @@ void Env::set_config(const char *key, void *p) {
     else if (k == "turn_mode") {
         if (!types.empty() && *(bool *)p != turn_mode) fatal("turn_mode must be configured before the agent types are registered (it changes their action layout)");
         turn_mode = *(bool *)p;
-    } else if (k == "goal_mode") {
-        if (*(bool *)p) fatal("%s is outside the hot-path scope of this engine (SURVEY.md 8a)", key);
-    } else fatal("invalid argument in GridWorld::set_config : %s", key);
+    } else if (k == "goal_mode") goal_mode = *(bool *)p;   // two more feature slots, never written (GridWorld.cc:137-138, :929-930)
+    else fatal("invalid argument in GridWorld::set_config : %s", key);
 }
 
 // AgentType::AgentType (AgentType.cc:30-123)
@@ -463,7 +462,7 @@ void Env::new_group(const char *type_name, int *handle) {
 }
 
 int Env::n_channel() const { return 1 + (food_mode ? 1 : 0) + (int)groups.size() * (minimap_mode ? 3 : 2); }  // GridWorld.cc:915-924
-int Env::feature_size(int g) const { return embedding_size + groups[g].type->n_action + 1 + (minimap_mode ? 2 : 0); }
+int Env::feature_size(int g) const { return embedding_size + groups[g].type->n_action + 1 + (goal_mode ? 2 : 0) + (minimap_mode ? 2 : 0); }  // GridWorld.cc:926-934
 
 // RewardEngine.cc:28-69
 void Env::define_agent_symbol(int no, int group, int index) {
@@ -1128,6 +1127,18 @@ void Env::host_random_blank(int bw, int bl, int &ox, int &oy) {
 }
 
 // GridWorld::add_agents (GridWorld.cc:180-290).  Cold path: placement is defined sequentially by the reference.
+// GridWorld::set_goal (GridWorld.cc:667-679; "deprecated" there): "random" draws a goal position for every agent of the group -- dead ones
+// that clear_dead has not removed yet included -- with two draws of the engine's generator each.  Nothing in the reference ever reads a
+// goal back (Agent::get_goal has no caller), so what the call leaves behind is the generator, 2 n draws further on.
+void Env::set_goal(int group, const char *method) {
+    if (!device_ready) fatal("set_goal called before reset");
+    if (group < 0 || group >= (int)groups.size()) fatal("invalid group handle in GridWorld::set_goal : %d", group);
+    if (std::string(method) != "random") fatal("invalid goal type in GridWorld::set_goal");
+    enter();
+    rng_on_device = false;
+    rng.skip(2u * (unsigned)groups[group].n);
+}
+
 void Env::add_agents(int group, int n, const char *method, const int *px, const int *py, const int *pdir) {
     if (!device_ready) fatal("add_agents called before reset");
     enter();

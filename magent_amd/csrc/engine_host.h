@@ -111,6 +111,7 @@ public:
     void add_reward_rule(int on, int *recv, float *val, int n, bool terminal);
     void reset();
     void add_agents(int group, int n, const char *method, const int *px, const int *py, const int *pdir);
+    void set_goal(int group, const char *method);
     void observe_host(int g, float *view, float *feat);
     void set_action_host(int g, const int *actions);
     void step(int *done);
@@ -253,7 +254,7 @@ private:
 
     // configuration
     int width = 0, height = 0, embedding_size = 0, device_id = 0;
-    bool minimap_mode = false, large_map_mode = false, food_mode = false, turn_mode = false;
+    bool minimap_mode = false, large_map_mode = false, food_mode = false, turn_mode = false, goal_mode = false;
     int bandwidth = 1, map_reach = 0;
     std::string render_dir;
     // text video dump (reference RenderGenerator.{h,cc}); host-side, off the hot path

@@ -150,8 +150,8 @@ __device__ __forceinline__ float feature_value(const RenderArgs &R, const AgentF
     float v = (f < 31 && ((a.id >> f) & 1)) ? 1.0f : 0.0f;                 // id bits, LSB first
     v = f >= R.E ? (a.la == rel ? 1.0f : 0.0f) : v;                        // one-hot last action
     v = rel == R.NA ? a.lr : v;                                            // a fresh agent's last_action == NA lands here
-    v = rel == R.NA + 1 ? a.fx : v;                                        // and is overwritten (GridWorld.cc:390-392)
-    v = rel == R.NA + 2 ? a.fy : v;
+    v = (R.minimap && rel == R.NA + 1) ? a.fx : v;                         // and is overwritten (GridWorld.cc:390-392)
+    v = (R.minimap && rel == R.NA + 2) ? a.fy : v;                         // (goal_mode: its two slots come last and stay zero, :929-930)
     return v;
 }
 

@@ -98,7 +98,7 @@ int gridworld_add_agents(EnvHandle game, GroupHandle group, int n, const char *m
     E(game)->add_agents(group, n, method, pos_x, pos_y, dir); return 0;
 }
 int gridworld_clear_dead(EnvHandle game) { E(game)->clear_dead(); return 0; }
-int gridworld_set_goal(EnvHandle, GroupHandle, const char *, const int *) { return 0; }  // deprecated in the reference; goals are never observed without goal_mode
+int gridworld_set_goal(EnvHandle game, GroupHandle group, const char *method, const int *) { E(game)->set_goal(group, method); return 0; }
 int gridworld_define_agent_symbol(EnvHandle game, int no, int group, int index) { E(game)->define_agent_symbol(no, group, index); return 0; }
 int gridworld_define_event_node(EnvHandle game, int no, int op, int *inputs, int n_inputs) { E(game)->define_event_node(no, op, inputs, n_inputs); return 0; }
 int gridworld_add_reward_rule(EnvHandle game, int on, int *receiver, float *value, int n_receiver, bool is_terminal, bool /*auto_value*/) {

@@ -13,7 +13,7 @@
 // State is kept as per-group struct-of-arrays + a packed occupancy grid; the *order* of every loop that the
 // reference executes sequentially is kept literally, because the results depend on it.
 //
-// Scope: what SURVEY.md section 8 puts on the path -- no goal_mode; turn_mode, sector ranges and the general rule search are restated too.  Reward rules
+// Scope: what SURVEY.md section 8 puts on the path -- goal_mode (two feature slots nothing writes, set_goal's draws), turn_mode, sector ranges and the general rule search are restated too.  Reward rules
 // are evaluated by the reference's recursive search over symbol bindings, literally (and/or/not over attack, kill,
 // collide, die, at, in, in_a_line; 'any', 'all' and fixed-index symbols); align aborts with a message (undefined in the reference).
 #include <algorithm>
@@ -168,7 +168,7 @@ const int EMPTY = -1, WALL = -2, FOOD = -3;   // FOOD: what a killed agent leave
 
 struct World {
     int w = 0, h = 0, embedding = 0;
-    bool minimap = false, large_map = false, food_mode = false, turn_mode = false;
+    bool minimap = false, large_map = false, food_mode = false, turn_mode = false, goal_mode = false;
     std::vector<Pending> turn_bound;
     std::vector<std::vector<Pending>> turn_sep;
     std::vector<float> food;        // per cell: what is left of the food (cells whose occ_g is FOOD)
@@ -184,7 +184,7 @@ struct World {
 
     int cell(int x, int y) const { return y * w + x; }
     int g2c(int g) const { return 1 + (food_mode ? 1 : 0) + g * (minimap ? 3 : 2); }  // GridWorld.cc:915-924
-    int feature_size(int g) const { return embedding + groups[g].type->n_action + 1 + (minimap ? 2 : 0); }
+    int feature_size(int g) const { return embedding + groups[g].type->n_action + 1 + (goal_mode ? 2 : 0) + (minimap ? 2 : 0); }   // GridWorld.cc:926-934
 
     // Map.cc:454-470
     bool blank_area(int x, int y, int bw, int bh, int self_g = -9, int self_i = -9) const {
@@ -264,7 +264,7 @@ int env_config_game(void *game, const char *key, void *p) {
     else if (k == "seed") e.rng.seed((unsigned long)*(int *)p);
     else if (k == "food_mode") e.food_mode = *(bool *)p;
     else if (k == "turn_mode") e.turn_mode = *(bool *)p;
-    else if (k == "goal_mode") { if (*(bool *)p) fatal("%s is outside the hot-path scope", key); }
+    else if (k == "goal_mode") e.goal_mode = *(bool *)p;   // GridWorld.cc:137-138
     else if (k == "render_dir") {}
     else fatal("invalid argument in set_config: %s", key);
     return 0;
@@ -855,7 +855,14 @@ int gridworld_add_reward_rule(void *game, int on, int *recv, float *val, int n, 
     return 0;
 }
 
-int gridworld_set_goal(void *, int, const char *, const int *) { fatal("set_goal is deprecated in the reference; outside the hot-path scope"); }
+// GridWorld.cc:667-679: a goal position per agent of the group (the dead that are still in the list included), x then y, from the engine's
+// generator; no code of the reference reads a goal back, so the draws are all that remains of the call
+int gridworld_set_goal(void *game, int group, const char *method, const int *) {
+    World &e = *W(game);
+    if (std::string(method) != "random") fatal("invalid goal type in GridWorld::set_goal");
+    for (int i = 0; i < e.groups[group].size(); i++) { (void)((int)e.rng() % e.w); (void)((int)e.rng() % e.h); }
+    return 0;
+}
 int env_render(void *) { return 0; }
 int env_render_next_file(void *) { return 0; }
 int discrete_snake_clear_dead(void *) { fatal("DiscreteSnake is a different game; outside the hot-path scope"); }

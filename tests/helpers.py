@@ -353,6 +353,8 @@ class Scenario(object):
                 env.add_agents(env.get_handles()[ev[1]], ev[2], **ev[3])
             elif ev[0] == "walls":
                 env.add_walls(method=ev[1], **ev[2])
+            elif ev[0] == "goal":
+                env.set_goal(env.get_handles()[ev[1]], "random")
             elif ev[0] == "reset":
                 env.reset()
                 self.populate(env, ev[1], 0)
@@ -812,6 +814,8 @@ def fuzz_scenario(seed):
             cfg.set({"food_mode": True})
         if turn_mode:
             cfg.set({"turn_mode": True})
+        if goal_mode:
+            cfg.set({"goal_mode": True})
         names = []
         for g, t in enumerate(specs):
             t = dict(t)
@@ -887,9 +891,17 @@ def fuzz_scenario(seed):
         acting = [g for g in acting if g != goal]
     if fuzz_turn == 2 and turn_mode and not TURN_MULTICELL_ON_ENGINE and any(t["width"] * t["length"] > 1 or t.get("can_absorb") for t in specs):
         turn_mode = False
+    # FUZZ_GOAL=1: goal_mode in half of the games and set_goal calls between steps (a generator of their own: the games of a seed stay
+    # what they are without it)
+    goal_mode, events = False, {}
+    if os.environ.get("FUZZ_GOAL", "0") == "1":
+        rg = np.random.RandomState(seed ^ 0x60A1)
+        goal_mode = bool(rg.rand() < 0.5)
+        for _ in range(int(rg.randint(1, 4))):
+            events.setdefault(int(rg.randint(0, 8)), []).append(("goal", int(rg.randint(G))))
     return Scenario("fuzz%d" % seed, make, 0, seed=int(rs.randint(1, 1 << 20)), place=place, steps=int(rs.randint(6, 14)),
                     action_seed=seed, walls=int(area * float(rs.choice([0, 0, 0.02, 0.08]))), acting=acting,
-                    clear_every=int(rs.choice([1, 1, 1, 2])), obs_every=int(rs.choice([1, 1, 2])))
+                    clear_every=int(rs.choice([1, 1, 1, 2])), obs_every=int(rs.choice([1, 1, 2])), events=events)
 
 
 def digest(trajectory):
@@ -935,6 +947,13 @@ def scenarios():
         Scenario("battle_epochs", "battle", 26, place=[rnd(0, 90), rnd(1, 90)], steps=140, action_seed=61, over={"small": {"hp": 6}},
                  events={40: [("add", 0, "random", {"n": 50}), ("add", 1, "random", {"n": 50})],
                          85: [("add", 0, "random", {"n": 60}), ("add", 1, "random", {"n": 60})], 120: [("add", 1, "random", {"n": 40})]}),
+        # goal_mode: two feature slots that nothing writes (GridWorld.cc:926-934); set_goal: two draws of the engine's generator per agent,
+        # with or without goal_mode (GridWorld.cc:667-679) -- seen in the shuffles and the placements that follow
+        Scenario("battle_goal_mode", "battle", 28, place=[rnd(0, 110), rnd(1, 110)], steps=16, action_seed=62, settings={"goal_mode": True},
+                 over={"small": {"hp": 4, "damage": 3}}, clear_every=2,
+                 events={0: [("goal", 0)], 5: [("goal", 1), ("add", 0, "random", {"n": 30})], 9: [("goal", 0), ("goal", 1)]}),
+        Scenario("pursuit_goals_drawn", "pursuit", 30, walls=20, place=[rnd(0, 40), rnd(1, 80)], steps=14, action_seed=63,
+                 events={3: [("goal", 1)], 4: [("add", 1, "random", {"n": 25})], 8: [("goal", 0)]}),
         Scenario("battle_walls", "battle", 50, walls=200, place=[rnd(0, 400), rnd(1, 400)], steps=20, action_seed=3),
         Scenario("battle_largemap", "battle", 120, place=[rnd(0, 3000), rnd(1, 3000)], steps=12, action_seed=5),
         Scenario("battle_largemap_odd", "battle", 101, place=[rnd(0, 2500), rnd(1, 2500)], steps=10, action_seed=6),

@@ -19,7 +19,7 @@ import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # a slice that touches every phase family: dense attack chains, striped moves, multi-cell bodies, rules, goals, turn_mode, food
-SLICE = ["battle_small_dense", "battle_brawl", "battle_walls", "gather", "forest", "tri_rect", "pursuit_dense", "bodies", "quad"]
+SLICE = ["battle_small_dense", "battle_brawl", "battle_walls", "gather", "forest", "tri_rect", "pursuit_dense", "bodies", "quad", "battle_goal_mode", "pursuit_goals_drawn"]
 
 
 @pytest.fixture(scope="module")
@@ -124,9 +124,9 @@ def test_emulated_fused_step_of_plain_games(emu):
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
     base = {"MAGENT_TUNE": "solo_step=0,scan_solo_max=100", "OMP_NUM_THREADS": "1"}
     plain = ("battle_small_dense,battle_brawl,battle_brawl_big,battle60,battle_walls,battle_largemap,battle_largemap_odd,battle_fill_full,"
-             "battle_no_clear,battle_tiny,gather,gather_largemap,battle_lowhp,quad,trans,chase,battle_events,battle_grow,rules_search,battle_epochs")
+             "battle_no_clear,battle_tiny,gather,gather_largemap,battle_lowhp,quad,trans,chase,battle_events,battle_grow,rules_search,battle_epochs,battle_goal_mode")
     names = [n for n in plain.split(",") if n in H.scenarios()]
-    assert len(names) == 20
+    assert len(names) == 21
     for extra in ({"HIPEMU_SCRAMBLE": "5"}, {"MAGENT_TUNE": "attack_pairs=0", "HIPEMU_SCRAMBLE": "8"}):
         p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"EMU_SCENARIOS": ",".join(names)}, base, extra), capture_output=True, text=True,
                            timeout=1500)

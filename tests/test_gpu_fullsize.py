@@ -130,6 +130,16 @@ def test_fuzz_turn_mode():
         assert out.returncode == 0 and "150 seeds, 0 failures" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
 
 
+def test_fuzz_goal_mode():
+    """goal_mode and set_goal (the deprecated pair of GridWorld.cc:137, :667-679: feature slots nothing writes, draws of the engine's
+    generator that every later shuffle and placement sees) in random games (FUZZ_GOAL=1), on both step drivers, HIP == oracle"""
+    for extra in ({}, {"MAGENT_TUNE": "solo_step=0"}):
+        env = H.merge_env(os.environ, {"OMP_NUM_THREADS": "1", "FUZZ_GOAL": "1"}, extra)
+        out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "120"], env=env,
+                             capture_output=True, text=True, timeout=1200)
+        assert out.returncode == 0 and "120 seeds, 0 failures" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
+
+
 def test_fuzz_fused_cycle():
     """random games (40 % of them turn_mode) with the HIP leg driven through env_cycle_many -- a whole environment cycle in two
     launches: set_action, step, rewards, clear_dead and the next minimap inside k_step_solo -- against the oracle driven through the

@@ -83,14 +83,14 @@ def test_battle_spaces_known_answers(hip_lib):
 
 def test_unsupported_features_fail_loudly(hip_lib):
     """no silent approximation: an out-of-scope feature aborts the process with a message"""
-    code = ("import magent_amd, sys\n"
-            "from magent_amd.builtin.config import _games\n"
-            "cfg = _games.make('battle', 40)\n"
-            "cfg.set({'goal_mode': True})\n"
-            "magent_amd.GridWorld(cfg)\n")
+    code = ("import ctypes, magent_amd\n"
+            "from magent_amd import c_lib\n"
+            "lib = c_lib.load()\n"
+            "game = ctypes.c_void_p()\n"
+            "lib.env_new_game(ctypes.byref(game), b'DiscreteSnake')\n")
     env = dict(os.environ, MAGENT_AMD_NO_TORCH="1", PYTHONPATH=ROOT)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
-    assert p.returncode != 0 and "magent-amd FATAL" in p.stderr and "goal_mode" in p.stderr
+    assert p.returncode != 0 and "magent-amd FATAL" in p.stderr and "DiscreteSnake" in p.stderr
 
 
 def test_no_cpu_fallback_without_gpu(hip_lib):

@@ -107,6 +107,16 @@ def test_oracle_matches_compiled_reference_on_random_games():
 
 
 @pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) not present")
+def test_oracle_goal_mode_matches_compiled_reference(monkeypatch):
+    """goal_mode (two feature slots nothing writes, GridWorld.cc:926-934) and set_goal between steps (two draws of the engine's
+    generator per agent, GridWorld.cc:667-679) in random games (FUZZ_GOAL=1)"""
+    monkeypatch.setenv("FUZZ_GOAL", "1")
+    for seed in range(50):
+        sc = H.fuzz_scenario(seed)
+        H.assert_same(H.run(sc, H.REF_LIB), H.run(sc, ORACLE), sc.name)
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) not present")
 def test_oracle_rule_search_matches_compiled_reference(monkeypatch):
     """random rule expressions over 'any' / 'all' / fixed-index symbols, in_a_line, several iterated symbols (FUZZ_RULES=2): the
     restated recursive search (RewardEngine.cc:216-443), the reference's Agent::index quirk included
