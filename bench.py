@@ -552,7 +552,7 @@ def main():
         median_ms = per_step[len(per_step) // 2] * 1e3 if per_step else None
 
         res = {"elapsed": elapsed, "agent_steps": agent_steps, "median_ms": median_ms, "n0": n0, "agents_at_end": [env.get_num(h) for h in handles],
-               "host_finished_steps": env.engine_stats()[0], "cycles_run": total_steps, "roofline": None, "breakdown": {}, "map_size": map_size}
+               "host_finished_steps": env.engine_stats()[0], "attack_round_hist": list(env.round_hist()), "cycles_run": total_steps, "roofline": None, "breakdown": {}, "map_size": map_size}
         if profile:
             n_launch, ms = env.profile_read("render")
             n_feat, ms_feat = env.profile_read("features")
@@ -680,7 +680,9 @@ def main():
                        "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": (args.backend if world > 1 else None),
                        "agents_at_start": R["n0"], "agents_at_end": R["agents_at_end"],
                        "io": "device-resident (env_*_device C-ABI)", "steps_finished_by_host_driver": R["host_finished_steps"],
-                       "host_driver_rate": R["host_finished_steps"] / float(R["cycles_run"])},
+                       "host_driver_rate": R["host_finished_steps"] / float(R["cycles_run"]),
+                       # steps of the run by the last round of the death-rank fixed point that still changed something (index; one more round confirms)
+                       "attack_round_hist": R["attack_round_hist"]},
             "roofline": R["roofline"],
             "breakdown": R["breakdown"],
         }

@@ -291,7 +291,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
         if (tid < CTR_TRIGGER_END - CTR_TRIGGER) W.counters[CTR_TRIGGER + tid] = 0;
         if (tid < NG) { S.rec->dead[tid] = dead_ct; S.rec->taken[tid] = taken_ct; }
         if (tid == 0) {
-            S.rec->triggers = mask;
+            S.rec->triggers = mask; S.rec->rounds_mask = 0u;
             S.rec->rng = (unsigned)W.counters[CTR_RNG];
             S.rec->last_a = A;
             S.rec->unsupported = __hip_atomic_load(&W.counters[CTR_UNSUPPORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -144,6 +144,7 @@ struct StepRecord {
     int last_a;                  // attack-list length
     int unsupported, pack_overflow, error, bad_action, hit_overflow;
     int rounds_attack, rounds_move;
+    unsigned rounds_mask;        // plain games: bit r = round r of the death-rank fixed point changed a death rank (r + 1 rounds were needed)
     int open_attack, open_move;  // multi-launch step: the optimistic rounds of a phase ran out (the host continues from that state)
     int n_marks; unsigned long long marks[40];   // wall_clock64 (100 MHz) at the phase boundaries of k_step_solo (tuning aid)
     volatile int seq;            // == the step's sequence number once everything above is visible

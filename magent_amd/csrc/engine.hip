@@ -1883,6 +1883,7 @@ void Env::step_end(int *done) {
                 if (boost_attack > 0) boost_attack--;
                 if (boost_move > 0) boost_move--;
                 if (rules_on_host) eval_rules_host();
+                if (step_was_plain) { int hi = 0; for (int b = 1; b < 32; b++) if ((r.rounds_mask >> b) & 1u) hi = b; round_hist[std::min(hi, 8)]++; }
             }
             int live = 0;
             for (size_t g = 0; g < groups.size(); g++) {
@@ -2318,6 +2319,11 @@ void Env::info_host(int g, const char *name, void *buf) {
         ib[4] = fallback_attack; ib[5] = fallback_move;      // (which phase's optimistic rounds ran out)
         ib[6] = last_render_kernel;                          // 0 k_render, 1 k_render_fast, 4 k_render_sweep2
         ib[7] = plain_steps;                                 // steps that took the fused passes of plain games (k_strike ...)
+        return;
+    }
+    if (k == "round_hist") {     // additive (tuning): plain steps since the last read by the last round of the death-rank fixed point that
+        // still changed something (0: none did; one more round than that was needed to see it converge), steps that ran out not counted
+        for (int q = 0; q < 9; q++) { ib[q] = round_hist[q]; round_hist[q] = 0; }
         return;
     }
     if (k == "batch_host_us") {  // additive (tuning): host microseconds per env_cycle_many round since the last read:

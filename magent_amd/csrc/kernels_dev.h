@@ -993,7 +993,7 @@ __device__ __forceinline__ void move_commit_body(const WorldView &W, const Group
 
 // ------------------------------------------------------------------------------------------------ the step of plain games
 // Plain games -- one-cell bodies, no turn_mode / food_mode / goals / kill_supply: battle, gather, every BASELINE configuration but the
-// reference's own 1M harness -- have a pipeline of their own behind the shuffle (round 4).  Five kinds of per-agent launches where the
+// reference's own 1M harness -- have a pipeline of their own behind the shuffle (round 4).  Four kinds of per-agent launches where the
 // generic step has nine, and half the dependent gathers per launch:
 //   k_plain_rank   every agent: its record {order key | rank in the shuffled attack list, death rank = "never", the cell its move is aimed
 //                  at}.  An attacker looks its target up ONCE, here: it keeps the target's reference (`atk`) and
@@ -1007,16 +1007,16 @@ __device__ __forceinline__ void move_commit_body(const WorldView &W, const Group
 //                  rules, and claims its target cell.  Nobody writes the map in this pass, so occupants are still found through the
 //                  phase-start map; whether an occupant is still there when the moves begin -- it may have been killed, or starve -- is
 //                  decided by the claimant from the occupant's record and `mv` (what starve_body would do with it).
-//   k_plain_init   who won its cell, and on whom its move depends (k_move_init without the map lookup: k_strike saved what it saw);
-//                  the agents that died in this step leave the map here, after its last reader
-//   k_plain_commit k_move_commit on the records
+//   k_plain_commit who moves -- the winner of its cell's claim whose target is empty or left by a winner in turn, asked of k_strike's records
+//                  (k_move_init and k_move_commit without the map lookups: k_strike saved what it saw) -- the map and the painted map
+//                  brought up to date; the agents that died in this step leave the map here, after its last reader
 // Per-agent state that other agents read lives in ONE 16-byte record per agent (`rec`: a claimant reads its occupant's key, death rank
 // and target with one request).  No per-cell pass is left in the step -- at BASELINE config 5's 3536 x 3536 cells the two fills of the
 // generic step are 150 MB per step: the hit masks are per agent and cleaned by their owners (k_strike), and a claim word carries the
 // EPOCH of the step that wrote it in its top bits (claim_word below), counting DOWN from step to step: a word of an earlier step loses
 // every atomicMin against this step's claims and reads as "nobody" -- nothing is cleaned; every 63rd step the host refills the array
 // (engine.hip: scratch_for).  The "inputs changed" stamps of the rounds count on across steps in the same way (PlainWorld::round_base).
-constexpr unsigned MV_DIED = 0xFFFFFFFBu;   // move status between k_strike and k_plain_init: killed or starved in this step, still on the map
+constexpr unsigned MV_DIED = 0xFFFFFFFBu;   // move status between k_strike and k_plain_commit: killed or starved in this step, still on the map
 constexpr unsigned MV_FAIL_SAME = 0xFFFFFFFCu;   // MV_FAIL of an agent whose hp this step left as it was: its painted cell is current (k_plain_commit)
 // claim word of the plain pipeline: [63:58] epoch (0..62; 63 = the fill pattern: nobody) | [57:30] order key (boundary bit, 27-bit insertion
 // index) | [29:0] agent reference.  Smaller = earlier: a later step's epoch is smaller, so stale words never win
@@ -1036,10 +1036,6 @@ struct StrikeRules {
     struct One { int ga, gb, op, rule_no, n_subj; float v[4]; } r[4];
 };
 
-__device__ __forceinline__ unsigned plain_resolve(const PlainGroup *ptab, unsigned m) {
-    while (m < MV_DIED) m = (unsigned)ptab[ref_group((int)m)].rec[ref_index((int)m)].w;
-    return m;
-}
 
 // ------------------------------------------------------------------------------------------------ move, generic bodies
 // Bodies larger than one cell (Map::do_move with width x height rectangles, Map.cc:313-333, 454-470).  A mover m with

@@ -24,13 +24,14 @@ __global__ void __launch_bounds__(64) k_step_report(int *counters, StepRecord *r
     const bool open = (oa | om) != 0;
     const bool trig = tid < CTR_TRIGGER_END - CTR_TRIGGER && counters[CTR_TRIGGER + tid] != 0;
     const unsigned long long mask = __ballot(trig);
+    const unsigned long long rounds = __ballot(tid < ROUND_SLOTS && counters[CTR_ROUND_CHANGED + tid] != 0);
     if (tid < NG) {
         int d = 0;
         for (int k = 0; k < DEAD_SLOTS; k++) d += counters[dead_slot(tid, k)];
         rec->dead[tid] = d; rec->taken[tid] = counters[CTR_TAKEN + tid];
     }
     if (tid == 0) {
-        rec->triggers = mask;
+        rec->triggers = mask; rec->rounds_mask = (unsigned)rounds;
         rec->rng = (unsigned)counters[CTR_RNG];
         rec->last_a = counters[CTR_ATTACK];
         rec->unsupported = counters[CTR_UNSUPPORTED]; rec->pack_overflow = counters[CTR_PACK_OVERFLOW];
@@ -364,7 +365,9 @@ __global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, 
 // (s_rank / s_ref: the thread's hit list, stride NT, slot tid -- sort_hits)
 __global__ void __launch_bounds__(256) k_plain_eval(WorldView W, PlainWorld PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, int round, int flag,
                                                    int *shuf_head, int *shuf_first) {
+    // (both counters requested before either is looked at: one trip to memory instead of two before a converged round returns)
     const int A = W.counters[CTR_ATTACK];
+    const int prev_changed = W.counters[CTR_ROUND_CHANGED + ((round - 1) & (ROUND_SLOTS - 1))];
     if (A == 0) return;
     // the shuffle's list heads and first-hit words have been read for the last time (k_plain_rank): back to zero for their next use
     if (round == 1)
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(256) k_plain_eval(WorldView W, PlainWorld PW, 
             shuf_head[k] = 0; shuf_first[k] = 0;
         }
     // nobody's death rank changed in the round before: nobody is stamped for this one
-    if (round > 1 && W.counters[CTR_ROUND_CHANGED + ((round - 1) & (ROUND_SLOTS - 1))] == 0) return;
+    if (round > 1 && prev_changed == 0) return;
     extern __shared__ unsigned s_hit[];
     const int NT = blockDim.x, tid = threadIdx.x;
     unsigned *s_rank = s_hit;
@@ -420,21 +423,26 @@ __global__ void __launch_bounds__(256) k_plain_eval(WorldView W, PlainWorld PW, 
 }
 
 __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, StrikeRules R) {
-    if (attack_open(W)) return;
     const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     const GroupDev &G = W.grp[g];
     const TypeDev &T = W.type[g];
+    if ((int)(blockIdx.x * blockDim.x) >= G.n) return;
+    // (the agent's own fields are requested before the counters are looked at: they travel together)
+    const int il = i < G.n ? i : G.n - 1;
+    const int pend = G.pend[il];
+    const int4 me = PW.g[g].rec[il];                     // {key | rank, death rank, move target, -}
+    const float hp0 = G.hp[il], nr0 = G.next_reward[il];
+    const bool dead0 = G.dead[il];
+    if (attack_open(W)) return;
     const bool attacked = W.counters[CTR_ATTACK] != 0;
     bool died = false, alive = false;
     unsigned trig = 0;
     if (i < G.n) {
-        const int pend = G.pend[i];
         if (pend != PEND_NONE) G.last_action[i] = pend_action(pend, T);     // Agent::set_action's `last_action = act` (see k_set_action_a)
-        bool dead = G.dead[i];
-        const int4 me = PW.g[g].rec[i];                  // {key | rank, death rank, move target, -}
-        float hp = G.hp[i];
+        bool dead = dead0;
+        float hp = hp0;
         const unsigned hp_before = __float_as_uint(hp);
-        float nr = G.next_reward[i];
+        float nr = nr0;
         const unsigned nr_before = __float_as_uint(nr);
         int last_op = OP_NULL, op_obj = -1;              // (what clear_dead left: with rules fused, the host has seen it run since the last step)
         // ---- the attack phase applied from the converged death ranks (attack_apply_body, one-cell bodies, no supply)
@@ -490,7 +498,7 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
             const unsigned key = (unsigned)me.x;
             int o = W.occ[c];
             bool ok = o == OCC_EMPTY;
-            if (o == OCC_WALL) PW.g[g].rec[i].z = -1;    // no move at all (Map::is_blank_area): k_plain_init / k_plain_commit see a non-mover
+            if (o == OCC_WALL) PW.g[g].rec[i].z = -1;    // no move at all (Map::is_blank_area): k_plain_commit sees a non-mover
             if (o >= 0) {
                 const int4 oc = ptab[ref_group(o)].rec[ref_index(o)];
                 const float orec = ttab[ref_group(o)].step_recover;
@@ -499,10 +507,10 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
                 if (gone) { ok = true; o = OCC_EMPTY; }                                          // the cell is empty when the moves begin
                 else ok = oc.z >= 0 && (unsigned)oc.x < key;                                     // the occupant may leave, and before my turn
             }
-            PW.g[g].atk[i] = o;              // what my target cell holds when the moves begin, for k_plain_init / k_plain_commit (a mover has no attack target)
+            PW.g[g].atk[i] = o;              // what my target cell holds when the moves begin, for k_plain_commit (a mover has no attack target)
             if (ok) atomicMin(&W.claim[c], claim_word(PW.epoch, key, ref_pack(g, i)));
         }
-        // (the move status k_plain_rank left says "hp as it was": corrected here where it is not; k_plain_init raises the winners')
+        // (the status k_plain_rank left says "hp as it was": corrected here where it is not)
         if (died) PW.g[g].rec[i].w = (int)MV_DIED;
         else if (__float_as_uint(hp) != hp_before) PW.g[g].rec[i].w = (int)MV_FAIL;
     }
@@ -519,56 +527,78 @@ __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, cons
     if (threadIdx.x == 0 && (int)(blockIdx.x * blockDim.x) < G.n) PW.alive[PW.alive_off[g] + blockIdx.x] = s_alive[0] + s_alive[1] + s_alive[2] + s_alive[3];
 }
 
-__global__ void __launch_bounds__(256) k_plain_init(WorldView W, PlainWorld PW) {
-    if (attack_open(W)) return;
-    const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    const GroupDev &G = W.grp[g];
-    if (i >= G.n) return;
-    const int2 me_zw = ((const int2 *)&PW.g[g].rec[i])[1];       // {move target, status}
-    struct { int z, w; } me{me_zw.x, me_zw.y};
-    if ((unsigned)me.w == MV_DIED) {             // Map::remove_agent (Map.cc:272, GridWorld.cc:536): nobody reads the map in this launch
-        cells_clear(W, G.x[i], G.y[i], 1, 1);
-        PW.g[g].rec[i].w = (int)MV_FAIL;
-        return;
-    }
-    const int c = me.z;
-    if (c < 0 || G.dead[i]) return;
-    const unsigned long long cl = W.claim[c];
-    if (!claim_live(cl, PW.epoch) || claim_ref(cl) != ref_pack(g, i)) return;   // not the static winner (or no claim of mine): stays MV_FAIL
-    const int o = PW.g[g].atk[i];
-    PW.g[g].rec[i].w = o == OCC_EMPTY ? (int)MV_OK : o;             // succeeds iff the occupant o succeeds
+// The end of the step of plain games: who moves (Map::do_move, Map.cc:313-358, in key order), the map and the painted map brought up to date.
+// One launch since round 4 (k_plain_init used to store every claim's static winner first): a mover decides from k_strike's records
+//   * it is the winner of its target cell -- the live claim word there names it --
+//   * and the cell is empty when the moves begin (atk = OCC_EMPTY), or its occupant is a winner that leaves in turn (the same question one
+//     record further: the occupant's target, that cell's claim word, its occupant ...; chains are short, most end at the first record),
+// reading only what k_strike left (rec, atk, claim): nothing this launch writes is read by another agent of it.  The killed and the starved
+// leave the map here (Map::remove_agent, Map.cc:272, GridWorld.cc:536) unless a mover has claimed their cell -- that mover found the cell
+// empty (k_strike's `gone`), so it succeeds and writes the cell itself; the same rule as for the cell a mover leaves behind.
+__device__ __forceinline__ const int4 *plain_rec(const PlainWorld &PW, int NG, int gg) {
+    const int4 *p = PW.g[0].rec;
+#pragma unroll
+    for (int k = 1; k < MAXG; k++) if (k < NG) p = gg == k ? PW.g[k].rec : p;      // (NG is wave-uniform; the table sits in scalar registers)
+    return p;
 }
-// (move_commit_body on the records: see there)
-__global__ void __launch_bounds__(256) k_plain_commit(WorldView W, PlainWorld PW, const PlainGroup *ptab) {
-    if (attack_open(W)) return;
+__device__ __forceinline__ const int *plain_atk(const PlainWorld &PW, int NG, int gg) {
+    const int *p = PW.g[0].atk;
+#pragma unroll
+    for (int k = 1; k < MAXG; k++) if (k < NG) p = gg == k ? PW.g[k].atk : p;
+    return p;
+}
+// does mover `a` (a packed ref; its record `ra` already read) leave its cell?  MV_OK or MV_FAIL
+__device__ __forceinline__ unsigned plain_leaves(const WorldView &W, const PlainWorld &PW, int a, int4 ra) {
+    for (int hops = 0;; hops++) {
+        if (ra.z < 0) return MV_FAIL;                                              // no move (or into a wall): it stays
+        const unsigned long long cl = W.claim[ra.z];
+        if (!claim_live(cl, PW.epoch) || claim_ref(cl) != a) return MV_FAIL;       // not the winner of its target
+        const int o = plain_atk(PW, W.G, ref_group(a))[ref_index(a)];
+        if (o == OCC_EMPTY) return MV_OK;
+        a = o;                                                                     // succeeds iff its own occupant leaves (a lower key: the chain ends)
+        ra = plain_rec(PW, W.G, ref_group(a))[ref_index(a)];
+    }
+}
+__global__ void __launch_bounds__(256) k_plain_commit(WorldView W, PlainWorld PW) {
     const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     const GroupDev &G = W.grp[g];
     if (i >= G.n) return;
-    const int4 me = PW.g[g].rec[i];
-    const int c = me.z;
-    if (c >= 0 && !G.dead[i]) {
-        if (plain_resolve(ptab, (unsigned)me.w) == MV_OK) {
-            const int old = G.y[i] * W.w + G.x[i];
-            if (!claim_live(W.claim[old], PW.epoch)) { W.occ[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }   // nobody claimed my cell
-            W.occ[c] = ref_pack(g, i);
-            const int ny = c / W.w;
-            G.x[i] = c - ny * W.w; G.y[i] = ny;
-        } else {
-            const int o = PW.g[g].atk[i];
-            int blocker;
-            if (o == OCC_EMPTY) blocker = claim_ref(W.claim[c]);           // lost an empty cell to the lowest key
-            else {
-                const int4 oc = ptab[ref_group(o)].rec[ref_index(o)];
-                const bool left_before = plain_resolve(ptab, (unsigned)oc.w) == MV_OK && (unsigned)oc.x < (unsigned)me.x;
-                blocker = left_before ? claim_ref(W.claim[c]) : o;
-            }
-            G.last_op[i] = OP_COLLIDE;
-            G.op_obj[i] = blocker;
-        }
-    }
+    // (my own record first, the question whether the attack rounds ran out behind it: the loads are in flight while the counter arrives)
+    const int4 me = PW.g[g].rec[i];                          // {key, death rank, move target, k_strike's status}
+    const int o = PW.g[g].atk[i];
+    const int px = G.x[i], py = G.y[i];
+    if (attack_open(W)) return;
+    const int self = ref_pack(g, i), old = py * W.w + px, c = me.z;
+    const bool died = (unsigned)me.w == MV_DIED;
+    const bool mover = c >= 0 && !died;                      // (a move target implies "alive when the step began": k_plain_rank)
+    const bool alive = me.y != -1 && !died;
+    const bool chain = mover && o >= 0;
+    // one level of independent loads: the claim words of my target and of my own cell, the record of my target's occupant
+    const unsigned long long cl_c = W.claim[mover ? c : 0];
+    const unsigned long long cl_old = W.claim[(mover || died) ? old : 0];
+    const int4 ro = plain_rec(PW, W.G, chain ? ref_group(o) : g)[chain ? ref_index(o) : i];
+    const unsigned s_o = chain ? plain_leaves(W, PW, o, ro) : MV_OK;
+    const bool winner = mover && claim_live(cl_c, PW.epoch) && claim_ref(cl_c) == self;
+    const bool ok = winner && s_o == MV_OK;
+    int cell = old;
+    if (ok) {
+        if (!claim_live(cl_old, PW.epoch)) { W.occ[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }   // nobody claimed my cell
+        W.occ[c] = self;
+        const int ny = c / W.w;
+        G.x[i] = c - ny * W.w; G.y[i] = ny;
+        cell = c;
+    } else if (mover) {
+        // Map::get_collide: what I ran into -- the occupant, or whoever took the cell before my turn (the lowest key: the claim's winner)
+        int blocker;
+        if (o == OCC_EMPTY) blocker = claim_ref(cl_c);
+        else blocker = (s_o == MV_OK && (unsigned)ro.x < (unsigned)me.x) ? claim_ref(cl_c) : o;
+        G.last_op[i] = OP_COLLIDE;
+        G.op_obj[i] = blocker;
+    } else if (died && !claim_live(cl_old, PW.epoch)) { W.occ[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }
     G.pend[i] = PEND_NONE;   // end of step: pending actions are consumed
     // live paint: every agent that moved or whose hp changed paints its cell (most agents of a battle stand at full hp: 4 of 5 stores saved)
-    if (W.live_paint && (unsigned)me.w != MV_FAIL_SAME) repaint_body(W, G, W.type[g], g, i);
+    if (W.live_paint && alive && (ok || (unsigned)me.w == MV_FAIL))
+        vc_store(W, cell, g, __float_as_uint(__fdiv_rn(G.hp[i], W.type[g].hp)));      // repaint_body for a 1 x 1 body
 }
 __global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted, int starve) {
     if (attack_open(W)) return;
@@ -1006,7 +1036,7 @@ void launch_movg_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) 
     hipLaunchKernelGGL(k_movg_vacate, g, dim3(256), 0, s, W);
     hipLaunchKernelGGL(k_movg_enter, g, dim3(256), 0, s, W);
 }
-// the step of plain games behind the shuffle: k_plain_rank, rounds of k_plain_eval, then k_strike, k_plain_init, k_plain_commit
+// the step of plain games behind the shuffle: k_plain_rank, rounds of k_plain_eval, then k_strike, k_plain_commit
 // (launch_plain_tail).  `rules`: the compiled rules, if every one of them pays the attacker of one event only (fused_rules); else
 // null, and launch_rules runs behind the commit as usual
 bool fused_rules(const RuleArgs *rules, int n) {
@@ -1044,8 +1074,7 @@ void launch_plain_tail(hipStream_t s, const WorldView &W, const PlainWorld &PW, 
     }
     dim3 g = grid_all(W, 256);
     hipLaunchKernelGGL(k_strike, g, dim3(256), 0, s, W, PW, ptab, gtab, ttab, R);
-    hipLaunchKernelGGL(k_plain_init, g, dim3(256), 0, s, W, PW);
-    hipLaunchKernelGGL(k_plain_commit, g, dim3(256), 0, s, W, PW, ptab);
+    hipLaunchKernelGGL(k_plain_commit, g, dim3(256), 0, s, W, PW);
 }
 
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {

@@ -487,6 +487,12 @@ class GridWorld(object):
         self._lib.env_get_info(self.game, 0, b"engine_stats", buf.ctypes.data)
         return tuple(int(v) for v in buf)
 
+    def round_hist(self):
+        """additive (tuning): plain steps since the last call, by the last attack round that still changed a death rank"""
+        buf = np.zeros(9, dtype=np.int32)
+        self._lib.env_get_info(self.game, 0, b"round_hist", buf.ctypes.data)
+        return tuple(int(v) for v in buf)
+
     def profile_enable(self, on=True):
         """on: False / 0 off, True / 1 every named phase, 2 only the observation render launches (cheap: for timed regions)"""
         self._require_device_api()

@@ -107,7 +107,7 @@ def test_emulated_large_world_drivers(emu):
 
 
 def test_emulated_fused_step_of_plain_games(emu):
-    """the pipeline of plain games (k_plain_rank, k_plain_eval, k_strike, k_plain_init, k_plain_commit; step.hip) forced onto small
+    """the pipeline of plain games (k_plain_rank, k_plain_eval, k_strike, k_plain_commit; step.hip) forced onto small
     worlds (MAGENT_TUNE=solo_step=0), workgroups and lanes in scrambled order: every scenario whose game it takes -- starving occupants
     whose cell is claimed in the same step (battle_lowhp), skipped clear_dead (stale events are paid again: rules not fused,
     battle_no_clear), agents and walls added mid-episode and a second episode (battle_events, battle_grow), 140 steps (the claim
