@@ -50,11 +50,11 @@ int env_reset(EnvHandle game);
 int env_get_observation(EnvHandle game, GroupHandle group, float **buffer);
 /* runtime_api.h:28 -> GridWorld::set_action (GridWorld.cc:403-454); actions int32[n].
  * A SECOND set_action for the same group before env_step appends, as in the reference: every agent of the group then acts once per
- * call (two entries in the shuffled attack list, two moves in list order), and last_action is the latest call's.  No caller of the
+ * call (two entries in the shuffled attack list, two turns / moves in list order), and last_action is the latest call's.  No caller of the
  * reference does that, so it is served off the hot path: the step runs the reference's sequential loops on one lane of the device
- * (exact, about a microsecond per list entry) -- for one-cell bodies without turn_mode, food_mode and goals; other games still
- * abort with a message (the reference's own error path is an abort too: LOG(FATAL), utility.h:77-103).  A step of this kind records
- * no attack events for env_render.  An action outside [0, n_action) is reported at env_step (FATAL; the reference indexes out of range). */
+ * (exact, about a microsecond per list entry; every game).  The same loops run a step in which a can_absorb group ("goals") was given
+ * actions: such goals move like any agent in the reference (Map.cc:313-358), which the parallel move resolution does not cover.
+ * An action outside [0, n_action) is reported at env_step (FATAL; the reference indexes out of range). */
 int env_set_action(EnvHandle game, GroupHandle group, const int *actions);
 /* runtime_api.h:29 -> GridWorld::step (GridWorld.cc:456-631) */
 int env_step(EnvHandle game, int *done);

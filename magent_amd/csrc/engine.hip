@@ -1377,7 +1377,10 @@ void Env::set_action_device(int g, const int *d_act) {
     if (g < 0 || g >= (int)groups.size()) fatal("invalid group handle in set_action : %d", g);
     use_device();
     HostGroup &G = groups[g];
-    if (G.acted || serial_calls_on) {   // a group is given actions again before the step: the reference appends (GridWorld.cc:403-454)
+    // a group is given actions again before the step: the reference appends (GridWorld.cc:403-454) -- or goals are given actions, which may
+    // move them (Map::do_move treats a goal that has taken nobody in like any mover; the parallel move resolution rests on goals that
+    // stand still): either way the step runs the reference's own loops on the device (k_step_serial)
+    if (G.acted || serial_calls_on || G.type->can_absorb) {
         serial_add_call(g, d_act);
         G.acted = true;
         return;
@@ -1414,9 +1417,6 @@ void Env::set_action_device(int g, const int *d_act) {
 // of the actions) in call order -- the earlier calls' actions are recovered from the pending actions they left -- and the step runs
 // the reference's sequential loops on the device (k_step_serial).
 void Env::serial_add_call(int g, const int *d_act) {
-    if (turn_mode || food_mode || any_absorb || any_multicell)
-        fatal("set_action called twice for group %d before step: the reference would execute both action lists; this engine does that for "
-              "one-cell bodies without turn_mode, food_mode and goals only", g);
     enter();
     auto keep = [&](int gg, const int *src, bool from_pend) {
         HostGroup &G = groups[gg];
@@ -1442,7 +1442,8 @@ void Env::serial_step() {
     WorldView W = view();
     size_t entries = 0;
     for (auto &c : serial_calls) entries += (size_t)groups[c.g].n;
-    int2 *alist = nullptr; int4 *mlist = nullptr, *msorted = nullptr; SerialCall *d_calls = nullptr;
+    int2 *alist = nullptr; int4 *mlist = nullptr, *msorted = nullptr, *events = nullptr; SerialCall *d_calls = nullptr;
+    HIP_OK(dev_malloc(arena, &events, sizeof(int4) * (entries + 1)));
     HIP_OK(dev_malloc(arena, &alist, sizeof(int2) * (entries + 1)));
     HIP_OK(dev_malloc(arena, &mlist, sizeof(int4) * (entries + 1)));
     HIP_OK(dev_malloc(arena, &msorted, sizeof(int4) * (entries + 1)));
@@ -1451,11 +1452,18 @@ void Env::serial_step() {
     const int n_sep = large_map_mode ? (width + bandwidth - 1) / bandwidth : 0;
     if (n_sep >= 39) fatal("internal: too many move stripes for the serial step");
     push_rng();
-    launch_step_serial(stream, W, d_calls, (int)serial_calls.size(), alist, mlist, msorted, n_sep);
+    launch_step_serial(stream, W, d_calls, (int)serial_calls.size(), alist, mlist, msorted, n_sep, events);
     if (!rules_on_host) launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
     launch_step_report(stream, d_counters, h_rec, ++step_seq, (int)groups.size());
     HIP_OK(hipStreamSynchronize(stream));    // (the slow path: the scratch goes back at once)
-    dfree(arena, alist); dfree(arena, mlist); dfree(arena, msorted); dfree(arena, d_calls);
+    if (!first_render) {                     // attack events are recorded once rendering has started (GridWorld.cc:484,508)
+        const int A = read_counters()[CTR_LAST_A];
+        std::vector<int4> ev((size_t)std::max(A, 0));
+        if (A > 0) read_back(ev.data(), events, sizeof(int4) * (size_t)A);
+        attack_events.clear();
+        for (const int4 &e : ev) if (e.w) attack_events.push_back({e.x, e.y, e.z});
+    }
+    dfree(arena, events); dfree(arena, alist); dfree(arena, mlist); dfree(arena, msorted); dfree(arena, d_calls);
     for (auto &c : serial_calls) if (c.actions) { int *buf = const_cast<int *>(c.actions); dfree(arena, buf); }
     serial_calls.clear();
     serial_calls_on = false;
@@ -1873,7 +1881,7 @@ void Env::step_end(int *done) {
         const StepRecord &r = *h_rec;
         if (!(r.open_attack | r.open_move)) {
             if (r.error) fatal("%s resolution did not converge", r.error == 1 ? "attack" : r.error == 2 ? "move" : "turn");
-            if (r.unsupported) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
+            if (r.unsupported) fatal("internal: a can_absorb agent moved on the parallel path (a set_action for goals switches the step to the literal loop)");
             if (r.pack_overflow) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
             if (r.bad_action) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
             if (r.hit_overflow) fatal("a target collected more attack hits than the engine's hit lists hold (256)");
@@ -1932,7 +1940,7 @@ void Env::step_end(int *done) {
         groups[g].acted = false;
         if (groups[g].n - groups[g].h_dead > 0) live++;
     }
-    if (c[CTR_UNSUPPORTED]) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
+    if (c[CTR_UNSUPPORTED]) fatal("internal: a can_absorb agent moved on the parallel path (a set_action for goals switches the step to the literal loop)");
     if (c[CTR_PACK_OVERFLOW]) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
     if (c[CTR_BAD_ACTION]) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
     if (c[CTR_HIT_OVERFLOW]) fatal("a target collected more attack hits than the engine's hit lists hold (256)");
@@ -1981,6 +1989,8 @@ bool Env::cycle_eligible(int n_group, float *const *view, float *const *feat, in
 bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, BatchItem &item) {
     int first_obs = -1;
     if (!cycle_eligible(n_group, view, feat, &first_obs)) return false;
+    // goals that are given actions may move: the call sequence (set_action_device sends such a step through the literal loop)
+    for (int g = 0; actions && g < n_group && g < (int)groups.size(); g++) if (actions[g] && groups[g].type->can_absorb) return false;
     enter();
     const int NG = (int)groups.size();
     int total_n = 0;
@@ -2037,7 +2047,7 @@ void Env::cycle_finish(int *done) {
     wait_record(step_seq);
     const StepRecord &r = *h_rec;
     if (r.error) fatal("%s resolution did not converge", r.error == 1 ? "attack" : "move");
-    if (r.unsupported) fatal("a can_absorb agent was given a move action: goals that move are not on the GPU path");
+    if (r.unsupported) fatal("internal: a can_absorb agent moved on the parallel path (a set_action for goals switches the step to the literal loop)");
     if (r.pack_overflow) fatal("internal: hp / type.hp outside [0, 2) met the packed view-cell format");
     if (r.bad_action) fatal("set_action: an action outside [0, n_action) (the reference indexes its tables out of range here)");
     if (r.hit_overflow) fatal("a target collected more attack hits than the engine's hit lists hold (256)");

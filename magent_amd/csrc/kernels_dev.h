@@ -1190,7 +1190,8 @@ __device__ __forceinline__ void movg_prep_body(const WorldView &W, int g, int i,
         int nx = G.x[i] + d.x, ny = G.y[i] + d.y;
         if ((d.x | d.y) != 0 && nx >= 0 && ny >= 0 && nx + fp.x < W.w && ny + fp.y < W.h) t = ny * W.w + nx;
     }
-    // goals that move themselves are outside the engine's scope (no shipped game gives them actions): reported, not guessed
+    // goals that move: Env::set_action_device sends a step in which goals were given actions through k_step_serial; reached only through
+    // env_cycle_many (actions handed to the fused cycle), where it is reported, not guessed
     if (t >= 0 && T.can_absorb) { W.counters[CTR_UNSUPPORTED] = 1; t = -1; }
     G.drank_a[i] = t;
     G.mv[i] = t >= 0 ? 0u : MV_FAIL;      // 0 = undecided (the packed-dependency encoding of the 1x1 path is not used here)

@@ -835,19 +835,34 @@ void launch_shuffle(hipStream_t s, int n_max, int *counters, const ShuffleBufs &
     hipLaunchKernelGGL(k_shuffle_draw, g, b, 0, s, counters, B.j, B.head, B.first, B.link, hitbits, ncell, powtab, tiled ? 1 : 0);
     hipLaunchKernelGGL(k_shuffle_chase, g, b, 0, s, counters, B.j, B.head, B.first, B.link, rank);
 }
-// ================================================================================================ repeated set_action: the literal loop
+// ================================================================================================ the literal loop: repeated set_action, goals that move
 // GridWorld::set_action APPENDS to the step's action lists (GridWorld.cc:403-454): a group that is given actions twice before a step
-// has every agent act twice -- two entries in the shuffled attack list, two moves in list order, the second from wherever the first
-// one ended.  The parallel phases above rest on "one pending action per agent"; no caller of the reference does this, so the case
-// is served by the reference's own sequential loops on ONE lane of the device, exact by construction and slow (about a microsecond
-// per list entry).  One-cell bodies without turn_mode, food_mode and goals; everything else still refuses.
+// has every agent act twice -- two entries in the shuffled attack list, two turns and two moves in list order, the second from wherever
+// the first one ended.  The parallel phases above rest on "one pending action per agent" (and the generic move resolution on "goals stand
+// still"); no caller of the reference does either, so these steps are served by the reference's own sequential loops on ONE lane of the
+// device: exact by construction, every game (bodies of any size, turn_mode, food_mode, goals, kill_supply), and slow -- about a
+// microsecond per list entry.
 //   attack loop GridWorld.cc:464-507 (Map::get_attack_obj Map.cc:209-252, Map::do_attack Map.cc:255-310, Agent::be_attack
-//   GridWorld.h:203-209), starve GridWorld.cc:519-542, moves GridWorld.cc:574-613 (Map::do_move Map.cc:313-358)
-__global__ void __launch_bounds__(64) k_step_serial(WorldView W, const SerialCall *calls, int n_calls, int2 *alist, int4 *mlist, int4 *msorted, int n_sep) {
+//   GridWorld.h:203-209), starve GridWorld.cc:519-542, turns GridWorld.cc:544-572 (Map::do_turn Map.cc:361-406), moves
+//   GridWorld.cc:574-613 (Map::do_move Map.cc:313-358, is_blank_area :454-470, get_collide :486-501)
+// events: {attacker id, target x, target y, 1} per executed attack in list order (GridWorld.cc:484), {., ., ., 0} for the dead's entries
+__device__ __forceinline__ bool serial_blank_area(const WorldView &W, int x, int y, int bw, int bl, int self) {
+    if (x < 0 || y < 0 || x + bw >= W.w || y + bl >= W.h) return false;
+    for (int a = 0; a < bw; a++)
+        for (int b = 0; b < bl; b++) {
+            const int o = W.occ[(y + b) * W.w + x + a];
+            if (o != OCC_EMPTY && o != self) return false;        // walls, food and other bodies occupy
+        }
+    return true;
+}
+__global__ void __launch_bounds__(64) k_step_serial(WorldView W, const SerialCall *calls, int n_calls, int2 *alist, int4 *mlist, int4 *msorted, int n_sep,
+                                                   int4 *events) {
     if (threadIdx.x != 0) return;
     const int bandwidth = W.bandwidth;
     int A = 0, M = 0;
-    // ---- the lists, in call order (Agent::set_action stores last_action at once: the last call wins)
+    // ---- the lists, in call order (Agent::set_action stores last_action at once: the last call wins).  Turns and moves share one
+    // array: list number 0 .. n_sep (stripes, then the boundary list) for a turn, n_sep + 1 + the same for a move -- every turn runs
+    // before the first move
     for (int c = 0; c < n_calls; c++) {
         const int g = calls[c].g;
         const GroupDev &G = W.grp[g];
@@ -855,13 +870,13 @@ __global__ void __launch_bounds__(64) k_step_serial(WorldView W, const SerialCal
         const int *act = calls[c].actions;
         for (int i = 0; i < G.n; i++) {
             const int a = act[i];
-            if (a < 0 || a >= T.n_move + T.n_attack) { W.counters[CTR_BAD_ACTION] = 1; continue; }
+            if (a < 0 || a >= T.n_move + T.n_turn + T.n_attack) { W.counters[CTR_BAD_ACTION] = 1; continue; }
             G.last_action[i] = a;
-            if (a < T.n_move) {
+            if (a < T.n_move + T.n_turn) {
                 int list = n_sep;                                            // the boundary list runs last
                 if (W.large_map) { const int x_ = G.x[i] % bandwidth; if (!(x_ < 4 || x_ > bandwidth - 4)) list = G.x[i] / bandwidth; }
-                mlist[M++] = make_int4(ref_pack(g, i), a, list, 0);
-            } else alist[A++] = make_int2(ref_pack(g, i), a - T.n_move);
+                mlist[M++] = make_int4(ref_pack(g, i), a, a < T.n_move ? n_sep + 1 + list : list, 0);
+            } else alist[A++] = make_int2(ref_pack(g, i), a - T.n_move - T.n_turn);
         }
     }
     // ---- shuffle (GridWorld.cc:464-468): minstd_rand0, (int)rng() % (i + 1)
@@ -878,11 +893,19 @@ __global__ void __launch_bounds__(64) k_step_serial(WorldView W, const SerialCal
         const int g = ref_group(alist[e].x), i = ref_index(alist[e].x), k = alist[e].y;
         const GroupDev &G = W.grp[g];
         const TypeDev &T = W.type[g];
-        if (G.dead[i]) continue;
-        const int2 d = W.delta[T.attack_off + k];
-        const int tx = G.x[i] + d.x, ty = G.y[i] + d.y;
-        int o = OCC_EMPTY;
-        if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) o = W.occ[ty * W.w + tx];
+        if (G.dead[i]) { events[e] = make_int4(0, 0, 0, 0); continue; }
+        const int2 tc = attack_target(W, G, T, i, k);
+        events[e] = make_int4(G.id[i], tc.x, tc.y, 1);
+        int o = OCC_EMPTY, cell = -1;
+        if (tc.x >= 0 && tc.x < W.w && tc.y >= 0 && tc.y < W.h) { cell = tc.y * W.w + tc.x; o = W.occ[cell]; }
+        if (o == OCC_FOOD) {      // Map.cc:292-303: eat; the attack counts as one on an object (reward 0.0 + attack_penalty)
+            const float add = fminf(T.eat_ability, W.food[cell]);
+            G.hp[i] = fminf(T.hp, G.hp[i] + add);
+            W.food[cell] -= add;
+            if (W.food[cell] < 0.1f) W.occ[cell] = OCC_EMPTY;
+            G.next_reward[i] += 0.0f + T.attack_penalty;
+            continue;
+        }
         if (o < 0 || (!T.attack_in_group && ref_group(o) == g)) { G.next_reward[i] += T.attack_penalty; continue; }
         const int tg = ref_group(o), ti = ref_index(o);
         const GroupDev &V = W.grp[tg];
@@ -892,9 +915,11 @@ __global__ void __launch_bounds__(64) k_step_serial(WorldView W, const SerialCal
         if (V.hp[ti] < 0.0f) { V.dead[ti] = 1; V.next_reward[ti] = TV.dead_penalty; }
         if (V.dead[ti]) {
             G.last_op[i] = OP_KILL; G.op_obj[i] = o;
-            W.occ[V.y[ti] * W.w + V.x[ti]] = OCC_EMPTY;
+            const int2 fp = body_dims(W, V, TV, ti);
+            body_fill(W, V.x[ti], V.y[ti], fp.x, fp.y, OCC_EMPTY);            // Map::remove_agent
             W.counters[dead_slot(tg, 0)] += 1;
             G.hp[i] = fminf(T.hp, G.hp[i] + TV.kill_supply);
+            if (W.food_mode) { W.occ[cell] = OCC_FOOD; W.food[cell] = TV.food_supply; }   // on the attacked cell only (Map.cc:277-284)
             reward = TV.kill_reward;
         } else { G.last_op[i] = OP_ATTACK; G.op_obj[i] = o; }
         G.next_reward[i] += reward + T.attack_penalty;
@@ -910,33 +935,69 @@ __global__ void __launch_bounds__(64) k_step_serial(WorldView W, const SerialCal
                 G.hp[i] -= -T.step_recover;
                 if (G.hp[i] < 0.0f) {
                     G.dead[i] = 1; G.next_reward[i] = T.dead_penalty;
-                    W.occ[G.y[i] * W.w + G.x[i]] = OCC_EMPTY;
+                    const int2 fp = body_dims(W, G, T, i);
+                    body_fill(W, G.x[i], G.y[i], fp.x, fp.y, OCC_EMPTY);
                     W.counters[dead_slot(g, 0)] += 1;
                 }
             }
         }
     }
-    // ---- moves: stripe lists 0 .. n_sep - 1, then the boundary list, each in insertion order (a stable counting sort by list)
-    int start[40];
-    for (int l = 0; l <= n_sep; l++) start[l] = 0;
+    // ---- turns, then moves: lists in number order, each in insertion order (a stable counting sort by list)
+    int start[80];
+    const int n_lists = 2 * (n_sep + 1);
+    for (int l = 0; l < n_lists; l++) start[l] = 0;
     for (int e = 0; e < M; e++) start[mlist[e].z]++;
-    for (int l = 0, run = 0; l <= n_sep; l++) { const int c = start[l]; start[l] = run; run += c; }
+    for (int l = 0, run = 0; l < n_lists; l++) { const int c = start[l]; start[l] = run; run += c; }
     for (int e = 0; e < M; e++) msorted[start[mlist[e].z]++] = mlist[e];
     for (int e = 0; e < M; e++) {
-        const int g = ref_group(msorted[e].x), i = ref_index(msorted[e].x);
+        const int self = msorted[e].x, g = ref_group(self), i = ref_index(self), a = msorted[e].y;
         const GroupDev &G = W.grp[g];
         const TypeDev &T = W.type[g];
         if (G.dead[i]) continue;
-        const int2 d = W.delta[T.move_off + msorted[e].y];
+        const int2 fp = body_dims(W, G, T, i);
+        if (a >= T.n_move) {
+            // Map::do_turn about the body's reference corner (turn offsets are 0, AgentType.cc:108): the new direction from the action
+            // number as the reference computes it (turned_dir), the footprint transposed
+            const int dir = G.dir[i], ndir = turned_dir(dir, a);
+            int rx, ry, sx, sy;
+            saved_to_real(dir, T.bw, T.bl, G.x[i], G.y[i], rx, ry);
+            real_to_saved(ndir, T.bw, T.bl, rx, ry, sx, sy);
+            const int2 nd = dims_for_dir(T, ndir);
+            if (serial_blank_area(W, sx, sy, nd.x, nd.y, self)) {
+                body_fill(W, G.x[i], G.y[i], fp.x, fp.y, OCC_EMPTY);
+                G.dir[i] = ndir;
+                body_fill(W, sx, sy, nd.x, nd.y, self);
+                G.x[i] = sx; G.y[i] = sy;
+            }
+            continue;
+        }
+        if (G.absorbed[i]) continue;                                              // a goal that has taken a mover in stands still (GridWorld.cc:580)
+        const int2 d = agent_delta(W, G, i, T.move_off, a);
         const int nx = G.x[i] + d.x, ny = G.y[i] + d.y;
-        if (nx < 0 || ny < 0 || nx + 1 >= W.w || ny + 1 >= W.h) continue;     // Map::is_blank_area's bounds; no collide object out there
-        const int c = ny * W.w + nx;
-        const int o = W.occ[c];
-        if (o == OCC_EMPTY || o == ref_pack(g, i)) {
-            W.occ[G.y[i] * W.w + G.x[i]] = OCC_EMPTY;
-            W.occ[c] = ref_pack(g, i);
+        if (serial_blank_area(W, nx, ny, fp.x, fp.y, self)) {
+            body_fill(W, G.x[i], G.y[i], fp.x, fp.y, OCC_EMPTY);
+            body_fill(W, nx, ny, fp.x, fp.y, self);
             G.x[i] = nx; G.y[i] = ny;
-        } else if (o >= 0) { G.last_op[i] = OP_COLLIDE; G.op_obj[i] = o; }    // Map::get_collide: agents only (walls are no objects)
+        } else if (!(nx < 0 || ny < 0 || nx + fp.x >= W.w || ny + fp.y >= W.h)) {
+            // Map::get_collide: the first agent met, x outer, y inner (walls and food are no objects)
+            int o = -1;
+            for (int bx = 0; bx < fp.x && o < 0; bx++)
+                for (int by = 0; by < fp.y; by++) {
+                    const int v = W.occ[(ny + by) * W.w + nx + bx];
+                    if (v >= 0 && v != self) { o = v; break; }
+                }
+            if (o < 0) continue;
+            const GroupDev &O = W.grp[ref_group(o)];
+            const int oi = ref_index(o);
+            if (W.type[ref_group(o)].can_absorb) {                                // Map.cc:341-350: the first mover to bump into a goal is taken in
+                if (O.absorbed[oi]) continue;                                     // a goal that is already taken: nothing happens, not even a collide
+                O.absorbed[oi] = 1; O.hp[oi] = O.hp[oi] * 2;
+                G.dead[i] = 1;                                                    // dead without counting in dead_ct (Map.cc:345-346)
+                body_fill(W, G.x[i], G.y[i], fp.x, fp.y, OCC_EMPTY);
+                W.counters[CTR_TAKEN + g] += 1;
+            }
+            G.last_op[i] = OP_COLLIDE; G.op_obj[i] = o;
+        }
     }
     // ---- the step's pending actions are consumed
     for (int g = 0; g < W.G; g++) for (int i = 0; i < W.grp[g].n; i++) W.grp[g].pend[i] = PEND_NONE;
@@ -946,8 +1007,8 @@ __global__ void __launch_bounds__(256) k_pend_to_actions(GroupDev G, TypeDev T, 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < G.n) out[i] = G.pend[i] == PEND_NONE ? T.n_move + T.n_turn + T.n_attack : pend_action(G.pend[i], T);   // (an action outside the space stays one)
 }
-void launch_step_serial(hipStream_t s, const WorldView &W, const SerialCall *calls, int n_calls, int2 *alist, int4 *mlist, int4 *msorted, int n_sep) {
-    hipLaunchKernelGGL(k_step_serial, dim3(1), dim3(64), 0, s, W, calls, n_calls, alist, mlist, msorted, n_sep);
+void launch_step_serial(hipStream_t s, const WorldView &W, const SerialCall *calls, int n_calls, int2 *alist, int4 *mlist, int4 *msorted, int n_sep, int4 *events) {
+    hipLaunchKernelGGL(k_step_serial, dim3(1), dim3(64), 0, s, W, calls, n_calls, alist, mlist, msorted, n_sep, events);
 }
 void launch_pend_to_actions(hipStream_t s, const GroupDev &G, const TypeDev &T, int *out) {
     if (G.n > 0) hipLaunchKernelGGL(k_pend_to_actions, dim3((G.n + 255) / 256), dim3(256), 0, s, G, T, out);

@@ -77,6 +77,14 @@ def main():
     for name, data in files.items():
         open(os.path.join(out, name), "wb").write(data)
     print("render files:", {k: len(v) for k, v in files.items()})
+    tmp = tempfile.mkdtemp()
+    files = H.render_episode(H.REF_LIB, tmp, twice=True)
+    out = os.path.join(HERE, "render_battle16_twice")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    for name, data in files.items():
+        open(os.path.join(out, name), "wb").write(data)
+    print("render files (a group given actions twice):", {k: len(v) for k, v in files.items()})
 
 
 if __name__ == "__main__":

@@ -373,6 +373,7 @@ def run(sc, lib, record=None, device_io=False, env_out=None):
     if env_out is not None:
         env_out.append(env)        # (the caller wants to look at the engine afterwards: engine_stats)
     rs = np.random.RandomState(sc.action_seed)
+    twice = np.random.RandomState(sc.action_seed ^ 0x7A1CE) if os.environ.get("FUZZ_TWICE", "0") == "1" else None
     acting = sc.acting if sc.acting is not None else list(range(len(handles)))
     if device_io:
         import torch
@@ -405,6 +406,9 @@ def run(sc, lib, record=None, device_io=False, env_out=None):
             rec["id%d" % g] = env.get_agent_id(h)
             if g in acting:
                 env.set_action(h, rs.randint(env.get_action_space(h)[0], size=n).astype(np.int32))
+        if twice is not None and not device_io:      # FUZZ_TWICE=1: some groups are given actions again before the step (GridWorld.cc:403-454 appends)
+            for g in [g for g in acting if twice.rand() < 0.4]:
+                env.set_action(handles[g], twice.randint(env.get_action_space(handles[g])[0], size=env.get_num(handles[g])).astype(np.int32))
         rec["done"] = np.array([env.step()], dtype=np.int32)
         for g, h in enumerate(handles):
             if device_io:
@@ -622,8 +626,9 @@ def fullsize_scenarios():
     return {s.name: s for s in S}
 
 
-def render_episode(lib, out_dir, steps=6):
-    """a short battle with the text video dump on: returns {file name: bytes} of what env.render() wrote"""
+def render_episode(lib, out_dir, steps=6, twice=False):
+    """a short battle with the text video dump on: returns {file name: bytes} of what env.render() wrote
+    (twice: group 0 is given actions a second time before every other step -- the attack events of the literal loop)"""
     sc = Scenario("render", "battle", 16, place=[(0, "random", {"n": 30}), (1, "random", {"n": 30})], steps=steps, action_seed=4,
                   over={"small": {"hp": 3, "damage": 2}})
     env, handles = sc.build(lib)
@@ -632,6 +637,8 @@ def render_episode(lib, out_dir, steps=6):
     for step in range(steps):
         for h in handles:
             env.set_action(h, rs.randint(21, size=env.get_num(h)).astype(np.int32))
+        if twice and step % 2 == 1:
+            env.set_action(handles[0], rs.randint(21, size=env.get_num(handles[0])).astype(np.int32))
         env.step()
         env.render()                       # before clear_dead, like examples/train_battle.py:88-96
         if step == 2:
@@ -888,7 +895,8 @@ def fuzz_scenario(seed):
     if rs.rand() < 0.15:          # one group of goals (can_absorb); goals are never given actions (engine scope)
         goal = int(rs.randint(G))
         specs[goal]["can_absorb"] = True
-        acting = [g for g in acting if g != goal]
+        if os.environ.get("FUZZ_GOALS_ACT", "0") != "1":     # (=1: the goals are given actions like everybody -- they move: the literal loop)
+            acting = [g for g in acting if g != goal]
     if fuzz_turn == 2 and turn_mode and not TURN_MULTICELL_ON_ENGINE and any(t["width"] * t["length"] > 1 or t.get("can_absorb") for t in specs):
         turn_mode = False
     # FUZZ_GOAL=1: goal_mode in half of the games and set_goal calls between steps (a generator of their own: the games of a seed stay
@@ -954,6 +962,12 @@ def scenarios():
                  events={0: [("goal", 0)], 5: [("goal", 1), ("add", 0, "random", {"n": 30})], 9: [("goal", 0), ("goal", 1)]}),
         Scenario("pursuit_goals_drawn", "pursuit", 30, walls=20, place=[rnd(0, 40), rnd(1, 80)], steps=14, action_seed=63,
                  events={3: [("goal", 1)], 4: [("add", 1, "random", {"n": 25})], 8: [("goal", 0)]}),
+        # goals that are given actions: Map::do_move treats a goal that has taken nobody in like any mover (Map.cc:313-358; one that has
+        # stands still, GridWorld.cc:580) -- the parallel move resolution rests on goals that stand still, so these steps run the
+        # reference's own loops on one lane of the device (k_step_serial)
+        Scenario("arrange_goals_move", ("arrange", 36, True), 0, place=[rnd(0, 150), rnd(1, 250), rnd(2, 30)], walls=40, steps=25, action_seed=64),
+        Scenario("arrange_goals_move_turn", ("arrange", 40, True), 0, place=[rnd(0, 160), rnd(1, 260), rnd(2, 30)], walls=30, steps=20, action_seed=65,
+                 settings={"turn_mode": True}, clear_every=2),
         Scenario("battle_walls", "battle", 50, walls=200, place=[rnd(0, 400), rnd(1, 400)], steps=20, action_seed=3),
         Scenario("battle_largemap", "battle", 120, place=[rnd(0, 3000), rnd(1, 3000)], steps=12, action_seed=5),
         Scenario("battle_largemap_odd", "battle", 101, place=[rnd(0, 2500), rnd(1, 2500)], steps=10, action_seed=6),

@@ -19,7 +19,7 @@ import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # a slice that touches every phase family: dense attack chains, striped moves, multi-cell bodies, rules, goals, turn_mode, food
-SLICE = ["battle_small_dense", "battle_brawl", "battle_walls", "gather", "forest", "tri_rect", "pursuit_dense", "bodies", "quad", "battle_goal_mode", "pursuit_goals_drawn"]
+SLICE = ["battle_small_dense", "battle_brawl", "battle_walls", "gather", "forest", "tri_rect", "pursuit_dense", "bodies", "quad", "battle_goal_mode", "pursuit_goals_drawn", "arrange_goals_move"]
 
 
 @pytest.fixture(scope="module")
@@ -83,6 +83,18 @@ def test_emulated_battle_render_kernels(emu, knobs):
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS="1", **knobs), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-1000:] + p.stderr[-3000:]
+
+
+def test_emulated_render_dumps(emu, tmp_path):
+    """env.render()'s text dump from the emulated engine, byte for byte what the reference's RenderGenerator wrote -- also when a group is
+    given actions twice (the attack events of k_step_serial)"""
+    for twice in (False, True):
+        d = tmp_path / ("twice" if twice else "once")
+        d.mkdir()
+        got = H.render_episode(emu, str(d), twice=twice)
+        gold = os.path.join(H.GOLDEN_DIR, "render_battle16_twice" if twice else "render_battle16")
+        for name in sorted(os.listdir(gold)):
+            assert got[name] == open(os.path.join(gold, name), "rb").read(), (twice, name)
 
 
 def test_emulated_large_world_drivers(emu):

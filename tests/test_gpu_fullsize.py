@@ -140,6 +140,16 @@ def test_fuzz_goal_mode():
         assert out.returncode == 0 and "120 seeds, 0 failures" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
 
 
+def test_fuzz_literal_loop():
+    """the reference's own loops on one lane of the device (k_step_serial), in random games of every kind (turn_mode in 60 % of them):
+    groups that are given actions twice before a step (FUZZ_TWICE=1), goals that are given actions and move (FUZZ_GOALS_ACT=1); HIP == oracle"""
+    for extra in ({"FUZZ_TWICE": "1"}, {"FUZZ_GOALS_ACT": "1"}):
+        env = H.merge_env(os.environ, {"OMP_NUM_THREADS": "1", "FUZZ_TURN": "1"}, extra)
+        out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "150"], env=env,
+                             capture_output=True, text=True, timeout=1500)
+        assert out.returncode == 0 and "150 seeds, 0 failures" in out.stdout, (extra, out.stdout[-3000:], out.stderr[-2000:])
+
+
 def test_fuzz_fused_cycle():
     """random games (40 % of them turn_mode) with the HIP leg driven through env_cycle_many -- a whole environment cycle in two
     launches: set_action, step, rewards, clear_dead and the next minimap inside k_step_solo -- against the oracle driven through the

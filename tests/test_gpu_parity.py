@@ -79,6 +79,17 @@ def test_render_text_dump_matches_reference(tmp_path):
         assert got[name] == want[name], name
 
 
+def test_render_text_dump_with_repeated_set_action(tmp_path):
+    """the same with a group that is given actions twice before every other step: the attack events of the literal loop (k_step_serial)
+    in the shuffled list's order, byte-identical to the reference's dump (tests/golden/render_battle16_twice)"""
+    got = H.render_episode(H.HIP_LIB, str(tmp_path), twice=True)
+    gold_dir = os.path.join(H.GOLDEN_DIR, "render_battle16_twice")
+    want = {name: open(os.path.join(gold_dir, name), "rb").read() for name in sorted(os.listdir(gold_dir))}
+    assert sorted(got) == sorted(want)
+    for name in want:
+        assert got[name] == want[name], name
+
+
 @pytest.mark.parametrize("block", range(4))
 def test_fuzz_random_games(block, oracle):
     """differential fuzzing (tests/helpers.fuzz_scenario): random in-scope games -- group count, body sizes, ranges,

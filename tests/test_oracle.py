@@ -117,6 +117,18 @@ def test_oracle_goal_mode_matches_compiled_reference(monkeypatch):
 
 
 @pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) not present")
+@pytest.mark.parametrize("knob", ["FUZZ_TWICE", "FUZZ_GOALS_ACT"])
+def test_oracle_literal_loop_cases_match_compiled_reference(monkeypatch, knob):
+    """groups given actions twice before a step (GridWorld.cc:403-454 appends) and goals given actions (they move, Map.cc:313-358) in random
+    games, 60 % of them turn_mode"""
+    monkeypatch.setenv(knob, "1")
+    monkeypatch.setenv("FUZZ_TURN", "1")
+    for seed in range(60):
+        sc = H.fuzz_scenario(seed)
+        H.assert_same(H.run(sc, H.REF_LIB), H.run(sc, ORACLE), sc.name)
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) not present")
 def test_oracle_rule_search_matches_compiled_reference(monkeypatch):
     """random rule expressions over 'any' / 'all' / fixed-index symbols, in_a_line, several iterated symbols (FUZZ_RULES=2): the
     restated recursive search (RewardEngine.cc:216-443), the reference's Agent::index quirk included

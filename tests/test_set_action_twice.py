@@ -2,9 +2,9 @@
 
 GridWorld::set_action appends to the step's action lists (/root/reference/src/gridworld/GridWorld.cc:403-454): every agent of
 such a group acts once per call -- two entries in the shuffled attack list, two moves in list order, the second from wherever
-the first one ended; `last_action` is the latest call's.  Rounds 1-2 refused this; the engine now serves it with the
+the first one ended; `last_action` is the latest call's.  Rounds 1-2 refused this; the engine serves it with the
 reference's own sequential loops on one lane of the device (k_step_serial: exact by construction, slow, taken only when it
-happens).  Pinned three ways: compiled reference == oracle (here, when oracle/_ref is present), oracle == the HIP sources on
+happens) -- for one-cell bodies since round 3, for every game since round 4.  Pinned three ways: compiled reference == oracle (here, when oracle/_ref is present), oracle == the HIP sources on
 the emulator (here), oracle == the HIP engine (GPU)."""
 import numpy as np
 import pytest
@@ -74,15 +74,48 @@ def test_repeated_set_action_on_the_gpu(world):
                       "oracle vs HIP engine, pattern %d" % pi)
 
 
+# every game family the reference plays: bodies larger than one cell, turn_mode, food_mode, goals (given actions too: they move), sector
+# ranges, kill_supply, three groups -- the scenarios' own configurations and placements, their groups given actions by PATTERNS
+GAMES = ["bodies", "bodies_turn", "battle_food", "bodies_food", "arrange_live", "sector_turn", "duo", "pursuit_dense", "tri_turn", "battle_turn"]
+
+
+def play_scenario(lib, name, steps, seed, pattern):
+    sc = H.scenarios()[name]
+    env, hs = sc.build(lib)
+    rs = np.random.RandomState(seed)
+    out = []
+    for step in range(steps):
+        rec = {}
+        order = [g % len(hs) for g in pattern[step % len(pattern)]] + ([2] if len(hs) > 2 and step % 2 else [])
+        for g in order:
+            env.set_action(hs[g], rs.randint(env.get_action_space(hs[g])[0], size=env.get_num(hs[g])).astype(np.int32))
+        rec["done"] = np.array([env.step()])
+        for gg, hh in enumerate(hs):
+            rec["reward%d" % gg] = env.get_reward(hh)
+            rec["alive%d" % gg] = env.get_alive(hh).astype(np.uint8)
+            rec["pos%d" % gg] = env.get_pos(hh)
+        if step % 3 != 2:
+            env.clear_dead()
+        for gg, hh in enumerate(hs):
+            if env.get_num(hh):
+                rec["view%d" % gg], rec["feat%d" % gg] = [a.copy() for a in env.get_observation(hh)]
+        out.append(rec)
+    return out
+
+
+@pytest.mark.parametrize("name", GAMES)
+def test_repeated_set_action_in_every_game(name):
+    emu = H.ensure_emu()
+    for pi, pat in enumerate(PATTERNS[1:]):
+        want = play_scenario(H.ensure_oracle(), name, 7, 11 + pi, pat)
+        if H.have_ref():
+            H.assert_same(play_scenario(H.REF_LIB, name, 7, 11 + pi, pat), want, "%s: reference vs oracle, pattern %d" % (name, pi))
+        H.assert_same(want, play_scenario(emu, name, 7, 11 + pi, pat), "%s: oracle vs emulated kernels, pattern %d" % (name, pi))
+
+
 @pytest.mark.gpu
-def test_repeated_set_action_is_still_refused_where_the_serial_step_does_not_reach():
-    """bodies larger than one cell (pursuit's predators): a clear message and an abort, not an approximation"""
-    import subprocess, sys
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import numpy as np, helpers as H\n"
-            "env = H.gridworld('pursuit', lib=H.HIP_LIB, map_size=30); env.reset(); hs = env.get_handles()\n"
-            "for h in hs: env.add_agents(h, 'random', n=10)\n"
-            "a = np.zeros(10, dtype=np.int32)\n"
-            "env.set_action(hs[0], a); env.set_action(hs[0], a)\n") % (H.ROOT, H.ROOT + "/tests")
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert p.returncode != 0 and "one-cell bodies" in p.stderr
+@pytest.mark.parametrize("name", GAMES + ["bodies_large", "sector_turn_large", "arrange_large"])
+def test_repeated_set_action_in_every_game_on_the_gpu(name):
+    for pi, pat in enumerate(PATTERNS[1:]):
+        H.assert_same(play_scenario(H.ensure_oracle(), name, 5, 11 + pi, pat), play_scenario(H.HIP_LIB, name, 5, 11 + pi, pat),
+                      "%s: oracle vs HIP engine, pattern %d" % (name, pi))

@@ -6,6 +6,8 @@ run MAGENT_TUNE=solo_step=0 python tools/fuzz_parity.py oracle hip 1200 2000
 run MAGENT_TUNE=solo_step=0,scan_solo_max=64 python tools/fuzz_parity.py oracle hip 2000 2600
 run FUZZ_TURN=2 python tools/fuzz_parity.py oracle hip 0 500
 run FUZZ_GOAL=1 python tools/fuzz_parity.py oracle hip 0 300
+run FUZZ_TWICE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 300
+run FUZZ_GOALS_ACT=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 400
 run FUZZ_RULES=2 python tools/fuzz_parity.py oracle hip 0 400
 run FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 500
 run FUZZ_BATCH=3 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 200
