@@ -331,15 +331,14 @@ __global__ void __launch_bounds__(256) k_plain_rank(WorldView W, PlainWorld PW, 
     unsigned key = G.key[i];          // a move's order key -- or, from the one-workgroup set_action, the attack's sequence number
     int tgt = -1, t = -1;
     if (!dead && att) {
-        const int k = pend & PEND_ARG;
-        const int2 d = W.delta[T.attack_off + k];
-        const int tx = x + d.x, ty = y + d.y;
-        const bool on_map = tx >= 0 && tx < W.w && ty >= 0 && ty < W.h;
-        const int o = on_map ? W.occ[ty * W.w + tx] : OCC_EMPTY;             // (requested before the chase below: the two chains overlap)
         // the attack's rank in the shuffled list: the chase of its own list entry (k_shuffle_chase's walk, by the agent itself -- no rank
         // array, one launch less); the lists are read-only in this launch and go back to zero in round 1 of k_plain_eval
         key = (unsigned)shuffle_chase_pos(seq >= 0 ? seq : (int)key, A, B.j, B.head, B.first, B.link);
-        {
+        const int k = pend & PEND_ARG;
+        const int2 d = W.delta[T.attack_off + k];
+        const int tx = x + d.x, ty = y + d.y;
+        if (tx >= 0 && tx < W.w && ty >= 0 && ty < W.h) {
+            const int o = W.occ[ty * W.w + tx];
             if (o >= 0 && (T.attack_in_group || ref_group(o) != g)) {       // Map::get_attack_obj (Map.cc:229-247)
                 tgt = o;
                 const PlainGroup TG = ptab[ref_group(o)];
@@ -372,7 +371,9 @@ __global__ void __launch_bounds__(256) k_plain_eval(WorldView W, PlainWorld PW, 
     if (A == 0) return;
     // the shuffle's list heads and first-hit words have been read for the last time (k_plain_rank): back to zero for their next use
     if (round == 1)
-        for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < A; k += gridDim.x * gridDim.y * blockDim.x) { shuf_head[k] = 0; shuf_first[k] = 0; }
+        for (int k = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; k < A; k += gridDim.x * gridDim.y * blockDim.x) {
+            shuf_head[k] = 0; shuf_first[k] = 0;
+        }
     // nobody's death rank changed in the round before: nobody is stamped for this one
     if (round > 1 && prev_changed == 0) return;
     extern __shared__ unsigned s_hit[];
