@@ -36,6 +36,7 @@ MAP_SIZE = 1000
 N_PER_GROUP = 400000
 WORKLOAD = "battle 1000x1000, 2x400k agents, random placement (C3(i): 2x500k does not fit 996,004 cells), random actions"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+EVENT_EVERY = 4         # timed region: the dominant kernel's launches of every 4th step carry HIP events (see measure / one_step)
 
 
 def cpu_baseline_worker(args):
@@ -381,6 +382,7 @@ def main():
                          "cell) -- a secondary reading; the headline stays on the reference's float32 tensors")
     ap.add_argument("--extra-timeout", type=int, default=300, help="N > 1: seconds the config-4 gather extra may take before the line is printed without it")
     ap.add_argument("--repeats", type=int, default=5, help="identical timed regions of --steps steps; the median one is reported")
+    ap.add_argument("--event-every", type=int, default=EVENT_EVERY, help="timed region: HIP events around the render launches of every N-th step (1: all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (capacity fill, test_1m, small worlds)")
@@ -483,16 +485,24 @@ def main():
         rendered = {"view": 0, "feat": 0, "launches": 0}
         step_ends = []
 
+        sampling = {"on": False}
+
         def one_step(s):
             n_now = 0
+            # inside the timed region the render launches of every EVENT_EVERY-th step carry a HIP event pair (a pair drains the stream: ~5 us
+            # each, measured 9-10 us per step with every launch timed); `rendered` counts the bytes of exactly those launches
+            timed = (not sampling["on"]) or (s - warmup) % max(1, args.event_every) == 0
+            if sampling["on"]:
+                env.profile_enable(2 if timed else 0)
             for g, h in enumerate(handles):
                 if g not in acting:
                     continue
                 n = env.get_num(h)
                 n_now += n
-                rendered["view"] += n * view_bytes[g]
-                rendered["feat"] += n * feat_bytes[g]
-                rendered["launches"] += 1
+                if timed:
+                    rendered["view"] += n * view_bytes[g]
+                    rendered["feat"] += n * feat_bytes[g]
+                    rendered["launches"] += 1
                 view = views[g][s % n_buf]
                 if gathers and args.backend == "nccl":   # the exchange of step t-1 may still read the tensor this render overwrites
                     gathers[g].release(view, env.stream)
@@ -527,6 +537,7 @@ def main():
             # inside the timed region only the dominant kernel carries HIP events (an event pair costs ~10 us of stream time;
             # timing every phase of every step would add ~10 % to the step); the phase breakdown is taken afterwards
             env.profile_enable(2)
+            sampling["on"] = True
             for name in ("render", "features", "paint", "minimap", "attack", "move", "turn", "set_action", "step", "rules", "clear_dead"):
                 env.profile_read(name)
         rendered["view"] = rendered["feat"] = rendered["launches"] = 0
@@ -553,6 +564,7 @@ def main():
 
         res = {"elapsed": elapsed, "agent_steps": agent_steps, "median_ms": median_ms, "n0": n0, "agents_at_end": [env.get_num(h) for h in handles],
                "host_finished_steps": env.engine_stats()[0], "attack_round_hist": list(env.round_hist()), "cycles_run": total_steps, "roofline": None, "breakdown": {}, "map_size": map_size}
+        sampling["on"] = False
         if profile:
             n_launch, ms = env.profile_read("render")
             n_feat, ms_feat = env.profile_read("features")
@@ -575,7 +587,8 @@ def main():
                 kname = {0: "k_render_cells16" if bf16 else "k_render", 1: "k_render_fast", 4: "k_render_sweep2"}.get(env.engine_stats()[6], "k_render")
                 res["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_scaled_from_profiles_not_this_run": traffic_note,
-                                   "launches": n_launch, "avg_launch_ms": round(ms / n_launch, 4),
+                                   "launches": n_launch, "launches_note": "HIP events around the render launches of every %d-th step of the timed region" % max(1, args.event_every),
+                                   "avg_launch_ms": round(ms / n_launch, 4),
                                    "algorithmic_bytes_per_launch": int(obs_bytes / n_launch)}
             # phase breakdown: a few more steps of the same episode, OUTSIDE the timed region, with an event pair around every phase
             extra = 5
@@ -590,7 +603,7 @@ def main():
             res["breakdown"]["note"] = "%d extra steps after the timed region" % extra
             env.profile_read("render"); env.profile_read("features")
             if res["roofline"]:
-                res["breakdown"]["render_ms_per_step"] = round(ms / steps, 4)
+                res["breakdown"]["render_ms_per_step"] = round(ms / n_launch * len(acting), 4)
             env.profile_enable(False)
         if gathers:
             res["gather"] = {"mode": gathers[acting[0]].mode, "payload_bytes_sent_per_step": sum(gathers[g].bytes_sent for g in acting),

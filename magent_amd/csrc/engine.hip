@@ -1572,7 +1572,7 @@ void Env::move_rounds_checked(const WorldView &W) {
 
 void Env::phase_tail(const WorldView &W, int from /* 0 = after attack rounds, 1 = after move rounds */) {
     if (step_was_plain) {              // (only its attack rounds can run out: from == 0)
-        launch_plain_tail(stream, W, plain_view(), d_ptab, d_gtab, d_ttab, step_fused_rules ? rule_args.data() : nullptr, (int)rule_args.size());
+        launch_plain_tail(stream, W, plain_view(), d_ptab, d_gtab, d_ttab, step_fused_rules ? rule_args.data() : nullptr, (int)rule_args.size(), nullptr, 0);
         if (!step_fused_rules && !rules_on_host) launch_rules(stream, W, rule_args.data(), (int)rule_args.size(), rule_progs.data(), d_gtab);
         return;
     }
@@ -1662,6 +1662,7 @@ void Env::step_begin() {
     step_was_solo = false;
     step_was_plain = false;
 
+    bool reported = false;      // (the plain pipeline with fused rules sends its report ahead of the moves)
     const bool beside = total_n > 0 && fast && side_wanted() && overlap_level >= 2 && !serial_calls_on;   // the read-only head of the step goes beside the renders
     if (!beside) join_side();
     step_calls.clear();
@@ -1737,7 +1738,11 @@ void Env::step_begin() {
             const bool fuse = step_fused_rules = !rules_on_host && !stale_events && fused_rules(rule_args.data(), (int)rule_args.size());
             {
                 ProfScope p(*this, "move");
-                launch_plain_tail(stream, W, PW, d_ptab, d_gtab, d_ttab, fuse ? rule_args.data() : nullptr, (int)rule_args.size());
+                // (with the rules fused -- or none -- nothing the report carries is decided behind k_strike: it goes out before the moves)
+                static const bool early = tune("early_report", 1) != 0;          // (MAGENT_TUNE early_report=0: behind the moves, for A/B runs)
+                reported = fuse && early;
+                launch_plain_tail(stream, W, PW, d_ptab, d_gtab, d_ttab, fuse ? rule_args.data() : nullptr, (int)rule_args.size(),
+                                  reported ? h_rec : nullptr, reported ? ++step_seq : 0);
             }
             if (!fuse && !rules_on_host) {
                 ProfScope p(*this, "rules");
@@ -1767,7 +1772,7 @@ void Env::step_begin() {
             if (any_multicell) launch_finish(stream, W);
         }
         }
-        launch_step_report(stream, d_counters, h_rec, ++step_seq, (int)groups.size());
+        if (!reported) launch_step_report(stream, d_counters, h_rec, ++step_seq, (int)groups.size());
     } else {
         // ---------------- checked driver
         scratch_for(2);

@@ -152,7 +152,7 @@ void launch_plain_rank(hipStream_t s, const WorldView &W, const PlainWorld &PW, 
 void launch_plain_eval(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, int round, int flag,
                        const ShuffleBufs &B);
 void launch_plain_tail(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab,
-                       const RuleArgs *rules /* null: not fused */, int n_rules);
+                       const RuleArgs *rules /* null: not fused */, int n_rules, StepRecord *rec /* non-null: the step's report goes out before the moves */, int seq);
 void launch_food_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag);
 void launch_attack_events(hipStream_t s, const WorldView &W, int4 *ev);
 void launch_move_prep(hipStream_t s, const WorldView &W, const GroupDev *gtab);   // starve / recover, then the move candidates

@@ -1124,7 +1124,7 @@ void launch_shuffle_draw(hipStream_t s, int n_max, int *counters, const ShuffleB
     hipLaunchKernelGGL(k_shuffle_draw, dim3((n_max + 255) / 256), dim3(256), 0, s, counters, B.j, B.head, B.first, B.link, (unsigned *)nullptr, (size_t)0, powtab, tiled ? 1 : 0);
 }
 void launch_plain_tail(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab,
-                       const RuleArgs *rules, int n_rules) {
+                       const RuleArgs *rules, int n_rules, StepRecord *rec, int seq) {
     StrikeRules R{};
     if (rules) {
         R.n = n_rules;
@@ -1135,6 +1135,10 @@ void launch_plain_tail(hipStream_t s, const WorldView &W, const PlainWorld &PW, 
     }
     dim3 g = grid_all(W, 256);
     hipLaunchKernelGGL(k_strike, g, dim3(256), 0, s, W, PW, ptab, gtab, ttab, R);
+    // the step's report BEFORE the moves, when nothing it carries is decided by them (deaths, rule triggers of the fused rules, the
+    // generator: all known once k_strike is through; `collide` rules are not fused): the host's `done` is on its way while k_plain_commit runs,
+    // and the caller's next launches (rewards, clear_dead) queue up behind it instead of finding the device idle
+    if (rec) hipLaunchKernelGGL(k_step_report, dim3(1), dim3(64), 0, s, W.counters, rec, seq, W.G);
     hipLaunchKernelGGL(k_plain_commit, g, dim3(256), 0, s, W, PW);
 }
 

@@ -15,6 +15,7 @@
 //   render=0|1|4        force k_render | k_render_fast | k_render_sweep2;  render_sweep=N workgroups, render_su=1..3 strips, render_depth=1..3
 //   att_threads=64|128|256   workgroup size of k_attack_eval
 //   policy_grid=N       workgroups of k_dqn_conv (tests: a few workgroups walk many tiles);  policy_stamps=1: per-phase cycle stamps
+//   early_report=0      the plain pipeline's step report behind the moves instead of ahead of them (A/B of the early `done`)
 //   batch_cycle=0       env_cycle_many runs its environments one after another instead of in one pair of launches
 #pragma once
 #include <cstdio>
@@ -26,7 +27,7 @@ namespace magent_amd {
 inline int tune(const char *key, int dflt) {
     static const char *const known[] = {"checked_step", "host_shuffle", "attack_pairs", "move_batches", "solo_step", "solo_max", "scan_solo_max", "overlap",
                                         "fold_minimap", "render", "render_sweep", "render_su", "render_depth", "att_threads", "policy_grid", "policy_stamps",
-                                        "batch_cycle"};
+                                        "batch_cycle", "early_report"};
     const char *s = std::getenv("MAGENT_TUNE");
     if (!s || !*s) return dflt;
     static bool checked = false;

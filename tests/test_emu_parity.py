@@ -139,7 +139,7 @@ def test_emulated_fused_step_of_plain_games(emu):
              "battle_no_clear,battle_tiny,gather,gather_largemap,battle_lowhp,quad,trans,chase,battle_events,battle_grow,rules_search,battle_epochs,battle_goal_mode")
     names = [n for n in plain.split(",") if n in H.scenarios()]
     assert len(names) == 21
-    for extra in ({"HIPEMU_SCRAMBLE": "5"}, {"MAGENT_TUNE": "attack_pairs=0", "HIPEMU_SCRAMBLE": "8"}):
+    for extra in ({"HIPEMU_SCRAMBLE": "5"}, {"MAGENT_TUNE": "attack_pairs=0,early_report=0", "HIPEMU_SCRAMBLE": "8"}):
         p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"EMU_SCENARIOS": ",".join(names)}, base, extra), capture_output=True, text=True,
                            timeout=1500)
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])

@@ -94,6 +94,7 @@ VARIANTS = {
     "host_shuffle": {"MAGENT_TUNE": "host_shuffle=1"},
     "multi_launch_step": {"MAGENT_TUNE": "solo_step=0"},
     "multi_launch_side_stream": {"MAGENT_TUNE": "solo_step=0,overlap=3"},   # set_action and the head of the step beside the renders
+    "multi_launch_late_report": {"MAGENT_TUNE": "solo_step=0,early_report=0"},   # the plain pipeline's report behind the moves (default: ahead of them)
     # the battle-shaped render kernels forced on small worlds (defaults: k_render_sweep2 only at scale, k_render_fast only for bf16 cells)
     "render_fast": {"MAGENT_TUNE": "render=1"},
     "render_sweep": {"MAGENT_TUNE": "render=4,render_sweep=5"},
