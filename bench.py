@@ -411,14 +411,22 @@ def main():
         local_rank %= torch.cuda.device_count()   # dry run: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the tiny timing reductions live
+    # The replicas share nothing on the data path, so the job's control plane -- the barriers around the timed region, the MAX / SUM of the
+    # ranks' times and counts, the digests of --check-gather -- runs over gloo on CPU tensors whatever --backend says: the headline then
+    # does not depend on a collective library that this code has never met on more than one GPU.  --backend names the DATA plane: the
+    # exchange of the observation shards (replicas.ObservationGather), over a group of its own -- RCCL over xGMI by default -- that is
+    # created where the first gather is asked for (inside the watchdog of extra.c4_gather_rccl on the default run).
+    red_dev = torch.device("cpu")
+    data_group = {"g": None}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        dist.init_process_group("gloo")
     from magent_amd import replicas
+
+    def gather_group():
+        if args.backend == "nccl" and data_group["g"] is None:
+            data_group["g"] = dist.new_group(backend="nccl")      # (every rank passes here together: measure() is called in lockstep)
+        return data_group["g"]
 
     def measure(workload, map_size, agents, steps, warmup, profile, gather="none", seed=12345 + rank, check_gather=False):
         """K timed steps of `workload`; returns the fields of the bench line that depend on the run"""
@@ -476,7 +484,7 @@ def main():
         gathers = None
         if gather != "none" and world > 1:   # the north star's batched-observation gather: every replica's view tensor to every rank
             gdev = dev if args.backend == "nccl" else torch.device("cpu")
-            gathers = [replicas.ObservationGather(vss[g], capacity=n0[g], device=gdev, mode="padded" if gather == "obs-padded" else "exact")
+            gathers = [replicas.ObservationGather(vss[g], capacity=n0[g], device=gdev, mode="padded" if gather == "obs-padded" else "exact", group=gather_group())
                        if g in acting else None for g in range(G)]
         staged = [torch.empty((n0[g],) + vss[g], dtype=torch.float32).pin_memory() if gathers and args.backend != "nccl" and g in acting else None
                   for g in range(G)]
@@ -690,7 +698,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOAD if is_default else names[args.workload],
                        "envs": world, "parallelism": "replicas x%d" % world, "gather": args.gather,
-                       "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": (args.backend if world > 1 else None),
+                       "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                       "backend": (("control plane gloo; observation gather: " + ("RCCL (nccl)" if args.backend == "nccl" else "gloo")) if world > 1 else None),
                        "agents_at_start": R["n0"], "agents_at_end": R["agents_at_end"],
                        "io": "device-resident (env_*_device C-ABI)", "steps_finished_by_host_driver": R["host_finished_steps"],
                        "host_driver_rate": R["host_finished_steps"] / float(R["cycles_run"]),

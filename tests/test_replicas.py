@@ -262,3 +262,33 @@ def test_one_rank_process_group_on_rccl():
         dist.destroy_process_group()
         for k in ("MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
             os.environ.pop(k, None)
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_data_group_under_a_gloo_control_plane():
+    """what bench.py --gpus N sets up: the job's control plane (barriers, timing reductions) on gloo, the observation exchange on a group of
+    its own created with backend nccl (= RCCL) -- one rank of it: the 1-GPU box cannot hold two.  The data group's collectives run on
+    device tensors, the default group's on CPU tensors, side by side in one process."""
+    assert not dist.is_initialized()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from magent_amd import replicas
+        data = dist.new_group(backend="nccl")
+        assert dist.get_backend() == "gloo" and dist.get_backend(data) == "nccl"
+        g = replicas.ObservationGather((13, 13, 7), capacity=64, device=dev, group=data)
+        view = torch.rand(64, 13, 13, 7, device=dev)
+        shards, counts = g.gather(view, 41)
+        x = torch.ones(1 << 16, device=dev)
+        dist.all_reduce(x, group=data)                                  # a collective of the data group on device memory
+        t = replicas.max_over_replicas(2.5, device=torch.device("cpu"))  # the control plane on CPU memory
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert counts == [41] and torch.equal(shards[0], view[:41]) and t == 2.5 and float(x.sum()) == float(1 << 16)
+    finally:
+        dist.destroy_process_group()
+        for k in ("MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
