@@ -280,7 +280,7 @@ Env::~Env() {
     (void)hipStreamSynchronize(stream);
     for (auto &g : groups) free_group(g);
     dfree(arena, d_occ); dfree(arena, d_viewcell); dfree(arena, d_claim); dfree(arena, d_food); dfree(arena, d_powtab); dfree(arena, d_counters); dfree(arena, d_gtab); dfree(arena, d_ttab);
-    dfree(arena, d_delta); dfree(arena, d_mask); dfree(arena, d_mini); dfree(arena, d_minif); dfree(arena, d_sums); dfree(arena, d_rank); dfree(arena, d_shuf); dfree(arena, d_events); dfree(arena, d_actions);
+    dfree(arena, d_delta); dfree(arena, d_mask); dfree(arena, d_mini); dfree(arena, d_minif); dfree(arena, d_sums); dfree(arena, d_rank); dfree(arena, d_shuf); dfree(arena, d_events); dfree(arena, serial_alist); dfree(arena, serial_mlist); dfree(arena, serial_dcalls); dfree(arena, d_actions);
     dfree(arena, d_stage_view); dfree(arena, d_stage_feat); dfree(arena, d_stage_small);
     dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d); dfree(arena, d_asums); dfree(arena, d_wpre); dfree(arena, d_ptab); dfree(arena, d_alive);
     if (batch_h) (void)hipHostFree(batch_h);
@@ -1442,12 +1442,12 @@ void Env::serial_step() {
     WorldView W = view();
     size_t entries = 0;
     for (auto &c : serial_calls) entries += (size_t)groups[c.g].n;
-    int2 *alist = nullptr; int4 *mlist = nullptr, *msorted = nullptr, *events = nullptr; SerialCall *d_calls = nullptr;
-    HIP_OK(dev_malloc(arena, &events, sizeof(int4) * (entries + 1)));
-    HIP_OK(dev_malloc(arena, &alist, sizeof(int2) * (entries + 1)));
-    HIP_OK(dev_malloc(arena, &mlist, sizeof(int4) * (entries + 1)));
-    HIP_OK(dev_malloc(arena, &msorted, sizeof(int4) * (entries + 1)));
-    HIP_OK(dev_malloc(arena, &d_calls, sizeof(SerialCall) * serial_calls.size()));
+    // (the lists' scratch is kept from one such step to the next; the attack events share the array of the checked driver's)
+    grow(arena, d_events, events_cap, entries + 1, stream);
+    grow(arena, serial_alist, serial_alist_cap, entries + 1, stream);
+    grow(arena, serial_mlist, serial_mlist_cap, 2 * (entries + 1), stream);
+    grow(arena, serial_dcalls, serial_dcalls_cap, serial_calls.size(), stream);
+    int2 *alist = serial_alist; int4 *mlist = serial_mlist, *msorted = serial_mlist + (entries + 1), *events = d_events; SerialCall *d_calls = serial_dcalls;
     HIP_OK(hipMemcpyAsync(d_calls, serial_calls.data(), sizeof(SerialCall) * serial_calls.size(), hipMemcpyHostToDevice, stream));
     const int n_sep = large_map_mode ? (width + bandwidth - 1) / bandwidth : 0;
     if (n_sep >= 39) fatal("internal: too many move stripes for the serial step");
@@ -1463,7 +1463,6 @@ void Env::serial_step() {
         attack_events.clear();
         for (const int4 &e : ev) if (e.w) attack_events.push_back({e.x, e.y, e.z});
     }
-    dfree(arena, events); dfree(arena, alist); dfree(arena, mlist); dfree(arena, msorted); dfree(arena, d_calls);
     for (auto &c : serial_calls) if (c.actions) { int *buf = const_cast<int *>(c.actions); dfree(arena, buf); }
     serial_calls.clear();
     serial_calls_on = false;

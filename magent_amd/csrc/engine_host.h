@@ -264,6 +264,8 @@ private:
     struct AttackEvent { int id, x, y; };
     std::vector<AttackEvent> attack_events;
     int4 *d_events = nullptr; size_t events_cap = 0;
+    int2 *serial_alist = nullptr; int4 *serial_mlist = nullptr; SerialCall *serial_dcalls = nullptr;   // scratch of the literal loop (serial_step)
+    size_t serial_alist_cap = 0, serial_mlist_cap = 0, serial_dcalls_cap = 0;
     void gen_render_config();
     MinStd rng;
     std::map<std::string, HostType> types;
