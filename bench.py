@@ -36,6 +36,7 @@ MAP_SIZE = 1000
 N_PER_GROUP = 400000
 WORKLOAD = "battle 1000x1000, 2x400k agents, random placement (C3(i): 2x500k does not fit 996,004 cells), random actions"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+PREHEAT_MS = 40.0       # per region, before the warm-up steps: back-to-back renders of step 0's observation (see measure)
 EVENT_EVERY = 4         # timed region: the dominant kernel's launches of every 4th step carry HIP events (see measure / one_step)
 
 
@@ -383,6 +384,8 @@ def main():
     ap.add_argument("--extra-timeout", type=int, default=300, help="N > 1: seconds the config-4 gather extra may take before the line is printed without it")
     ap.add_argument("--repeats", type=int, default=5, help="identical timed regions of --steps steps; the median one is reported")
     ap.add_argument("--event-every", type=int, default=EVENT_EVERY, help="timed region: HIP events around the render launches of every N-th step (1: all)")
+    ap.add_argument("--preheat-ms", type=float, default=PREHEAT_MS,
+                    help="milliseconds of untimed render launches before the warm-up steps of every region: the device's sustained state (see measure); 0: none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (capacity fill, test_1m, small worlds)")
@@ -538,6 +541,24 @@ def main():
             step_ends.append(time.perf_counter())
             return n_now
 
+        # Before the W warm-up steps: the device itself is brought to its sustained state.  Every region starts behind the host-side
+        # construction of a fresh world (the device idles for half a second), and the first ~10 ms of GPU work after that run in a transient of
+        # the device's power management: by kernel timestamps the same render launch takes 0.32 -> 0.38 -> 0.32 ms over the first dozen launches,
+        # whatever the actions, and settles at 0.29-0.30 (profiles/r04_summary.md, "The first milliseconds").  So the observation of step 0 is
+        # rendered again and again for --preheat-ms of wall time -- the episode does not advance, nothing of it is timed -- and the W warm-up
+        # steps and the K timed steps then see the device as a long-running job sees it.
+        preheat_launches = 0
+        if args.preheat_ms > 0 and acting and env.get_num(handles[acting[0]]) > 0:
+            g0 = acting[0]
+            t_heat = time.perf_counter()
+            while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
+                for _ in range(16):
+                    if bf16:
+                        env.get_observation_device_bf16(handles[g0], views[g0][0], feats[g0])
+                    else:
+                        env.get_observation_device(handles[g0], views[g0][0], feats[g0])
+                env.sync()
+                preheat_launches += 16
         for s in range(warmup):
             one_step(s)
         env.sync()
@@ -571,7 +592,7 @@ def main():
         median_ms = per_step[len(per_step) // 2] * 1e3 if per_step else None
 
         res = {"elapsed": elapsed, "agent_steps": agent_steps, "median_ms": median_ms, "n0": n0, "agents_at_end": [env.get_num(h) for h in handles],
-               "host_finished_steps": env.engine_stats()[0], "attack_round_hist": list(env.round_hist()), "cycles_run": total_steps, "roofline": None, "breakdown": {}, "map_size": map_size}
+               "host_finished_steps": env.engine_stats()[0], "preheat_launches": preheat_launches, "attack_round_hist": list(env.round_hist()), "cycles_run": total_steps, "roofline": None, "breakdown": {}, "map_size": map_size}
         sampling["on"] = False
         if profile:
             n_launch, ms = env.profile_read("render")
@@ -601,6 +622,7 @@ def main():
             # phase breakdown: a few more steps of the same episode, OUTSIDE the timed region, with an event pair around every phase
             extra = 5
             env.profile_enable(1)
+            before = (rendered["view"], rendered["feat"])
             for s in range(total_steps, total_steps + extra):
                 one_step(s)
             env.sync()
@@ -609,10 +631,39 @@ def main():
                 if k:
                     res["breakdown"][name + "_ms_per_step"] = round(t_ms / extra, 4)
             res["breakdown"]["note"] = "%d extra steps after the timed region" % extra
-            env.profile_read("render"); env.profile_read("features")
+            n2, ms2 = env.profile_read("render")
+            n2f, _ = env.profile_read("features")
             if res["roofline"]:
                 res["breakdown"]["render_ms_per_step"] = round(ms / n_launch * len(acting), 4)
+                if n2 and ms2 > 0:
+                    # the same kernel in the breakdown steps, where EVERY launch of every phase sits between event pairs: each launch starts
+                    # behind a drained stream (the method of the rounds before; ~2 % faster than in the loop's steady state, profiles/r04_summary.md)
+                    b2 = (rendered["view"] - before[0]) + ((rendered["feat"] - before[1]) if n2f == 0 else 0)
+                    res["roofline"]["behind_a_drained_stream"] = {"launches": n2, "avg_launch_ms": round(ms2 / n2, 4),
+                                                                  "achieved": round(b2 / (ms2 * 1e-3) / 1e9, 1), "frac": round(b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                                  "note": "the %d breakdown steps after the timed region: every launch between event pairs" % extra}
             env.profile_enable(False)
+            if res["roofline"] and not gathers:
+                # ... and the kernel ALONE: back-to-back launches of the first acting group's render, nothing in between, by HIP events
+                # (inside the cycle the same launch is 5-10 % slower by plain kernel timestamps too: profiles/r04_summary.md)
+                g0 = acting[0]
+                n_alone = env.get_num(handles[g0])
+                if n_alone > 0:
+                    env.profile_enable(2); env.profile_read("render"); env.profile_read("features")
+                    for _ in range(30):
+                        if bf16:
+                            env.get_observation_device_bf16(handles[g0], views[g0][0], feats[g0])
+                        else:
+                            env.get_observation_device(handles[g0], views[g0][0], feats[g0])
+                    env.sync()
+                    n3, ms3 = env.profile_read("render")
+                    n3f, _ = env.profile_read("features")
+                    env.profile_enable(False)
+                    if n3 and ms3 > 0:
+                        b3 = n3 * n_alone * (view_bytes[g0] + (feat_bytes[g0] if n3f == 0 else 0))
+                        res["roofline"]["kernel_alone"] = {"launches": n3, "agents_per_launch": n_alone, "avg_launch_ms": round(ms3 / n3, 4),
+                                                           "achieved": round(b3 / (ms3 * 1e-3) / 1e9, 1), "frac": round(b3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                           "note": "30 back-to-back launches of the same render after the run, nothing in between"}
         if gathers:
             res["gather"] = {"mode": gathers[acting[0]].mode, "payload_bytes_sent_per_step": sum(gathers[g].bytes_sent for g in acting),
                              "view_buffers": n_buf}
@@ -704,7 +755,10 @@ def main():
                        "io": "device-resident (env_*_device C-ABI)", "steps_finished_by_host_driver": R["host_finished_steps"],
                        "host_driver_rate": R["host_finished_steps"] / float(R["cycles_run"]),
                        # steps of the run by the last round of the death-rank fixed point that still changed something (index; one more round confirms)
-                       "attack_round_hist": R["attack_round_hist"]},
+                       "attack_round_hist": R["attack_round_hist"],
+                       # untimed, before the W warm-up steps of every region: step 0's observation rendered over and over for --preheat-ms, so that
+                       # the region sees the device's sustained state and not the power-management transient of its first milliseconds of work
+                       "preheat": {"ms": args.preheat_ms, "render_launches": R["preheat_launches"]}},
             "roofline": R["roofline"],
             "breakdown": R["breakdown"],
         }

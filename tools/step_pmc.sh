@@ -3,7 +3,7 @@
 # tools/step_pmc_summary.py into profiles/<round>_step_pmc.json.   usage: bash tools/step_pmc.sh <tag> [extra bench args]
 R=$GRAFT_REPO_ROOT; TAG=${1:-steppmc}; shift; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-profile --no-extras $*"
+B="python $R/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-profile --no-extras --preheat-ms 0 $*"
 run() { name=$1; shift; timeout 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$name -o bench -- $B > $O/$name.log 2>&1; echo "$name rc=$?"; }
 run sq     SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM
 run tcc    TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
