@@ -18,7 +18,7 @@ __global__ void k_step_reset(int *counters) {
 // The end-of-step report of the multi-launch step, straight into pinned host memory (the host spins on `seq`: a stream
 // synchronisation behind a device-to-host copy costs several times the PCIe write it waits for), and the per-step counters
 // back to zero -- unless a phase was left open: then the host continues from exactly this state and resets afterwards.
-__global__ void __launch_bounds__(64) k_step_report(int *counters, StepRecord *rec, int seq, int NG) {
+__device__ __forceinline__ void step_report_body(int *counters, StepRecord *rec, int seq, int NG) {      // (one wave: threads 0..63)
     const int tid = threadIdx.x;
     const int oa = counters[CTR_OPEN_ATTACK], om = counters[CTR_OPEN_MOVE];
     const bool open = (oa | om) != 0;
@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(64) k_step_report(int *counters, StepRecord *r
     __threadfence_system();
     if (tid == 0) __hip_atomic_store((int *)&rec->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__global__ void __launch_bounds__(64) k_step_report(int *counters, StepRecord *rec, int seq, int NG) { step_report_body(counters, rec, seq, NG); }
 __global__ void k_set_rng(int *counters, unsigned x) { if (threadIdx.x == 0) counters[CTR_RNG] = (int)x; }
 
 // memset that respects the gate: the claim array still holds the attack phase's hit bits when the host has to continue
@@ -559,7 +560,11 @@ __device__ __forceinline__ unsigned plain_leaves(const WorldView &W, const Plain
         ra = plain_rec(PW, W.G, ref_group(a))[ref_index(a)];
     }
 }
-__global__ void __launch_bounds__(256) k_plain_commit(WorldView W, PlainWorld PW) {
+__global__ void __launch_bounds__(256) k_plain_commit(WorldView W, PlainWorld PW, StepRecord *rec, int seq) {
+    // The step's report rides in the first wave of this launch when nothing it carries is decided by the moves (rec != null: the rules are
+    // fused or there are none): deaths, rule triggers and the generator are final since k_strike -- a launch boundary ago -- and nothing
+    // the report resets is read by this kernel.  The host has `done` while the moves run; its next launches queue up behind them.
+    if (rec && (blockIdx.x | blockIdx.y) == 0 && threadIdx.x < 64) step_report_body(W.counters, rec, seq, W.G);
     const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     const GroupDev &G = W.grp[g];
     if (i >= G.n) return;
@@ -1139,11 +1144,8 @@ void launch_plain_tail(hipStream_t s, const WorldView &W, const PlainWorld &PW, 
     }
     dim3 g = grid_all(W, 256);
     hipLaunchKernelGGL(k_strike, g, dim3(256), 0, s, W, PW, ptab, gtab, ttab, R);
-    // the step's report BEFORE the moves, when nothing it carries is decided by them (deaths, rule triggers of the fused rules, the
-    // generator: all known once k_strike is through; `collide` rules are not fused): the host's `done` is on its way while k_plain_commit runs,
-    // and the caller's next launches (rewards, clear_dead) queue up behind it instead of finding the device idle
-    if (rec) hipLaunchKernelGGL(k_step_report, dim3(1), dim3(64), 0, s, W.counters, rec, seq, W.G);
-    hipLaunchKernelGGL(k_plain_commit, g, dim3(256), 0, s, W, PW);
+    // (rec != null: the step's report goes out from the first wave of the commit's launch -- see k_plain_commit)
+    hipLaunchKernelGGL(k_plain_commit, g, dim3(256), 0, s, W, PW, rec, seq);
 }
 
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {
