@@ -1380,7 +1380,7 @@ void Env::set_action_device(int g, const int *d_act) {
     // a group is given actions again before the step: the reference appends (GridWorld.cc:403-454) -- or goals are given actions, which may
     // move them (Map::do_move treats a goal that has taken nobody in like any mover; the parallel move resolution rests on goals that
     // stand still): either way the step runs the reference's own loops on the device (k_step_serial)
-    if (G.acted || serial_calls_on || G.type->can_absorb) {
+    if (G.acted || serial_calls_on || (G.type->can_absorb && G.n > 0)) {     // (an empty group of goals moves nobody)
         serial_add_call(g, d_act);
         G.acted = true;
         return;
@@ -1994,7 +1994,7 @@ bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, con
     int first_obs = -1;
     if (!cycle_eligible(n_group, view, feat, &first_obs)) return false;
     // goals that are given actions may move: the call sequence (set_action_device sends such a step through the literal loop)
-    for (int g = 0; actions && g < n_group && g < (int)groups.size(); g++) if (actions[g] && groups[g].type->can_absorb) return false;
+    for (int g = 0; actions && g < n_group && g < (int)groups.size(); g++) if (actions[g] && groups[g].type->can_absorb && groups[g].n > 0) return false;
     enter();
     const int NG = (int)groups.size();
     int total_n = 0;
