@@ -231,3 +231,12 @@ def test_committed_bench_line_keeps_the_contract():
     c5 = x["c5_train_round_1m"]
     assert c5["bf16_policy"]["agents"] == [499849, 499849] and "bf16" in c5["bf16_policy"]["policy_dtype"] and c5["f32_policy"]["policy_dtype"].startswith("f32")
     assert x["battle_selfplay_2x400k_f32_policy"]["policy_dtype"] == "f32"
+
+
+def test_bench_command_line_parses_without_a_gpu():
+    """bench.py is the driver's contract: its command line (and with it the whole file) must at least compile and describe itself on the
+    CPU box -- the flags the driver passes (--gpus, --steps, --warmup) and the ones the profiles quote"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    for flag in ("--gpus", "--steps", "--warmup", "--repeats", "--event-every", "--preheat-ms", "--backend", "--gather", "--no-extras"):
+        assert flag in p.stdout, flag
