@@ -367,11 +367,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--map-size", type=int, default=MAP_SIZE)
     ap.add_argument("--agents", type=int, default=N_PER_GROUP, help="agents per group")
-    ap.add_argument("--workload", choices=["battle", "battle_fill", "test_1m", "gather"], default="battle",
+    ap.add_argument("--workload", choices=["battle", "battle_fill", "test_1m", "gather", "battle_c5", "battle_c5_melee"], default="battle",
                     help="battle_fill: SURVEY.md 8d C3(ii), the map filled to capacity by add_agents('fill') (2 x 498,002 at 1000 x 1000; nobody can "
                          "move); test_1m: the reference's own harness (scripts/test/test_1m.py): pursuit-like game, map sqrt(20 N), "
                          "N/10 walls, N/2 prey + N/2 2x2 predators, N = 2 * --agents; "
-                         "gather: BASELINE config 4 (examples/train_gather.py: --agents agents + agents/5 food, only agents act)")
+                         "gather: BASELINE config 4 (examples/train_gather.py: --agents agents + agents/5 food, only agents act); "
+                         "battle_c5: BASELINE config 5's world -- examples/train_battle.py's own generate_map at --map-size (3536: 2 x 499,849 "
+                         "agents on 12.5 M cells), random actions; battle_c5_melee: the same two lattices interleaved (every agent has hostile "
+                         "neighbours at distance 1: the state a self-play episode reaches once the fronts have met)")
     ap.add_argument("--gather", choices=["none", "obs", "obs-padded"], default="none",
                     help="obs: exchange the observation tensors of every replica over RCCL each step (counts first, then sends / receives "
                          "sized by count, on a side stream under the step); obs-padded: one all_gather_into_tensor of capacity rows")
@@ -455,6 +458,15 @@ def main():
             env.add_agents(handles[0], "random", n=agents // 5)
             env.add_agents(handles[1], "random", n=agents)
             acting = [1]
+        elif workload in ("battle_c5", "battle_c5_melee"):   # examples/train_battle.py:15-40 at --map_size `map_size`
+            form = train_battle_formation(map_size)
+            if workload == "battle_c5_melee":               # the right square pushed into the left one: odd columns of the same square
+                (g_l, left), (g_r, right) = form
+                right = right.copy()
+                right[:, 0] += left[0, 0] + 1 - right[0, 0]
+                form = [(g_l, left), (g_r, right)]
+            for g, pos in form:
+                env.add_agents(handles[g], method="custom", pos=pos)
         elif workload == "battle_fill":   # the two halves of the inner map, every cell taken
             half = (map_size - 2) // 2
             env.add_agents(handles[0], "fill", pos=(1, 1), size=(half, map_size - 2))
@@ -730,6 +742,8 @@ def main():
                      R["map_size"], R["map_size"], 2 * args.agents // 10, args.agents, args.agents),
                  "gather": "gather %dx%d (train_gather.py), %d agents + %d food, only the agents act" % (args.map_size, args.map_size, args.agents, args.agents // 5),
                  "battle_fill": "battle %dx%d filled to capacity by add_agents('fill'): %s agents (SURVEY.md 8d C3(ii)), random actions" % (args.map_size, args.map_size, R["n0"]),
+                 "battle_c5": "battle %dx%d, examples/train_battle.py's generate_map formation: %s agents, random actions" % (args.map_size, args.map_size, R["n0"]),
+                 "battle_c5_melee": "battle %dx%d, the two lattices of train_battle.py's formation interleaved: %s agents, random actions" % (args.map_size, args.map_size, R["n0"]),
                  "battle": "battle %dx%d, 2x%d agents, random placement, random actions" % (args.map_size, args.map_size, args.agents)}
         rec = {
             "metric": "agent-steps/sec (step+obs) on battle map; bit-exact vs CPU ref",

@@ -214,14 +214,15 @@ class GridWorld(object):
                 buf = self._dev_cache[which][(g, slot)] = torch.empty((n,) + space, dtype=dtype, device=dev)
             out.append(buf[:n])
         # (the event only covers work queued on the torch stream it was recorded on: a caller that has switched streams since -- a
-        # worker stream, another thread -- gets the full ordering against its CURRENT stream instead)
+        # worker stream, another thread -- is ordered against its CURRENT stream as well, not instead: readers queued on the old
+        # stream still hold this set; ADVICE rounds 3 and 4)
         guard = self._dev_guard.get((g, slot))
         cur = torch.cuda.current_stream(dev)
-        if guard is None or guard[1] != cur.cuda_stream:
-            self.order_after_torch()
-        else:
+        if guard is not None:
             for st in self._streams():
                 st.wait_event(guard[0])
+        if guard is None or guard[1] != cur.cuda_stream:
+            self.order_after_torch()
         if self._obs_bf16:
             self.get_observation_device_bf16(g, out[0], out[1])
         else:
