@@ -154,6 +154,7 @@ constexpr int CTR_CHANGED = 0, CTR_ATTACK = 1, CTR_DEAD = 2 /* unused: see CTR_D
 // movers taken in by goals, per group: dead, but not counted in the reference's dead_ct (Map.cc:345); cleared with CTR_DEAD
 constexpr int CTR_TAKEN = 64, CTR_UNSUPPORTED = 72;
 constexpr int CTR_HIT_OVERFLOW = 74;  // turn_mode: a target collected more hits than its list holds (the list is sized for the worst case otherwise)
+constexpr int CTR_GOALS_ACT = 75;    // scratch of Env::set_action_device: some goal was given an action that is not the zero move
 constexpr int CTR_BAD_ACTION = 73;   // set_action met an action outside [0, n_action): reported at the end of the step (the reference: UB)
 // Deaths are counted in DEAD_SLOTS counters per group, each on its own cache line: device-scope atomics on ONE address
 // serialise at ~15 ns apiece on this part (measured: 4.8k of them cost a 800k-agent step 70 us).  dead_ct of group g =

@@ -960,6 +960,7 @@ void Env::reset() {
     id_counter = 0;
     for (auto &c : serial_calls) if (c.actions) { int *buf = const_cast<int *>(c.actions); dfree(arena, buf); }
     serial_calls.clear(); step_calls.clear(); serial_calls_on = false;
+    alive_valid = false;
     // a fresh episode starts with two pairs of optimistic attack rounds: the first steps of a dense placement hold the deepest
     // dependency chains (measured at 2 x 400k: one pair runs out once in the first few steps, two never did), and a step that runs
     // out costs a host round trip; the budget falls back to one pair after 64 steps that did not need the second
@@ -1142,6 +1143,7 @@ void Env::set_goal(int group, const char *method) {
 void Env::add_agents(int group, int n, const char *method, const int *px, const int *py, const int *pdir) {
     if (!device_ready) fatal("add_agents called before reset");
     enter();
+    alive_valid = false;            // (the groups change: k_strike's survivor counts no longer describe them)
     download_occ();
     std::string m(method);
     auto add_wall = [&](int x, int y) {  // Map::add_wall (Map.cc:108-115)
@@ -1380,7 +1382,25 @@ void Env::set_action_device(int g, const int *d_act) {
     // a group is given actions again before the step: the reference appends (GridWorld.cc:403-454) -- or goals are given actions, which may
     // move them (Map::do_move treats a goal that has taken nobody in like any mover; the parallel move resolution rests on goals that
     // stand still): either way the step runs the reference's own loops on the device (k_step_serial)
-    if (G.acted || serial_calls_on || (G.type->can_absorb && G.n > 0)) {     // (an empty group of goals moves nobody)
+    // ... unless every goal is told to stand still (the zero move): such a call is an ordinary one -- one small launch and one read-back
+    // decide it, against about a microsecond per list entry of the whole world on the literal loop's single lane
+    bool goals_act = G.type->can_absorb && G.n > 0 && !G.acted && !serial_calls_on;     // (an empty group of goals moves nobody)
+    if (goals_act) {
+        enter();
+        int *flag = d_counters + CTR_GOALS_ACT;
+        HIP_OK(hipMemsetAsync(flag, 0, sizeof(int), stream));
+        launch_any_real_action(stream, d_act, G.n, G.tdev, d_delta, flag);
+        int h_flag = 0;
+        read_back(&h_flag, flag, sizeof(int));
+        goals_act = h_flag != 0;
+        static bool told = false;
+        if (goals_act && !told) {
+            told = true;
+            std::fprintf(stderr, "magent-amd: a group of goals (can_absorb) was given actions that move, turn or attack: such steps run the reference's "
+                                 "sequential loops on one lane of the device -- exact, about a microsecond per action of the whole world (INTEGRATION.md)\n");
+        }
+    }
+    if (G.acted || serial_calls_on || goals_act) {
         serial_add_call(g, d_act);
         G.acted = true;
         return;
@@ -1996,6 +2016,7 @@ bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, con
     // goals that are given actions may move: the call sequence (set_action_device sends such a step through the literal loop)
     for (int g = 0; actions && g < n_group && g < (int)groups.size(); g++) if (actions[g] && groups[g].type->can_absorb && groups[g].n > 0) return false;
     enter();
+    alive_valid = false;            // (the one-launch cycle compacts by itself)
     const int NG = (int)groups.size();
     int total_n = 0;
     for (auto &g : groups) total_n += g.n;
@@ -2305,6 +2326,7 @@ void Env::clear_dead() {
     if (any) { h_occ_valid = false; mini_valid = false; }
     for (auto &G : groups) G.indexed = G.n;   // Agent::set_index (GridWorld.cc:655)
     stale_events = false;
+    alive_valid = false;                      // (k_strike's survivor counts describe the arrays as the step left them: consumed)
     if (solo_mini) { mini_valid = true; mini_pop = mini_population(mini_skip); solo_mini = false; }
 }
 

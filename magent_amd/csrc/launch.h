@@ -104,6 +104,7 @@ struct BatchItem {
 struct SerialCall { int g; const int *actions; };
 void launch_step_serial(hipStream_t s, const WorldView &W, const SerialCall *calls, int n_calls, int2 *alist, int4 *mlist, int4 *msorted, int n_sep, int4 *events);
 void launch_pend_to_actions(hipStream_t s, const GroupDev &G, const TypeDev &T, int *out);
+void launch_any_real_action(hipStream_t s, const int *actions, int n, const TypeDev &T, const int2 *delta, int *flag);
 void launch_step_report(hipStream_t s, int *counters, StepRecord *rec, int seq, int NG);
 void launch_commit_action(hipStream_t s, const GroupDev &G, const TypeDev &T);
 void launch_cycle_batch(hipStream_t s, const BatchItem *d_items, int n_env, int slots, int max_blocks, size_t render_lds, size_t step_lds);

@@ -1020,6 +1020,22 @@ __global__ void __launch_bounds__(256) k_pend_to_actions(GroupDev G, TypeDev T, 
 void launch_step_serial(hipStream_t s, const WorldView &W, const SerialCall *calls, int n_calls, int2 *alist, int4 *mlist, int4 *msorted, int n_sep, int4 *events) {
     hipLaunchKernelGGL(k_step_serial, dim3(1), dim3(64), 0, s, W, calls, n_calls, alist, mlist, msorted, n_sep, events);
 }
+// does any of these actions do more than stand still?  (a group of goals that is only ever told to stay where it is steps through the
+// parallel phases like a group that was given no actions; anything else -- a displacement, a turn, an attack, an action outside the space --
+// sends the step through the literal loop: Env::set_action_device)
+__global__ void __launch_bounds__(256) k_any_real_action(const int *actions, int n, TypeDev T, const int2 *delta, int *flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool real = false;
+    if (i < n) {
+        const int a = actions[i];
+        real = true;
+        if (a >= 0 && a < T.n_move) { const int2 d = delta[T.move_off + a]; real = (d.x | d.y) != 0; }
+    }
+    if (__ballot(real) && lane_id() == 0) *flag = 1;
+}
+void launch_any_real_action(hipStream_t s, const int *actions, int n, const TypeDev &T, const int2 *delta, int *flag) {
+    if (n > 0) hipLaunchKernelGGL(k_any_real_action, dim3((n + 255) / 256), dim3(256), 0, s, actions, n, T, delta, flag);
+}
 void launch_pend_to_actions(hipStream_t s, const GroupDev &G, const TypeDev &T, int *out) {
     if (G.n > 0) hipLaunchKernelGGL(k_pend_to_actions, dim3((G.n + 255) / 256), dim3(256), 0, s, G, T, out);
 }

@@ -24,7 +24,28 @@
 
 namespace magent_amd {
 
+// The MAGENT_* variables of rounds 1-3 are gone; a script that still sets one would otherwise run the default path and believe it had not
+// (ADVICE round 4).  Checked once, at the first use of any knob: a removed name aborts with its MAGENT_TUNE equivalent.
+inline void tune_refuse_removed_variables() {
+    static const char *const removed[][2] = {
+        {"MAGENT_CHECKED_STEP", "checked_step"}, {"MAGENT_HOST_SHUFFLE", "host_shuffle"}, {"MAGENT_OPT_ATTACK_PAIRS", "attack_pairs"},
+        {"MAGENT_OPT_MOVE_BATCHES", "move_batches"}, {"MAGENT_SOLO_STEP", "solo_step"}, {"MAGENT_SOLO_MAX", "solo_max"},
+        {"MAGENT_SCAN_SOLO_MAX", "scan_solo_max"}, {"MAGENT_OVERLAP", "overlap"}, {"MAGENT_FOLD_MINIMAP", "fold_minimap"},
+        {"MAGENT_RENDER_FAST", "render"}, {"MAGENT_RENDER_SWEEP", "render_sweep"}, {"MAGENT_RENDER_SU", "render_su"},
+        {"MAGENT_RENDER_DEPTH", "render_depth"}, {"MAGENT_ATT_THREADS", "att_threads"}, {"MAGENT_POLICY_GRID", "policy_grid"},
+        {"MAGENT_BATCH_CYCLE", "batch_cycle"}, {"MAGENT_HIP_POLICY", nullptr}, {"MAGENT_FEAT_SEPARATE", nullptr}, {"MAGENT_RENDER_NT", nullptr},
+        {"MAGENT_RENDER_SPAN", nullptr}, {"MAGENT_RENDER_UNROLL", nullptr}, {"MAGENT_RENDER_PAD", nullptr}, {"MAGENT_RENDER_XCD", nullptr}};
+    for (const auto &r : removed)
+        if (std::getenv(r[0])) {
+            if (r[1]) std::fprintf(stderr, "magent-amd FATAL: the environment variable %s is no longer read: use MAGENT_TUNE=%s=... (magent_amd/csrc/tune.h)\n", r[0], r[1]);
+            else std::fprintf(stderr, "magent-amd FATAL: the environment variable %s is no longer read and has no successor: the knob was removed (magent_amd/csrc/tune.h)\n", r[0]);
+            std::abort();
+        }
+}
+
 inline int tune(const char *key, int dflt) {
+    static const bool legacy_checked = (tune_refuse_removed_variables(), true);
+    (void)legacy_checked;
     static const char *const known[] = {"checked_step", "host_shuffle", "attack_pairs", "move_batches", "solo_step", "solo_max", "scan_solo_max", "overlap",
                                         "fold_minimap", "render", "render_sweep", "render_su", "render_depth", "att_threads", "policy_grid", "policy_stamps",
                                         "batch_cycle", "early_report"};

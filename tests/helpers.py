@@ -312,13 +312,22 @@ class Scenario(object):
                stream continues across reset, GridWorld.cc:72-118)"""
 
     def __init__(self, name, game, map_size, seed=12345, place=(), steps=10, action_seed=0, walls=0,
-                 acting=None, over=None, clear_every=1, obs_every=1, events=None, settings=None, engine=True):
+                 acting=None, over=None, clear_every=1, obs_every=1, events=None, settings=None, engine=True, still=()):
         self.name, self.game, self.map_size, self.seed = name, game, map_size, seed
         self.engine = engine                # False: the engine refuses this game (turn_mode); the oracle is pinned on it all the same
         self.settings = settings or {}      # extra GridWorld settings (food_mode, ...) and, for custom games, type overrides
         self.place, self.steps, self.action_seed, self.walls = list(place), steps, action_seed, walls
         self.acting, self.over, self.clear_every, self.obs_every = acting, over or {}, clear_every, obs_every
         self.events = events or {}
+        self.still = tuple(still)           # groups that are given actions but told to stand still: every move drawn becomes the zero move
+
+    def draw(self, rs, env, g, h, n):
+        """this step's actions of group g: uniform over its action space (one draw from `rs`, whatever `still` says)"""
+        a = rs.randint(env.get_action_space(h)[0], size=n).astype(np.int32)
+        if g in self.still:
+            n_move = env.get_view2attack(h)[0] - (2 if self.settings.get("turn_mode") else 0)
+            a[:] = n_move // 2              # (the move tables are circle ranges: the centre, (0, 0), is the middle entry)
+        return a
 
     def config(self):
         if callable(self.game):
@@ -396,7 +405,7 @@ def run(sc, lib, record=None, device_io=False, env_out=None):
                     rec["view%d" % g], rec["feat%d" % g] = d_view[g][:n].cpu().numpy(), d_feat[g][:n].cpu().numpy()
                 rec["id%d" % g] = env.get_agent_id(h)
                 if g in acting:
-                    a = torch.from_numpy(rs.randint(env.get_action_space(h)[0], size=n).astype(np.int32)).to(dev)
+                    a = torch.from_numpy(sc.draw(rs, env, g, h, n)).to(dev)
                     device_sync(lib)
                     env.set_action_device(h, a)
                 continue
@@ -405,7 +414,7 @@ def run(sc, lib, record=None, device_io=False, env_out=None):
                 rec["view%d" % g], rec["feat%d" % g] = view.copy(), feat.copy()
             rec["id%d" % g] = env.get_agent_id(h)
             if g in acting:
-                env.set_action(h, rs.randint(env.get_action_space(h)[0], size=n).astype(np.int32))
+                env.set_action(h, sc.draw(rs, env, g, h, n))
         if twice is not None and not device_io:      # FUZZ_TWICE=1: some groups are given actions again before the step (GridWorld.cc:403-454 appends)
             for g in [g for g in acting if twice.rand() < 0.4]:
                 env.set_action(handles[g], twice.randint(env.get_action_space(handles[g])[0], size=env.get_num(handles[g])).astype(np.int32))
@@ -452,7 +461,7 @@ def run_cycle(sc, lib, fused):
         rec = {}
         sc.apply_events(env, step)
         nums = [env.get_num(h) for h in handles]
-        acts = [rs.randint(env.get_action_space(h)[0], size=nums[g]).astype(np.int32) if g in acting else None for g, h in enumerate(handles)]
+        acts = [sc.draw(rs, env, g, h, nums[g]) if g in acting else None for g, h in enumerate(handles)]
         observe = [step % sc.obs_every == 0 and nums[g] > 0 for g in range(len(handles))]
         for g, h in enumerate(handles):
             rec["id%d" % g] = env.get_agent_id(h)
@@ -968,6 +977,11 @@ def scenarios():
         Scenario("arrange_goals_move", ("arrange", 36, True), 0, place=[rnd(0, 150), rnd(1, 250), rnd(2, 30)], walls=40, steps=25, action_seed=64),
         Scenario("arrange_goals_move_turn", ("arrange", 40, True), 0, place=[rnd(0, 160), rnd(1, 260), rnd(2, 30)], walls=30, steps=20, action_seed=65,
                  settings={"turn_mode": True}, clear_every=2),
+        # ... and goals that are given actions every step but told to stay where they are (the zero move): an ordinary step of the parallel
+        # phases -- Env::set_action_device looks at the actions before it sends a step through the literal loop
+        Scenario("arrange_goals_stand", ("arrange", 36, True), 0, place=[rnd(0, 150), rnd(1, 250), rnd(2, 30)], walls=40, steps=25, action_seed=66, still=(0,)),
+        Scenario("arrange_goals_stand_turn", ("arrange", 40, True), 0, place=[rnd(0, 160), rnd(1, 260), rnd(2, 30)], walls=30, steps=20, action_seed=67,
+                 settings={"turn_mode": True}, clear_every=2, still=(0,)),
         Scenario("battle_walls", "battle", 50, walls=200, place=[rnd(0, 400), rnd(1, 400)], steps=20, action_seed=3),
         Scenario("battle_largemap", "battle", 120, place=[rnd(0, 3000), rnd(1, 3000)], steps=12, action_seed=5),
         Scenario("battle_largemap_odd", "battle", 101, place=[rnd(0, 2500), rnd(1, 2500)], steps=10, action_seed=6),

@@ -19,7 +19,7 @@ import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # a slice that touches every phase family: dense attack chains, striped moves, multi-cell bodies, rules, goals, turn_mode, food
-SLICE = ["battle_small_dense", "battle_brawl", "battle_walls", "gather", "forest", "tri_rect", "pursuit_dense", "bodies", "quad", "battle_goal_mode", "pursuit_goals_drawn", "arrange_goals_move"]
+SLICE = ["battle_small_dense", "battle_brawl", "battle_walls", "gather", "forest", "tri_rect", "pursuit_dense", "bodies", "quad", "battle_goal_mode", "pursuit_goals_drawn", "arrange_goals_move", "arrange_goals_stand"]
 
 
 @pytest.fixture(scope="module")
@@ -143,3 +143,18 @@ def test_emulated_fused_step_of_plain_games(emu):
         p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"EMU_SCENARIOS": ",".join(names)}, base, extra), capture_output=True, text=True,
                            timeout=1500)
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])
+
+
+@pytest.mark.parametrize("env,needle", [({"MAGENT_SOLO_STEP": "0"}, "MAGENT_TUNE=solo_step="), ({"MAGENT_RENDER_PAD": "1"}, "has no successor"),
+                                        ({"MAGENT_TUNE": "solo_stepp=0"}, "unknown entry")],
+                         ids=["removed_variable_with_successor", "removed_variable_without", "unknown_tune_key"])
+def test_a_knob_the_engine_does_not_read_aborts(emu, env, needle):
+    """csrc/tune.h: a typo in MAGENT_TUNE, or one of the MAGENT_* variables of rounds 1-3 still set by an old script, must not silently
+    run the default path -- the first environment of the process aborts with the variable's successor named"""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import helpers as H\n"
+            "H.gridworld('battle', lib=H.ensure_emu(), map_size=12)\n"
+            "print('constructed')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    e = {k: v for k, v in os.environ.items() if not k.startswith("MAGENT_")}
+    p = subprocess.run([sys.executable, "-c", code], env=dict(e, **env), capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "constructed" not in p.stdout and "magent-amd FATAL" in p.stderr and needle in p.stderr, (p.stdout, p.stderr[-800:])

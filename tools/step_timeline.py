@@ -1,15 +1,18 @@
 """Timeline of ONE step out of a rocprofv3 --kernel-trace csv: start offset, duration and idle gap before every kernel.
 
-usage: python tools/step_timeline.py gpurun_out/<dir>/bench_kernel_trace.csv [k-th step from the end, default 3]"""
+usage: python tools/step_timeline.py gpurun_out/<dir>/bench_kernel_trace.csv [k-th step from the end, default 3] [kernel that ends a cycle]"""
 import csv
 import sys
 
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 names = [r["Kernel_Name"].split("(")[0].replace("magent_amd::", "").replace("void ", "") for r in rows]
-marks = [i for i, n in enumerate(names) if n.startswith("k_step_report")]
-if not marks:      # the one-launch step has no reset kernel of its own: a cycle ends with clear_dead
-    marks = [i for i, n in enumerate(names) if n.startswith("k_clear_solo_all")]
+marks = []
+# a cycle ends with clear_dead's last launch (plain games: k_clear_finish, or k_mini_norm when nobody died; the one-launch step: its own launch)
+for mark in ([sys.argv[3]] if len(sys.argv) > 3 else ["k_step_report", "k_plain_commit", "k_clear_solo_all", "k_step_solo"]):
+    marks = [i for i, n in enumerate(names) if n.startswith(mark)]
+    if len(marks) > back:
+        break
 a, b = marks[-back], marks[-back + 1]
 t0 = prev = int(rows[a]["End_Timestamp"])
 busy = gaps = 0
