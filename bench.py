@@ -90,7 +90,7 @@ def run_cpu_baseline(map_size=MAP_SIZE, agents=N_PER_GROUP, steps=4):
         try:
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--cpu-lib", lib,
                                   "--cpu-steps", str(steps if th > 1 or steps > 50 else min(steps, 3)), "--map-size", str(map_size), "--agents", str(agents)],
-                                 env=env, capture_output=True, text=True, timeout=600)
+                                 env=env, capture_output=True, text=True, timeout=900)
             rec = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # the baseline is a reported extra; never fail the bench for it
             sys.stderr.write("cpu_baseline(%d threads) failed: %r\n" % (th, e))
@@ -98,8 +98,8 @@ def run_cpu_baseline(map_size=MAP_SIZE, agents=N_PER_GROUP, steps=4):
         rate = rec["agent_steps"] / rec["seconds"]
         if best is None or rate > best["value"]:
             best = {"value": rate, "unit": "agent-steps/s", "cores": th, "kind": kind,
-                    "sample": "%d timed steps (+1 warm-up; the 1-thread leg: 3) of the same workload, %d OpenMP thread(s), host buffers "
-                              "(reference ABI); best of threads %s" % (steps, th, threads)}
+                    "sample": "%d timed steps (+1 warm-up; the 1-thread leg: 3 -- about 5 s per step there) of the same workload, %d OpenMP thread(s), host buffers "
+                              "(reference ABI); best of threads %s; %.1f s of CPU wall time for this leg" % (steps if th > 1 or steps > 50 else min(steps, 3), th, threads, rec["seconds"])}
     return best
 
 
@@ -202,7 +202,9 @@ def selfplay_extra(torch, magent_amd, n=400000, steps=4, infer_dtype="bf16"):
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside a launcher: re-run this command line as N ranks, one per GPU, the way the driver's
-    own launcher would (torch.distributed.run, rendezvous on 127.0.0.1); rank 0's JSON line passes through on stdout"""
+    own launcher would (torch.distributed.run, rendezvous on 127.0.0.1); rank 0's JSON line passes through on stdout.
+    Returns 0 once that line has been seen -- the headline is measured before anything that can fail on one rank is tried, and a rank that
+    dies later (the launcher then ends the others) costs the extra it died in, not the run (see `relay_sigterm`) -- else the launcher's code."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -212,7 +214,35 @@ def spawn_ranks(n):
                OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        lines += line.startswith('{"metric"')
+    rc = proc.wait()
+    return 0 if lines == 1 else (rc or 1)
+
+
+def relay_sigterm(on_term):
+    """SIGTERM -> `on_term()` on a helper thread, whatever the main thread is blocked in.  torch.distributed.run ends every rank with
+    SIGTERM as soon as one rank has died; a Python-level handler only runs when the main thread comes back to the interpreter, which it
+    does not while it waits inside a collective.  The C-level handler that `signal.set_wakeup_fd` installs writes the signal's number into
+    a pipe at once; the thread reading that pipe acts."""
+    import signal
+    import threading
+    r, w = os.pipe()
+    os.set_blocking(w, False)
+    signal.signal(signal.SIGTERM, lambda *a: None)         # (a Python handler must exist, else the default action -- die at once -- stays)
+    signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+
+    def watch():
+        while True:
+            b = os.read(r, 1)
+            if b and b[0] == signal.SIGTERM:
+                on_term()
+    t = threading.Thread(target=watch, daemon=True)
+    t.start()
 
 
 def host_abi_extra(magent_amd, n=N_PER_GROUP, steps=3, warm=2):
@@ -389,6 +419,9 @@ def main():
     ap.add_argument("--event-every", type=int, default=EVENT_EVERY, help="timed region: HIP events around the render launches of every N-th step (1: all)")
     ap.add_argument("--preheat-ms", type=float, default=PREHEAT_MS,
                     help="milliseconds of untimed render launches before the warm-up steps of every region: the device's sustained state (see measure); 0: none")
+    ap.add_argument("--no-cold", action="store_true", help="skip the three extra regions without the preheat (`no_preheat` in the line)")
+    ap.add_argument("--force-extra", action="store_true", help="test hook: run the N > 1 extra behind a non-default headline workload too")
+    ap.add_argument("--fault", default="", help="test hook (tests/test_bench_multi.py): 'kill-rank-1-in-extra' makes rank 1 die inside the N > 1 extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (capacity fill, test_1m, small worlds)")
@@ -434,7 +467,7 @@ def main():
             data_group["g"] = dist.new_group(backend="nccl")      # (every rank passes here together: measure() is called in lockstep)
         return data_group["g"]
 
-    def measure(workload, map_size, agents, steps, warmup, profile, gather="none", seed=12345 + rank, check_gather=False):
+    def measure(workload, map_size, agents, steps, warmup, profile, gather="none", seed=12345 + rank, check_gather=False, preheat_ms=None):
         """K timed steps of `workload`; returns the fields of the bench line that depend on the run"""
         from magent_amd.builtin.config import _games
         if workload == "test_1m":
@@ -505,7 +538,7 @@ def main():
                   for g in range(G)]
         last_sent = {}
         torch.cuda.synchronize()
-        rendered = {"view": 0, "feat": 0, "launches": 0}
+        rendered = {"view": 0, "feat": 0, "launches": 0, "agents": []}
         step_ends = []
 
         sampling = {"on": False}
@@ -526,6 +559,7 @@ def main():
                     rendered["view"] += n * view_bytes[g]
                     rendered["feat"] += n * feat_bytes[g]
                     rendered["launches"] += 1
+                    rendered["agents"].append(n)
                 view = views[g][s % n_buf]
                 if gathers and args.backend == "nccl":   # the exchange of step t-1 may still read the tensor this render overwrites
                     gathers[g].release(view, env.stream)
@@ -560,10 +594,12 @@ def main():
         # rendered again and again for --preheat-ms of wall time -- the episode does not advance, nothing of it is timed -- and the W warm-up
         # steps and the K timed steps then see the device as a long-running job sees it.
         preheat_launches = 0
-        if args.preheat_ms > 0 and acting and env.get_num(handles[acting[0]]) > 0:
+        if preheat_ms is None:
+            preheat_ms = args.preheat_ms
+        if preheat_ms > 0 and acting and env.get_num(handles[acting[0]]) > 0:
             g0 = acting[0]
             t_heat = time.perf_counter()
-            while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
+            while (time.perf_counter() - t_heat) * 1e3 < preheat_ms:
                 for _ in range(16):
                     if bf16:
                         env.get_observation_device_bf16(handles[g0], views[g0][0], feats[g0])
@@ -582,6 +618,7 @@ def main():
             for name in ("render", "features", "paint", "minimap", "attack", "move", "turn", "set_action", "step", "rules", "clear_dead"):
                 env.profile_read(name)
         rendered["view"] = rendered["feat"] = rendered["launches"] = 0
+        del rendered["agents"][:]
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -617,10 +654,12 @@ def main():
                 achieved = obs_bytes / (ms * 1e-3) / 1e9
                 traffic, traffic_note = None, None
                 pmc = os.path.join(ROOT, "profiles", "render_pmc.json")
-                if os.path.exists(pmc) and workload == "battle" and not bf16 and map_size == MAP_SIZE:   # (the PMC passes ran this workload)
+                pmc_key = {("battle", 1000): "battle_1000", ("battle_c5", 3536): "battle_c5_3536", ("test_1m", 4472): "test_1m",
+                           ("gather", 500): "gather_500"}.get((workload, map_size))
+                if os.path.exists(pmc) and pmc_key and not bf16:     # (the PMC passes ran these workloads: tools/measure.sh <tag> bytes)
                     try:     # PMC bytes per rendered AGENT (separate rocprofv3 --pmc passes, profiles/), scaled to this run's launches
-                        rec = json.load(open(pmc))
-                        agents_per_launch = (rendered["view"] / view_bytes[acting[0]]) / n_launch
+                        rec = json.load(open(pmc))["workloads"][pmc_key]
+                        agents_per_launch = sum(rendered["agents"]) / float(n_launch)
                         traffic = rec["hbm_bytes_per_agent"] * agents_per_launch
                         traffic_note = "PMC FETCH_SIZE + WRITE_SIZE per rendered agent (%s) x %.0f agents per launch of this run" % (rec.get("source", "profiles/"), agents_per_launch)
                     except Exception:
@@ -736,6 +775,17 @@ def main():
         R.setdefault("gather", {})["verified"] = runs[0][2]["gather"]["verified"]
     repeats_ms = [round(r[0] / args.steps * 1e3, 4) for r in runs]
 
+    # ... and the same region WITHOUT the preheat, beside it (ADVICE / VERDICT round 4): what a caller sees whose device was idle a moment
+    # ago -- the figure every line of rounds 1-3 carried.  Three regions, the median one; N = 1 only (no barriers involved).
+    cold = None
+    if world == 1 and args.preheat_ms > 0 and not args.no_cold:
+        cr = [measure(args.workload, args.map_size, args.agents, args.steps, args.warmup, not args.no_profile, preheat_ms=0.0) for _ in range(3)]
+        cr.sort(key=lambda r: r["elapsed"])
+        c = cr[1]
+        cold = {"ms_per_step": c["elapsed"] / args.steps * 1e3, "value": c["agent_steps"] / c["elapsed"], "regions_ms_per_step": [round(r["elapsed"] / args.steps * 1e3, 4) for r in cr],
+                "render_frac_in_region": (c["roofline"] or {}).get("frac"), "render_avg_launch_ms": (c["roofline"] or {}).get("avg_launch_ms"),
+                "note": "the same %d-step region without the preheat renders (--preheat-ms 0): the device's first milliseconds after an idle period; "
+                        "VERDICT / BASELINE comparisons use the sustained figure (`value`), lines of rounds 1-3 carried this one" % args.steps}
     if rank == 0:
         is_default = is_default_workload(args)
         names = {"test_1m": "reference test_1m.py harness: pursuit-like %dx%d, %d walls, %d prey + %d 2x2 predators" % (
@@ -755,7 +805,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_median": R["median_ms"],
             "repeats": len(runs), "repeats_ms_per_step": repeats_ms,
-            "value_is": "the repeat with the median time of %d identical %d-step regions" % (len(runs), args.steps),
+            "value_is": "the repeat with the median time of %d identical %d-step regions, each behind %.0f ms of untimed renders (the device's sustained state)" % (len(runs), args.steps, args.preheat_ms),
+            "ms_per_step_no_preheat": cold["ms_per_step"] if cold else None, "no_preheat": cold,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -780,7 +831,7 @@ def main():
             rec["config"]["gather_detail"] = R["gather"]
         if world == 1 and not args.no_cpu_baseline:
             small = args.map_size * args.map_size <= 250000
-            rec["cpu_baseline"] = run_cpu_baseline(args.map_size, args.agents, steps=200 if small else 8) \
+            rec["cpu_baseline"] = run_cpu_baseline(args.map_size, args.agents, steps=200 if small else 20) \
                 if args.workload == "battle" else None
         else:
             rec["cpu_baseline"] = None
@@ -795,6 +846,16 @@ def main():
                 T = measure("test_1m", 0, 500000, 10, 3, True)
                 extra["test_1m_2x500k"] = {"agent_steps_per_s": T["agent_steps"] / T["elapsed"], "ms_per_step": T["elapsed"] / 10 * 1e3, "agents": T["n0"], "map": T["map_size"],
                                            "roofline": T["roofline"]}
+                # BASELINE config 5's world measured like the headline: battle 3536 x 3536, 2 x 499,849 agents in
+                # examples/train_battle.py's own formation (two squares 6 columns apart), and the same two lattices interleaved (the melee a
+                # self-play episode reaches once the fronts have met); each leg with the roofline of ITS render launches, the phase breakdown,
+                # the death-rank rounds it needed and the steps the host had to finish
+                extra["c5_cycle_3536"] = {}
+                for leg, wl in (("formation", "battle_c5"), ("melee", "battle_c5_melee")):
+                    C5 = measure(wl, 3536, 0, 10, 3, True)
+                    extra["c5_cycle_3536"][leg] = {"agent_steps_per_s": C5["agent_steps"] / C5["elapsed"], "ms_per_step": C5["elapsed"] / 10 * 1e3,
+                                                   "agents": C5["n0"], "agents_at_end": C5["agents_at_end"], "roofline": C5["roofline"], "breakdown": C5["breakdown"],
+                                                   "attack_round_hist": C5["attack_round_hist"], "steps_finished_by_host_driver": C5["host_finished_steps"]}
                 C4 = measure("gather", 500, 100000, 20, 5, True)
                 extra["gather_500_100k"] = {"agent_steps_per_s": C4["agent_steps"] / C4["elapsed"], "ms_per_step": C4["elapsed"] / 20 * 1e3, "agents": C4["n0"],
                                             "workload": "BASELINE config 4, one replica: gather 500x500 (train_gather.py), 100k agents + 20k food, only the agents act",
@@ -812,7 +873,7 @@ def main():
             except Exception as e:     # secondary lines never fail the bench
                 extra["error"] = repr(e)
             rec["extra"] = extra
-    if world > 1 and is_default_workload(args) and not args.no_extras:
+    if world > 1 and (is_default_workload(args) or args.force_extra) and not args.no_extras:
         # north-star configuration 4 on the ranks of this job: gather 500 x 500, 100k agents + 20k food per replica, every replica's
         # observation tensor to every rank each step (counts first, rows sized by count, on a side stream under the step) -- timed
         # without and with the exchange, every gathered shard checked bit for bit against the rows its owner rendered.
@@ -823,17 +884,22 @@ def main():
         XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md: one xGMI link, per direction
         done_flag = threading.Event()
 
-        def bail():
+        def bail(why=None):
             if done_flag.is_set():
                 return
+            done_flag.set()
             if rank == 0:
-                rec.setdefault("extra", {})["c4_gather_rccl"] = {"error": "did not finish within %d s (a rank failed, or a collective did not return)" % args.extra_timeout}
+                rec.setdefault("extra", {})["c4_gather_rccl"] = {"error": why or "did not finish within %d s (a rank failed, or a collective did not return)" % args.extra_timeout}
                 print(json.dumps(rec), flush=True)
             os._exit(0)
         watchdog = threading.Timer(args.extra_timeout, bail)
         watchdog.daemon = True
         watchdog.start()
+        # a rank that DIES in here (not: raises) makes the launcher end the others with SIGTERM: rank 0 answers it with its one line
+        relay_sigterm(lambda: bail("the launcher ended this rank with SIGTERM inside the extra: another rank died (the headline above was already measured)"))
         try:
+            if args.fault == "kill-rank-1-in-extra" and rank == 1:
+                os._exit(17)
             A = measure("gather", 500, 100000, args.steps, args.warmup, False, gather="none")
             B = measure("gather", 500, 100000, args.steps, args.warmup, False, gather="obs", check_gather=True)
             ea = replicas.max_over_replicas(A["elapsed"], device=red_dev)

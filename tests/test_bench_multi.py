@@ -21,15 +21,62 @@ def test_gpus_flag_spawns_ranks(monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
     seen = {}
-    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+
+    class FakeLauncher(object):          # (the launcher's stdout is passed through line by line; rank 0's one JSON line makes the call a success)
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            seen.update(cmd=cmd, env=env)
+            self.stdout = iter(["some launcher noise\n", '{"metric": "m", "value": 1}\n'])
+
+        def wait(self):
+            return seen.get("rc", 0)
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeLauncher)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.main() == 0
+    seen["rc"] = 1                       # a rank died after rank 0 had printed its line: the line stands, so does the run
     assert bench.main() == 0
     cmd = seen["cmd"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_sigterm_reaches_a_rank_that_is_blocked_outside_the_interpreter():
+    """CPU: bench.relay_sigterm -- what lets rank 0 print its one line when the launcher ends it because another rank died.  The main
+    thread sits in a blocking read (a collective that never returns, for the purpose); SIGTERM must still produce the line, once."""
+    code = ("import os, sys, threading\n"
+            "sys.path.insert(0, %r)\n"
+            "import bench\n"
+            "def on_term():\n"
+            "    print('{\"metric\": \"m\", \"extra\": \"sigterm\"}', flush=True)\n"
+            "    os._exit(0)\n"
+            "bench.relay_sigterm(on_term)\n"
+            "print('ready', flush=True)\n"
+            "r, w = os.pipe()\n"
+            "os.read(r, 1)\n" % ROOT)
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True)
+    assert p.stdout.readline().strip() == "ready"
+    p.terminate()
+    out = p.stdout.read()
+    assert p.wait(timeout=30) == 0 and out.count('{"metric"') == 1, out
+
+
+@pytest.mark.gpu
+def test_a_rank_that_dies_in_the_extra_costs_the_extra_not_the_line():
+    """`bench.py --gpus 2` where rank 1 dies inside extra.c4_gather_rccl (--fault, a test hook): torch.distributed.run ends rank 0 with
+    SIGTERM; rank 0 still prints exactly ONE JSON line -- the headline it had already measured, the extra marked as failed -- and the
+    command succeeds"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--repeats", "1", "--map-size", "200", "--agents", "6000", "--force-extra", "--fault", "kill-rank-1-in-extra"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    rec = json.loads(lines[0])
+    # (which of the two ends the extra first is a race: the launcher's SIGTERM, or the collective library noticing the dead peer and raising)
+    err = rec["extra"]["c4_gather_rccl"]["error"]
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and ("SIGTERM" in err or "rror" in err), err
 
 
 @pytest.mark.gpu

@@ -18,7 +18,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=${1:-m}; JOBS=${2:-
 ARGS="$*"
 O=$R/gpurun_out/$TAG; mkdir -p $O
 export OMP_NUM_THREADS=${OMP_NUM_THREADS:-1}
-short="--steps 8 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras"
+short="--steps 8 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras --no-cold"
 
 table() {   # kernel table of a rocprofv3 --stats csv
 python - "$1" <<'PY'
@@ -43,7 +43,7 @@ for job in ${JOBS//,/ }; do
               run MAGENT_TUNE=solo_step=0,scan_solo_max=64 python tools/fuzz_parity.py oracle hip 1600 2200
               run MAGENT_TUNE=solo_step=0,attack_pairs=0 python tools/fuzz_parity.py oracle hip 2200 2700
               run FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 300) 2>&1 | tee $O/fuzz.log ;;
-    line)    (cd /tmp && export TMPDIR=/tmp && timeout 900 python $R/bench.py --no-cpu-baseline --no-extras $ARGS > $O/line.json 2> $O/line.err)
+    line)    (cd /tmp && export TMPDIR=/tmp && timeout 900 python $R/bench.py --no-cpu-baseline --no-extras --no-cold $ARGS > $O/line.json 2> $O/line.err)
              python - $O/line.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -75,7 +75,15 @@ def main():
                            "(it writes exactly w*h*4 bytes packed / w*h*8 unpacked); FETCH_SIZE is uncalibrated for 8-byte gathers on gfx950 and counts "
                            "Infinity-Cache hits (MI355X_MICROARCH.md, HBM section) -- an upper bound on HBM reads",
                    "source": tag}
-            json.dump(rec, open(os.path.join(out_dir, "render_pmc.json"), "w"), indent=1)
+            # profiles/render_pmc.json holds one record per workload (bench.py scales `roofline.traffic` from it); this tool refreshes the headline's
+            pmc_path = os.path.join(out_dir, "render_pmc.json")
+            allrec = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+            if "workloads" not in allrec:
+                allrec = {"note": rec["note"], "workloads": {}}
+            rec.pop("note")
+            rec["workload"] = "battle 1000x1000, 2x400k random (the headline)"
+            allrec["workloads"]["battle_1000"] = rec
+            json.dump(allrec, open(pmc_path, "w"), indent=1)
             lines += ["", "k_render: algorithmic bytes per launch = n_g * 4 * VH*VW*C; measured write %.3f GB, fetch %.3f GB" %
                       (rec["write_bytes_per_launch"] / 1e9, rec["fetch_bytes_per_launch"] / 1e9)]
     target = os.path.join(out_dir, tag + "_summary.md")
