@@ -133,6 +133,10 @@ struct WorldView {
     int vc_packed;               // viewcell holds one 32-bit word per cell (<= 3 groups, no goals), else an int2
     int live_paint;              // the step keeps `viewcell` current itself (vacated cells, then every live agent's body)
     int plain;                   // one-cell bodies, no turn_mode / food_mode / goals / kill_supply: the games the fused step takes
+    // generic move resolution: the candidates onto a cell, as a list -- node = {link to the next node + 1 (0: none), the candidate}; the list
+    // heads are per cell (the step's `wanted` / hit words); a candidate of group g owns nodes node_base[g] + i * (bw * bl) + 0 .. bw * bl - 1
+    int2 *mv_nodes;
+    int node_base[MAXG];
 };
 
 // What a step reports to the host.  The one-launch step (k_step_solo) writes it straight into pinned host memory and

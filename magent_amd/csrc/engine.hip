@@ -282,7 +282,7 @@ Env::~Env() {
     dfree(arena, d_occ); dfree(arena, d_viewcell); dfree(arena, d_claim); dfree(arena, d_food); dfree(arena, d_powtab); dfree(arena, d_counters); dfree(arena, d_gtab); dfree(arena, d_ttab);
     dfree(arena, d_delta); dfree(arena, d_mask); dfree(arena, d_mini); dfree(arena, d_minif); dfree(arena, d_sums); dfree(arena, d_rank); dfree(arena, d_shuf); dfree(arena, d_events); dfree(arena, serial_alist); dfree(arena, serial_mlist); dfree(arena, serial_dcalls); dfree(arena, d_actions);
     dfree(arena, d_stage_view); dfree(arena, d_stage_feat); dfree(arena, d_stage_small);
-    dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d); dfree(arena, d_asums); dfree(arena, d_wpre); dfree(arena, d_ptab); dfree(arena, d_alive);
+    dfree(arena, d_mvnodes); dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d); dfree(arena, d_asums); dfree(arena, d_wpre); dfree(arena, d_ptab); dfree(arena, d_alive);
     if (batch_h) (void)hipHostFree(batch_h);
     if (h_rec) (void)hipHostFree(h_rec);
     if (pool) {
@@ -921,12 +921,26 @@ WorldView Env::view() const {
     W.vc_packed = (groups.size() <= 3 && !any_absorb) ? 1 : 0;
     W.live_paint = live_paint_now ? 1 : 0;   // (set for the length of a step whose painted map was current at its start)
     W.plain = plain_world ? 1 : 0;
+    int nodes = 0;
     for (int g = 0; g < W.G; g++) {
         W.type[g] = groups[g].tdev;
         W.grp[g] = groups[g].cur;
         W.grp[g].n = groups[g].n;
+        W.node_base[g] = nodes;
+        nodes += groups[g].cap * groups[g].tdev.bw * groups[g].tdev.bl;
     }
+    W.mv_nodes = d_mvnodes;      // (sized by move_nodes() before a step of the generic move resolution)
     return W;
+}
+
+// the node array of the generic move resolution's candidate lists (WorldView::mv_nodes): one node per agent and body cell, by capacity --
+// only worlds whose moves take the generic path ever allocate it
+void Env::move_nodes() {
+    if (!any_multicell) return;
+    size_t nodes = 0;
+    for (auto &G : groups) nodes += (size_t)G.cap * G.tdev.bw * G.tdev.bl;
+    if (nodes >= (1u << 31)) fatal("too many body cells for the move phase's candidate lists");
+    if (nodes > mvnodes_cap) { enter(); grow(arena, d_mvnodes, mvnodes_cap, nodes, stream); }
 }
 
 void Env::ensure_tables() {
@@ -1668,6 +1682,7 @@ void Env::step_begin() {
     use_device();
     if (!tables_valid) { ensure_tables(); state_epoch++; }   // (enqueued on `stream`: the side stream has to see it)
     step_live_paint = live_paint_now = paint_valid;   // the painted map is current: every driver of the step keeps it so
+    move_nodes();
     WorldView W = view();
     int total_n = 0;
     for (auto &g : groups) total_n += g.n;
@@ -2016,6 +2031,7 @@ bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, con
     // goals that are given actions may move: the call sequence (set_action_device sends such a step through the literal loop)
     for (int g = 0; actions && g < n_group && g < (int)groups.size(); g++) if (actions[g] && groups[g].type->can_absorb && groups[g].n > 0) return false;
     enter();
+    move_nodes();
     alive_valid = false;            // (the one-launch cycle compacts by itself)
     const int NG = (int)groups.size();
     int total_n = 0;

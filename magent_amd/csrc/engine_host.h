@@ -215,7 +215,9 @@ private:
     StepRecord *h_rec = nullptr;          // pinned: written by k_step_solo, spun on by step_end
     int step_seq = 0;
     int solo_nt_eval = 0;
-    unsigned *d_hit = nullptr;            // per cell: hit bits / wanted counters of the one-launch step, zero between phases
+    unsigned *d_hit = nullptr;            // per cell: hit bits / candidate-list heads of the one-launch step, zero between phases
+    int2 *d_mvnodes = nullptr; size_t mvnodes_cap = 0;   // nodes of the generic move resolution's candidate lists (WorldView::mv_nodes)
+    void move_nodes();
     bool claim_clean = false;             // every claim word is CLAIM_NONE (the one-launch step keeps it so)
     bool claim_epochs = false;            // ... or written only by steps of the plain pipeline in the current window of epochs (scratch_for)
     unsigned plain_epoch = 0;             // steps of the plain pipeline so far: claim-word epochs and round stamps derive from it

@@ -1053,29 +1053,36 @@ struct MoveProbe {
     int blocker;      // first occupant Map::get_collide would meet (x outer, y inner), -1 if none
 };
 
-// every move candidate (other than `self`) with a lower key whose target rectangle covers cell (cx, cy), found by
-// pulling: f(packed ref, move status) -> true stops the search
+// every move candidate (other than `self`) with a lower key whose target rectangle covers cell c: the cell's list (movg_prep_body: every
+// candidate threads one node per cell of its target rectangle onto that cell -- `head[c]` = last node + 1, 0 = none; a node = {next link,
+// the candidate}).  f(packed ref, move status) -> true stops the walk.  (Rounds 1-4 found the entrants by PULLING -- every (group, move,
+// body offset) that could reach the cell probed on the map: ~60 dependent probes per contested cell in a pursuit world, and the slowest
+// lane sets a wave's time: k_movg_sweep 121 us at 1M agents.  A list is two or three entries long.)
 template <class F>
-__device__ __forceinline__ void for_each_entrant(const WorldView &W, int cx, int cy, unsigned key, int self, F f) {
-    for (int ga = 0; ga < W.G; ga++) {
-        const TypeDev TA = W.type[ga];
-        const GroupDev A = W.grp[ga];
-        for (int k = 0; k < TA.n_move; k++) {
-            const int2 d = W.delta[TA.move_off + k];
-            if ((d.x | d.y) == 0) continue;
-            for (int ax = 0; ax < TA.bw; ax++)
-                for (int ay = 0; ay < TA.bl; ay++) {
-                    const int px = cx - d.x - ax, py = cy - d.y - ay;
-                    if (px < 0 || py < 0 || px >= W.w || py >= W.h) continue;
-                    const int e = W.occ[py * W.w + px];
-                    if (e < 0 || e == self || ref_group(e) != ga) continue;
-                    const int ei = ref_index(e);
-                    if (A.x[ei] != px || A.y[ei] != py) continue;          // not that body's top-left cell
-                    if (A.pend[ei] != (PEND_MOVE | k) || A.drank_a[ei] < 0 || A.key[ei] >= key) continue;
-                    if (f(e, A.mv[ei])) return;
-                }
-        }
+__device__ __forceinline__ void for_each_entrant(const WorldView &W, const GroupDev *gtab, const unsigned *head, int c, unsigned key, int self, F f) {
+    for (unsigned h = head[c]; h != 0u;) {
+        const int2 nd = W.mv_nodes[h - 1u];
+        h = (unsigned)nd.x;
+        const int e = nd.y;
+        if (e == self) continue;
+        const GroupDev &A = gtab[ref_group(e)];
+        const int ei = ref_index(e);
+        if (A.key[ei] >= key) continue;
+        if (f(e, A.mv[ei])) return;
     }
+}
+// is some OTHER candidate's target rectangle on cell c?  (`self` is a candidate onto c itself: its node is in the list)
+__device__ __forceinline__ bool other_entrants(const WorldView &W, const unsigned *head, int c, int self) {
+    const unsigned h = head[c];
+    if (h == 0u) return false;
+    const int2 nd = W.mv_nodes[h - 1u];
+    return nd.y != self || nd.x != 0;
+}
+// (movg_prep_body) candidate `self` = (g, i) onto the k-th cell of its target rectangle
+__device__ __forceinline__ void entrant_push(const WorldView &W, unsigned *head, int c, int g, int i, int cells, int k) {
+    const unsigned node = (unsigned)W.node_base[g] + (unsigned)i * (unsigned)cells + (unsigned)k;
+    const unsigned old = atomicExch(&head[c], node + 1u);
+    W.mv_nodes[node] = make_int2((int)old, ref_pack(g, i));
 }
 
 // turn_mode: the rectangle a candidate enters depends on the way it faces, so candidates are found by scanning the
@@ -1112,16 +1119,15 @@ __device__ __forceinline__ void for_each_candidate_onto(const WorldView &W, cons
     });
 }
 template <class F>
-__device__ __forceinline__ void for_each_mover_onto(const WorldView &W, const GroupDev *gtab, int cx, int cy, unsigned key, int self, F f) {
-    if (W.turn_mode) for_each_candidate_onto(W, gtab, cx, cy, key, self, PEND_MOVE, false, f);
-    else for_each_entrant(W, cx, cy, key, self, f);
+__device__ __forceinline__ void for_each_mover_onto(const WorldView &W, const GroupDev *gtab, const unsigned *head, int cx, int cy, unsigned key, int self, F f) {
+    for_each_entrant(W, gtab, head, cy * W.w + cx, key, self, f);     // (turn_mode too: a candidate registers the rectangle it would enter as it faces)
 }
 
 // MODE 0: is the move blocked? (stops at the first definite obstacle)   MODE 1: all moves are decided -- who is the
 // collide object?   MODE 2 (can_absorb types present): the outcome depends on WHICH agent is met first, so the scan
 // stops at the first cell that holds an agent or whose state is still unknown
 template <int MODE>
-__device__ __forceinline__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g, int i, int tgt_cell, const unsigned *wanted) {
+__device__ __forceinline__ MoveProbe move_probe(const WorldView &W, const GroupDev *gtab, int g, int i, int tgt_cell, const unsigned *head) {
     const GroupDev G = W.grp[g];
     const TypeDev T = W.type[g];
     const unsigned key = G.key[i];
@@ -1153,10 +1159,9 @@ __device__ __forceinline__ MoveProbe move_probe(const WorldView &W, const GroupD
                 }
                 if (!gone) occupant = o;             // (possibly only "maybe": flagged by `unknown`)
             }
-            // entrants with lower keys -- only where some OTHER candidate's target rectangle covers the cell at all
-            // (wanted[c] counts the candidates whose rectangle covers c; mine is one of them)
-            if ((occupant < 0 || unknown) && wanted[c] > 1)
-                for_each_mover_onto(W, gtab, cx, cy, key, self, [&](int e, unsigned st) {
+            // entrants with lower keys: the other candidates on the cell's list (mine is one of its nodes)
+            if ((occupant < 0 || unknown) && other_entrants(W, head, c, self))
+                for_each_mover_onto(W, gtab, head, cx, cy, key, self, [&](int e, unsigned st) {
                     if (st == MV_OK) { occupant = e; return true; }
                     if (st == 0) unknown = true;
                     return false;
@@ -1177,7 +1182,7 @@ __device__ __forceinline__ MoveProbe move_probe(const WorldView &W, const GroupD
 
 // candidates: alive movers with a non-zero delta whose target rectangle is inside the map (Map.cc:455)
 // (starve: false when the turn phase of this step has already run starvation -- turn_prep_body)
-__device__ __forceinline__ void movg_prep_body(const WorldView &W, int g, int i, unsigned *wanted, int slot, bool starve) {
+__device__ __forceinline__ void movg_prep_body(const WorldView &W, int g, int i, unsigned *head, int slot, bool starve) {
     const GroupDev &G = W.grp[g];
     const TypeDev &T = W.type[g];
     if (starve) starve_body(W, g, G, T, i, slot);
@@ -1198,16 +1203,16 @@ __device__ __forceinline__ void movg_prep_body(const WorldView &W, int g, int i,
     if (t >= 0) {
         const int ny = t / W.w, nx = t - ny * W.w;
         for (int by = 0; by < fp.y; by++)
-            for (int bx = 0; bx < fp.x; bx++) atomicAdd(&wanted[(ny + by) * W.w + nx + bx], 1u);
+            for (int bx = 0; bx < fp.x; bx++) entrant_push(W, head, (ny + by) * W.w + nx + bx, g, i, T.bw * T.bl, by * fp.x + bx);
     }
 }
 
-__device__ __forceinline__ void movg_sweep_body(const WorldView &W, const GroupDev *gtab, int g, int i, const unsigned *wanted, int *flagp) {
+__device__ __forceinline__ void movg_sweep_body(const WorldView &W, const GroupDev *gtab, int g, int i, const unsigned *head, int *flagp) {
     const GroupDev &G = W.grp[g];
     const int t = G.drank_a[i];
     if (t < 0 || G.mv[i] != 0) return;
     if (!W.any_absorb) {
-        MoveProbe r = move_probe<0>(W, gtab, g, i, t, wanted);
+        MoveProbe r = move_probe<0>(W, gtab, g, i, t, head);
         if (r.blocked) G.mv[i] = MV_FAIL;
         else if (!r.undecided) G.mv[i] = MV_OK;
         else if (flagp) *flagp = 1;
@@ -1215,7 +1220,7 @@ __device__ __forceinline__ void movg_sweep_body(const WorldView &W, const GroupD
     }
     // Map::do_move with goals (Map.cc:334-353): the collide object is the first agent met; a goal that is still free
     // takes the mover in, a taken one is bumped without any effect
-    MoveProbe r = move_probe<2>(W, gtab, g, i, t, wanted);
+    MoveProbe r = move_probe<2>(W, gtab, g, i, t, head);
     unsigned st = 0;
     if (!r.undecided) {
         if (!r.blocked) st = MV_OK;
@@ -1228,15 +1233,12 @@ __device__ __forceinline__ void movg_sweep_body(const WorldView &W, const GroupD
                 const TypeDev TB = W.type[bg];
                 const unsigned key = G.key[i];
                 const int self = ref_pack(g, i), goal = r.blocker;
-                const int2 gd = body_dims(W, B, TB, bi), md = body_dims(W, G, W.type[g], i);
+                const int2 gd = body_dims(W, B, TB, bi);
                 bool lost = false, unknown = false;
                 for (int bx = 0; bx < gd.x && !lost; bx++)
                     for (int by = 0; by < gd.y && !lost; by++) {
                         const int cx = B.x[bi] + bx, cy = B.y[bi] + by;
-                        const int ty = t / W.w, tx = t - ty * W.w;
-                        const bool mine = cx >= tx && cx < tx + md.x && cy >= ty && cy < ty + md.y;
-                        if (wanted[cy * W.w + cx] <= (mine ? 1u : 0u)) continue;   // no other candidate reaches this cell
-                        for_each_mover_onto(W, gtab, cx, cy, key, self, [&](int, unsigned s2) {
+                        for_each_mover_onto(W, gtab, head, cx, cy, key, self, [&](int, unsigned s2) {      // (a cell nobody else reaches: an empty walk)
                             if (mv_taken(s2) && mv_taken_by(s2) == goal) { lost = true; return true; }
                             if (s2 == 0) unknown = true;
                             return false;
@@ -1252,13 +1254,13 @@ __device__ __forceinline__ void movg_sweep_body(const WorldView &W, const GroupD
 }
 
 // Map::get_collide for failed moves (Map.cc:334-353, 486-501): first agent met in the target rectangle
-__device__ __forceinline__ void movg_collide_body(const WorldView &W, const GroupDev *gtab, int g, int i, const unsigned *wanted) {
+__device__ __forceinline__ void movg_collide_body(const WorldView &W, const GroupDev *gtab, int g, int i, const unsigned *head) {
     const GroupDev &G = W.grp[g];
     const int t = G.drank_a[i];
     if (t < 0) return;
     const unsigned st = G.mv[i];
     if (st == MV_FAIL) {
-        MoveProbe r = move_probe<1>(W, gtab, g, i, t, wanted);
+        MoveProbe r = move_probe<1>(W, gtab, g, i, t, head);
         if (r.blocker >= 0) { G.last_op[i] = OP_COLLIDE; G.op_obj[i] = r.blocker; }
     } else if (mv_taken(st)) {   // exactly one mover per goal ends up here
         const int goal = mv_taken_by(st);
