@@ -62,7 +62,7 @@ __device__ __forceinline__ void solo_step_main(WorldView &s_W, const SoloStep &S
         const bool listed = !W.any_multicell;
         if (tid == 0) s_ntgt = 0;
         __syncthreads();
-        SOLO_EACH(g, i) attack_rank_body(W, g, i, S.rank, S.hit, listed ? S.slink : nullptr, &s_ntgt);
+        SOLO_EACH(g, i) attack_rank_body(W, gtab, g, i, S.rank, S.hit, listed ? S.slink : nullptr, &s_ntgt);
         __syncthreads();
         SOLO_MARK();   // 5: rank
         // ---- death ranks: in-place fixed point, one round per barrier pair

@@ -104,6 +104,9 @@ struct GroupDev {
     unsigned *key;               // attack: sequence number -> rank after the shuffle; move: order key
     int *drank_a, *drank_b;      // attack fixed point: rank at which the agent dies (ping-pong)
     unsigned *mv;                // move resolution status / dependency (generic step); hp after the attack phase, as float bits (every step)
+    unsigned char *hitf;         // generic attack phase: somebody's attack lands on me in this step (set by the attacker in attack_rank_body,
+                                 // cleared by the owner in attack_apply_body; zero between steps) -- what saves every agent a look at the hit
+                                 // words of all its body cells: 2.5 M random reads per pass in a 1 M-agent pursuit world
     int *hits;                   // reward rules: number of rule hits received as the object of an event
     // food_mode scratch of the attack phase: what my attack eats (-1 = it eats nothing), written by the owner of the
     // food; the cell on which I was killed and what is left of the food there (-1 = none)

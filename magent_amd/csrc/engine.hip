@@ -854,7 +854,7 @@ void Env::free_group(HostGroup &g) {
     GroupDev &c = g.cur, &a = g.alt;
     dfree(arena, c.x); dfree(arena, c.y); dfree(arena, c.id); dfree(arena, c.last_action); dfree(arena, c.op_obj); dfree(arena, c.pend); dfree(arena, c.hp);
     dfree(arena, c.next_reward); dfree(arena, c.last_reward); dfree(arena, c.dead); dfree(arena, c.last_op); dfree(arena, c.key); dfree(arena, c.drank_a);
-    dfree(arena, c.drank_b); dfree(arena, c.mv); dfree(arena, c.hits); dfree(arena, c.absorbed); dfree(arena, a.absorbed); dfree(arena, c.dir); dfree(arena, a.dir);
+    dfree(arena, c.drank_b); dfree(arena, c.mv); dfree(arena, c.hits); dfree(arena, c.hitf); dfree(arena, c.absorbed); dfree(arena, a.absorbed); dfree(arena, c.dir); dfree(arena, a.dir);
     dfree(arena, c.eat); dfree(arena, c.fleft); dfree(arena, c.fcell);
     dfree(arena, g.pl.rec); dfree(arena, g.pl.atk); dfree(arena, g.pl.hmask); dfree(arena, g.pl.hlist);
     ptab_valid = false;
@@ -896,6 +896,8 @@ void Env::ensure_capacity(HostGroup &g, int need) {
     regrow(arena, c.last_reward, n, ncap); regrow(arena, c.dead, n, ncap); regrow(arena, c.last_op, n, ncap); regrow(arena, c.key, n, ncap);
     regrow(arena, c.drank_a, n, ncap); regrow(arena, c.drank_b, n, ncap); regrow(arena, c.mv, n, ncap); regrow(arena, c.hits, n, ncap);
     HIP_OK(hipMemset(c.hits, 0, sizeof(int) * ncap));
+    regrow(arena, c.hitf, 0, ncap);
+    HIP_OK(hipMemset(c.hitf, 0, ncap));            // (zero between steps: attack_apply_body leaves them so)
     regrow(arena, c.absorbed, n, ncap); regrow(arena, a.absorbed, 0, ncap);
     if (turn_mode) { regrow(arena, c.dir, n, ncap); regrow(arena, a.dir, 0, ncap); }
     regrow(arena, c.eat, 0, ncap); regrow(arena, c.fleft, 0, ncap); regrow(arena, c.fcell, 0, ncap);   // attack-phase scratch (food_mode)
@@ -1761,7 +1763,7 @@ void Env::step_begin() {
                 for (int r = 0; r < 2 * pairs; r++)
                     launch_plain_eval(a, W, PW, d_ptab, d_gtab, d_ttab, ++attack_round, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1, shuffle_bufs());
             } else {
-                launch_attack_rank(a, W, d_rank, shuffle_bufs(), false, d_asums, d_wpre, seq_plan());
+                launch_attack_rank(a, W, d_gtab, d_rank, shuffle_bufs(), false, d_asums, d_wpre, seq_plan());
                 for (int r = 0; r < 2 * pairs; r++)
                     launch_attack_iter(a, W, d_gtab, d_ttab, ++attack_round, attack_kmax, r == 2 * pairs - 1 ? CTR_OPEN_ATTACK : -1);
             }
@@ -1837,7 +1839,7 @@ void Env::step_begin() {
                 push_rng();
                 launch_shuffle(stream, total_n, d_counters, shuffle_bufs(), d_rank, d_hit, (size_t)width * height, d_powtab, step_sa_tiled);
             }
-            launch_attack_rank(stream, W, d_rank, shuffle_bufs(), host_shuffle, d_asums, d_wpre, seq_plan());
+            launch_attack_rank(stream, W, d_gtab, d_rank, shuffle_bufs(), host_shuffle, d_asums, d_wpre, seq_plan());
             attack_round = 0;
             attack_rounds_checked(W);
             if (!first_render) {   // attack events are recorded once rendering has started (GridWorld.cc:484,508)

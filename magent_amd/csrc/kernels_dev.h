@@ -568,7 +568,7 @@ __device__ __forceinline__ void shuffle_chase_body(int i, int A, const int *j, c
 // rank[seq] = position of attack-list entry `seq` after the reference's shuffle (GridWorld.cc:464-468)
 // (tlist / n_tlist, one-launch step with one-cell bodies: the attacker that sets the FIRST bit of a cell appends the agent standing
 // there -- every target exactly once -- and the evaluation rounds visit the targets instead of scanning every agent)
-__device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int i, const int *rank, unsigned *hitbits, int *tlist = nullptr,
+__device__ __forceinline__ void attack_rank_body(const WorldView &W, const GroupDev *gtab, int g, int i, const int *rank, unsigned *hitbits, int *tlist = nullptr,
                                                  int *n_tlist = nullptr, int seq = -1 /* >= 0: the attack's sequence number (else it is in `key`) */) {
     const GroupDev &G = W.grp[g];
     const TypeDev &T = W.type[g];
@@ -591,6 +591,9 @@ __device__ __forceinline__ void attack_rank_body(const WorldView &W, int g, int 
             if ((o >= 0 && (T.attack_in_group || ref_group(o) != g || W.food_mode)) || o == OCC_FOOD) {
                 if (!tlist) atomicOr(&hitbits[ty * W.w + tx], 1u << (T.attack_bit + k));
                 else if (atomicOr(&hitbits[ty * W.w + tx], 1u << (T.attack_bit + k)) == 0u) tlist[atomicAdd(n_tlist, 1)] = o;
+                // the agent whose cell it is hears of it: "some hit word of my body is set" without a look at every one of them
+                // (several attackers may say so at once: the same byte, the same value)
+                if (o >= 0) gtab[ref_group(o)].hitf[ref_index(o)] = 1;
             }
         }
     }
@@ -684,6 +687,7 @@ __device__ __forceinline__ void attack_eval_body(const WorldView &W, const Group
     const int dr_me_cur = G.drank_a[i];
     if (dr_me_cur == -1) return;                      // dead before the phase
     if (G.drank_b[i] < round - 1) return;             // no input has changed since my last evaluation
+    if (!G.hitf[i]) return;                           // nobody hits me: I stay alive (RANK_INF, the initial value) -- no hit word is looked at
     const int pend = G.pend[i];
     const bool attacker = (pend & ~PEND_ARG) == PEND_ATTACK;
 
@@ -794,11 +798,8 @@ __device__ __forceinline__ void attack_apply_body(const WorldView &W, const Grou
     if (dr == -1) return;                             // dead before the phase
     const int pend = G.pend[i];
     const bool attacker = (pend & ~PEND_ARG) == PEND_ATTACK;
-    const int x = G.x[i], y = G.y[i];
-    bool hit = false;
-    const int2 fp = body_dims(W, G, T, i);
-    for (int by = 0; by < fp.y; by++)
-        for (int bx = 0; bx < fp.x; bx++) hit |= hitbits[(y + by) * W.w + x + bx] != 0;
+    const bool hit = G.hitf[i] != 0;                  // (= some hit word of my body is set: attack_rank_body)
+    if (hit) G.hitf[i] = 0;                           // zero between steps
     if (!hit && !attacker) return;
     unsigned my_rank = 0xFFFFFFFFu;
     int tgt = -1, tgt_dr = RANK_INF;

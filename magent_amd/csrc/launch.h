@@ -127,7 +127,7 @@ void launch_set_counter(hipStream_t s, int *counters, int index, int value, int 
 struct SeqPlan { int off[MAXG]; };
 void launch_set_action(hipStream_t s, const WorldView &W, int g, const int *actions, int call_base, int *sums, int *wpre, int tile_off /* < 0: one-workgroup form */);
 void launch_seq_assign(hipStream_t s, const WorldView &W, int g, const int *sums, const int *wpre, int tile_off, bool write_total);
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits, const int *sums, const int *wpre,
+void launch_attack_rank(hipStream_t s, const WorldView &W, const GroupDev *gtab, const int *rank, const ShuffleBufs &B, bool clear_hitbits, const int *sums, const int *wpre,
                         const SeqPlan &P);
 void launch_attack_iter(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int round, int kmax, int flag /* counter to raise on a change, < 0 = none */);
 void launch_attack_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab, int kmax);

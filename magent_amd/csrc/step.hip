@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) k_shuffle_chase(int *counters, const int 
     if (i >= A) return;
     shuffle_chase_body(i, A, j, head, first, link, rank);
 }
-__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *rank, unsigned *hitbits, int *shuf_head, int *shuf_first,
+__global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const GroupDev *gtab, const int *rank, unsigned *hitbits, int *shuf_head, int *shuf_first,
                                                      const int *sums, const int *wpre, SeqPlan P) {
     if ((blockIdx.x | blockIdx.y | threadIdx.x) == 0) W.counters[CTR_CHANGED] = 0;   // attack rounds start
     const int A = W.counters[CTR_ATTACK];
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) k_attack_rank(WorldView W, const int *ran
     int seq = -1;
     if (P.off[g] >= 0) seq = attack_seq(sums, wpre, P.off[g], i, i < n && (W.grp[g].pend[i] & ~PEND_ARG) == PEND_ATTACK);   // (every thread of the workgroup)
     if (i >= n) return;
-    attack_rank_body(W, g, i, rank, hitbits, nullptr, nullptr, seq);
+    attack_rank_body(W, gtab, g, i, rank, hitbits, nullptr, nullptr, seq);
 }
 // workgroup size: as large as the hit lists (kmax x threads x 8 B of LDS) allow, see att_threads()
 __global__ void __launch_bounds__(256) k_attack_eval(WorldView W, const GroupDev *gtab, const TypeDev *ttab, int round,
@@ -1050,10 +1050,10 @@ void launch_set_counter(hipStream_t s, int *counters, int index, int value, int 
 }
 
 // (the hit bits have an array of their own, WorldView::hitbits -- until round 4 they shared the move phase's claim words)
-void launch_attack_rank(hipStream_t s, const WorldView &W, const int *rank, const ShuffleBufs &B, bool clear_hitbits, const int *sums, const int *wpre,
+void launch_attack_rank(hipStream_t s, const WorldView &W, const GroupDev *gtab, const int *rank, const ShuffleBufs &B, bool clear_hitbits, const int *sums, const int *wpre,
                         const SeqPlan &P) {
     if (clear_hitbits) (void)hipMemsetAsync(W.hitbits, 0, sizeof(unsigned) * (size_t)W.w * W.h, s);   // (else k_shuffle_draw did it, or the fused step keeps them zero)
-    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, rank, W.hitbits, B.head, B.first, sums, wpre, P);
+    hipLaunchKernelGGL(k_attack_rank, grid_all(W, 256), dim3(256), 0, s, W, gtab, rank, W.hitbits, B.head, B.first, sums, wpre, P);
 }
 static int att_threads(int kmax) {
     static const int forced = tune("att_threads", 0);
