@@ -977,6 +977,7 @@ void Env::reset() {
     for (auto &c : serial_calls) if (c.actions) { int *buf = const_cast<int *>(c.actions); dfree(arena, buf); }
     serial_calls.clear(); step_calls.clear(); serial_calls_on = false;
     alive_valid = false;
+    map_scattered = map_warm = false;
     // a fresh episode starts with two pairs of optimistic attack rounds: the first steps of a dense placement hold the deepest
     // dependency chains (measured at 2 x 400k: one pair runs out once in the first few steps, two never did), and a step that runs
     // out costs a host round trip; the budget falls back to one pair after 64 steps that did not need the second
@@ -1189,6 +1190,7 @@ void Env::add_agents(int group, int n, const char *method, const int *px, const 
         sx.push_back(x); sy.push_back(y); sid.push_back(id_counter++); sdir.push_back(dir);
     };
     if (m == "random") {
+        if (n > 0) map_scattered = true;      // agents that stand next to each other in the group stand anywhere on the map (observe_device)
         for (int i = 0; i < n; i++) {
             rng_on_device = false;
             const int dir = turn_mode ? (int)(rng() % DIR_NUM) : DIR_NORTH;   // drawn before the position (GridWorld.cc:230)
@@ -1365,6 +1367,16 @@ void Env::observe_device(int g, float *view, float *feat, bool cells16) {
     const bool feat_aligned = (((uintptr_t)feat) & 15) == 0;
     R.cells16 = cells16 ? 1 : 0;
     {
+        // A painted map that does not fit the L2s, looked at by agents whose order in the group says nothing about where they stand (random
+        // placement): every window row is an L2 miss, served by the Infinity Cache -- if the map is still there.  Behind a step it is not
+        // (the step's kernels have been through half a gigabyte of other arrays); streaming the map through once, ahead of the first render
+        // of a cycle, puts it back: 80 MB in 13 us, and the two renders of the reference's 1M harness run 0.242 -> 0.215 ms each
+        // (profiles/r05_summary.md; MAGENT_TUNE touch_map=0 / 1: never / before every such render).  Spatially ordered populations
+        // (train_battle.py's formation) read the map once either way: nothing to warm.
+        static const int touch = tune("touch_map", -1);
+        const bool big_map = (size_t)width * height * (W.vc_packed ? 4 : 8) > (16u << 20);
+        if (big_map && (touch > 0 || (touch < 0 && map_scattered && !map_warm))) launch_touch_map(stream, W);
+        map_warm = true;                      // (a render walks the map itself)
         ProfScope p(*this, "render", true);
         last_render_kernel = launch_render(stream, W, R, P, aligned, aligned);
     }
@@ -1694,6 +1706,7 @@ void Env::step_begin() {
     const bool fast = !checked_step && !host_shuffle && first_render && !generic_turns;
     step_pending = true;
     alive_valid = false;
+    map_warm = false;
     step_was_fast = false;
     step_was_solo = false;
     step_was_plain = false;

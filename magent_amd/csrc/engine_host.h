@@ -229,6 +229,8 @@ private:
     int *d_alive = nullptr; size_t alive_cap = 0;      // survivors per 256 agents, left by k_strike for clear_dead (PlainWorld::alive)
     int alive_off[MAXG] = {}, alive_n[MAXG] = {};
     bool alive_valid = false;
+    bool map_scattered = false;           // some group was placed by add_agents("random"): neighbours in the group are not neighbours on the map
+    bool map_warm = false;                // an observation render has walked the painted map since the last step (observe_device: touch_map)
     PlainWorld plain_view();
     void plain_arrays(HostGroup &g, size_t n, size_t cap);
     bool stale_events = false;            // a step has run since the last clear_dead: last_op / op_obj are not all OP_NULL / -1

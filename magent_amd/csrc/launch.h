@@ -103,6 +103,7 @@ struct BatchItem {
 // one set_action call of a step in which some group was given actions more than once (k_step_serial)
 struct SerialCall { int g; const int *actions; };
 void launch_step_serial(hipStream_t s, const WorldView &W, const SerialCall *calls, int n_calls, int2 *alist, int4 *mlist, int4 *msorted, int n_sep, int4 *events);
+void launch_touch_map(hipStream_t s, const WorldView &W);
 void launch_pend_to_actions(hipStream_t s, const GroupDev &G, const TypeDev &T, int *out);
 void launch_any_real_action(hipStream_t s, const int *actions, int n, const TypeDev &T, const int2 *delta, int *flag);
 void launch_step_report(hipStream_t s, int *counters, StepRecord *rec, int seq, int NG);

@@ -348,6 +348,17 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_multi(WorldView W,
     else render_block<true, true, 1, PACKED, false>(render_world(W, M.R[k].g), M.R[k], M.P[k], blockIdx.x, M.blocks[k]);
 }
 
+// the painted map streamed through the caches ahead of the renders of a map that does not fit the L2s (Env::observe_device: when, and why)
+__global__ void __launch_bounds__(256) k_touch(const uint4 *p, size_t n16, unsigned *sink) {
+    unsigned acc = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) { const uint4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x9E3779B9u) *sink = acc;      // (never, in practice: keeps the loads)
+}
+void launch_touch_map(hipStream_t s, const WorldView &W) {
+    const size_t bytes = (size_t)W.w * W.h * (W.vc_packed ? 4 : 8);
+    hipLaunchKernelGGL(k_touch, dim3(2048), dim3(256), 0, s, (const uint4 *)W.viewcell, bytes / 16, (unsigned *)W.counters + CTR_GOALS_ACT);
+}
+
 void launch_paint(hipStream_t s, const WorldView &W, const GroupDev *gtab, const TypeDev *ttab) {
     int ncell = W.w * W.h;
     int blocks = (ncell + 255) / 256;

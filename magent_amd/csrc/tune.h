@@ -17,6 +17,8 @@
 //   policy_grid=N       workgroups of k_dqn_conv (tests: a few workgroups walk many tiles);  policy_stamps=1: per-phase cycle stamps
 //   early_report=0      the plain pipeline's step report behind the moves instead of ahead of them (A/B of the early `done`)
 //   batch_cycle=0       env_cycle_many runs its environments one after another instead of in one pair of launches
+//   touch_map=0|1       never / before every render of a map beyond the L2s: the painted map streamed through the caches first (default: before the
+//                       first render of a cycle when some group was placed at random)
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +50,7 @@ inline int tune(const char *key, int dflt) {
     (void)legacy_checked;
     static const char *const known[] = {"checked_step", "host_shuffle", "attack_pairs", "move_batches", "solo_step", "solo_max", "scan_solo_max", "overlap",
                                         "fold_minimap", "render", "render_sweep", "render_su", "render_depth", "att_threads", "policy_grid", "policy_stamps",
-                                        "batch_cycle", "early_report"};
+                                        "batch_cycle", "early_report", "touch_map"};
     const char *s = std::getenv("MAGENT_TUNE");
     if (!s || !*s) return dflt;
     static bool checked = false;

@@ -158,3 +158,10 @@ def test_a_knob_the_engine_does_not_read_aborts(emu, env, needle):
     e = {k: v for k, v in os.environ.items() if not k.startswith("MAGENT_")}
     p = subprocess.run([sys.executable, "-c", code], env=dict(e, **env), capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and "constructed" not in p.stdout and "magent-amd FATAL" in p.stderr and needle in p.stderr, (p.stdout, p.stderr[-800:])
+
+
+def test_emulated_render_of_a_map_beyond_the_l2s(emu):
+    """a painted map of more than 16 MB under a randomly placed population: the first render of every cycle goes behind a launch that
+    streams the map through the caches (Env::observe_device, k_touch) -- it only reads, the observations stay what they are"""
+    sc = H.Scenario("battle_2100_scattered", "battle", 2100, place=[(0, "random", {"n": 300}), (1, "random", {"n": 300})], steps=3, action_seed=71)
+    H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, emu), "battle 2100 x 2100 (hipemu)")
