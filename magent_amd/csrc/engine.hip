@@ -1246,6 +1246,7 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
     const HostType &t = *G.type;
     const int NG = (int)groups.size();
     R = RenderArgs{};
+    P = RenderPlan{};
     R.g = g; R.n = G.n;
     R.VH = t.view.height; R.VW = t.view.width; R.C = n_channel(); R.S = R.VH * R.VW * R.C;
     R.F = feature_size(g); R.E = embedding_size; R.NA = t.n_action;

@@ -13,6 +13,12 @@
 #   stats     rocprofv3 --kernel-trace --stats of a short run      -> stats/bench_kernel_stats.csv + a table
 #   bytes     FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ / TCC_EA0_WRREQ passes (separate --pmc runs) -> bytes.json + a table
 #   pmc       the full counter set of tools/step_pmc.sh
+#   ab        `line` once per MAGENT_TUNE setting of AB="set1;set2;..." ("-" = the defaults)   -> ab_<n>.json, one row each
+#   timeline  the launches of one step in order, from the trace `stats` wrote (tools/step_timeline.py)
+#   default   the driver's default command timed end to end (wall seconds, return code)                       -> full.json
+#   n8        the default N = 8 command as a dry run over gloo on this one GPU + tests/test_bench_multi.py      -> n8_gloo.json
+#   probes    tools/probe/*.hip + tools/render_locality.py (how stores and window reads behave on this part)
+# Environment: K (pytest -k of `parity`), AB (settings of `ab`), FUZZ_FROM / FUZZ_N (first seed and seeds per generator of `fuzz`; default 0 / as listed)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=${1:-m}; JOBS=${2:-line}; shift; shift
 [ "$1" = "--" ] && shift
 ARGS="$*"
@@ -38,11 +44,15 @@ for job in ${JOBS//,/ }; do
              cp $R/gpurun_out/callers.json $O/ 2>/dev/null ;;
     fuzz)    (cd $R
               run() { echo "-- $*"; env "$@" 2>&1 | tail -1; }
-              run python tools/fuzz_parity.py oracle hip 0 600
-              run MAGENT_TUNE=solo_step=0 python tools/fuzz_parity.py oracle hip 600 1600
-              run MAGENT_TUNE=solo_step=0,scan_solo_max=64 python tools/fuzz_parity.py oracle hip 1600 2200
-              run MAGENT_TUNE=solo_step=0,attack_pairs=0 python tools/fuzz_parity.py oracle hip 2200 2700
-              run FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip 0 300) 2>&1 | tee $O/fuzz.log ;;
+              F=${FUZZ_FROM:-0}; s() { echo $((F + $1)); }
+              run python tools/fuzz_parity.py oracle hip $(s 0) $(s 600)
+              run MAGENT_TUNE=solo_step=0 python tools/fuzz_parity.py oracle hip $(s 600) $(s 1600)
+              run MAGENT_TUNE=solo_step=0,scan_solo_max=64 python tools/fuzz_parity.py oracle hip $(s 1600) $(s 2200)
+              run MAGENT_TUNE=solo_step=0,attack_pairs=0 python tools/fuzz_parity.py oracle hip $(s 2200) $(s 2700)
+              run MAGENT_TUNE=solo_step=0,move_batches=0 python tools/fuzz_parity.py oracle hip $(s 2700) $(s 3000)
+              run FUZZ_TURN=1 MAGENT_TUNE=solo_step=0 python tools/fuzz_parity.py oracle hip $(s 0) $(s 300)
+              run FUZZ_RULES=2 MAGENT_TUNE=solo_step=0 python tools/fuzz_parity.py oracle hip $(s 0) $(s 200)
+              run FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip $(s 0) $(s 300)) 2>&1 | tee $O/fuzz.log ;;
     line)    (cd /tmp && export TMPDIR=/tmp && timeout 900 python $R/bench.py --no-cpu-baseline --no-extras --no-cold $ARGS > $O/line.json 2> $O/line.err)
              python - $O/line.json <<'PY'
 import json, sys
@@ -62,6 +72,54 @@ PY
              done
              python $R/tools/pmc_bytes.py $O $O/bytes.json ;;
     pmc)     bash $R/tools/step_pmc.sh ${TAG}/pmc $ARGS | tail -3 ;;
+    ab)      i=0; IFS=';' read -ra SETS <<< "${AB:--}"
+             for t in "${SETS[@]}"; do
+               [ "$t" = "-" ] && t=""
+               (cd /tmp && export TMPDIR=/tmp && MAGENT_TUNE="$t" timeout 900 python $R/bench.py --no-cpu-baseline --no-extras --no-cold $ARGS > $O/ab_$i.json 2> $O/ab_$i.err)
+               python - $O/ab_$i.json "$t" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"] or {}; b = d["breakdown"]
+    print("%-44s %.4f ms/step | %s %.4f ms/launch frac %.3f | render %.4f attack %.4f move %.4f clear %.4f order %s" % (
+        sys.argv[2] or "(defaults)", d["ms_per_step"], r.get("kernel"), r.get("avg_launch_ms", 0), r.get("frac", 0), b.get("render_ms_per_step", 0),
+        b.get("attack_ms_per_step", 0), b.get("move_ms_per_step", 0), b.get("clear_dead_ms_per_step", 0), b.get("map_order_ms_per_step")))
+except Exception as e:
+    print("%-44s FAILED: %r" % (sys.argv[2], e))
+PY
+               i=$((i + 1))
+             done ;;
+    timeline) python $R/tools/step_timeline.py $O/stats/bench_kernel_trace.csv 3 ;;
+    default) python - <<PY
+import subprocess, time, json
+t0 = time.time()
+p = subprocess.run(["python", "$R/bench.py"] + "$ARGS".split(), capture_output=True, text=True, timeout=1500, cwd="/tmp")
+dt = time.time() - t0
+open("$O/full.json", "w").write(p.stdout); open("$O/full.err", "w").write(p.stderr)
+rec = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+print("default bench.py: wall %.1f s rc %d" % (dt, p.returncode))
+print("%.4e  %.4f ms  no_preheat %s  frac %s" % (rec["value"], rec["ms_per_step"], rec.get("ms_per_step_no_preheat"), rec["roofline"]["frac"]))
+print("cpu:", rec["cpu_baseline"])
+e = rec.get("extra", {})
+print({k: (v.get("ms_per_step") if isinstance(v, dict) else v) for k, v in e.items()})
+print(e.get("error"))
+PY
+             ;;
+    n8)      (cd $R && timeout 1500 python -m pytest tests/test_bench_multi.py -x -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -3) | tee $O/n8_tests.log
+             python - <<PY
+import subprocess, time, json
+t0 = time.time()
+p = subprocess.run(["python", "$R/bench.py", "--gpus", "8", "--backend", "gloo", "--extra-timeout", "900"], capture_output=True, text=True, timeout=1500, cwd="/tmp")
+dt = time.time() - t0
+lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+rec = json.loads(lines[-1])
+rec["dry_run"] = {"command": "python bench.py --gpus 8 --backend gloo", "wall_seconds": round(dt, 1), "returncode": p.returncode, "json_lines": len(lines),
+                  "note": "8 ranks share ONE MI355X over gloo: the driver's default N = 8 command end to end (headline on config 3 per rank, then extra.c4_gather_rccl with every shard verified); a dry run of the code path and its footprint, not a measurement of xGMI"}
+json.dump(rec, open("$O/n8_gloo.json", "w"), indent=1)
+print("wall %.1f s, rc %d, %d line(s); value %.3e; extra verified %s" % (dt, p.returncode, len(lines), rec["value"], rec["extra"]["c4_gather_rccl"].get("verified")))
+PY
+             ;;
+    probes)  (cd $R && hipcc --offload-arch=gfx950 -O3 -o /tmp/scatter_chunks tools/probe/scatter_chunks.hip && /tmp/scatter_chunks > $O/scatter_chunks.txt 2>&1
+              python tools/render_locality.py 2>&1 | grep -v amdgpu.ids | tee $O/render_locality.txt) ;;
     *)       echo "unknown job $job" ;;
   esac
 done
