@@ -266,6 +266,7 @@ Env::Env() {
     solo_enabled = tune("solo_step", 1) != 0;
     if (tune_set("overlap")) { overlap_level = tune("overlap", 0); overlap_enabled = overlap_level != 0; }
     solo_max_agents = std::max(0, tune("solo_max", solo_max_agents));
+    batch_solo_max = std::max(0, tune("batch_solo_max", batch_solo_max));
 }
 
 template <class T>
@@ -1664,9 +1665,15 @@ void Env::step(int *done) {
 // Worlds of up to `solo_max_agents` agents step in ONE launch (k_step_solo).  Not taken: food_mode (its per-cell food
 // evaluation sweeps the map), hit lists that do not fit one workgroup's LDS, the A/B drivers, and steps that record attack
 // events for the text render.
+// Two limits (measured on the MI355X, profiles/r05_summary.md "one workgroup or a dozen launches"): an environment stepping on its own
+// is faster through the multi-launch pipeline from ~1500 agents on in battle (2 x 1200: 0.093 ms per cycle against 0.141; 2 x 2000:
+// 0.090 against 0.138; 2 x 8000: 0.109 against 0.389 -- one workgroup is one CU of 256) and level with it below; games with fewer
+// fighters per agent (gather, pursuit) cross over later, at 2500-3000, and lose 0.015 ms per cycle to the lower limit there.  An
+// environment that is one of a batch (env_cycle_many: one workgroup per environment, all in one launch) keeps the one-launch step up
+// to 16384 agents -- the other CUs are busy with the other environments.
 bool Env::solo_ok(int total_n) {
     return solo_enabled && !checked_step && !host_shuffle && !opt_fixed && first_render && !food_mode && !rules_on_host && total_n > 0 &&
-           total_n <= solo_max_agents && solo_nt_eval >= 64;
+           total_n <= (batch_width > 1 ? batch_solo_max : solo_max_agents) && solo_nt_eval >= 64;
 }
 
 // the host side of k_step_solo's report: spin on the sequence number in pinned memory (a stream synchronisation costs
@@ -2181,12 +2188,13 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
     int lead_e = -1;
     for (int e = 0; e < n_env; e++) {
         const int o = e * n_group;
+        envs[e]->batch_width = n_env;      // (solo_ok: the batch's limit; plan_render: the launch is shared)
         eligible[e] = envs[e]->cycle_eligible(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, nullptr);
         if (eligible[e] && lead_e < 0) lead_e = e;
     }
     std::vector<int> alone;
     if (lead_e < 0) {
-        for (int e = 0; e < n_env; e++) alone.push_back(e);
+        for (int e = 0; e < n_env; e++) { alone.push_back(e); envs[e]->batch_width = 1; }
         others(alone);
         return;
     }
@@ -2208,7 +2216,6 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
     std::vector<char> in_batch(n_env, 0);
     for (int e = 0; e < n_env; e++) {
         const int o = e * n_group;
-        envs[e]->batch_width = n_env;
         BatchItem &it = lead.batch_h[e];
         in_batch[e] = eligible[e] && envs[e]->device_id == lead.device_id &&
                       envs[e]->cycle_prepare(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
@@ -2232,7 +2239,7 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         launch_cycle_batch(lead.stream, lead.batch_d, n_env, slots, max_blocks, render_lds, step_lds);
         HIP_OK(hipGetLastError());
     }
-    for (int e = 0; e < n_env; e++) if (!in_batch[e]) alone.push_back(e);
+    for (int e = 0; e < n_env; e++) if (!in_batch[e]) { alone.push_back(e); envs[e]->batch_width = 1; }
     if (!alone.empty()) others(alone);
     const auto t2 = std::chrono::steady_clock::now();
     auto t3 = t2;
@@ -2240,6 +2247,7 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
     for (int e = 0; e < n_env; e++) {
         if (!in_batch[e]) continue;
         envs[e]->cycle_finish(&done[e]);
+        envs[e]->batch_width = 1;          // (whatever is called on the environment next is called on it alone)
         if (first) { t3 = std::chrono::steady_clock::now(); first = false; }
     }
     const auto t4 = std::chrono::steady_clock::now();

@@ -166,7 +166,8 @@ public:
     bool opt_fixed = false;
     // one-launch step of small worlds (k_step_solo): on by default, MAGENT_TUNE solo_step=0 keeps the multi-launch drivers
     bool solo_enabled = true;
-    int solo_max_agents = 16384;
+    int solo_max_agents = 1536;          // ... for an environment stepping on its own; as one of a batch (env_cycle_many):
+    int batch_solo_max = 16384;          // (Env::solo_ok: the measurements behind the two limits)
     double batch_us[4] = {0, 0, 0, 0};   // host time of env_cycle_many rounds led by this environment (info "batch_host_us")
     long batch_rounds = 0;
     int batch_width = 1;                 // environments rendered by the launch this one is part of (plan_render)

@@ -68,9 +68,12 @@ __global__ void k_set_tables(WorldView W, GroupDev *gtab, TypeDev *ttab) {
     int i = threadIdx.x;
     if (i < MAXG) { gtab[i] = W.grp[i]; ttab[i] = W.type[i]; }
 }
-// (MAGENT_TUNE scan_solo_max: tests lower it so that small worlds run the multi-block scans of the large ones)
+// clear_dead compacts groups of up to this many agents in one workgroup (MAGENT_TUNE scan_solo_max; tests lower it further so that
+// small worlds run the multi-block scans of the large ones).  1024 since round 5, measured (profiles/r05_summary.md): one workgroup
+// walking 20000 agents takes 0.108 ms where the block scans take 0.016 (battle 600 x 600, 2 x 20000: 0.202 -> 0.121 ms per cycle);
+// at 2 x 2000 the block scans are level or ahead (0.0100 against 0.0131)
 static int scan_solo_max() {
-    static const int v = std::max(0, std::min(SOLO_MAX, tune("scan_solo_max", SOLO_MAX)));
+    static const int v = std::max(0, std::min(SOLO_MAX, tune("scan_solo_max", 1024)));
     return v;
 }
 __global__ void __launch_bounds__(SCAN_THREADS) k_set_action_a(WorldView W, int g, const int *actions, int call_base, int *sums, int *wpre, int tile_off) {

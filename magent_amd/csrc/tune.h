@@ -8,8 +8,9 @@
 //   attack_pairs=N      optimistic pairs of attack rounds (0: none -- every step continues on the host)      default 1, 2 after a run-out
 //   move_batches=N      optimistic batches of generic move sweeps (0: none)                                   default 1, 2 after a run-out
 //   solo_step=0         worlds that would step in ONE launch (k_step_solo) take the multi-launch drivers
-//   solo_max=N          most agents a world may have to step in one launch                                   default 16384
-//   scan_solo_max=N     groups up to N agents compact in one workgroup (clear_dead)                          default 32768
+//   solo_max=N          most agents a world may have to step in one launch                                   default 1536
+//   batch_solo_max=N    ... when it is one of a batch (env_cycle_many)                                        default 16384
+//   scan_solo_max=N     groups up to N agents compact in one workgroup (clear_dead)                          default 1024
 //   overlap=1..3        set_action / the shuffle / the attack rounds on a second stream beside the renders   default 0 (measured: DESIGN 3.5)
 //   fold_minimap=0      the next minimap by k_minimap instead of clear_dead's own launches
 //   render=0|1|4        force k_render | k_render_fast | k_render_sweep2;  render_sweep=N workgroups, render_su=1..3 strips, render_depth=1..3
@@ -48,7 +49,7 @@ inline void tune_refuse_removed_variables() {
 inline int tune(const char *key, int dflt) {
     static const bool legacy_checked = (tune_refuse_removed_variables(), true);
     (void)legacy_checked;
-    static const char *const known[] = {"checked_step", "host_shuffle", "attack_pairs", "move_batches", "solo_step", "solo_max", "scan_solo_max", "overlap",
+    static const char *const known[] = {"checked_step", "host_shuffle", "attack_pairs", "move_batches", "solo_step", "solo_max", "batch_solo_max", "scan_solo_max", "overlap",
                                         "fold_minimap", "render", "render_sweep", "render_su", "render_depth", "att_threads", "policy_grid", "policy_stamps",
                                         "batch_cycle", "early_report", "touch_map"};
     const char *s = std::getenv("MAGENT_TUNE");

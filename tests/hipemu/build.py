@@ -20,7 +20,15 @@ DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\
 
 
 def build(force=False):
+    # one builder at a time (pytest-xdist workers, the tests' subprocesses): whoever waited finds the library fresh and returns
+    import fcntl
     os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(force)
+
+
+def _build(force):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "emu_runtime.cc"), os.path.join(HERE, "hip", "hip_runtime.h"),
                                                                  os.path.abspath(__file__)]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):

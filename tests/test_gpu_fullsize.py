@@ -93,6 +93,8 @@ VARIANTS = {
     "move_runs_out": {"MAGENT_TUNE": "move_batches=0"},
     "host_shuffle": {"MAGENT_TUNE": "host_shuffle=1"},
     "multi_launch_step": {"MAGENT_TUNE": "solo_step=0"},
+    # the one-launch step up to the limit it has inside a batch (an environment on its own leaves it at 1536 agents since round 5)
+    "one_launch_step_to_16384": {"MAGENT_TUNE": "solo_max=16384"},
     "multi_launch_side_stream": {"MAGENT_TUNE": "solo_step=0,overlap=3"},   # set_action and the head of the step beside the renders
     "multi_launch_late_report": {"MAGENT_TUNE": "solo_step=0,early_report=0"},   # the plain pipeline's report behind the moves (default: ahead of them)
     # the battle-shaped render kernels forced on small worlds (defaults: k_render_sweep2 only at scale, k_render_fast only for bf16 cells)
@@ -159,6 +161,21 @@ def test_fuzz_fused_cycle():
     out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "150"], env=env,
                          capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0 and "150 seeds, 0 failures" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
+
+
+def test_one_launch_cycle_between_the_two_limits():
+    """worlds between the limit of the one-launch step for an environment on its own (1536 agents) and its limit inside a batch (16384):
+    the two-launch cycle of env_cycle_many with the first limit raised to the second (what a batch of such worlds runs per environment),
+    and with the default limits (the same call falls back to the multi-launch pipeline); both against the oracle's call sequence"""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, helpers as H\n"
+            "for n in ('battle_brawl_big', 'battle_largemap', 'tri_rect_large', 'bodies_large', 'pursuit_large', 'gather_largemap', 'duo_large'):\n"
+            "    sc = H.scenarios()[n]\n"
+            "    H.assert_same(H.run_cycle(sc, H.ensure_oracle(), fused=False), H.run_cycle(sc, H.HIP_LIB, fused=True), n)\n"
+            "print('ok')\n") % (H.ROOT, os.path.join(H.ROOT, "tests"))
+    for extra in ({"MAGENT_TUNE": "solo_max=16384"}, {}):
+        p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"OMP_NUM_THREADS": "1"}, extra), capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])
 
 
 def test_fuzz_batched_cycle():

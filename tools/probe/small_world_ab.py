@@ -1,0 +1,6 @@
+import sys, os, json
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch, magent_amd, bench
+dev = torch.device("cuda", 0)
+r = bench.small_world_extras(torch, magent_amd, dev)
+print(os.environ.get("MAGENT_TUNE", "(defaults)"), {k: round(v["ms_per_cycle"], 4) for k, v in r.items()})
