@@ -817,7 +817,7 @@ def main():
                        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
                        "backend": (("control plane gloo; observation gather: " + ("RCCL (nccl)" if args.backend == "nccl" else "gloo")) if world > 1 else None),
                        "agents_at_start": R["n0"], "agents_at_end": R["agents_at_end"],
-                       "io": "device-resident (env_*_device C-ABI)", "steps_finished_by_host_driver": R["host_finished_steps"],
+                       "io": "device-resident (env_*_device C-ABI)", "tune": os.environ.get("MAGENT_TUNE") or None, "steps_finished_by_host_driver": R["host_finished_steps"],
                        "host_driver_rate": R["host_finished_steps"] / float(R["cycles_run"]),
                        # steps of the run by the last round of the death-rank fixed point that still changed something (index; one more round confirms)
                        "attack_round_hist": R["attack_round_hist"],
