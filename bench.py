@@ -843,8 +843,8 @@ def main():
                 extra["battle_fill_2x498002"] = {"agent_steps_per_s": F["agent_steps"] / F["elapsed"], "ms_per_step": F["elapsed"] / 10 * 1e3, "agents": F["n0"]}
                 # every other BASELINE configuration with the roofline of ITS render kernel (algorithmic bytes 4 * (VH*VW*C + F) per
                 # rendered agent: test_1m 5 channels without minimap, gather 15 x 15 x 7 = 6444 B, C2 the battle shape at 2 x 2000)
-                T = measure("test_1m", 0, 500000, 10, 3, True)
-                extra["test_1m_2x500k"] = {"agent_steps_per_s": T["agent_steps"] / T["elapsed"], "ms_per_step": T["elapsed"] / 10 * 1e3, "agents": T["n0"], "map": T["map_size"],
+                T = measure("test_1m", 0, 500000, 24, 4, True)       # (24 steps: 12 render launches between event pairs)
+                extra["test_1m_2x500k"] = {"agent_steps_per_s": T["agent_steps"] / T["elapsed"], "ms_per_step": T["elapsed"] / 24 * 1e3, "agents": T["n0"], "map": T["map_size"],
                                            "roofline": T["roofline"]}
                 # BASELINE config 5's world measured like the headline: battle 3536 x 3536, 2 x 499,849 agents in
                 # examples/train_battle.py's own formation (two squares 6 columns apart), and the same two lattices interleaved (the melee a
@@ -852,11 +852,11 @@ def main():
                 # the death-rank rounds it needed and the steps the host had to finish
                 extra["c5_cycle_3536"] = {}
                 for leg, wl in (("formation", "battle_c5"), ("melee", "battle_c5_melee")):
-                    C5 = measure(wl, 3536, 0, 10, 3, True)
-                    extra["c5_cycle_3536"][leg] = {"agent_steps_per_s": C5["agent_steps"] / C5["elapsed"], "ms_per_step": C5["elapsed"] / 10 * 1e3,
+                    C5 = measure(wl, 3536, 0, 24, 4, True)
+                    extra["c5_cycle_3536"][leg] = {"agent_steps_per_s": C5["agent_steps"] / C5["elapsed"], "ms_per_step": C5["elapsed"] / 24 * 1e3,
                                                    "agents": C5["n0"], "agents_at_end": C5["agents_at_end"], "roofline": C5["roofline"], "breakdown": C5["breakdown"],
                                                    "attack_round_hist": C5["attack_round_hist"], "steps_finished_by_host_driver": C5["host_finished_steps"]}
-                C4 = measure("gather", 500, 100000, 20, 5, True)
+                C4 = measure("gather", 500, 100000, 20, 5, True)     # (the agents of this game starve within a few dozen steps: a longer region would time a smaller world)
                 extra["gather_500_100k"] = {"agent_steps_per_s": C4["agent_steps"] / C4["elapsed"], "ms_per_step": C4["elapsed"] / 20 * 1e3, "agents": C4["n0"],
                                             "workload": "BASELINE config 4, one replica: gather 500x500 (train_gather.py), 100k agents + 20k food, only the agents act",
                                             "roofline": C4["roofline"], "breakdown": C4["breakdown"]}

@@ -63,9 +63,10 @@ int env_get_reward(EnvHandle game, GroupHandle group, float *buffer);
 
 /* runtime_api.h:33 -> GridWorld::get_info (GridWorld.cc:709-894).  names: num,id,pos,alive,global_minimap,
  * walls_info,render_window_info,attack_event,action_space,view_space,feature_space,view2attack,attack_base,
- * groups_info,both_attack (mean_info: deprecated in the reference, FATAL here).
- * Additive name: engine_stats -> int32[4] = {steps whose optimistic fixed-point rounds ran out and were finished by the
- * host-checked driver, attack rounds / move rounds of the last such continuation, attack rounds launched last step}. */
+ * groups_info,both_attack,mean_info ("deprecated" in the reference, GridWorld.cc:765-786: float[2 + n_action] = mean x,
+ * mean y, share of every action; served since round 5 -- only ask for groups that have been given actions: the reference
+ * counts an agent that never acted one past the end of a heap array).
+ * Additive names (tuning / tests): engine_stats -> int32[8], round_hist -> int32[9] (magent_amd/gridworld.py). */
 int env_get_info(EnvHandle game, GroupHandle group, const char *name, void *buffer);
 
 /* runtime_api.h:36-37 -> RenderGenerator (text video dump; host-side, off the hot path) */

@@ -2437,9 +2437,38 @@ void Env::info_host(int g, const char *name, void *buf) {
         return;
     }
     if (k == "both_attack") { ib[0] = 0; return; }
-    if (k == "mean_info") fatal("mean_info is deprecated in the reference and not provided by this engine");
     if (!device_ready) fatal("get_info(%s) called before reset", name);
     use_device();
+    if (k == "mean_info") {      // GridWorld.cc:765-786 ("deprecated" there; a cold path here: the arrays are fetched to the host)
+        // [mean x, mean y, share of every action]: float sums in agent order (the reference's loop under one OpenMP thread), dead agents that
+        // have not been cleared included, the last action of every agent counted.  An agent that has never been given an action holds
+        // n_action (GridWorld.h:140): the reference counts it one past the end of its `new int[n_action]`; here it is counted nowhere.
+        need_group();
+        HostGroup &G = groups[g];
+        const int n = G.n, na = G.type->n_action;
+        if (G.acted && !serial_calls_on && n > 0) {    // set_action came first: Agent::get_action shows the new action (as in observe_device)
+            join_side();
+            GroupDev D = G.cur; D.n = n;
+            launch_commit_action(stream, D, G.tdev);
+        }
+        HIP_OK(hipStreamSynchronize(stream));
+        std::vector<int> xs(n), ys(n), la(n);
+        if (n) {
+            HIP_OK(hipMemcpy(xs.data(), G.cur.x, sizeof(int) * n, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(ys.data(), G.cur.y, sizeof(int) * n, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(la.data(), G.cur.last_action, sizeof(int) * n, hipMemcpyDeviceToHost));
+        }
+        float sum_x = 0, sum_y = 0;
+        std::vector<int> counter(na, 0);
+        for (int i = 0; i < n; i++) {
+            sum_x += xs[i]; sum_y += ys[i];
+            if (la[i] >= 0 && la[i] < na) counter[la[i]]++;
+        }
+        const size_t agent_size = (size_t)n;
+        fb[0] = sum_x / agent_size; fb[1] = sum_y / agent_size;
+        for (int i = 0; i < na; i++) fb[2 + i] = (float)(1.0 * counter[i] / agent_size);
+        return;
+    }
     if (k == "id" || k == "pos" || k == "alive") {
         need_group();
         int n = groups[g].n;

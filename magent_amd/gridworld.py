@@ -312,7 +312,10 @@ class GridWorld(object):
         return self._info(-1, b"global_minimap", buf)
 
     def get_mean_info(self, handle):
-        raise NotImplementedError("mean_info is deprecated in the reference and not provided by this engine")
+        """-> float32[2 + n_action]: mean x, mean y, the share of every action among the group's last actions ("deprecated" in the reference,
+        gridworld.py:375-380, GridWorld.cc:765-786)"""
+        g = _gid(handle)
+        return self._info(g, b"mean_info", np.empty(2 + self.action_space[g][0], dtype=np.float32))
 
     def set_seed(self, seed):
         self._config("seed", int, int(seed))

@@ -820,6 +820,18 @@ int env_get_info(void *game, int group, const char *name, void *buf) {
             for (int j = 0; j < O.size(); j++) fb[((O.y[j] / sh) * vw + O.x[j] / sw) * NG + ch]++;
             for (int c = 0; c < vh * vw; c++) fb[c * NG + ch] /= O.size();
         }
+    } else if (k == "mean_info") {      // GridWorld.cc:765-786 ("deprecated"): float sums in agent order, Agent::get_action = the last action set
+        Group &G = e.groups[group];
+        const int na = G.type->n_action;
+        float sum_x = 0, sum_y = 0;
+        std::vector<int> counter(na, 0);      // (an agent never given an action holds n_action: one past the reference's array, counted nowhere here)
+        for (int i = 0; i < G.size(); i++) {
+            sum_x += G.x[i]; sum_y += G.y[i];
+            if (G.last_action[i] >= 0 && G.last_action[i] < na) counter[G.last_action[i]]++;
+        }
+        const size_t agent_size = (size_t)G.size();
+        fb[0] = sum_x / agent_size; fb[1] = sum_y / agent_size;
+        for (int i = 0; i < na; i++) fb[2 + i] = (float)(1.0 * counter[i] / agent_size);
     } else if (k == "walls_info") {
         int ct = 0;
         for (int c = 0; c < e.w * e.h; c++) if (e.occ_g[c] == WALL) { ct++; ib[2 * ct] = c % e.w; ib[2 * ct + 1] = c / e.w; }

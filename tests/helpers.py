@@ -441,6 +441,32 @@ def run(sc, lib, record=None, device_io=False, env_out=None):
     return out
 
 
+def mean_info_trace(sc, lib, steps=6):
+    """get_info("mean_info") (GridWorld.cc:765-786, "deprecated" there) of every acting, non-empty group of scenario `sc` at three points of
+    every step: between set_action and step (Agent::get_action already shows the new action), behind the step (the dead still counted), behind
+    clear_dead.  Only groups that have been given actions are asked: the reference counts an agent that never acted one past the end of a
+    heap array."""
+    env, handles = sc.build(lib)
+    rs = np.random.RandomState(sc.action_seed)
+    acting = sc.acting if sc.acting is not None else list(range(len(handles)))
+    out = []
+    for step in range(min(steps, sc.steps)):
+        sc.apply_events(env, step)
+        asked = []
+        for g, h in enumerate(handles):
+            n = env.get_num(h)
+            if g in acting:
+                env.set_action(h, sc.draw(rs, env, g, h, n))
+                if n > 0:
+                    asked.append(h)
+        out += [env.get_mean_info(h).copy() for h in asked]
+        env.step()
+        out += [env.get_mean_info(h).copy() for h in asked]
+        env.clear_dead()
+        out += [env.get_mean_info(h).copy() for h in asked if env.get_num(h) > 0]
+    return out
+
+
 def run_cycle(sc, lib, fused):
     """Play `sc` one environment CYCLE at a time (observe + set_action per group, step, rewards, clear_dead) and record what a
     caller of magent_amd.EnvBatch.cycle can see: observations, ids, rewards, done, and the state AFTER clear_dead.

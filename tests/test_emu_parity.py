@@ -33,6 +33,18 @@ def test_emulated_kernels_match_oracle(emu, name):
     H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, emu), name + " (hipemu)")
 
 
+def test_emulated_mean_info(emu):
+    """get_info("mean_info") of the engine (host arithmetic over the device's arrays; the pending actions of a set_action committed first)
+    against the oracle: between set_action and step, behind the step, behind clear_dead -- the one-launch step and the pipeline"""
+    import test_oracle
+    for name in test_oracle.MEAN_INFO:
+        sc = H.scenarios()[name]
+        want, got = H.mean_info_trace(sc, H.ensure_oracle()), H.mean_info_trace(sc, emu)
+        assert len(want) == len(got) and len(want) > 0, name
+        for k, (a, b) in enumerate(zip(want, got)):
+            assert a.tobytes() == b.tobytes(), (name, k, a, b)
+
+
 def test_emulated_kernels_do_not_depend_on_lane_order(emu):
     """the same under two scrambled lane / workgroup orders (a subprocess each: the order is fixed when the library starts)"""
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"

@@ -32,6 +32,23 @@ def test_hip_matches_oracle_and_golden(name, oracle):
     assert H.digest(got) == DIGESTS[name]["sha256"]     # the committed vectors from the compiled reference
 
 
+def test_mean_info_matches_oracle_and_reference(oracle):
+    """get_info("mean_info") (GridWorld.cc:765-786: mean position, the share of every action; float sums in agent order): the HIP engine
+    against the oracle -- and against the compiled reference where it travelled -- between set_action and step, behind the step and behind
+    clear_dead; scenarios of both step drivers (the one-launch step, the pipeline of large_map_mode worlds) and a large group (2 x 40,000)"""
+    names = ["battle_small_dense", "battle_walls", "battle_largemap_odd", "gather", "pursuit_dense", "tri_rect", "bodies", "bodies_turn", "battle_events",
+             "battle_brawl_dense_big"]
+    for name in names:
+        sc = SCENARIOS[name]
+        want, got = H.mean_info_trace(sc, oracle), H.mean_info_trace(sc, H.HIP_LIB)
+        assert len(want) == len(got) and len(want) > 0, name
+        for k, (a, b) in enumerate(zip(want, got)):
+            assert a.tobytes() == b.tobytes(), (name, k, a, b)
+        if H.have_ref():
+            ref = H.mean_info_trace(sc, H.REF_LIB)
+            assert [a.tobytes() for a in ref] == [a.tobytes() for a in got], name
+
+
 @pytest.mark.parametrize("name", sorted(k for k in SCENARIOS if SCENARIOS[k].engine and SCENARIOS[k].clear_every == 1))
 def test_fused_cycle_matches_oracle(name, oracle):
     """env_cycle_many / EnvBatch.cycle: a whole environment cycle in two launches for small worlds (k_render_multi, then

@@ -106,6 +106,21 @@ def test_oracle_matches_compiled_reference_on_random_games():
         H.assert_same(H.run(sc, H.REF_LIB), H.run(sc, ORACLE), sc.name)
 
 
+MEAN_INFO = ["battle_small_dense", "battle_walls", "battle_largemap_odd", "gather", "pursuit_dense", "tri_rect", "bodies", "bodies_turn", "battle_events"]
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) not present")
+def test_oracle_mean_info_matches_compiled_reference():
+    """get_info("mean_info") -- mean position and the share of every action, float sums in agent order -- between set_action and step,
+    behind the step and behind clear_dead (GridWorld.cc:765-786; the reference under one OpenMP thread, as every parity run)"""
+    for name in MEAN_INFO:
+        sc = H.scenarios()[name]
+        want, got = H.mean_info_trace(sc, H.REF_LIB), H.mean_info_trace(sc, ORACLE)
+        assert len(want) == len(got) and len(want) > 0, name
+        for k, (a, b) in enumerate(zip(want, got)):
+            assert a.tobytes() == b.tobytes(), (name, k, a, b)
+
+
 @pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) not present")
 def test_oracle_goal_mode_matches_compiled_reference(monkeypatch):
     """goal_mode (two feature slots nothing writes, GridWorld.cc:926-934) and set_goal between steps (two draws of the engine's
