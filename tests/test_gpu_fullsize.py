@@ -157,10 +157,13 @@ def test_fuzz_fused_cycle():
     """random games (40 % of them turn_mode) with the HIP leg driven through env_cycle_many -- a whole environment cycle in two
     launches: set_action, step, rewards, clear_dead and the next minimap inside k_step_solo -- against the oracle driven through the
     reference call sequence"""
-    env = dict(os.environ, OMP_NUM_THREADS="1", FUZZ_CYCLE="1", FUZZ_TURN="1")
-    out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "150"], env=env,
-                         capture_output=True, text=True, timeout=1200)
-    assert out.returncode == 0 and "150 seeds, 0 failures" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
+    # (with the one-launch step's limit for a single environment raised to the batch's: the two-launch cycle at every size a batch runs it;
+    # and with the defaults: worlds beyond 1536 agents fall back to the ordinary launches inside the same call)
+    for extra in ({"MAGENT_TUNE": "solo_max=16384"}, {}):
+        env = H.merge_env(os.environ, {"OMP_NUM_THREADS": "1", "FUZZ_CYCLE": "1", "FUZZ_TURN": "1"}, extra)
+        out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "120"], env=env,
+                             capture_output=True, text=True, timeout=1200)
+        assert out.returncode == 0 and "120 seeds, 0 failures" in out.stdout, (extra, out.stdout[-3000:], out.stderr[-2000:])
 
 
 def test_one_launch_cycle_between_the_two_limits():

@@ -43,7 +43,7 @@ for job in ${JOBS//,/ }; do
     callers) (cd $R && timeout 1800 python -m pytest tests/test_callers.py -x -q -m gpu -s 2>&1 | grep -v amdgpu.ids | tail -16) | tee $O/callers.log
              cp $R/gpurun_out/callers.json $O/ 2>/dev/null ;;
     fuzz)    (cd $R
-              run() { echo "-- $*"; env "$@" 2>&1 | tail -1; }
+              run() { echo "-- $*"; timeout 300 env "$@" 2>&1 | tail -1; }     # (a game whose rules make the reference's search cubic can take minutes in the ORACLE: bounded)
               F=${FUZZ_FROM:-0}; s() { echo $((F + $1)); }
               run python tools/fuzz_parity.py oracle hip $(s 0) $(s 600)
               run MAGENT_TUNE=solo_step=0 python tools/fuzz_parity.py oracle hip $(s 600) $(s 1600)
@@ -52,7 +52,10 @@ for job in ${JOBS//,/ }; do
               run MAGENT_TUNE=solo_step=0,move_batches=0 python tools/fuzz_parity.py oracle hip $(s 2700) $(s 3000)
               run FUZZ_TURN=1 MAGENT_TUNE=solo_step=0 python tools/fuzz_parity.py oracle hip $(s 0) $(s 300)
               run FUZZ_RULES=2 MAGENT_TUNE=solo_step=0 python tools/fuzz_parity.py oracle hip $(s 0) $(s 200)
-              run FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip $(s 0) $(s 300)) 2>&1 | tee $O/fuzz.log ;;
+              run FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip $(s 0) $(s 300)
+              # (the one-launch step at the sizes only a batch gives it by default since round 5: 1536 < agents <= 16384)
+              run MAGENT_TUNE=solo_max=16384 python tools/fuzz_parity.py oracle hip $(s 3000) $(s 3400)
+              run MAGENT_TUNE=solo_max=16384 FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip $(s 300) $(s 600)) 2>&1 | tee $O/fuzz.log ;;
     line)    (cd /tmp && export TMPDIR=/tmp && timeout 900 python $R/bench.py --no-cpu-baseline --no-extras --no-cold $ARGS > $O/line.json 2> $O/line.err)
              python - $O/line.json <<'PY'
 import json, sys
