@@ -20,10 +20,10 @@ REFERENCE_ABI = [
     ("env_delete_game", [_vp]),
     ("env_config_game", [_vp, _cp, _vp]),
     ("env_reset", [_vp]),
-    ("env_get_observation", [_vp, _i, _c.POINTER(_fp)]),
-    ("env_set_action", [_vp, _i, _ip]),
+    ("env_get_observation", [_vp, _i, _c.POINTER(_vp)]),      # float *buffers[2]: addresses (numpy's .ctypes.data costs a third of data_as)
+    ("env_set_action", [_vp, _i, _vp]),
     ("env_step", [_vp, _ip]),
-    ("env_get_reward", [_vp, _i, _fp]),
+    ("env_get_reward", [_vp, _i, _vp]),
     ("env_get_info", [_vp, _i, _cp, _vp]),
     ("env_render", [_vp]),
     ("env_render_next_file", [_vp]),

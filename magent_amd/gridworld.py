@@ -80,6 +80,8 @@ class GridWorld(object):
             config = _builtin_config(config, **kwargs)
 
         self.game = ctypes.c_void_p()
+        self._num = ctypes.c_int32(0)
+        self._num_ref = ctypes.byref(self._num)       # (get_num's out-parameter; one environment is driven by one thread at a time)
         L.env_new_game(ctypes.byref(self.game), b"GridWorld")
         _live_worlds.add(self)
 
@@ -187,7 +189,7 @@ class GridWorld(object):
             return self._observe_device_cached(g, n)
         view = self._buf(0, g, (n,) + self.view_space[g])
         feat = self._buf(1, g, (n,) + self.feature_space[g])
-        bufs = (_F32P * 2)(_f32(view), _f32(feat))
+        bufs = (ctypes.c_void_p * 2)(view.ctypes.data, feat.ctypes.data)
         self._lib.env_get_observation(self.game, g, bufs)
         return view, feat
 
@@ -251,7 +253,7 @@ class GridWorld(object):
             return
         assert isinstance(actions, np.ndarray) and actions.dtype == np.int32
         actions = np.ascontiguousarray(actions)
-        self._lib.env_set_action(self.game, _gid(handle), _i32(actions))
+        self._lib.env_set_action(self.game, _gid(handle), actions.ctypes.data)
 
     def step(self):
         done = ctypes.c_int32(0)
@@ -261,7 +263,7 @@ class GridWorld(object):
     def get_reward(self, handle):
         g = _gid(handle)
         out = np.empty(self.get_num(g), dtype=np.float32)
-        self._lib.env_get_reward(self.game, g, _f32(out))
+        self._lib.env_get_reward(self.game, g, out.ctypes.data)
         return out
 
     def clear_dead(self):
@@ -276,7 +278,9 @@ class GridWorld(object):
         return buf
 
     def get_num(self, handle):
-        return int(self._info(_gid(handle), b"num", np.zeros(1, dtype=np.int32))[0])
+        # (called by nearly every other method: a ctypes int kept for the purpose, not a fresh numpy array per call -- 6 -> 1.5 us)
+        self._lib.env_get_info(self.game, handle.value if hasattr(handle, "value") else int(handle), b"num", self._num_ref)
+        return self._num.value
 
     def get_action_space(self, handle):
         return self.action_space[_gid(handle)]
@@ -382,13 +386,13 @@ class GridWorld(object):
         self._require_device_api()
         g = _gid(handle)
         n = self.get_num(g)
-        dev = torch.device("cuda", self.device_id)
         if view is None:
-            view = torch.empty((n,) + self.view_space[g], dtype=torch.float32, device=dev)
+            view = torch.empty((n,) + self.view_space[g], dtype=torch.float32, device=torch.device("cuda", self.device_id))
         if feature is None:
-            feature = torch.empty((n,) + self.feature_space[g], dtype=torch.float32, device=dev)
+            feature = torch.empty((n,) + self.feature_space[g], dtype=torch.float32, device=torch.device("cuda", self.device_id))
         assert view.is_contiguous() and feature.is_contiguous()
-        assert view.numel() >= n * int(np.prod(self.view_space[g])) and feature.numel() >= n * self.feature_space[g][0]
+        vs = self.view_space[g]
+        assert view.numel() >= n * vs[0] * vs[1] * vs[2] and feature.numel() >= n * self.feature_space[g][0]
         ptrs = (ctypes.c_void_p * 2)(view.data_ptr(), feature.data_ptr())
         self._lib.env_get_observation_device(self.game, g, ptrs)
         return view, feature

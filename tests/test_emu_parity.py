@@ -121,10 +121,10 @@ def test_emulated_large_world_drivers(emu):
             "    H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, emu), n)\n"
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
     base = {"MAGENT_TUNE": "solo_step=0,scan_solo_max=100", "OMP_NUM_THREADS": "1"}
-    wide = "battle_brawl,battle_brawl_dense_big,battle_largemap_odd,gather_largemap,battle_grow,battle_events,tri_rect,bodies,forest"
+    wide = "battle_brawl,battle60,battle_largemap_odd,gather_largemap,battle_grow,battle_events,tri_rect,bodies,forest"     # (the 80,000-agent brawl: GPU suite)
     plain = "battle_brawl,battle_largemap_odd,gather_largemap,battle_grow"        # (one-cell bodies, large_map_mode among them)
     for extra, names in (({}, wide), ({"MAGENT_TUNE": "attack_pairs=0"}, plain), ({"MAGENT_TUNE": "fold_minimap=0"}, plain),
-                         ({"HIPEMU_SCRAMBLE": "3"}, plain + ",battle_brawl_dense_big"),
+                         ({"HIPEMU_SCRAMBLE": "3"}, plain + ",battle60"),
                          ({"MAGENT_TUNE": "move_batches=0,attack_pairs=0", "HIPEMU_SCRAMBLE": "11"}, plain)):
         p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"EMU_SCENARIOS": names}, base, extra), capture_output=True, text=True, timeout=900)
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])
@@ -151,8 +151,9 @@ def test_emulated_fused_step_of_plain_games(emu):
              "battle_no_clear,battle_tiny,gather,gather_largemap,battle_lowhp,quad,trans,chase,battle_events,battle_grow,rules_search,battle_epochs,battle_goal_mode")
     names = [n for n in plain.split(",") if n in H.scenarios()]
     assert len(names) == 21
-    for extra in ({"HIPEMU_SCRAMBLE": "5"}, {"MAGENT_TUNE": "attack_pairs=0,early_report=0", "HIPEMU_SCRAMBLE": "8"}):
-        p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"EMU_SCENARIOS": ",".join(names)}, base, extra), capture_output=True, text=True,
+    big = {"battle_brawl_big", "battle_largemap", "gather_largemap", "battle_fill_full"}      # (thousands of agents lane by lane: once)
+    for extra, chosen in (({"HIPEMU_SCRAMBLE": "5"}, names), ({"MAGENT_TUNE": "attack_pairs=0,early_report=0", "HIPEMU_SCRAMBLE": "8"}, [n for n in names if n not in big])):
+        p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"EMU_SCENARIOS": ",".join(chosen)}, base, extra), capture_output=True, text=True,
                            timeout=1500)
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])
 

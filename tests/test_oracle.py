@@ -39,8 +39,10 @@ def test_oracle_matches_golden_arrays(name):
 
 
 @pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) not present")
-@pytest.mark.parametrize("name", sorted(SCENARIOS))
+@pytest.mark.parametrize("name", sorted(k for k in SCENARIOS if k not in ("battle_brawl_dense_big", "battle_brawl_big")))
 def test_oracle_matches_compiled_reference(name):
+    # (the two largest brawls -- 80,000 and 9,000 agents, two minutes of the single-threaded reference -- are pinned to it through the digests
+    # tests/golden/make_golden.py took from the compiled reference: test_oracle_matches_golden_digest)
     H.assert_same(H.run(SCENARIOS[name], H.REF_LIB), H.run(SCENARIOS[name], ORACLE), name)
 
 
