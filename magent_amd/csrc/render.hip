@@ -193,8 +193,12 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_fast(RenderWorld W
 // ahead -- x / y one round further -- in a ring of register slots that is never copied (a copy of a register with a load in
 // flight waits for the load); the only branches are wave-uniform; a wave carries SU steps through SU LDS strips at once so that
 // their ds_write -> ds_read -> store round trips overlap.  (SU = 2, DV = 2 measured best; SU = 3 / 4 and two workgroups per CU lose.)
-template <bool CELLS16, int DV, int SU>
+// (MINI: the game has minimap channels -- 7 floats per cell [wall | has, hp, minimap | has, hp, minimap]; without -- round 5 -- 5: [wall | has, hp | has, hp],
+// the shape of the reference's pursuit-like 1M harness)
+template <bool CELLS16, int DV, int SU, bool MINI = true>
 __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_sweep2(RenderWorld W, RenderArgs R, RenderPlan P, int sweep) {
+    constexpr int C = MINI ? 7 : 5;                   // floats per window cell
+    constexpr int Q2 = 16 * C - 64;                   // a strip is 16 * C float4: 64 in a first store instruction, Q2 in a second
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int N = DV + 2;                         // ring slots: rounds r .. r + DV + 1
     const int VHW = R.VH * R.VW;
@@ -203,13 +207,13 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_sweep2(RenderWorld
         features_body<true>(W, R, P, blockIdx.x - sweep, gridDim.x - sweep);   // workgroups, where four waves per CU crawl through them)
         return;
     }
-    float *strips = (float *)smem + (size_t)wave * (SU * 64 * 7);
-    RenderFastPos *wtab = (RenderFastPos *)((float *)smem + RENDER_WAVES * SU * 64 * 7);
+    float *strips = (float *)smem + (size_t)wave * (SU * 64 * C);
+    RenderFastPos *wtab = (RenderFastPos *)((float *)smem + RENDER_WAVES * SU * 64 * C);
     const GroupDev Gd = W.grp;
     const TypeDev T = W.type;
     const unsigned total_cells = (unsigned)R.n * (unsigned)VHW;
     const unsigned total_steps = (total_cells + 63u) / 64u;
-    const size_t total_floats = (size_t)total_cells * 7;
+    const size_t total_floats = (size_t)total_cells * C;
     const unsigned *vc = (const unsigned *)W.viewcell;
     const unsigned g = (unsigned)R.g;
     const unsigned ncell_map = (unsigned)W.w * (unsigned)W.h;
@@ -217,8 +221,8 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_sweep2(RenderWorld
         const int vy = fdiv_u32(c, P.div_vw), vx = c - vy * R.VW;
         RenderFastPos e;
         e.dxy = ((T.view_y1 + vy) << 16) | ((T.view_x1 + vx) & 0xFFFF);
-        e.m0 = R.mini[(int)g * VHW + c];
-        e.m1 = R.mini[(1 - (int)g) * VHW + c];
+        e.m0 = MINI ? R.mini[(int)g * VHW + c] : 0.0f;
+        e.m1 = MINI ? R.mini[(1 - (int)g) * VHW + c] : 0.0f;
         e.mask = W.mask[T.mask_off + c];
         wtab[c] = e;
     }
@@ -261,7 +265,7 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_sweep2(RenderWorld
             const unsigned step0 = first_step(round + s);
             if (step0 >= total_steps) { running = false; break; }
             request((s + DV) % N);
-            float cs[SU][7];
+            float cs[SU][C];
 #pragma unroll
             for (int u = 0; u < SU; u++) {
                 const int cell = ic[s][u];
@@ -270,11 +274,16 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_sweep2(RenderWorld
                 const unsigned top = v0 >> 30;
                 const float hp = __uint_as_float(v0 & 0x3FFFFFFFu);
                 const bool mine = top == g, theirs = top == 1u - g;
-                const bool self = cell == (int)(fdiv_u32(y[s][u], P.div_scale_h) * R.VW + fdiv_u32(x[s][u], P.div_scale_w));
-                const float m0 = (self && wt.m0 == wt.m0) ? wt.m0 + 1.0f : wt.m0;
-                const float m1 = (self && wt.m1 == wt.m1) ? wt.m1 + 1.0f : wt.m1;
-                cs[u][0] = v0 == VC_WALL ? 1.0f : 0.0f; cs[u][1] = mine ? 1.0f : 0.0f; cs[u][2] = mine ? hp : 0.0f; cs[u][3] = m0;
-                cs[u][4] = theirs ? 1.0f : 0.0f; cs[u][5] = theirs ? hp : 0.0f; cs[u][6] = m1;
+                cs[u][0] = v0 == VC_WALL ? 1.0f : 0.0f; cs[u][1] = mine ? 1.0f : 0.0f; cs[u][2] = mine ? hp : 0.0f;
+                if (MINI) {
+                    const bool self = cell == (int)(fdiv_u32(y[s][u], P.div_scale_h) * R.VW + fdiv_u32(x[s][u], P.div_scale_w));
+                    const float m0 = (self && wt.m0 == wt.m0) ? wt.m0 + 1.0f : wt.m0;
+                    const float m1 = (self && wt.m1 == wt.m1) ? wt.m1 + 1.0f : wt.m1;
+                    cs[u][3] = m0;
+                    cs[u][C - 3] = theirs ? 1.0f : 0.0f; cs[u][C - 2] = theirs ? hp : 0.0f; cs[u][C - 1] = m1;
+                } else {
+                    cs[u][3] = theirs ? 1.0f : 0.0f; cs[u][4] = theirs ? hp : 0.0f;
+                }
             }
             const unsigned k_grp = step0 * 64u;
             if (CELLS16) {
@@ -283,45 +292,45 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_sweep2(RenderWorld
                     const unsigned k = k_grp + 64u * u + lane;
                     cell16_t o;
 #pragma unroll
-                    for (int e = 0; e < 7; e++) o[e] = (__bf16)cs[u][e];
+                    for (int e = 0; e < 7; e++) o[e] = (__bf16)(e < C ? cs[u][e < C ? e : 0] : 0.0f);
                     o[7] = (__bf16)1.0f;
                     if (k < total_cells) __builtin_nontemporal_store(o, (cell16_t *)R.view + k);
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < SU; u++) {
-                    float *dst = strips + u * (64 * 7) + lane * 7;
+                    float *dst = strips + u * (64 * C) + lane * C;
 #pragma unroll
-                    for (int e = 0; e < 7; e++) dst[e] = cs[u][e];
+                    for (int e = 0; e < C; e++) dst[e] = cs[u][e];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const size_t f_grp = (size_t)k_grp * 7;
-                if (total_floats - f_grp >= (size_t)(SU * 64 * 7)) {
+                const size_t f_grp = (size_t)k_grp * C;
+                if (total_floats - f_grp >= (size_t)(SU * 64 * C)) {
                     v4f q0[SU], q1[SU];
 #pragma unroll
                     for (int u = 0; u < SU; u++) {
-                        const v4f *src4 = (const v4f *)(strips + u * (64 * 7));
+                        const v4f *src4 = (const v4f *)(strips + u * (64 * C));
                         q0[u] = src4[lane];
-                        q1[u] = src4[lane + (lane < 48 ? 64 : 0)];   // (lanes 48..63 re-read a vector they do not store: no branch around the read)
+                        q1[u] = src4[lane + (lane < Q2 ? 64 : 0)];   // (lanes Q2..63 re-read a vector they do not store: no branch around the read)
                     }
 #pragma unroll
                     for (int u = 0; u < SU; u++) {
-                        v4f *out4 = (v4f *)(R.view + f_grp + (size_t)u * (64 * 7));
+                        v4f *out4 = (v4f *)(R.view + f_grp + (size_t)u * (64 * C));
                         __builtin_nontemporal_store(q0[u], out4 + lane);
-                        if (lane < 48) __builtin_nontemporal_store(q1[u], out4 + lane + 64);
+                        if (lane < Q2) __builtin_nontemporal_store(q1[u], out4 + lane + 64);
                     }
                 } else {
 #pragma unroll
                     for (int u = 0; u < SU; u++) {
-                        const size_t f0 = f_grp + (size_t)u * (64 * 7);
+                        const size_t f0 = f_grp + (size_t)u * (64 * C);
                         if (f0 >= total_floats) break;
                         const size_t remain = total_floats - f0;
-                        const float *strip_u = strips + u * (64 * 7);
-                        const int nq = remain >= (size_t)(64 * 7) ? 16 * 7 : (int)(remain >> 2);
+                        const float *strip_u = strips + u * (64 * C);
+                        const int nq = remain >= (size_t)(64 * C) ? 16 * C : (int)(remain >> 2);
                         for (int q = lane; q < nq; q += 64) __builtin_nontemporal_store(((const v4f *)strip_u)[q], (v4f *)(R.view + f0) + q);
-                        if (remain < (size_t)(64 * 7))
+                        if (remain < (size_t)(64 * C))
                             for (int e = (nq << 2) + lane; e < (int)remain; e += 64) R.view[f0 + e] = strip_u[e];
                     }
                 }
@@ -388,7 +397,11 @@ int launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const 
     size_t lds = (size_t)RENDER_WAVES * P.strip_floats * sizeof(float);
     dim3 grid(P.spans + P.feat_blocks), block(64 * RENDER_WAVES);
     const bool packed = W.vc_packed != 0;   // must match launch_paint
-    if (render_fast_ok(W, R, P, vec4 && nt)) {
+    // the sweeping kernel takes the two-group shapes with packed view cells: [wall | has, hp, minimap | ...] (battle, gather: also as bf16 cells and
+    // through k_render_fast) and, since round 5, [wall | has, hp | has, hp] (no minimap channels: the reference's pursuit-like 1M harness)
+    const bool fast_ok = render_fast_ok(W, R, P, vec4 && nt);
+    const bool sweep5_ok = vec4 && nt && W.G == 2 && !R.minimap && !R.food && R.C == 5 && W.vc_packed && !R.turn && !R.cells16 && R.VH * R.VW >= 16 && R.VH * R.VW <= 1024;
+    if (fast_ok || sweep5_ok) {
         // MAGENT_TUNE render: 0 generic kernels | 1 k_render_fast | 4 k_render_sweep2 | unset: bf16 cells -> 1; float32 -> 4 at scale, else generic
         static const int forced = tune("render", -1);
         static const int sweep_fixed = tune("render_sweep", 0);   // (tests: few workgroups, many rounds)
@@ -396,18 +409,21 @@ int launch_render(hipStream_t s, const WorldView &W, const RenderArgs &R, const 
         static const int dv_env = tune("render_depth", 2);
         const long long steps = ((long long)R.n * R.VH * R.VW + 63) / 64;
         const int VHW = R.VH * R.VW;
+        const int Cc = fast_ok ? 7 : 5;
         int mode = forced;
         if (mode < 0) mode = R.cells16 ? 1 : (steps >= 256ll * RENDER_WAVES * 2 * 8 ? 4 : 0);   // (a sweep wants >= 8 rounds of 256 workgroups)
+        if (mode == 1 && !fast_ok) mode = 0;
         if (mode == 4) {
             const int SUv = su_env >= 3 ? 3 : su_env >= 2 ? 2 : 1;
             const int sweep = (int)std::min<long long>(sweep_fixed > 0 ? sweep_fixed : 256, (steps + RENDER_WAVES * SUv - 1) / (RENDER_WAVES * SUv));
             dim3 sgrid(sweep + P.feat_blocks);
-            const size_t sl = (size_t)RENDER_WAVES * SUv * 64 * 7 * sizeof(float) + (size_t)VHW * sizeof(RenderFastPos);
+            const size_t sl = (size_t)RENDER_WAVES * SUv * 64 * Cc * sizeof(float) + (size_t)VHW * sizeof(RenderFastPos);
             const RenderPlan &Ps = P;
-#define SW2(C16, DVV, SUV) hipLaunchKernelGGL((k_render_sweep2<C16, DVV, SUV>), sgrid, block, sl, s, render_world(W, R.g), R, Ps, sweep)
-#define SW2D(C16, SUV) do { if (dv_env <= 1) SW2(C16, 1, SUV); else if (dv_env == 2) SW2(C16, 2, SUV); else SW2(C16, 3, SUV); } while (0)
-            if (R.cells16) { if (SUv == 3) SW2D(true, 3); else if (SUv == 2) SW2D(true, 2); else SW2D(true, 1); }
-            else { if (SUv == 3) SW2D(false, 3); else if (SUv == 2) SW2D(false, 2); else SW2D(false, 1); }
+#define SW2(C16, DVV, SUV, MI) hipLaunchKernelGGL((k_render_sweep2<C16, DVV, SUV, MI>), sgrid, block, sl, s, render_world(W, R.g), R, Ps, sweep)
+#define SW2D(C16, SUV, MI) do { if (dv_env <= 1) SW2(C16, 1, SUV, MI); else if (dv_env == 2) SW2(C16, 2, SUV, MI); else SW2(C16, 3, SUV, MI); } while (0)
+            if (!fast_ok) { if (SUv == 3) SW2D(false, 3, false); else if (SUv == 2) SW2D(false, 2, false); else SW2D(false, 1, false); }
+            else if (R.cells16) { if (SUv == 3) SW2D(true, 3, true); else if (SUv == 2) SW2D(true, 2, true); else SW2D(true, 1, true); }
+            else { if (SUv == 3) SW2D(false, 3, true); else if (SUv == 2) SW2D(false, 2, true); else SW2D(false, 1, true); }
 #undef SW2D
 #undef SW2
             return 4;

@@ -67,12 +67,12 @@ def test_emulated_battle_render_kernels(emu, knobs):
     """the battle-shaped render kernels (k_render_fast: LDS tables + one-step look-ahead; k_render_sweep2: persistent workgroups
     sweeping the output, register ring of requests, several strips per wave) forced onto small worlds with few workgroups, so
     that every workgroup plays many rounds: float32 observations against the oracle, and the bf16-cell form against the rounded
-    float32 one"""
+    float32 one; the sweeping kernel also in its 5-channel form (two groups without minimap channels: pursuit, forest, double_attack)"""
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import numpy as np, torch\n"
             "import helpers as H\n"
             "emu = H.ensure_emu()\n"
-            "for n in ('battle_small_dense', 'battle_walls', 'battle_largemap_odd', 'battle_tiny', 'battle_grow', 'gather'):\n"
+            "for n in ('battle_small_dense', 'battle_walls', 'battle_largemap_odd', 'battle_tiny', 'battle_grow', 'gather', 'pursuit_dense', 'forest', 'double_attack'):\n"
             "    sc = H.scenarios()[n]\n"
             "    H.assert_same(H.run(sc, H.ensure_oracle()), H.run(sc, emu), n)\n"
             "env = H.gridworld('battle', lib=emu, map_size=45)\n"

@@ -86,7 +86,7 @@ def test_bf16_cell_observation_at_full_size():
 # (read once per process) and must reproduce the oracle on dense scenarios: long attack chains, conga lines of movers,
 # multi-cell bodies, goals, three groups.
 DENSE = ["battle_brawl", "battle_brawl_big", "battle_brawl_dense_big", "battle_fill_full", "bodies_large", "tri_rect_large",
-         "arrange_live", "battle_food", "battle_turn_large", "bodies_turn", "bodies_turn_large", "arrange_turn"]
+         "arrange_live", "battle_food", "battle_turn_large", "bodies_turn", "bodies_turn_large", "arrange_turn", "pursuit_large"]
 VARIANTS = {
     "checked_step": {"MAGENT_TUNE": "checked_step=1"},
     "attack_runs_out": {"MAGENT_TUNE": "attack_pairs=0"},
