@@ -1652,6 +1652,7 @@ void Env::scratch_for(int path) {
     if (!claim_clean && !(path == 1 && claim_epochs)) {
         HIP_OK(hipMemsetAsync(d_claim, 0xFF, sizeof(unsigned long long) * ncell, stream));
         claim_clean = true;
+        if (path == 1) claim_refills++;
     }
     if (path == 0) claim_epochs = true;                // (filled is a special case of "filled or written in this window")
     else { claim_clean = false; claim_epochs = true; }
@@ -1777,6 +1778,7 @@ void Env::step_begin() {
             if (overlap_level == 2 && a != stream) { join_side(); a = stream; }
             attack_round = 0;
             const int pairs = opt_fixed ? opt_attack_pairs : (boost_attack > 0 ? 2 : 1);
+            if (plain) { if (pairs >= 2) pairs_two_steps++; else if (pairs == 1) pairs_one_steps++; }
             // rounds after the first only touch agents whose inputs changed: they are launched back to back and the
             // LAST one reports whether anything still moved (one gate for all of them)
             if (plain) {
@@ -2031,7 +2033,7 @@ bool Env::cycle_eligible(int n_group, float *const *view, float *const *feat, in
     if (n_group != NG) fatal("env_cycle_many: n_group (%d) differs from the number of groups (%d)", n_group, NG);
     int total_n = 0;
     for (auto &g : groups) total_n += g.n;
-    bool fused = solo_ok(total_n) && !step_pending;
+    bool fused = solo_ok(total_n) && !step_pending && !serial_calls_on;   // (a group given actions twice: the literal loop, by the call sequence)
     // the observed groups must share one minimap (same window, same "skip absorbed" rule) to be rendered by one launch
     int n_obs = 0, first_obs = -1;
     for (int g = 0; g < NG && fused; g++) {
@@ -2066,6 +2068,10 @@ bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, con
     M = RenderMulti{};
     for (int g = 0; g < NG; g++) {
         if (!(view && view[g]) || groups[g].n == 0) continue;
+        if (groups[g].acted) {      // env_set_action_device came first: the feature rows show the new last_action (as in observe_device)
+            GroupDev G = groups[g].cur; G.n = groups[g].n;
+            launch_commit_action(stream, G, groups[g].tdev);
+        }
         const int k = M.n++;
         prepare_render(g, W, M.R[k], M.P[k], view[g], feat[g]);
         M.blocks[k] = M.P[k].spans + M.P[k].feat_blocks;
@@ -2074,6 +2080,14 @@ bool Env::cycle_prepare(int n_group, float *const *view, float *const *feat, con
     shuffle_buffers(total_n);
     push_rng();
     scratch_for(0);
+    {   // groups that were given their actions by env_set_action_device before this call (a NULL entry in `actions`): when the world was
+        // beyond the one-launch step's limit for an environment on its own (but within the batch's), that call left tile counts -- the
+        // sequence numbers and the attack list's length are written out here, as Env::step_begin does
+        bool first = true;
+        for (int g = 0; g < NG; g++)
+            if (groups[g].sa_off >= 0) { launch_seq_assign(stream, W, g, d_asums, d_wpre, groups[g].sa_off, first); first = false; groups[g].sa_off = -1; }
+        step_calls.clear();
+    }
     step_live_paint = live_paint_now = paint_valid;
     W.live_paint = step_live_paint ? 1 : 0;
     const ShuffleBufs B = shuffle_bufs();
@@ -2397,6 +2411,14 @@ void Env::info_host(int g, const char *name, void *buf) {
         ib[7] = plain_steps;                                 // steps that took the fused passes of plain games (k_strike ...)
         return;
     }
+    if (k == "pipeline_stats") { // additive (tests): what only changes with the LENGTH of an episode of the plain pipeline
+        ib[0] = plain_steps;                                 // steps through k_plain_rank ... k_plain_commit
+        ib[1] = pairs_two_steps; ib[2] = pairs_one_steps;    // ... launched with two / with one optimistic pair of death-rank rounds
+        ib[3] = claim_refills;                               // times the claim words were refilled for such a step (a new window of 63 epochs, or another path wrote them)
+        ib[4] = (int)(plain_epoch % 63u);                    // where the current window stands
+        ib[5] = fallback_attack;                             // steps whose optimistic rounds ran out
+        return;
+    }
     if (k == "round_hist") {     // additive (tuning): plain steps since the last read by the last round of the death-rank fixed point that
         // still changed something (0: none did; one more round than that was needed to see it converge), steps that ran out not counted
         for (int q = 0; q < 9; q++) { ib[q] = round_hist[q]; round_hist[q] = 0; }
@@ -2446,6 +2468,7 @@ void Env::info_host(int g, const char *name, void *buf) {
         need_group();
         HostGroup &G = groups[g];
         const int n = G.n, na = G.type->n_action;
+        if (n == 0) fatal("get_info(mean_info) of an empty group (the reference asserts agent_size != 0 here, GridWorld.cc:782)");
         if (G.acted && !serial_calls_on && n > 0) {    // set_action came first: Agent::get_action shows the new action (as in observe_device)
             join_side();
             GroupDev D = G.cur; D.n = n;

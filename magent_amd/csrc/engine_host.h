@@ -225,6 +225,7 @@ private:
     bool hit_clean = false;               // every hit word is zero (both of those steps keep it so)
     void scratch_for(int path);
     int plain_steps = 0, plain_slots = 0;
+    int pairs_two_steps = 0, pairs_one_steps = 0, claim_refills = 0;   // (env_get_info "pipeline_stats")
     bool plain_world = false, step_was_plain = false, step_fused_rules = false, ptab_valid = false;
     PlainGroup *d_ptab = nullptr;
     int *d_alive = nullptr; size_t alive_cap = 0;      // survivors per 256 agents, left by k_strike for clear_dead (PlainWorld::alive)

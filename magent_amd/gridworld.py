@@ -495,6 +495,13 @@ class GridWorld(object):
         self._lib.env_get_info(self.game, 0, b"engine_stats", buf.ctypes.data)
         return tuple(int(v) for v in buf)
 
+    def pipeline_stats(self):
+        """additive (tests): (steps of the plain pipeline, of which launched with two optimistic pairs of death-rank rounds, with one, refills
+        of the claim words for such steps, position in the current window of 63 epochs, steps whose optimistic rounds ran out)"""
+        buf = np.zeros(6, dtype=np.int32)
+        self._lib.env_get_info(self.game, 0, b"pipeline_stats", buf.ctypes.data)
+        return tuple(int(v) for v in buf)
+
     def round_hist(self):
         """additive (tuning): plain steps since the last call, by the last attack round that still changed a death rank"""
         buf = np.zeros(9, dtype=np.int32)

@@ -467,7 +467,7 @@ def mean_info_trace(sc, lib, steps=6):
     return out
 
 
-def run_cycle(sc, lib, fused):
+def run_cycle(sc, lib, fused, preset=False):
     """Play `sc` one environment CYCLE at a time (observe + set_action per group, step, rewards, clear_dead) and record what a
     caller of magent_amd.EnvBatch.cycle can see: observations, ids, rewards, done, and the state AFTER clear_dead.
 
@@ -504,11 +504,15 @@ def run_cycle(sc, lib, fused):
                     rec["view%d" % g], rec["feat%d" % g] = views[g].cpu().numpy(), feats[g].cpu().numpy()
                 rec["reward%d" % g] = rews[g].cpu().numpy()
         else:
+            assert not (preset and fused)
+            for g, h in enumerate(handles):       # (preset: every set_action ahead of every observation)
+                if preset and acts[g] is not None:
+                    env.set_action(h, acts[g])
             for g, h in enumerate(handles):
                 if observe[g]:
                     v, f = env.get_observation(h)
                     rec["view%d" % g], rec["feat%d" % g] = v.copy(), f.copy()
-                if acts[g] is not None:
+                if not preset and acts[g] is not None:
                     env.set_action(h, acts[g])
             done = env.step()
             for g, h in enumerate(handles):
@@ -526,11 +530,14 @@ def run_cycle(sc, lib, fused):
     return out
 
 
-def run_cycle_batch(scs, lib):
+def run_cycle_batch(scs, lib, preset=False):
     """run_cycle(fused=True) for SEVERAL environments of one configuration at once: a single magent_amd.EnvBatch, so that for
     small worlds all of them share one pair of launches per cycle (k_render_batch + k_step_solo_batch).  Returns one trajectory
     per scenario; an environment whose groups are all empty keeps cycling with the others (its trajectory stops there, as
-    run_cycle's does)."""
+    run_cycle's does).
+    preset: the actions are handed over by env_set_action_device BEFORE the call and the cycle is given none (the NULL entries
+    include/magent_runtime_api.h documents): the observations then show the new last_action, as the reference's do when
+    set_action comes first (GridWorld.cc:386-396) -- the checker's leg is run_cycle(..., preset=True)."""
     import torch
     built = [sc.build(lib) for sc in scs]
     envs, handles = [b[0] for b in built], [b[1] for b in built]
@@ -557,7 +564,14 @@ def run_cycle_batch(scs, lib):
             rews.append([torch.empty(nums[g], device=dev) for g in range(len(hs))])
             recs.append(rec); observes.append(observe)
         device_sync(lib)
-        dones = batch.cycle(views, feats, d_acts, rews)
+        if preset:
+            for env, hs, per_env in zip(envs, handles, d_acts):
+                for h, a in zip(hs, per_env):
+                    if a is not None:
+                        env.set_action_device(h, a)
+            dones = batch.cycle(views, feats, None, rews)
+        else:
+            dones = batch.cycle(views, feats, d_acts, rews)
         for k, (sc, env, hs) in enumerate(zip(scs, envs, handles)):
             env.sync()
             rec = recs[k]
@@ -578,7 +592,7 @@ def run_cycle_batch(scs, lib):
     return out
 
 
-def run_hashed(sc, lib, device_io=False):
+def run_hashed(sc, lib, device_io=False, env_out=None):
     """run(sc, lib) for sizes whose trajectories do not fit in memory: every array of every step is reduced to its
     xxh3-128 (10 GB/s on one core; SHA-256 would cost more than the engines) as soon as the step is over.
     Returns [{key: hex digest} per step]."""
@@ -590,7 +604,7 @@ def run_hashed(sc, lib, device_io=False):
                       for k, v in rec.items()})
         rec.clear()
 
-    run(sc, lib, record=keep, device_io=device_io)
+    run(sc, lib, record=keep, device_io=device_io, env_out=env_out)
     return steps
 
 
@@ -643,9 +657,18 @@ def fullsize_scenarios():
         # ~300k attack-list entries compared bit for bit at 2 x 400k
         Scenario("c3_battle1000_deaths", "battle", 1000, place=[rnd(0, 400000), rnd(1, 400000)], steps=6,
                  over={"small": {"hp": 4, "damage": 3}}),
-        # C3(i) as bench.py plays it: default hp (10) / damage (2), 30 steps -- the first deaths come after a few steps, then
-        # compaction every step; the horizon of a bench run (25 cycles) and more
-        Scenario("c3_battle1000_long", "battle", 1000, place=[rnd(0, 400000), rnd(1, 400000)], steps=30),
+        # C3(i) as bench.py plays it: default hp (10) / damage (2), 72 steps -- the first deaths come after a few steps, then
+        # compaction every step; longer than a bench run (25 cycles), and past the two things of the plain pipeline that only change
+        # with the length of an episode: the refill of the claim words (every 63 steps) and the fall from two optimistic pairs of
+        # death-rank rounds to one (after 64 steps that did not need the second)
+        Scenario("c3_battle1000_long", "battle", 1000, place=[rnd(0, 400000), rnd(1, 400000)], steps=72),
+        # a whole episode's length of the multi-launch pipeline at a size the reference plays in a minute: battle 300 x 300, 2 x 10,000,
+        # hp 4 / damage 3, 200 steps (examples/train_battle.py plays rounds of 550), reinforcements at steps 70 and 130 so that there are
+        # kills in every one of the 200 steps -- three windows of claim-word epochs, the carried round stamps, both pair budgets
+        Scenario("battle300_long", "battle", 300, place=[rnd(0, 10000), rnd(1, 10000)], steps=200, action_seed=77,
+                 over={"small": {"hp": 4, "damage": 3}},
+                 events={70: [("add", 0, "random", {"n": 9000}), ("add", 1, "random", {"n": 9000})],
+                         130: [("add", 0, "random", {"n": 9000}), ("add", 1, "random", {"n": 9000})]}),
         # C4: gather 500x500 (train_gather.py), 20k food + 100k agents, only the agents act
         Scenario("c4_gather500", "gather", 500, place=[rnd(0, 20000), rnd(1, 100000)], acting=[1], steps=8),
         # the reference's own 1M harness (scripts/test/test_1m.py:62-71): map sqrt(20 N), N/10 walls, N/2 2x2 predators, N/2 prey
@@ -659,6 +682,14 @@ def fullsize_scenarios():
                  over={"small": {"hp": 4, "damage": 3}}),
     ]
     return {s.name: s for s in S}
+
+
+def preset_batch_scenarios():
+    """two battle worlds between the one-launch step's limit for an environment on its own (1536 agents) and its limit inside a batch
+    (16384): env_set_action_device on such a world leaves tile counts (the multi-launch form), and a batch then steps it in one launch"""
+    rnd = lambda g, n: (g, "random", {"n": n})
+    return [Scenario("preset_a", "battle", 60, place=[rnd(0, 1000), rnd(1, 1000)], steps=6, action_seed=81, over={"small": {"hp": 4, "damage": 3}}),
+            Scenario("preset_b", "battle", 60, place=[rnd(0, 900), rnd(1, 1100)], steps=6, action_seed=82, seed=4242, over={"small": {"hp": 4, "damage": 3}})]
 
 
 def render_episode(lib, out_dir, steps=6, twice=False):

@@ -158,6 +158,16 @@ def test_emulated_fused_step_of_plain_games(emu):
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])
 
 
+def test_emulated_batch_cycle_of_worlds_given_their_actions_beforehand(emu):
+    """env_set_action_device on a world of 1537..16384 agents takes the tiled form (attack counts in spread counters, no
+    sequence numbers yet); env_cycle_many over two such environments with NULL action entries then steps each in ONE launch -- which needs
+    the numbers written out first (Env::cycle_prepare: k_seq_assign, as Env::step_begin does) and the new last_action in the feature rows"""
+    scs = H.preset_batch_scenarios()
+    got = H.run_cycle_batch(scs, emu, preset=True)
+    for sc, g in zip(scs, got):
+        H.assert_same(H.run_cycle(sc, H.ensure_oracle(), fused=False, preset=True), g, sc.name + " (preset actions, batch of 2, hipemu)")
+
+
 @pytest.mark.parametrize("env,needle", [({"MAGENT_SOLO_STEP": "0"}, "MAGENT_TUNE=solo_step="), ({"MAGENT_RENDER_PAD": "1"}, "has no successor"),
                                         ({"MAGENT_TUNE": "solo_stepp=0"}, "unknown entry")],
                          ids=["removed_variable_with_successor", "removed_variable_without", "unknown_tune_key"])

@@ -22,6 +22,15 @@ with open(os.path.join(H.GOLDEN_DIR, "digests_fullsize.json")) as f:
     GOLD = json.load(f)
 
 
+def _golden_check(names, tune=None, device_io=False, timeout=1500):
+    env = H.merge_env(os.environ, {"OMP_NUM_THREADS": "1"}, {"MAGENT_TUNE": tune} if tune else {})
+    cmd = [sys.executable, os.path.join(H.ROOT, "tools", "gpu_golden_check.py")] + (["--device-io"] if device_io else []) + list(names)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == len(names) and all(l["ok"] for l in lines), (tune, out.stdout[-3000:], out.stderr[-2000:])
+    return {l["name"]: l for l in lines}
+
+
 @pytest.mark.parametrize("name", sorted(FULL))
 def test_fullsize_matches_reference_digest_and_oracle(name):
     """c2_battle200 (40 steps), c3_battle1000_deaths (2x400k, hp 4 / damage 3, 6 steps: kills, dead_penalty, compaction,
@@ -45,11 +54,16 @@ def test_fullsize_matches_reference_digest_and_oracle(name):
 def test_fullsize_device_abi_matches_reference_digest(name):
     """the call sequence bench.py TIMES (env_get_observation_device into caller-owned tensors sized once, env_set_action_device,
     env_get_reward_device) at 2 x 400k agents, against the digests of the compiled reference: `c3_battle1000_long` is the bench
-    workload itself (default hp, 30 steps: longer than a bench run) -- every view, feature row, reward, position, alive flag of
-    every step.  `c5_battle3536_*`: BASELINE config 5's world (examples/train_battle.py --map_size 3536: 2 x 499,849 agents in the
-    script's own formation, 12.5 M cells) and the same two lattices interleaved (a million agents with hostile neighbours)"""
-    got = H.run_hashed(FULL[name], H.HIP_LIB, device_io=True)
-    H.assert_same_hashed(GOLD[name], got, name + " (device ABI) vs compiled-reference digest")
+    workload itself (default hp, 72 steps: three bench runs long, and past the first refill of the plain pipeline's claim words at
+    step 63 and the fall from two optimistic pairs of death-rank rounds to one after step 64 -- both asserted from the engine's own
+    counters) -- every view, feature row, reward, position, alive flag of every step.  `c5_battle3536_*`: BASELINE config 5's world
+    (examples/train_battle.py --map_size 3536: 2 x 499,849 agents in the script's own formation, 12.5 M cells) and the same two
+    lattices interleaved (a million agents with hostile neighbours)"""
+    r = _golden_check([name], device_io=True, timeout=2400)[name]
+    plain_steps, two, one, refills, _, _ = r["pipeline_stats"]
+    assert plain_steps == r["steps"] == FULL[name].steps, r          # the multi-launch pipeline played every step
+    if name == "c3_battle1000_long":
+        assert refills >= 2 and two >= 64 and one >= 1, r
 
 
 def test_bf16_cell_observation_at_full_size():
@@ -85,7 +99,9 @@ def test_bf16_cell_observation_at_full_size():
 # path for the rare step whose optimistic fixed-point rounds run out.  Each variant is forced through the environment
 # (read once per process) and must reproduce the oracle on dense scenarios: long attack chains, conga lines of movers,
 # multi-cell bodies, goals, three groups.
-DENSE = ["battle_brawl", "battle_brawl_big", "battle_brawl_dense_big", "battle_fill_full", "bodies_large", "tri_rect_large",
+# (battle_epochs: 140 steps, 180-420 agents -- with solo_step=0 the multi-launch pipeline plays it: the claim words' epoch window
+# is refilled twice and the budget of optimistic rounds falls from two pairs to one on the way)
+DENSE = ["battle_epochs", "battle_brawl", "battle_brawl_big", "battle_brawl_dense_big", "battle_fill_full", "bodies_large", "tri_rect_large",
          "arrange_live", "battle_food", "battle_turn_large", "bodies_turn", "bodies_turn_large", "arrange_turn", "pursuit_large"]
 VARIANTS = {
     "checked_step": {"MAGENT_TUNE": "checked_step=1"},
@@ -111,6 +127,27 @@ def test_step_driver_variants(variant):
                          text=True, timeout=900)
     assert out.returncode == 0 and "failures: 0" in out.stdout, (out.stdout[-3000:], out.stderr[-2000:])
     assert out.stdout.count("OK  ") == len(DENSE)
+
+
+@pytest.mark.parametrize("tune", [None, "attack_pairs=0", "early_report=0", "overlap=3"], ids=["default", "attack_runs_out", "late_report", "side_stream"])
+def test_long_episodes_of_the_plain_pipeline(tune):
+    """What only acts with the LENGTH of an episode: the plain pipeline's claim words carry a 6-bit epoch and
+    are refilled when a window of 63 steps begins (Env::scratch_for), the "inputs changed" round stamps count on from step to step
+    (PlainWorld::round_base), and the step driver falls from two optimistic pairs of death-rank rounds to one after 64 steps that did not
+    need the second (Env::reset / step_end).  `battle300_long`: battle 300 x 300, 2 x 10,000 agents, hp 4 / damage 3, 200 steps with
+    reinforcements at steps 70 and 130 -- kills in every step, three windows -- through the multi-launch pipeline (the default driver at
+    this size), every array of every step against the digests of the COMPILED REFERENCE; also with every step's rounds running out
+    (the host-checked continuation for 200 steps), with the report behind the moves, and with the head of the step on the side stream.
+    The test asserts that the pipeline really played every step, that the window was refilled, and that both pair budgets were used.
+    (A refill every 64 steps instead of 63 makes this test fail: tests/README.md, profiles/r06_raw/mutation_refill.txt.)"""
+    r = _golden_check(["battle300_long"], tune)["battle300_long"]
+    plain_steps, two, one, refills, _, ran_out = r["pipeline_stats"]
+    assert r["steps"] == 200 and plain_steps == 200, r
+    assert refills >= 4, r                     # the first step, steps 63 / 126 / 189 (the reinforcements' steps too: add_agents keeps the words)
+    if tune == "attack_pairs=0":
+        assert ran_out == 200, r               # every step was finished by the host-checked driver
+    else:
+        assert two >= 64 and one >= 1 and two + one == 200, r   # ... the fall from two pairs to one happened
 
 
 def test_fuzz_rule_search_on_the_host_path():

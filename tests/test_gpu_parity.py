@@ -58,6 +58,15 @@ def test_fused_cycle_matches_oracle(name, oracle):
     H.assert_same(want, got, name + " (cycle)")
 
 
+def test_batch_cycle_of_worlds_given_their_actions_beforehand(oracle):
+    """env_set_action_device on worlds of 2000 agents (beyond the one-launch step's limit for an environment on its own:
+    the tiled set_action), then EnvBatch.cycle with no actions over the two of them (within the batch's limit: one launch per step)"""
+    scs = H.preset_batch_scenarios()
+    got = H.run_cycle_batch(scs, H.HIP_LIB, preset=True)
+    for sc, g in zip(scs, got):
+        H.assert_same(H.run_cycle(sc, oracle, fused=False, preset=True), g, sc.name + " (preset actions, batch of 2)")
+
+
 @pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) did not travel")
 @pytest.mark.parametrize("name", ["battle_brawl", "battle_largemap", "gather"])
 def test_hip_matches_compiled_reference(name):
