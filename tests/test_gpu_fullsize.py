@@ -60,10 +60,12 @@ def test_fullsize_device_abi_matches_reference_digest(name):
     (examples/train_battle.py --map_size 3536: 2 x 499,849 agents in the script's own formation, 12.5 M cells) and the same two
     lattices interleaved (a million agents with hostile neighbours)"""
     r = _golden_check([name], device_io=True, timeout=2400)[name]
-    plain_steps, two, one, refills, _, _ = r["pipeline_stats"]
+    plain_steps, two, one, refills, _, ran_out = r["pipeline_stats"]
     assert plain_steps == r["steps"] == FULL[name].steps, r          # the multi-launch pipeline played every step
     if name == "c3_battle1000_long":
-        assert refills >= 2 and two >= 64 and one >= 1, r
+        # (a step whose rounds run out puts the budget back to two pairs for 64 steps: on the MI355X that happens once in this episode,
+        # so the fall to one pair is asserted where it does happen -- test_long_episodes_of_the_plain_pipeline)
+        assert refills >= 2 and two >= 64 and two + one == 72 and (one >= 1 or ran_out >= 1), r
 
 
 def test_bf16_cell_observation_at_full_size():
