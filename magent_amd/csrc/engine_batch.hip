@@ -173,84 +173,322 @@ void Env::cycle(int n_group, float *const *view, float *const *feat, const int *
 }
 
 // many small environments, one pair of launches: every environment that can take the two-launch cycle is described in an
-// item of a device array (one workgroup of k_step_solo_batch each); the others go one by one
-// (others: called once the batch's launches are enqueued, with the list of environments that did NOT take the two-launch form --
-// too large for the one-launch step, food_mode, rules on the host; they keep their own streams and the caller runs their
-// ordinary cycles, on its host threads, while the batch is in flight)
+// item of a device array (one workgroup of k_step_solo_batch each); worlds beyond the one-launch step whose game the pipeline of plain
+// games takes share ONE chain of launches (pipe.hip); the others go one by one
+// (others: called once the batches' launches are enqueued, with the list of environments that took neither form -- food_mode, rules on the
+// host, generic bodies beyond the one-launch step ...; they keep their own streams and the caller runs their ordinary cycles, on its host
+// threads, while the batches are in flight)
 void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **feat, const int **actions, float **rewards, int *done,
                      const std::function<void(const std::vector<int> &)> &others) {
-    // the batch shares the stream of its first eligible environment: launches need no cross-stream events.  Environments that
-    // cannot join are not touched (they used to adopt the stream too and then ran one after the other)
-    std::vector<char> eligible(n_env, 0);
-    int lead_e = -1;
+    // Which form does every environment take?  kind 1: the two-launch cycle (one workgroup steps the world); kind 2: the batched pipeline.
+    // A world that could take either goes to the pipeline from `batch_pipe_min` agents on (measured on the MI355X, profiles/r06_summary.md:
+    // one workgroup steps 4000 agents in ~0.3 ms whatever else the chip does; 32 such worlds through the pipeline share ~0.2 ms)
+    static const int pipe_min = std::max(1, tune("batch_pipe_min", 1537));
+    static const bool pipe_on = tune("batch_pipe", 1) != 0;
+    std::vector<char> kind(n_env, 0);
+    std::vector<int> alone;
+    int n_pipe = 0;
     for (int e = 0; e < n_env; e++) {
         const int o = e * n_group;
         envs[e]->batch_width = n_env;      // (solo_ok: the batch's limit; plan_render: the launch is shared)
-        eligible[e] = envs[e]->cycle_eligible(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, nullptr);
-        if (eligible[e] && lead_e < 0) lead_e = e;
+        const bool solo = envs[e]->cycle_eligible(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, nullptr);
+        int total = 0;
+        const bool pipe = pipe_on && envs[e]->pipe_eligible(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr, &total);
+        kind[e] = pipe && (!solo || total >= pipe_min) ? 2 : solo ? 1 : 0;
+        n_pipe += kind[e] == 2;
     }
-    std::vector<int> alone;
-    if (lead_e < 0) {
-        for (int e = 0; e < n_env; e++) { alone.push_back(e); envs[e]->batch_width = 1; }
-        others(alone);
-        return;
-    }
-    Env &lead = *envs[lead_e];
-    lead.use_device();
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int e = 0; e < n_env; e++) if (eligible[e] && e != lead_e) envs[e]->adopt_stream(lead);
-    if ((size_t)n_env > lead.batch_cap) {
-        HIP_OK(hipStreamSynchronize(lead.stream));
-        if (lead.batch_h) HIP_OK(hipHostFree(lead.batch_h));
-        dfree(lead.arena, lead.batch_d);
-        lead.batch_cap = std::max<size_t>((size_t)n_env, lead.batch_cap * 2);
-        HIP_OK(hipHostMalloc((void **)&lead.batch_h, sizeof(BatchItem) * lead.batch_cap, hipHostMallocDefault));
-        HIP_OK(dev_malloc(lead.arena, &lead.batch_d, sizeof(BatchItem) * lead.batch_cap));
-    }
-    // item e describes environment e (an environment that cannot take the two-launch cycle leaves a skip marker and goes alone
-    // below).  A description costs ~0.2 us of host time (measured: 28 us for 128 environments) -- sharing them out over threads
-    // cost more than it saved.
-    std::vector<char> in_batch(n_env, 0);
+    if (n_pipe == 1)       // (a batch of one: the environment's own launches do the same with less ceremony)
+        for (int e = 0; e < n_env; e++) if (kind[e] == 2) kind[e] = envs[e]->cycle_eligible(n_group, view ? view + e * n_group : nullptr, feat ? feat + e * n_group : nullptr, nullptr) ? 1 : 0;
+    int lead_e = -1, lead_p = -1;
     for (int e = 0; e < n_env; e++) {
-        const int o = e * n_group;
-        BatchItem &it = lead.batch_h[e];
-        in_batch[e] = eligible[e] && envs[e]->device_id == lead.device_id &&
-                      envs[e]->cycle_prepare(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
-                                             rewards ? rewards + o : nullptr, it);
-        if (!in_batch[e]) { it.M.n = 0; it.S.rec = nullptr; }
+        if (kind[e] == 1 && lead_e < 0) lead_e = e;
+        if (kind[e] == 2 && lead_p < 0) lead_p = e;
+    }
+    // every batch shares the stream of its first environment: launches need no cross-stream events; the two batches overlap on the device.
+    // Environments that join neither are not touched (they used to adopt the stream too and then ran one after the other)
+    for (int e = 0; e < n_env; e++) {
+        if (kind[e] == 1 && e != lead_e) { if (envs[e]->device_id == envs[lead_e]->device_id) envs[e]->adopt_stream(*envs[lead_e]); else kind[e] = 0; }
+        if (kind[e] == 2 && e != lead_p) { if (envs[e]->device_id == envs[lead_p]->device_id) envs[e]->adopt_stream(*envs[lead_p]); else kind[e] = 0; }
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    // ---------------- the two-launch cycle of small worlds, all of them in one pair of launches
+    if (lead_e >= 0) {
+        Env &lead = *envs[lead_e];
+        lead.use_device();
+        if ((size_t)n_env > lead.batch_cap) {
+            HIP_OK(hipStreamSynchronize(lead.stream));
+            if (lead.batch_h) HIP_OK(hipHostFree(lead.batch_h));
+            dfree(lead.arena, lead.batch_d);
+            lead.batch_cap = std::max<size_t>((size_t)n_env, lead.batch_cap * 2);
+            HIP_OK(hipHostMalloc((void **)&lead.batch_h, sizeof(BatchItem) * lead.batch_cap, hipHostMallocDefault));
+            HIP_OK(dev_malloc(lead.arena, &lead.batch_d, sizeof(BatchItem) * lead.batch_cap));
+        }
+        // item e describes environment e (an environment that does not take the two-launch cycle leaves a skip marker).  A description costs
+        // ~0.2 us of host time (measured: 28 us for 128 environments) -- sharing them out over threads cost more than it saved.
+        int slots = 0, max_blocks = 0, n_in = 0;
+        size_t render_lds = 0, step_lds = 0;
+        for (int e = 0; e < n_env; e++) {
+            const int o = e * n_group;
+            BatchItem &it = lead.batch_h[e];
+            if (kind[e] == 1 && !envs[e]->cycle_prepare(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr,
+                                                       rewards ? rewards + o : nullptr, it)) kind[e] = 0;
+            if (kind[e] != 1) { it.M.n = 0; it.S.rec = nullptr; continue; }
+            n_in++;
+            slots = std::max(slots, it.M.n);
+            for (int q = 0; q < it.M.n; q++) { max_blocks = std::max(max_blocks, it.M.blocks[q]); render_lds = std::max(render_lds, render_strip_lds(it.M.P[q])); }
+            step_lds = std::max(step_lds, solo_step_lds(it.W, it.S));
+        }
+        if (n_in > 0) {
+            HIP_OK(hipMemcpyAsync(lead.batch_d, lead.batch_h, sizeof(BatchItem) * (size_t)n_env, hipMemcpyHostToDevice, lead.stream));
+            launch_cycle_batch(lead.stream, lead.batch_d, n_env, slots, max_blocks, render_lds, step_lds);
+            HIP_OK(hipGetLastError());
+        }
     }
     const auto t1 = std::chrono::steady_clock::now();
-    int slots = 0, max_blocks = 0, n_in = 0;
-    size_t render_lds = 0, step_lds = 0;
-    for (int e = 0; e < n_env; e++) {
-        if (!in_batch[e]) continue;
-        n_in++;
-        const BatchItem &it = lead.batch_h[e];
-        slots = std::max(slots, it.M.n);
-        for (int q = 0; q < it.M.n; q++) { max_blocks = std::max(max_blocks, it.M.blocks[q]); render_lds = std::max(render_lds, render_strip_lds(it.M.P[q])); }
-        step_lds = std::max(step_lds, solo_step_lds(it.W, it.S));
-    }
-    if (n_in > 0) {
+    // ---------------- the pipeline, batched: one launch per phase for every world beyond the one-launch step (pipe.hip)
+    PipeDims PD{};
+    if (lead_p >= 0) {
+        Env &lead = *envs[lead_p];
         lead.use_device();
-        HIP_OK(hipMemcpyAsync(lead.batch_d, lead.batch_h, sizeof(BatchItem) * (size_t)n_env, hipMemcpyHostToDevice, lead.stream));
-        launch_cycle_batch(lead.stream, lead.batch_d, n_env, slots, max_blocks, render_lds, step_lds);
+        if ((size_t)n_env > lead.pipe_cap) {
+            HIP_OK(hipStreamSynchronize(lead.stream));
+            if (lead.pipe_h) HIP_OK(hipHostFree(lead.pipe_h));
+            if (lead.pipec_h) HIP_OK(hipHostFree(lead.pipec_h));
+            dfree(lead.arena, lead.pipe_d); dfree(lead.arena, lead.pipec_d);
+            lead.pipe_cap = std::max<size_t>((size_t)n_env, lead.pipe_cap * 2);
+            HIP_OK(hipHostMalloc((void **)&lead.pipe_h, sizeof(PipeItem) * lead.pipe_cap, hipHostMallocDefault));
+            HIP_OK(hipHostMalloc((void **)&lead.pipec_h, sizeof(PipeClear) * lead.pipe_cap, hipHostMallocDefault));
+            HIP_OK(dev_malloc(lead.arena, &lead.pipe_d, sizeof(PipeItem) * lead.pipe_cap));
+            HIP_OK(dev_malloc(lead.arena, &lead.pipec_d, sizeof(PipeClear) * lead.pipe_cap));
+        }
+        // the items of the batch are packed (item k = the k-th environment of kind 2): no empty grid planes
+        // every environment launches as many rounds as the one with the largest budget (a round that has nothing to do returns at once)
+        // (MAGENT_TUNE attack_pairs=N fixes the budget for the process: 0 leaves every attack phase to the host)
+        int rounds = lead.opt_fixed ? 2 * lead.opt_attack_pairs : 2;
+        for (int e = 0; e < n_env && !lead.opt_fixed; e++) if (kind[e] == 2) rounds = std::max(rounds, 2 * (envs[e]->boost_attack > 0 ? 2 : 1));
+        PD.G = n_group; PD.rounds = rounds;
+        int k = 0;
+        for (int e = 0; e < n_env; e++) {
+            if (kind[e] != 2) continue;
+            const int o = e * n_group;
+            PipeItem &it = lead.pipe_h[k++];
+            envs[e]->pipe_prepare(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr, it, rounds);
+            for (int g = 0; g < n_group; g++) PD.max_n = std::max(PD.max_n, it.W.grp[g].n);
+            PD.max_total = std::max(PD.max_total, it.n_max);
+            PD.kmax = std::max(PD.kmax, it.PW.kmax);
+            PD.slots = std::max(PD.slots, it.M.n);
+            for (int q = 0; q < it.M.n; q++) { PD.render_blocks = std::max(PD.render_blocks, it.M.blocks[q]); PD.render_lds = std::max(PD.render_lds, render_strip_lds(it.M.P[q])); }
+        }
+        PD.n_env = k;
+        HIP_OK(hipMemcpyAsync(lead.pipe_d, lead.pipe_h, sizeof(PipeItem) * (size_t)k, hipMemcpyHostToDevice, lead.stream));
+        launch_pipe_step(lead.stream, lead.pipe_d, PD);
         HIP_OK(hipGetLastError());
     }
-    for (int e = 0; e < n_env; e++) if (!in_batch[e]) { alone.push_back(e); envs[e]->batch_width = 1; }
+    for (int e = 0; e < n_env; e++) if (kind[e] == 0) { alone.push_back(e); envs[e]->batch_width = 1; }
     if (!alone.empty()) others(alone);
     const auto t2 = std::chrono::steady_clock::now();
     auto t3 = t2;
     bool first = true;
     for (int e = 0; e < n_env; e++) {
-        if (!in_batch[e]) continue;
+        if (kind[e] != 1) continue;
         envs[e]->cycle_finish(&done[e]);
         envs[e]->batch_width = 1;          // (whatever is called on the environment next is called on it alone)
         if (first) { t3 = std::chrono::steady_clock::now(); first = false; }
     }
+    if (lead_p >= 0) {
+        Env &lead = *envs[lead_p];
+        lead.use_device();
+        // the steps' reports (they left the device ahead of the moves), then get_reward + clear_dead of every environment in two launches
+        int k = 0;
+        bool any = false;
+        for (int e = 0; e < n_env; e++) {
+            if (kind[e] != 2) continue;
+            envs[e]->step_end(&done[e]);
+            if (first) { t3 = std::chrono::steady_clock::now(); first = false; }
+        }
+        for (int e = 0; e < n_env; e++) {
+            if (kind[e] != 2) continue;
+            PipeClear &cl = lead.pipec_h[k++];
+            any |= envs[e]->pipe_clear(rewards ? rewards + e * n_group : nullptr, cl);
+            PD.hist_lds = std::max(PD.hist_lds, sizeof(int) * (size_t)cl.M.vh * cl.M.vw);
+        }
+        if (any) {
+            HIP_OK(hipMemcpyAsync(lead.pipec_d, lead.pipec_h, sizeof(PipeClear) * (size_t)k, hipMemcpyHostToDevice, lead.stream));
+            launch_pipe_clear(lead.stream, lead.pipe_d, lead.pipec_d, PD);
+            HIP_OK(hipGetLastError());
+        }
+        // env_cycle_many promises finished outputs at return: k_pipe_finish sets a word per environment behind everything else
+        k = 0;
+        for (int e = 0; e < n_env; e++) {
+            if (kind[e] != 2) continue;
+            const PipeClear &cl = lead.pipec_h[k++];
+            if (cl.gtab) {
+                for (unsigned spins = 0; __atomic_load_n(cl.done_flag, __ATOMIC_ACQUIRE) != cl.done_seq; spins++)
+                    if ((spins & 0x3FFF) == 0x3FFF) {
+                        const hipError_t q = hipStreamQuery(lead.stream);
+                        if (q == hipSuccess) { if (__atomic_load_n(cl.done_flag, __ATOMIC_ACQUIRE) == cl.done_seq) break; fatal("the batched clear_dead finished without publishing its word"); }
+                        if (q != hipErrorNotReady) fatal("batched cycle failed: %s", hipGetErrorString(q));
+                    }
+            } else HIP_OK(hipStreamSynchronize(envs[e]->stream));      // (it ended its cycle by launches of its own)
+            envs[e]->batch_width = 1;
+            envs[e]->pipe_rounds++;
+        }
+    }
     const auto t4 = std::chrono::steady_clock::now();
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    lead.batch_us[0] += us(t0, t1); lead.batch_us[1] += us(t1, t2); lead.batch_us[2] += us(t2, t3); lead.batch_us[3] += us(t3, t4);
-    lead.batch_rounds++;
+    Env &acct = *envs[lead_e >= 0 ? lead_e : lead_p >= 0 ? lead_p : 0];
+    acct.batch_us[0] += us(t0, t1); acct.batch_us[1] += us(t1, t2); acct.batch_us[2] += us(t2, t3); acct.batch_us[3] += us(t3, t4);
+    acct.batch_rounds++;
+}
+
+// ------------------------------------------------------------------------------------------------ the pipeline, batched
+// Can this environment's cycle go through the batched pipeline?  Plain games (Env::reset: plain_world) under the single-sync driver whose
+// rules k_strike evaluates itself -- what battle and gather are -- with every observed group's buffers 16-byte aligned.  No device work.
+bool Env::pipe_eligible(int n_group, float *const *view, float *const *feat, const int *const *actions, int *total_out) {
+    if (!device_ready) fatal("cycle called before reset");
+    const int NG = (int)groups.size();
+    if (n_group != NG) fatal("env_cycle_many: n_group (%d) differs from the number of groups (%d)", n_group, NG);
+    int total_n = 0;
+    for (auto &g : groups) total_n += g.n;
+    if (total_out) *total_out = total_n;
+    if (!plain_world || checked_step || host_shuffle || !first_render || serial_calls_on || step_pending || rules_on_host || stale_events || total_n == 0) return false;
+    if (overlap_enabled) return false;
+    if (!fused_rules(rule_args.data(), (int)rule_args.size())) return false;
+    int n_obs = 0, first_obs = -1;
+    for (int g = 0; g < NG; g++) {
+        if (groups[g].acted) return false;                         // (given its actions by env_set_action_device already: the call sequence)
+        if (!(view && view[g]) || groups[g].n == 0) continue;
+        if (!feat || !feat[g] || (((uintptr_t)view[g]) & 15) || (((uintptr_t)feat[g]) & 15)) return false;
+        if (first_obs < 0) first_obs = g;
+        else if (minimap_mode && (groups[g].type->view.height != groups[first_obs].type->view.height || groups[g].type->view.width != groups[first_obs].type->view.width))
+            return false;                                          // (one minimap per environment and cycle)
+        n_obs++;
+    }
+    (void)actions;
+    return n_obs <= RENDER_MULTI_MAX;
+}
+
+// Everything of one environment's cycle up to the step's report, as an item of the batch: what observe_device, set_action_device and
+// step_begin would do on the host, with the launches left to the batch (launch_pipe_step).  Stale state that only the first cycle meets
+// -- the painted map, the first minimap, tables, grown buffers -- is brought up to date by launches of the environment's own, on the
+// batch's stream, ahead of the batch's.
+void Env::pipe_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, PipeItem &it, int rounds) {
+    enter();
+    const int NG = (int)groups.size();
+    (void)n_group;
+    int total_n = 0;
+    for (auto &g : groups) total_n += g.n;
+    if (!tables_valid) ensure_tables();
+    it.M = RenderMulti{};
+    // ---- the observations: worlds whose renders fill the chip by themselves launch their own (launch_render picks the sweeping kernel
+    // at that size); the others share the batch's render launch
+    bool own_render = false;
+    for (int g = 0; g < NG; g++)
+        if (view && view[g] && groups[g].n > 0 && (long long)groups[g].n * groups[g].type->view.height * groups[g].type->view.width >= 16384ll * 64) own_render = true;
+    {
+        const WorldView W0 = this->view();
+        for (int g = 0; g < NG; g++) {
+            if (!(view && view[g]) || groups[g].n == 0) continue;
+            if (own_render) { observe_device(g, view[g], feat[g]); continue; }
+            const int k = it.M.n++;
+            prepare_render(g, W0, it.M.R[k], it.M.P[k], view[g], feat[g]);
+            it.M.blocks[k] = it.M.P[k].spans + it.M.P[k].feat_blocks;
+        }
+        map_warm = true;
+    }
+    // ---- set_action: tile counts per call, in call order (Env::set_action_device)
+    step_sa_tiled = true; sa_tiles = 0;
+    step_calls.clear();
+    for (int g = 0; g < MAXG; g++) { it.actions[g] = nullptr; it.call_base[g] = 0; it.P.off[g] = -1; }
+    for (int g = 0; g < NG; g++) {
+        HostGroup &G = groups[g];
+        if (!(actions && actions[g])) continue;
+        G.acted = true;
+        if (G.n == 0) continue;
+        if ((long long)move_seq_base + G.n >= (1ll << 27)) fatal("more than 2^27 agents given actions in one step");
+        it.actions[g] = actions[g]; it.call_base[g] = move_seq_base; it.P.off[g] = sa_tiles;
+        move_seq_base += G.n;
+        sa_tiles += (G.n + SCAN_TILE_HOST - 1) / SCAN_TILE_HOST;
+    }
+    if ((size_t)sa_tiles > asums_cap) {
+        grow(arena, d_asums, asums_cap, (size_t)sa_tiles, stream);
+        grow(arena, d_wpre, wpre_cap, asums_cap * (SCAN_TILE_HOST / 64), stream);
+    }
+    // ---- the step (Env::step_begin, single-sync driver, plain games, rules fused, the report ahead of the moves)
+    step_live_paint = live_paint_now = paint_valid;
+    step_pending = true;
+    map_warm = false;
+    step_was_fast = true; step_was_solo = false; step_was_plain = true; step_fused_rules = true;
+    plain_steps++;
+    scratch_for(1);
+    shuffle_buffers(total_n);
+    push_rng();
+    attack_round = rounds;
+    if (rounds >= 4) pairs_two_steps++; else if (rounds >= 2) pairs_one_steps++;
+    it.W = this->view();
+    it.PW = plain_view();
+    it.ptab = d_ptab; it.gtab = d_gtab; it.ttab = d_ttab;
+    it.B = shuffle_bufs(); it.powtab = d_powtab;
+    it.sums = d_asums; it.wpre = d_wpre;
+    it.R = strike_rules(rule_args.data(), (int)rule_args.size());
+    it.rec = h_rec; it.seq = ++step_seq;
+    it.n_max = total_n;
+    alive_valid = true;
+    stale_events = true;
+    for (auto &g : groups) g.sa_off = -1;
+    state_epoch++;
+}
+
+// get_reward + clear_dead of one environment as an item of the batch (Env::get_reward_device, Env::clear_dead: the three-launch form, with
+// the survivor counts k_strike left).  Returns false -- and runs the ordinary calls -- when those counts do not describe the groups.
+bool Env::pipe_clear(float *const *rewards, PipeClear &cl) {
+    cl = PipeClear{};
+    enter();
+    const int NG = (int)groups.size();
+    bool counted = alive_valid;
+    for (int g = 0; g < NG; g++) counted &= groups[g].n == alive_n[g];
+    if (!counted) {          // (a step that the host finished re-ran k_strike over the same groups: still counted; anything else comes here)
+        for (int g = 0; g < NG; g++) if (rewards && rewards[g]) get_reward_device(g, rewards[g]);
+        clear_dead();
+        return false;
+    }
+    if (!h_done) { HIP_OK(hipHostMalloc((void **)&h_done, sizeof(int), hipHostMallocDefault)); *h_done = 0; }
+    bool any = false;
+    for (int g = 0; g < NG; g++) {
+        HostGroup &G = groups[g];
+        if (rewards && rewards[g] && G.n > 0) { cl.rewards[g] = rewards[g]; cl.group_reward[g] = G.group_reward; }
+        G.group_reward = 0;
+        const int gone = G.h_dead + G.h_taken;
+        cl.A.mode[g] = G.n == 0 ? 0 : (gone > 0 ? 2 : 1);
+        cl.A.sums_off[g] = alive_off[g];
+        cl.A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed, G.alt.dir};
+        cl.new_n[g] = G.n - gone;
+        any |= gone > 0;
+    }
+    cl.A.sums_per_tile = SCAN_TILE_HOST / 256;
+    cl.sums = d_alive;
+    cl.M = next_minimap();
+    cl.counts = fold_counts();
+    cl.gtab = d_gtab; cl.ttab = d_ttab;
+    cl.done_flag = h_done; cl.done_seq = step_seq;
+    for (int g = 0; g < NG; g++) {
+        HostGroup &G = groups[g];
+        if (cl.A.mode[g] == 2) {       // survivors: double-buffered arrays went to alt, the rest is reset in place
+            std::swap(G.cur.x, G.alt.x); std::swap(G.cur.y, G.alt.y); std::swap(G.cur.id, G.alt.id);
+            std::swap(G.cur.hp, G.alt.hp); std::swap(G.cur.last_action, G.alt.last_action);
+            std::swap(G.cur.last_reward, G.alt.last_reward); std::swap(G.cur.next_reward, G.alt.next_reward);
+            std::swap(G.cur.absorbed, G.alt.absorbed); std::swap(G.cur.dir, G.alt.dir);
+            G.n -= G.h_dead + G.h_taken;
+        }
+        G.h_dead = 0; G.h_taken = 0;
+        G.indexed = G.n;
+    }
+    tables_valid = true;
+    if (any) { h_occ_valid = false; mini_valid = false; }
+    stale_events = false;
+    alive_valid = false;
+    if (cl.M.vh > 0) { mini_valid = true; mini_pop = mini_population(mini_skip); }
+    return true;
 }
 
 // every environment of a batch shares the first one's stream (kept alive by whoever still uses it)

@@ -212,6 +212,13 @@ private:
     void adopt_stream(Env &lead);
     bool cyc_next_mini = false, cyc_mini_skip = false; int cyc_mini_vh = 0, cyc_mini_vw = 0;
     BatchItem *batch_h = nullptr, *batch_d = nullptr; size_t batch_cap = 0;   // (lead environment of a batch)
+    // many environments per launch through the pipeline of plain games (engine_batch.hip: "the pipeline, batched"; pipe.hip)
+    bool pipe_eligible(int n_group, float *const *view, float *const *feat, const int *const *actions, int *total_out);
+    void pipe_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, PipeItem &it, int rounds);
+    bool pipe_clear(float *const *rewards, PipeClear &cl);
+    PipeItem *pipe_h = nullptr, *pipe_d = nullptr; PipeClear *pipec_h = nullptr, *pipec_d = nullptr; size_t pipe_cap = 0;   // (lead environment of such a batch)
+    int *h_done = nullptr;                // pinned: k_pipe_finish's word for this environment (PipeClear::done_flag)
+    int pipe_rounds = 0;                  // cycles this environment took through the batched pipeline (env_get_info "pipeline_stats")
     void wait_record(int seq);
     StepRecord *h_rec = nullptr;          // pinned: written by k_step_solo, spun on by step_end
     int step_seq = 0;

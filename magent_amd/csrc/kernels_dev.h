@@ -1032,10 +1032,7 @@ __device__ __forceinline__ int claim_ref(unsigned long long w) { return (int)(w 
 // as soon as its own attack is known -- provided every last_op was OP_NULL when the step began (clear_dead has run since the last step:
 // otherwise an event of the LAST step is paid again unless a collision overwrites it, which only the move phase knows; the host then
 // runs k_rule behind the commit as before)
-struct StrikeRules {
-    int n;
-    struct One { int ga, gb, op, rule_no, n_subj; float v[4]; } r[4];
-};
+// (struct StrikeRules: launch.h)
 
 
 // ------------------------------------------------------------------------------------------------ move, generic bodies

@@ -146,6 +146,12 @@ struct PlainWorld {
     int epoch;            // of this step's claim words (step.hip: claim_word): 62 - (plain step number mod 63)
     int round_base;       // + round = the "inputs changed" stamp of a round of this step (they count on from step to step)
 };
+// the rules k_strike evaluates itself (kernels_dev.h: "rules of the shape Event(a, attack | kill, b) that pay receivers bound to `a` only")
+struct StrikeRules {
+    int n;
+    struct One { int ga, gb, op, rule_no, n_subj; float v[4]; } r[4];
+};
+StrikeRules strike_rules(const RuleArgs *rules /* null: none fused */, int n_rules);
 bool fused_rules(const RuleArgs *rules, int n);
 bool plain_eval_lds_ok(int kmax);
 void launch_shuffle_draw(hipStream_t s, int n_max, int *counters, const ShuffleBufs &B, const unsigned *powtab, bool tiled);
@@ -193,6 +199,33 @@ int solo_step_static_lds();
 bool solo_step_allow_lds(size_t bytes);
 void launch_init_reward(hipStream_t s, const WorldView &W, int g);
 void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D, int new_n, int *sums);
+
+// ---- many environments per launch through the pipeline of plain games (env_cycle_many on worlds beyond the one-launch step; pipe.hip).
+// One PipeItem per environment, in a device array; every kernel of the batch finds its environment by blockIdx.z.
+struct PipeItem {
+    WorldView W;
+    PlainWorld PW;
+    const PlainGroup *ptab; const GroupDev *gtab; const TypeDev *ttab;     // the environment's device tables
+    ShuffleBufs B; const unsigned *powtab;
+    int *sums, *wpre;                  // tile counts of this step's set_action calls (k_set_action_a's)
+    SeqPlan P;                         // where each group's call leaves them (-1: the group is given no actions)
+    const int *actions[MAXG]; int call_base[MAXG];
+    StrikeRules R;
+    StepRecord *rec; int seq;
+    int n_max;                         // agents of all groups: the bound of the attack list
+    RenderMulti M;                     // the observations (M.n == 0: rendered by launches of the environment's own, ahead of the batch)
+};
+// ... and what the end of the cycle needs once the host has seen the step's report: get_reward + clear_dead
+struct PipeClear {
+    ClearArgs A; MiniArgs M; int *counts; const int *sums;
+    int new_n[MAXG];                   // group sizes behind the compaction
+    float *rewards[MAXG]; float group_reward[MAXG];
+    GroupDev *gtab; TypeDev *ttab;     // device tables to refresh
+    int *done_flag; int done_seq;      // pinned: set once the environment's outputs are complete (the host spins on it)
+};
+struct PipeDims { int n_env, max_n, max_total, G, slots, render_blocks, rounds, kmax; size_t render_lds, hist_lds; };
+void launch_pipe_step(hipStream_t s, const PipeItem *d_items, const PipeDims &D);
+void launch_pipe_clear(hipStream_t s, const PipeItem *d_items, const PipeClear *d_clears, const PipeDims &D);
 
 // agents per workgroup of the scan-based passes (set_action, clear_dead).  2 per thread: at 400k agents that is 782 workgroups --
 // the earlier 8 per thread left 196, less than one per CU, and every such launch was bound by its own latency chain

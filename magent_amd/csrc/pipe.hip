@@ -1,0 +1,133 @@
+// pipe.hip -- MANY environments per launch through the pipeline of plain games (env_cycle_many on worlds beyond the one-launch step)
+//
+// A world of a few thousand to a few hundred thousand agents steps through a dozen launches (step.hip: set_action, the shuffle's draws,
+// k_plain_rank, rounds of k_plain_eval, k_strike, k_plain_commit, the compaction of clear_dead) of 3-30 us each, and most of that is the
+// launch itself and the latency chain inside it, not work: BASELINE config 2 (battle 200 x 200, 2 x 2000) is 16 launches around 20 us of
+// work, config 4 (gather 500 x 500, 100k agents) 13 around 70.  Reinforcement-learning callers run MANY such worlds per GPU; here the same
+// kernel bodies (plain_dev.h) are launched ONCE per phase for all environments of an env_cycle_many call:
+//   grid = (tiles of the largest group, groups, environments), the environment's description read from a device array of PipeItem
+// so that n environments cost one chain of launches instead of n.  GridWorld.cc:292-401 (observations), :403-454 (set_action), :456-631
+// (step), :694-704 (get_reward), :633-665 (clear_dead) -- bit-identical to the same environments stepped one by one (the bodies are the same).
+#include "plain_dev.h"
+
+namespace magent_amd {
+
+// (an item is read through scalar loads: the index is the workgroup's, nothing in these launches writes the array)
+#define PIPE_ITEM() const PipeItem &it = items[blockIdx.z]; const int g = blockIdx.y; if (g >= it.W.G) return
+
+// the observations of every environment that did not render them itself: blockIdx.y = environment * slots + slot (as k_render_batch)
+__global__ void __launch_bounds__(64 * RENDER_WAVES) k_pipe_render(const PipeItem *__restrict__ items, int slots) {
+    const int e = blockIdx.y / slots, k = blockIdx.y - e * slots;
+    const PipeItem &it = items[e];
+    if (k >= it.M.n || (int)blockIdx.x >= it.M.blocks[k]) return;
+    const RenderArgs R = it.M.R[k];
+    const RenderPlan P = it.M.P[k];
+    RenderWorld V;
+    V.w = it.W.w; V.h = it.W.h; V.G = it.W.G; V.viewcell = it.W.viewcell; V.mask = it.W.mask; V.grp = it.W.grp[R.g]; V.type = it.W.type[R.g];
+    // (plain games: no turn_mode)
+    if (it.W.vc_packed) render_block<true, true, 1, true, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
+    else render_block<true, true, 1, false, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_pipe_set_action(const PipeItem *__restrict__ items) {
+    PIPE_ITEM();
+    if (!it.actions[g] || (int)(blockIdx.x * SCAN_TILE) >= it.W.grp[g].n) return;
+    set_action_tile_body(it.W, g, it.actions[g], it.call_base[g], it.sums, it.wpre, it.P.off[g]);
+}
+__global__ void __launch_bounds__(256) k_pipe_draw(const PipeItem *__restrict__ items) {
+    const PipeItem &it = items[blockIdx.z];
+    if ((int)(blockIdx.x * 256) >= it.n_max) return;
+    shuffle_draw_launch_body(it.W.counters, it.B.j, it.B.head, it.B.first, it.B.link, nullptr, 0, it.powtab, 1);
+}
+__global__ void __launch_bounds__(256) k_pipe_rank(const PipeItem *__restrict__ items) {
+    PIPE_ITEM();
+    plain_rank_body(it.W, it.PW, it.ptab, it.B, it.sums, it.wpre, it.P);
+}
+__global__ void __launch_bounds__(256) k_pipe_eval(const PipeItem *__restrict__ items, int round, int flag) {
+    PIPE_ITEM();
+    plain_eval_body(it.W, it.PW, it.ptab, it.gtab, it.ttab, round, flag, it.B.head, it.B.first);
+}
+__global__ void __launch_bounds__(256) k_pipe_strike(const PipeItem *__restrict__ items) {
+    PIPE_ITEM();
+    strike_body(it.W, it.PW, it.ptab, it.gtab, it.ttab, it.R);
+}
+__global__ void __launch_bounds__(256) k_pipe_commit(const PipeItem *__restrict__ items) {
+    PIPE_ITEM();
+    plain_commit_body(it.W, it.PW, it.rec, it.seq);
+}
+// tests only (MAGENT_TUNE attack_pairs=0): no optimistic round at all -- every environment's attack phase is left open for the host
+__global__ void k_pipe_force_open(const PipeItem *__restrict__ items) {
+    if (threadIdx.x == 0) items[blockIdx.x].W.counters[CTR_OPEN_ATTACK] = 1;
+}
+// get_reward + clear_dead's compaction (Agent::init_reward alone for groups without deaths), the next minimap's histogram
+__global__ void __launch_bounds__(SCAN_THREADS) k_pipe_clear(const PipeItem *__restrict__ items, const PipeClear *__restrict__ clears) {
+    PIPE_ITEM();
+    const PipeClear &cl = clears[blockIdx.z];
+    if (cl.A.mode[g] == 0) return;
+    clear_compact_body(it.W, cl.A, cl.sums, cl.M, cl.counts, cl.rewards[g], cl.group_reward[g]);
+}
+// ... then the death counters, the device copies of the group / type tables as the compaction leaves them (the double-buffered arrays have
+// changed places: ClearArgs::dst are the current ones), the division of the next minimap -- and the word the host waits for
+__global__ void __launch_bounds__(256) k_pipe_finish(const PipeItem *__restrict__ items, const PipeClear *__restrict__ clears) {
+    const PipeItem &it = items[blockIdx.z];
+    const PipeClear &cl = clears[blockIdx.z];
+    if (cl.gtab == nullptr) return;            // an environment that ended its cycle by launches of its own
+    const int NG = it.W.G;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < MAXG) {
+            const int q = threadIdx.x;
+            GroupDev N = it.W.grp[q];
+            if (q < NG) {
+                if (cl.A.mode[q] == 2) {
+                    const ClearArgs::Alt D = cl.A.dst[q];
+                    N.x = D.x; N.y = D.y; N.id = D.id; N.last_action = D.last_action; N.hp = D.hp; N.next_reward = D.next_reward;
+                    N.last_reward = D.last_reward; N.absorbed = D.absorbed; N.dir = D.dir;
+                }
+                N.n = cl.new_n[q];
+            }
+            cl.gtab[q] = N; cl.ttab[q] = it.W.type[q];
+        }
+        for (int q = 0; q < NG; q++) {
+            if (cl.A.mode[q] != 2) continue;
+            if (threadIdx.x < DEAD_SLOTS) it.W.counters[dead_slot(q, threadIdx.x)] = 0;
+            if (threadIdx.x == 0) it.W.counters[CTR_TAKEN + q] = 0;
+        }
+        // every output of the cycle -- rewards, compacted arrays (the launch before), tables -- is written: the host may return
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(cl.done_flag, cl.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (cl.M.vh > 0) {         // mini_norm_body with the sizes behind the compaction
+        const int VHW = cl.M.vh * cl.M.vw, k = blockIdx.x * blockDim.x + threadIdx.x;
+        if (k < NG * VHW) {
+            const int tot = cl.new_n[k / VHW];
+            int cnt = 0;
+            for (int c = 0; c < MINI_COPIES; c++) { cnt += cl.counts[c * NG * VHW + k]; cl.counts[c * NG * VHW + k] = 0; }
+            cl.M.out[k] = tot == 0 ? __int_as_float(0xFFC00000) : __fdiv_rn((float)min(cnt, 1 << 24), (float)(unsigned)tot);
+        }
+    }
+}
+
+static size_t pipe_eval_lds(int kmax) { return (size_t)kmax * 256 * 8; }
+void launch_pipe_step(hipStream_t s, const PipeItem *d_items, const PipeDims &D) {
+    const dim3 by_agent((D.max_n + 255) / 256, D.G, D.n_env);
+    if (D.slots > 0 && D.render_blocks > 0)
+        hipLaunchKernelGGL(k_pipe_render, dim3(D.render_blocks, D.n_env * D.slots), dim3(64 * RENDER_WAVES), D.render_lds, s, d_items, D.slots);
+    hipLaunchKernelGGL(k_pipe_set_action, dim3((D.max_n + SCAN_TILE - 1) / SCAN_TILE, D.G, D.n_env), dim3(SCAN_THREADS), 0, s, d_items);
+    hipLaunchKernelGGL(k_pipe_draw, dim3((D.max_total + 255) / 256, 1, D.n_env), dim3(256), 0, s, d_items);
+    hipLaunchKernelGGL(k_pipe_rank, by_agent, dim3(256), 0, s, d_items);
+    if (pipe_eval_lds(D.kmax) > (48u << 10))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pipe_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_eval_lds(D.kmax));
+    // (the last round raises CTR_OPEN_ATTACK of the environments in which something still changed: those continue on the host)
+    for (int r = 1; r <= D.rounds; r++)
+        hipLaunchKernelGGL(k_pipe_eval, by_agent, dim3(256), pipe_eval_lds(D.kmax), s, d_items, r, r == D.rounds ? CTR_OPEN_ATTACK : -1);
+    if (D.rounds == 0) hipLaunchKernelGGL(k_pipe_force_open, dim3(D.n_env), dim3(64), 0, s, d_items);
+    hipLaunchKernelGGL(k_pipe_strike, by_agent, dim3(256), 0, s, d_items);
+    hipLaunchKernelGGL(k_pipe_commit, by_agent, dim3(256), 0, s, d_items);
+}
+void launch_pipe_clear(hipStream_t s, const PipeItem *d_items, const PipeClear *d_clears, const PipeDims &D) {
+    hipLaunchKernelGGL(k_pipe_clear, dim3((D.max_n + SCAN_TILE - 1) / SCAN_TILE, D.G, D.n_env), dim3(SCAN_THREADS), D.hist_lds, s, d_items, d_clears);
+    const int blocks = std::max(1, (int)((D.hist_lds / sizeof(int)) * D.G + 255) / 256);
+    hipLaunchKernelGGL(k_pipe_finish, dim3(blocks, 1, D.n_env), dim3(256), 0, s, d_items, d_clears);
+}
+
+}  // namespace magent_amd

@@ -423,7 +423,10 @@ __device__ __forceinline__ void plain_commit_body(const WorldView &W, const Plai
 // (M.vh > 0: the minimap of the NEXT observations rides along -- every block adds the survivors it handles to an LDS histogram of
 // their minimap cells and flushes it with one global atomic per non-empty bin; k_clear_finish / k_mini_norm divide.  That is
 // k_minimap + k_minimap_norm, two launches per cycle, gone: the positions pass through this kernel anyway)
-__device__ __forceinline__ void clear_compact_body(const WorldView &W, const ClearArgs &A, const int *sums, const MiniArgs &M, int *counts) {
+// (reward_out != null: GridWorld::get_reward (GridWorld.cc:694-704) rides along -- every agent's next_reward + the group's, the dead included,
+// read by the thread that resets it)
+__device__ __forceinline__ void clear_compact_body(const WorldView &W, const ClearArgs &A, const int *sums, const MiniArgs &M, int *counts,
+                                                   float *reward_out = nullptr, float group_reward = 0.0f) {
     extern __shared__ int s_hist[];
     const int g = blockIdx.y;
     const GroupDev &G = W.grp[g];
@@ -438,7 +441,9 @@ __device__ __forceinline__ void clear_compact_body(const WorldView &W, const Cle
         for (int k = 0; k < SCAN_ITEMS; k++) {
             const int i = blockIdx.x * SCAN_TILE + k * SCAN_THREADS + threadIdx.x;
             if (i < G.n) {
-                G.last_reward[i] = G.next_reward[i]; G.next_reward[i] = step_reward; G.last_op[i] = OP_NULL; G.op_obj[i] = -1;
+                const float nr = G.next_reward[i];
+                if (reward_out) reward_out[i] = nr + group_reward;
+                G.last_reward[i] = nr; G.next_reward[i] = step_reward; G.last_op[i] = OP_NULL; G.op_obj[i] = -1;
                 if (VHW > 0) atomicAdd(&s_hist[(G.y[i] / M.scale_h) * M.vw + G.x[i] / M.scale_w], 1);
             }
         }
@@ -448,6 +453,7 @@ __device__ __forceinline__ void clear_compact_body(const WorldView &W, const Cle
         // (the single-buffered state goes back to its rest values at every agent's OWN index -- all that matters are the positions below
         // the new size, and each is some thread's own; `dead` is read by that thread alone in this launch: no second pass for it)
         block_rank([&](int i) {
+                       if (reward_out) reward_out[i] = G.next_reward[i] + group_reward;
                        const bool d = G.dead[i];
                        if (d) G.dead[i] = 0;
                        G.last_op[i] = OP_NULL; G.op_obj[i] = -1; G.pend[i] = PEND_NONE;

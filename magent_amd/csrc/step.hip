@@ -696,6 +696,17 @@ bool fused_rules(const RuleArgs *rules, int n) {
     for (int k = 0; k < n; k++) if (rules[k].pair || rules[k].prog >= 0 || rules[k].n_obj || (rules[k].op != OP_ATTACK && rules[k].op != OP_KILL)) return false;
     return true;
 }
+StrikeRules strike_rules(const RuleArgs *rules, int n_rules) {
+    StrikeRules R{};
+    if (rules) {
+        R.n = n_rules;
+        for (int k = 0; k < n_rules; k++) {
+            R.r[k].ga = rules[k].ga; R.r[k].gb = rules[k].gb; R.r[k].op = rules[k].op; R.r[k].rule_no = rules[k].rule_no; R.r[k].n_subj = rules[k].n_subj;
+            for (int q = 0; q < 4; q++) R.r[k].v[q] = rules[k].v_subj[q];
+        }
+    }
+    return R;
+}
 void launch_plain_rank(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const ShuffleBufs &B, const int *sums,
                        const int *wpre, const SeqPlan &P) {
     hipLaunchKernelGGL(k_plain_rank, grid_all(W, 256), dim3(256), 0, s, W, PW, ptab, B, sums, wpre, P);
@@ -715,14 +726,7 @@ void launch_shuffle_draw(hipStream_t s, int n_max, int *counters, const ShuffleB
 }
 void launch_plain_tail(hipStream_t s, const WorldView &W, const PlainWorld &PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab,
                        const RuleArgs *rules, int n_rules, StepRecord *rec, int seq) {
-    StrikeRules R{};
-    if (rules) {
-        R.n = n_rules;
-        for (int k = 0; k < n_rules; k++) {
-            R.r[k].ga = rules[k].ga; R.r[k].gb = rules[k].gb; R.r[k].op = rules[k].op; R.r[k].rule_no = rules[k].rule_no; R.r[k].n_subj = rules[k].n_subj;
-            for (int q = 0; q < 4; q++) R.r[k].v[q] = rules[k].v_subj[q];
-        }
-    }
+    const StrikeRules R = strike_rules(rules, n_rules);
     dim3 g = grid_all(W, 256);
     hipLaunchKernelGGL(k_strike, g, dim3(256), 0, s, W, PW, ptab, gtab, ttab, R);
     // (rec != null: the step's report goes out from the first wave of the commit's launch -- see k_plain_commit)

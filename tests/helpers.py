@@ -530,7 +530,7 @@ def run_cycle(sc, lib, fused, preset=False):
     return out
 
 
-def run_cycle_batch(scs, lib, preset=False):
+def run_cycle_batch(scs, lib, preset=False, envs_out=None):
     """run_cycle(fused=True) for SEVERAL environments of one configuration at once: a single magent_amd.EnvBatch, so that for
     small worlds all of them share one pair of launches per cycle (k_render_batch + k_step_solo_batch).  Returns one trajectory
     per scenario; an environment whose groups are all empty keeps cycling with the others (its trajectory stops there, as
@@ -541,6 +541,8 @@ def run_cycle_batch(scs, lib, preset=False):
     import torch
     built = [sc.build(lib) for sc in scs]
     envs, handles = [b[0] for b in built], [b[1] for b in built]
+    if envs_out is not None:
+        envs_out.extend(envs)
     dev = torch_device(envs[0], lib)
     batch = magent_amd.EnvBatch(envs, n_threads=1)
     batch.order_streams = not is_emu(lib)
@@ -692,6 +694,19 @@ def preset_batch_scenarios():
             Scenario("preset_b", "battle", 60, place=[rnd(0, 900), rnd(1, 1100)], steps=6, action_seed=82, seed=4242, over={"small": {"hp": 4, "damage": 3}})]
 
 
+def pipe_batch_scenarios():
+    """environments of one env_cycle_many call that take all three of its forms: plain worlds beyond the one-launch step (the batched pipeline,
+    pipe.hip: deaths from the first step, a group that dies out, reinforcements that change every grid size mid-episode, a non-square
+    large_map_mode world), a world small enough for the two-launch cycle, and gather (its two groups look through different windows: it goes alone)"""
+    rnd = lambda g, n: (g, "random", {"n": n})
+    S = scenarios()
+    return [Scenario("pipe_a", "battle", 60, place=[rnd(0, 1000), rnd(1, 1000)], steps=12, action_seed=91, over={"small": {"hp": 4, "damage": 3}}),
+            Scenario("pipe_b", "battle", 70, place=[rnd(0, 1500), rnd(1, 700)], steps=12, action_seed=92, seed=99, over={"small": {"hp": 3, "damage": 3, "step_recover": -0.3}},
+                     events={4: [("add", 1, "random", {"n": 900})], 8: [("add", 0, "fill", {"pos": (2, 2), "size": (30, 20)})]}),
+            Scenario("pipe_c", "battle", 104, place=[rnd(0, 2600), rnd(1, 60)], steps=12, action_seed=93, over={"small": {"damage": 11}}),
+            S["battle_brawl"], S["gather"]]
+
+
 def render_episode(lib, out_dir, steps=6, twice=False):
     """a short battle with the text video dump on: returns {file name: bytes} of what env.render() wrote
     (twice: group 0 is given actions a second time before every other step -- the attack events of the literal loop)"""
@@ -783,6 +798,15 @@ def fuzz_scenario(seed):
                                                   if j != i or a["attack_in_group"]) for i, t in enumerate(specs))
         if kmax * (4 if turn_mode else 1) <= 256 and all(max(t["width"], t["length"]) + 2 < min(w, h) for t in specs):
             break
+    # FUZZ_PLAIN=1: the same draws, bent into a game the pipeline of plain games takes (Env::reset: plain_world) with rules k_strike evaluates
+    # itself -- one-cell bodies, no kill_supply / food / goals / turn_mode, one view window, subject-paying attack | kill rules only --
+    # so that batches of them go through env_cycle_many's batched pipeline (pipe.hip)
+    fuzz_plain = os.environ.get("FUZZ_PLAIN", "0") == "1"
+    if fuzz_plain:
+        turn_mode = False
+        for t in specs:
+            t.update(width=1, length=1, kill_supply=0.0, view_range=specs[0]["view_range"])
+            t.pop("view_sector", None)
     rules = []
     for _ in range(int(rs.randint(0, 5))):
         a, b = int(rs.randint(G)), int(rs.randint(G))
@@ -880,6 +904,10 @@ def fuzz_scenario(seed):
             recv = [k for k in sorted(used) if rs.rand() < 0.7] or [sorted(used)[0]]
             tree_rules.append((syms, kinds, expr, recv, [frac(-1, 1) for _ in recv], bool(rs.rand() < 0.1)))
 
+    if fuzz_plain:
+        rules = [(a, "attack" if op == "collide" else op, b, "s" * len(who), vals) for a, op, b, who, vals in rules]
+        pair_rules, prog_rules = [], []
+
     def make():
         cfg = gw.Config()
         cfg.set({"map_width": w, "map_height": h, "minimap_mode": minimap, "embedding_size": emb})
@@ -953,12 +981,12 @@ def fuzz_scenario(seed):
                                       "size": (int(rs.randint(2, w // 5 + 3)), int(rs.randint(2, h // 5 + 3)))}))
         place.append((g, "random", {"n": min(n, 4000)}))
     acting = [g for g in range(G) if rs.rand() < 0.85] or [0]
-    if rs.rand() < 0.3:           # food_mode: the killed leave food, attackers eat it
+    if rs.rand() < 0.3 and not fuzz_plain:           # food_mode: the killed leave food, attackers eat it
         food_mode = True
         for t in specs:
             t["food_supply"] = float(rs.choice([0, 0.05, 1, 2.5, 6]))
             t["eat_ability"] = float(rs.choice([0, 0.5, 1, 3]))
-    if rs.rand() < 0.15:          # one group of goals (can_absorb); goals are never given actions (engine scope)
+    if rs.rand() < 0.15 and not fuzz_plain:          # one group of goals (can_absorb); goals are never given actions (engine scope)
         goal = int(rs.randint(G))
         specs[goal]["can_absorb"] = True
         if os.environ.get("FUZZ_GOALS_ACT", "0") != "1":     # (=1: the goals are given actions like everybody -- they move: the literal loop)

@@ -168,6 +168,28 @@ def test_emulated_batch_cycle_of_worlds_given_their_actions_beforehand(emu):
         H.assert_same(H.run_cycle(sc, H.ensure_oracle(), fused=False, preset=True), g, sc.name + " (preset actions, batch of 2, hipemu)")
 
 
+def test_emulated_batched_pipeline(emu):
+    """env_cycle_many over worlds beyond the one-launch step: ONE launch per phase of the plain pipeline for all of them (pipe.hip:
+    k_pipe_render, _set_action, _draw, _rank, _eval x rounds, _strike, _commit, then _clear + _finish with get_reward folded in), beside a
+    small world on the two-launch cycle and one that goes alone in the same call -- every environment against the oracle driven alone
+    through the reference call sequence; also with the small world in the pipeline's batch too (batch_pipe_min=1) and one optimistic pair
+    of rounds only, and with none at all (attack_pairs=0: every step of every environment is finished by the host, environment by environment)"""
+    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import helpers as H\n"
+            "emu = H.ensure_emu()\n"
+            "scs = H.pipe_batch_scenarios()\n"
+            "seen = []\n"
+            "got = H.run_cycle_batch(scs, emu, envs_out=seen)\n"
+            "for sc, g in zip(scs, got):\n"
+            "    H.assert_same(H.run_cycle(sc, H.ensure_oracle(), fused=False), g, sc.name + ' (batched pipeline, hipemu)')\n"
+            "stats = [e.pipeline_stats() for e in seen]\n"
+            "assert all(s[6] >= 8 for s in stats[:3]) and (stats[3][6] > 0) == any(k in os.environ.get('MAGENT_TUNE', '') for k in ('batch_pipe_min=1', 'attack_pairs=0')) and stats[4][6] == 0, stats\n"
+            "print('ok', stats)\n") % (ROOT, os.path.join(ROOT, "tests"))
+    for extra in ({}, {"HIPEMU_SCRAMBLE": "7"}, {"MAGENT_TUNE": "attack_pairs=1,batch_pipe_min=1"}, {"MAGENT_TUNE": "attack_pairs=0", "HIPEMU_SCRAMBLE": "9"}):
+        p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"OMP_NUM_THREADS": "1"}, extra), capture_output=True, text=True, timeout=1500)
+        assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1500:] + p.stderr[-3000:])
+
+
 @pytest.mark.parametrize("env,needle", [({"MAGENT_SOLO_STEP": "0"}, "MAGENT_TUNE=solo_step="), ({"MAGENT_RENDER_PAD": "1"}, "has no successor"),
                                         ({"MAGENT_TUNE": "solo_stepp=0"}, "unknown entry")],
                          ids=["removed_variable_with_successor", "removed_variable_without", "unknown_tune_key"])

@@ -60,7 +60,7 @@ def test_fullsize_device_abi_matches_reference_digest(name):
     (examples/train_battle.py --map_size 3536: 2 x 499,849 agents in the script's own formation, 12.5 M cells) and the same two
     lattices interleaved (a million agents with hostile neighbours)"""
     r = _golden_check([name], device_io=True, timeout=2400)[name]
-    plain_steps, two, one, refills, _, ran_out = r["pipeline_stats"]
+    plain_steps, two, one, refills, _, ran_out = r["pipeline_stats"][:6]
     assert plain_steps == r["steps"] == FULL[name].steps, r          # the multi-launch pipeline played every step
     if name == "c3_battle1000_long":
         # (a step whose rounds run out puts the budget back to two pairs for 64 steps: on the MI355X that happens once in this episode,
@@ -143,7 +143,7 @@ def test_long_episodes_of_the_plain_pipeline(tune):
     The test asserts that the pipeline really played every step, that the window was refilled, and that both pair budgets were used.
     (A refill every 64 steps instead of 63 makes this test fail: tests/README.md, profiles/r06_raw/mutation_refill.txt.)"""
     r = _golden_check(["battle300_long"], tune)["battle300_long"]
-    plain_steps, two, one, refills, _, ran_out = r["pipeline_stats"]
+    plain_steps, two, one, refills, _, ran_out = r["pipeline_stats"][:6]
     assert r["steps"] == 200 and plain_steps == 200, r
     assert refills >= 4, r                     # the first step, steps 63 / 126 / 189 (the reinforcements' steps too: add_agents keeps the words)
     if tune == "attack_pairs=0":
@@ -218,6 +218,18 @@ def test_one_launch_cycle_between_the_two_limits():
     for extra in ({"MAGENT_TUNE": "solo_max=16384"}, {}):
         p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"OMP_NUM_THREADS": "1"}, extra), capture_output=True, text=True, timeout=900)
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1000:] + p.stderr[-3000:])
+
+
+def test_fuzz_batched_pipeline():
+    """three environments per random PLAIN game (FUZZ_PLAIN=1: one-cell bodies, subject-paying attack / kill rules, one view window -- what
+    the pipeline of plain games takes) in ONE magent_amd.EnvBatch with every world sent through the batched pipeline (batch_pipe_min=1:
+    pipe.hip's one launch per phase for all of them), each against the oracle driven alone through the reference call sequence; the second
+    leg with one optimistic pair of death-rank rounds (steps that run out are finished by the host, environment by environment)"""
+    for tune in ("batch_pipe_min=1", "batch_pipe_min=1,attack_pairs=1"):
+        env = dict(os.environ, OMP_NUM_THREADS="1", FUZZ_BATCH="3", FUZZ_PLAIN="1", MAGENT_TUNE=tune)
+        out = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fuzz_parity.py"), "oracle", "hip", "0", "150"], env=env,
+                             capture_output=True, text=True, timeout=1500)
+        assert out.returncode == 0 and "150 seeds, 0 failures" in out.stdout and "batched pipeline (pipe.hip): 150" in out.stdout, (tune, out.stdout[-3000:], out.stderr[-2000:])
 
 
 def test_fuzz_batched_cycle():

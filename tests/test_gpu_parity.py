@@ -67,6 +67,31 @@ def test_batch_cycle_of_worlds_given_their_actions_beforehand(oracle):
         H.assert_same(H.run_cycle(sc, oracle, fused=False, preset=True), g, sc.name + " (preset actions, batch of 2)")
 
 
+def test_batched_pipeline(oracle):
+    """env_cycle_many over worlds beyond the one-launch step: one launch per phase of the plain pipeline for all of them (pipe.hip), beside a
+    world on the two-launch cycle and one that goes alone in the same call; every environment against the oracle driven alone through the
+    reference call sequence.  Then two worlds of 80,000 agents with kills from the first step (their renders are launches of their own:
+    the sweeping kernel) beside a 2000-agent one."""
+    import copy
+    scs = H.pipe_batch_scenarios()
+    seen = []
+    got = H.run_cycle_batch(scs, H.HIP_LIB, envs_out=seen)
+    for sc, g in zip(scs, got):
+        H.assert_same(H.run_cycle(sc, oracle, fused=False), g, sc.name + " (batched pipeline)")
+    stats = [e.pipeline_stats() for e in seen]
+    assert all(s[6] >= 8 for s in stats[:3]) and stats[3][6] == 0 and stats[4][6] == 0, stats
+    big = []
+    for k in range(2):
+        c = copy.deepcopy(SCENARIOS["battle_brawl_dense_big"]); c.seed, c.action_seed, c.obs_every = 777 + k, 50 + k, 1
+        big.append(c)
+    big.append(H.pipe_batch_scenarios()[0])
+    seen = []
+    got = H.run_cycle_batch(big, H.HIP_LIB, envs_out=seen)
+    for sc, g in zip(big, got):
+        H.assert_same(H.run_cycle(sc, oracle, fused=False), g, sc.name + " (batched pipeline, 2 x 80,000 agents + 2000)")
+    assert all(e.pipeline_stats()[6] >= 6 for e in seen), [e.pipeline_stats() for e in seen]
+
+
 @pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) did not travel")
 @pytest.mark.parametrize("name", ["battle_brawl", "battle_largemap", "gather"])
 def test_hip_matches_compiled_reference(name):
