@@ -144,7 +144,7 @@ struct WorldView {
 
 // What a step reports to the host.  The one-launch step (k_step_solo) writes it straight into pinned host memory and
 // publishes `seq` last; the host spins on `seq` instead of synchronising the stream.
-struct StepRecord {
+struct alignas(16) StepRecord {
     int dead[MAXG], taken[MAXG]; // dead_ct per group as of this step (accumulated until clear_dead); movers taken in by goals
     unsigned long long triggers; // bit k: reward rule k fired in this step
     unsigned rng;                // engine RNG state after the step

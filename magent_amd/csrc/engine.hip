@@ -235,10 +235,10 @@ Env::~Env() {
     dfree(arena, d_mvnodes); dfree(arena, d_hit); dfree(arena, d_rule_args); dfree(arena, d_rule_progs); dfree(arena, batch_d); dfree(arena, d_asums); dfree(arena, d_wpre); dfree(arena, d_ptab); dfree(arena, d_alive);
     if (batch_h) (void)hipHostFree(batch_h);
     if (h_rec) (void)hipHostFree(h_rec);
-    dfree(arena, pipe_d); dfree(arena, pipec_d);
+    dfree(arena, pipe_d); dfree(arena, reports_d); dfree(arena, pipe_ticket); dfree(arena, d_newn);
     if (pipe_h) (void)hipHostFree(pipe_h);
-    if (pipec_h) (void)hipHostFree(pipec_h);
-    if (h_done) (void)hipHostFree(h_done);
+    if (reports_h) (void)hipHostFree(reports_h);
+    if (pipe_flag) (void)hipHostFree(pipe_flag);
     if (pool) {
         delete pool;
         for (int i = 0; i < COPY_RING; i++) { (void)hipHostFree(h_ring[i]); (void)hipEventDestroy(ring_ev[i]); }

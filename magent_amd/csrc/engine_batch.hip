@@ -247,41 +247,66 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
     const auto t1 = std::chrono::steady_clock::now();
     // ---------------- the pipeline, batched: one launch per phase for every world beyond the one-launch step (pipe.hip)
     PipeDims PD{};
+    std::vector<int> piped;
     if (lead_p >= 0) {
         Env &lead = *envs[lead_p];
         lead.use_device();
         if ((size_t)n_env > lead.pipe_cap) {
             HIP_OK(hipStreamSynchronize(lead.stream));
             if (lead.pipe_h) HIP_OK(hipHostFree(lead.pipe_h));
-            if (lead.pipec_h) HIP_OK(hipHostFree(lead.pipec_h));
-            dfree(lead.arena, lead.pipe_d); dfree(lead.arena, lead.pipec_d);
+            if (lead.reports_h) HIP_OK(hipHostFree(lead.reports_h));
+            dfree(lead.arena, lead.pipe_d); dfree(lead.arena, lead.reports_d);
             lead.pipe_cap = std::max<size_t>((size_t)n_env, lead.pipe_cap * 2);
             HIP_OK(hipHostMalloc((void **)&lead.pipe_h, sizeof(PipeItem) * lead.pipe_cap, hipHostMallocDefault));
-            HIP_OK(hipHostMalloc((void **)&lead.pipec_h, sizeof(PipeClear) * lead.pipe_cap, hipHostMallocDefault));
+            HIP_OK(hipHostMalloc((void **)&lead.reports_h, sizeof(StepRecord) * lead.pipe_cap, hipHostMallocDefault));
             HIP_OK(dev_malloc(lead.arena, &lead.pipe_d, sizeof(PipeItem) * lead.pipe_cap));
-            HIP_OK(dev_malloc(lead.arena, &lead.pipec_d, sizeof(PipeClear) * lead.pipe_cap));
+            HIP_OK(dev_malloc(lead.arena, &lead.reports_d, sizeof(StepRecord) * lead.pipe_cap));
+            if (!lead.pipe_ticket) {
+                HIP_OK(dev_malloc(lead.arena, &lead.pipe_ticket, sizeof(int)));
+                HIP_OK(hipMemsetAsync(lead.pipe_ticket, 0, sizeof(int), lead.stream));
+                HIP_OK(hipHostMalloc((void **)&lead.pipe_flag, sizeof(int), hipHostMallocDefault));
+                *lead.pipe_flag = 0;
+            }
         }
-        // the items of the batch are packed (item k = the k-th environment of kind 2): no empty grid planes
         // every environment launches as many rounds as the one with the largest budget (a round that has nothing to do returns at once)
         // (MAGENT_TUNE attack_pairs=N fixes the budget for the process: 0 leaves every attack phase to the host)
         int rounds = lead.opt_fixed ? 2 * lead.opt_attack_pairs : 2;
         for (int e = 0; e < n_env && !lead.opt_fixed; e++) if (kind[e] == 2) rounds = std::max(rounds, 2 * (envs[e]->boost_attack > 0 ? 2 : 1));
         PD.G = n_group; PD.rounds = rounds;
-        int k = 0;
+        // the observations: one sweeping launch when every observed group of the batch has the battle shape, else the generic render's
+        bool sweep_ok = true;
+        for (int e = 0; e < n_env; e++) if (kind[e] == 2) sweep_ok &= envs[e]->pipe_sweep_ok(view ? view + e * n_group : nullptr);
+        int sweep_feat = 0, sweep_vhw = 0;
+        long long sweep_steps = 0;
         for (int e = 0; e < n_env; e++) {
             if (kind[e] != 2) continue;
             const int o = e * n_group;
-            PipeItem &it = lead.pipe_h[k++];
-            envs[e]->pipe_prepare(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr, it, rounds);
+            PipeItem &it = lead.pipe_h[piped.size()];
+            envs[e]->pipe_prepare(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr, rewards ? rewards + o : nullptr, it, rounds, sweep_ok);
+            it.rec = lead.reports_d + piped.size();
+            piped.push_back(e);
             for (int g = 0; g < n_group; g++) PD.max_n = std::max(PD.max_n, it.W.grp[g].n);
             PD.max_total = std::max(PD.max_total, it.n_max);
             PD.kmax = std::max(PD.kmax, it.PW.kmax);
             PD.slots = std::max(PD.slots, it.M.n);
-            for (int q = 0; q < it.M.n; q++) { PD.render_blocks = std::max(PD.render_blocks, it.M.blocks[q]); PD.render_lds = std::max(PD.render_lds, render_strip_lds(it.M.P[q])); }
+            PD.hist_cells = std::max(PD.hist_cells, it.Mi.vh * it.Mi.vw);
+            for (int q = 0; q < it.M.n; q++) {
+                PD.render_blocks = std::max(PD.render_blocks, sweep_ok ? it.M.P[q].feat_blocks : it.M.blocks[q]);
+                PD.render_lds = std::max(PD.render_lds, sweep_ok ? render_sweep_lds(it.M.R[q].VH * it.M.R[q].VW, 7) : render_strip_lds(it.M.P[q]));
+                sweep_feat = std::max(sweep_feat, it.M.P[q].feat_blocks);
+                sweep_vhw = std::max(sweep_vhw, it.M.R[q].VH * it.M.R[q].VW);
+                sweep_steps = std::max(sweep_steps, ((long long)it.M.R[q].n * it.M.R[q].VH * it.M.R[q].VW + 63) / 64);
+            }
         }
-        PD.n_env = k;
-        HIP_OK(hipMemcpyAsync(lead.pipe_d, lead.pipe_h, sizeof(PipeItem) * (size_t)k, hipMemcpyHostToDevice, lead.stream));
-        launch_pipe_step(lead.stream, lead.pipe_d, PD);
+        PD.n_env = (int)piped.size();
+        if (sweep_ok && PD.slots > 0) {
+            // `sweep` workgroups per (environment, group) segment: ~4 workgroups per CU over the whole launch, at least 8 steps' worth each
+            const int segs = PD.n_env * PD.slots;
+            PD.sweep = (int)std::max<long long>(1, std::min<long long>(std::max(4, 1024 / segs), (sweep_steps + 7) / 8));
+        }
+        PipeCtl C{lead.reports_d, lead.reports_h, lead.pipe_ticket, lead.pipe_flag, ++lead.pipe_flag_seq, PD.n_env};
+        HIP_OK(hipMemcpyAsync(lead.pipe_d, lead.pipe_h, sizeof(PipeItem) * piped.size(), hipMemcpyHostToDevice, lead.stream));
+        launch_pipe_cycle(lead.stream, lead.pipe_d, PD, C);
         HIP_OK(hipGetLastError());
     }
     for (int e = 0; e < n_env; e++) if (kind[e] == 0) { alone.push_back(e); envs[e]->batch_width = 1; }
@@ -298,38 +323,17 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
     if (lead_p >= 0) {
         Env &lead = *envs[lead_p];
         lead.use_device();
-        // the steps' reports (they left the device ahead of the moves), then get_reward + clear_dead of every environment in two launches
-        int k = 0;
-        bool any = false;
-        for (int e = 0; e < n_env; e++) {
-            if (kind[e] != 2) continue;
-            envs[e]->step_end(&done[e]);
-            if (first) { t3 = std::chrono::steady_clock::now(); first = false; }
-        }
-        for (int e = 0; e < n_env; e++) {
-            if (kind[e] != 2) continue;
-            PipeClear &cl = lead.pipec_h[k++];
-            any |= envs[e]->pipe_clear(rewards ? rewards + e * n_group : nullptr, cl);
-            PD.hist_lds = std::max(PD.hist_lds, sizeof(int) * (size_t)cl.M.vh * cl.M.vw);
-        }
-        if (any) {
-            HIP_OK(hipMemcpyAsync(lead.pipec_d, lead.pipec_h, sizeof(PipeClear) * (size_t)k, hipMemcpyHostToDevice, lead.stream));
-            launch_pipe_clear(lead.stream, lead.pipe_d, lead.pipec_d, PD);
-            HIP_OK(hipGetLastError());
-        }
-        // env_cycle_many promises finished outputs at return: k_pipe_finish sets a word per environment behind everything else
-        k = 0;
-        for (int e = 0; e < n_env; e++) {
-            if (kind[e] != 2) continue;
-            const PipeClear &cl = lead.pipec_h[k++];
-            if (cl.gtab) {
-                for (unsigned spins = 0; __atomic_load_n(cl.done_flag, __ATOMIC_ACQUIRE) != cl.done_seq; spins++)
-                    if ((spins & 0x3FFF) == 0x3FFF) {
-                        const hipError_t q = hipStreamQuery(lead.stream);
-                        if (q == hipSuccess) { if (__atomic_load_n(cl.done_flag, __ATOMIC_ACQUIRE) == cl.done_seq) break; fatal("the batched clear_dead finished without publishing its word"); }
-                        if (q != hipErrorNotReady) fatal("batched cycle failed: %s", hipGetErrorString(q));
-                    }
-            } else HIP_OK(hipStreamSynchronize(envs[e]->stream));      // (it ended its cycle by launches of its own)
+        // ONE word for the whole batch: k_pipe_finish's last workgroup sets it behind every environment's outputs and reports
+        for (unsigned spins = 0; __atomic_load_n(lead.pipe_flag, __ATOMIC_ACQUIRE) != lead.pipe_flag_seq; spins++)
+            if ((spins & 0x3FFF) == 0x3FFF) {
+                const hipError_t q = hipStreamQuery(lead.stream);
+                if (q == hipSuccess) { if (__atomic_load_n(lead.pipe_flag, __ATOMIC_ACQUIRE) == lead.pipe_flag_seq) break; fatal("the batched cycle finished without publishing its word"); }
+                if (q != hipErrorNotReady) fatal("batched cycle failed: %s", hipGetErrorString(q));
+            }
+        if (first) { t3 = std::chrono::steady_clock::now(); first = false; }
+        for (size_t k = 0; k < piped.size(); k++) {
+            const int e = piped[k];
+            envs[e]->pipe_after(rewards ? rewards + e * n_group : nullptr, lead.reports_h[k], &done[e]);
             envs[e]->batch_width = 1;
             envs[e]->pipe_rounds++;
         }
@@ -368,14 +372,26 @@ bool Env::pipe_eligible(int n_group, float *const *view, float *const *feat, con
     return n_obs <= RENDER_MULTI_MAX;
 }
 
-// Everything of one environment's cycle up to the step's report, as an item of the batch: what observe_device, set_action_device and
-// step_begin would do on the host, with the launches left to the batch (launch_pipe_step).  Stale state that only the first cycle meets
+// are this environment's observed groups of the shape the sweeping render takes?  (Env::cycle_many: one launch form for the whole batch)
+bool Env::pipe_sweep_ok(float *const *view) {
+    const WorldView W = this->view();
+    for (int g = 0; g < (int)groups.size(); g++) {
+        if (!(view && view[g]) || groups[g].n == 0) continue;
+        RenderArgs R; RenderPlan P;
+        plan_render(g, R, P, nullptr, nullptr);
+        if (!render_sweep_mini_ok(W, R)) return false;
+    }
+    return true;
+}
+
+// Everything of one environment's cycle as an item of the batch: what observe_device, set_action_device, step_begin, get_reward_device and
+// clear_dead would do on the host, with the launches left to the batch (launch_pipe_cycle).  Stale state that only the first cycle meets
 // -- the painted map, the first minimap, tables, grown buffers -- is brought up to date by launches of the environment's own, on the
 // batch's stream, ahead of the batch's.
-void Env::pipe_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, PipeItem &it, int rounds) {
+void Env::pipe_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, PipeItem &it, int rounds, bool sweep_ok) {
     enter();
     const int NG = (int)groups.size();
-    (void)n_group;
+    (void)n_group; (void)sweep_ok;
     int total_n = 0;
     for (auto &g : groups) total_n += g.n;
     if (!tables_valid) ensure_tables();
@@ -399,7 +415,7 @@ void Env::pipe_prepare(int n_group, float *const *view, float *const *feat, cons
     // ---- set_action: tile counts per call, in call order (Env::set_action_device)
     step_sa_tiled = true; sa_tiles = 0;
     step_calls.clear();
-    for (int g = 0; g < MAXG; g++) { it.actions[g] = nullptr; it.call_base[g] = 0; it.P.off[g] = -1; }
+    for (int g = 0; g < MAXG; g++) { it.actions[g] = nullptr; it.call_base[g] = 0; it.P.off[g] = -1; it.rewards[g] = nullptr; it.group_reward[g] = 0; }
     for (int g = 0; g < NG; g++) {
         HostGroup &G = groups[g];
         if (!(actions && actions[g])) continue;
@@ -414,7 +430,7 @@ void Env::pipe_prepare(int n_group, float *const *view, float *const *feat, cons
         grow(arena, d_asums, asums_cap, (size_t)sa_tiles, stream);
         grow(arena, d_wpre, wpre_cap, asums_cap * (SCAN_TILE_HOST / 64), stream);
     }
-    // ---- the step (Env::step_begin, single-sync driver, plain games, rules fused, the report ahead of the moves)
+    // ---- the step (Env::step_begin, single-sync driver, plain games, rules fused)
     step_live_paint = live_paint_now = paint_valid;
     step_pending = true;
     map_warm = false;
@@ -431,54 +447,61 @@ void Env::pipe_prepare(int n_group, float *const *view, float *const *feat, cons
     it.B = shuffle_bufs(); it.powtab = d_powtab;
     it.sums = d_asums; it.wpre = d_wpre;
     it.R = strike_rules(rule_args.data(), (int)rule_args.size());
-    it.rec = h_rec; it.seq = ++step_seq;
+    it.seq = ++step_seq;              // (it.rec: the batch's)
     it.n_max = total_n;
     alive_valid = true;
     stale_events = true;
     for (auto &g : groups) g.sa_off = -1;
+    // ---- get_reward + clear_dead (Env::get_reward_device, Env::clear_dead: the form with k_strike's survivor counts; which groups compact
+    // is decided on the device)
+    it.A = ClearArgs{};
+    for (int g = 0; g < NG; g++) {
+        HostGroup &G = groups[g];
+        if (rewards && rewards[g] && G.n > 0) { it.rewards[g] = rewards[g]; it.group_reward[g] = G.group_reward; }
+        it.A.sums_off[g] = alive_off[g];
+        it.A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed, G.alt.dir};
+    }
+    it.A.sums_per_tile = SCAN_TILE_HOST / 256;
+    it.alive_sums = d_alive;
+    it.Mi = next_minimap();
+    it.counts = fold_counts();
+    pipe_folded = it.Mi.vh > 0;
+    it.gtab_out = d_gtab; it.ttab_out = d_ttab;
+    if (!d_newn) HIP_OK(dev_malloc(arena, &d_newn, sizeof(int) * MAXG));
+    it.newn = d_newn;
     state_epoch++;
 }
 
-// get_reward + clear_dead of one environment as an item of the batch (Env::get_reward_device, Env::clear_dead: the three-launch form, with
-// the survivor counts k_strike left).  Returns false -- and runs the ordinary calls -- when those counts do not describe the groups.
-bool Env::pipe_clear(float *const *rewards, PipeClear &cl) {
-    cl = PipeClear{};
-    enter();
+// The host's side of the end of a batched cycle: the step's report (Env::step_end: `done`, death counts, the generator -- and, when the
+// optimistic rounds ran out, the continuation of the step), then the mirror of what k_pipe_clear / k_pipe_finish did on the device.  An
+// environment whose step the host had to finish was skipped by those kernels: its rewards and its clear_dead are the ordinary calls.
+void Env::pipe_after(float *const *rewards, const StepRecord &report, int *done) {
+    static_assert(offsetof(StepRecord, marks) == PIPE_REPORT_BYTES && sizeof(StepRecord) % 16 == 0, "what k_pipe_finish sends of a report: everything ahead of the tuning marks");
+    std::memcpy((void *)h_rec, (const void *)&report, PIPE_REPORT_BYTES);
+    h_rec->n_marks = 0;
+    h_rec->seq = step_seq;
+    const int fallbacks = fallback_steps;
+    step_end(done);
     const int NG = (int)groups.size();
-    bool counted = alive_valid;
-    for (int g = 0; g < NG; g++) counted &= groups[g].n == alive_n[g];
-    if (!counted) {          // (a step that the host finished re-ran k_strike over the same groups: still counted; anything else comes here)
+    if (fallback_steps != fallbacks) {
         for (int g = 0; g < NG; g++) if (rewards && rewards[g]) get_reward_device(g, rewards[g]);
         clear_dead();
-        return false;
+        HIP_OK(hipStreamSynchronize(stream));      // (env_cycle_many promises finished outputs at return)
+        return;
     }
-    if (!h_done) { HIP_OK(hipHostMalloc((void **)&h_done, sizeof(int), hipHostMallocDefault)); *h_done = 0; }
+    enter();
     bool any = false;
     for (int g = 0; g < NG; g++) {
         HostGroup &G = groups[g];
-        if (rewards && rewards[g] && G.n > 0) { cl.rewards[g] = rewards[g]; cl.group_reward[g] = G.group_reward; }
         G.group_reward = 0;
         const int gone = G.h_dead + G.h_taken;
-        cl.A.mode[g] = G.n == 0 ? 0 : (gone > 0 ? 2 : 1);
-        cl.A.sums_off[g] = alive_off[g];
-        cl.A.dst[g] = {G.alt.x, G.alt.y, G.alt.id, G.alt.last_action, G.alt.hp, G.alt.next_reward, G.alt.last_reward, G.alt.absorbed, G.alt.dir};
-        cl.new_n[g] = G.n - gone;
-        any |= gone > 0;
-    }
-    cl.A.sums_per_tile = SCAN_TILE_HOST / 256;
-    cl.sums = d_alive;
-    cl.M = next_minimap();
-    cl.counts = fold_counts();
-    cl.gtab = d_gtab; cl.ttab = d_ttab;
-    cl.done_flag = h_done; cl.done_seq = step_seq;
-    for (int g = 0; g < NG; g++) {
-        HostGroup &G = groups[g];
-        if (cl.A.mode[g] == 2) {       // survivors: double-buffered arrays went to alt, the rest is reset in place
+        if (gone > 0 && G.n > 0) {       // survivors: double-buffered arrays went to alt, the rest was reset in place
             std::swap(G.cur.x, G.alt.x); std::swap(G.cur.y, G.alt.y); std::swap(G.cur.id, G.alt.id);
             std::swap(G.cur.hp, G.alt.hp); std::swap(G.cur.last_action, G.alt.last_action);
             std::swap(G.cur.last_reward, G.alt.last_reward); std::swap(G.cur.next_reward, G.alt.next_reward);
             std::swap(G.cur.absorbed, G.alt.absorbed); std::swap(G.cur.dir, G.alt.dir);
-            G.n -= G.h_dead + G.h_taken;
+            G.n -= gone;
+            any = true;
         }
         G.h_dead = 0; G.h_taken = 0;
         G.indexed = G.n;
@@ -487,8 +510,7 @@ bool Env::pipe_clear(float *const *rewards, PipeClear &cl) {
     if (any) { h_occ_valid = false; mini_valid = false; }
     stale_events = false;
     alive_valid = false;
-    if (cl.M.vh > 0) { mini_valid = true; mini_pop = mini_population(mini_skip); }
-    return true;
+    if (pipe_folded) { mini_valid = true; mini_pop = mini_population(mini_skip); }
 }
 
 // every environment of a batch shares the first one's stream (kept alive by whoever still uses it)

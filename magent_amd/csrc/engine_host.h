@@ -214,10 +214,14 @@ private:
     BatchItem *batch_h = nullptr, *batch_d = nullptr; size_t batch_cap = 0;   // (lead environment of a batch)
     // many environments per launch through the pipeline of plain games (engine_batch.hip: "the pipeline, batched"; pipe.hip)
     bool pipe_eligible(int n_group, float *const *view, float *const *feat, const int *const *actions, int *total_out);
-    void pipe_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, PipeItem &it, int rounds);
-    bool pipe_clear(float *const *rewards, PipeClear &cl);
-    PipeItem *pipe_h = nullptr, *pipe_d = nullptr; PipeClear *pipec_h = nullptr, *pipec_d = nullptr; size_t pipe_cap = 0;   // (lead environment of such a batch)
-    int *h_done = nullptr;                // pinned: k_pipe_finish's word for this environment (PipeClear::done_flag)
+    void pipe_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, PipeItem &it, int rounds, bool sweep_ok);
+    void pipe_after(float *const *rewards, const StepRecord &report, int *done);
+    bool pipe_sweep_ok(float *const *view);
+    // (lead environment of such a batch) the items, every environment's report on the device and in pinned memory, the last-workgroup ticket
+    PipeItem *pipe_h = nullptr, *pipe_d = nullptr; StepRecord *reports_d = nullptr, *reports_h = nullptr; size_t pipe_cap = 0;
+    int *pipe_ticket = nullptr, *pipe_flag = nullptr; int pipe_flag_seq = 0;
+    int *d_newn = nullptr;                // [MAXG] group sizes behind the batched compaction (PipeItem::newn)
+    bool pipe_folded = false;             // the batch's compaction makes the next minimap
     int pipe_rounds = 0;                  // cycles this environment took through the batched pipeline (env_get_info "pipeline_stats")
     void wait_record(int seq);
     StepRecord *h_rec = nullptr;          // pinned: written by k_step_solo, spun on by step_end

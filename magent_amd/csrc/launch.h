@@ -201,7 +201,9 @@ void launch_init_reward(hipStream_t s, const WorldView &W, int g);
 void launch_compact(hipStream_t s, const WorldView &W, int g, const GroupDev &D, int new_n, int *sums);
 
 // ---- many environments per launch through the pipeline of plain games (env_cycle_many on worlds beyond the one-launch step; pipe.hip).
-// One PipeItem per environment, in a device array; every kernel of the batch finds its environment by blockIdx.z.
+// One PipeItem per environment, in a device array; every kernel of the batch finds its environment by blockIdx.z.  The whole cycle --
+// observations, set_action, step, get_reward, clear_dead -- is ONE chain of launches without a host round trip in it: what the host would
+// decide between the step and clear_dead (which groups compact, the sizes behind the compaction) the kernels read from the death counters.
 struct PipeItem {
     WorldView W;
     PlainWorld PW;
@@ -211,21 +213,24 @@ struct PipeItem {
     SeqPlan P;                         // where each group's call leaves them (-1: the group is given no actions)
     const int *actions[MAXG]; int call_base[MAXG];
     StrikeRules R;
-    StepRecord *rec; int seq;
+    StepRecord *rec; int seq;          // DEVICE memory: the step's report (the batch's last workgroup sends all of them to the host at once)
     int n_max;                         // agents of all groups: the bound of the attack list
     RenderMulti M;                     // the observations (M.n == 0: rendered by launches of the environment's own, ahead of the batch)
-};
-// ... and what the end of the cycle needs once the host has seen the step's report: get_reward + clear_dead
-struct PipeClear {
-    ClearArgs A; MiniArgs M; int *counts; const int *sums;
-    int new_n[MAXG];                   // group sizes behind the compaction
+    // ---- get_reward + clear_dead (an environment whose attack rounds ran out is skipped: the host finishes its step and clears it)
+    ClearArgs A;                       // (mode: decided on the device; sums_off / dst as Env::clear_dead sets them)
+    MiniArgs Mi; int *counts;          // the next observations' minimap, folded into the compaction
+    const int *alive_sums;             // k_strike's survivor counts
     float *rewards[MAXG]; float group_reward[MAXG];
-    GroupDev *gtab; TypeDev *ttab;     // device tables to refresh
-    int *done_flag; int done_seq;      // pinned: set once the environment's outputs are complete (the host spins on it)
+    GroupDev *gtab_out; TypeDev *ttab_out;
+    int *newn;                         // [MAXG] device scratch: group sizes behind the compaction (k_pipe_clear -> k_pipe_finish)
 };
-struct PipeDims { int n_env, max_n, max_total, G, slots, render_blocks, rounds, kmax; size_t render_lds, hist_lds; };
-void launch_pipe_step(hipStream_t s, const PipeItem *d_items, const PipeDims &D);
-void launch_pipe_clear(hipStream_t s, const PipeItem *d_items, const PipeClear *d_clears, const PipeDims &D);
+// what the batch's last workgroup does: every environment's report to pinned host memory in one piece, then the word the host waits for
+struct PipeCtl { const StepRecord *reports_d; StepRecord *reports_h; int *ticket; int *flag_h; int flag_seq; int n_env; };
+constexpr int PIPE_REPORT_BYTES = 128;     // of a StepRecord: everything ahead of the tuning marks
+struct PipeDims { int n_env, max_n, max_total, G, slots, render_blocks, rounds, kmax, sweep, hist_cells; size_t render_lds; };
+void launch_pipe_cycle(hipStream_t s, const PipeItem *d_items, const PipeDims &D, const PipeCtl &C);
+bool render_sweep_mini_ok(const WorldView &W, const RenderArgs &R);
+size_t render_sweep_lds(int VHW, int C);
 
 // agents per workgroup of the scan-based passes (set_action, clear_dead).  2 per thread: at 400k agents that is 782 workgroups --
 // the earlier 8 per thread left 196, less than one per CU, and every such launch was bound by its own latency chain

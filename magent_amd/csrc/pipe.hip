@@ -6,9 +6,14 @@
 // work, config 4 (gather 500 x 500, 100k agents) 13 around 70.  Reinforcement-learning callers run MANY such worlds per GPU; here the same
 // kernel bodies (plain_dev.h) are launched ONCE per phase for all environments of an env_cycle_many call:
 //   grid = (tiles of the largest group, groups, environments), the environment's description read from a device array of PipeItem
-// so that n environments cost one chain of launches instead of n.  GridWorld.cc:292-401 (observations), :403-454 (set_action), :456-631
-// (step), :694-704 (get_reward), :633-665 (clear_dead) -- bit-identical to the same environments stepped one by one (the bodies are the same).
+// so that n environments cost one chain of launches instead of n -- and the chain has no host round trip in it: which groups compact, and
+// to what size, k_pipe_clear / k_pipe_finish read from the death counters the step left (the host learns the same numbers from the
+// reports, which the batch's last workgroup sends to pinned memory in one piece: 32 separate reports cost 32 x 20 small PCIe writes,
+// 43 us of the first version's k_pipe_commit).
+// GridWorld.cc:292-401 (observations), :403-454 (set_action), :456-631 (step), :694-704 (get_reward), :633-665 (clear_dead) -- bit-identical
+// to the same environments stepped one by one (the bodies are the same).
 #include "plain_dev.h"
+#include "render_sweep_dev.h"
 
 namespace magent_amd {
 
@@ -28,6 +33,18 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_pipe_render(const PipeIte
     if (it.W.vc_packed) render_block<true, true, 1, true, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
     else render_block<true, true, 1, false, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
 }
+// ... and when every observed group of the batch has the battle shape [wall | has, hp, minimap | has, hp, minimap] (two groups, packed view
+// cells): the sweeping kernel (render_sweep_dev.h), `sweep` workgroups per (environment, group) segment + the feature rows' workgroups
+__global__ void __launch_bounds__(64 * RENDER_WAVES) k_pipe_render_sweep(const PipeItem *__restrict__ items, int slots, int sweep) {
+    const int e = blockIdx.y / slots, k = blockIdx.y - e * slots;
+    const PipeItem &it = items[e];
+    if (k >= it.M.n) return;
+    const RenderArgs R = it.M.R[k];
+    const RenderPlan P = it.M.P[k];
+    RenderWorld V;
+    V.w = it.W.w; V.h = it.W.h; V.G = it.W.G; V.viewcell = it.W.viewcell; V.mask = it.W.mask; V.grp = it.W.grp[R.g]; V.type = it.W.type[R.g];
+    render_sweep2_body<false, 2, 2, true>(V, R, P, sweep);
+}
 __global__ void __launch_bounds__(SCAN_THREADS) k_pipe_set_action(const PipeItem *__restrict__ items) {
     PIPE_ITEM();
     if (!it.actions[g] || (int)(blockIdx.x * SCAN_TILE) >= it.W.grp[g].n) return;
@@ -46,73 +63,102 @@ __global__ void __launch_bounds__(256) k_pipe_eval(const PipeItem *__restrict__ 
     PIPE_ITEM();
     plain_eval_body(it.W, it.PW, it.ptab, it.gtab, it.ttab, round, flag, it.B.head, it.B.first);
 }
+// tests only (MAGENT_TUNE attack_pairs=0): no optimistic round at all -- every environment's attack phase is left open for the host
+__global__ void k_pipe_force_open(const PipeItem *__restrict__ items) {
+    if (threadIdx.x == 0) items[blockIdx.x].W.counters[CTR_OPEN_ATTACK] = 1;
+}
 __global__ void __launch_bounds__(256) k_pipe_strike(const PipeItem *__restrict__ items) {
     PIPE_ITEM();
     strike_body(it.W, it.PW, it.ptab, it.gtab, it.ttab, it.R);
 }
 __global__ void __launch_bounds__(256) k_pipe_commit(const PipeItem *__restrict__ items) {
     PIPE_ITEM();
-    plain_commit_body(it.W, it.PW, it.rec, it.seq);
+    plain_commit_body(it.W, it.PW, it.rec, it.seq);         // (the report goes to device memory here: k_pipe_finish sends them all)
 }
-// tests only (MAGENT_TUNE attack_pairs=0): no optimistic round at all -- every environment's attack phase is left open for the host
-__global__ void k_pipe_force_open(const PipeItem *__restrict__ items) {
-    if (threadIdx.x == 0) items[blockIdx.x].W.counters[CTR_OPEN_ATTACK] = 1;
+// dead_ct + movers taken in of group g, as the step left them (Env::step_end adds up the same counters from the report)
+__device__ __forceinline__ int pipe_gone(const int *counters, int g) {
+    int gone = counters[CTR_TAKEN + g];
+#pragma unroll
+    for (int k = 0; k < DEAD_SLOTS; k++) gone += counters[dead_slot(g, k)];
+    return gone;
 }
 // get_reward + clear_dead's compaction (Agent::init_reward alone for groups without deaths), the next minimap's histogram
-__global__ void __launch_bounds__(SCAN_THREADS) k_pipe_clear(const PipeItem *__restrict__ items, const PipeClear *__restrict__ clears) {
+__global__ void __launch_bounds__(SCAN_THREADS) k_pipe_clear(const PipeItem *__restrict__ items) {
     PIPE_ITEM();
-    const PipeClear &cl = clears[blockIdx.z];
-    if (cl.A.mode[g] == 0) return;
-    clear_compact_body(it.W, cl.A, cl.sums, cl.M, cl.counts, cl.rewards[g], cl.group_reward[g]);
+    if (attack_open(it.W)) return;             // the host finishes this environment's step, then clears it by launches of its own
+    const int n = it.W.grp[g].n;
+    if (n == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) it.newn[g] = 0; return; }
+    const int gone = pipe_gone(it.W.counters, g);
+    if (blockIdx.x == 0 && threadIdx.x == 0) it.newn[g] = n - gone;
+    clear_compact_body(it.W, it.A, gone > 0 ? 2 : 1, it.alive_sums, it.Mi, it.counts, it.rewards[g], it.group_reward[g]);
 }
-// ... then the death counters, the device copies of the group / type tables as the compaction leaves them (the double-buffered arrays have
-// changed places: ClearArgs::dst are the current ones), the division of the next minimap -- and the word the host waits for
-__global__ void __launch_bounds__(256) k_pipe_finish(const PipeItem *__restrict__ items, const PipeClear *__restrict__ clears) {
+// ... then the death counters, the device copies of the group / type tables as the compaction leaves them (the double-buffered arrays of a
+// compacted group have changed places: ClearArgs::dst are the current ones), the division of the next minimap -- and, from the LAST
+// environment to get there, every environment's report to the host in one piece and the word the host waits for
+__global__ void __launch_bounds__(256) k_pipe_finish(const PipeItem *__restrict__ items, PipeCtl C) {
     const PipeItem &it = items[blockIdx.z];
-    const PipeClear &cl = clears[blockIdx.z];
-    if (cl.gtab == nullptr) return;            // an environment that ended its cycle by launches of its own
     const int NG = it.W.G;
+    const bool open = attack_open(it.W);
     if (blockIdx.x == 0) {
-        if (threadIdx.x < MAXG) {
-            const int q = threadIdx.x;
-            GroupDev N = it.W.grp[q];
-            if (q < NG) {
-                if (cl.A.mode[q] == 2) {
-                    const ClearArgs::Alt D = cl.A.dst[q];
-                    N.x = D.x; N.y = D.y; N.id = D.id; N.last_action = D.last_action; N.hp = D.hp; N.next_reward = D.next_reward;
-                    N.last_reward = D.last_reward; N.absorbed = D.absorbed; N.dir = D.dir;
+        if (!open) {
+            if (threadIdx.x < MAXG) {
+                const int q = threadIdx.x;
+                GroupDev N = it.W.grp[q];
+                if (q < NG) {
+                    const int n_new = it.newn[q];
+                    if (n_new != N.n) {            // compacted: mode 2
+                        const ClearArgs::Alt D = it.A.dst[q];
+                        N.x = D.x; N.y = D.y; N.id = D.id; N.last_action = D.last_action; N.hp = D.hp; N.next_reward = D.next_reward;
+                        N.last_reward = D.last_reward; N.absorbed = D.absorbed; N.dir = D.dir;
+                    }
+                    N.n = n_new;
                 }
-                N.n = cl.new_n[q];
+                it.gtab_out[q] = N; it.ttab_out[q] = it.W.type[q];
             }
-            cl.gtab[q] = N; cl.ttab[q] = it.W.type[q];
+            for (int q = 0; q < NG; q++) {         // (zero where the group did not compact: nothing to reset, nothing lost)
+                if (threadIdx.x < DEAD_SLOTS) it.W.counters[dead_slot(q, threadIdx.x)] = 0;
+                if (threadIdx.x == 0) it.W.counters[CTR_TAKEN + q] = 0;
+            }
         }
-        for (int q = 0; q < NG; q++) {
-            if (cl.A.mode[q] != 2) continue;
-            if (threadIdx.x < DEAD_SLOTS) it.W.counters[dead_slot(q, threadIdx.x)] = 0;
-            if (threadIdx.x == 0) it.W.counters[CTR_TAKEN + q] = 0;
-        }
-        // every output of the cycle -- rewards, compacted arrays (the launch before), tables -- is written: the host may return
-        __threadfence_system();
+        // every output of this environment's cycle -- rewards, compacted arrays (the launch before), tables -- is written
+        __threadfence();
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(cl.done_flag, cl.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __shared__ int s_last;
+        if (threadIdx.x == 0) s_last = atomicAdd(C.ticket, 1) == C.n_env - 1;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            const int words = PIPE_REPORT_BYTES / 16;                      // 16-byte pieces of one report
+            for (int k = threadIdx.x; k < C.n_env * words; k += blockDim.x) {
+                const int e = k / words, q = k - e * words;
+                ((uint4 *)&C.reports_h[e])[q] = ((const uint4 *)&C.reports_d[e])[q];
+            }
+            if (threadIdx.x == 0) *C.ticket = 0;
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(C.flag_h, C.flag_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
-    if (cl.M.vh > 0) {         // mini_norm_body with the sizes behind the compaction
-        const int VHW = cl.M.vh * cl.M.vw, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!open && it.Mi.vh > 0) {         // mini_norm_body with the sizes behind the compaction (k_pipe_clear left them)
+        const int VHW = it.Mi.vh * it.Mi.vw, k = blockIdx.x * blockDim.x + threadIdx.x;
         if (k < NG * VHW) {
-            const int tot = cl.new_n[k / VHW];
+            const int tot = it.newn[k / VHW];
             int cnt = 0;
-            for (int c = 0; c < MINI_COPIES; c++) { cnt += cl.counts[c * NG * VHW + k]; cl.counts[c * NG * VHW + k] = 0; }
-            cl.M.out[k] = tot == 0 ? __int_as_float(0xFFC00000) : __fdiv_rn((float)min(cnt, 1 << 24), (float)(unsigned)tot);
+            for (int c = 0; c < MINI_COPIES; c++) { cnt += it.counts[c * NG * VHW + k]; it.counts[c * NG * VHW + k] = 0; }
+            it.Mi.out[k] = tot == 0 ? __int_as_float(0xFFC00000) : __fdiv_rn((float)min(cnt, 1 << 24), (float)(unsigned)tot);
         }
     }
 }
 
 static size_t pipe_eval_lds(int kmax) { return (size_t)kmax * 256 * 8; }
-void launch_pipe_step(hipStream_t s, const PipeItem *d_items, const PipeDims &D) {
-    const dim3 by_agent((D.max_n + 255) / 256, D.G, D.n_env);
-    if (D.slots > 0 && D.render_blocks > 0)
+size_t render_sweep_lds(int VHW, int C) { return (size_t)RENDER_WAVES * 2 * 64 * C * sizeof(float) + (size_t)VHW * sizeof(RenderFastPos); }
+void launch_pipe_cycle(hipStream_t s, const PipeItem *d_items, const PipeDims &D, const PipeCtl &C) {
+    const dim3 by_agent((D.max_n + 255) / 256, D.G, D.n_env), by_tile((D.max_n + SCAN_TILE - 1) / SCAN_TILE, D.G, D.n_env);
+    if (D.slots > 0 && D.sweep > 0)
+        hipLaunchKernelGGL(k_pipe_render_sweep, dim3(D.sweep + D.render_blocks, D.n_env * D.slots), dim3(64 * RENDER_WAVES), D.render_lds, s, d_items, D.slots, D.sweep);
+    else if (D.slots > 0 && D.render_blocks > 0)
         hipLaunchKernelGGL(k_pipe_render, dim3(D.render_blocks, D.n_env * D.slots), dim3(64 * RENDER_WAVES), D.render_lds, s, d_items, D.slots);
-    hipLaunchKernelGGL(k_pipe_set_action, dim3((D.max_n + SCAN_TILE - 1) / SCAN_TILE, D.G, D.n_env), dim3(SCAN_THREADS), 0, s, d_items);
+    hipLaunchKernelGGL(k_pipe_set_action, by_tile, dim3(SCAN_THREADS), 0, s, d_items);
     hipLaunchKernelGGL(k_pipe_draw, dim3((D.max_total + 255) / 256, 1, D.n_env), dim3(256), 0, s, d_items);
     hipLaunchKernelGGL(k_pipe_rank, by_agent, dim3(256), 0, s, d_items);
     if (pipe_eval_lds(D.kmax) > (48u << 10))
@@ -123,11 +169,8 @@ void launch_pipe_step(hipStream_t s, const PipeItem *d_items, const PipeDims &D)
     if (D.rounds == 0) hipLaunchKernelGGL(k_pipe_force_open, dim3(D.n_env), dim3(64), 0, s, d_items);
     hipLaunchKernelGGL(k_pipe_strike, by_agent, dim3(256), 0, s, d_items);
     hipLaunchKernelGGL(k_pipe_commit, by_agent, dim3(256), 0, s, d_items);
-}
-void launch_pipe_clear(hipStream_t s, const PipeItem *d_items, const PipeClear *d_clears, const PipeDims &D) {
-    hipLaunchKernelGGL(k_pipe_clear, dim3((D.max_n + SCAN_TILE - 1) / SCAN_TILE, D.G, D.n_env), dim3(SCAN_THREADS), D.hist_lds, s, d_items, d_clears);
-    const int blocks = std::max(1, (int)((D.hist_lds / sizeof(int)) * D.G + 255) / 256);
-    hipLaunchKernelGGL(k_pipe_finish, dim3(blocks, 1, D.n_env), dim3(256), 0, s, d_items, d_clears);
+    hipLaunchKernelGGL(k_pipe_clear, by_tile, dim3(SCAN_THREADS), sizeof(int) * (size_t)D.hist_cells, s, d_items);
+    hipLaunchKernelGGL(k_pipe_finish, dim3(std::max(1, (D.hist_cells * D.G + 255) / 256), 1, D.n_env), dim3(256), 0, s, d_items, C);
 }
 
 }  // namespace magent_amd

@@ -425,7 +425,7 @@ __device__ __forceinline__ void plain_commit_body(const WorldView &W, const Plai
 // k_minimap + k_minimap_norm, two launches per cycle, gone: the positions pass through this kernel anyway)
 // (reward_out != null: GridWorld::get_reward (GridWorld.cc:694-704) rides along -- every agent's next_reward + the group's, the dead included,
 // read by the thread that resets it)
-__device__ __forceinline__ void clear_compact_body(const WorldView &W, const ClearArgs &A, const int *sums, const MiniArgs &M, int *counts,
+__device__ __forceinline__ void clear_compact_body(const WorldView &W, const ClearArgs &A, int mode, const int *sums, const MiniArgs &M, int *counts,
                                                    float *reward_out = nullptr, float group_reward = 0.0f) {
     extern __shared__ int s_hist[];
     const int g = blockIdx.y;
@@ -437,7 +437,7 @@ __device__ __forceinline__ void clear_compact_body(const WorldView &W, const Cle
         for (int k = threadIdx.x; k < VHW; k += SCAN_THREADS) s_hist[k] = 0;
         __syncthreads();
     }
-    if (A.mode[g] == 1) {
+    if (mode == 1) {
         for (int k = 0; k < SCAN_ITEMS; k++) {
             const int i = blockIdx.x * SCAN_TILE + k * SCAN_THREADS + threadIdx.x;
             if (i < G.n) {
@@ -447,7 +447,7 @@ __device__ __forceinline__ void clear_compact_body(const WorldView &W, const Cle
                 if (VHW > 0) atomicAdd(&s_hist[(G.y[i] / M.scale_h) * M.vw + G.x[i] / M.scale_w], 1);
             }
         }
-    } else if (A.mode[g] == 2) {
+    } else if (mode == 2) {
         const ClearArgs::Alt D = A.dst[g];
         const int bw = W.type[g].bw, bl = W.type[g].bl;
         // (the single-buffered state goes back to its rest values at every agent's OWN index -- all that matters are the positions below

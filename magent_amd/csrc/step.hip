@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_clear_count(WorldView W, Clear
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) k_clear_compact(WorldView W, ClearArgs A, const int *sums, MiniArgs M, int *counts) {
-    clear_compact_body(W, A, sums, M, counts);
+    clear_compact_body(W, A, A.mode[blockIdx.y], sums, M, counts);
 }
 __global__ void __launch_bounds__(256) k_mini_norm(WorldView Wn, MiniArgs M, int *counts) {
     mini_norm_body(Wn, M, counts, blockIdx.x * blockDim.x + threadIdx.x);
