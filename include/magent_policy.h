@@ -58,6 +58,33 @@ int policy_dqn_infer(const PolicyDqnShape *shape, const PolicyDqnWeights *weight
 int policy_dqn_infer_bf16(const PolicyDqnShape *shape, const PolicyDqnWeights *weights, const void *view_cells, const float *feature, int n,
                           void *act_workspace, int *actions, float *q, void *stream);
 
+/* ---- the same network in the reference's own arithmetic: float32 inputs, weights, activations and accumulation, on the f32 matrix
+ * instruction (v_mfma_f32_32x32x2_f32: bit for bit a k-ordered chain of fmaf) -- magent_amd/csrc/policy_f32.hip.
+ * Weights in "f32 fragment order" (float, 16-byte units of 4 values): the reduction index is cut into groups of 8; for group m and 32-wide
+ * output tile T, lane l (0..63) holds W[out = 32 T + (l & 31)][k = 8 m + 4 (l >> 5) + 0..3].  The reduction index k of each layer:
+ *   conv1      : tap (ky * 3 + kx) * 8 + channel (channels padded to 8); the bias is the weight of (tap 0, channel 7): the kernel
+ *                feeds a constant 1.0 there                                                                     [9][64][4]
+ *   conv2      : tap * 32 + channel                                                                              [36][64][4]
+ *   dense_view : position (y * (view_w - 4) + x) * 32 + channel                                                  [K/8][8][64][4]
+ *   dense_emb  : feature index (padded to a multiple of 8)                                                       [FK/8][8][64][4]
+ *   head       : hidden unit (dense_view's 256, then dense_emb's 256); outputs 0..n_action-1 = advantage, output n_action = value,
+ *                the rest zero                                                                                   [64][64][4]
+ * Channels, hidden units and biases are in their natural order (float[32], float[256], float[256]). */
+typedef struct {
+    const void *conv1, *conv2, *dense_view, *dense_emb, *head;
+    const float *conv2_bias, *dense_view_bias, *dense_emb_bias;
+    float value_bias;
+} PolicyDqnWeightsF32;
+
+/* 1 if the f32 kernels take this shape (view_c <= 7, feat <= 56, n_action <= 31, views up to ~19 x 19: the conv kernel's LDS images of
+ * two agents must fit 160 KB) */
+int policy_dqn_f32_supported(const PolicyDqnShape *shape);
+/* size of the activation workspace (conv2's output, float32) for n agents */
+int policy_dqn_f32_act_bytes(const PolicyDqnShape *shape, int n, size_t *bytes);
+/* as policy_dqn_infer: view float[n][view_h][view_w][view_c], feature float[n][feat] as env_get_observation_device writes them */
+int policy_dqn_infer_f32(const PolicyDqnShape *shape, const PolicyDqnWeightsF32 *weights, const float *view, const float *feature, int n,
+                         void *act_workspace, int *actions, float *q, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,11 +98,18 @@ class DeepQNetwork(BaseModel):
         self.infer_dtype = (infer_dtype or os.environ.get("MAGENT_POLICY_DTYPE", "f32")).lower()
         if self.infer_dtype not in ("f32", "bf16"):
             raise ValueError("infer_dtype must be 'f32' or 'bf16', not %r" % (self.infer_dtype,))
+        # "f32" on the GPU goes through hand-written kernels too since round 6: the same float32 arithmetic -- inputs, weights, activations,
+        # accumulation -- on the f32 matrix instruction (magent_amd/csrc/policy_f32.hip; tests/test_policy.py pins it to the PyTorch network
+        # within float32 round-off).  MAGENT_POLICY_F32=torch keeps the PyTorch / MIOpen forward pass (A/B runs, bench.py's comparison).
         self._hip = None
-        if self.device.type == "cuda" and self.infer_dtype == "bf16":
+        if self.device.type == "cuda":
             try:
-                from .hip_policy import HipDqnPolicy
-                self._hip = HipDqnPolicy(self.qnet, self.view_space, self.feature_space, self.num_actions, self.device)
+                if self.infer_dtype == "bf16":
+                    from .hip_policy import HipDqnPolicy
+                    self._hip = HipDqnPolicy(self.qnet, self.view_space, self.feature_space, self.num_actions, self.device)
+                elif os.environ.get("MAGENT_POLICY_F32", "hip").lower() != "torch":
+                    from .hip_policy import HipDqnPolicyF32
+                    self._hip = HipDqnPolicyF32(self.qnet, self.view_space, self.feature_space, self.num_actions, self.device)
             except (ValueError, OSError, AttributeError):
                 self._hip = None
         # replay memory; mask == 0 marks the padding transition that closes an unfinished episode (dqn.py:249-252)
@@ -128,8 +135,8 @@ class DeepQNetwork(BaseModel):
         eps = 0 if policy == "greedy" else eps
         n = len(view)
         if (self._hip is not None and n > 0 and isinstance(view, torch.Tensor) and isinstance(feature, torch.Tensor) and view.is_cuda
-                and view.dtype in (torch.float32, torch.bfloat16) and feature.dtype == torch.float32 and view.is_contiguous()
-                and feature.is_contiguous()):
+                and (view.dtype == torch.float32 or (view.dtype == torch.bfloat16 and self.infer_dtype == "bf16")) and feature.dtype == torch.float32
+                and view.is_contiguous() and feature.is_contiguous()):
             best = self._hip.infer(view, feature)
             if eps > 0:
                 rnd = torch.randint(self.num_actions, best.shape, dtype=torch.int32, device=self.device)

@@ -60,6 +60,9 @@ POLICY_ABI = [
     ("policy_dqn_act_bytes", [_vp, _i, _c.POINTER(_c.c_size_t)]),
     ("policy_dqn_infer", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     ("policy_dqn_infer_bf16", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    ("policy_dqn_f32_supported", [_vp]),
+    ("policy_dqn_f32_act_bytes", [_vp, _i, _c.POINTER(_c.c_size_t)]),
+    ("policy_dqn_infer_f32", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
 ]
 
 _cache = {}

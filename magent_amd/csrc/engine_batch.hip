@@ -274,8 +274,8 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         for (int e = 0; e < n_env && !lead.opt_fixed; e++) if (kind[e] == 2) rounds = std::max(rounds, 2 * (envs[e]->boost_attack > 0 ? 2 : 1));
         PD.G = n_group; PD.rounds = rounds;
         // the observations: one sweeping launch when every observed group of the batch has the battle shape, else the generic render's
-        bool sweep_ok = true;
-        for (int e = 0; e < n_env; e++) if (kind[e] == 2) sweep_ok &= envs[e]->pipe_sweep_ok(view ? view + e * n_group : nullptr);
+        bool sweep_ok = tune("pipe_sweep", -1) != 0;
+        for (int e = 0; e < n_env && sweep_ok; e++) if (kind[e] == 2) sweep_ok &= envs[e]->pipe_sweep_ok(view ? view + e * n_group : nullptr);
         int sweep_feat = 0, sweep_vhw = 0;
         long long sweep_steps = 0;
         for (int e = 0; e < n_env; e++) {
@@ -302,7 +302,8 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         if (sweep_ok && PD.slots > 0) {
             // `sweep` workgroups per (environment, group) segment: ~4 workgroups per CU over the whole launch, at least 8 steps' worth each
             const int segs = PD.n_env * PD.slots;
-            PD.sweep = (int)std::max<long long>(1, std::min<long long>(std::max(4, 1024 / segs), (sweep_steps + 7) / 8));
+            static const int forced = tune("pipe_sweep", -1);
+            PD.sweep = (int)std::max<long long>(1, std::min<long long>(forced > 0 ? forced : std::max(4, 1024 / segs), (sweep_steps + 7) / 8));
         }
         PipeCtl C{lead.reports_d, lead.reports_h, lead.pipe_ticket, lead.pipe_flag, ++lead.pipe_flag_seq, PD.n_env};
         HIP_OK(hipMemcpyAsync(lead.pipe_d, lead.pipe_h, sizeof(PipeItem) * piped.size(), hipMemcpyHostToDevice, lead.stream));

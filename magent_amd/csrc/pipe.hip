@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) k_pipe_strike(const PipeItem *__restrict_
 }
 __global__ void __launch_bounds__(256) k_pipe_commit(const PipeItem *__restrict__ items) {
     PIPE_ITEM();
-    plain_commit_body(it.W, it.PW, it.rec, it.seq);         // (the report goes to device memory here: k_pipe_finish sends them all)
+    plain_commit_body(it.W, it.PW, it.rec, it.seq, REPORT_DEVICE);      // (the report goes to device memory here: k_pipe_finish sends them all)
 }
 // dead_ct + movers taken in of group g, as the step left them (Env::step_end adds up the same counters from the report)
 __device__ __forceinline__ int pipe_gone(const int *counters, int g) {
@@ -134,9 +134,12 @@ __global__ void __launch_bounds__(256) k_pipe_finish(const PipeItem *__restrict_
                 ((uint4 *)&C.reports_h[e])[q] = ((const uint4 *)&C.reports_d[e])[q];
             }
             if (threadIdx.x == 0) *C.ticket = 0;
-            __threadfence_system();
+            // (the host reads nothing but the reports, which live in pinned memory and never sit in the L2: every wave waits until its
+            // stores have been acknowledged, the workgroup meets, the word goes out -- no write-back of the L2's dirty lines, REPORT_HOST_ACKED)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(C.flag_h, C.flag_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (threadIdx.x == 0) __hip_atomic_store(C.flag_h, C.flag_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if (!open && it.Mi.vh > 0) {         // mini_norm_body with the sizes behind the compaction (k_pipe_clear left them)

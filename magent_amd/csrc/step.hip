@@ -15,7 +15,8 @@ __global__ void k_step_reset(int *counters) {
     for (int k = threadIdx.x; k < ROUND_SLOTS; k += blockDim.x) counters[CTR_ROUND_CHANGED + k] = 0;
     for (int k = threadIdx.x; k < ATT_SLOTS; k += blockDim.x) counters[att_slot(k)] = 0;
 }
-__global__ void __launch_bounds__(64) k_step_report(int *counters, StepRecord *rec, int seq, int NG) { step_report_body(counters, rec, seq, NG); }
+__global__ void __launch_bounds__(64) k_step_report(int *counters, StepRecord *rec, int seq, int NG, int mode) { step_report_body(counters, rec, seq, NG, mode); }
+static int report_mode() { static const int m = tune("report_fence", 1) != 0 ? REPORT_HOST : REPORT_HOST_ACKED; return m; }
 __global__ void k_set_rng(int *counters, unsigned x) { if (threadIdx.x == 0) counters[CTR_RNG] = (int)x; }
 
 // memset that respects the gate: the claim array still holds the attack phase's hit bits when the host has to continue
@@ -221,8 +222,8 @@ __global__ void __launch_bounds__(256) k_plain_eval(WorldView W, PlainWorld PW, 
 __global__ void __launch_bounds__(256) k_strike(WorldView W, PlainWorld PW, const PlainGroup *ptab, const GroupDev *gtab, const TypeDev *ttab, StrikeRules R) {
     strike_body(W, PW, ptab, gtab, ttab, R);
 }
-__global__ void __launch_bounds__(256) k_plain_commit(WorldView W, PlainWorld PW, StepRecord *rec, int seq) {
-    plain_commit_body(W, PW, rec, seq);
+__global__ void __launch_bounds__(256) k_plain_commit(WorldView W, PlainWorld PW, StepRecord *rec, int seq, int report_mode) {
+    plain_commit_body(W, PW, rec, seq, report_mode);
 }
 __global__ void __launch_bounds__(256) k_movg_prep(WorldView W, unsigned *wanted, int starve) {
     if (attack_open(W)) return;
@@ -606,7 +607,7 @@ void launch_pend_to_actions(hipStream_t s, const GroupDev &G, const TypeDev &T, 
 }
 
 void launch_step_report(hipStream_t s, int *counters, StepRecord *rec, int seq, int NG) {
-    hipLaunchKernelGGL(k_step_report, dim3(1), dim3(64), 0, s, counters, rec, seq, NG);
+    hipLaunchKernelGGL(k_step_report, dim3(1), dim3(64), 0, s, counters, rec, seq, NG, report_mode());
 }
 void launch_step_reset(hipStream_t s, int *counters) { hipLaunchKernelGGL(k_step_reset, dim3(1), dim3(64), 0, s, counters); }
 void launch_set_rng(hipStream_t s, int *counters, unsigned x) { hipLaunchKernelGGL(k_set_rng, dim3(1), dim3(64), 0, s, counters, x); }
@@ -730,7 +731,7 @@ void launch_plain_tail(hipStream_t s, const WorldView &W, const PlainWorld &PW, 
     dim3 g = grid_all(W, 256);
     hipLaunchKernelGGL(k_strike, g, dim3(256), 0, s, W, PW, ptab, gtab, ttab, R);
     // (rec != null: the step's report goes out from the first wave of the commit's launch -- see k_plain_commit)
-    hipLaunchKernelGGL(k_plain_commit, g, dim3(256), 0, s, W, PW, rec, seq);
+    hipLaunchKernelGGL(k_plain_commit, g, dim3(256), 0, s, W, PW, rec, seq, report_mode());
 }
 
 void launch_move_apply(hipStream_t s, const WorldView &W, const GroupDev *gtab) {

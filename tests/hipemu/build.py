@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "magent_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libmagent_emu.so")
-SOURCES = ["render.hip", "step.hip", "pipe.hip", "cycle.hip", "engine.hip", "engine_rules.hip", "engine_observe.hip", "engine_step.hip", "engine_batch.hip", "runtime_api.hip", "policy.hip"]     # (MFMAs: hipemu::mfma_32x32x16_bf16)
+SOURCES = ["render.hip", "step.hip", "pipe.hip", "cycle.hip", "engine.hip", "engine_rules.hip", "engine_observe.hip", "engine_step.hip", "engine_batch.hip", "runtime_api.hip", "policy.hip", "policy_f32.hip"]     # (MFMAs: hipemu::mfma_32x32x16_bf16)
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-g1", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-w",
          "-I", HERE, "-I", OUT, "-I", CSRC, "-I", os.path.join(ROOT, "include")]

@@ -140,7 +140,30 @@ template <typename V8, typename V16> static inline V16 mfma_32x32x16_bf16(V8 a, 
     }
     return d;
 }
+// v_mfma_f32_32x32x2_f32: lane l holds A[row = l & 31][k = l >> 5] and B[k = l >> 5][col = l & 31], one float each; the result map is the
+// 32 x 32 one above; D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) -- bit for bit a k-ordered chain of fmaf (cdna_hip_programming.md).
+template <typename V16> static inline V16 mfma_32x32x2_f32(float a, float b, V16 c) {
+    static_assert(sizeof(V16) == 64, "accumulator of v_mfma_f32_32x32x2_f32");
+    static const char site = 0;
+    unsigned long long mine, all[64];
+    unsigned ua, ub;
+    memcpy(&ua, &a, 4); memcpy(&ub, &b, 4);
+    mine = ((unsigned long long)ub << 32) | ua;
+    wave_meet(&site, mine);
+    if (wave_mask() != ~0ull) { fprintf(stderr, "hipemu: MFMA with inactive lanes\n"); abort(); }
+    for (int l = 0; l < 64; l++) all[l] = wave_posted(l);
+    auto A = [&](int lane) { unsigned u = (unsigned)all[lane]; float f; memcpy(&f, &u, 4); return f; };
+    auto B = [&](int lane) { unsigned u = (unsigned)(all[lane] >> 32); float f; memcpy(&f, &u, 4); return f; };
+    const int col = lane_ & 31, g = lane_ >> 5;
+    V16 d;
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+        d[r] = __builtin_fmaf(A(row + 32), B(col + 32), __builtin_fmaf(A(row), B(col), c[r]));
+    }
+    return d;
+}
 }  // namespace hipemu
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu::mfma_32x32x2_f32((a), (b), (c))
 
 // ------------------------------------------------------------------------------------------------ arithmetic intrinsics
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }

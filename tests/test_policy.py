@@ -113,7 +113,8 @@ def test_bf16_policy_against_the_f32_network():
     torch.manual_seed(7)
     m = DeepQNetwork(env, hs[0], "pin", memory_size=16, infer_dtype="bf16")
     assert m._hip is not None and m.infer_dtype == "bf16"
-    assert DeepQNetwork(env, hs[1], "dflt", memory_size=16)._hip is None           # float32 unless asked otherwise
+    from magent_amd.builtin.torch_model.hip_policy import HipDqnPolicyF32
+    assert isinstance(DeepQNetwork(env, hs[1], "dflt", memory_size=16)._hip, HipDqnPolicyF32)           # float32 unless asked otherwise
     rs = np.random.RandomState(5)
     for step in range(6):
         for h in hs:
@@ -136,6 +137,93 @@ def test_bf16_policy_against_the_f32_network():
     assert worst <= 0.02, worst
     assert agree >= 0.97 * total, (agree, total)
     assert unexplained == 0
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("view_space,feat,n_action,n", [((13, 13, 7), 34, 21, 1000), ((13, 13, 7), 34, 21, 4 * 256 * 5 + 77 * 4 + 3), ((9, 9, 5), 18, 9, 777),
+                                                         ((13, 11, 6), 40, 31, 300), ((7, 7, 3), 5, 5, 131), ((13, 13, 7), 34, 21, 1), ((5, 5, 1), 1, 2, 40),
+                                                         ((15, 15, 7), 36, 33 - 2, 200), ((16, 16, 4), 56, 13, 300)])
+def test_hip_f32_policy_matches_the_torch_network(view_space, feat, n_action, n):
+    """k_dqn_conv_f32 + k_dqn_head_f32 (magent_amd/csrc/policy_f32.hip: float32 in, float32 accumulate, v_mfma_f32_32x32x2_f32) against the
+    PyTorch float32 network itself.  Nothing is rounded anywhere: the only difference is the order of the float32 sums (the matrix
+    instruction adds in k order, MIOpen / rocBLAS in theirs) -- tolerance 1e-4 of max |Q|, measured ~1e-6"""
+    import torch
+    from magent_amd.builtin.torch_model.dqn import _QNet
+    from magent_amd.builtin.torch_model.hip_policy import HipDqnPolicyF32
+    torch.manual_seed(4321 + n)
+    dev = torch.device("cuda", 0)
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    qnet = _QNet(view_space, (feat,), n_action, True, True).to(dev)
+    with torch.no_grad():
+        for p in qnet.parameters():
+            p.mul_(3.0)
+    view = (torch.rand((n,) + view_space, device=dev) < 0.3).float() * torch.rand((n,) + view_space, device=dev)
+    featv = torch.rand((n, feat), device=dev) * 2 - 0.5
+    pol = HipDqnPolicyF32(qnet, view_space, (feat,), n_action, dev, chunk=2048)     # several chunks on the larger cases
+    actions, q = pol.infer(view, featv, want_q=True)
+    with torch.no_grad():
+        ref = qnet(view, featv)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    err = (q - ref).abs().max().item()
+    assert err <= 1e-4 * scale, (err, scale)
+    assert torch.equal(actions.long(), q.argmax(dim=1))
+    assert torch.equal(pol.infer(view, featv), actions)
+
+
+@pytest.mark.gpu
+def test_f32_policy_on_real_observations_and_its_rate():
+    """BASELINE config 5's policy step at the reference's precision: battle 1000 x 1000, 2 x 400k agents six steps into an episode, every
+    agent's Q values from the HIP float32 kernels against the PyTorch float32 network (max |dQ| <= 1e-4 max |Q|; greedy actions equal
+    except where the network's best two Q values are closer than twice the measured error), and both forward passes timed: the line is
+    printed (profiles/r06_summary.md keeps it), the kernels must beat PyTorch's rate"""
+    import time
+    import torch
+    import magent_amd
+    from magent_amd.builtin.torch_model import DeepQNetwork
+    from magent_amd.builtin.torch_model.hip_policy import HipDqnPolicyF32
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    env = magent_amd.GridWorld("battle", map_size=1000, device_obs=True)
+    env.set_seed(12345); env.reset()
+    hs = env.get_handles()
+    for h in hs:
+        env.add_agents(h, "random", n=400000)
+    torch.manual_seed(7)
+    m = DeepQNetwork(env, hs[0], "pin", memory_size=16)
+    assert isinstance(m._hip, HipDqnPolicyF32) and m.infer_dtype == "f32"
+    rs = np.random.RandomState(5)
+    for step in range(6):
+        for h in hs:
+            env.set_action(h, torch.from_numpy(rs.randint(21, size=env.get_num(h)).astype(np.int32)).cuda())
+        env.step(); env.clear_dead()
+    worst, agree, total, unexplained = 0.0, 0, 0, 0
+    t_hip = t_torch = 0.0
+    for h in hs:
+        view, feat = env.get_observation(h); env.sync()
+        m._hip.infer(view, feat)      # (packs the weights, sizes the workspace)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        a32, q_hip = m._hip.infer(view, feat, want_q=True)
+        torch.cuda.synchronize(); t_hip += time.perf_counter() - t0
+        m.qnet(view[:65536], feat[:65536])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        q32 = torch.cat([m.qnet(view[b:b + 65536], feat[b:b + 65536]) for b in range(0, len(view), 65536)]).detach()
+        torch.cuda.synchronize(); t_torch += time.perf_counter() - t0
+        scale = float(q32.abs().max())
+        err = float((q_hip - q32).abs().max())
+        worst = max(worst, err / scale)
+        same = a32.long() == q32.argmax(dim=1)
+        top2 = q32.topk(2, dim=1).values
+        unexplained += int((~same & ((top2[:, 0] - top2[:, 1]) > 2 * err)).sum())
+        agree += int(same.sum()); total += len(same)
+    flop = 2.0 * (11 * 11 * 32 * 63 + 9 * 9 * 32 * 288 + 2592 * 256 + 34 * 256 + 512 * 22) * total
+    print("f32 policy on %d real observations: max |dQ| / max |Q| = %.2e, greedy actions equal for %.4f %%; HIP f32 kernels %.2f ms (%.1f TFLOP/s = %.2f of the 157.3 "
+          "TFLOP/s f32 matrix peak), PyTorch f32 %.2f ms" % (total, worst, 100.0 * agree / total, t_hip * 1e3, flop / t_hip / 1e12, flop / t_hip / 157.3e12, t_torch * 1e3))
+    assert worst <= 1e-4, worst
+    assert unexplained == 0 and agree >= 0.999 * total, (agree, total, unexplained)
+    assert t_hip < t_torch
     env.close()
 
 
