@@ -203,8 +203,9 @@ def selfplay_extra(torch, magent_amd, n=400000, steps=4, infer_dtype="bf16"):
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside a launcher: re-run this command line as N ranks, one per GPU, the way the driver's
     own launcher would (torch.distributed.run, rendezvous on 127.0.0.1); rank 0's JSON line passes through on stdout.
-    Returns 0 once that line has been seen -- the headline is measured before anything that can fail on one rank is tried, and a rank that
-    dies later (the launcher then ends the others) costs the extra it died in, not the run (see `relay_sigterm`) -- else the launcher's code."""
+    The line carries the launcher's return code ("launcher_rc": a rank that died behind the headline is visible in the record).  Returns 0
+    once that line has been seen -- the headline is measured before anything that can fail on one rank is tried, and a rank that dies later
+    (the launcher then ends the others) costs the extra it died in, not the run (see `relay_sigterm`) -- else the launcher's code."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -215,13 +216,24 @@ def spawn_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = 0
+    held = []
     for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            held.append(line)       # (rank 0 prints it last: held for the moment it takes the launcher to end, so that it can carry the launcher's code)
+            continue
         sys.stdout.write(line)
         sys.stdout.flush()
-        lines += line.startswith('{"metric"')
     rc = proc.wait()
-    return 0 if lines == 1 else (rc or 1)
+    for line in held:
+        try:      # the launcher's return code rides in the record: a rank that died behind the headline is visible to whoever reads the line
+            rec = json.loads(line)
+            rec["launcher_rc"] = rc
+            line = json.dumps(rec) + "\n"
+        except ValueError:
+            pass
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    return 0 if len(held) == 1 else (rc or 1)
 
 
 def relay_sigterm(on_term):

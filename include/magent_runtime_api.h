@@ -126,11 +126,16 @@ int env_step_many(EnvHandle *games, int n, int *done);
  *   for g: env_get_observation_device(e, g, {view, feat});   for g: env_set_action_device(e, g, actions);
  *   env_step(e, &done[e]);   for g: env_get_reward_device(e, g, rewards);   gridworld_clear_dead(e)
  * Device pointer arrays are indexed [e * n_group + g]; a NULL entry skips that call for that group.
- * Worlds small enough for the one-launch step (<= 16384 agents) run the whole cycle in TWO launches
- * (observation render of all groups; everything else), and with n_env >= 2 ALL such environments share one pair of
- * launches on the first environment's stream (one workgroup per environment for the step): small worlds are
- * launch-latency bound, many of them fill the GPU.  Larger worlds run the calls one after the other on n_threads host
- * threads inside the library.  `actions` must hold the actions BEFORE the call (they are read by the second launch, in
+ * Three forms, chosen per environment:
+ *   - worlds small enough for the one-launch step -- <= 1536 agents for an environment cycled on its own (n_env == 1), <= 16384 as one
+ *     of a batch (n_env >= 2); MAGENT_TUNE solo_max / batch_solo_max -- run the whole cycle in TWO launches (observation render of
+ *     all groups; everything else), and with n_env >= 2 ALL such environments share one pair of launches on the first one's stream
+ *     (one workgroup per environment for the step): small worlds are launch-latency bound, many of them fill the GPU;
+ *   - with n_env >= 2, worlds of >= 1537 agents (MAGENT_TUNE batch_pipe_min) whose game the pipeline of plain games takes (one-cell
+ *     bodies, no turn_mode / food_mode / goals / kill_supply, rules that pay the attacker: battle, gather) share ONE chain of launches,
+ *     one per phase for all of them, without a host round trip inside the cycle (pipe.hip; MAGENT_TUNE batch_pipe=0 switches it off);
+ *   - every other world runs the calls one after the other on n_threads host threads inside the library.
+ * `actions` must hold the actions BEFORE the call (they are read by the second launch, in
  * stream order after the render -- the caller's policy reads the observation of the PREVIOUS cycle, or orders its own
  * stream with env_get_stream); the outputs are complete when the call returns (the host has waited for `done`). */
 int env_cycle_many(EnvHandle *games, int n_env, int n_group, float **view, float **feat, const int **actions,

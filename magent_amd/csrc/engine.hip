@@ -557,6 +557,7 @@ void Env::reset() {
     serial_calls.clear(); step_calls.clear(); serial_calls_on = false;
     alive_valid = false;
     map_scattered = map_warm = false;
+    placed_random = placed_total = 0;
     // a fresh episode starts with two pairs of optimistic attack rounds: the first steps of a dense placement hold the deepest
     // dependency chains (measured at 2 x 400k: one pair runs out once in the first few steps, two never did), and a step that runs
     // out costs a host round trip; the budget falls back to one pair after 64 steps that did not need the second
@@ -769,7 +770,7 @@ void Env::add_agents(int group, int n, const char *method, const int *px, const 
         sx.push_back(x); sy.push_back(y); sid.push_back(id_counter++); sdir.push_back(dir);
     };
     if (m == "random") {
-        if (n > 0) map_scattered = true;      // agents that stand next to each other in the group stand anywhere on the map (observe_device)
+        placed_random += n;                   // agents that stand next to each other in the group stand anywhere on the map (observe_device)
         for (int i = 0; i < n; i++) {
             rng_on_device = false;
             const int dir = turn_mode ? (int)(rng() % DIR_NUM) : DIR_NORTH;   // drawn before the position (GridWorld.cc:230)
@@ -792,6 +793,10 @@ void Env::add_agents(int group, int n, const char *method, const int *px, const 
     } else fatal("unsupported method in GridWorld::add_agents : %s", method);
 
     const int k = (int)sx.size();
+    placed_total += k;
+    // (the map counts as scattered while at least a quarter of everything placed since the reset was placed at random: a few random
+    // agents beside a large formation do not make every step pay the stream-through -- ADVICE round 5)
+    map_scattered = placed_random > 0 && 4ll * placed_random >= placed_total;
     if (G.n + k > REF_MASK) fatal("too many agents in one group");
     if (k > 0) {
         ensure_capacity(G, G.n + k);

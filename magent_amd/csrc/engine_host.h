@@ -242,7 +242,8 @@ private:
     int *d_alive = nullptr; size_t alive_cap = 0;      // survivors per 256 agents, left by k_strike for clear_dead (PlainWorld::alive)
     int alive_off[MAXG] = {}, alive_n[MAXG] = {};
     bool alive_valid = false;
-    bool map_scattered = false;           // some group was placed by add_agents("random"): neighbours in the group are not neighbours on the map
+    bool map_scattered = false;           // a quarter or more of the agents were placed by add_agents("random"): neighbours in the group are not neighbours on the map
+    long long placed_random = 0, placed_total = 0;
     bool map_warm = false;                // an observation render has walked the painted map since the last step (observe_device: touch_map)
     PlainWorld plain_view();
     void plain_arrays(HostGroup &g, size_t n, size_t cap);

@@ -134,12 +134,9 @@ __global__ void __launch_bounds__(256) k_pipe_finish(const PipeItem *__restrict_
                 ((uint4 *)&C.reports_h[e])[q] = ((const uint4 *)&C.reports_d[e])[q];
             }
             if (threadIdx.x == 0) *C.ticket = 0;
-            // (the host reads nothing but the reports, which live in pinned memory and never sit in the L2: every wave waits until its
-            // stores have been acknowledged, the workgroup meets, the word goes out -- no write-back of the L2's dirty lines, REPORT_HOST_ACKED)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __threadfence_system();        // (the one system-scope release of the whole batch)
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(C.flag_h, C.flag_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (threadIdx.x == 0) __hip_atomic_store(C.flag_h, C.flag_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if (!open && it.Mi.vh > 0) {         // mini_norm_body with the sizes behind the compaction (k_pipe_clear left them)

@@ -87,12 +87,12 @@ __device__ __forceinline__ void shuffle_draw_launch_body(int *counters, int *j, 
 // The end-of-step report of the multi-launch step, straight into pinned host memory (the host spins on `seq`: a stream
 // synchronisation behind a device-to-host copy costs several times the PCIe write it waits for), and the per-step counters
 // back to zero -- unless a phase was left open: then the host continues from exactly this state and resets afterwards.
-// `mode`: where `rec` lives and how `seq` follows the rest.  REPORT_HOST: pinned host memory, behind a system-scope release (the L2's
-// dirty lines are written back first: ~10 us when a step's kernels have just been through it).  REPORT_HOST_ACKED: pinned host memory; the
-// wave waits until every one of its stores has been acknowledged, then sends `seq` -- the host reads nothing but the record, which never
-// sits in the L2, so there is nothing to write back (MAGENT_TUNE report_fence=0; A/B in profiles/r06_summary.md).  REPORT_DEVICE: device
-// memory, read by a later launch (pipe.hip: k_pipe_finish sends every environment's report to the host in one piece).
-constexpr int REPORT_HOST = 1, REPORT_HOST_ACKED = 2, REPORT_DEVICE = 0;
+// `mode`: where `rec` lives.  REPORT_HOST: pinned host memory, `seq` behind a system-scope release (which writes the L2's dirty lines back
+// first: ~10 us when a step's kernels have just been through it).  REPORT_DEVICE: device memory, read by a later launch (pipe.hip:
+// k_pipe_finish sends every environment's report to the host in one piece, behind ONE such release).
+// (Tried in round 6 and withdrawn: "wait until the wave's stores are acknowledged, then send `seq` with a relaxed store" instead of the
+// release -- the acknowledgement comes from the L2, not from host memory: the host saw `seq` ahead of the record, profiles/r06_summary.md.)
+constexpr int REPORT_HOST = 1, REPORT_DEVICE = 0;
 __device__ __forceinline__ void step_report_body(int *counters, StepRecord *rec, int seq, int NG, int mode = REPORT_HOST) {      // (one wave: threads 0..63)
     const int tid = threadIdx.x;
     const int oa = counters[CTR_OPEN_ATTACK], om = counters[CTR_OPEN_MOVE];
@@ -121,12 +121,6 @@ __device__ __forceinline__ void step_report_body(int *counters, StepRecord *rec,
         if (tid == 0) counters[CTR_ATTACK] = 0;
     }
     if (mode == REPORT_DEVICE) { if (tid == 0) rec->seq = seq; return; }
-    if (mode == REPORT_HOST_ACKED) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (compiler: the stores above stay above)
-        __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): loads and stores share the counter on this part
-        if (tid == 0) __hip_atomic_store((int *)&rec->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
     __threadfence_system();
     if (tid == 0) __hip_atomic_store((int *)&rec->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -16,7 +16,7 @@ __global__ void k_step_reset(int *counters) {
     for (int k = threadIdx.x; k < ATT_SLOTS; k += blockDim.x) counters[att_slot(k)] = 0;
 }
 __global__ void __launch_bounds__(64) k_step_report(int *counters, StepRecord *rec, int seq, int NG, int mode) { step_report_body(counters, rec, seq, NG, mode); }
-static int report_mode() { static const int m = tune("report_fence", 1) != 0 ? REPORT_HOST : REPORT_HOST_ACKED; return m; }
+static int report_mode() { return REPORT_HOST; }
 __global__ void k_set_rng(int *counters, unsigned x) { if (threadIdx.x == 0) counters[CTR_RNG] = (int)x; }
 
 // memset that respects the gate: the claim array still holds the attack phase's hit bits when the host has to continue

@@ -20,7 +20,6 @@
 //   batch_cycle=0       env_cycle_many runs its environments one after another instead of in one pair of launches
 //   batch_pipe=0        env_cycle_many never takes the batched pipeline (pipe.hip): worlds beyond the one-launch step go one by one
 //   batch_pipe_min=N    ... and takes it for worlds of N agents or more that could also step in one launch                 default 1537
-//   report_fence=0      the step's report to the host without the system-scope release (plain_dev.h: REPORT_HOST_ACKED); A/B of the default
 //   pipe_sweep=N        workgroups per (environment, group) segment of the batched sweeping render (0: the generic render)    default: by size
 //   touch_map=0|1       never / before every render of a map beyond the L2s: the painted map streamed through the caches first (default: before the
 //                       first render of a cycle when some group was placed at random)
@@ -55,7 +54,7 @@ inline int tune(const char *key, int dflt) {
     (void)legacy_checked;
     static const char *const known[] = {"checked_step", "host_shuffle", "attack_pairs", "move_batches", "solo_step", "solo_max", "batch_solo_max", "scan_solo_max", "overlap",
                                         "fold_minimap", "render", "render_sweep", "render_su", "render_depth", "att_threads", "policy_grid", "policy_stamps",
-                                        "batch_cycle", "early_report", "touch_map", "batch_pipe", "batch_pipe_min", "report_fence", "pipe_sweep"};
+                                        "batch_cycle", "early_report", "touch_map", "batch_pipe", "batch_pipe_min", "pipe_sweep"};
     const char *s = std::getenv("MAGENT_TUNE");
     if (!s || !*s) return dflt;
     static bool checked = false;
