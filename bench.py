@@ -154,8 +154,59 @@ def small_world_extras(torch, magent_amd, dev, steps=200, warmup=20):
         for e in envs:
             e.sync()
         dt = time.perf_counter() - t0
-        out[label] = {"agent_steps_per_s": total / dt, "ms_per_cycle": dt / steps * 1e3, "envs": K}
+        out[label] = {"agent_steps_per_s": total / dt, "ms_per_cycle": dt / steps * 1e3, "envs": K,
+                      "envs_in_batched_pipeline": sum(1 for e in envs if e.pipeline_stats()[6] > 0)}     # (pipe.hip: worlds beyond the one-launch step, one launch per phase for all)
         del batch, envs
+    return out
+
+
+def many_worlds_extra(torch, magent_amd, dev, game, map_size, n, K, steps=20, warmup=5):
+    import numpy as np
+    """K environments of a BASELINE configuration on ONE GPU, cycled by one magent_amd.EnvBatch call per round (env_cycle_many): worlds
+    beyond the one-launch step share one chain of launches, one per phase (pipe.hip) -- ms per round, aggregate agent-steps/s"""
+    from magent_amd.builtin.config import _games
+    envs = []
+    for k in range(K):
+        env = magent_amd.GridWorld(_games.make(game, map_size))
+        env.set_seed(1000 + k); env.reset()
+        hs = env.get_handles()
+        if game == "gather":          # examples/train_gather.py: food, then agents; only the agents act and are observed
+            env.add_agents(hs[0], "random", n=n // 5)
+            env.add_agents(hs[1], "random", n=n)
+        else:
+            for h in hs:
+                env.add_agents(h, "random", n=n)
+        envs.append(env)
+    hs = envs[0].get_handles()
+    acting = [1] if game == "gather" else list(range(len(hs)))
+    cap = [envs[0].get_num(h) for h in hs]
+    mk = lambda shape, dtype=torch.float32: torch.empty(shape, dtype=dtype, device=dev)
+    views = [[mk((cap[g],) + envs[0].get_view_space(h)) if g in acting else None for g, h in enumerate(hs)] for _ in envs]
+    feats = [[mk((cap[g],) + envs[0].get_feature_space(h)) if g in acting else None for g, h in enumerate(hs)] for _ in envs]
+    rews = [[mk(cap[g]) if g in acting else None for g in range(len(hs))] for _ in envs]
+    na = [envs[0].get_action_space(h)[0] for h in hs]
+    acts = [[[torch.randint(na[g], (cap[g],), dtype=torch.int32, device=dev) if g in acting else None for g in range(len(hs))] for _ in envs] for _ in range(4)]
+    batch = magent_amd.EnvBatch(envs, n_threads=8)
+    batch.order_streams = False
+    view_p, feat_p, rew_p = batch.pointers(views), batch.pointers(feats), batch.pointers(rews)
+    act_p = [batch.pointers(a) for a in acts]
+    torch.cuda.synchronize()
+    total, t0 = 0, 0.0
+    for s in range(steps + warmup):
+        if s == warmup:
+            for e in envs:
+                e.sync()
+            total, t0 = 0, time.perf_counter()
+        total += sum(sum(n_[g] for g in acting) for n_ in batch.nums())
+        batch.cycle(view_p, feat_p, act_p[s % 4], rew_p)
+    for e in envs:
+        e.sync()
+    dt = time.perf_counter() - t0
+    out = {"envs": K, "game": game, "map": map_size, "agents_per_env_at_start": cap, "agents_per_env_at_end": batch.nums()[0], "ms_per_round": dt / steps * 1e3,
+           "agent_steps_per_s": total / dt, "envs_in_batched_pipeline": sum(1 for e in envs if e.pipeline_stats()[6] > 0),
+           "observation_bytes_per_round_at_start": K * sum(cap[g] * 4 * (int(np.prod(envs[0].get_view_space(hs[g]))) + envs[0].get_feature_space(hs[g])[0]) for g in acting)}
+    for e in envs:
+        e.close()
     return out
 
 
@@ -170,8 +221,9 @@ def selfplay_extra(torch, magent_amd, n=400000, steps=4, infer_dtype="bf16"):
     for h in hs:
         env.add_agents(h, "random", n=n)
     models = [DeepQNetwork(env, h, "m%d" % i, memory_size=16, infer_batch_size=65536, infer_dtype=infer_dtype) for i, h in enumerate(hs)]
-    cells = all(m._hip is not None for m in models)
-    env.use_bf16_observations(cells)       # the MFMA kernels take the views as bf16 cells (2.7 KB per agent instead of 4.7)
+    cells = infer_dtype == "bf16" and all(m._hip is not None for m in models)
+    hip_f32 = infer_dtype == "f32" and all(type(m._hip).__name__ == "HipDqnPolicyF32" for m in models)
+    env.use_bf16_observations(cells)       # the bf16 MFMA kernels take the views as bf16 cells (2.7 KB per agent instead of 4.7)
     total, t0, rew = 0, 0.0, [None] * len(hs)
     for s in range(steps + 2):
         if s == 2:
@@ -195,7 +247,9 @@ def selfplay_extra(torch, magent_amd, n=400000, steps=4, infer_dtype="bf16"):
     dt = time.perf_counter() - t0
     out = {"agent_steps_per_s": total / dt, "ms_per_step": dt / steps * 1e3, "agents": [n, n],
            "policy_dtype": "bf16 (inputs, weights, activations; f32 accumulation)" if cells else "f32",
-           "policy": "DQN forward pass, bf16 MFMA kernels on bf16-cell observations" if cells else "DQN forward pass, PyTorch float32 (the reference's arithmetic)"}
+           "policy": "DQN forward pass, bf16 MFMA kernels on bf16-cell observations" if cells else
+                     "DQN forward pass, float32 on v_mfma_f32_32x32x2_f32 (policy_f32.hip: the reference's arithmetic)" if hip_f32 else
+                     "DQN forward pass, PyTorch float32 (the reference's arithmetic)"}
     env.close()
     return out
 
@@ -383,9 +437,19 @@ def train_round_extra(torch, magent_amd, map_size=1000, steps=12, on_step=None, 
     out = {"map_size": map_size, "agents": n0, "steps": steps, "env_ms_per_step": t_env / steps * 1e3, "infer_ms_per_step": t_infer / steps * 1e3,
            "sample_ms_per_step": t_sample / steps * 1e3,
            "agent_steps_per_s_sampling": agent_steps / (t_env + t_infer + t_sample),
-           "policy_dtype": "bf16 inference (MFMA kernels: inputs, weights, activations bf16, f32 accumulation), f32 training" if all(m.model._hip is not None for m in models)
+           "policy_dtype": "bf16 inference (MFMA kernels: inputs, weights, activations bf16, f32 accumulation), f32 training" if infer_dtype == "bf16" and all(m.model._hip is not None for m in models)
+                           else "f32 inference (policy_f32.hip: float32 in, float32 accumulate, v_mfma_f32_32x32x2_f32), f32 training" if all(type(m.model._hip).__name__ == "HipDqnPolicyF32" for m in models)
                            else "f32 inference (PyTorch), f32 training",
            "policy": "DQN (2 x conv3x3(32) -> dense 256 || dense 256 -> dueling head)"}
+    if infer_dtype == "f32":
+        # the forward pass against the f32 matrix peak (MI355X_MICROARCH.md: 157.3 TFLOP/s, v_mfma_f32_32x32x2_f32): useful FLOPs of the
+        # network per agent (valid convolutions 13x13 -> 11x11 -> 9x9 for the battle shape; generic below) x agents inferred / time
+        vh, vw, vc = env.get_view_space(handles[0])
+        nf, na = env.get_feature_space(handles[0])[0], env.get_action_space(handles[0])[0]
+        flop = 2.0 * ((vh - 2) * (vw - 2) * 32 * 9 * vc + (vh - 4) * (vw - 4) * 32 * 288 + (vh - 4) * (vw - 4) * 32 * 256 + nf * 256 + 512 * (na + 1))
+        out["roofline"] = {"bound": "mfma_f32", "achieved": flop * agent_steps / t_infer / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                           "frac": flop * agent_steps / t_infer / 157.3e12, "flop_per_agent": flop, "kernels": "k_dqn_conv_f32 + k_dqn_head_f32",
+                           "note": "useful FLOPs of the network x agents inferred / synchronised wall time of infer_action (e-greedy draw included)"}
     if train:
         # the first train() of a process also pays for MIOpen's choice of convolution kernels (seconds); a second round -- the
         # same number of steps played again -- is what a training run pays per round
@@ -872,6 +936,8 @@ def main():
                 extra["gather_500_100k"] = {"agent_steps_per_s": C4["agent_steps"] / C4["elapsed"], "ms_per_step": C4["elapsed"] / 20 * 1e3, "agents": C4["n0"],
                                             "workload": "BASELINE config 4, one replica: gather 500x500 (train_gather.py), 100k agents + 20k food, only the agents act",
                                             "roofline": C4["roofline"], "breakdown": C4["breakdown"]}
+                extra["gather_500_100k"]["eight_replicas_one_gpu"] = many_worlds_extra(torch, magent_amd, dev, "gather", 500, 100000, 8, steps=20)
+                extra["battle_600_2x20000_8env"] = many_worlds_extra(torch, magent_amd, dev, "battle", 600, 20000, 8, steps=40)
                 C2 = measure("battle", 200, 2000, 200, 20, True)
                 extra["battle_200_2x2000"] = small_world_extras(torch, magent_amd, dev)
                 extra["battle_200_2x2000"]["calls_with_events"] = {"ms_per_step": C2["elapsed"] / 200 * 1e3, "roofline": C2["roofline"], "breakdown": C2["breakdown"]}
@@ -881,7 +947,12 @@ def main():
                 extra["c5_train_round_2x40k"] = train_round_extra(torch, magent_amd)
                 # BASELINE config 5 at the size it names: train_battle.py --map_size 3536, 2 x 499,849 agents in its own formation
                 extra["c5_train_round_1m"] = {"bf16_policy": train_round_extra(torch, magent_amd, map_size=3536, steps=6),
-                                              "f32_policy": train_round_extra(torch, magent_amd, map_size=3536, steps=3, infer_dtype="f32")}
+                                              "f32_policy": train_round_extra(torch, magent_amd, map_size=3536, steps=4, infer_dtype="f32")}
+                os.environ["MAGENT_POLICY_F32"] = "torch"      # (the same loop with PyTorch's float32 forward pass: what round 5 measured)
+                try:
+                    extra["c5_train_round_1m"]["f32_policy_pytorch"] = train_round_extra(torch, magent_amd, map_size=3536, steps=2, train=False, infer_dtype="f32")
+                finally:
+                    del os.environ["MAGENT_POLICY_F32"]
             except Exception as e:     # secondary lines never fail the bench
                 extra["error"] = repr(e)
             rec["extra"] = extra

@@ -303,10 +303,10 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
             // `sweep` workgroups per (environment, group) segment: ~4 workgroups per CU over the whole launch, at least 8 steps' worth each
             const int segs = PD.n_env * PD.slots;
             static const int forced = tune("pipe_sweep", -1);
-            PD.sweep = (int)std::max<long long>(1, std::min<long long>(forced > 0 ? forced : std::max(4, 1024 / segs), (sweep_steps + 7) / 8));
+            PD.sweep = (int)std::max<long long>(1, std::min<long long>(forced > 0 ? forced : std::max(8, 2048 / segs), (sweep_steps + 7) / 8));
         }
         PipeCtl C{lead.reports_d, lead.reports_h, lead.pipe_ticket, lead.pipe_flag, ++lead.pipe_flag_seq, PD.n_env};
-        HIP_OK(hipMemcpyAsync(lead.pipe_d, lead.pipe_h, sizeof(PipeItem) * piped.size(), hipMemcpyHostToDevice, lead.stream));
+        launch_pipe_upload(lead.stream, lead.pipe_h, lead.pipe_d, PD.n_env);
         launch_pipe_cycle(lead.stream, lead.pipe_d, PD, C);
         HIP_OK(hipGetLastError());
     }
@@ -375,13 +375,17 @@ bool Env::pipe_eligible(int n_group, float *const *view, float *const *feat, con
 
 // are this environment's observed groups of the shape the sweeping render takes?  (Env::cycle_many: one launch form for the whole batch)
 bool Env::pipe_sweep_ok(float *const *view) {
-    const WorldView W = this->view();
-    for (int g = 0; g < (int)groups.size(); g++) {
-        if (!(view && view[g]) || groups[g].n == 0) continue;
-        RenderArgs R; RenderPlan P;
-        plan_render(g, R, P, nullptr, nullptr);
-        if (!render_sweep_mini_ok(W, R)) return false;
+    if (pipe_sweep_shape < 0) {        // (a property of the game's configuration: decided once per reset, for every group)
+        const WorldView W = this->view();
+        pipe_sweep_shape = 0;
+        for (int g = 0; g < (int)groups.size(); g++) {
+            RenderArgs R; RenderPlan P;
+            plan_render(g, R, P, nullptr, nullptr);
+            if (render_sweep_mini_ok(W, R)) pipe_sweep_shape |= 1 << g;
+        }
     }
+    for (int g = 0; g < (int)groups.size(); g++)
+        if (view && view[g] && groups[g].n > 0 && !((pipe_sweep_shape >> g) & 1)) return false;
     return true;
 }
 
@@ -402,16 +406,13 @@ void Env::pipe_prepare(int n_group, float *const *view, float *const *feat, cons
     bool own_render = false;
     for (int g = 0; g < NG; g++)
         if (view && view[g] && groups[g].n > 0 && (long long)groups[g].n * groups[g].type->view.height * groups[g].type->view.width >= 16384ll * 64) own_render = true;
-    {
-        const WorldView W0 = this->view();
-        for (int g = 0; g < NG; g++) {
-            if (!(view && view[g]) || groups[g].n == 0) continue;
-            if (own_render) { observe_device(g, view[g], feat[g]); continue; }
-            const int k = it.M.n++;
-            prepare_render(g, W0, it.M.R[k], it.M.P[k], view[g], feat[g]);
-            it.M.blocks[k] = it.M.P[k].spans + it.M.P[k].feat_blocks;
-        }
-        map_warm = true;
+    it.W = this->view();
+    for (int g = 0; g < NG; g++) {
+        if (!(view && view[g]) || groups[g].n == 0) continue;
+        if (own_render) { observe_device(g, view[g], feat[g]); continue; }
+        const int k = it.M.n++;
+        prepare_render(g, it.W, it.M.R[k], it.M.P[k], view[g], feat[g]);
+        it.M.blocks[k] = it.M.P[k].spans + it.M.P[k].feat_blocks;
     }
     // ---- set_action: tile counts per call, in call order (Env::set_action_device)
     step_sa_tiled = true; sa_tiles = 0;
@@ -442,7 +443,7 @@ void Env::pipe_prepare(int n_group, float *const *view, float *const *feat, cons
     push_rng();
     attack_round = rounds;
     if (rounds >= 4) pairs_two_steps++; else if (rounds >= 2) pairs_one_steps++;
-    it.W = this->view();
+    it.W.live_paint = live_paint_now ? 1 : 0;       // (the one field of the view that the renders' bookkeeping above can change: Env::view)
     it.PW = plain_view();
     it.ptab = d_ptab; it.gtab = d_gtab; it.ttab = d_ttab;
     it.B = shuffle_bufs(); it.powtab = d_powtab;

@@ -222,6 +222,7 @@ private:
     int *pipe_ticket = nullptr, *pipe_flag = nullptr; int pipe_flag_seq = 0;
     int *d_newn = nullptr;                // [MAXG] group sizes behind the batched compaction (PipeItem::newn)
     bool pipe_folded = false;             // the batch's compaction makes the next minimap
+    int pipe_sweep_shape = -1;            // bit g: group g's observation has the shape the sweeping render takes (-1: not looked at since the reset)
     int pipe_rounds = 0;                  // cycles this environment took through the batched pipeline (env_get_info "pipeline_stats")
     void wait_record(int seq);
     StepRecord *h_rec = nullptr;          // pinned: written by k_step_solo, spun on by step_end

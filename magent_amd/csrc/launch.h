@@ -223,11 +223,13 @@ struct PipeItem {
     float *rewards[MAXG]; float group_reward[MAXG];
     GroupDev *gtab_out; TypeDev *ttab_out;
     int *newn;                         // [MAXG] device scratch: group sizes behind the compaction (k_pipe_clear -> k_pipe_finish)
+    int pad_[2];
 };
 // what the batch's last workgroup does: every environment's report to pinned host memory in one piece, then the word the host waits for
 struct PipeCtl { const StepRecord *reports_d; StepRecord *reports_h; int *ticket; int *flag_h; int flag_seq; int n_env; };
 constexpr int PIPE_REPORT_BYTES = 128;     // of a StepRecord: everything ahead of the tuning marks
 struct PipeDims { int n_env, max_n, max_total, G, slots, render_blocks, rounds, kmax, sweep, hist_cells; size_t render_lds; };
+void launch_pipe_upload(hipStream_t s, const PipeItem *h_items, PipeItem *d_items, int n_env);      // (h_items: pinned, device-visible)
 void launch_pipe_cycle(hipStream_t s, const PipeItem *d_items, const PipeDims &D, const PipeCtl &C);
 bool render_sweep_mini_ok(const WorldView &W, const RenderArgs &R);
 size_t render_sweep_lds(int VHW, int C);

@@ -150,6 +150,16 @@ __global__ void __launch_bounds__(256) k_pipe_finish(const PipeItem *__restrict_
     }
 }
 
+// the items from pinned host memory to the device in ONE launch (hipMemcpyAsync of the 150 KB of a 32-environment batch ran as four to five
+// blit launches of ~5 us each, ahead of everything else of the cycle: profiles/r06_summary.md)
+__global__ void __launch_bounds__(256) k_pipe_upload(const uint4 *__restrict__ src_host, uint4 *__restrict__ dst, int n16) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += gridDim.x * blockDim.x) dst[k] = src_host[k];
+}
+void launch_pipe_upload(hipStream_t s, const PipeItem *h_items, PipeItem *d_items, int n_env) {
+    static_assert(sizeof(PipeItem) % 16 == 0, "PipeItem is moved in 16-byte pieces");
+    const int n16 = (int)(sizeof(PipeItem) / 16) * n_env;
+    hipLaunchKernelGGL(k_pipe_upload, dim3(std::min(256, (n16 + 255) / 256)), dim3(256), 0, s, (const uint4 *)h_items, (uint4 *)d_items, n16);
+}
 static size_t pipe_eval_lds(int kmax) { return (size_t)kmax * 256 * 8; }
 size_t render_sweep_lds(int VHW, int C) { return (size_t)RENDER_WAVES * 2 * 64 * C * sizeof(float) + (size_t)VHW * sizeof(RenderFastPos); }
 void launch_pipe_cycle(hipStream_t s, const PipeItem *d_items, const PipeDims &D, const PipeCtl &C) {
