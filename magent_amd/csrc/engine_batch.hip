@@ -273,8 +273,11 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         int rounds = lead.opt_fixed ? 2 * lead.opt_attack_pairs : 2;
         for (int e = 0; e < n_env && !lead.opt_fixed; e++) if (kind[e] == 2) rounds = std::max(rounds, 2 * (envs[e]->boost_attack > 0 ? 2 : 1));
         PD.G = n_group; PD.rounds = rounds;
-        // the observations: one sweeping launch when every observed group of the batch has the battle shape, else the generic render's
-        bool sweep_ok = tune("pipe_sweep", -1) != 0;
+        // the observations of the worlds that do not render for themselves (< 1 M window cells per group): the generic render's workgroups,
+        // one launch.  (MAGENT_TUNE pipe_sweep=N: the sweeping kernel instead, N workgroups per (environment, group) segment, when every
+        // observed group has the battle shape -- measured level or behind at these sizes: 32 x (2 x 2000): 0.238 ms per round against 0.231,
+        // profiles/r06_summary.md; the segments are too short for its four-round ring to pay.)
+        bool sweep_ok = tune("pipe_sweep", 0) > 0;
         for (int e = 0; e < n_env && sweep_ok; e++) if (kind[e] == 2) sweep_ok &= envs[e]->pipe_sweep_ok(view ? view + e * n_group : nullptr);
         int sweep_feat = 0, sweep_vhw = 0;
         long long sweep_steps = 0;

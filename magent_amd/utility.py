@@ -47,9 +47,11 @@ class EpisodesBuffer(object):
         self._slots_sorted = np.zeros(0, np.int64)
         self._steps = []             # (slots[k], views[k, ...], features[k, ...], actions[k], rewards[k], alives[k]) per recorded step
         self._entries = None
+        self._sorted_n = None        # size of the group when its ids were last seen in ascending order (None: not known to be)
+        self._expect_alive = 0       # tracked agents alive at the end of the last recorded step
 
     def record_step(self, ids, obs, acts, rewards, alives):
-        ids = np.asarray(ids).astype(np.int64, copy=False)
+        ids = np.asarray(ids)
         views, features = obs[0], obs[1]
         n = len(ids)
         if not self.is_full:
@@ -63,15 +65,34 @@ class EpisodesBuffer(object):
                         self.is_full = True
                         break
             if admitted:
+                self._expect_alive = 1 << 62      # (new agents are tracked: this step goes through the general search)
                 keys = np.fromiter(self._slot.keys(), dtype=np.int64, count=len(self._slot))
                 order = np.argsort(keys, kind="stable")
                 self._ids_sorted, self._slots_sorted = keys[order], np.arange(len(keys), dtype=np.int64)[order]
         if n == 0 or not self._slot:
             return
-        rows = np.nonzero(np.isin(ids, self._ids_sorted))[0]
+        # Which rows of this step belong to tracked agents?  The engine hands a group's ids out in ascending order (ids are given in
+        # placement order and clear_dead keeps the order), so the tracked ids are LOOKED UP in them -- k log n instead of a pass over all n
+        # (1.2 ms per side and step at 500k agents, all of `sample_step`'s time) -- whenever a cheap check says the ids are ascending:
+        # the full check runs when the group has grown since the last step, and a look-up that misses an agent that was alive a step ago
+        # sends the step through the general search.
+        rows = None
+        if self._sorted_n is not None and n <= self._sorted_n:
+            pos = np.searchsorted(ids, self._ids_sorted)
+            pos_c = np.minimum(pos, n - 1)
+            hit = ids[pos_c] == self._ids_sorted
+            if int(hit.sum()) >= self._expect_alive:
+                rows = np.sort(pos_c[hit])
+        if rows is None:
+            self._sorted_n = n if n < 2 or bool(np.all(ids[1:] > ids[:-1])) else None
+            rows = np.nonzero(np.isin(ids, self._ids_sorted))[0]
+        else:
+            self._sorted_n = n
         if len(rows) == 0:
+            self._expect_alive = 0
             return
         slots = self._slots_sorted[np.searchsorted(self._ids_sorted, ids[rows])]
+        self._expect_alive = int(np.asarray(alives)[rows].astype(bool).sum())      # tracked agents that will still be listed after clear_dead
 
         def take(a):
             if isinstance(a, np.ndarray):

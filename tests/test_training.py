@@ -86,6 +86,40 @@ def test_episodes_buffer_packed_is_the_loop_over_episodes():
     assert EpisodesBuffer(3).packed() is None
 
 
+def test_episodes_buffer_row_lookup_equals_the_search():
+    """record_step finds the tracked agents' rows by looking the tracked ids up in the step's (ascending) ids -- k log n instead of a pass
+    over every id of a million-agent step -- and must record exactly what the general search records: agents dying and being cleared,
+    new ones appended, a step whose ids are NOT ascending (the look-up must notice and search), a group that shrinks to nothing"""
+    from magent_amd.utility import EpisodesBuffer
+    for seed in range(6):
+        rs = np.random.RandomState(100 + seed)
+        np.random.seed(seed)
+        fast, plain = EpisodesBuffer(capacity=40), EpisodesBuffer(capacity=40)
+        ids = np.sort(rs.choice(5000, size=600, replace=False)).astype(np.int32)
+        next_id = 5000
+        for t in range(25):
+            n = len(ids)
+            order = rs.permutation(n) if (t % 9 == 5 and n > 1) else np.arange(n)       # (now and then: ids in no order at all)
+            step_ids = ids[order]
+            views, feats = rs.rand(n, 2, 2, 1).astype(np.float32), rs.rand(n, 3).astype(np.float32)
+            acts, rewards = rs.randint(5, size=n).astype(np.int32), rs.rand(n).astype(np.float32)
+            alives = rs.rand(n) > (0.9 if t == 20 else 0.1)
+            state = np.random.get_state()
+            fast.record_step(step_ids, (views, feats), acts, rewards, alives)
+            np.random.set_state(state)
+            plain._sorted_n = None; plain._expect_alive = 1 << 62                       # (never takes the look-up)
+            plain.record_step(step_ids, (views, feats), acts, rewards, alives)
+            ids = ids[np.sort(order[alives])] if False else step_ids[alives][np.argsort(step_ids[alives])]     # clear_dead keeps the order; the next step is ascending again
+            if t % 4 == 1:
+                ids = np.concatenate([ids, np.arange(next_id, next_id + 30, dtype=np.int32)]); next_id += 30
+        a, b = fast.packed(), plain.packed()
+        assert (a is None) == (b is None)
+        if a is not None:
+            for x, y in zip(a, b):
+                assert np.array_equal(np.asarray(x), np.asarray(y))
+        assert fast._slot == plain._slot
+
+
 def _np_qnet(params, view, feature, use_dueling=True):
     """NumPy fp32 restatement of the reference network (tf_model/dqn.py:151-189): conv3x3(32) -> conv3x3(32), both VALID, NHWC,
     relu -> flatten (h, w, c order) -> dense 256 relu || dense 256 relu on the features -> concat -> dueling head
