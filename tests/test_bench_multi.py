@@ -135,3 +135,29 @@ def test_default_multi_rank_line_carries_the_c4_gather_extra():
     assert x["verified"]["all_shards_bit_identical"] is True and x["verified"]["distinct_replicas"] == 2
     assert x["payload_bytes_to_each_peer"] > 50000 * 6300 and x["exchange_ms"] > 0 and x["GBps_per_link"] > 0
     assert x["ms_per_step_with_gather"] > 0 and x["ms_per_step_without_gather"] > 0 and x["xgmi_link_peak_GBps"] == 153.0
+
+
+@pytest.mark.gpu
+def test_default_eight_rank_command_as_a_dry_run():
+    """THE command the driver runs for the 8-GPU scaling point -- `python bench.py --gpus 8` with its default steps and warm-up, nothing else but
+    the dry-run backend (8 ranks share this box's one GPU, so the process groups are gloo; everything else is the N = 8 path: eight engine
+    replicas, the barrier + max-over-ranks timing, the lazily created gather group behind a watchdog, extra.c4_gather_rccl with seven peers
+    per rank).  Must finish within two minutes, print exactly ONE JSON line, and that line must carry what the scaling report reads: the
+    whole-job rate, rccl_ranks, the rates with and without the gather, GB/s per link, every shard pair verified."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo"], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=ROOT)
+    wall = time.time() - t0
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    assert wall < 120, wall
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["launcher_rc"] == 0 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["rccl_ranks"] == 8 and rec["config"]["envs"] == 8 and rec["config"]["gather"] == "none"
+    x = rec["extra"]["c4_gather_rccl"]
+    for key in ("ms_per_step_without_gather", "agent_steps_per_s_without_gather", "ms_per_step_with_gather", "agent_steps_per_s_with_gather", "exchange_ms",
+                "payload_bytes_to_each_peer", "GBps_per_link", "xgmi_link_peak_GBps", "link_frac"):
+        assert x[key] > 0, key
+    assert x["verified"]["all_shards_bit_identical"] is True and x["verified"]["pairs_checked"] == 64 and x["verified"]["distinct_replicas"] == 8

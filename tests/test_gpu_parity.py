@@ -92,6 +92,27 @@ def test_batched_pipeline(oracle):
     assert all(e.pipeline_stats()[6] >= 6 for e in seen), [e.pipeline_stats() for e in seen]
 
 
+def test_batched_pipeline_over_a_long_episode(oracle):
+    """the batched pipeline over what only acts with the length of an episode (the claim words' epoch window, refilled every 63 steps by every
+    environment of the batch for itself; the carried round stamps; the batch's budget of optimistic rounds, the largest of its environments'):
+    two 200 x 200 worlds of 2 x 4500 agents with different seeds -- `battle300_long`'s recipe at the same density: hp 4 / damage 3,
+    reinforcements at steps 70 and 130, kills in every step -- for 150 steps through ONE EnvBatch, every environment against the oracle driven
+    alone through the reference call sequence (observations compared every 10th step: the trajectories are held in memory)"""
+    rnd = lambda g, n: (g, "random", {"n": n})
+    scs = [H.Scenario("battle200_long_%d" % k, "battle", 200, seed=4000 + 17 * k, place=[rnd(0, 4500), rnd(1, 4500)], steps=150, action_seed=300 + k, obs_every=10,
+                      over={"small": {"hp": 4, "damage": 3}},
+                      events={70: [("add", 0, "random", {"n": 4000}), ("add", 1, "random", {"n": 4000})],
+                              130: [("add", 0, "random", {"n": 4000}), ("add", 1, "random", {"n": 4000})]}) for k in range(2)]
+    seen = []
+    got = H.run_cycle_batch(scs, H.HIP_LIB, envs_out=seen)
+    for sc, g in zip(scs, got):
+        assert len(g) == 150
+        H.assert_same(H.run_cycle(sc, oracle, fused=False), g, sc.name + " (batched pipeline, 150 steps)")
+    for e in seen:
+        st = e.pipeline_stats()
+        assert st[6] == 150 and st[3] >= 3, st          # every cycle through the batch; the window refilled at steps 1, 63, 126
+
+
 @pytest.mark.skipif(not H.have_ref(), reason="compiled reference (oracle/_ref) did not travel")
 @pytest.mark.parametrize("name", ["battle_brawl", "battle_largemap", "gather"])
 def test_hip_matches_compiled_reference(name):
