@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv_f32(ConvArgs A) {
     constexpr int NW = CONV_THREADS / 64, TS = TA == 4 ? 2 : 1;      // (TS: log2 TA)
     const int H = A.H, W = A.W, VP = A.VP, AP = A.AP;
     const int H1 = H - 2, H2 = H - 4, W2 = W - 4, HW = H * W, NP2 = H2 * W2;
-    const int E1 = TA * H1 * W, P2 = TA * NP2, PLV = TA * VP, PL1 = TA * AP;
+    const int W1 = W - 2, E1 = TA * H1 * W1, P2 = TA * NP2, PLV = TA * VP, PL1 = TA * AP;
     f32x4 *s_view = (f32x4 *)s_raw;                 // [2 planes][TA][VP]
     f32x4 *s_c1 = s_view + 2 * PLV;                 // [8 planes][TA][AP]
     f32x4 *s_w1 = s_c1 + 8 * PL1;                   // [9][64]
@@ -91,8 +91,7 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv_f32(ConvArgs A) {
     for (int k = tid; k < 9 * 64; k += CONV_THREADS) s_w1[k] = A.w1[k];
     for (int k = tid; k < 36 * 64; k += CONV_THREADS) s_w2[k] = A.w2[k];
     if (tid < 32) s_bias[tid] = A.b2[tid];
-    // plane 0: channels 0..3; plane 1: channels 4..6 and the constant 1.0 of conv1's bias.  The cells behind every agent's H W stay
-    // zero in BOTH planes (conv1 runs over full rows: the last two positions of a row read them -- finite garbage that conv2 never uses)
+    // plane 0: channels 0..3; plane 1: channels 4..6 and the constant 1.0 of conv1's bias (the cells behind every agent's H W stay zero)
     for (int c = tid; c < 2 * PLV; c += CONV_THREADS) s_view[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     // a tile's window cells are fetched a whole tile AHEAD into registers (policy.hip: k_dqn_conv)
@@ -140,10 +139,12 @@ __global__ void __launch_bounds__(CONV_THREADS) k_dqn_conv_f32(ConvArgs A) {
     for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
         const int a0 = tile * TA;
         __syncthreads();     // s_view holds this tile; the previous conv2's readers of s_c1 are done
-        // ---- conv1: [E1 positions, full rows] x [32 channels], K = 9 taps x 8 channels
+        // ---- conv1: [E1 = TA x H1 x W1 valid positions] x [32 channels], K = 9 taps x 8 channels.  (Only the valid columns: 4 x 121 positions
+        // are 16 tiles -- four per SIMD; over full rows of 13, as policy.hip has them, they were 18: five on two of the four SIMDs.)
         for (int t = w; t < T1; t += NW) {
             const int E = min(t * 32 + r32, E1 - 1);
-            const int pos = E >> TS, ag = E & (TA - 1);          // position (= top-left cell = c1 position), agent
+            const int p1 = E >> TS, ag = E & (TA - 1);           // valid position, agent
+            const int y1 = p1 / W1, pos = y1 * W + (p1 - y1 * W1);      // its top-left window cell = its place in conv1's image (rows of W)
             const f32x4 *vb = s_view + g * PLV + ag * VP + pos;
             f32x16 acc = {0};
             f32x4 x[2];

@@ -677,7 +677,9 @@ def fullsize_scenarios():
         Scenario("test_1m", "pursuit", 4472, walls=100000, place=[rnd(0, 500000), rnd(1, 500000)], steps=2),
         # C5 at the size BASELINE.json names: examples/train_battle.py --map_size 3536, its own formation (2 x 499,849 on every
         # other cell of two squares 6 columns apart; 12.5 M cells, large_map_mode), 8 steps of random actions
-        Scenario("c5_battle3536_formation", "battle", 3536, place=battle_formation(3536), steps=8, action_seed=31),
+        # (round 6: 66 steps instead of 8 -- past the first refill of the claim words' epoch window and the fall to one optimistic pair at
+        # this size too; the fronts meet around step 3, kills from step ~8 on)
+        Scenario("c5_battle3536_formation", "battle", 3536, place=battle_formation(3536), steps=66, action_seed=31),
         # ... and the same two lattices interleaved, hp 4 / damage 3: a million agents with hostile neighbours on both sides --
         # ~380k attacks per step nearly all of which land, thousands of kills per step, dense move contention
         Scenario("c5_battle3536_melee", "battle", 3536, place=battle_melee(3536), steps=5, action_seed=32,
