@@ -55,7 +55,12 @@ for job in ${JOBS//,/ }; do
               run FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip $(s 0) $(s 300)
               # (the one-launch step at the sizes only a batch gives it by default since round 5: 1536 < agents <= 16384)
               run MAGENT_TUNE=solo_max=16384 python tools/fuzz_parity.py oracle hip $(s 3000) $(s 3400)
-              run MAGENT_TUNE=solo_max=16384 FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip $(s 300) $(s 600)) 2>&1 | tee $O/fuzz.log ;;
+              run MAGENT_TUNE=solo_max=16384 FUZZ_CYCLE=1 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip $(s 300) $(s 600)
+              # (round 6: three environments per plain game through env_cycle_many's batched pipeline, pipe.hip -- every world in the batch, then with one / no optimistic pair)
+              run FUZZ_PLAIN=1 FUZZ_BATCH=3 MAGENT_TUNE=batch_pipe_min=1 python tools/fuzz_parity.py oracle hip $(s 0) $(s 400)
+              run FUZZ_PLAIN=1 FUZZ_BATCH=3 MAGENT_TUNE=batch_pipe_min=1,attack_pairs=1 python tools/fuzz_parity.py oracle hip $(s 400) $(s 700)
+              run FUZZ_PLAIN=1 FUZZ_BATCH=4 MAGENT_TUNE=batch_pipe_min=1,attack_pairs=0 python tools/fuzz_parity.py oracle hip $(s 700) $(s 900)
+              run FUZZ_BATCH=3 FUZZ_TURN=1 python tools/fuzz_parity.py oracle hip $(s 0) $(s 200)) 2>&1 | tee $O/fuzz.log ;;
     line)    (cd /tmp && export TMPDIR=/tmp && timeout 900 python $R/bench.py --no-cpu-baseline --no-extras --no-cold $ARGS > $O/line.json 2> $O/line.err)
              python - $O/line.json <<'PY'
 import json, sys
