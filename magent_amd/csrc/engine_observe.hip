@@ -40,6 +40,7 @@ void Env::plan_render(int g, RenderArgs &R, RenderPlan &P, float *view, float *f
     // steps run one after the other: a step is ~1 us of latency)
     // (`batch_width` environments share the launch under env_cycle_many)
     int per = (int)std::min<long long>(32, std::max<long long>(4, steps * batch_width / 2048));
+    if (batch_width > 1) { static const int forced = tune("pipe_span", 0); if (forced > 0) per = forced; }     // (tuning: steps per workgroup of a batched render)
     P.steps_per_span = per;
     P.spans = (int)((steps + per - 1) / per);
     P.xcd_chunk = P.spans >= 64 ? P.spans / 8 : 0;
