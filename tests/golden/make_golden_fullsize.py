@@ -21,10 +21,12 @@ import helpers as H  # noqa: E402
 
 def main():
     assert H.have_ref(), "build oracle/_ref first: make -C oracle ref"
-    path = os.path.join(HERE, "digests_fullsize.json")
+    episodes = "--episodes" in sys.argv          # (whole episodes: tests/helpers.episode_scenarios -> digests_episode.json)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    path = os.path.join(HERE, "digests_episode.json" if episodes else "digests_fullsize.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
-    S = H.fullsize_scenarios()
-    for name in sys.argv[1:] or sorted(S):
+    S = H.episode_scenarios() if episodes else H.fullsize_scenarios()
+    for name in args or sorted(S):
         t = time.time()
         out[name] = H.run_hashed(S[name], H.REF_LIB)
         print(name, len(out[name]), "steps", "%.1fs" % (time.time() - t), flush=True)

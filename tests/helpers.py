@@ -709,6 +709,14 @@ def pipe_batch_scenarios():
             S["battle_brawl"], S["gather"]]
 
 
+def episode_scenarios():
+    """whole episodes at full size -- too long for the driver's suite (minutes of GPU time, an hour and a half of single-threaded reference to
+    generate): compared once per round by hand (tools/gpu_golden_check.py --episodes; tests/golden/digests_episode.json; the run is kept under
+    profiles/).  `c5_battle3536_episode`: BASELINE config 5's world (examples/train_battle.py --map_size 3536, 2 x 499,849 agents in the script's
+    own formation) for the 550 steps of one of the script's rounds (train_battle.py:45-140: `while not done` ... `if step_ct > 550: break`)"""
+    return {"c5_battle3536_episode": Scenario("c5_battle3536_episode", "battle", 3536, place=battle_formation(3536), steps=550, action_seed=31)}
+
+
 def render_episode(lib, out_dir, steps=6, twice=False):
     """a short battle with the text video dump on: returns {file name: bytes} of what env.render() wrote
     (twice: group 0 is given actions a second time before every other step -- the attack events of the literal loop)"""

@@ -2,7 +2,7 @@
 scenarios on the HIP engine and compare every array of every step with the digests of the COMPILED REFERENCE
 (tests/golden/digests_fullsize.json).  The engine reads MAGENT_TUNE once per process, so every driver variant is a process of its own.
 
-    python tools/gpu_golden_check.py [--device-io] name [name ...]
+    python tools/gpu_golden_check.py [--device-io] [--episodes] name [name ...]
 
 Prints one JSON line per scenario: {"name", "steps", "ok", "first_difference", "pipeline_stats", "engine_stats", "seconds"}."""
 import json
@@ -19,9 +19,10 @@ import helpers as H  # noqa: E402
 args = sys.argv[1:]
 device_io = "--device-io" in args
 names = [a for a in args if not a.startswith("--")]
-with open(os.path.join(H.GOLDEN_DIR, "digests_fullsize.json")) as f:
+episodes = "--episodes" in args          # whole episodes (tests/helpers.episode_scenarios, tests/golden/digests_episode.json): by hand, not in the suite
+with open(os.path.join(H.GOLDEN_DIR, "digests_episode.json" if episodes else "digests_fullsize.json")) as f:
     GOLD = json.load(f)
-FULL = H.fullsize_scenarios()
+FULL = H.episode_scenarios() if episodes else H.fullsize_scenarios()
 bad = 0
 for name in names:
     t = time.time()
