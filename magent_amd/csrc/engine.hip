@@ -559,7 +559,6 @@ void Env::reset() {
     map_scattered = map_warm = false;
     placed_random = placed_total = 0;
     pipe_sweep_shape = -1;
-    for (auto &sg_ : pipe_group_sig) sg_ = 0;
     // a fresh episode starts with two pairs of optimistic attack rounds: the first steps of a dense placement hold the deepest
     // dependency chains (measured at 2 x 400k: one pair runs out once in the first few steps, two never did), and a step that runs
     // out costs a host round trip; the budget falls back to one pair after 64 steps that did not need the second

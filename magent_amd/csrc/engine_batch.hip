@@ -279,17 +279,6 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         // profiles/r06_summary.md; the segments are too short for its four-round ring to pay.)
         bool sweep_ok = tune("pipe_sweep", 0) > 0;
         for (int e = 0; e < n_env && sweep_ok; e++) if (kind[e] == 2) sweep_ok &= envs[e]->pipe_sweep_ok(view ? view + e * n_group : nullptr);
-        // ... by default, where every observed group of the batch has the battle shape AND the same window (shape, offsets, mask): ONE sweep
-        // over all of them (k_pipe_render_gsweep: the batch's window cells as one sequence of steps, walked by 256 workgroups together)
-        static const bool gsweep_on = tune("pipe_gsweep", 1) != 0;
-        bool gsweep = gsweep_on && !sweep_ok;
-        unsigned long long gsig = 0;
-        for (int e = 0; e < n_env && gsweep; e++) {
-            if (kind[e] != 2) continue;
-            const unsigned long long sg_ = envs[e]->pipe_view_signature(view ? view + e * n_group : nullptr);
-            if (sg_ == 0 || (gsig != 0 && sg_ != gsig && sg_ != 1)) gsweep = false;
-            if (sg_ > 1) gsig = sg_;
-        }
         int sweep_feat = 0, sweep_vhw = 0;
         long long sweep_steps = 0;
         for (int e = 0; e < n_env; e++) {
@@ -313,22 +302,6 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
             }
         }
         PD.n_env = (int)piped.size();
-        if (gsweep && PD.slots > 0 && PD.n_env * PD.slots <= PIPE_GSWEEP_MAX_SEGS) {
-            long long steps = 0;
-            int nseg = 0;
-            for (int k = 0; k < PD.n_env; k++) {
-                PipeItem &it = lead.pipe_h[k];
-                it.seg_base = nseg;
-                for (int q = 0; q < it.M.n; q++) { it.seg_step0[q] = (int)steps; steps += ((long long)it.M.R[q].n * it.M.R[q].VH * it.M.R[q].VW + 63) / 64; }
-                nseg += it.M.n;
-            }
-            if (nseg > 0 && steps > 0 && steps < (1ll << 31)) {
-                PD.gsweep_steps = (int)steps; PD.gsweep_segs = nseg;
-                for (int e : piped) envs[e]->pipe_gsweeps++;
-                PD.render_blocks = sweep_feat;
-                PD.render_lds = render_gsweep_lds(sweep_vhw, nseg);
-            }
-        }
         if (sweep_ok && PD.slots > 0) {
             // `sweep` workgroups per (environment, group) segment: ~4 workgroups per CU over the whole launch, at least 8 steps' worth each
             const int segs = PD.n_env * PD.slots;
@@ -404,29 +377,6 @@ bool Env::pipe_eligible(int n_group, float *const *view, float *const *feat, con
 }
 
 // are this environment's observed groups of the shape the sweeping render takes?  (Env::cycle_many: one launch form for the whole batch)
-// the window of this environment's observed groups as a number: 0 = not the shape the sweeping render takes, or the observed groups look
-// through different windows; 1 = nothing to render here; else a hash of (rows, columns, offsets, mask) -- environments with equal numbers can
-// share k_pipe_render_gsweep's one table of window positions
-unsigned long long Env::pipe_view_signature(float *const *view) {
-    if (!pipe_sweep_ok(view)) return 0;
-    unsigned long long sig = 1;
-    for (int g = 0; g < (int)groups.size(); g++) {
-        if (!(view && view[g]) || groups[g].n == 0) continue;
-        if (pipe_group_sig[g] == 0) {      // (a property of the group's type: once per reset)
-            const HostType &t = *groups[g].type;
-            unsigned long long h = 1469598103934665603ull;
-            auto mix = [&](unsigned long long v) { h = (h ^ v) * 1099511628211ull; };
-            mix((unsigned)t.view.height); mix((unsigned)t.view.width); mix((unsigned)groups[g].tdev.view_x1); mix((unsigned)groups[g].tdev.view_y1);
-            for (unsigned char c : t.view.in) mix(c);
-            pipe_group_sig[g] = h | 2;
-        }
-        const unsigned long long h = pipe_group_sig[g];
-        if (sig > 1 && sig != h) return 0;
-        sig = h;
-    }
-    return sig;
-}
-
 bool Env::pipe_sweep_ok(float *const *view) {
     if (pipe_sweep_shape < 0) {        // (a property of the game's configuration: decided once per reset, for every group)
         const WorldView W = this->view();

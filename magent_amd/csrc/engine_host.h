@@ -217,15 +217,12 @@ private:
     void pipe_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, PipeItem &it, int rounds, bool sweep_ok);
     void pipe_after(float *const *rewards, const StepRecord &report, int *done);
     bool pipe_sweep_ok(float *const *view);
-    unsigned long long pipe_view_signature(float *const *view);
     // (lead environment of such a batch) the items, every environment's report on the device and in pinned memory, the last-workgroup ticket
     PipeItem *pipe_h = nullptr, *pipe_d = nullptr; StepRecord *reports_d = nullptr, *reports_h = nullptr; size_t pipe_cap = 0;
     int *pipe_ticket = nullptr, *pipe_flag = nullptr; int pipe_flag_seq = 0;
     int *d_newn = nullptr;                // [MAXG] group sizes behind the batched compaction (PipeItem::newn)
     bool pipe_folded = false;             // the batch's compaction makes the next minimap
-    unsigned long long pipe_group_sig[MAXG] = {};      // window signature of every group (Env::pipe_view_signature); 0: not computed since the reset
     int pipe_sweep_shape = -1;            // bit g: group g's observation has the shape the sweeping render takes (-1: not looked at since the reset)
-    int pipe_gsweeps = 0;                 // ... whose observations were rendered by the batch-wide sweep (k_pipe_render_gsweep)
     int pipe_rounds = 0;                  // cycles this environment took through the batched pipeline (env_get_info "pipeline_stats")
     void wait_record(int seq);
     StepRecord *h_rec = nullptr;          // pinned: written by k_step_solo, spun on by step_end

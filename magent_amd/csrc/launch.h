@@ -223,19 +223,16 @@ struct PipeItem {
     float *rewards[MAXG]; float group_reward[MAXG];
     GroupDev *gtab_out; TypeDev *ttab_out;
     int *newn;                         // [MAXG] device scratch: group sizes behind the compaction (k_pipe_clear -> k_pipe_finish)
-    int seg_step0[RENDER_MULTI_MAX];   // k_pipe_render_gsweep: first 64-cell step of observation slot k in the batch-wide step sequence
-    int seg_base, pad_;                // ... and the index of slot 0's segment in the batch's list of segments
+    int pad_[2];
 };
 // what the batch's last workgroup does: every environment's report to pinned host memory in one piece, then the word the host waits for
 struct PipeCtl { const StepRecord *reports_d; StepRecord *reports_h; int *ticket; int *flag_h; int flag_seq; int n_env; };
 constexpr int PIPE_REPORT_BYTES = 128;     // of a StepRecord: everything ahead of the tuning marks
-struct PipeDims { int n_env, max_n, max_total, G, slots, render_blocks, rounds, kmax, sweep, hist_cells, gsweep_steps, gsweep_segs; size_t render_lds; };      // gsweep_steps > 0: the batch-wide sweeping render
+struct PipeDims { int n_env, max_n, max_total, G, slots, render_blocks, rounds, kmax, sweep, hist_cells; size_t render_lds; };
 void launch_pipe_upload(hipStream_t s, const PipeItem *h_items, PipeItem *d_items, int n_env);      // (h_items: pinned, device-visible)
 void launch_pipe_cycle(hipStream_t s, const PipeItem *d_items, const PipeDims &D, const PipeCtl &C);
 bool render_sweep_mini_ok(const WorldView &W, const RenderArgs &R);
 size_t render_sweep_lds(int VHW, int C);
-size_t render_gsweep_lds(int VHW, int n_seg);
-constexpr int PIPE_GSWEEP_MAX_SEGS = 256;
 
 // agents per workgroup of the scan-based passes (set_action, clear_dead).  2 per thread: at 400k agents that is 782 workgroups --
 // the earlier 8 per thread left 196, less than one per CU, and every such launch was bound by its own latency chain

@@ -45,156 +45,6 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_pipe_render_sweep(const P
     V.w = it.W.w; V.h = it.W.h; V.G = it.W.G; V.viewcell = it.W.viewcell; V.mask = it.W.mask; V.grp = it.W.grp[R.g]; V.type = it.W.type[R.g];
     render_sweep2_body<false, 2, 2, true>(V, R, P, sweep);
 }
-// ... and ONE sweep over the observations of ALL environments (the default for battle-shaped groups): the window cells of every
-// (environment, group) segment, 64 per step, form one batch-wide sequence of steps; 256 persistent four-wave workgroups walk it together as
-// k_render_sweep2 walks one tensor -- round r of workgroup b is the 4 x 2 consecutive steps from (r * 256 + b) * 8 -- so that everything in
-// flight lies within a few megabytes of ONE or two neighbouring tensors at any time (what HBM takes fastest: render_sweep_dev.h), instead of
-// every segment being written by workgroups of its own at the same time.  A step belongs to one segment (a segment's last step is partial);
-// the ring of k_render_sweep2 carries the segment with each step.  All segments share the window shape (checked by the host).
-struct SweepSeg {
-    const int *x, *y; const unsigned *vc; float *view; const float *mini;
-    unsigned step0, n_cells; int g, w, h; FastDiv dsw, dsh;
-};
-constexpr int GSWEEP_MAX_SEGS = 256;
-__global__ void __launch_bounds__(64 * RENDER_WAVES) k_pipe_render_gsweep(const PipeItem *__restrict__ items, int n_env, int slots, int n_seg, int sweep, unsigned total_steps, int feat_blocks) {
-    constexpr int C = 7, SU = 2, DV = 2, N = DV + 2, Q2 = 16 * C - 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if ((int)blockIdx.x >= sweep) {     // trailing workgroups: the feature rows, `feat_blocks` workgroups per segment
-        const int fb = blockIdx.x - sweep, s = fb / feat_blocks, e = s / slots, k = s - e * slots;
-        const PipeItem &it = items[e];
-        if (k >= it.M.n) return;
-        const RenderArgs R = it.M.R[k];
-        const RenderPlan P = it.M.P[k];
-        RenderWorld V;
-        V.w = it.W.w; V.h = it.W.h; V.G = it.W.G; V.viewcell = it.W.viewcell; V.mask = it.W.mask; V.grp = it.W.grp[R.g]; V.type = it.W.type[R.g];
-        features_body<true>(V, R, P, fb - s * feat_blocks, feat_blocks);
-        return;
-    }
-    float *strips = (float *)smem + (size_t)wave * (SU * 64 * C);
-    RenderFastPos *wtab = (RenderFastPos *)((float *)smem + RENDER_WAVES * SU * 64 * C);
-    const int VH = items[0].M.R[0].VH, VW = items[0].M.R[0].VW, VHW = VH * VW;
-    SweepSeg *segs = (SweepSeg *)(wtab + VHW);
-    const FastDiv div_vhw = items[0].M.P[0].div_vhw, div_vw = items[0].M.P[0].div_vw;
-    for (int t = threadIdx.x; t < n_env * slots; t += 64 * RENDER_WAVES) {     // (the list holds the observed slots only, in (environment, slot) order)
-        const int e = t / slots, k = t - e * slots;
-        const PipeItem &it = items[e];
-        if (k >= it.M.n) continue;
-        const RenderArgs &R = it.M.R[k];
-        SweepSeg Q;
-        Q.x = it.W.grp[R.g].x; Q.y = it.W.grp[R.g].y; Q.vc = (const unsigned *)it.W.viewcell; Q.view = R.view; Q.mini = R.mini;
-        Q.step0 = (unsigned)it.seg_step0[k]; Q.n_cells = (unsigned)R.n * (unsigned)VHW; Q.g = R.g; Q.w = it.W.w; Q.h = it.W.h;
-        Q.dsw = it.M.P[k].div_scale_w; Q.dsh = it.M.P[k].div_scale_h;
-        segs[it.seg_base + k] = Q;
-    }
-    {
-        const PipeItem &it0 = items[0];
-        const TypeDev &T = it0.W.type[it0.M.R[0].g];
-        for (int c = threadIdx.x; c < VHW; c += 64 * RENDER_WAVES) {
-            const int vy = fdiv_u32(c, div_vw), vx = c - vy * VW;
-            RenderFastPos e;
-            e.dxy = ((T.view_y1 + vy) << 16) | ((T.view_x1 + vx) & 0xFFFF);
-            e.m0 = 0.0f; e.m1 = 0.0f;
-            e.mask = it0.W.mask[T.mask_off + c];
-            wtab[c] = e;
-        }
-    }
-    __syncthreads();
-    // the segment of a global step: the last one whose first step is <= S
-    auto find = [&](unsigned S) {      // (first steps ascend along the list: binary search)
-        int lo = 0, hi = n_seg - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (segs[mid].step0 <= S) lo = mid; else hi = mid - 1; }
-        return lo;
-    };
-    int sg[N][SU], ia[N][SU], ic[N][SU], x[N][SU], y[N][SU];
-    unsigned ls[N][SU], v[N][SU], in[N][SU];
-    float m0[N][SU], m1[N][SU];
-    auto first_step = [&](unsigned round) { return ((round * (unsigned)sweep + blockIdx.x) * RENDER_WAVES + wave) * SU; };
-    auto index = [&](unsigned round, int slot) {
-#pragma unroll
-        for (int u = 0; u < SU; u++) {
-            const unsigned S = min(first_step(round) + u, total_steps - 1u);
-            const int s = find(S);
-            const SweepSeg &Q = segs[s];
-            sg[slot][u] = s; ls[slot][u] = S - Q.step0;
-            const unsigned kk = min(ls[slot][u] * 64u + lane, Q.n_cells - 1u);
-            ia[slot][u] = (int)fdiv_u32(kk, div_vhw);
-            ic[slot][u] = (int)(kk - (unsigned)ia[slot][u] * VHW);
-            x[slot][u] = Q.x[ia[slot][u]]; y[slot][u] = Q.y[ia[slot][u]];
-        }
-    };
-    auto request = [&](int slot) {
-#pragma unroll
-        for (int u = 0; u < SU; u++) {
-            const SweepSeg &Q = segs[sg[slot][u]];
-            const RenderFastPos wt = wtab[ic[slot][u]];
-            const int mx = x[slot][u] + ((wt.dxy << 16) >> 16), my = y[slot][u] + (wt.dxy >> 16);
-            const bool inside = wt.mask && (unsigned)mx < (unsigned)Q.w && (unsigned)my < (unsigned)Q.h;
-            in[slot][u] = inside ? 1u : 0u;
-            v[slot][u] = Q.vc[min((unsigned)(my * Q.w + mx), (unsigned)Q.w * (unsigned)Q.h - 1u)];
-            m0[slot][u] = Q.mini[Q.g * VHW + ic[slot][u]];
-            m1[slot][u] = Q.mini[(1 - Q.g) * VHW + ic[slot][u]];
-        }
-    };
-#pragma unroll
-    for (int j = 0; j < N; j++) index(j, j);
-#pragma unroll
-    for (int j = 0; j < DV; j++) request(j);
-    bool running = true;
-    for (unsigned round = 0; running; round += N) {
-#pragma unroll
-        for (int s = 0; s < N; s++) {
-            if (!running) break;
-            const unsigned S0 = first_step(round + s);
-            if (S0 >= total_steps) { running = false; break; }
-            request((s + DV) % N);
-#pragma unroll
-            for (int u = 0; u < SU; u++) {
-                const SweepSeg &Q = segs[sg[s][u]];
-                const int cell = ic[s][u];
-                const unsigned g = (unsigned)Q.g;
-                const unsigned v0 = in[s][u] ? v[s][u] : VC_EMPTY;
-                const unsigned top = v0 >> 30;
-                const float hp = __uint_as_float(v0 & 0x3FFFFFFFu);
-                const bool mine = top == g, theirs = top == 1u - g;
-                const bool self = cell == (int)(fdiv_u32(y[s][u], Q.dsh) * VW + fdiv_u32(x[s][u], Q.dsw));
-                const float a0 = m0[s][u], a1 = m1[s][u];
-                float *dst = strips + u * (64 * C) + lane * C;
-                dst[0] = v0 == VC_WALL ? 1.0f : 0.0f; dst[1] = mine ? 1.0f : 0.0f; dst[2] = mine ? hp : 0.0f;
-                dst[3] = (self && a0 == a0) ? a0 + 1.0f : a0;
-                dst[4] = theirs ? 1.0f : 0.0f; dst[5] = theirs ? hp : 0.0f;
-                dst[6] = (self && a1 == a1) ? a1 + 1.0f : a1;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int u = 0; u < SU; u++) {
-                if (S0 + u >= total_steps) break;
-                const SweepSeg &Q = segs[sg[s][u]];
-                const size_t f0 = (size_t)ls[s][u] * 64u * C, total_floats = (size_t)Q.n_cells * C;
-                if (f0 >= total_floats) continue;
-                const size_t remain = total_floats - f0;
-                const float *strip_u = strips + u * (64 * C);
-                if (remain >= (size_t)(64 * C)) {
-                    const v4f *src4 = (const v4f *)strip_u;
-                    const v4f q0 = src4[lane], q1 = src4[lane + (lane < Q2 ? 64 : 0)];
-                    v4f *out4 = (v4f *)(Q.view + f0);
-                    __builtin_nontemporal_store(q0, out4 + lane);
-                    if (lane < Q2) __builtin_nontemporal_store(q1, out4 + lane + 64);
-                } else {
-                    const int nq = (int)(remain >> 2);
-                    for (int q = lane; q < nq; q += 64) __builtin_nontemporal_store(((const v4f *)strip_u)[q], (v4f *)(Q.view + f0) + q);
-                    for (int e = (nq << 2) + lane; e < (int)remain; e += 64) Q.view[f0 + e] = strip_u[e];
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            index(round + s + N, s);
-        }
-    }
-}
-size_t render_gsweep_lds(int VHW, int n_seg) { return (size_t)RENDER_WAVES * 2 * 64 * 7 * sizeof(float) + (size_t)VHW * sizeof(RenderFastPos) + (size_t)n_seg * sizeof(SweepSeg); }
 __global__ void __launch_bounds__(SCAN_THREADS) k_pipe_set_action(const PipeItem *__restrict__ items) {
     PIPE_ITEM();
     if (!it.actions[g] || (int)(blockIdx.x * SCAN_TILE) >= it.W.grp[g].n) return;
@@ -314,11 +164,7 @@ static size_t pipe_eval_lds(int kmax) { return (size_t)kmax * 256 * 8; }
 size_t render_sweep_lds(int VHW, int C) { return (size_t)RENDER_WAVES * 2 * 64 * C * sizeof(float) + (size_t)VHW * sizeof(RenderFastPos); }
 void launch_pipe_cycle(hipStream_t s, const PipeItem *d_items, const PipeDims &D, const PipeCtl &C) {
     const dim3 by_agent((D.max_n + 255) / 256, D.G, D.n_env), by_tile((D.max_n + SCAN_TILE - 1) / SCAN_TILE, D.G, D.n_env);
-    if (D.slots > 0 && D.gsweep_steps > 0) {
-        const int sweep = std::min(256, (D.gsweep_steps + RENDER_WAVES * 2 - 1) / (RENDER_WAVES * 2));
-        hipLaunchKernelGGL(k_pipe_render_gsweep, dim3(sweep + D.render_blocks * D.n_env * D.slots), dim3(64 * RENDER_WAVES), D.render_lds, s, d_items, D.n_env, D.slots, D.gsweep_segs,
-                           sweep, (unsigned)D.gsweep_steps, D.render_blocks);
-    } else if (D.slots > 0 && D.sweep > 0)
+    if (D.slots > 0 && D.sweep > 0)
         hipLaunchKernelGGL(k_pipe_render_sweep, dim3(D.sweep + D.render_blocks, D.n_env * D.slots), dim3(64 * RENDER_WAVES), D.render_lds, s, d_items, D.slots, D.sweep);
     else if (D.slots > 0 && D.render_blocks > 0)
         hipLaunchKernelGGL(k_pipe_render, dim3(D.render_blocks, D.n_env * D.slots), dim3(64 * RENDER_WAVES), D.render_lds, s, d_items, D.slots);
