@@ -8,8 +8,9 @@
 //   grid = (tiles of the largest group, groups, environments), the environment's description read from a device array of PipeItem
 // so that n environments cost one chain of launches instead of n -- and the chain has no host round trip in it: which groups compact, and
 // to what size, k_pipe_clear / k_pipe_finish read from the death counters the step left (the host learns the same numbers from the
-// reports, which the batch's last workgroup sends to pinned memory in one piece: 32 separate reports cost 32 x 20 small PCIe writes,
-// 43 us of the first version's k_pipe_commit).
+// reports, which the batch's last workgroup sends to pinned memory in one piece behind ONE system-scope release: every environment
+// publishing its own report -- a release, i.e. a write-back of the L2's dirty lines, each -- made the first version's k_pipe_commit 43 us
+// for 32 environments; it is 11 now).
 // GridWorld.cc:292-401 (observations), :403-454 (set_action), :456-631 (step), :694-704 (get_reward), :633-665 (clear_dead) -- bit-identical
 // to the same environments stepped one by one (the bodies are the same).
 #include "plain_dev.h"
@@ -33,8 +34,9 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_pipe_render(const PipeIte
     if (it.W.vc_packed) render_block<true, true, 1, true, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
     else render_block<true, true, 1, false, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
 }
-// ... and when every observed group of the batch has the battle shape [wall | has, hp, minimap | has, hp, minimap] (two groups, packed view
-// cells): the sweeping kernel (render_sweep_dev.h), `sweep` workgroups per (environment, group) segment + the feature rows' workgroups
+// ... or, with MAGENT_TUNE pipe_sweep=N, when every observed group of the batch has the battle shape [wall | has, hp, minimap | has, hp,
+// minimap] (two groups, packed view cells): the sweeping kernel (render_sweep_dev.h), N workgroups per (environment, group) segment + the
+// feature rows' workgroups.  Measured level or behind the generic workgroups at the sizes a batch renders (segments < 1 M window cells)
 __global__ void __launch_bounds__(64 * RENDER_WAVES) k_pipe_render_sweep(const PipeItem *__restrict__ items, int slots, int sweep) {
     const int e = blockIdx.y / slots, k = blockIdx.y - e * slots;
     const PipeItem &it = items[e];

@@ -714,7 +714,10 @@ def episode_scenarios():
     generate): compared once per round by hand (tools/gpu_golden_check.py --episodes; tests/golden/digests_episode.json; the run is kept under
     profiles/).  `c5_battle3536_episode`: BASELINE config 5's world (examples/train_battle.py --map_size 3536, 2 x 499,849 agents in the script's
     own formation) for the 550 steps of one of the script's rounds (train_battle.py:45-140: `while not done` ... `if step_ct > 550: break`)"""
-    return {"c5_battle3536_episode": Scenario("c5_battle3536_episode", "battle", 3536, place=battle_formation(3536), steps=550, action_seed=31)}
+    rnd = lambda g, n: (g, "random", {"n": n})
+    return {"c5_battle3536_episode": Scenario("c5_battle3536_episode", "battle", 3536, place=battle_formation(3536), steps=550, action_seed=31),
+            # ... and the bench's own workload (C3(i): battle 1000 x 1000, 2 x 400k placed at random) for the same 550 steps
+            "c3_battle1000_episode": Scenario("c3_battle1000_episode", "battle", 1000, place=[rnd(0, 400000), rnd(1, 400000)], steps=550)}
 
 
 def render_episode(lib, out_dir, steps=6, twice=False):
