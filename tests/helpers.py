@@ -673,6 +673,11 @@ def fullsize_scenarios():
                          130: [("add", 0, "random", {"n": 9000}), ("add", 1, "random", {"n": 9000})]}),
         # C4: gather 500x500 (train_gather.py), 20k food + 100k agents, only the agents act
         Scenario("c4_gather500", "gather", 500, place=[rnd(0, 20000), rnd(1, 100000)], acting=[1], steps=8),
+        # whole episodes of the two smaller BASELINE configurations (round 6): config 2 for the 550 steps of a train_battle.py round (the
+        # multi-launch pipeline at 4000 agents: nine epoch windows), config 4 until the agents have starved (train_gather.py's world: the
+        # population falls from 100k to a few thousand -- the step moves from the pipeline to the one-launch step on the way)
+        Scenario("c2_battle200_episode", "battle", 200, place=[rnd(0, 2000), rnd(1, 2000)], steps=550, action_seed=41),
+        Scenario("c4_gather500_episode", "gather", 500, place=[rnd(0, 20000), rnd(1, 100000)], acting=[1], steps=150, action_seed=42),
         # the reference's own 1M harness (scripts/test/test_1m.py:62-71): map sqrt(20 N), N/10 walls, N/2 2x2 predators, N/2 prey
         Scenario("test_1m", "pursuit", 4472, walls=100000, place=[rnd(0, 500000), rnd(1, 500000)], steps=2),
         # C5 at the size BASELINE.json names: examples/train_battle.py --map_size 3536, its own formation (2 x 499,849 on every
