@@ -185,8 +185,8 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
     // one workgroup steps 4000 agents in ~0.3 ms whatever else the chip does; 32 such worlds through the pipeline share ~0.2 ms)
     static const int pipe_min = std::max(1, tune("batch_pipe_min", 1537));
     static const bool pipe_on = tune("batch_pipe", 1) != 0;
-    std::vector<char> kind(n_env, 0);
-    std::vector<int> alone;
+    std::vector<char> kind(n_env, 0), solo_too(n_env, 0);
+    std::vector<int> alone, totals(n_env, 0);
     int n_pipe = 0;
     for (int e = 0; e < n_env; e++) {
         const int o = e * n_group;
@@ -195,10 +195,12 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         int total = 0;
         const bool pipe = pipe_on && envs[e]->pipe_eligible(n_group, view ? view + o : nullptr, feat ? feat + o : nullptr, actions ? actions + o : nullptr, &total);
         kind[e] = pipe && (!solo || total >= pipe_min) ? 2 : solo ? 1 : 0;
+        solo_too[e] = solo; totals[e] = total;
         n_pipe += kind[e] == 2;
     }
-    if (n_pipe == 1)       // (a batch of one: the environment's own launches do the same with less ceremony)
-        for (int e = 0; e < n_env; e++) if (kind[e] == 2) kind[e] = envs[e]->cycle_eligible(n_group, view ? view + e * n_group : nullptr, feat ? feat + e * n_group : nullptr, nullptr) ? 1 : 0;
+    if (n_pipe == 1)       // (a batch of one: the environment's own launches do the same with less ceremony -- the one-workgroup step only
+        // below the limit an environment on its own has for it, Env::solo_ok: beyond it the ordinary launches are the faster ones)
+        for (int e = 0; e < n_env; e++) if (kind[e] == 2) kind[e] = solo_too[e] && totals[e] <= envs[e]->solo_max_agents ? 1 : 0;
     int lead_e = -1, lead_p = -1;
     for (int e = 0; e < n_env; e++) {
         if (kind[e] == 1 && lead_e < 0) lead_e = e;
