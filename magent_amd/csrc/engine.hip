@@ -562,7 +562,8 @@ void Env::reset() {
     // a fresh episode starts with two pairs of optimistic attack rounds: the first steps of a dense placement hold the deepest
     // dependency chains (measured at 2 x 400k: one pair runs out once in the first few steps, two never did), and a step that runs
     // out costs a host round trip; the budget falls back to one pair after 64 steps that did not need the second
-    boost_attack = 64;
+    boost_window = 64;
+    boost_attack = boost_window;
     file_ct++; frame_ct = 0;   // RenderGenerator::next_file (GridWorld.cc:97)
     large_map_mode = width * height > 99 * 99;
     const int n_sep = large_map_mode ? (width * height > 1000 * 1000 ? 16 : 8) : 1;
