@@ -270,23 +270,41 @@ def spawn_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    held = []
+    import threading
+    held, lock, done = [], threading.Lock(), {"printed": False}
+
+    def emit(rc):
+        """rank 0's line, once: with the launcher's return code when the launcher has ended (a rank that died behind the
+        headline is visible to whoever reads the line), with `null` when it has not ended two minutes after the line was seen -- a rank that
+        hangs behind the headline must not take the measured line with it"""
+        with lock:
+            if done["printed"]:
+                return
+            done["printed"] = True
+            for line in held:
+                try:
+                    rec = json.loads(line)
+                    rec["launcher_rc"] = rc
+                    line = json.dumps(rec) + "\n"
+                except ValueError:
+                    pass
+                sys.stdout.write(line)
+            sys.stdout.flush()
+    timer = None
     for line in proc.stdout:
         if line.startswith('{"metric"'):
             held.append(line)       # (rank 0 prints it last: held for the moment it takes the launcher to end, so that it can carry the launcher's code)
+            if timer is None:
+                timer = threading.Timer(120.0, emit, args=(None,))
+                timer.daemon = True
+                timer.start()
             continue
         sys.stdout.write(line)
         sys.stdout.flush()
     rc = proc.wait()
-    for line in held:
-        try:      # the launcher's return code rides in the record: a rank that died behind the headline is visible to whoever reads the line
-            rec = json.loads(line)
-            rec["launcher_rc"] = rc
-            line = json.dumps(rec) + "\n"
-        except ValueError:
-            pass
-        sys.stdout.write(line)
-    sys.stdout.flush()
+    if timer is not None:
+        timer.cancel()
+    emit(rc)
     return 0 if len(held) == 1 else (rc or 1)
 
 
