@@ -275,11 +275,13 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         int rounds = lead.opt_fixed ? 2 * lead.opt_attack_pairs : 2;
         for (int e = 0; e < n_env && !lead.opt_fixed; e++) if (kind[e] == 2) rounds = std::max(rounds, 2 * (envs[e]->boost_attack > 0 ? 2 : 1));
         PD.G = n_group; PD.rounds = rounds;
-        // the observations of the worlds that do not render for themselves (< 1 M window cells per group): the generic render's workgroups,
-        // one launch.  (MAGENT_TUNE pipe_sweep=N: the sweeping kernel instead, N workgroups per (environment, group) segment, when every
-        // observed group has the battle shape -- measured level or behind at these sizes: 32 x (2 x 2000): 0.238 ms per round against 0.231,
-        // profiles/r06_summary.md; the segments are too short for its four-round ring to pay.)
-        bool sweep_ok = tune("pipe_sweep", 0) > 0;
+        // the observations of the worlds that do not render for themselves (< 1 M window cells per group), one launch: when every observed
+        // group has the battle shape, the sweeping kernel with ~256 workgroups over all (environment, group) segments together -- its own
+        // geometry, one workgroup per CU (measured on the MI355X, profiles/r06_summary.md: 32 x (2 x 2000) 0.232 ms per round against 0.259
+        // with the generic workgroups on the same box, 8 worlds 0.111 against 0.123, 128 worlds 0.718 against 0.812) -- else, or with
+        // MAGENT_TUNE pipe_sweep=0, the generic render's workgroups (pipe_sweep=N: N sweeping workgroups per segment)
+        static const int sweep_tune = tune("pipe_sweep", -1);
+        bool sweep_ok = sweep_tune != 0;
         for (int e = 0; e < n_env && sweep_ok; e++) if (kind[e] == 2) sweep_ok &= envs[e]->pipe_sweep_ok(view ? view + e * n_group : nullptr);
         int sweep_feat = 0, sweep_vhw = 0;
         long long sweep_steps = 0;
@@ -305,10 +307,11 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         }
         PD.n_env = (int)piped.size();
         if (sweep_ok && PD.slots > 0) {
-            // `sweep` workgroups per (environment, group) segment: ~4 workgroups per CU over the whole launch, at least 8 steps' worth each
+            // `sweep` workgroups per (environment, group) segment: 256 over the whole launch (four times that while the segments are few:
+            // 16 segments measured level at 16 and 64 each), at least 8 steps' worth each
             const int segs = PD.n_env * PD.slots;
-            static const int forced = tune("pipe_sweep", -1);
-            PD.sweep = (int)std::max<long long>(1, std::min<long long>(forced > 0 ? forced : std::max(8, 2048 / segs), (sweep_steps + 7) / 8));
+            const int want = sweep_tune > 0 ? sweep_tune : segs <= 16 ? 1024 / segs : std::max(1, 256 / segs);
+            PD.sweep = (int)std::max<long long>(1, std::min<long long>(want, (sweep_steps + 7) / 8));
         }
         PipeCtl C{lead.reports_d, lead.reports_h, lead.pipe_ticket, lead.pipe_flag, ++lead.pipe_flag_seq, PD.n_env};
         launch_pipe_upload(lead.stream, lead.pipe_h, lead.pipe_d, PD.n_env);

@@ -18,6 +18,31 @@
 
 namespace magent_amd {
 
+// A pointer that a kernel reads from memory -- every pointer of an item -- is a GENERIC pointer to the compiler, and what goes through it a
+// FLAT instruction: counted on the LDS counter as well as on the memory counter, so that a wait for an LDS read also waits for every store
+// in flight (the sweeping render's whole design is that it does not), and slower to issue.  Pointers in kernel arguments are known to be
+// global; these say the same of an item's (device memory, all of them -- the pinned report is written through a kernel argument).
+// (a cast to the global address space and back is folded away before it can tell anybody anything; the pointer -- the same in every lane: an
+// item belongs to the workgroup -- goes through its scalar halves instead, and comes back as a global pointer)
+template <class T> __device__ __forceinline__ T *glob(T *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (T *)(__attribute__((address_space(1))) T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void globalize(GroupDev &G) {
+    G.x = glob(G.x); G.y = glob(G.y); G.id = glob(G.id); G.last_action = glob(G.last_action); G.op_obj = glob(G.op_obj); G.pend = glob(G.pend);
+    G.hp = glob(G.hp); G.next_reward = glob(G.next_reward); G.last_reward = glob(G.last_reward); G.dead = glob(G.dead); G.last_op = glob(G.last_op);
+    G.absorbed = glob(G.absorbed); G.dir = glob(G.dir); G.key = glob(G.key); G.drank_a = glob(G.drank_a); G.drank_b = glob(G.drank_b); G.mv = glob(G.mv);
+    G.hitf = glob(G.hitf); G.hits = glob(G.hits); G.eat = glob(G.eat); G.fleft = glob(G.fleft); G.fcell = glob(G.fcell);
+}
+__device__ __forceinline__ void globalize(RenderArgs &R) { R.mini = glob(R.mini); R.view = glob(R.view); R.feat = glob(R.feat); }
+__device__ __forceinline__ RenderWorld pipe_render_world(const PipeItem &it, int g) {
+    RenderWorld V;
+    V.w = it.W.w; V.h = it.W.h; V.G = it.W.G; V.viewcell = glob(it.W.viewcell); V.mask = glob(it.W.mask); V.grp = it.W.grp[g]; V.type = it.W.type[g];
+    globalize(V.grp);
+    return V;
+}
+
 // (an item is read through scalar loads: the index is the workgroup's, nothing in these launches writes the array)
 #define PIPE_ITEM() const PipeItem &it = items[blockIdx.z]; const int g = blockIdx.y; if (g >= it.W.G) return
 
@@ -26,26 +51,33 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_pipe_render(const PipeIte
     const int e = blockIdx.y / slots, k = blockIdx.y - e * slots;
     const PipeItem &it = items[e];
     if (k >= it.M.n || (int)blockIdx.x >= it.M.blocks[k]) return;
-    const RenderArgs R = it.M.R[k];
+    RenderArgs R = it.M.R[k];
+    globalize(R);
     const RenderPlan P = it.M.P[k];
-    RenderWorld V;
-    V.w = it.W.w; V.h = it.W.h; V.G = it.W.G; V.viewcell = it.W.viewcell; V.mask = it.W.mask; V.grp = it.W.grp[R.g]; V.type = it.W.type[R.g];
+    const RenderWorld V = pipe_render_world(it, R.g);
     // (plain games: no turn_mode)
     if (it.W.vc_packed) render_block<true, true, 1, true, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
     else render_block<true, true, 1, false, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
 }
-// ... or, with MAGENT_TUNE pipe_sweep=N, when every observed group of the batch has the battle shape [wall | has, hp, minimap | has, hp,
-// minimap] (two groups, packed view cells): the sweeping kernel (render_sweep_dev.h), N workgroups per (environment, group) segment + the
-// feature rows' workgroups.  Measured level or behind the generic workgroups at the sizes a batch renders (segments < 1 M window cells)
-__global__ void __launch_bounds__(64 * RENDER_WAVES) k_pipe_render_sweep(const PipeItem *__restrict__ items, int slots, int sweep) {
-    const int e = blockIdx.y / slots, k = blockIdx.y - e * slots;
+// ... or, when every observed group of the batch has the battle shape [wall | has, hp, minimap | has, hp, minimap] (two groups, packed view
+// cells): the sweeping kernel (render_sweep_dev.h), `sweep` workgroups per (environment, group) segment -- ~256 over the launch, the
+// geometry it has on its own -- + the feature rows' workgroups.  (Round 6 first measured it level with the generic workgroups and left it
+// off: its loads and stores were FLAT instructions then -- see glob() above -- and its workgroups sat on half of the XCDs -- below.)
+// (a flat grid: the sweeping workgroups of all segments first -- `sweep` consecutive ones per segment, so that consecutive workgroup numbers,
+// which the dispatcher deals out over the eight XCDs in turn, are the sweeping ones: with (sweep + feature workgroups) per segment on one
+// axis, sweep = 4 and 68 feature workgroups put every sweeping workgroup of every segment on XCDs 0..3 -- then the feature rows' workgroups)
+__global__ void __launch_bounds__(64 * RENDER_WAVES) k_pipe_render_sweep(const PipeItem *__restrict__ items, int slots, int sweep, int segs, int feat_blocks) {
+    int seg, bx;
+    if ((int)blockIdx.x < segs * sweep) { seg = blockIdx.x / sweep; bx = blockIdx.x - seg * sweep; }
+    else { const int f = blockIdx.x - segs * sweep; seg = f / feat_blocks; bx = sweep + (f - seg * feat_blocks); }
+    const int e = seg / slots, k = seg - e * slots;
     const PipeItem &it = items[e];
     if (k >= it.M.n) return;
-    const RenderArgs R = it.M.R[k];
+    RenderArgs R = it.M.R[k];
+    globalize(R);
     const RenderPlan P = it.M.P[k];
-    RenderWorld V;
-    V.w = it.W.w; V.h = it.W.h; V.G = it.W.G; V.viewcell = it.W.viewcell; V.mask = it.W.mask; V.grp = it.W.grp[R.g]; V.type = it.W.type[R.g];
-    render_sweep2_body<false, 2, 2, true>(V, R, P, sweep);
+    const RenderWorld V = pipe_render_world(it, R.g);
+    render_sweep2_body<false, 2, 2, true>(V, R, P, sweep, bx, sweep + feat_blocks);
 }
 __global__ void __launch_bounds__(SCAN_THREADS) k_pipe_set_action(const PipeItem *__restrict__ items) {
     PIPE_ITEM();
@@ -167,7 +199,7 @@ size_t render_sweep_lds(int VHW, int C) { return (size_t)RENDER_WAVES * 2 * 64 *
 void launch_pipe_cycle(hipStream_t s, const PipeItem *d_items, const PipeDims &D, const PipeCtl &C) {
     const dim3 by_agent((D.max_n + 255) / 256, D.G, D.n_env), by_tile((D.max_n + SCAN_TILE - 1) / SCAN_TILE, D.G, D.n_env);
     if (D.slots > 0 && D.sweep > 0)
-        hipLaunchKernelGGL(k_pipe_render_sweep, dim3(D.sweep + D.render_blocks, D.n_env * D.slots), dim3(64 * RENDER_WAVES), D.render_lds, s, d_items, D.slots, D.sweep);
+        hipLaunchKernelGGL(k_pipe_render_sweep, dim3((D.sweep + D.render_blocks) * D.n_env * D.slots), dim3(64 * RENDER_WAVES), D.render_lds, s, d_items, D.slots, D.sweep, D.n_env * D.slots, std::max(1, D.render_blocks));
     else if (D.slots > 0 && D.render_blocks > 0)
         hipLaunchKernelGGL(k_pipe_render, dim3(D.render_blocks, D.n_env * D.slots), dim3(64 * RENDER_WAVES), D.render_lds, s, d_items, D.slots);
     hipLaunchKernelGGL(k_pipe_set_action, by_tile, dim3(SCAN_THREADS), 0, s, d_items);

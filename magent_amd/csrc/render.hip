@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_fast(RenderWorld W
 }
 template <bool CELLS16, int DV, int SU, bool MINI = true>
 __global__ void __launch_bounds__(64 * RENDER_WAVES) k_render_sweep2(RenderWorld W, RenderArgs R, RenderPlan P, int sweep) {
-    render_sweep2_body<CELLS16, DV, SU, MINI>(W, R, P, sweep);
+    render_sweep2_body<CELLS16, DV, SU, MINI>(W, R, P, sweep, blockIdx.x, gridDim.x);
 }
 // the shapes k_render_fast takes
 bool render_sweep_mini_ok(const WorldView &W, const RenderArgs &R) {     // (launch.h: the float32 battle shape the sweeping kernel takes)

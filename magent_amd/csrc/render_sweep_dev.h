@@ -16,17 +16,17 @@ namespace magent_amd {
 // (MINI: the game has minimap channels -- 7 floats per cell [wall | has, hp, minimap | has, hp, minimap]; without -- round 5 -- 5: [wall | has, hp | has, hp],
 // the shape of the reference's pursuit-like 1M harness)
 // (the body is shared: render.hip's k_render_sweep2 -- one group per launch, 256 workgroups -- and pipe.hip's k_pipe_render_sweep -- the groups
-// of MANY environments per launch, blockIdx.y = segment, `sweep` workgroups each; blockIdx.x / gridDim.x are the position within a segment)
+// of MANY environments per launch, `sweep` workgroups per segment; bx / nb: the workgroup's position within its segment, of sweep + feature workgroups)
 template <bool CELLS16, int DV, int SU, bool MINI = true>
-__device__ __forceinline__ void render_sweep2_body(const RenderWorld &W, const RenderArgs &R, const RenderPlan &P, int sweep) {
+__device__ __forceinline__ void render_sweep2_body(const RenderWorld &W, const RenderArgs &R, const RenderPlan &P, int sweep, unsigned bx, unsigned nb) {
     constexpr int C = MINI ? 7 : 5;                   // floats per window cell
     constexpr int Q2 = 16 * C - 64;                   // a strip is 16 * C float4: 64 in a first store instruction, Q2 in a second
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int N = DV + 2;                         // ring slots: rounds r .. r + DV + 1
     const int VHW = R.VH * R.VW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if ((int)blockIdx.x >= sweep) {     // trailing workgroups: the feature rows (measured: better here than at the end of the sweeping
-        features_body<true>(W, R, P, blockIdx.x - sweep, gridDim.x - sweep);   // workgroups, where four waves per CU crawl through them)
+    if ((int)bx >= sweep) {     // trailing workgroups: the feature rows (measured: better here than at the end of the sweeping
+        features_body<true>(W, R, P, bx - sweep, nb - sweep);   // workgroups, where four waves per CU crawl through them)
         return;
     }
     float *strips = (float *)smem + (size_t)wave * (SU * 64 * C);
@@ -54,7 +54,7 @@ __device__ __forceinline__ void render_sweep2_body(const RenderWorld &W, const R
     unsigned v[N][SU], in[N][SU];
     // (P.xcd_chunk < 0, tuning: workgroup b -- which runs on XCD b % 8 -- takes slot (b % 8) * (sweep / 8) + b / 8 of the round, so that an XCD's
     // workgroups write one contiguous eighth of the window)
-    const unsigned slot = (P.xcd_chunk < 0 && (sweep & 7) == 0) ? (blockIdx.x & 7u) * ((unsigned)sweep >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const unsigned slot = (P.xcd_chunk < 0 && (sweep & 7) == 0) ? (bx & 7u) * ((unsigned)sweep >> 3) + (bx >> 3) : bx;
     auto first_step = [&](unsigned round) { return ((round * (unsigned)sweep + slot) * RENDER_WAVES + wave) * SU; };
     auto index = [&](unsigned round, int slot) {
 #pragma unroll

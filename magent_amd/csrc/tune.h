@@ -20,7 +20,7 @@
 //   batch_cycle=0       env_cycle_many runs its environments one after another instead of in one pair of launches
 //   batch_pipe=0        env_cycle_many never takes the batched pipeline (pipe.hip): worlds beyond the one-launch step go one by one
 //   batch_pipe_min=N    ... and takes it for worlds of N agents or more that could also step in one launch                 default 1537
-//   pipe_sweep=N        the batched render of env_cycle_many's pipeline through the sweeping kernel, N workgroups per (environment, group)   default 0: generic
+//   pipe_sweep=N        the batched render of env_cycle_many's pipeline: N sweeping workgroups per (environment, group) segment; 0: the generic workgroups   default: ~256 sweeping workgroups over the launch when every observed group has the battle shape
 //   pipe_span=N         64-cell steps per workgroup of a batched render (env_cycle_many)                                          default: by size, <= 32
 //   touch_map=0|1       never / before every render of a map beyond the L2s: the painted map streamed through the caches first (default: before the
 //                       first render of a cycle when some group was placed at random)

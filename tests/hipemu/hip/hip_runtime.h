@@ -108,6 +108,7 @@ template <typename T> static inline T shfl_at(const void *site, T v, int src) {
 // A[row = l & 31][k = 8 (l >> 5) + 0..7] and B[k = 8 (l >> 5) + 0..7][col = l & 31]; result register r of lane l is
 // D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31].  The sum is taken in double and rounded once (the hardware's own
 // internal order is not documented: tests compare with a tolerance, as they do on the GPU).
+#define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)

@@ -185,7 +185,8 @@ def test_emulated_batched_pipeline(emu):
             "stats = [e.pipeline_stats() for e in seen]\n"
             "assert all(s[6] >= 8 for s in stats[:3]) and (stats[3][6] > 0) == any(k in os.environ.get('MAGENT_TUNE', '') for k in ('batch_pipe_min=1', 'attack_pairs=0')) and stats[4][6] == 0, stats\n"
             "print('ok', stats)\n") % (ROOT, os.path.join(ROOT, "tests"))
-    for extra in ({}, {"HIPEMU_SCRAMBLE": "7"}, {"MAGENT_TUNE": "attack_pairs=1,batch_pipe_min=1"}, {"MAGENT_TUNE": "attack_pairs=0", "HIPEMU_SCRAMBLE": "9"}):
+    for extra in ({}, {"HIPEMU_SCRAMBLE": "7"}, {"MAGENT_TUNE": "attack_pairs=1,batch_pipe_min=1,pipe_sweep=0"},
+                  {"MAGENT_TUNE": "attack_pairs=0,pipe_sweep=3", "HIPEMU_SCRAMBLE": "9"}):      # (pipe_sweep: the batch's render -- 0 generic workgroups, N sweeping ones per segment; default ~256 per launch)
         p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"OMP_NUM_THREADS": "1"}, extra), capture_output=True, text=True, timeout=1500)
         assert p.returncode == 0 and "ok" in p.stdout, (extra, p.stdout[-1500:] + p.stderr[-3000:])
 

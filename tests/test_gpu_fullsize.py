@@ -232,6 +232,24 @@ def test_fuzz_batched_pipeline():
         assert out.returncode == 0 and "150 seeds, 0 failures" in out.stdout and "batched pipeline (pipe.hip): 150" in out.stdout, (tune, out.stdout[-3000:], out.stderr[-2000:])
 
 
+@pytest.mark.parametrize("tune", ["pipe_sweep=0", "pipe_sweep=3", "pipe_sweep=32"])
+def test_batched_pipeline_render_forms(tune):
+    """the batch's render launch in its other forms -- the generic workgroups (pipe_sweep=0: what every shape but the battle one takes) and the
+    sweeping kernel at workgroup counts the default (~256 over the launch) does not pick -- on tests/test_gpu_parity.py's batched-pipeline scenarios, every
+    environment against the oracle driven alone through the reference call sequence"""
+    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import helpers as H\n"
+            "scs = H.pipe_batch_scenarios()\n"
+            "seen = []\n"
+            "got = H.run_cycle_batch(scs, H.HIP_LIB, envs_out=seen)\n"
+            "for sc, g in zip(scs, got):\n"
+            "    H.assert_same(H.run_cycle(sc, H.ensure_oracle(), fused=False), g, sc.name + ' (batched pipeline)')\n"
+            "assert all(e.pipeline_stats()[6] >= 8 for e in seen[:3])\n"
+            "print('ok')\n") % (H.ROOT, os.path.join(H.ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"OMP_NUM_THREADS": "1"}, {"MAGENT_TUNE": tune}), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "ok" in p.stdout, (tune, p.stdout[-1500:] + p.stderr[-3000:])
+
+
 def test_fuzz_batched_cycle():
     """three environments per random game in ONE magent_amd.EnvBatch -- k_render_batch + k_step_solo_batch: one pair of launches for
     all of them -- each against the oracle driven alone through the reference call sequence"""
