@@ -82,7 +82,21 @@ __device__ __forceinline__ int2 attack_target(const WorldView &W, const GroupDev
 // host; rounds after convergence find nothing to do, and everything after a phase whose rounds ran out returns at
 // once so that the host can take over from exactly that state.  No gate kernel: the last round of a phase writes the
 // phase's flag itself (`flag` = counter index, < 0 = do not report).
-__device__ __forceinline__ bool attack_open(const WorldView &W) { return W.counters[CTR_OPEN_ATTACK] != 0; }
+// A pointer that a kernel reads from MEMORY -- a device table's, an item's of a batch (pipe.hip) -- is a GENERIC pointer to the compiler, and what
+// goes through it a FLAT instruction: counted on the LDS counter as well as on the memory counter, so that a wait for an LDS read or a scalar
+// load also waits for every store in flight (the sweeping render's whole design is that it does not: with FLAT stores its batched form ran at
+// half its speed, profiles/r06_summary.md), and without the scalar-base addressing of the GLOBAL instructions.  Pointers in kernel arguments
+// are known to be global; glob() says the same of one that is not (all of them are device or pinned host memory -- never LDS, never scratch).
+// (A cast to the global address space and straight back is folded away before it tells anybody anything; the way through an integer is not.)
+template <class T> __device__ __forceinline__ T *glob(T *p) { return (T *)(__attribute__((address_space(1))) T *)(unsigned long long)p; }
+__device__ __forceinline__ GroupDev glob_group(GroupDev G) {
+    G.x = glob(G.x); G.y = glob(G.y); G.id = glob(G.id); G.last_action = glob(G.last_action); G.op_obj = glob(G.op_obj); G.pend = glob(G.pend);
+    G.hp = glob(G.hp); G.next_reward = glob(G.next_reward); G.last_reward = glob(G.last_reward); G.dead = glob(G.dead); G.last_op = glob(G.last_op);
+    G.absorbed = glob(G.absorbed); G.dir = glob(G.dir); G.key = glob(G.key); G.drank_a = glob(G.drank_a); G.drank_b = glob(G.drank_b); G.mv = glob(G.mv);
+    G.hitf = glob(G.hitf); G.hits = glob(G.hits); G.eat = glob(G.eat); G.fleft = glob(G.fleft); G.fcell = glob(G.fcell);
+    return G;
+}
+__device__ __forceinline__ bool attack_open(const WorldView &W) { return glob(W.counters)[CTR_OPEN_ATTACK] != 0; }
 __device__ __forceinline__ bool step_open(const WorldView &W) { return (W.counters[CTR_OPEN_ATTACK] | W.counters[CTR_OPEN_MOVE]) != 0; }
 
 // ------------------------------------------------------------------------------------------------ paint
@@ -96,9 +110,9 @@ constexpr unsigned VC_EMPTY = 0xFFFFFFFFu, VC_WALL = 0xFFFFFFFEu, VC_FOOD = 0xFF
 // one cell of the painted copy, in whichever format the game uses (must match k_paint)
 __device__ __forceinline__ void vc_store(const WorldView &W, int c, int code, unsigned hpbits) {
     if (W.vc_packed) {
-        ((unsigned *)W.viewcell)[c] = code == OCC_EMPTY ? VC_EMPTY : code == OCC_WALL ? VC_WALL : code == OCC_FOOD ? VC_FOOD : (((unsigned)code << 30) | hpbits);
-        if (code >= 0 && (hpbits >> 30)) W.counters[CTR_PACK_OVERFLOW] = 1;
-    } else W.viewcell[c] = make_int2(code, (int)hpbits);
+        ((unsigned *)glob(W.viewcell))[c] = code == OCC_EMPTY ? VC_EMPTY : code == OCC_WALL ? VC_WALL : code == OCC_FOOD ? VC_FOOD : (((unsigned)code << 30) | hpbits);
+        if (code >= 0 && (hpbits >> 30)) glob(W.counters)[CTR_PACK_OVERFLOW] = 1;
+    } else glob(W.viewcell)[c] = make_int2(code, (int)hpbits);
 }
 // Map::clear_area; with live_paint the painted copy follows at once (the step keeps it current: cells are emptied where
 // they are vacated, and at the end of the step every live agent paints its own body -- repaint_body)
@@ -593,7 +607,7 @@ __device__ __forceinline__ void attack_rank_body(const WorldView &W, const Group
                 else if (atomicOr(&hitbits[ty * W.w + tx], 1u << (T.attack_bit + k)) == 0u) tlist[atomicAdd(n_tlist, 1)] = o;
                 // the agent whose cell it is hears of it: "some hit word of my body is set" without a look at every one of them
                 // (several attackers may say so at once: the same byte, the same value)
-                if (o >= 0) gtab[ref_group(o)].hitf[ref_index(o)] = 1;
+                if (o >= 0) glob(gtab[ref_group(o)].hitf)[ref_index(o)] = 1;
             }
         }
     }
@@ -720,7 +734,7 @@ __device__ __forceinline__ void attack_eval_body(const WorldView &W, const Group
     }
     // death rank of my target as of the current iterate
     int tgt_dr = RANK_INF;
-    if (tgt >= 0) tgt_dr = gtab[ref_group(tgt)].drank_a[ref_index(tgt)];
+    if (tgt >= 0) tgt_dr = glob(gtab[ref_group(tgt)].drank_a)[ref_index(tgt)];
     const bool kill = W.any_kill_supply && tgt >= 0 && (unsigned)tgt_dr == my_rank;
     // what my own attack feeds me at my rank (add_hp: capped at the type's hp even when it adds nothing): the kill supply,
     // or in food_mode what I eat (the owner of the food says how much; -1 = my attack meets no food)
@@ -764,7 +778,7 @@ __device__ __forceinline__ void attack_eval_body(const WorldView &W, const Group
             float e = -1.0f;
             if (k > kd && present && attack_cell(W, gtab, a) == c_food) {
                 const unsigned r = s_rank[k * ATT_THREADS + tid];
-                if ((unsigned)gtab[ref_group(a)].drank_a[ref_index(a)] >= r) {       // alive at its turn
+                if ((unsigned)glob(gtab[ref_group(a)].drank_a)[ref_index(a)] >= r) {       // alive at its turn
                     e = fminf(ttab[ref_group(a)].eat_ability, food);
                     food -= e;
                     if ((double)food < 0.1) present = false;
@@ -781,9 +795,9 @@ __device__ __forceinline__ void attack_eval_body(const WorldView &W, const Group
         G.drank_a[i] = dr;
         // who reads my death rank: my target (is its attacker alive at that rank?) and, for the kill supply, my attackers
         const int reader = W.food_mode ? aimed : tgt;
-        if (reader >= 0) gtab[ref_group(reader)].drank_b[ref_index(reader)] = round;
+        if (reader >= 0) glob(gtab[ref_group(reader)].drank_b)[ref_index(reader)] = round;
         if (W.any_kill_supply)
-            for (int k = 0; k < nh; k++) { const int a = s_ref[k * ATT_THREADS + tid]; gtab[ref_group(a)].drank_b[ref_index(a)] = round; }
+            for (int k = 0; k < nh; k++) { const int a = s_ref[k * ATT_THREADS + tid]; glob(gtab[ref_group(a)].drank_b)[ref_index(a)] = round; }
         if (flagp) *flagp = 1;                        // (multi-launch driver: only the last round of a batch reports)
     }
 }
@@ -811,7 +825,7 @@ __device__ __forceinline__ void attack_apply_body(const WorldView &W, const Grou
             int o = W.occ[ty * W.w + tx];
             if (o >= 0 && (T.attack_in_group || ref_group(o) != g)) tgt = o;
         }
-        if (tgt >= 0) tgt_dr = gtab[ref_group(tgt)].drank_a[ref_index(tgt)];
+        if (tgt >= 0) tgt_dr = glob(gtab[ref_group(tgt)].drank_a)[ref_index(tgt)];
     }
     const float eaten = W.food_mode && attacker ? G.eat[i] : -1.0f;   // >= 0: my attack ate (food_mode)
     float hp;
@@ -954,7 +968,7 @@ __device__ __forceinline__ void move_init_body(const WorldView &W, int g, int i)
 // launches -- or workgroup barriers, in the one-launch step -- to shorten chains that are one or two links long on average;
 // a long "conga line" now costs its length in dependent loads to the agents at its tail, and nothing to anybody else).
 __device__ __forceinline__ unsigned move_resolve(const GroupDev *gtab, unsigned m) {
-    while (m < MV_OK) m = gtab[ref_group((int)m)].mv[ref_index((int)m)];
+    while (m < MV_OK) m = glob(gtab[ref_group((int)m)].mv)[ref_index((int)m)];
     return m;
 }
 
@@ -1473,7 +1487,7 @@ __device__ __forceinline__ void rule_prog_body(const WorldView &W, const GroupDe
                     for (int k = 0; k < P.n_subj; k++) nr += P.v_subj[k];
                     G.next_reward[i] = nr;
                 }
-                if (P.n_obj) atomicAdd(&gtab[P.gb].hits[ref_index(ent[1])], 1);
+                if (P.n_obj) atomicAdd(&glob(gtab[P.gb].hits)[ref_index(ent[1])], 1);
             }
         }
     }

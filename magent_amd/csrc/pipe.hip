@@ -18,28 +18,12 @@
 
 namespace magent_amd {
 
-// A pointer that a kernel reads from memory -- every pointer of an item -- is a GENERIC pointer to the compiler, and what goes through it a
-// FLAT instruction: counted on the LDS counter as well as on the memory counter, so that a wait for an LDS read also waits for every store
-// in flight (the sweeping render's whole design is that it does not), and slower to issue.  Pointers in kernel arguments are known to be
-// global; these say the same of an item's (device memory, all of them -- the pinned report is written through a kernel argument).
-// (a cast to the global address space and back is folded away before it can tell anybody anything; the pointer -- the same in every lane: an
-// item belongs to the workgroup -- goes through its scalar halves instead, and comes back as a global pointer)
-template <class T> __device__ __forceinline__ T *glob(T *p) {
-    const unsigned long long u = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    return (T *)(__attribute__((address_space(1))) T *)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ void globalize(GroupDev &G) {
-    G.x = glob(G.x); G.y = glob(G.y); G.id = glob(G.id); G.last_action = glob(G.last_action); G.op_obj = glob(G.op_obj); G.pend = glob(G.pend);
-    G.hp = glob(G.hp); G.next_reward = glob(G.next_reward); G.last_reward = glob(G.last_reward); G.dead = glob(G.dead); G.last_op = glob(G.last_op);
-    G.absorbed = glob(G.absorbed); G.dir = glob(G.dir); G.key = glob(G.key); G.drank_a = glob(G.drank_a); G.drank_b = glob(G.drank_b); G.mv = glob(G.mv);
-    G.hitf = glob(G.hitf); G.hits = glob(G.hits); G.eat = glob(G.eat); G.fleft = glob(G.fleft); G.fcell = glob(G.fcell);
-}
+// (glob(): kernels_dev.h -- every pointer of an item is one that the kernel reads from memory)
 __device__ __forceinline__ void globalize(RenderArgs &R) { R.mini = glob(R.mini); R.view = glob(R.view); R.feat = glob(R.feat); }
 __device__ __forceinline__ RenderWorld pipe_render_world(const PipeItem &it, int g) {
     RenderWorld V;
     V.w = it.W.w; V.h = it.W.h; V.G = it.W.G; V.viewcell = glob(it.W.viewcell); V.mask = glob(it.W.mask); V.grp = it.W.grp[g]; V.type = it.W.type[g];
-    globalize(V.grp);
+    V.grp = glob_group(V.grp);
     return V;
 }
 

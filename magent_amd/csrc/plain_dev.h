@@ -160,8 +160,8 @@ __device__ __forceinline__ void plain_rank_body(const WorldView &W, const PlainW
                 tgt = o;
                 const PlainGroup TG = ptab[ref_group(o)];
                 const int slot = T.attack_bit + k;
-                TG.hlist[(size_t)ref_index(o) * PW.S + slot] = make_uint2(key, (unsigned)ref_pack(g, i));
-                atomicOr(&TG.hmask[ref_index(o)], 1u << slot);
+                glob(TG.hlist)[(size_t)ref_index(o) * PW.S + slot] = make_uint2(key, (unsigned)ref_pack(g, i));
+                atomicOr(&glob(TG.hmask)[ref_index(o)], 1u << slot);
             }
         }
     } else if (!dead && (pend & ~PEND_ARG) == PEND_MOVE) {      // (an attacker that was dead before the step: its list entry exists, and does nothing)
@@ -223,7 +223,7 @@ __device__ __forceinline__ void plain_eval_body(const WorldView &W, const PlainW
     for (int k = 0; k < nh; k++) {
         const unsigned r = s_rank[k * NT + tid];
         const int a = s_ref[k * NT + tid];
-        const int adr = ptab[ref_group(a)].rec[ref_index(a)].y;
+        const int adr = glob(ptab[ref_group(a)].rec)[ref_index(a)].y;
         if ((unsigned)adr >= r) {
             hp -= ttab[ref_group(a)].damage;
             if (hp < 0.0f) { dr = (int)r; break; }       // death iff hp < 0 strictly (GridWorld.h:205)
@@ -233,7 +233,7 @@ __device__ __forceinline__ void plain_eval_body(const WorldView &W, const PlainW
     if (dr != dr_cur) {
         PW.g[g].rec[i].y = dr;
         const int reader = PW.g[g].atk[i];               // who reads my death rank: my target (is its attacker alive at that rank?)
-        if (reader >= 0) gtab[ref_group(reader)].drank_b[ref_index(reader)] = PW.round_base + round;
+        if (reader >= 0) glob(gtab[ref_group(reader)].drank_b)[ref_index(reader)] = PW.round_base + round;
         if (flag >= 0) W.counters[flag] = 1;             // (only the last round of a batch reports)
         W.counters[CTR_ROUND_CHANGED + (round & (ROUND_SLOTS - 1))] = 1;
     }
@@ -272,7 +272,7 @@ __device__ __forceinline__ void strike_body(const WorldView &W, const PlainWorld
                 const unsigned my_rank = (unsigned)me.x;
                 const int tgt = PW.g[g].atk[i];
                 int tgt_dr = RANK_INF;
-                if (tgt >= 0) tgt_dr = ptab[ref_group(tgt)].rec[ref_index(tgt)].y;
+                if (tgt >= 0) tgt_dr = glob(ptab[ref_group(tgt)].rec)[ref_index(tgt)].y;
                 if ((unsigned)me.y >= my_rank) {             // alive at my turn (GridWorld.cc:479-480)
                     float own;
                     if (tgt < 0 || (unsigned)tgt_dr < my_rank) own = T.attack_penalty;   // blank, or the target died before my turn (Map.cc:229-231)
@@ -317,10 +317,10 @@ __device__ __forceinline__ void strike_body(const WorldView &W, const PlainWorld
             bool ok = o == OCC_EMPTY;
             if (o == OCC_WALL) PW.g[g].rec[i].z = -1;    // no move at all (Map::is_blank_area): k_plain_commit sees a non-mover
             if (o >= 0) {
-                const int4 oc = ptab[ref_group(o)].rec[ref_index(o)];
+                const int4 oc = glob(ptab[ref_group(o)].rec)[ref_index(o)];
                 const float orec = ttab[ref_group(o)].step_recover;
                 bool gone = attacked && oc.y != RANK_INF;                                       // killed in this step's attack phase
-                if (!gone && !(orec > 0)) gone = __uint_as_float(gtab[ref_group(o)].mv[ref_index(o)]) - (-orec) < 0.0f;   // ... or about to starve
+                if (!gone && !(orec > 0)) gone = __uint_as_float(glob(gtab[ref_group(o)].mv)[ref_index(o)]) - (-orec) < 0.0f;   // ... or about to starve
                 if (gone) { ok = true; o = OCC_EMPTY; }                                          // the cell is empty when the moves begin
                 else ok = oc.z >= 0 && (unsigned)oc.x < key;                                     // the occupant may leave, and before my turn
             }
@@ -353,22 +353,22 @@ __device__ __forceinline__ void strike_body(const WorldView &W, const PlainWorld
 // leave the map here (Map::remove_agent, Map.cc:272, GridWorld.cc:536) unless a mover has claimed their cell -- that mover found the cell
 // empty (k_strike's `gone`), so it succeeds and writes the cell itself; the same rule as for the cell a mover leaves behind.
 __device__ __forceinline__ const int4 *plain_rec(const PlainWorld &PW, int NG, int gg) {
-    const int4 *p = PW.g[0].rec;
+    const int4 *p = glob(PW.g[0].rec);
 #pragma unroll
-    for (int k = 1; k < MAXG; k++) if (k < NG) p = gg == k ? PW.g[k].rec : p;      // (NG is wave-uniform; the table sits in scalar registers)
+    for (int k = 1; k < MAXG; k++) if (k < NG) p = gg == k ? glob(PW.g[k].rec) : p;      // (NG is wave-uniform; the table sits in scalar registers)
     return p;
 }
 __device__ __forceinline__ const int *plain_atk(const PlainWorld &PW, int NG, int gg) {
-    const int *p = PW.g[0].atk;
+    const int *p = glob(PW.g[0].atk);
 #pragma unroll
-    for (int k = 1; k < MAXG; k++) if (k < NG) p = gg == k ? PW.g[k].atk : p;
+    for (int k = 1; k < MAXG; k++) if (k < NG) p = gg == k ? glob(PW.g[k].atk) : p;
     return p;
 }
 // does mover `a` (a packed ref; its record `ra` already read) leave its cell?  MV_OK or MV_FAIL
 __device__ __forceinline__ unsigned plain_leaves(const WorldView &W, const PlainWorld &PW, int a, int4 ra) {
     for (int hops = 0;; hops++) {
         if (ra.z < 0) return MV_FAIL;                                              // no move (or into a wall): it stays
-        const unsigned long long cl = W.claim[ra.z];
+        const unsigned long long cl = glob(W.claim)[ra.z];
         if (!claim_live(cl, PW.epoch) || claim_ref(cl) != a) return MV_FAIL;       // not the winner of its target
         const int o = plain_atk(PW, W.G, ref_group(a))[ref_index(a)];
         if (o == OCC_EMPTY) return MV_OK;
@@ -380,13 +380,13 @@ __device__ __forceinline__ void plain_commit_body(const WorldView &W, const Plai
     // The step's report rides in the first wave of this launch when nothing it carries is decided by the moves (rec != null: the rules are
     // fused or there are none): deaths, rule triggers and the generator are final since k_strike -- a launch boundary ago -- and nothing
     // the report resets is read by this kernel.  The host has `done` while the moves run; its next launches queue up behind them.
-    if (rec && (blockIdx.x | blockIdx.y) == 0 && threadIdx.x < 64) step_report_body(W.counters, rec, seq, W.G, report_mode);
+    if (rec && (blockIdx.x | blockIdx.y) == 0 && threadIdx.x < 64) step_report_body(glob(W.counters), glob(rec), seq, W.G, report_mode);
     const int g = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    const GroupDev &G = W.grp[g];
+    const GroupDev G = glob_group(W.grp[g]);
     if (i >= G.n) return;
     // (my own record first, the question whether the attack rounds ran out behind it: the loads are in flight while the counter arrives)
-    const int4 me = PW.g[g].rec[i];                          // {key, death rank, move target, k_strike's status}
-    const int o = PW.g[g].atk[i];
+    const int4 me = glob(PW.g[g].rec)[i];                          // {key, death rank, move target, k_strike's status}
+    const int o = glob(PW.g[g].atk)[i];
     const int px = G.x[i], py = G.y[i];
     if (attack_open(W)) return;
     const int self = ref_pack(g, i), old = py * W.w + px, c = me.z;
@@ -397,18 +397,18 @@ __device__ __forceinline__ void plain_commit_body(const WorldView &W, const Plai
     // one level of independent loads: the claim word of my target, the record of my target's occupant, and the claim word of my own cell
     // where it is likely to be needed (the dead; movers into an empty cell -- most of them win it).  A mover behind an occupant asks for it
     // only once it knows that it moves: most of those do not, and every such word is a request of its own (PMC: 14 MB per step)
-    const unsigned long long cl_c = W.claim[mover ? c : 0];
+    const unsigned long long cl_c = glob(W.claim)[mover ? c : 0];
     const bool old_now = died || (mover && !chain);
-    unsigned long long cl_old = W.claim[old_now ? old : 0];
+    unsigned long long cl_old = glob(W.claim)[old_now ? old : 0];
     const int4 ro = plain_rec(PW, W.G, chain ? ref_group(o) : g)[chain ? ref_index(o) : i];
     const unsigned s_o = chain ? plain_leaves(W, PW, o, ro) : MV_OK;
     const bool winner = mover && claim_live(cl_c, PW.epoch) && claim_ref(cl_c) == self;
     const bool ok = winner && s_o == MV_OK;
-    if (ok && !old_now) cl_old = W.claim[old];
+    if (ok && !old_now) cl_old = glob(W.claim)[old];
     int cell = old;
     if (ok) {
-        if (!claim_live(cl_old, PW.epoch)) { W.occ[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }   // nobody claimed my cell
-        W.occ[c] = self;
+        if (!claim_live(cl_old, PW.epoch)) { glob(W.occ)[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }   // nobody claimed my cell
+        glob(W.occ)[c] = self;
         const int ny = c / W.w;
         G.x[i] = c - ny * W.w; G.y[i] = ny;
         cell = c;
@@ -419,7 +419,7 @@ __device__ __forceinline__ void plain_commit_body(const WorldView &W, const Plai
         else blocker = (s_o == MV_OK && (unsigned)ro.x < (unsigned)me.x) ? claim_ref(cl_c) : o;
         G.last_op[i] = OP_COLLIDE;
         G.op_obj[i] = blocker;
-    } else if (died && !claim_live(cl_old, PW.epoch)) { W.occ[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }
+    } else if (died && !claim_live(cl_old, PW.epoch)) { glob(W.occ)[old] = OCC_EMPTY; if (W.live_paint) vc_store(W, old, OCC_EMPTY, 0u); }
     G.pend[i] = PEND_NONE;   // end of step: pending actions are consumed
     // live paint: every agent that moved or whose hp changed paints its cell (most agents of a battle stand at full hp: 4 of 5 stores saved)
     if (W.live_paint && alive && (ok || (unsigned)me.w == MV_FAIL))
