@@ -277,9 +277,9 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         PD.G = n_group; PD.rounds = rounds;
         // the observations of the worlds that do not render for themselves (< 1 M window cells per group), one launch: when every observed
         // group has the battle shape, the sweeping kernel with ~256 workgroups over all (environment, group) segments together -- its own
-        // geometry, one workgroup per CU (measured on the MI355X, profiles/r06_summary.md: 32 x (2 x 2000) 0.232 ms per round against 0.259
-        // with the generic workgroups on the same box, 8 worlds 0.111 against 0.123, 128 worlds 0.718 against 0.812) -- else, or with
-        // MAGENT_TUNE pipe_sweep=0, the generic render's workgroups (pipe_sweep=N: N sweeping workgroups per segment)
+        // geometry, one workgroup per CU (measured on the MI355X, one box, in turn with the generic workgroups, profiles/r06_summary.md:
+        // 32 x (2 x 2000) 0.226-0.236 ms per round against 0.233-0.240, 128 worlds 0.707-0.725 against 0.733-0.756, 8 worlds level) -- else,
+        // or with MAGENT_TUNE pipe_sweep=0, the generic render's workgroups (pipe_sweep=N: N sweeping workgroups per segment)
         static const int sweep_tune = tune("pipe_sweep", -1);
         bool sweep_ok = sweep_tune != 0;
         for (int e = 0; e < n_env && sweep_ok; e++) if (kind[e] == 2) sweep_ok &= envs[e]->pipe_sweep_ok(view ? view + e * n_group : nullptr);

@@ -35,10 +35,13 @@ __global__ void __launch_bounds__(64 * RENDER_WAVES) k_pipe_render(const PipeIte
     const int e = blockIdx.y / slots, k = blockIdx.y - e * slots;
     const PipeItem &it = items[e];
     if (k >= it.M.n || (int)blockIdx.x >= it.M.blocks[k]) return;
-    RenderArgs R = it.M.R[k];
-    globalize(R);
+    const RenderArgs R = it.M.R[k];
     const RenderPlan P = it.M.P[k];
-    const RenderWorld V = pipe_render_world(it, R.g);
+    // (NOT through glob(): with GLOBAL instructions this kernel compiles to 97 VGPRs -- 5 waves per SIMD -- against 50 -- 7 -- with the FLAT ones its
+    // generic pointers give it, and its independent workgroups live on occupancy: measured on one box, FLAT / GLOBAL in turn, 32 worlds of 2 x 2000:
+    // 0.232-0.241 / 0.252 ms per round, 128 worlds 0.72-0.74 / 0.80-0.81, profiles/r06_raw/pipe_ab_global_address_sweep.txt)
+    RenderWorld V;
+    V.w = it.W.w; V.h = it.W.h; V.G = it.W.G; V.viewcell = it.W.viewcell; V.mask = it.W.mask; V.grp = it.W.grp[R.g]; V.type = it.W.type[R.g];
     // (plain games: no turn_mode)
     if (it.W.vc_packed) render_block<true, true, 1, true, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
     else render_block<true, true, 1, false, false>(V, R, P, blockIdx.x, it.M.blocks[k]);
