@@ -139,7 +139,7 @@ def small_world_extras(torch, magent_amd, dev, steps=200, warmup=20):
                 for e in envs:
                     e.sync()
                 total, t0 = 0, time.perf_counter()
-            total += sum(map(sum, batch.nums()))
+            total += int(batch.nums_array().sum())
             if batched:
                 batch.cycle(views_p, feats_p, acts_p[s % 4], rews_p)
             else:
@@ -197,7 +197,7 @@ def many_worlds_extra(torch, magent_amd, dev, game, map_size, n, K, steps=20, wa
             for e in envs:
                 e.sync()
             total, t0 = 0, time.perf_counter()
-        total += sum(sum(n_[g] for g in acting) for n_ in batch.nums())
+        total += int(batch.nums_array().sum() if len(acting) == len(hs) else batch.nums_array()[:, acting].sum())
         batch.cycle(view_p, feat_p, act_p[s % 4], rew_p)
     for e in envs:
         e.sync()

@@ -685,6 +685,7 @@ class EnvBatch(object):
         self.order_streams = True
         self._stream_ptrs = (ctypes.c_void_p * (2 * n))()
         self._uniq, self._uniq_key = None, None
+        self._nums = None
 
     def pointers(self, tensors):
         """the device-pointer array of a list (per env) of lists (per group) of CUDA tensors (None entries allowed).  cycle()
@@ -703,9 +704,16 @@ class EnvBatch(object):
 
     def nums(self):
         """agent counts [env][group] (host mirror, no device work)"""
-        out = (ctypes.c_int32 * (len(self.envs) * self.n_group))()
-        self._lib.env_num_many(self._handles, len(self.envs), self.n_group, out)
-        return [list(out[e * self.n_group:(e + 1) * self.n_group]) for e in range(len(self.envs))]
+        return self.nums_array().tolist()
+
+    def nums_array(self):
+        """the same as an int32 numpy array [env][group] over a buffer of the batch's own (valid until the next call): one library call and
+        no per-environment Python work -- at 32 environments the nested lists cost a caller's loop 8 us of a 225 us round"""
+        if self._nums is None:
+            self._nums_c = (ctypes.c_int32 * (len(self.envs) * self.n_group))()
+            self._nums = np.frombuffer(self._nums_c, dtype=np.int32).reshape(len(self.envs), self.n_group)
+        self._lib.env_num_many(self._handles, len(self.envs), self.n_group, self._nums_c)
+        return self._nums
 
     def cycle(self, views=None, feats=None, actions=None, rewards=None):
         """each argument: list (per env) of lists (per group) of CUDA tensors or None, or the result of pointers();
@@ -720,8 +728,7 @@ class EnvBatch(object):
         if self.order_streams:
             for e in self._distinct():
                 e.order_after_torch()
-        self._cycle_raw(views, feats, actions, rewards)
-        return [bool(d) for d in self._done]
+        return self._cycle_raw(views, feats, actions, rewards)
 
     def _distinct(self):
         """one environment per distinct engine stream.  Batched environments share their leader's stream, and an environment may join

@@ -33,7 +33,7 @@ for s in range(STEPS + 10):
         for e in envs: e.sync()
         envs[0]._lib.env_get_info(envs[0].game, 0, b"batch_host_us", us.ctypes.data)      # reset: warm-up rounds allocate
         t0 = time.perf_counter(); total = 0
-    total += sum(map(sum, batch.nums()))
+    total += int(batch.nums_array().sum())
     batch.cycle(view_p, feat_p, act_ptrs[s % 4], rew_p)
 for e in envs: e.sync()
 dt = time.perf_counter() - t0

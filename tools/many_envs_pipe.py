@@ -53,12 +53,15 @@ for s in range(STEPS + WARM):
         for e in envs: e.sync()
         envs[0]._lib.env_get_info(envs[0].game, 0, b"batch_host_us", us.ctypes.data)
         t0 = time.perf_counter(); total = 0
-    total += sum(sum(n[g] for g in acting) for n in batch.nums())
+    total += int(batch.nums_array().sum() if len(acting) == len(hs) else batch.nums_array()[:, acting].sum())
     batch.cycle(view_p, feat_p, act_ptrs[s % 4], rew_p)
 for e in envs: e.sync()
 dt = time.perf_counter() - t0
 envs[0]._lib.env_get_info(envs[0].game, 0, b"batch_host_us", us.ctypes.data)
-piped = sum(1 for e in envs if e.pipeline_stats()[6] > 0)
+stats = np.array([e.pipeline_stats() for e in envs])
+piped = int((stats[:, 6] > 0).sum())
+hist = np.array([e.round_hist() for e in envs]).sum(axis=0)
 print(json.dumps({"game": game, "map": MAP, "agents_per_env_at_start": cap, "agents_per_env_at_end": batch.nums()[0], "envs": K, "steps": STEPS,
                   "tune": os.environ.get("MAGENT_TUNE", ""), "ms_per_round": round(dt / STEPS * 1e3, 4), "agent_steps_per_s": round(total / dt),
-                  "envs_in_batched_pipeline": piped, "host_us_per_round": [round(float(v), 1) for v in us]}))
+                  "envs_in_batched_pipeline": piped, "host_us_per_round": [round(float(v), 1) for v in us],
+                  "env_steps_two_pairs_one_pair_ran_out": [int(stats[:, 1].sum()), int(stats[:, 2].sum()), int(stats[:, 5].sum())], "last_changing_round_hist": [int(v) for v in hist]}))
