@@ -94,7 +94,7 @@ def test_batched_pipeline(oracle):
 
 def test_batched_pipeline_over_a_long_episode(oracle):
     """the batched pipeline over what only acts with the length of an episode (the claim words' epoch window, refilled every 63 steps by every
-    environment of the batch for itself; the carried round stamps; the batch's budget of optimistic rounds, the largest of its environments'):
+    environment of the batch for itself; the carried round stamps; the batch's budget of optimistic rounds: three, four while some environment's is raised):
     two 200 x 200 worlds of 2 x 4500 agents with different seeds -- `battle300_long`'s recipe at the same density: hp 4 / damage 3,
     reinforcements at steps 70 and 130, kills in every step -- for 150 steps through ONE EnvBatch, every environment against the oracle driven
     alone through the reference call sequence (observations compared every 10th step: the trajectories are held in memory)"""
