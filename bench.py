@@ -299,8 +299,8 @@ def spawn_ranks(n):
                 timer.daemon = True
                 timer.start()
             continue
-        sys.stdout.write(line)
-        sys.stdout.flush()
+        sys.stderr.write(line)      # (anything else a rank prints: not the line)
+        sys.stderr.flush()
     rc = proc.wait()
     if timer is not None:
         timer.cancel()
@@ -530,6 +530,14 @@ def main():
         return cpu_baseline_worker(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
+
+    # stdout carries rank 0's ONE JSON line and nothing else: whatever the legs below print on the way (the reference-style training loops of the
+    # config 5 legs report every batch) goes to stderr
+    real_stdout, sys.stdout = sys.stdout, sys.stderr
+
+    def emit(record):
+        real_stdout.write(json.dumps(record) + "\n")
+        real_stdout.flush()
 
     import torch
     import torch.distributed as dist
@@ -991,7 +999,7 @@ def main():
             done_flag.set()
             if rank == 0:
                 rec.setdefault("extra", {})["c4_gather_rccl"] = {"error": why or "did not finish within %d s (a rank failed, or a collective did not return)" % args.extra_timeout}
-                print(json.dumps(rec), flush=True)
+                emit(rec)
             os._exit(0)
         watchdog = threading.Timer(args.extra_timeout, bail)
         watchdog.daemon = True
@@ -1025,11 +1033,11 @@ def main():
             sys.stderr.write("rank %d: extra.c4_gather_rccl failed: %r\n" % (rank, e))
             if rank == 0:
                 rec.setdefault("extra", {})["c4_gather_rccl"] = {"error": repr(e)}
-                print(json.dumps(rec), flush=True)
+                emit(rec)
             done_flag.set()
             os._exit(0)
     if rank == 0:
-        print(json.dumps(rec))
+        emit(rec)
     if world > 1:
         dist.destroy_process_group()
 

@@ -33,14 +33,17 @@ def test_gpus_flag_spawns_ranks(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     import io
-    out = io.StringIO()
+    out, err = io.StringIO(), io.StringIO()
     monkeypatch.setattr(sys, "stdout", out)
+    monkeypatch.setattr(sys, "stderr", err)
     assert bench.main() == 0
     seen["rc"] = 1                       # a rank died after rank 0 had printed its line: the line stands, so does the run -- and it says so
     assert bench.main() == 0
     monkeypatch.undo()
     lines = [json.loads(ln) for ln in out.getvalue().splitlines() if ln.startswith('{"metric"')]
-    assert [ln["launcher_rc"] for ln in lines] == [0, 1] and lines[0]["value"] == 1 and "some launcher noise" in out.getvalue()
+    assert [ln["launcher_rc"] for ln in lines] == [0, 1] and lines[0]["value"] == 1
+    # stdout is the line and nothing else: what the launcher or a rank prints beside it is relayed to stderr
+    assert len(out.getvalue().splitlines()) == 2 and "some launcher noise" in err.getvalue()
     cmd = seen["cmd"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
