@@ -564,6 +564,7 @@ void Env::reset() {
     // out costs a host round trip; the budget falls back to one pair after 64 steps that did not need the second
     boost_window = 64;
     boost_attack = boost_window;
+    boost_ran_out = false;
     file_ct++; frame_ct = 0;   // RenderGenerator::next_file (GridWorld.cc:97)
     large_map_mode = width * height > 99 * 99;
     const int n_sep = large_map_mode ? (width * height > 1000 * 1000 ? 16 : 8) : 1;

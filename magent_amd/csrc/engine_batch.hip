@@ -272,14 +272,14 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         }
         // every environment launches as many rounds as the one with the largest budget (a round that has nothing to do returns at once)
         // (MAGENT_TUNE attack_pairs=N fixes the budget for the process: 0 leaves every attack phase to the host)
-        // THREE rounds, four while some environment's budget is raised (Env::step_end: after a run-out, and for the first 64 steps behind a reset): a round is a launch of ~5 us for the whole
+        // THREE rounds, four while some environment's budget is raised (Env::step_end: for its window after a step of the episode ran out -- not for the first 64 steps behind a reset, the single environment's precaution: three rounds already are one more than its one pair): a round is a launch of ~5 us for the whole
         // batch whatever it finds to do, and the batch runs as many as its neediest environment -- so the single environment's 2-or-4 is the wrong
         // grain here.  Measured (32 x battle 200 x 200, 2 x 2000, 9920 environment steps, tools/many_envs_pipe.py): the last round that changes a
         // death rank is round 0 or 1 in 99.9 % of the steps and round 2 in the rest, never later; with two rounds every 34th round of the batch
         // had an environment run out (~0.27 ms of host each), with two-or-four one run-out kept all 32 environments at four for its window
         // (86 % of the steps).  Three rounds: no run-out seen, one launch less than four.
         int rounds = lead.opt_fixed ? 2 * lead.opt_attack_pairs : 3;
-        for (int e = 0; e < n_env && !lead.opt_fixed; e++) if (kind[e] == 2 && envs[e]->boost_attack > 0) rounds = 4;
+        for (int e = 0; e < n_env && !lead.opt_fixed; e++) if (kind[e] == 2 && envs[e]->boost_attack > 0 && envs[e]->boost_ran_out) rounds = 4;
         PD.G = n_group; PD.rounds = rounds;
         // the observations of the worlds that do not render for themselves (< 1 M window cells per group), one launch: when every observed
         // group has the battle shape, the sweeping kernel with ~256 workgroups over all (environment, group) segments together -- its own

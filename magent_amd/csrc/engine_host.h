@@ -162,6 +162,7 @@ public:
     bool checked_step = false;            // host-checked convergence instead of the single-sync driver
     // optimistic rounds of the single-sync driver: one pair / batch, two for 64 steps after a run-out (or fixed by env)
     int opt_attack_pairs = 1, opt_move_batches = 1, boost_attack = 0, boost_move = 0, boost_window = 64;
+    bool boost_ran_out = false;           // the raised budget follows a step of this episode that ran out (not: the first 64 steps behind a reset)
     int round_hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // (env_get_info "round_hist")
     bool opt_fixed = false;
     // one-launch step of small worlds (k_step_solo): on by default, MAGENT_TUNE solo_step=0 keeps the multi-launch drivers

@@ -587,7 +587,7 @@ void Env::step_end(int *done) {
             // stays at two from then on (64, 128, ... steps): in a dense world -- the bench's 2 x 400k at random: 8 run-outs in the 70 one-pair
             // steps of a 550-step episode, profiles/r06_raw/c3_episode_550_steps.txt -- a run-out (a host round trip and the host-checked rounds)
             // costs ten times what the second pair does; a sparse one (config 5's formation: 486 one-pair steps, none ran out) keeps the saving
-            if (phase == 1) { if (boost_attack == 0) boost_window = std::min(boost_window * 2, 4096); boost_attack = boost_window; } else boost_move = 64;
+            if (phase == 1) { if (boost_attack == 0) boost_window = std::min(boost_window * 2, 4096); boost_attack = boost_window; boost_ran_out = true; } else boost_move = 64;
             HIP_OK(hipMemsetAsync(d_counters + CTR_OPEN_ATTACK, 0, 2 * sizeof(int), stream));   // both phase flags
             clear_changed();
             if (phase == 1) { attack_rounds_checked(W); phase_tail(W, 0); }
