@@ -475,7 +475,10 @@ class GridWorld(object):
         """engine work queued from now on waits for what is queued on torch's current stream (no host blocking)"""
         import torch
         for st in self._streams():
-            st.wait_stream(torch.cuda.current_stream(st.device))
+            cur = torch.cuda.current_stream(st.device)
+            if cur.query():        # nothing is pending there: nothing to wait for (a stream query costs a tenth of an event record + wait:
+                continue           # measured 15 us per 32-environment round, bench.py extra.battle_200_2x2000.cycle_32env_default_ordering)
+            st.wait_stream(cur)
 
     def order_torch_after(self):
         """torch's current stream waits for the engine work queued so far (no host blocking)"""

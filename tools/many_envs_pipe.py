@@ -42,7 +42,7 @@ rews = [[torch.empty(cap[g], device=dev) if g in acting else None for g in range
 na = [envs[0].get_action_space(h)[0] for h in hs]
 acts = [[[torch.randint(na[g], (cap[g],), dtype=torch.int32, device=dev) if g in acting else None for g in range(len(hs))] for _ in envs] for _ in range(4)]
 batch = magent_amd.EnvBatch(envs, n_threads=8)
-batch.order_streams = False
+batch.order_streams = os.environ.get("ORDER_STREAMS", "0") == "1"      # (default here: this loop orders by env.sync(), no torch work touches the buffers in between)
 view_p, feat_p, rew_p = batch.pointers(views), batch.pointers(feats), batch.pointers(rews)
 act_ptrs = [batch.pointers(a) for a in acts]
 us = np.zeros(4, dtype=np.float32)
