@@ -410,7 +410,7 @@ bool Env::pipe_sweep_ok(float *const *view) {
 void Env::pipe_prepare(int n_group, float *const *view, float *const *feat, const int *const *actions, float *const *rewards, PipeItem &it, int rounds, bool sweep_ok) {
     enter();
     const int NG = (int)groups.size();
-    (void)n_group; (void)sweep_ok;
+    (void)n_group;
     int total_n = 0;
     for (auto &g : groups) total_n += g.n;
     if (!tables_valid) ensure_tables();
@@ -428,6 +428,7 @@ void Env::pipe_prepare(int n_group, float *const *view, float *const *feat, cons
         prepare_render(g, it.W, it.M.R[k], it.M.P[k], view[g], feat[g]);
         it.M.blocks[k] = it.M.P[k].spans + it.M.P[k].feat_blocks;
     }
+    if (sweep_ok && it.M.n > 0) pipe_sweep_rounds++;
     // ---- set_action: tile counts per call, in call order (Env::set_action_device)
     step_sa_tiled = true; sa_tiles = 0;
     step_calls.clear();

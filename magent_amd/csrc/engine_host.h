@@ -224,6 +224,7 @@ private:
     int *d_newn = nullptr;                // [MAXG] group sizes behind the batched compaction (PipeItem::newn)
     bool pipe_folded = false;             // the batch's compaction makes the next minimap
     int pipe_sweep_shape = -1;            // bit g: group g's observation has the shape the sweeping render takes (-1: not looked at since the reset)
+    int pipe_sweep_rounds = 0;            // ... with its observations written by the batch's sweeping render (k_pipe_render_sweep)
     int pipe_rounds = 0;                  // cycles this environment took through the batched pipeline (env_get_info "pipeline_stats")
     void wait_record(int seq);
     StepRecord *h_rec = nullptr;          // pinned: written by k_step_solo, spun on by step_end

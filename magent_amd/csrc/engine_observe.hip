@@ -202,6 +202,7 @@ void Env::info_host(int g, const char *name, void *buf) {
         ib[4] = (int)(plain_epoch % 63u);                    // where the current window stands
         ib[5] = fallback_attack;                             // steps whose optimistic rounds ran out
         ib[6] = pipe_rounds;                                 // cycles that went through the batched pipeline (env_cycle_many, pipe.hip)
+        ib[7] = pipe_sweep_rounds;                           // ... of which the batch's render launch was the sweeping kernel
         return;
     }
     if (k == "round_hist") {     // additive (tuning): plain steps since the last read by the last round of the death-rank fixed point that

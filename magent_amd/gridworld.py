@@ -500,7 +500,7 @@ class GridWorld(object):
 
     def pipeline_stats(self):
         """additive (tests): (steps of the plain pipeline, of which launched with two optimistic pairs of death-rank rounds, with one, refills
-        of the claim words for such steps, position in the current window of 63 epochs, steps whose optimistic rounds ran out, cycles through the BATCHED pipeline of env_cycle_many, 0)"""
+        of the claim words for such steps, position in the current window of 63 epochs, steps whose optimistic rounds ran out, cycles through the BATCHED pipeline of env_cycle_many, of which rendered by the batch's sweeping kernel)"""
         buf = np.zeros(8, dtype=np.int32)
         self._lib.env_get_info(self.game, 0, b"pipeline_stats", buf.ctypes.data)
         return tuple(int(v) for v in buf)

@@ -244,7 +244,7 @@ def test_batched_pipeline_render_forms(tune):
             "got = H.run_cycle_batch(scs, H.HIP_LIB, envs_out=seen)\n"
             "for sc, g in zip(scs, got):\n"
             "    H.assert_same(H.run_cycle(sc, H.ensure_oracle(), fused=False), g, sc.name + ' (batched pipeline)')\n"
-            "assert all(e.pipeline_stats()[6] >= 8 for e in seen[:3])\n"
+            "assert all(e.pipeline_stats()[6] >= 8 and (e.pipeline_stats()[7] > 0) == ('pipe_sweep=0' not in os.environ['MAGENT_TUNE']) for e in seen[:3])\n"
             "print('ok')\n") % (H.ROOT, os.path.join(H.ROOT, "tests"))
     p = subprocess.run([sys.executable, "-c", code], env=H.merge_env(os.environ, {"OMP_NUM_THREADS": "1"}, {"MAGENT_TUNE": tune}), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "ok" in p.stdout, (tune, p.stdout[-1500:] + p.stderr[-3000:])

@@ -80,6 +80,7 @@ def test_batched_pipeline(oracle):
         H.assert_same(H.run_cycle(sc, oracle, fused=False), g, sc.name + " (batched pipeline)")
     stats = [e.pipeline_stats() for e in seen]
     assert all(s[6] >= 8 for s in stats[:3]) and stats[3][6] == 0 and stats[4][6] == 0, stats
+    assert all(s[7] == s[6] for s in stats[:3]), stats      # battle-shaped observations: the batch's render was the sweeping kernel in every cycle
     big = []
     for k in range(2):
         c = copy.deepcopy(SCENARIOS["battle_brawl_dense_big"]); c.seed, c.action_seed, c.obs_every = 777 + k, 50 + k, 1

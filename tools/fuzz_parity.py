@@ -26,7 +26,7 @@ if "," in sys.argv[3]:       # an explicit list of seeds:  fuzz_parity.py hip or
     seeds = [int(x) for x in sys.argv[3].split(",") if x]
 else:
     seeds = list(range(int(sys.argv[3]), int(sys.argv[4])))
-bad, t0, piped = [], time.time(), 0
+bad, t0, piped, swept = [], time.time(), 0, 0
 for seed in seeds:
     sc = H.fuzz_scenario(seed)
     print("seed", seed, flush=True, file=sys.stderr)
@@ -41,6 +41,7 @@ for seed in seeds:
             seen = []
             hip_side = H.run_cycle_batch(scs, H.HIP_LIB, envs_out=seen)
             piped += any(e.pipeline_stats()[6] > 0 for e in seen)
+            swept += any(e.pipeline_stats()[7] > 0 for e in seen)
             other = b if a == "hip" else a
             for k, c in enumerate(scs):
                 H.assert_same(H.run_cycle(c, LIBS[other], fused=False), hip_side[k], "%s (batch of %d, env %d)" % (sc.name, nb, k))
@@ -53,6 +54,6 @@ for seed in seeds:
         bad.append(seed)
         print("FAIL seed %d: %s" % (seed, str(e)[:300]), flush=True)
 if int(os.environ.get("FUZZ_BATCH", "0")) > 1:
-    print("games with environments in the batched pipeline (pipe.hip): %d" % piped)
+    print("games with environments in the batched pipeline (pipe.hip): %d (observations by its sweeping render: %d)" % (piped, swept))
 print("%d seeds, %d failures %s, %.1fs" % (len(seeds), len(bad), bad, time.time() - t0))
 sys.exit(1 if bad else 0)
