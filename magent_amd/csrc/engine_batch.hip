@@ -281,7 +281,7 @@ void Env::cycle_many(Env **envs, int n_env, int n_group, float **view, float **f
         int rounds = lead.opt_fixed ? 2 * lead.opt_attack_pairs : 3;
         for (int e = 0; e < n_env && !lead.opt_fixed; e++) if (kind[e] == 2 && envs[e]->boost_attack > 0 && envs[e]->boost_ran_out) rounds = 4;
         PD.G = n_group; PD.rounds = rounds;
-        // the observations of the worlds that do not render for themselves (< 1 M window cells per group), one launch: when every observed
+        // the observations of the worlds that do not render for themselves (< 3.1 M window cells per group: pipe_own_cells), one launch: when every observed
         // group has the battle shape, the sweeping kernel with ~256 workgroups over all (environment, group) segments together -- its own
         // geometry, one workgroup per CU (measured on the MI355X, one box, in turn with the generic workgroups, profiles/r06_summary.md:
         // 32 x (2 x 2000) 0.226-0.236 ms per round against 0.233-0.240, 128 worlds 0.707-0.725 against 0.733-0.756, 8 worlds level) -- else,
@@ -403,6 +403,14 @@ bool Env::pipe_sweep_ok(float *const *view) {
     return true;
 }
 
+// window cells of a group from which an environment of a batch renders by launches of its own (MAGENT_TUNE pipe_own=N: N x 65536 cells).
+// Measured on the MI355X, own launches / the batch's one launch (profiles/r06_summary.md): 16 worlds of 2 x 8000 (1.35 M cells per group) 0.413 / 0.349 ms
+// per round, 8 worlds of 2 x 20,000 (3.4 M) 0.409 / 0.415, 8 gather worlds of 100k agents (4.9 M) 0.456 / 0.491 -- the line was at 1 M until then
+static long long pipe_own_cells() {
+    static const long long v = 65536ll * tune("pipe_own", 48);
+    return v;
+}
+
 // Everything of one environment's cycle as an item of the batch: what observe_device, set_action_device, step_begin, get_reward_device and
 // clear_dead would do on the host, with the launches left to the batch (launch_pipe_cycle).  Stale state that only the first cycle meets
 // -- the painted map, the first minimap, tables, grown buffers -- is brought up to date by launches of the environment's own, on the
@@ -419,7 +427,7 @@ void Env::pipe_prepare(int n_group, float *const *view, float *const *feat, cons
     // at that size); the others share the batch's render launch
     bool own_render = false;
     for (int g = 0; g < NG; g++)
-        if (view && view[g] && groups[g].n > 0 && (long long)groups[g].n * groups[g].type->view.height * groups[g].type->view.width >= 16384ll * 64) own_render = true;
+        if (view && view[g] && groups[g].n > 0 && (long long)groups[g].n * groups[g].type->view.height * groups[g].type->view.width >= pipe_own_cells()) own_render = true;
     it.W = this->view();
     for (int g = 0; g < NG; g++) {
         if (!(view && view[g]) || groups[g].n == 0) continue;

@@ -21,6 +21,7 @@
 //   batch_pipe=0        env_cycle_many never takes the batched pipeline (pipe.hip): worlds beyond the one-launch step go one by one
 //   batch_pipe_min=N    ... and takes it for worlds of N agents or more that could also step in one launch                 default 1537
 //   pipe_sweep=N        the batched render of env_cycle_many's pipeline: N sweeping workgroups per (environment, group) segment; 0: the generic workgroups   default: ~256 sweeping workgroups over the launch when every observed group has the battle shape
+//   pipe_own=N          window cells of a group (x 65536) from which a world of a batch renders by launches of its own instead of the batch's                          default 48
 //   pipe_span=N         64-cell steps per workgroup of a batched render (env_cycle_many)                                          default: by size, <= 32
 //   touch_map=0|1       never / before every render of a map beyond the L2s: the painted map streamed through the caches first (default: before the
 //                       first render of a cycle when some group was placed at random)
@@ -55,7 +56,7 @@ inline int tune(const char *key, int dflt) {
     (void)legacy_checked;
     static const char *const known[] = {"checked_step", "host_shuffle", "attack_pairs", "move_batches", "solo_step", "solo_max", "batch_solo_max", "scan_solo_max", "overlap",
                                         "fold_minimap", "render", "render_sweep", "render_su", "render_depth", "att_threads", "policy_grid", "policy_stamps",
-                                        "batch_cycle", "early_report", "touch_map", "batch_pipe", "batch_pipe_min", "pipe_sweep", "pipe_span"};
+                                        "batch_cycle", "early_report", "touch_map", "batch_pipe", "batch_pipe_min", "pipe_sweep", "pipe_span", "pipe_own"};
     const char *s = std::getenv("MAGENT_TUNE");
     if (!s || !*s) return dflt;
     static bool checked = false;
