@@ -508,7 +508,7 @@ def main():
     ap.add_argument("--obs", choices=["f32", "bf16"], default="f32",
                     help="bf16: render the observations as the policy kernels' bf16 cells (env_get_observation_device_bf16, 8 x bf16 per window "
                          "cell) -- a secondary reading; the headline stays on the reference's float32 tensors")
-    ap.add_argument("--extra-timeout", type=int, default=300, help="N > 1: seconds the config-4 gather extra may take before the line is printed without it")
+    ap.add_argument("--extra-timeout", type=int, default=180, help="N > 1: seconds the config-4 gather extra may take before the line is printed without it")
     ap.add_argument("--repeats", type=int, default=5, help="identical timed regions of --steps steps; the median one is reported")
     ap.add_argument("--event-every", type=int, default=EVENT_EVERY, help="timed region: HIP events around the render launches of every N-th step (1: all)")
     ap.add_argument("--preheat-ms", type=float, default=PREHEAT_MS,
